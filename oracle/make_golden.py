@@ -1,0 +1,169 @@
+"""TEST INFRASTRUCTURE — generate tests/golden/*.npz by running the REFERENCE (imported from
+/root/reference, this container only) on seeded inputs and key-seeded parameters.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden            (from the repo root)
+
+Fixtures hold only inputs' seeds and the reference's outputs (KB-scale); inputs, parameters
+and dropout masks are regenerated from seeds by ``oracle.param_fill`` on any machine.
+The reference's randomness is pinned by patching its Bernoulli draw sites so that they use the
+seeded masks below, in call order:
+  * ``F.dropout`` (model/unidefense.py:213 p=0.2 ; :155 and :230 via nn.Dropout(p=drop_rate))
+  * ``drop_connect`` (model/efficientnet/model.py:133 -> utils.py:131-156)
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from oracle import ref_import, param_fill, eb4  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def make_rng(n: int, seed: int, drop_rate: float, nblk: int = 32, dc_rate: float = 0.2):
+    """Seeded keep-masks for every Bernoulli site of UniDefenseModelEb4.forward (train mode)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def bern(shape, keep):
+        return (torch.rand(shape, generator=g) < keep).float()
+
+    rng = {"dec_keep": bern((n, 160, 16, 16), 0.8),
+           "emb_keep": bern((n, 272, 8, 8), 1.0 - drop_rate),
+           "feat_keep": bern((n, 1792), 1.0 - drop_rate),
+           "drop_connect": {}}
+    for idx in range(1, nblk):
+        rng["drop_connect"][idx] = bern((n,), 1.0 - dc_rate * idx / nblk)
+    return rng
+
+
+def pooled(t, k=8):
+    return torch.nn.functional.adaptive_avg_pool2d(t, k)
+
+
+def pack_outputs(out, prefix, store):
+    ld = out["loss_dict"]
+    store[prefix + "cls_out"] = out["cls_out"].detach().numpy()
+    store[prefix + "rec_pool8"] = pooled(out["rec"].detach()).numpy()
+    store[prefix + "factorization"] = ld["factorization"].detach().numpy()[:, :64]
+    store[prefix + "freq_mask"] = ld["freq_mask"].detach().numpy()
+    store[prefix + "spat_mask"] = ld["spat_mask"].detach().numpy()
+    store[prefix + "spatial"] = ld["spatial"].detach().numpy()
+    store[prefix + "freq"] = ld["freq"].detach().numpy()
+    for i, t in enumerate(ld["triplet"]):
+        store[prefix + f"triplet{i}"] = t.detach().numpy()
+
+
+def run_reference_train(m, ref_loss_mod, x, tgt, rng, drop_rate, lam):
+    """Reference forward (train mode, masks injected) + pass-1 loss + backward."""
+    import model.efficientnet.model as effmod
+    F = torch.nn.functional
+    orig_dropout, orig_dc = F.dropout, effmod.drop_connect
+    queue = [("dec_keep", 0.2), ("emb_keep", drop_rate), ("feat_keep", drop_rate)]
+    dc_calls = []
+
+    def fake_dropout(inp, p=0.5, training=True, inplace=False):
+        name, pp = queue.pop(0)
+        assert abs(pp - p) < 1e-12 and training, (name, p, pp, training)
+        scale = rng[name].to(inp.dtype) / (1.0 - p)
+        return inp.mul_(scale) if inplace else inp * scale
+
+    # block order of drop_connect calls = blocks with a skip connection and rate > 0
+    arch = eb4.eb4_arch()
+    dc_order = [i for i, b in enumerate(arch["blocks"]) if b["skip"] and i > 0]
+
+    def fake_dc(inputs, p, training):
+        idx = dc_order[len(dc_calls)]
+        dc_calls.append(idx)
+        assert abs(p - 0.2 * idx / 32) < 1e-12 and training
+        return inputs / (1 - p) * rng["drop_connect"][idx].reshape(-1, 1, 1, 1)
+
+    F.dropout, effmod.drop_connect = fake_dropout, fake_dc
+    try:
+        m.train()
+        out = m(x)
+    finally:
+        F.dropout, effmod.drop_connect = orig_dropout, orig_dc
+    assert not queue and len(dc_calls) == len(dc_order)
+    # pass-1 loss exactly as engine/abstract_engine.py:214-267 with the reference's criteria
+    ld = out["loss_dict"]
+    n_real = int((tgt == 0).sum()); n_fake = len(tgt) - n_real
+    trip_fn = ref_loss_mod.LOSSES["aw_triplet"]
+    trip = sum(trip_fn(f, tgt) for f in ld["triplet"])
+    cls = ref_loss_mod.LOSSES["cross_entropy"](out["cls_out"], tgt)
+    real_rec = ld["spatial"].narrow(0, 0, n_real).mean()
+    real_freq = ld["freq"].narrow(0, 0, n_real).mean()
+    total = cls + lam["lambda_mask"] * ld["freq_mask"].mean() + lam["lambda_mask"] * ld["spat_mask"].mean() + \
+        lam["lambda_triplet"] * trip + lam["lambda_recons"] * real_rec + lam["lambda_freq"] * real_freq
+    m.zero_grad()
+    total.backward()
+    losses = {"total_loss": total, "cls_loss": cls, "triplet_loss": trip, "real_rec_loss": real_rec,
+              "real_freq_loss": real_freq}
+    return out, losses
+
+
+LAMBDAS = dict(lambda_triplet=0.1, lambda_recons=0.1, lambda_freq=1.0, lambda_mask=0.1, lambda_fac=0.1)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_model, ref_loss = ref_import.import_reference()
+    torch.manual_seed(0)
+    drop_rate = 0.5
+    m = ref_model.load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=drop_rate)
+
+    # ---------------- fixture 1: eval mode, N=2, sf_coef=0 (frequency branch visible) --------
+    store = {}
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    x = param_fill.make_input(2, 256, seed=1)
+    m.eval()
+    with torch.no_grad():
+        pack_outputs(m(x), "", store)
+    store["meta"] = np.array([2, 256, 1], dtype=np.int64)   # n, size, input seed
+    np.savez_compressed(os.path.join(OUT, "udeb4_eval_n2.npz"), **store)
+    print("wrote udeb4_eval_n2.npz")
+
+    # ---------------- fixture 1b: eval, default sf_coef=-10 -----------------------------------
+    store = {}
+    param_fill.fill_module_(m, sf_coef=-10.0, fuse_coef=0.0)
+    with torch.no_grad():
+        pack_outputs(m(x), "", store)
+    store["meta"] = np.array([2, 256, 1], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "udeb4_eval_n2_init.npz"), **store)
+    print("wrote udeb4_eval_n2_init.npz")
+
+    # ---------------- fixture 2: train mode fwd + pass-1 loss + bwd, N=4, masks injected ------
+    store = {}
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    n = 4
+    x = param_fill.make_input(n, 256, seed=2)
+    tgt = param_fill.make_labels(n)
+    rng = make_rng(n, seed=3, drop_rate=drop_rate)
+    out, losses = run_reference_train(m, ref_loss, x, tgt, rng, drop_rate, LAMBDAS)
+    pack_outputs(out, "", store)
+    for k, v in losses.items():
+        store["loss_" + k] = np.array(v.item(), dtype=np.float64)
+    names, norms, heads = [], [], []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(p.grad.double().norm().item())
+        h = torch.zeros(8)
+        f = p.grad.flatten()[:8]
+        h[: f.numel()] = f
+        heads.append(h.numpy())
+    store["grad_names"] = np.array(names)
+    store["grad_norms"] = np.array(norms, dtype=np.float64)
+    store["grad_heads"] = np.stack(heads)
+    store["meta"] = np.array([n, 256, 2, 3], dtype=np.int64)   # n, size, input seed, mask seed
+    np.savez_compressed(os.path.join(OUT, "udeb4_train_n4.npz"), **store)
+    print("wrote udeb4_train_n4.npz  (%d grads)" % len(names))
+
+
+if __name__ == "__main__":
+    main()
