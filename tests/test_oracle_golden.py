@@ -9,7 +9,7 @@ import torch
 from oracle import eb4, param_fill
 from tests import oracle_util as ou
 
-GRAD_FLOOR = 1e-4
+GRAD_RTOL, GRAD_ATOL = 1e-3, 2e-5
 RTOL = 2e-5   # fp32 CPU restatement vs fp32 CPU reference (different op grouping only)
 
 
@@ -62,12 +62,13 @@ def test_train_fwd_bwd_matches_reference(golden_dir):
         assert gr is not None, k
         ref_norm = float(g["grad_norms"][i])
         got = gr.double().norm().item()
-        # gradients: relative to the tensor's own norm.  Absolute floor 1e-4: the bias of a BN whose
-        # output only feeds (via 1x1 convs) other batch-stat BNs has a mathematically ZERO gradient;
-        # what both sides hold there is ~1e-6 of rounding noise, which must not be compared.
-        err = abs(got - ref_norm) / max(ref_norm, GRAD_FLOOR)
+        # allclose-style bound (rtol on the tensor's norm + atol).  The atol matters for the bias of a
+        # BN whose output only feeds (via 1x1 convs) other batch-stat BNs: its gradient is
+        # mathematically ZERO and both sides hold ~5e-6 of rounding noise there.
+        tol = GRAD_RTOL * ref_norm + GRAD_ATOL
+        err = abs(got - ref_norm)
         head = gr.flatten()[:8].numpy()
-        herr = np.abs(head - g["grad_heads"][i][: head.size]).max() / max(ref_norm, GRAD_FLOOR)
-        worst = max(worst, err, herr)
-        assert err < 2e-3 and herr < 2e-3, f"{k}: norm err {err:.2e} head err {herr:.2e}"
-    print("worst grad rel err", worst)
+        herr = np.abs(head - g["grad_heads"][i][: head.size]).max()
+        worst = max(worst, err / tol, herr / tol)
+        assert err < tol and herr < tol, f"{k}: norm err {err:.2e} head err {herr:.2e} tol {tol:.2e}"
+    print("worst grad err / tol", worst)
