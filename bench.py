@@ -1,0 +1,157 @@
+"""bench.py — images/sec of ONE forward+backward of UniDefenseModelEb4 (pass-1 loss of the train step,
+engine/abstract_engine.py:210-281 in the reference) at 256x256, bs=32 per GPU, fp32, synthetic inputs.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (metric/unit from BASELINE.json; value = whole-job images/s with inputs
+resident in HBM; weak scaling: bs=32 per GPU).  Extra objects:
+  roofline     — dominant kernel = the fp32 MFMA GEMM (ud_gemm): algorithmic FLOPs of all its launches in
+                 the timed region / their HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak.
+  cpu_baseline — the oracle (CPU restatement, "port") timed on the host cores on a bounded sample (bs 4).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+LAMBDAS = dict(lambda_triplet=0.1, lambda_recons=0.1, lambda_freq=1.0, lambda_mask=0.1)   # uniatt/Prot1/model_udeb4.yml
+
+
+def pass1_loss(out, tgt, n_real, losses):
+    ld = out["loss_dict"]
+    trip = sum(losses["aw_triplet"](f, tgt) for f in ld["triplet"])
+    cls = losses["cross_entropy"](out["cls_out"], tgt)
+    return cls + LAMBDAS["lambda_mask"] * (ld["freq_mask"].mean() + ld["spat_mask"].mean()) + \
+        LAMBDAS["lambda_triplet"] * trip + LAMBDAS["lambda_recons"] * ld["spatial"].narrow(0, 0, n_real).mean() + \
+        LAMBDAS["lambda_freq"] * ld["freq"].narrow(0, 0, n_real).mean()
+
+
+def cpu_baseline(bs=4, iters=2):
+    """Oracle forward + pass-1 loss + backward on the host cores (all of them), bounded sample."""
+    from oracle import param_fill
+    from tests import oracle_util as ou
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = param_fill.make_input(bs, 256, seed=0)
+    tgt = param_fill.make_labels(bs)
+    rng = ou.make_rng(bs, 1, 0.5)
+    sd = ou.oracle_state(-10.0, 0.0, requires_grad=True)
+    ou.oracle_train_pass1(sd, x, tgt, rng, 0.5)          # warm-up
+    ts = []
+    for _ in range(iters):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        ou.oracle_train_pass1(sd, x, tgt, rng, 0.5)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return {"value": bs / ts[len(ts) // 2], "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (pure-torch CPU restatement) fwd+pass-1 loss+bwd, UDEB4 256x256 bs={bs}, fp32, "
+                      f"median of {iters} after 1 warm-up, torch threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from unidefense_amd import kernels as K
+    from unidefense_amd.loss import LOSSES
+    from unidefense_amd.model import load_model
+    from unidefense_amd.engine.parallel import wrap_data_parallel
+
+    torch.manual_seed(1234)
+    model = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5).to(dev).train()
+    model = wrap_data_parallel(model, local_rank) if world > 1 else model
+    bs = args.batch
+    g = torch.Generator().manual_seed(100 + rank)
+    x = (2.0 * torch.rand(bs, 3, 256, 256, generator=g) - 1.0).to(dev)
+    tgt = torch.tensor([0] * (bs // 2) + [1] * (bs // 2), device=dev)
+    for k_ in ("aw_triplet",):
+        LOSSES[k_].n_real = bs // 2
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        out = model(x)
+        loss = pass1_loss(out, tgt, bs // 2, LOSSES)
+        loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    K.GEMM_PROFILE = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    if rank == 0:
+        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+        gemm_flops = sum(f for _, _, f in prof)
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        line = {
+            "metric": "images/sec fwd+bwd (256x256, EffNet-b4)", "value": world * bs * args.steps / elapsed,
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "UDEB4 (EfficientNet-b4 + SFConv) 256x256 fwd + pass-1 loss + bwd, "
+                                   "spatial+frequency branches on, bs=32/GPU (BASELINE configs[1]/[2])",
+                       "global_batch": world * bs, "parallelism": f"dp{world}", "final_loss": float(loss)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (ud_gemm, v_mfma_f32_32x32x2_f32)",
+                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": len(prof) / max(args.steps, 1),
+                         "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
+                         "gemm_gflop_per_step": gemm_flops / 1e9 / max(args.steps, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

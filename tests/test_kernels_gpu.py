@@ -1,0 +1,447 @@
+"""GPU parity tests, operator level: every HIP operator (forward AND backward, called through the C ABI
+via unidefense_amd.tape) against the same op of the oracle / plain torch evaluated on the CPU in float64.
+
+Tolerance: 1e-3 relative to the tensor's max magnitude (BASELINE.json north_star: "within 1e-3 rel fp32");
+observed errors are ~1e-6..1e-5 and are printed.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def to_pix(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def check(name, got, ref, tol=RTOL):
+    e = rel_err(got, ref)
+    print(f"  {name}: rel err {e:.3e}")
+    assert e <= tol, f"{name}: rel err {e:.3e} > {tol}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def run_tape(fn, inputs, params, gouts_fn):
+    """fn(tape, *inputs_cuda, *params_cuda) -> output or tuple.  Returns outputs, input grads, param grads."""
+    from unidefense_amd import tape as T
+    tape = T.Tape()
+    outs = fn(tape, *inputs, *params)
+    single = not isinstance(outs, (tuple, list))
+    outs_l = [outs] if single else list(outs)
+    gouts = gouts_fn(outs_l)
+    for o, g in zip(outs_l, gouts):
+        if g is not None:
+            tape.add_grad(o, g)
+    # collect input grads before replay clears them: wrap by recording a sentinel first node
+    grads_in = {}
+    pg = tape.param_grads
+
+    def grab():
+        for i, t in enumerate(inputs):
+            grads_in[i] = tape.grads.get(id(t))
+    tape.nodes.insert(0, grab)      # runs last in the reversed replay
+    tape.backward()
+    return outs_l, [grads_in.get(i) for i in range(len(inputs))], [pg.get(p) for p in params]
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 24), (1280, 3264, 3264 // 8), (520, 40, 96),
+                                   (1000, 24, 144), (64, 3, 180), (33, 130, 20)])
+def test_gemm_nt_nn_tn(M, N, K):
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    ref = a.double() @ w.double().t()
+    check("nt", Kk.gemm_nt(a.to(dev), w.to(dev)), ref)
+    wk = rnd(K, N, seed=3)
+    check("nn", Kk.gemm_nn(a.to(dev), wk.to(dev)), a.double() @ wk.double())
+    at, bt = rnd(K, M, seed=4), rnd(K, N, seed=5)
+    check("tn", Kk.gemm_tn(at.to(dev), bt.to(dev)), at.double().t() @ bt.double())
+
+
+def test_gemm_tn_splitk_and_accumulate():
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    K_, M, N = 70000, 96, 48
+    at, bt = rnd(K_, M, seed=4), rnd(K_, N, seed=5)
+    check("tn split-k", Kk.gemm_tn(at.to(dev), bt.to(dev)), at.double().t() @ bt.double())
+    a, w = rnd(200, 64, seed=1), rnd(72, 64, seed=2)
+    base = rnd(200, 72, seed=3)
+    out = base.to(dev).clone()
+    Kk.gemm_nt(a.to(dev), w.to(dev), out=out, accumulate=True)
+    check("nt accumulate", out, base.double() + a.double() @ w.double().t())
+
+
+@pytest.mark.parametrize("N,H,Ci,Co", [(2, 16, 160, 80), (2, 8, 272, 272), (1, 32, 20, 3), (2, 16, 40, 20)])
+def test_conv3x3(N, H, Ci, Co):
+    dev = _dev()
+    from unidefense_amd import tape as T
+    x = rnd(N, Ci, H, H, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1)
+    gy = rnd(N, Co, H, H, seed=3)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr.backward(gy.double())
+    xp, wp = to_pix(x).to(dev), w.to(dev)
+    outs, gin, gp = run_tape(lambda t, a, b: T.conv_dense(t, a, b, 1, 1, 1, H, H), [xp], [wp],
+                             lambda o: [to_pix(gy).to(dev)])
+    check("y", to_nchw(outs[0]), yr)
+    check("dx", to_nchw(gin[0]), xr.grad)
+    check("dw", gp[0], wr.grad)
+
+
+def test_stem_conv():
+    dev = _dev()
+    from unidefense_amd import tape as T
+    N, H = 2, 64
+    x = rnd(N, 3, H, H, seed=1)
+    w = rnd(48, 3, 3, 3, seed=2, scale=0.3)
+    gy = rnd(N, 48, H // 2, H // 2, seed=3)
+    xr, wr = x.double(), w.double().requires_grad_()
+    yr = F.conv2d(F.pad(xr, [0, 1, 0, 1]), wr, None, 2, 0)
+    yr.backward(gy.double())
+    outs, gin, gp = run_tape(lambda t, a, b: T.conv_dense(t, a, b, 2, 0, 0, H // 2, H // 2, need_dx=False),
+                             [to_pix(x).to(dev)], [w.to(dev)], lambda o: [to_pix(gy).to(dev)])
+    check("y", to_nchw(outs[0]), yr)
+    check("dw", gp[0], wr.grad)
+
+
+@pytest.mark.parametrize("N,H,C", [(2, 16, 80), (1, 32, 20)])
+def test_conv_transpose(N, H, C):
+    dev = _dev()
+    from unidefense_amd import tape as T
+    x = rnd(N, C, H, H, seed=1)
+    w = rnd(C, C, 3, 3, seed=2, scale=0.1)
+    gy = rnd(N, C, 2 * H, 2 * H, seed=3)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = F.conv_transpose2d(xr, wr, None, 2, 1, 1)
+    yr.backward(gy.double())
+    outs, gin, gp = run_tape(lambda t, a, b: T.conv_transpose_s2(t, a, b), [to_pix(x).to(dev)], [w.to(dev)],
+                             lambda o: [to_pix(gy).to(dev)])
+    check("y", to_nchw(outs[0]), yr)
+    check("dx", to_nchw(gin[0]), xr.grad)
+    check("dw", gp[0], wr.grad)
+
+
+@pytest.mark.parametrize("k,s,pad,H,C", [(3, 1, (1, 1, 1, 1), 16, 48), (3, 2, (0, 1, 0, 1), 32, 144),
+                                         (5, 1, (2, 2, 2, 2), 16, 960), (5, 2, (2, 2, 2, 2), 32, 192),
+                                         (5, 2, (1, 2, 1, 2), 16, 960), (3, 1, (1, 1, 1, 1), 8, 2688)])
+def test_dwconv(k, s, pad, H, C):
+    dev = _dev()
+    from unidefense_amd import tape as T
+    N = 2
+    x = rnd(N, C, H, H, seed=1)
+    w = rnd(C, 1, k, k, seed=2, scale=0.3)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = F.conv2d(F.pad(xr, list(pad)), wr, None, s, 0, 1, C)
+    gy = rnd(*yr.shape, seed=3)
+    yr.backward(gy.double())
+    outs, gin, gp = run_tape(lambda t, a, b: T.dwconv(t, a, b, s, pad), [to_pix(x).to(dev)], [w.to(dev)],
+                             lambda o: [to_pix(gy).to(dev)])
+    check("y", to_nchw(outs[0]), yr)
+    check("dx", to_nchw(gin[0]), xr.grad)
+    check("dw", gp[0], wr.grad)
+
+
+@pytest.mark.parametrize("N,H,C,act", [(4, 16, 144, 1), (2, 8, 1632, 0), (3, 32, 24, 1), (2, 4, 2688, 1)])
+def test_batchnorm(N, H, C, act):
+    dev = _dev()
+    from unidefense_amd import tape as T
+    x = rnd(N, C, H, H, seed=1) * 2 + 0.5
+    g, b = rnd(C, seed=2) * 0.1 + 1, rnd(C, seed=3) * 0.1
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr, gr, br = x.double().requires_grad_(), g.double().requires_grad_(), b.double().requires_grad_()
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    yr = F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.01, 1e-3)
+    if act:
+        yr = yr * torch.sigmoid(yr)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy.double())
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    outs, gin, gp = run_tape(
+        lambda t, a, w_, b_: T.batchnorm_act(t, a, w_, b_, rm_d, rv_d, 1e-3, 0.01, True, act),
+        [to_pix(x).to(dev)], [g.to(dev).requires_grad_(), b.to(dev).requires_grad_()], lambda o: [to_pix(gy).to(dev)])
+    check("y", to_nchw(outs[0]), yr)
+    check("dx", to_nchw(gin[0]), xr.grad)
+    check("dgamma", gp[0], gr.grad)
+    check("dbeta", gp[1], br.grad)
+    check("running_mean", rm_d, rm_r)
+    check("running_var", rv_d, rv_r)
+
+
+def test_batchnorm1d_rows():
+    dev = _dev()
+    from unidefense_amd import tape as T
+    N, C = 32, 1792
+    x = rnd(N, C, seed=1) + 1.0
+    g, b = rnd(C, seed=2) * 0.1 + 1, rnd(C, seed=3) * 0.1
+    xr, gr = x.double().requires_grad_(), g.double().requires_grad_()
+    yr = F.batch_norm(xr, None, None, gr, b.double(), True, 0.1, 1e-5)
+    gy = rnd(N, C, seed=4)
+    yr.backward(gy.double())
+    rm_d, rv_d = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    outs, gin, gp = run_tape(lambda t, a, w_, b_: T.batchnorm_act(t, a, w_, b_, rm_d, rv_d, 1e-5, 0.1, True, 0),
+                             [x.to(dev)], [g.to(dev).requires_grad_(), b.to(dev)], lambda o: [gy.to(dev)])
+    check("y", outs[0], yr)
+    check("dx", gin[0], xr.grad)
+    check("dgamma", gp[0], gr.grad)
+
+
+@pytest.mark.parametrize("N,H,C", [(2, 32, 80), (3, 16, 20), (2, 128, 20)])
+def test_instancenorm_swish(N, H, C):
+    dev = _dev()
+    from unidefense_amd import tape as T
+    x = rnd(N, C, H, H, seed=1) * 1.5 + 0.3
+    g, b = rnd(C, seed=2) * 0.1 + 1, rnd(C, seed=3) * 0.1
+    xr, gr, br = x.double().requires_grad_(), g.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    yr = yr * torch.sigmoid(yr)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy.double())
+    outs, gin, gp = run_tape(lambda t, a, w_, b_: T.instancenorm_act(t, a, w_, b_, 1e-5, 1), [to_pix(x).to(dev)],
+                             [g.to(dev).requires_grad_(), b.to(dev).requires_grad_()], lambda o: [to_pix(gy).to(dev)])
+    check("y", to_nchw(outs[0]), yr)
+    check("dx", to_nchw(gin[0]), xr.grad)
+    check("dgamma", gp[0], gr.grad)
+    check("dbeta", gp[1], br.grad)
+
+
+@pytest.mark.parametrize("S,C,norm", [(8, 1632, "ortho"), (8, 3, "ortho"), (8, 272, "ortho"), (16, 672, "ortho"),
+                                      (16, 40, None), (32, 336, "ortho"), (64, 192, "ortho"), (32, 20, None)])
+def test_rfft2_irfft2(S, C, norm):
+    dev = _dev()
+    from unidefense_amd import tape as T
+    N = 2
+    x = rnd(N, C, S, S, seed=1)
+    xr = x.double().requires_grad_()
+    fr = torch.fft.rfft2(xr, norm=norm)
+    yr = torch.cat([fr.real, fr.imag], 1)
+    gy = rnd(*yr.shape, seed=2)
+    yr.backward(gy.double())
+    outs, gin, _ = run_tape(lambda t, a: T.rfft2_cat(t, a, norm), [to_pix(x).to(dev)], [],
+                            lambda o: [to_pix(gy).to(dev)])
+    check("rfft2", to_nchw(outs[0]), yr)
+    check("rfft2 adjoint", to_nchw(gin[0]), xr.grad)
+    # inverse
+    y = rnd(N, 2 * C, S, S // 2 + 1, seed=3)
+    yr2 = y.double().requires_grad_()
+    re, im = torch.tensor_split(yr2, 2, dim=1)
+    xr2 = torch.fft.irfft2(torch.complex(re, im), s=(S, S), norm=norm)
+    gx = rnd(N, C, S, S, seed=4)
+    xr2.backward(gx.double())
+    outs, gin, _ = run_tape(lambda t, a: T.irfft2_split(t, a, norm), [to_pix(y).to(dev)], [],
+                            lambda o: [to_pix(gx).to(dev)])
+    check("irfft2", to_nchw(outs[0]), xr2)
+    check("irfft2 adjoint", to_nchw(gin[0]), yr2.grad)
+
+
+@pytest.mark.parametrize("C,k,s,pad,S", [(192, 5, 2, (2, 2, 2, 2), 64), (336, 5, 1, (2, 2, 2, 2), 32),
+                                         (672, 3, 1, (1, 1, 1, 1), 16), (960, 5, 2, (1, 2, 1, 2), 16),
+                                         (1632, 5, 1, (2, 2, 2, 2), 8)])
+def test_sfconv(C, k, s, pad, S):
+    """SFConv2dStaticSamePadding.forward/backward vs the oracle restatement (oracle/eb4.py:sfconv)."""
+    dev = _dev()
+    from unidefense_amd import tape as T
+    from oracle import eb4
+    N = 2
+    x = rnd(N, C, S, S, seed=1)
+    w = rnd(C, 1, k, k, seed=2, scale=0.3)
+    wf = rnd(2 * C, 2 * C, 1, 1, seed=3, scale=math.sqrt(1.0 / C))
+    alpha = torch.tensor(0.2)
+    sd = {"p.weight": w.double().requires_grad_(), "p.freq_conv.weight": wf.double().requires_grad_(),
+          "p.sf_coef": alpha.double().requires_grad_()}
+    xr = x.double().requires_grad_()
+    yr = eb4.sfconv(xr, sd, "p", s, pad, "ortho")
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy.double())
+    outs, gin, gp = run_tape(lambda t, a, w_, wf_, al: T.sfconv_dw(t, a, w_, wf_, al, s, pad, "ortho"),
+                             [to_pix(x).to(dev)], [w.to(dev), wf.to(dev), alpha.to(dev)],
+                             lambda o: [to_pix(gy).to(dev)])
+    check("y", to_nchw(outs[0]), yr)
+    check("dx", to_nchw(gin[0]), xr.grad)
+    check("dw", gp[0], sd["p.weight"].grad)
+    check("dwf", gp[1], sd["p.freq_conv.weight"].grad)
+    check("dalpha", gp[2].reshape(()), sd["p.sf_coef"].grad)
+
+
+@pytest.mark.parametrize("C,Cs,H", [(144, 6, 32), (1632, 68, 8), (336, 14, 16)])
+def test_squeeze_excite(C, Cs, H):
+    dev = _dev()
+    from unidefense_amd import tape as T
+    N = 3
+    x = rnd(N, C, H, H, seed=1)
+    wr_, br_ = rnd(Cs, C, 1, 1, seed=2, scale=0.1), rnd(Cs, seed=3, scale=0.1)
+    we_, be_ = rnd(C, Cs, 1, 1, seed=4, scale=0.3), rnd(C, seed=5, scale=0.1)
+    ps = [t.double().requires_grad_() for t in (wr_, br_, we_, be_)]
+    xr = x.double().requires_grad_()
+    s = F.adaptive_avg_pool2d(xr, 1)
+    s = F.conv2d(s, ps[0], ps[1])
+    s = s * torch.sigmoid(s)
+    s = F.conv2d(s, ps[2], ps[3])
+    yr = torch.sigmoid(s) * xr
+    gy = rnd(*yr.shape, seed=6)
+    yr.backward(gy.double())
+    outs, gin, gp = run_tape(lambda t, a, *p: T.squeeze_excite(t, a, *p), [to_pix(x).to(dev)],
+                             [t.to(dev) for t in (wr_, br_, we_, be_)], lambda o: [to_pix(gy).to(dev)])
+    check("y", to_nchw(outs[0]), yr)
+    check("dx", to_nchw(gin[0]), xr.grad)
+    for i, nm in enumerate(("dWr", "dbr", "dWe", "dbe")):
+        check(nm, gp[i], ps[i].grad)
+
+
+def test_small_ops():
+    dev = _dev()
+    from unidefense_amd import tape as T
+    N, C, H = 4, 160, 16
+    x, skip = rnd(N, C, H, H, seed=1), rnd(N, C, H, H, seed=2)
+    keep = torch.tensor([1.0, 0.0, 1.0, 1.0])
+    gy = rnd(N, C, H, H, seed=3)
+    # residual + drop connect
+    xr, sr = x.double().requires_grad_(), skip.double().requires_grad_()
+    yr = xr / 0.9 * keep.double().view(-1, 1, 1, 1) + sr
+    yr.backward(gy.double())
+    outs, gin, _ = run_tape(lambda t, a, b: T.residual(t, a, b, keep.to(dev), 0.9),
+                            [to_pix(x).to(dev), to_pix(skip).to(dev)], [], lambda o: [to_pix(gy).to(dev)])
+    check("residual y", to_nchw(outs[0]), yr)
+    check("residual dx", to_nchw(gin[0]), xr.grad)
+    check("residual dskip", to_nchw(gin[1]), sr.grad)
+    # mean over HW
+    xr = x.double().requires_grad_()
+    mr = xr.mean((2, 3))
+    gm = rnd(N, C, seed=4)
+    mr.backward(gm.double())
+    outs, gin, _ = run_tape(lambda t, a: T.mean_hw(t, a), [to_pix(x).to(dev)], [], lambda o: [gm.to(dev)])
+    check("mean_hw", outs[0], mr)
+    check("mean_hw dx", to_nchw(gin[0]), xr.grad)
+    # gate mix
+    al = torch.tensor(0.3)
+    pr, qr, ar = x.double().requires_grad_(), skip.double().requires_grad_(), al.double().requires_grad_()
+    a_ = torch.sigmoid(ar)
+    yr = (1 - a_) * pr + a_ * qr
+    yr.backward(gy.double())
+    outs, gin, gp = run_tape(lambda t, a, b, c: T.gate_mix(t, a, b, c), [x.to(dev), skip.to(dev)], [al.to(dev)],
+                             lambda o: [gy.to(dev)])
+    check("gate_mix y", outs[0], yr)
+    check("gate_mix dp", gin[0], pr.grad)
+    check("gate_mix dq", gin[1], qr.grad)
+    check("gate_mix dalpha", gp[0].reshape(()), ar.grad)
+    # dropout with mask, linear
+    mask = (rnd(N, 1792, seed=5) > 0).float()
+    f = rnd(N, 1792, seed=6)
+    w, b = rnd(2, 1792, seed=7, scale=0.05), rnd(2, seed=8)
+    fr, wr, br = f.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.linear(fr * mask.double() / 0.5, wr, br)
+    gl = rnd(N, 2, seed=9)
+    yr.backward(gl.double())
+    outs, gin, gp = run_tape(lambda t, a, w_, b_: T.linear(t, T.dropout_mask(t, a, mask.to(dev), 0.5), w_, b_),
+                             [f.to(dev)], [w.to(dev), b.to(dev)], lambda o: [gl.to(dev)])
+    check("linear y", outs[0], yr)
+    check("linear dx", gin[0], fr.grad)
+    check("linear dW", gp[0], wr.grad)
+    check("linear db", gp[1], br.grad)
+
+
+def test_image_tail():
+    """tanh -> planes -> bilinear(align_corners) -> L1 + frequency L1 (model/unidefense.py:101,244-253)."""
+    dev = _dev()
+    from unidefense_amd import tape as T
+    N, S = 2, 64
+    d = rnd(N, 3, S, S, seed=1)
+    x = (torch.rand(N, 3, 2 * S, 2 * S, generator=torch.Generator().manual_seed(2)) * 2 - 1).float()
+    dr = d.double().requires_grad_()
+    rec_r = F.interpolate(torch.tanh(dr), size=(2 * S, 2 * S), mode="bilinear", align_corners=True)
+    sp_r = (rec_r - x.double()).abs().mean((1, 2, 3))
+    fa = torch.fft.rfft2(rec_r, norm="ortho")
+    fb = torch.fft.rfft2(x.double(), norm="ortho")
+    fq_r = ((fa.real - fb.real).abs() + (fa.imag - fb.imag).abs()).mean((1, 2, 3))
+    gs, gf = rnd(N, seed=3), rnd(N, seed=4)
+    grec = rnd(N, 3, 2 * S, 2 * S, seed=5) * 1e-4
+    (sp_r * gs.double()).sum().add((fq_r * gf.double()).sum()).add((rec_r * grec.double()).sum()).backward()
+    xd = x.to(dev)
+
+    def fn(t, a):
+        planes = T.tanh_to_planes(t, a)
+        rec = T.bilinear(t, planes, 2 * S, 2 * S)
+        sp, fq = T.rec_losses(t, rec, xd, "ortho")
+        return rec, sp, fq
+    outs, gin, _ = run_tape(fn, [to_pix(d).to(dev)], [], lambda o: [grec.to(dev), gs.to(dev), gf.to(dev)])
+    check("rec", outs[0], rec_r)
+    check("spatial", outs[1], sp_r)
+    check("freq", outs[2], fq_r)
+    check("d(dec3)", to_nchw(gin[0]), dr.grad)
+
+
+def test_bilinear_down():
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    x = rnd(2, 3, 128, 128, seed=1)
+    ref = F.interpolate(x.double(), size=(8, 8), mode="bilinear", align_corners=True)
+    check("128->8", Kk.bilinear_fwd(x.to(dev), 8, 8), ref)
+
+
+@pytest.mark.parametrize("kind", ["freq", "spat"])
+def test_dynamic_filter(kind):
+    """FrequencyDynamicFilter / SpatialDynamicFilter (model/modules.py:79-134) vs oracle.dynamic_filter."""
+    dev = _dev()
+    from unidefense_amd import tape as T
+    from oracle import eb4
+    N, h = 4, 8
+    if kind == "freq":
+        C, w_, D, k = 544, 5, 6, 1
+    else:
+        C, w_, D, k = 272, 8, 3, 3
+    x = rnd(N, C, h, w_, seed=1)
+    diff = rnd(N, D, h, w_, seed=2).abs()
+    sd = {"f.layer1.0.weight": rnd(C, C, k, k, seed=3, scale=math.sqrt(2.0 / (C * k * k))).double().requires_grad_(),
+          "f.layer1.1.weight": (rnd(C, seed=4) * 0.1 + 1).double().requires_grad_(),
+          "f.layer1.1.bias": (rnd(C, seed=5) * 0.1).double().requires_grad_(),
+          "f.layer2.0.weight": rnd(1, 2 + D, 1, 1, seed=6, scale=0.5).double().requires_grad_()}
+    xr = x.double().requires_grad_()
+    o = eb4.dynamic_filter(xr, diff.double(), sd, "f", True, k // 2)
+    g_out, g_mask = rnd(*o["out"].shape, seed=7), rnd(*o["mask"].shape, seed=8)
+    ((o["out"] * g_out.double()).sum() + (o["mask"] * g_mask.double()).sum()).backward()
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    diff_p = to_pix(diff).to(dev)
+
+    def fn(t, a, w1, g1, b1, w2):
+        if k == 1:
+            proj = T.conv1x1(t, a, w1)
+        else:
+            proj = T.conv_dense(t, a, w1, 1, 1, 1, h, w_)
+        proj = T.batchnorm_act(t, proj, g1, b1, rm, rv, 1e-5, 0.1, True, 1)
+        return T.dynamic_filter(t, a, proj, diff_p, w2)
+    params = [sd[k_].detach().float().to(dev).requires_grad_() for k_ in
+              ("f.layer1.0.weight", "f.layer1.1.weight", "f.layer1.1.bias", "f.layer2.0.weight")]
+    outs, gin, gp = run_tape(fn, [to_pix(x).to(dev)], params,
+                             lambda o_: [to_pix(g_out).to(dev), to_pix(g_mask).to(dev)])
+    check("out", to_nchw(outs[0]), o["out"])
+    check("mask", to_nchw(outs[1]), o["mask"])
+    check("dx", to_nchw(gin[0]), xr.grad)
+    for p_, k_ in zip(gp, ("f.layer1.0.weight", "f.layer1.1.weight", "f.layer1.1.bias", "f.layer2.0.weight")):
+        check("d " + k_, p_, sd[k_].grad)

@@ -1,0 +1,215 @@
+// Depthwise k x k convolution (k = 3, 5; stride 1, 2; static asymmetric zero padding) on pixel-major
+// [N][H][W][C] fp32, forward + data gradient + weight gradient.
+//
+// Serves the spatial branch of SFConv2dStaticSamePadding.forward (model/efficientnet/exp.py:49-51) and the
+// plain depthwise Conv2dStaticSamePadding (model/efficientnet/utils.py:277-280) — ZeroPad2d(left, right,
+// top, bottom) followed by an unpadded grouped conv; the pads are passed explicitly (pad_t, pad_l; the
+// bottom/right pads are implied by the output size).
+//
+// HBM-bound: lanes run over channels (4 per lane, 16-B loads), so every global access of a wave is one
+// contiguous segment; the k*k taps re-read neighbouring pixels through L1/L2.  Weights are passed
+// tap-major wt[k*k][C] so that the per-lane weight loads are coalesced too.
+#include "ud_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct DwGeom {
+    int N, H, W, C4, Ho, Wo, stride, pad_t, pad_l;
+};
+
+template <int K>
+__global__ __launch_bounds__(NT) void dw_fwd(DwGeom q, const float* __restrict__ x, const float* __restrict__ wt,
+                                             float* __restrict__ y) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const long total = (long)q.N * q.Ho * q.Wo * q.C4;
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
+        int c4 = (int)(e % q.C4);
+        long pix = e / q.C4;
+        int wo = (int)(pix % q.Wo);
+        long t = pix / q.Wo;
+        int ho = (int)(t % q.Ho);
+        int n = (int)(t / q.Ho);
+        const int ih0 = ho * q.stride - q.pad_t, iw0 = wo * q.stride - q.pad_l;
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            int ih = ih0 + kh;
+            if (ih < 0 || ih >= q.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                int iw = iw0 + kw;
+                if (iw < 0 || iw >= q.W) continue;
+                f32x4 a = x4[(((long)n * q.H + ih) * q.W + iw) * q.C4 + c4];
+                f32x4 w = w4[(kh * K + kw) * q.C4 + c4];
+                acc += a * w;
+            }
+        }
+        y4[e] = acc;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const float* __restrict__ dy, const float* __restrict__ wt,
+                                                  float* __restrict__ dx) {
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    const long total = (long)q.N * q.H * q.W * q.C4;
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
+        int c4 = (int)(e % q.C4);
+        long pix = e / q.C4;
+        int w = (int)(pix % q.W);
+        long t = pix / q.W;
+        int h = (int)(t % q.H);
+        int n = (int)(t / q.H);
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            int th = h + q.pad_t - kh;
+            if (th < 0 || (th % q.stride) != 0) continue;
+            int ho = th / q.stride;
+            if (ho >= q.Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                int tw = w + q.pad_l - kw;
+                if (tw < 0 || (tw % q.stride) != 0) continue;
+                int wo = tw / q.stride;
+                if (wo >= q.Wo) continue;
+                f32x4 g = dy4[(((long)n * q.Ho + ho) * q.Wo + wo) * q.C4 + c4];
+                f32x4 ww = w4[(kh * K + kw) * q.C4 + c4];
+                acc += g * ww;
+            }
+        }
+        dx4[e] = acc;
+    }
+}
+
+// partial weight gradient: part[(p * rpi + ri)][tap][C]
+template <int K>
+__global__ __launch_bounds__(NT) void dw_bwd_weight_partial(DwGeom q, int rpi, int pix_per_chunk,
+                                                            const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ part) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    int t = threadIdx.x, ri, c4;
+    bool active;
+    if (q.C4 <= NT) {
+        ri = t / q.C4; c4 = t % q.C4; active = ri < rpi;
+    } else {
+        ri = 0; c4 = blockIdx.y * NT + t; active = c4 < q.C4;
+    }
+    if (!active) return;
+    const long npix = (long)q.N * q.Ho * q.Wo;
+    const long p_begin = (long)blockIdx.x * pix_per_chunk;
+    long p_end = p_begin + pix_per_chunk;
+    if (p_end > npix) p_end = npix;
+    f32x4 acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    for (long pix = p_begin + ri; pix < p_end; pix += rpi) {
+        int wo = (int)(pix % q.Wo);
+        long tt = pix / q.Wo;
+        int ho = (int)(tt % q.Ho);
+        int n = (int)(tt / q.Ho);
+        f32x4 g = dy4[pix * q.C4 + c4];
+        const int ih0 = ho * q.stride - q.pad_t, iw0 = wo * q.stride - q.pad_l;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            int ih = ih0 + kh;
+            bool okh = (ih >= 0) && (ih < q.H);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                int iw = iw0 + kw;
+                if (okh && iw >= 0 && iw < q.W) {
+                    f32x4 a = x4[(((long)n * q.H + ih) * q.W + iw) * q.C4 + c4];
+                    acc[kh * K + kw] += a * g;
+                }
+            }
+        }
+    }
+    const long pidx = (long)blockIdx.x * rpi + ri;
+    f32x4* out = reinterpret_cast<f32x4*>(part) + pidx * (K * K) * q.C4;
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) out[(long)i * q.C4 + c4] = acc[i];
+}
+
+__global__ void dw_bwd_weight_finalize(int nparts, int KKC, const float* __restrict__ part, float* __restrict__ dwt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KKC) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += part[(long)p * KKC + i];
+    dwt[i] = a;
+}
+
+int ew_blocks(long total) {
+    long b = (total + NT - 1) / NT;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+bool geom_ok(const DwGeom& q, int K) {
+    return q.N > 0 && q.H > 0 && q.W > 0 && q.C4 > 0 && q.Ho > 0 && q.Wo > 0 && (q.stride == 1 || q.stride == 2) &&
+           (K == 3 || K == 5);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W, int C, int Ho, int Wo, int K,
+                  int stride, int pad_t, int pad_l, ud_stream_t stream) {
+    if (C % 4) return UD_EINVAL;
+    DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
+    if (!geom_ok(q, K)) return UD_EINVAL;
+    long total = (long)N * Ho * Wo * q.C4;
+    if (K == 3) hipLaunchKernelGGL(dw_fwd<3>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, q, x, wt, y);
+    else hipLaunchKernelGGL(dw_fwd<5>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, q, x, wt, y);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_dwconv_bwd_data(const float* dy, const float* wt, float* dx, int N, int H, int W, int C, int Ho, int Wo, int K,
+                       int stride, int pad_t, int pad_l, ud_stream_t stream) {
+    if (C % 4) return UD_EINVAL;
+    DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
+    if (!geom_ok(q, K)) return UD_EINVAL;
+    long total = (long)N * H * W * q.C4;
+    if (K == 3) hipLaunchKernelGGL(dw_bwd_data<3>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, q, dy, wt, dx);
+    else hipLaunchKernelGGL(dw_bwd_data<5>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, q, dy, wt, dx);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+// number of float partial rows (each K*K*C floats) the weight-gradient pass needs for `chunks` chunks
+int ud_dwconv_bwd_weight_parts(int C, int chunks) {
+    int C4 = C / 4;
+    int rpi = (C4 <= NT) ? NT / C4 : 1;
+    return chunks * rpi;
+}
+
+int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* part, int chunks, int N, int H, int W,
+                         int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream) {
+    if (C % 4 || chunks < 1) return UD_EINVAL;
+    DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
+    if (!geom_ok(q, K)) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int rpi = (q.C4 <= NT) ? NT / q.C4 : 1;
+    long npix = (long)N * Ho * Wo;
+    int ppc = (int)((npix + chunks - 1) / chunks);
+    dim3 grid((unsigned)chunks, (unsigned)((q.C4 + NT - 1) / NT), 1);
+    // chunks beyond the pixel range write zeros (their loops are empty), so the finalize can sum all parts
+    if (K == 3) hipLaunchKernelGGL(dw_bwd_weight_partial<3>, grid, dim3(NT), 0, s, q, rpi, ppc, x, dy, part);
+    else hipLaunchKernelGGL(dw_bwd_weight_partial<5>, grid, dim3(NT), 0, s, q, rpi, ppc, x, dy, part);
+    UD_LAUNCH_CHECK();
+    int KKC = K * K * C;
+    hipLaunchKernelGGL(dw_bwd_weight_finalize, dim3(ud_cdiv(KKC, 256)), dim3(256), 0, s, chunks * rpi, KKC, part, dwt);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

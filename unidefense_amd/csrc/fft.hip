@@ -1,0 +1,246 @@
+// Batched small real 2-D FFT (S x S, S = 8, 16, 32, 64) on pixel-major [N][S][S][C] fp32, and its inverse.
+//
+// Serves torch.fft.rfft2 / irfft2 of SFConv2dStaticSamePadding.forward (model/efficientnet/exp.py:55,60),
+// of UniDefenseModelEb4.attention (model/unidefense.py:130-145), and both autograd adjoints:
+//     d(rfft2)  = irfft2-kernel with interior columns weighted 1/2
+//     d(irfft2) = rfft2-kernel  with interior columns weighted 2
+// (half-spectrum conventions of pocketfft/cuFFT c2r: the imaginary parts of the kx = 0 and kx = S/2
+// columns — after the column transform — are ignored).
+//
+// Layout choice: the channel is the LANE.  Each lane transforms its own (n, c) plane, so there are no
+// cross-lane butterflies at all, every global access of a wave is one contiguous run of channels, and
+// the output is written directly in the [pixels][Re(0..C) | Im(0..C)] operand layout of the spectral
+// 1x1 GEMM (the torch.cat / tensor_split / torch.complex shuffles of exp.py:56,59 cost nothing).
+// A workgroup of 512 threads owns CB channels of one image (S * CB = 512):
+//   pass 1: thread (h, c) does the S-point row transform in registers      -> LDS [kx][h][c]
+//   pass 2: thread (kx, c) does the S-point column transform in registers  -> global
+// (inverse: columns first, then Hermitian-extended rows).  HBM traffic is the algorithmic minimum:
+// one read of the input and one write of the output.
+#include "ud_common.h"
+
+namespace {
+
+constexpr int NT = 512;
+
+// exp(-2*pi*i*j/64), j = 0..31
+__device__ constexpr float TW_RE[32] = {
+    1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f,
+    8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f,
+    3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 0.0f, -9.801714033e-02f,
+    -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f,
+    -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f,
+    -9.807852804e-01f, -9.951847267e-01f};
+__device__ constexpr float TW_IM[32] = {
+    0.0f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f,
+    -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f,
+    -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f,
+    -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f,
+    -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f,
+    -1.950903220e-01f, -9.801714033e-02f};
+
+template <int S>
+__device__ __forceinline__ constexpr int brev(int i) {
+    int r = 0;
+    for (int b = 1; b < S; b <<= 1) {
+        r = (r << 1) | (i & 1);
+        i >>= 1;
+    }
+    return r;
+}
+
+// In-register radix-2 DIT.  Input in bit-reversed slots, output in natural order.  Fully unrolled: every
+// index and twiddle is a compile-time constant, so re[]/im[] live in VGPRs.
+template <int S, bool INV>
+__device__ __forceinline__ void fft_inreg(float (&re)[S], float (&im)[S]) {
+#pragma unroll
+    for (int len = 2; len <= S; len <<= 1) {
+        const int hl = len >> 1;
+        const int tstep = 64 / len;
+#pragma unroll
+        for (int i = 0; i < S; i += len) {
+#pragma unroll
+            for (int j = 0; j < hl; ++j) {
+                const float wr = TW_RE[j * tstep];
+                const float wi = INV ? -TW_IM[j * tstep] : TW_IM[j * tstep];
+                const float xr = re[i + j + hl], xi = im[i + j + hl];
+                const float tr = wr * xr - wi * xi;
+                const float ti = wr * xi + wi * xr;
+                const float ur = re[i + j], ui = im[i + j];
+                re[i + j] = ur + tr;
+                im[i + j] = ui + ti;
+                re[i + j + hl] = ur - tr;
+                im[i + j + hl] = ui - ti;
+            }
+        }
+    }
+}
+
+template <int S, int CB>
+struct Lds {
+    static constexpr int WH = S / 2 + 1;
+    static constexpr int KSTRIDE = S * CB + (CB < 32 ? CB : 0);   // skew so that a 32-lane half never aliases banks
+    static constexpr int PLANE = WH * KSTRIDE;                     // floats per (re|im) plane
+    static constexpr size_t BYTES = 2ull * PLANE * sizeof(float);
+};
+
+// Y[n][ky][kx][c] = f(kx) * sum_{h,w} x[n][h][w][c] e^{-2 pi i (ky h + kx w)/S};  Re at channel c, Im at C + c.
+// f(kx) = scale for kx in {0, S/2}, scale * w_int otherwise.
+template <int S, int CB>
+__global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, float* __restrict__ Y, int C,
+                                                   float scale, float w_int) {
+    using L = Lds<S, CB>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Lre = lds;
+    float* Lim = lds + L::PLANE;
+    const int t = threadIdx.x;
+    const int c = t % CB, q = t / CB;          // q = h in pass 1, kx in pass 2   (q in [0, S))
+    const int n = blockIdx.y;
+    const int ch = blockIdx.x * CB + c;
+    const bool cok = ch < C;
+    float re[S], im[S];
+    // ---- pass 1: rows
+    {
+        const float* src = x + (((long)n * S + q) * S) * C + ch;
+#pragma unroll
+        for (int w = 0; w < S; ++w) {
+            re[brev<S>(w)] = cok ? src[(long)w * C] : 0.f;
+            im[brev<S>(w)] = 0.f;
+        }
+        fft_inreg<S, false>(re, im);
+#pragma unroll
+        for (int kx = 0; kx <= S / 2; ++kx) {
+            Lre[kx * L::KSTRIDE + q * CB + c] = re[kx];
+            Lim[kx * L::KSTRIDE + q * CB + c] = im[kx];
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: columns
+    if (q <= S / 2 && cok) {
+#pragma unroll
+        for (int h = 0; h < S; ++h) {
+            re[brev<S>(h)] = Lre[q * L::KSTRIDE + h * CB + c];
+            im[brev<S>(h)] = Lim[q * L::KSTRIDE + h * CB + c];
+        }
+        fft_inreg<S, false>(re, im);
+        const float f = (q == 0 || q == S / 2) ? scale : scale * w_int;
+        float* dst = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
+#pragma unroll
+        for (int ky = 0; ky < S; ++ky) {
+            dst[(long)ky * L::WH * 2 * C] = re[ky] * f;
+            dst[(long)ky * L::WH * 2 * C + C] = im[ky] * f;
+        }
+    }
+}
+
+// x[n][h][w][c] = scale * C2R( f(kx) * Y[n][ky][kx][c] )   with the Hermitian extension along kx
+template <int S, int CB>
+__global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y, float* __restrict__ x, int C,
+                                                    float scale, float w_int) {
+    using L = Lds<S, CB>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Lre = lds;
+    float* Lim = lds + L::PLANE;
+    const int t = threadIdx.x;
+    const int c = t % CB, q = t / CB;          // q = kx in pass 1, h in pass 2
+    const int n = blockIdx.y;
+    const int ch = blockIdx.x * CB + c;
+    const bool cok = ch < C;
+    float re[S], im[S];
+    // ---- pass 1: inverse transform along ky for each kept column kx
+    if (q <= S / 2) {
+        const float f = (q == 0 || q == S / 2) ? 1.f : w_int;
+        const float* src = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
+#pragma unroll
+        for (int ky = 0; ky < S; ++ky) {
+            re[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C] * f : 0.f;
+            im[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C + C] * f : 0.f;
+        }
+        fft_inreg<S, true>(re, im);
+#pragma unroll
+        for (int h = 0; h < S; ++h) {
+            Lre[q * L::KSTRIDE + h * CB + c] = re[h];
+            Lim[q * L::KSTRIDE + h * CB + c] = im[h];
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: Hermitian-extended inverse transform along kx, real part only
+    if (cok) {
+#pragma unroll
+        for (int kx = 0; kx <= S / 2; ++kx) {
+            const float zr = Lre[kx * L::KSTRIDE + q * CB + c];
+            const float zi = Lim[kx * L::KSTRIDE + q * CB + c];
+            re[brev<S>(kx)] = zr;
+            im[brev<S>(kx)] = (kx == 0 || kx == S / 2) ? 0.f : zi;   // c2r ignores these imaginary parts
+            if (kx > 0 && kx < S / 2) {
+                re[brev<S>(S - kx)] = zr;
+                im[brev<S>(S - kx)] = -zi;
+            }
+        }
+        fft_inreg<S, true>(re, im);
+        float* dst = x + (((long)n * S + q) * S) * C + ch;
+#pragma unroll
+        for (int w = 0; w < S; ++w) dst[(long)w * C] = re[w] * scale;
+    }
+}
+
+template <int S, int CB>
+int launch_rfft2(const float* x, float* Y, int N, int C, float scale, float w_int, hipStream_t s) {
+    using L = Lds<S, CB>;
+    static bool attr_set = false;
+    if (L::BYTES > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfft2_kernel<S, CB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
+    hipLaunchKernelGGL((rfft2_kernel<S, CB>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int S, int CB>
+int launch_irfft2(const float* Y, float* x, int N, int C, float scale, float w_int, hipStream_t s) {
+    using L = Lds<S, CB>;
+    static bool attr_set = false;
+    if (L::BYTES > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&irfft2_kernel<S, CB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
+    hipLaunchKernelGGL((irfft2_kernel<S, CB>), grid, dim3(NT), L::BYTES, s, Y, x, C, scale, w_int);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ud_rfft2(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, ud_stream_t stream) {
+    if (N < 1 || C < 1) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (S) {
+        case 8: return launch_rfft2<8, 64>(x, Y, N, C, scale, w_interior, s);
+        case 16: return launch_rfft2<16, 32>(x, Y, N, C, scale, w_interior, s);
+        case 32: return launch_rfft2<32, 16>(x, Y, N, C, scale, w_interior, s);
+        case 64: return launch_rfft2<64, 8>(x, Y, N, C, scale, w_interior, s);
+        default: return UD_EINVAL;
+    }
+}
+
+int ud_irfft2(const float* Y, float* x, int N, int S, int C, float scale, float w_interior, ud_stream_t stream) {
+    if (N < 1 || C < 1) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    switch (S) {
+        case 8: return launch_irfft2<8, 64>(Y, x, N, C, scale, w_interior, s);
+        case 16: return launch_irfft2<16, 32>(Y, x, N, C, scale, w_interior, s);
+        case 32: return launch_irfft2<32, 16>(Y, x, N, C, scale, w_interior, s);
+        case 64: return launch_irfft2<64, 8>(Y, x, N, C, scale, w_interior, s);
+        default: return UD_EINVAL;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,372 @@
+// fp32 GEMM / implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One kernel template serves every GEMM-shaped op of the UniDefense step (include/unidefense_hip.h,
+// ud_gemm): 1x1 convs incl. the spectral freq_conv (model/efficientnet/exp.py:57), dense 3x3 convs and
+// the transposed conv of the decoder (model/unidefense.py:59-102) as implicit GEMMs with a gather
+// loader, and all their data / weight gradients.
+//
+// Structure: 256 threads = 4 wave64; block tile BM x BN x 16; each wave owns TM x TN tiles of 32x32
+// (16 accumulator VGPRs each).  Operand tiles are staged global -> registers -> LDS in a K-MAJOR LDS
+// image  As[k][m], Bs[k][n]  whatever the global layout is, so the MFMA feed is the same conflict-free
+// ds_read_b32 pattern for all modes (lane l reads [k0 + (l>>5)][col0 + (l&31)]: each 32-lane half reads
+// 32 consecutive floats).  Register prefetch of tile t+1 overlaps the MFMAs of tile t; one barrier
+// per K-tile.  fp32 MFMA is exact f32 FMA chaining (k ascending), the same arithmetic as the reference's
+// fp32 path up to summation order.
+#include "ud_common.h"
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ void decode_row(const ud_conv_geom& g, int m, int M, int& nbase, int& ih0,
+                                           int& iw0, bool& valid) {
+    valid = m < M;
+    int mm = valid ? m : 0;
+    int ow = mm % g.Wout;
+    int t = mm / g.Wout;
+    int oh = t % g.Hout;
+    int n = t / g.Hout;
+    nbase = n * g.Hin * g.Win;
+    if (!g.transposed) {
+        ih0 = oh * g.stride - g.pad_t;
+        iw0 = ow * g.stride - g.pad_l;
+    } else {
+        ih0 = oh + g.pad_t;
+        iw0 = ow + g.pad_l;
+    }
+}
+
+// element offset of source pixel's channel 0, ok=false when the tap falls outside the input
+__device__ __forceinline__ long gather_pixel(const ud_conv_geom& g, int nbase, int ih0, int iw0, int kh,
+                                             int kw, bool& ok) {
+    int ih, iw;
+    if (!g.transposed) {
+        ih = ih0 + kh;
+        iw = iw0 + kw;
+        ok = (ih >= 0) && (ih < g.Hin) && (iw >= 0) && (iw < g.Win);
+    } else {
+        int th = ih0 - kh, tw = iw0 - kw;
+        ok = (th >= 0) && (tw >= 0) && (th % g.stride == 0) && (tw % g.stride == 0);
+        ih = th / g.stride;
+        iw = tw / g.stride;
+        ok = ok && (ih < g.Hin) && (iw < g.Win);
+    }
+    return ((long)nbase + (long)ih * g.Win + iw) * (long)g.Cin;
+}
+
+__device__ __forceinline__ f32x4 load4(const float* p, bool vec) {
+    f32x4 v;
+    if (vec) {
+        v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+        v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Operand tile loader.  MODE 0: [row][k] K-contiguous.  MODE 1: [k][row] row-contiguous.
+// MODE 2 (as A): conv gather, row = (n,oh,ow), k = (tap,ci)  -> K-contiguous inside a tap.
+// MODE 2 (as B, "BGATHER"): conv gather, k = (n,oh,ow), row(col) = (tap,ci) -> row-contiguous.
+// ROWS = BM or BN.  The loader keeps NV float4 per thread in registers.
+// ---------------------------------------------------------------------------------------------
+template <int ROWS, int MODE, bool IS_B>
+struct Loader {
+    static constexpr bool KCONTIG = (MODE == 0) || (MODE == 2 && !IS_B);
+    static constexpr int TOTAL_V = ROWS * BK / 4;                     // float4 in one tile
+    static constexpr int NV = (TOTAL_V + NTHREADS - 1) / NTHREADS;    // per thread
+    static constexpr int LDS_LD = ROWS + 4;
+
+    const float* base;
+    long ld;
+    int dim;        // number of valid rows (M or N)
+    int K;
+    bool vec;       // 16-byte loads allowed
+    ud_conv_geom g;
+    // per-thread cached gather state
+    int c_nbase[NV], c_ih0[NV], c_iw0[NV];
+    bool c_valid[NV];
+    int c_kh[NV], c_kw[NV], c_ci[NV];
+    f32x4 regs[NV];
+
+    __device__ __forceinline__ void init(const float* p, long ld_, int dim_, int K_, bool vec_,
+                                         const ud_conv_geom& g_, int row0, int tid) {
+        base = p; ld = ld_; dim = dim_; K = K_; vec = vec_; g = g_;
+        if constexpr (MODE == 2 && !IS_B) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                int f = tid + i * NTHREADS;
+                int row = f >> 2;
+                decode_row(g, row0 + row, dim, c_nbase[i], c_ih0[i], c_iw0[i], c_valid[i]);
+                c_valid[i] = c_valid[i] && (f < TOTAL_V);
+            }
+        }
+        if constexpr (MODE == 2 && IS_B) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                int f = tid + i * NTHREADS;
+                int nq = f % (ROWS / 4);
+                int col = row0 + nq * 4;
+                c_valid[i] = (col < dim) && (f < TOTAL_V);
+                int cc = c_valid[i] ? col : 0;
+                int tap = cc / g.Cin;
+                c_ci[i] = cc % g.Cin;
+                c_kh[i] = tap / g.KW;
+                c_kw[i] = tap % g.KW;
+            }
+        }
+    }
+
+    // issue the global loads of the tile whose first k is k0 (rows start at row0)
+    __device__ __forceinline__ void load(int row0, int k0, int k_end, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int f = tid + i * NTHREADS;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE == 0) {
+                int row = f >> 2, kq = f & 3;
+                int r = row0 + row, k = k0 + kq * 4;
+                if (f < TOTAL_V && r < dim && k < k_end) {
+                    const float* p = base + (long)r * ld + k;
+                    if (k + 3 < k_end) {
+                        v = load4(p, vec);
+                    } else {
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) if (k + e < k_end) v[e] = p[e];
+                    }
+                }
+            } else if constexpr (MODE == 1) {
+                int kr = f / (ROWS / 4), q = f % (ROWS / 4);
+                int k = k0 + kr, r = row0 + q * 4;
+                if (f < TOTAL_V && k < k_end && r < dim) {
+                    const float* p = base + (long)k * ld + r;
+                    if (r + 3 < dim) {
+                        v = load4(p, vec);
+                    } else {
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) if (r + e < dim) v[e] = p[e];
+                    }
+                }
+            } else if constexpr (MODE == 2 && !IS_B) {
+                int kq = f & 3;
+                int k = k0 + kq * 4;
+                if (c_valid[i] && k < k_end) {
+                    if (vec) {   // Cin % 4 == 0: the 4 k's share one tap
+                        int tap = k / g.Cin, ci = k % g.Cin;
+                        bool ok;
+                        long off = gather_pixel(g, c_nbase[i], c_ih0[i], c_iw0[i], tap / g.KW, tap % g.KW, ok);
+                        if (ok) v = *reinterpret_cast<const f32x4*>(base + off + ci);
+                    } else {
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                            int kk = k + e;
+                            if (kk < k_end) {
+                                int tap = kk / g.Cin, ci = kk % g.Cin;
+                                bool ok;
+                                long off = gather_pixel(g, c_nbase[i], c_ih0[i], c_iw0[i], tap / g.KW, tap % g.KW, ok);
+                                if (ok) v[e] = base[off + ci];
+                            }
+                        }
+                    }
+                }
+            } else {   // MODE 2 as B: k indexes pixels, columns index (tap, ci)
+                int kr = f / (ROWS / 4), q = f % (ROWS / 4);
+                int k = k0 + kr;
+                if (c_valid[i] && k < k_end) {
+                    int nbase, ih0, iw0; bool rv;
+                    decode_row(g, k, K, nbase, ih0, iw0, rv);
+                    if (vec) {
+                        bool ok;
+                        long off = gather_pixel(g, nbase, ih0, iw0, c_kh[i], c_kw[i], ok);
+                        if (ok) v = *reinterpret_cast<const f32x4*>(base + off + c_ci[i]);
+                    } else {
+                        int col = row0 + q * 4;
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) {
+                            int cc = col + e;
+                            if (cc < dim) {
+                                int tap = cc / g.Cin, ci = cc % g.Cin;
+                                bool ok;
+                                long off = gather_pixel(g, nbase, ih0, iw0, tap / g.KW, tap % g.KW, ok);
+                                if (ok) v[e] = base[off + ci];
+                            }
+                        }
+                    }
+                }
+            }
+            regs[i] = v;
+        }
+    }
+
+    // write the registers into the K-major LDS image  S[k][row]
+    __device__ __forceinline__ void store(float* S, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int f = tid + i * NTHREADS;
+            if (f < TOTAL_V) {
+                if constexpr (KCONTIG) {
+                    int row = f >> 2, kq = f & 3;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * LDS_LD + row] = regs[i][e];
+                } else {
+                    int kr = f / (ROWS / 4), q = f % (ROWS / 4);
+                    *reinterpret_cast<f32x4*>(&S[kr * LDS_LD + q * 4]) = regs[i];
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, int tiles_m, int a_vec, int b_vec) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+    static_assert(TM >= 1 && TN >= 1, "tile");
+    using LA = Loader<BM, AMODE, false>;
+    using LB = Loader<BN, BMODE, true>;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LA::LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LB::LDS_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y, bz = blockIdx.z;
+
+    // K range of this split
+    const int kt_total = (d.K + BK - 1) / BK;
+    const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
+    const int k_begin = split * kt_per * BK;
+    int k_end = k_begin + kt_per * BK;
+    if (k_end > d.K) k_end = d.K;
+    const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
+
+    const float* Ap = d.A + (long)bz * d.strideA;
+    const float* Bp = d.B + (long)bz * d.strideB;
+    float* Cp = d.C + (long)bz * d.strideC;
+
+    LA la; LB lb;
+    la.init(Ap, d.lda, d.M, d.K, a_vec != 0, d.g, m0, tid);
+    lb.init(Bp, d.ldb, d.N, d.K, b_vec != 0, d.g, n0, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nkt > 0) {
+        la.load(m0, k_begin, k_end, tid);
+        lb.load(n0, k_begin, k_end, tid);
+        la.store(As[0], tid);
+        lb.store(Bs[0], tid);
+    }
+    __syncthreads();
+
+    const int a_col = wm * (TM * 32) + l31;
+    const int b_col = wn * (TN * 32) + l31;
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1 < nkt);
+        if (more) {
+            la.load(m0, k_begin + (kt + 1) * BK, k_end, tid);
+            lb.load(n0, k_begin + (kt + 1) * BK, k_end, tid);
+        }
+        const float* Ab = As[cur];
+        const float* Bb = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ab[(kk + half) * LA::LDS_LD + a_col + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bb[(kk + half) * LB::LDS_LD + b_col + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            la.store(As[cur ^ 1], tid);
+            lb.store(Bs[cur ^ 1], tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (nkt == 0 && d.out_mode != 0) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < d.M && col < d.N) {
+                    float* p = Cp + (long)row * d.ldc + col;
+                    float v = acc[i][j][r];
+                    if (d.out_mode == 0) *p = v;
+                    else if (d.out_mode == 1) *p += v;
+                    else atomicAdd(p, v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
+int launch_cfg(const ud_gemm_desc& d, int a_vec, int b_vec, hipStream_t s) {
+    int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
+    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, (unsigned)d.batch);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, AMODE, BMODE>), grid, dim3(NTHREADS), 0, s, d, tiles_m,
+                       a_vec, b_vec);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int AMODE, int BMODE>
+int launch_modes(const ud_gemm_desc& d, int a_vec, int b_vec, hipStream_t s) {
+    if (d.N <= 32) return launch_cfg<256, 32, 4, 1, AMODE, BMODE>(d, a_vec, b_vec, s);
+    if (d.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, BMODE>(d, a_vec, b_vec, s);
+    return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(d, a_vec, b_vec, s);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
+    if (!dp) return UD_EINVAL;
+    ud_gemm_desc d = *dp;
+    if (d.M <= 0 || d.N <= 0 || d.K < 0 || d.split_k < 1 || d.batch < 1) return UD_EINVAL;
+    if (d.split_k > 1 && d.out_mode != 2) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    // vector-load eligibility
+    int a_vec = 0, b_vec = 0;
+    if (d.a_mode == 0) a_vec = aligned16(d.A) && d.lda % 4 == 0 && d.strideA % 4 == 0;
+    else if (d.a_mode == 1) a_vec = aligned16(d.A) && d.lda % 4 == 0 && d.strideA % 4 == 0;
+    else a_vec = aligned16(d.A) && d.g.Cin % 4 == 0;
+    if (d.b_mode == 0) b_vec = aligned16(d.B) && d.ldb % 4 == 0 && d.strideB % 4 == 0;
+    else if (d.b_mode == 1) b_vec = aligned16(d.B) && d.ldb % 4 == 0 && d.strideB % 4 == 0;
+    else b_vec = aligned16(d.B) && d.g.Cin % 4 == 0;
+    if (d.a_mode == 2 || d.b_mode == 2) {
+        const ud_conv_geom& g = d.g;
+        if (g.N <= 0 || g.Hin <= 0 || g.Win <= 0 || g.Cin <= 0 || g.Hout <= 0 || g.Wout <= 0 || g.KH <= 0 ||
+            g.KW <= 0 || g.stride <= 0)
+            return UD_EINVAL;
+        long rows = (long)g.N * g.Hout * g.Wout, cols = (long)g.KH * g.KW * g.Cin;
+        if (d.a_mode == 2 && (rows != d.M || cols != d.K)) return UD_EINVAL;
+        if (d.b_mode == 2 && (rows != d.K || cols != d.N)) return UD_EINVAL;
+    }
+    if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0>(d, a_vec, b_vec, s);
+    if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1>(d, a_vec, b_vec, s);
+    if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1>(d, a_vec, b_vec, s);
+    if (d.a_mode == 2 && d.b_mode == 0) return launch_modes<2, 0>(d, a_vec, b_vec, s);
+    if (d.a_mode == 1 && d.b_mode == 2) return launch_modes<1, 2>(d, a_vec, b_vec, s);
+    return UD_EINVAL;
+}

@@ -1,0 +1,36 @@
+// Shared helpers for the gfx950 kernels of libunidefense_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/unidefense_hip.h"
+
+#define UD_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return -(int)e__;            \
+    } while (0)
+
+static inline int ud_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float ud_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float ud_swish(float x) { return x * ud_sigmoid(x); }
+// d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))      (model/efficientnet/utils.py:73-77)
+__device__ __forceinline__ float ud_swish_grad(float x) {
+    float s = ud_sigmoid(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// wave64 all-reduce (sum) via DPP-free shuffles
+__device__ __forceinline__ float ud_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float ud_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,550 @@
+"""Thin launch wrappers over the C ABI (unidefense_amd.lib): allocate outputs as torch tensors on the
+current device and enqueue the HIP kernels on torch's current stream.  No autograd here, no math in
+torch — torch only owns device memory and the stream.
+
+Tensor convention: fp32, contiguous, pixel-major [N, H, W, C] (a row-major matrix [N*H*W, C]);
+image-domain 3-channel tensors are planes [N, 3, H, W].
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as _lib
+from .lib import ConvGeom, GemmDesc
+
+_call = _lib.call
+
+# when set to a list, every ud_gemm launch is bracketed by HIP events: (start, end, flops) tuples
+GEMM_PROFILE = None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError(f"expected a contiguous fp32 CUDA tensor, got {t.dtype} {t.device} "
+                             f"contiguous={t.is_contiguous()} shape={tuple(t.shape)}")
+
+
+def empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM family
+# ---------------------------------------------------------------------------------------------
+def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_k=1, geom=None,
+          batch=1, strideA=0, strideB=0, strideC=0, a_off=0, b_off=0):
+    d = GemmDesc()
+    d.A = A.data_ptr() + 4 * a_off
+    d.B = B.data_ptr() + 4 * b_off
+    d.C = Cout.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
+    d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
+    if geom is not None:
+        d.g = geom
+    if GEMM_PROFILE is not None:
+        # live HIP-event timing of the dominant kernel on the stream it is launched on (bench.py roofline)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("ud_gemm", C.byref(d), _stream())
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch))
+        return Cout
+    _call("ud_gemm", C.byref(d), _stream())
+    return Cout
+
+
+def gemm_nt(a, w, out=None, accumulate=False):
+    """out[M,N] (+)= a[M,K] @ w[N,K]^T     (1x1 conv / linear forward)"""
+    _chk(a, w)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = empty((M, N), a)
+    return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 1 if accumulate else 0)
+
+
+def gemm_nn(a, w, out=None, accumulate=False):
+    """out[M,N] (+)= a[M,K] @ w[K,N]       (data gradient of a 1x1 conv: dY @ W)"""
+    _chk(a, w)
+    M, K = a.shape
+    N = w.shape[1]
+    assert w.shape[0] == K
+    if out is None:
+        out = empty((M, N), a)
+    return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if accumulate else 0)
+
+
+def _pick_split(tiles, K):
+    """split-K factor for a weight-gradient GEMM whose reduction runs over K pixels."""
+    if tiles >= 512 or K < 1024:
+        return 1
+    s = min(max(1, K // 512), -(-768 // tiles))
+    return max(1, min(s, 256))
+
+
+def _tiles(M, N):
+    bn = 32 if N <= 32 else (64 if N <= 64 else 128)
+    bm = 256 if N <= 32 else 128
+    return -(-M // bm) * -(-N // bn)
+
+
+def gemm_tn(a, b):
+    """out[M,N] = a[K,M]^T @ b[K,N]        (weight gradient: dY^T @ X, reduction over pixels)"""
+    _chk(a, b)
+    K, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K
+    split = _pick_split(_tiles(M, N), K)
+    if split > 1:
+        out = torch.zeros((M, N), dtype=torch.float32, device=a.device)
+        return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 2, split)
+    out = empty((M, N), a)
+    return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 0, 1)
+
+
+def conv_geom(N, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_t, pad_l, transposed=0):
+    g = ConvGeom()
+    g.N, g.Hin, g.Win, g.Cin, g.Hout, g.Wout = N, Hin, Win, Cin, Hout, Wout
+    g.KH, g.KW, g.stride, g.pad_t, g.pad_l, g.transposed = KH, KW, stride, pad_t, pad_l, transposed
+    return g
+
+
+def conv_gather_nt(x, wmat, g):
+    """Implicit-GEMM conv: rows (n,oh,ow) x k=(tap,ci) gathered from x[N,Hin,Win,Cin]; wmat[Cout, KH*KW*Cin].
+    Returns [N, Hout, Wout, Cout]."""
+    _chk(x, wmat)
+    M = g.N * g.Hout * g.Wout
+    K = g.KH * g.KW * g.Cin
+    Co = wmat.shape[0]
+    assert wmat.shape[1] == K and x.numel() == g.N * g.Hin * g.Win * g.Cin
+    out = empty((g.N, g.Hout, g.Wout, Co), x)
+    _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, geom=g)
+    return out
+
+
+def conv_gather_wgrad(a, x, g):
+    """out[Ma, KH*KW*Cin] = a[(n,oh,ow), Ma]^T @ gather(x)[(n,oh,ow), (tap,ci)]."""
+    _chk(a, x)
+    Kdim = g.N * g.Hout * g.Wout
+    Ma = a.shape[-1]
+    assert a.numel() == Kdim * Ma
+    Ncols = g.KH * g.KW * g.Cin
+    split = _pick_split(_tiles(Ma, Ncols), Kdim)
+    if split > 1:
+        out = torch.zeros((Ma, Ncols), dtype=torch.float32, device=a.device)
+        return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2, split, geom=g)
+    out = empty((Ma, Ncols), a)
+    return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 0, 1, geom=g)
+
+
+# ---------------------------------------------------------------------------------------------
+# normalisation / column reductions
+# ---------------------------------------------------------------------------------------------
+def _chunks(G, R, Cc):
+    return _call("ud_reduce_chunks", G, R, Cc)
+
+
+def norm_stats(x2, G, R, eps, momentum=0.0, running_mean=None, running_var=None):
+    """x2: [G*R, C].  Returns (mean[G,C], invstd[G,C]); updates running stats in place when given."""
+    _chk(x2)
+    Cc = x2.shape[-1]
+    P = _chunks(G, R, Cc)
+    part = empty((2, G * P, Cc), x2)
+    mean = empty((G, Cc), x2)
+    invstd = empty((G, Cc), x2)
+    _call("ud_norm_stats", _p(x2), G, R, Cc, P, eps, _p(part[0]), _p(part[1]), _p(mean), _p(invstd), None,
+          momentum, _p(running_mean), _p(running_var), _stream())
+    return mean, invstd
+
+
+def norm_apply(x2, G, R, mean, invstd, gamma, beta, act):
+    _chk(x2, mean, invstd, gamma, beta)
+    y = torch.empty_like(x2)
+    _call("ud_norm_apply_fwd", _p(x2), G, R, x2.shape[-1], _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
+          _p(y), _stream())
+    return y
+
+
+def norm_bwd(x2, dy, G, R, mean, invstd, gamma, beta, act):
+    """Returns (dx, dgamma[C], dbeta[C])."""
+    _chk(x2, dy)
+    Cc = x2.shape[-1]
+    P = _chunks(G, R, Cc)
+    part = empty((2, G * P, Cc), x2)
+    s = empty((2, G, Cc), x2)
+    dg = empty((Cc,), x2)
+    db = empty((Cc,), x2)
+    dx = torch.empty_like(x2)
+    _call("ud_norm_bwd", _p(x2), _p(dy), G, R, Cc, P, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
+          _p(part[0]), _p(part[1]), _p(s[0]), _p(s[1]), _p(dg), _p(db), _p(dx), _stream())
+    return dx, dg, db
+
+
+def group_colsum(x2, G, R, scale):
+    _chk(x2)
+    Cc = x2.shape[-1]
+    P = _chunks(G, R, Cc)
+    part = empty((G * P, Cc), x2)
+    out = empty((G, Cc), x2)
+    _call("ud_group_colsum", _p(x2), G, R, Cc, P, scale, _p(part), _p(out), _stream())
+    return out
+
+
+def group_coldot(a2, b2, G, R, scale=1.0):
+    _chk(a2, b2)
+    Cc = a2.shape[-1]
+    P = _chunks(G, R, Cc)
+    part = empty((G * P, Cc), a2)
+    out = empty((G, Cc), a2)
+    _call("ud_group_coldot", _p(a2), _p(b2), G, R, Cc, P, scale, _p(part), _p(out), _stream())
+    return out
+
+
+def bcast_rows(g, HW, scale):
+    """g[N,C] -> out[N,HW,C] = g * scale."""
+    _chk(g)
+    N, Cc = g.shape
+    out = empty((N, HW, Cc), g)
+    _call("ud_bcast_rows", _p(g), scale, _p(out), N, HW, Cc, _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# depthwise conv
+# ---------------------------------------------------------------------------------------------
+def dwconv_fwd(x, wt, K, stride, pad_t, pad_l, Ho, Wo):
+    _chk(x, wt)
+    N, H, W, Cc = x.shape
+    y = empty((N, Ho, Wo, Cc), x)
+    _call("ud_dwconv_fwd", _p(x), _p(wt), _p(y), N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+    return y
+
+
+def dwconv_bwd_data(dy, wt, K, stride, pad_t, pad_l, H, W):
+    _chk(dy, wt)
+    N, Ho, Wo, Cc = dy.shape
+    dx = empty((N, H, W, Cc), dy)
+    _call("ud_dwconv_bwd_data", _p(dy), _p(wt), _p(dx), N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+    return dx
+
+
+def dwconv_bwd_weight(x, dy, K, stride, pad_t, pad_l):
+    _chk(x, dy)
+    N, H, W, Cc = x.shape
+    _, Ho, Wo, _ = dy.shape
+    npix = N * Ho * Wo
+    slabs = -(-(Cc // 4) // 256)
+    chunks = max(1, min(npix // 64 if npix >= 64 else 1, max(1, 1024 // slabs)))
+    parts = _call("ud_dwconv_bwd_weight_parts", Cc, chunks)
+    part = empty((parts, K * K, Cc), x)
+    dwt = empty((K * K, Cc), x)
+    _call("ud_dwconv_bwd_weight", _p(x), _p(dy), _p(dwt), _p(part), chunks, N, H, W, Cc, Ho, Wo, K, stride, pad_t,
+          pad_l, _stream())
+    return dwt
+
+
+# ---------------------------------------------------------------------------------------------
+# FFT
+# ---------------------------------------------------------------------------------------------
+def rfft2(x, scale, w_interior=1.0):
+    """x[N,S,S,C] -> Y[N,S,S/2+1,2C] (Re | Im channel halves)."""
+    _chk(x)
+    N, S, S2, Cc = x.shape
+    assert S == S2
+    Y = empty((N, S, S // 2 + 1, 2 * Cc), x)
+    _call("ud_rfft2", _p(x), _p(Y), N, S, Cc, scale, w_interior, _stream())
+    return Y
+
+
+def irfft2(Y, scale, w_interior=1.0):
+    """Y[N,S,S/2+1,2C] -> x[N,S,S,C]."""
+    _chk(Y)
+    N, S, Wh, C2 = Y.shape
+    assert Wh == S // 2 + 1 and C2 % 2 == 0
+    x = empty((N, S, S, C2 // 2), Y)
+    _call("ud_irfft2", _p(Y), _p(x), N, S, C2 // 2, scale, w_interior, _stream())
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# small FC, SE, mixing, elementwise
+# ---------------------------------------------------------------------------------------------
+def fc_fwd(x, W, b, act_in=0):
+    _chk(x, W, b)
+    N, I = x.shape
+    O = W.shape[0]
+    y = empty((N, O), x)
+    _call("ud_fc_fwd", _p(x), _p(W), _p(b), _p(y), N, I, O, act_in, _stream())
+    return y
+
+
+def fc_bwd(dy, W, x, act_in=0, need_dx=True, need_db=True):
+    _chk(dy, W, x)
+    N, I = x.shape
+    O = W.shape[0]
+    dx = empty((N, I), x) if need_dx else None
+    dW = empty((O, I), x)
+    db = empty((O,), x) if need_db else None
+    _call("ud_fc_bwd", _p(dy), _p(W), _p(x), _p(dx), _p(dW), _p(db), N, I, O, act_in, _stream())
+    return dx, dW, db
+
+
+def se_scale_fwd(x, s):
+    _chk(x, s)
+    N, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    _call("ud_se_scale_fwd", _p(x), _p(s), _p(y), N, H * W, Cc, _stream())
+    return y
+
+
+def se_scale_bwd(dy, s, dpool):
+    _chk(dy, s, dpool)
+    N, H, W, Cc = dy.shape
+    dx = torch.empty_like(dy)
+    _call("ud_se_scale_bwd", _p(dy), _p(s), _p(dpool), _p(dx), N, H * W, Cc, _stream())
+    return dx
+
+
+def sigmoid_grad_mul_(s, v):
+    _chk(s, v)
+    _call("ud_sigmoid_grad_mul", _p(s), _p(v), v.numel(), _stream())
+    return v
+
+
+def sfmix_fwd(spat, freq, alpha, pool):
+    _chk(spat, freq, alpha)
+    N, Ho, Wo, Cc = spat.shape
+    y = torch.empty_like(spat)
+    _call("ud_sfmix_fwd", _p(spat), _p(freq), _p(alpha), _p(y), N, Ho, Wo, Cc, int(pool), _stream())
+    return y
+
+
+def sfmix_bwd(spat, freq, alpha, dy, pool):
+    _chk(spat, freq, alpha, dy)
+    N, Ho, Wo, Cc = spat.shape
+    nb = _call("ud_sfmix_blocks", N, Ho, Wo, Cc)
+    part = empty((nb,), spat)
+    dspat = torch.empty_like(spat)
+    dfreq = torch.empty_like(freq)
+    dalpha = empty((), spat)
+    _call("ud_sfmix_bwd", _p(spat), _p(freq), _p(alpha), _p(dy), _p(dspat), _p(dfreq), _p(part), _p(dalpha), N, Ho,
+          Wo, Cc, int(pool), _stream())
+    return dspat, dfreq, dalpha
+
+
+def gate_mix_fwd(p, q, alpha):
+    _chk(p, q, alpha)
+    y = torch.empty_like(p)
+    _call("ud_gate_mix_fwd", _p(p), _p(q), _p(alpha), _p(y), p.numel(), _stream())
+    return y
+
+
+def gate_mix_bwd(p, q, alpha, dy):
+    _chk(p, q, alpha, dy)
+    nb = _call("ud_gate_mix_blocks", p.numel())
+    part = empty((nb,), p)
+    dp = torch.empty_like(p)
+    dq = torch.empty_like(p)
+    dalpha = empty((), p)
+    _call("ud_gate_mix_bwd", _p(p), _p(q), _p(alpha), _p(dy), _p(dp), _p(dq), _p(part), _p(dalpha), p.numel(),
+          _stream())
+    return dp, dq, dalpha
+
+
+def residual(x, skip, keep=None, inv_keep=1.0):
+    """out = x * (keep[n] * inv_keep) + skip   (skip / keep may be None)."""
+    _chk(x, skip, keep)
+    out = torch.empty_like(x)
+    _call("ud_residual_fwd", _p(x), _p(skip), _p(keep), inv_keep, _p(out), x.numel(), x.numel() // x.shape[0],
+          _stream())
+    return out
+
+
+def axpby(a, alpha, b=None, beta=1.0, out=None):
+    _chk(a, b)
+    if out is None:
+        out = torch.empty_like(a)
+    _call("ud_axpby", _p(a), alpha, _p(b), beta, _p(out), a.numel(), _stream())
+    return out
+
+
+def mask_scale(x, mask, scale):
+    _chk(x, mask)
+    out = torch.empty_like(x)
+    _call("ud_mask_scale", _p(x), _p(mask), scale, _p(out), x.numel(), _stream())
+    return out
+
+
+def absdiff(a, b=None):
+    _chk(a, b)
+    out = torch.empty_like(a)
+    _call("ud_absdiff", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def pix_to_planes(x, tanh=False):
+    """[N,H,W,C] -> [N,C,H,W] (optionally through tanh)."""
+    _chk(x)
+    N, H, W, Cc = x.shape
+    out = empty((N, Cc, H, W), x)
+    _call("ud_pix_to_planes", _p(x), _p(out), N, Cc, H * W, 1 if tanh else 0, _stream())
+    return out
+
+
+def planes_to_pix(x, tanh_out=None):
+    """[N,C,H,W] -> [N,H,W,C]; with tanh_out (planes): multiply by (1 - tanh_out^2)."""
+    _chk(x, tanh_out)
+    N, Cc, H, W = x.shape
+    out = empty((N, H, W, Cc), x)
+    _call("ud_planes_to_pix", _p(x), _p(tanh_out), _p(out), N, Cc, H * W, 2 if tanh_out is not None else 0,
+          _stream())
+    return out
+
+
+def bilinear_fwd(x, Ho, Wo):
+    _chk(x)
+    N, Cc, Hi, Wi = x.shape
+    y = empty((N, Cc, Ho, Wo), x)
+    _call("ud_bilinear_fwd", _p(x), _p(y), N * Cc, Hi, Wi, Ho, Wo, _stream())
+    return y
+
+
+def bilinear_bwd(dy, Hi, Wi):
+    _chk(dy)
+    N, Cc, Ho, Wo = dy.shape
+    dx = empty((N, Cc, Hi, Wi), dy)
+    _call("ud_bilinear_bwd", _p(dy), _p(dx), N * Cc, Hi, Wi, Ho, Wo, _stream())
+    return dx
+
+
+def l1_fwd(a, b, scale):
+    """out[n] = scale * sum |a[n] - b[n]|"""
+    _chk(a, b)
+    N = a.shape[0]
+    per = a.numel() // N
+    P = _call("ud_l1_chunks", per)
+    part = empty((N, P), a)
+    out = empty((N,), a)
+    _call("ud_l1_fwd", _p(a), _p(b), _p(part), _p(out), N, per, scale, _stream())
+    return out
+
+
+def l1_bwd(a, b, g, scale, out=None):
+    """da (+)= g[n] * scale * sign(a - b)   (accumulates into `out` when given)."""
+    _chk(a, b, g, out)
+    N = a.shape[0]
+    acc = out is not None
+    if out is None:
+        out = torch.empty_like(a)
+    _call("ud_l1_bwd", _p(a), _p(b), _p(g), scale, 1 if acc else 0, _p(out), N, a.numel() // N, _stream())
+    return out
+
+
+def dynfilter_fwd(proj2, diff2, w2, x2):
+    _chk(proj2, diff2, w2, x2)
+    M, Cc = proj2.shape
+    D = diff2.shape[1]
+    Cx = x2.shape[1]
+    pre = empty((M, 2 + D), x2)
+    argmax = torch.empty((M,), dtype=torch.int32, device=x2.device)
+    mask = empty((M,), x2)
+    out = torch.empty_like(x2)
+    _call("ud_dynfilter_fwd", _p(proj2), _p(diff2), _p(w2), _p(x2), _p(pre), C.c_void_p(argmax.data_ptr()), _p(mask),
+          _p(out), M, Cc, D, Cx, _stream())
+    return out, mask, pre, argmax
+
+
+def dynfilter_bwd(dout2, dmask_ext, x2, mask, argmax, w2, Cproj):
+    _chk(dout2, dmask_ext, x2, mask, w2)
+    M, Cx = x2.shape
+    dx = torch.empty_like(x2)
+    dlogit = empty((M,), x2)
+    dproj = empty((M, Cproj), x2)
+    _call("ud_dynfilter_bwd", _p(dout2), _p(dmask_ext), _p(x2), _p(mask), C.c_void_p(argmax.data_ptr()), _p(w2),
+          _p(dx), _p(dlogit), _p(dproj), M, Cproj, Cx, _stream())
+    return dx, dlogit, dproj
+
+
+# ---------------------------------------------------------------------------------------------
+# Large-plane rfft2 (S >= 128) of [P, S, S] planes as three batched MFMA GEMMs against DFT matrices
+# (row transform, then the complex column transform as two real GEMMs).  Used for the 256x256 frequency
+# reconstruction loss (model/unidefense.py:246-253).
+# ---------------------------------------------------------------------------------------------
+_DFT_CACHE = {}
+
+
+def _dft_mats(S, device, ortho=True):
+    key = (S, str(device), ortho)
+    if key in _DFT_CACHE:
+        return _DFT_CACHE[key]
+    Wh = S // 2 + 1
+    Whp = -(-Wh // 4) * 4
+    s = 1.0 / math.sqrt(S) if ortho else 1.0
+    k = torch.arange(S, dtype=torch.float64)
+    ang = 2.0 * math.pi * torch.outer(k, k) / S          # [k][w]
+    cosm, sinm = torch.cos(ang) * s, torch.sin(ang) * s
+    fw_cos = torch.zeros(Whp, S, dtype=torch.float64)
+    fw_sin = torch.zeros(Whp, S, dtype=torch.float64)
+    fw_cos[:Wh] = cosm[:Wh]
+    fw_sin[:Wh] = -sinm[:Wh]                               # Im of e^{-i t} = -sin
+    # column transform on stacked [Re; Im]:  Yre = C Tre + S Tim ;  Yim = C Tim - S Tre
+    fh = torch.zeros(2 * S, 2 * S, dtype=torch.float64)
+    fh[:S, :S], fh[:S, S:] = cosm, sinm
+    fh[S:, :S], fh[S:, S:] = -sinm, cosm
+    mats = tuple(m.to(torch.float32).to(device).contiguous() for m in (fw_cos, fw_sin, fh))
+    _DFT_CACHE[key] = mats
+    return mats
+
+
+def dft_rfft2_planes(d, ortho=True):
+    """d: [P, S, S] real planes -> Y [P, 2S, Whp]: rows [0,S) = Re(ky), rows [S,2S) = Im(ky); columns
+    [0, S/2] valid, the rest zero padding (Whp = ceil4(S/2+1))."""
+    _chk(d)
+    P, S, _ = d.shape
+    fw_cos, fw_sin, fh = _dft_mats(S, d.device, ortho)
+    Whp = fw_cos.shape[0]
+    d2 = d.view(P * S, S)
+    t_re = gemm_nt(d2, fw_cos)                      # [P*S, Whp]
+    t_im = gemm_nt(d2, fw_sin)
+    Y = empty((P, 2 * S, Whp), d)
+    # Y_p = fh[:, :S] @ Tre_p + fh[:, S:] @ Tim_p     (batched over planes; A shared)
+    _gemm(fh, t_re, Y, 2 * S, Whp, S, 2 * S, Whp, Whp, 0, 1, 0, batch=P, strideA=0, strideB=S * Whp,
+          strideC=2 * S * Whp)
+    _gemm(fh, t_im, Y, 2 * S, Whp, S, 2 * S, Whp, Whp, 0, 1, 1, batch=P, strideA=0, strideB=S * Whp,
+          strideC=2 * S * Whp, a_off=S)
+    return Y
+
+
+def dft_rfft2_planes_adjoint(dY, S, ortho=True):
+    """Adjoint of dft_rfft2_planes: dY [P, 2S, Whp] -> dd [P, S, S]."""
+    _chk(dY)
+    P = dY.shape[0]
+    fw_cos, fw_sin, fh = _dft_mats(S, dY.device, ortho)
+    Whp = fw_cos.shape[0]
+    dt_re = empty((P * S, Whp), dY)
+    dt_im = empty((P * S, Whp), dY)
+    # dTre_p = fh[:, :S]^T @ dY_p ;  dTim_p = fh[:, S:]^T @ dY_p        (A[k][m] = fh[k][m(+S)])
+    _gemm(fh, dY, dt_re, S, Whp, 2 * S, 2 * S, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
+          strideC=S * Whp)
+    _gemm(fh, dY, dt_im, S, Whp, 2 * S, 2 * S, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
+          strideC=S * Whp, a_off=S)
+    dd = gemm_nn(dt_re, fw_cos)                     # [P*S, Whp] @ [Whp, S]
+    gemm_nn(dt_im, fw_sin, out=dd, accumulate=True)
+    return dd.view(P, S, S)

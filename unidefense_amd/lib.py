@@ -1,0 +1,119 @@
+"""ctypes binding of libunidefense_hip.so (the C ABI declared in include/unidefense_hip.h).
+
+The library is REQUIRED: importing this module without the built ``.so`` raises — there is no
+fallback path of any kind (no torch ops, no CPU code) behind the product's operators.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunidefense_hip.so")
+
+
+class UDLibraryError(RuntimeError):
+    pass
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "KH", "KW", "stride",
+                                       "pad_t", "pad_l", "transposed")]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_long), ("ldb", C.c_long), ("ldc", C.c_long),
+                ("a_mode", C.c_int), ("b_mode", C.c_int), ("out_mode", C.c_int), ("split_k", C.c_int),
+                ("batch", C.c_int), ("strideA", C.c_long), ("strideB", C.c_long), ("strideC", C.c_long),
+                ("g", ConvGeom)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+# name -> argtypes (the trailing stream argument included); every function returns int
+_SIGNATURES = {
+    "ud_gemm": [C.POINTER(GemmDesc), _P],
+    "ud_reduce_chunks": [_I, _I, _I],
+    "ud_norm_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "ud_norm_apply_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
+    "ud_norm_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ud_group_colsum": [_P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "ud_group_coldot": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "ud_dwconv_fwd": [_P, _P, _P] + [_I] * 10 + [_P],
+    "ud_dwconv_bwd_data": [_P, _P, _P] + [_I] * 10 + [_P],
+    "ud_dwconv_bwd_weight_parts": [_I, _I],
+    "ud_dwconv_bwd_weight": [_P, _P, _P, _P, _I] + [_I] * 10 + [_P],
+    "ud_rfft2": [_P, _P, _I, _I, _I, _F, _F, _P],
+    "ud_irfft2": [_P, _P, _I, _I, _I, _F, _F, _P],
+    "ud_fc_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ud_fc_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ud_se_scale_fwd": [_P, _P, _P, _I, _I, _I, _P],
+    "ud_se_scale_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "ud_sigmoid_grad_mul": [_P, _P, _L, _P],
+    "ud_sfmix_blocks": [_I, _I, _I, _I],
+    "ud_sfmix_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ud_sfmix_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ud_gate_mix_blocks": [_L],
+    "ud_gate_mix_fwd": [_P, _P, _P, _P, _L, _P],
+    "ud_gate_mix_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "ud_residual_fwd": [_P, _P, _P, _F, _P, _L, _L, _P],
+    "ud_axpby": [_P, _F, _P, _F, _P, _L, _P],
+    "ud_mask_scale": [_P, _P, _F, _P, _L, _P],
+    "ud_absdiff": [_P, _P, _P, _L, _P],
+    "ud_bcast_rows": [_P, _F, _P, _I, _I, _I, _P],
+    "ud_pix_to_planes": [_P, _P, _I, _I, _I, _I, _P],
+    "ud_planes_to_pix": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ud_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ud_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ud_l1_chunks": [_L],
+    "ud_l1_fwd": [_P, _P, _P, _P, _I, _L, _F, _P],
+    "ud_l1_bwd": [_P, _P, _P, _F, _I, _P, _I, _L, _P],
+    "ud_dynfilter_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ud_dynfilter_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+}
+
+# helpers that return a count rather than a status code
+_COUNT_FUNCS = {"ud_reduce_chunks", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+                "ud_l1_chunks"}
+
+EXPORTED = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises UDLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UDLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C unidefense_amd/csrc`. unidefense_amd has no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise UDLibraryError(f"{LIB_PATH} does not export {name}; rebuild it")
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(status: int, name: str):
+    if status != 0:
+        raise UDLibraryError(f"{name} failed with status {status}"
+                             + (" (invalid argument)" if status == -1000 else " (-hipError_t)"))
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point and raise on failure."""
+    fn = getattr(load(), name)
+    st = fn(*args)
+    if name in _COUNT_FUNCS:
+        if st < 0:
+            check(st, name)
+        return st
+    check(st, name)
+    return 0

@@ -1,0 +1,45 @@
+"""Asymmetrical weighted triplet loss on [N, d] feature vectors.
+
+Reference semantics: loss/triplet_loss.py:16-82.  The tensors are tiny (N = batch, d <= 1792); SURVEY.md
+K17 keeps these as device-side torch ops (latency-, not bandwidth-bound), so there is no HIP kernel behind
+this module — it is host logic around a handful of [N,N] ops.  Written with multiplicative masks instead
+of the reference's boolean gather + reshape, so it needs no host synchronisation (graph-capture safe) when
+``n_real`` is supplied; the value is identical whenever every anchor has at least one positive and one
+negative (the reference additionally requires equal counts per anchor for its reshape).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def pairwise_distance(x: torch.Tensor) -> torch.Tensor:
+    """sqrt(clamp(|xi|^2 + |xj|^2 - 2 xi.xj, 1e-12))  (loss/triplet_loss.py:16-30)."""
+    sq = (x * x).sum(dim=1, keepdim=True)
+    d2 = sq + sq.t() - 2.0 * torch.mm(x, x.t())
+    return d2.clamp(min=1e-12).sqrt()
+
+
+class AsymmetricalWeightedTripletLoss(nn.Module):
+    """Anchors are the real samples (label 0), which come first in the batch (loss/triplet_loss.py:46-53).
+    Per anchor: positives weighted by softmax(+d), negatives by softmax(-d); SoftMargin(wn - wp, +1)."""
+
+    def __init__(self):
+        super().__init__()
+        self.n_real = None      # optional: set by the engine (= sum_real) to avoid a device read-back
+
+    def forward(self, global_feat, labels, normalize_feature=False):
+        if normalize_feature:
+            global_feat = global_feat / (global_feat.norm(2, dim=-1, keepdim=True) + 1e-12)
+        n = global_feat.shape[0]
+        n_real = self.n_real if self.n_real is not None else int((labels == 0).sum().item())
+        dist = pairwise_distance(global_feat)[:n_real]                        # [R, N]
+        same = labels[:n_real].unsqueeze(1) == labels.unsqueeze(0)              # [R, N]
+        eye = torch.eye(n, dtype=torch.bool, device=labels.device)[:n_real]
+        pos = (same & ~eye).to(dist.dtype)
+        neg = (~same).to(dist.dtype)
+        e_ap = torch.exp(dist) * pos
+        e_an = torch.exp(-dist) * neg
+        wp = e_ap / (e_ap.sum(1, keepdim=True) + 1e-12)
+        wn = e_an / (e_an.sum(1, keepdim=True) + 1e-12)
+        margin = (wn * dist).sum(1) - (wp * dist).sum(1)
+        return F.soft_margin_loss(margin, torch.ones_like(margin))

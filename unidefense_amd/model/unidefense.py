@@ -1,0 +1,387 @@
+"""UniDefenseModelEb4 on the MI355X HIP kernels.
+
+Mirror of the reference's ``model/unidefense.py:28-256`` (class surface, constructor kwargs, forward
+signature and return dict, state-dict key names).  The torch.nn modules below are only PARAMETER
+CONTAINERS (they give the reference's key names, shapes and default initialisers); their ``forward`` is
+never called — all compute goes through ``unidefense_amd.tape`` operators, i.e. the hand-written HIP kernels.
+Internally every activation is pixel-major [N,H,W,C]; the public tensors keep the reference's NCHW shapes.
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from .. import tape as T
+from .arch import DELIMITER_DICT, build_arch
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (same attribute names as the reference => same state-dict keys)
+# ---------------------------------------------------------------------------------------------
+class _SFConvParams(nn.Conv2d):
+    """model/efficientnet/exp.py:7-44 (SFConv2dStaticSamePadding: weight + freq_conv + sf_coef)."""
+
+    def __init__(self, channels, k):
+        super().__init__(channels, channels, k, groups=channels, bias=False)
+        self.freq_conv = nn.Conv2d(channels * 2, channels * 2, kernel_size=1, bias=False)
+        self.sf_coef = nn.Parameter(torch.tensor(-10.0))
+
+
+class _MBConvParams(nn.Module):
+    """model/efficientnet/model.py:52-92."""
+
+    def __init__(self, spec, eps, momentum):
+        super().__init__()
+        self.spec = spec
+        if spec.expand != 1:
+            self._expand_conv = nn.Conv2d(spec.cin, spec.cexp, 1, bias=False)
+            self._bn0 = nn.BatchNorm2d(spec.cexp, momentum=momentum, eps=eps)
+        if spec.sf_norm is not None:
+            self._depthwise_conv = _SFConvParams(spec.cexp, spec.k)
+        else:
+            self._depthwise_conv = nn.Conv2d(spec.cexp, spec.cexp, spec.k, groups=spec.cexp, bias=False)
+        self._bn1 = nn.BatchNorm2d(spec.cexp, momentum=momentum, eps=eps)
+        self._se_reduce = nn.Conv2d(spec.cexp, spec.cse, 1)
+        self._se_expand = nn.Conv2d(spec.cse, spec.cexp, 1)
+        self._project_conv = nn.Conv2d(spec.cexp, spec.cout, 1, bias=False)
+        self._bn2 = nn.BatchNorm2d(spec.cout, momentum=momentum, eps=eps)
+
+
+class _Backbone(nn.Module):
+    """model/efficientnet/model.py:166-231 with include_top=False."""
+
+    def __init__(self, arch):
+        super().__init__()
+        eps, mom = arch["bn_eps"], arch["bn_momentum"]
+        self._conv_stem = nn.Conv2d(3, arch["stem"]["cout"], 3, stride=2, bias=False)
+        self._bn0 = nn.BatchNorm2d(arch["stem"]["cout"], momentum=mom, eps=eps)
+        self._blocks = nn.ModuleList([_MBConvParams(s, eps, mom) for s in arch["blocks"]])
+        self._conv_head = nn.Conv2d(arch["head"]["cin"], arch["head"]["cout"], 1, bias=False)
+        self._bn1 = nn.BatchNorm2d(arch["head"]["cout"], momentum=mom, eps=eps)
+
+
+class Classifier(nn.Module):
+    """model/modules.py:24-32."""
+
+    def __init__(self, depth=512, num_classes=2):
+        super().__init__()
+        self.fc = nn.Linear(depth, num_classes)
+        self.fc.weight.data.normal_(0, 0.01)
+        self.fc.bias.data.fill_(0.0)
+
+
+class _FilterParams(nn.Module):
+    """model/modules.py:79-89 / 108-118 (layer1 = conv + norm + act, layer2 = conv + sigmoid)."""
+
+    def __init__(self, cin, k, d_in, affine, bias):
+        super().__init__()
+        self.layer1 = nn.Sequential(nn.Conv2d(cin, cin, k, 1, k // 2, bias=bias), nn.BatchNorm2d(cin, affine=affine),
+                                    nn.Identity())
+        self.layer2 = nn.Sequential(nn.Conv2d(d_in, 1, 1, bias=bias), nn.Identity())
+
+
+def _decoder(cin, cout, affine, bias, last):
+    """model/unidefense.py:59-102: indices 0,1,3,4,6,7(,9) carry parameters."""
+    mods = [nn.Conv2d(cin, cout, 3, 1, 1, bias=bias), nn.InstanceNorm2d(cout, affine=affine), nn.Identity(),
+            nn.ConvTranspose2d(cout, cout, 3, 2, 1, output_padding=1, bias=bias),
+            nn.InstanceNorm2d(cout, affine=affine), nn.Identity(),
+            nn.Conv2d(cout, cout, 3, 1, 1, bias=bias), nn.InstanceNorm2d(cout, affine=affine), nn.Identity()]
+    if last:
+        mods += [nn.Conv2d(cout, 3, 3, 1, 1, bias=bias), nn.Identity()]
+    return nn.Sequential(*mods)
+
+
+# ---------------------------------------------------------------------------------------------
+# the single autograd node wrapping the taped HIP forward/backward
+# ---------------------------------------------------------------------------------------------
+_OUT_KEYS = ("cls_out", "rec", "factorization", "triplet0", "triplet1", "triplet2", "freq_mask", "spat_mask",
+             "spatial", "freq")
+
+
+class _NetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, rng, *params):
+        tape = T.Tape()
+        outs = model._run(x, tape, rng)
+        ctx.tape = tape
+        ctx.outs = outs
+        ctx.params = params
+        ctx.model = model
+        return tuple(outs[k] for k in _OUT_KEYS)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        tape, outs = ctx.tape, ctx.outs
+        for k, g in zip(_OUT_KEYS, gouts):
+            if g is not None:
+                tape.add_grad(outs[k], g.contiguous().to(torch.float32))
+        tape.backward()
+        grads = [tape.param_grads.get(p) if p.requires_grad else None for p in ctx.params]
+        sync = getattr(ctx.model, "_grad_sync", None)
+        if sync is not None:                       # data parallel: average over ranks (engine/parallel.py)
+            grads = sync(grads)
+        grads = tuple(grads)
+        ctx.tape = ctx.outs = ctx.model = None
+        return (None, None, None) + grads
+
+
+class UniDefenseModelEb4(nn.Module):
+    """UniDefense model with EfficientNet backbone (reference: model/unidefense.py:28-256)."""
+
+    path = "model/unidefense.py"
+
+    def __init__(self,
+                 extractor,
+                 extractor_weights: Optional[str] = None,
+                 bias: bool = False,
+                 drop_rate: float = 0.2,
+                 affine: bool = True,
+                 num_classes: int = 1,
+                 delimiter: Optional[List] = None,
+                 freq_norm: str = 'ortho',
+                 **kwargs):
+        super().__init__()
+        if bias or not affine:
+            raise NotImplementedError("the HIP path implements the reference's configs: bias=False, affine=True")
+        self.arch = build_arch(extractor, freq_norm, kwargs.pop("image_size", None))
+        if "drop_connect_rate" in kwargs:
+            self.arch["drop_connect_rate"] = kwargs.pop("drop_connect_rate")
+        for k_ in ("batch_norm_momentum", "batch_norm_epsilon"):
+            if k_ in kwargs:
+                v = kwargs.pop(k_)
+                if k_ == "batch_norm_momentum":
+                    self.arch["bn_momentum"] = 1 - v
+                else:
+                    self.arch["bn_eps"] = v
+        if kwargs:
+            raise TypeError(f"unsupported override params: {sorted(kwargs)}")
+        self.backbone = _Backbone(self.arch)
+        num_features = self.arch["head"]["cout"]
+        self.freq_norm = freq_norm
+        self.drop_rate = drop_rate
+
+        self.dec_block1 = _decoder(160, 80, affine, bias, False)
+        self.dec_block2 = _decoder(80, 40, affine, bias, False)
+        self.dec_block3 = _decoder(40, 20, affine, bias, True)
+
+        self.bottleneck = nn.BatchNorm1d(num_features)
+        self.bottleneck.bias.requires_grad_(False)
+        nn.init.constant_(self.bottleneck.weight, 1.0)
+        nn.init.constant_(self.bottleneck.bias, 0.0)
+
+        self.delimiter = delimiter or DELIMITER_DICT[extractor]
+        self.classifier = Classifier(num_features, num_classes)
+
+        att_depth = 272
+        self.freq_filter = _FilterParams(att_depth * 2, 1, 8, affine, bias)
+        self.spat_filter = _FilterParams(att_depth, 3, 5, affine, bias)
+        self.fuse_coef = nn.Parameter(torch.tensor(0.))
+
+        if extractor_weights is not None:
+            self.load_backbone_weights(extractor_weights)
+
+    # -- pretrained backbone (model/efficientnet/utils.py:589-634): missing sf_coef / freq_conv keys tolerated
+    def load_backbone_weights(self, path):
+        sd = torch.load(path, map_location="cpu")
+        sd.pop("_fc.weight", None)
+        sd.pop("_fc.bias", None)
+        ret = self.backbone.load_state_dict(sd, strict=False)
+        bad = [k for k in ret.missing_keys if "sf_coef" not in k and "freq_conv" not in k]
+        if bad or ret.unexpected_keys:
+            raise RuntimeError(f"pretrained weights mismatch: missing {bad}, unexpected {ret.unexpected_keys}")
+
+    def forward(self, x, pert_real_list=None, pert_fake_list=None, preserve_color=None, rng=None, **kwargs):
+        """Returns {'cls_out','rec','loss_dict'} like the reference (model/unidefense.py:174-256).
+        rng: optional dict of explicit keep-masks (NCHW-shaped like the reference's tensors):
+        'drop_connect' {block: [N]}, 'dec_keep' [N,160,h,w], 'emb_keep' [N,272,h,w], 'feat_keep' [N,F]."""
+        if self.training and pert_real_list is not None and pert_fake_list is not None:
+            from .perturb import perturb_input
+            x = perturb_input(x, pert_real_list, pert_fake_list, preserve_color)
+        if not x.is_cuda:
+            raise RuntimeError("unidefense_amd runs on the GPU only (no CPU path); move the model and input to cuda")
+        x = x.contiguous().to(torch.float32)
+        if self.training and torch.is_grad_enabled():
+            params = tuple(self.parameters())
+            vals = _NetFunction.apply(self, x, rng, *params)
+            outs = dict(zip(_OUT_KEYS, vals))
+        else:
+            with torch.no_grad():
+                outs = self._run(x, None, rng)
+        loss_dict = {
+            "factorization": outs["factorization"],
+            "triplet": [outs["triplet0"], outs["triplet1"], outs["triplet2"]],
+            "freq_mask": outs["freq_mask"].permute(0, 3, 1, 2),      # [N,h,w,1] -> [N,1,h,w]
+            "spat_mask": outs["spat_mask"].permute(0, 3, 1, 2),
+            "spatial": outs["spatial"],
+            "freq": outs["freq"],
+        }
+        return {"cls_out": outs["cls_out"], "rec": outs["rec"], "loss_dict": loss_dict}
+
+    # ---------------------------------------------------------------------------------------
+    def _bn(self, tape, x, bn, act):
+        training = self.training
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return T.batchnorm_act(tape, x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                               bn.momentum if bn.momentum is not None else 0.1, training, act)
+
+    def _mbconv(self, tape, x, blk, keep, keep_prob):
+        """MBConvBlock.forward (model/efficientnet/model.py:94-135)."""
+        sp = blk.spec
+        inp = x
+        if sp.expand != 1:
+            x = T.conv1x1(tape, x, blk._expand_conv.weight)
+            x = self._bn(tape, x, blk._bn0, 1)
+        dw = blk._depthwise_conv
+        if sp.sf_norm is not None:
+            x = T.sfconv_dw(tape, x, dw.weight, dw.freq_conv.weight, dw.sf_coef, sp.stride, sp.pad, sp.sf_norm)
+        else:
+            x = T.dwconv(tape, x, dw.weight, sp.stride, sp.pad)
+        x = self._bn(tape, x, blk._bn1, 1)
+        x = T.squeeze_excite(tape, x, blk._se_reduce.weight, blk._se_reduce.bias, blk._se_expand.weight,
+                             blk._se_expand.bias)
+        x = T.conv1x1(tape, x, blk._project_conv.weight)
+        x = self._bn(tape, x, blk._bn2, 0)
+        if sp.skip:
+            if self.training and keep is not None:
+                x = T.residual(tape, x, inp, keep, keep_prob)
+            else:
+                x = T.residual(tape, x, inp)
+        return x
+
+    def _blocks(self, tape, x, stage, rng):
+        """forward_backbone_block (model/unidefense.py:159-172)."""
+        start = self.delimiter[stage - 1] if stage > 0 else 0
+        end = self.delimiter[stage]
+        nblk = len(self.backbone._blocks)
+        rate0 = self.arch["drop_connect_rate"]
+        for idx in range(start, end):
+            rate = rate0 * float(idx) / nblk if rate0 else 0.0
+            keep = rng["drop_connect"].get(idx) if (self.training and rate) else None
+            x = self._mbconv(tape, x, self.backbone._blocks[idx], keep, 1.0 - rate)
+        return x
+
+    def _decoder(self, tape, x, dec, last):
+        x = T.conv_dense(tape, x, dec[0].weight, 1, 1, 1, x.shape[1], x.shape[2])
+        x = T.instancenorm_act(tape, x, dec[1].weight, dec[1].bias, dec[1].eps, 1)
+        x = T.conv_transpose_s2(tape, x, dec[3].weight)
+        x = T.instancenorm_act(tape, x, dec[4].weight, dec[4].bias, dec[4].eps, 1)
+        x = T.conv_dense(tape, x, dec[6].weight, 1, 1, 1, x.shape[1], x.shape[2])
+        x = T.instancenorm_act(tape, x, dec[7].weight, dec[7].bias, dec[7].eps, 1)
+        if last:
+            x = T.conv_dense(tape, x, dec[9].weight, 1, 1, 1, x.shape[1], x.shape[2])
+        return x
+
+    def _attention(self, tape, pred_planes, x_planes, emb, rng):
+        """UniDefenseModelEb4.attention (model/unidefense.py:125-157); pred/x carry no gradient."""
+        N, h, w, Cc = emb.shape
+        norm = self.freq_norm
+        pred = K.planes_to_pix(K.bilinear_fwd(pred_planes, h, w))       # [N,h,w,3]
+        xs = K.planes_to_pix(K.bilinear_fwd(x_planes, h, w))
+        sf, _ = T._fft_scales(h, norm)
+        freq_diff = K.absdiff(K.rfft2(pred, sf), K.rfft2(xs, sf))       # [N,h,w/2+1,6]
+        emb_freq = T.rfft2_cat(tape, emb, norm)                         # [N,h,w/2+1,2C]
+        ff = self.freq_filter
+        proj = T.conv1x1(tape, emb_freq, ff.layer1[0].weight)
+        proj = self._bn(tape, proj, ff.layer1[1], 1)
+        f_out, freq_mask = T.dynamic_filter(tape, emb_freq, proj, freq_diff, ff.layer2[0].weight)
+        freq_filtered = T.irfft2_split(tape, f_out, norm)
+
+        spat_diff = K.absdiff(pred, xs)                                  # [N,h,w,3]
+        sfm = self.spat_filter
+        proj = T.conv_dense(tape, emb, sfm.layer1[0].weight, 1, 1, 1, h, w)
+        proj = self._bn(tape, proj, sfm.layer1[1], 1)
+        s_out, spat_mask = T.dynamic_filter(tape, emb, proj, spat_diff, sfm.layer2[0].weight)
+
+        out = T.gate_mix(tape, s_out, freq_filtered, self.fuse_coef)
+        e = emb
+        if self.training and self.drop_rate > 0:
+            e = T.dropout_mask(tape, emb, self._keep_mask(rng, "emb_keep", emb, 1.0 - self.drop_rate), self.drop_rate)
+        out = T.add(tape, out, e)
+        return out, freq_mask, spat_mask
+
+    @staticmethod
+    def _to_pix_mask(m):
+        """NCHW keep-mask -> pixel-major."""
+        return m.permute(0, 2, 3, 1).contiguous() if m.dim() == 4 else m.contiguous()
+
+    def _prepare_rng(self, rng, n, device):
+        """Resolve the drop-connect keep vectors (given or freshly drawn); the dropout keep-masks are
+        resolved lazily by _keep_mask once the activation shapes are known."""
+        out = {"drop_connect": {}, "_given": rng or {}}
+        if not self.training:
+            return out
+        rate0 = self.arch["drop_connect_rate"]
+        nblk = len(self.arch["blocks"])
+        given = out["_given"].get("drop_connect", {})
+        for idx, b in enumerate(self.arch["blocks"]):
+            rate = rate0 * float(idx) / nblk if rate0 else 0.0
+            if b.skip and rate:
+                k_ = given.get(idx)
+                out["drop_connect"][idx] = (
+                    k_.to(device=device, dtype=torch.float32).contiguous() if k_ is not None
+                    else (torch.rand((n,), device=device) < 1.0 - rate).to(torch.float32))
+        return out
+
+    def _keep_mask(self, rng, name, like, keep_p):
+        """Keep-mask for a dropout site: the caller-supplied NCHW mask (converted) or a fresh Bernoulli draw."""
+        m = rng["_given"].get(name)
+        if m is not None:
+            m = self._to_pix_mask(m.to(device=like.device, dtype=torch.float32))
+            assert m.shape == like.shape, (name, tuple(m.shape), tuple(like.shape))
+            return m
+        return (torch.rand(like.shape, device=like.device) < keep_p).to(torch.float32)
+
+    def _run(self, x, tape, rng):
+        """The whole forward on HIP kernels.  x: [N,3,H,W] planes."""
+        N, _, H, W = x.shape
+        arch = self.arch
+        bb = self.backbone
+        st = arch["stem"]
+        pl, pr, pt, pb = st["pad"]
+        Ho = (H + pt + pb - 3) // 2 + 1
+        Wo = (W + pl + pr - 3) // 2 + 1
+        rng = self._prepare_rng(rng, N, x.device)
+
+        x_pix = K.planes_to_pix(x)                                       # [N,H,W,3]
+        h = T.conv_dense(tape, x_pix, bb._conv_stem.weight, 2, pt, pl, Ho, Wo, need_dx=False)
+        h = self._bn(tape, h, bb._bn0, 1)
+        x_b0 = self._blocks(tape, h, 0, rng)
+        x_b1 = self._blocks(tape, x_b0, 1, rng)
+        x_b2 = self._blocks(tape, x_b1, 2, rng)
+        x_b3 = self._blocks(tape, x_b2, 3, rng)
+        x_b4 = self._blocks(tape, x_b3, 4, rng)
+
+        d_in = x_b4
+        if self.training:                                                # F.dropout(x_b4, 0.2), unidefense.py:213
+            d_in = T.dropout_mask(tape, x_b4, self._keep_mask(rng, "dec_keep", x_b4, 0.8), 0.2)
+        dec1 = self._decoder(tape, d_in, self.dec_block1, False)
+        dec2 = self._decoder(tape, dec1, self.dec_block2, False)
+        dec3_pix = self._decoder(tape, dec2, self.dec_block3, True)
+        dec3 = T.tanh_to_planes(tape, dec3_pix)                          # [N,3,128,128]
+
+        x_b5 = self._blocks(tape, x_b4, 5, rng)
+        att, freq_mask, spat_mask = self._attention(tape, dec3, x, x_b5, rng)
+        h = self._blocks(tape, att, 6, rng)
+
+        h = T.conv1x1(tape, h, bb._conv_head.weight)
+        h = self._bn(tape, h, bb._bn1, 1)
+        feat = T.mean_hw(tape, h)                                        # [N,1792]
+        feat = self._bn(tape, feat, self.bottleneck, 0)
+        if self.training and self.drop_rate > 0:
+            # in-place dropout in the reference: 'factorization' aliases the dropped tensor (:229-230)
+            feat = T.dropout_mask(tape, feat, self._keep_mask(rng, "feat_keep", feat, 1.0 - self.drop_rate),
+                                  self.drop_rate)
+        cls_out = T.linear(tape, feat, self.classifier.fc.weight, self.classifier.fc.bias)
+
+        t0 = T.mean_hw(tape, x_b4)
+        t1 = T.mean_hw(tape, dec1)
+        t2 = T.mean_hw(tape, dec2)
+
+        rec = T.bilinear(tape, dec3, H, W)
+        spatial, freq = T.rec_losses(tape, rec, x, self.freq_norm)
+        return {"cls_out": cls_out, "rec": rec, "factorization": feat, "triplet0": t0, "triplet1": t1,
+                "triplet2": t2, "freq_mask": freq_mask, "spat_mask": spat_mask,
+                "spatial": spatial, "freq": freq,
+                "_feats": {"x_b4": x_b4, "x_b5": x_b5, "dec1": dec1, "dec2": dec2, "dec3": dec3}}

@@ -1,0 +1,482 @@
+"""Reverse-mode tape + differentiable operators of the UniDefense hot path, built on the HIP kernels.
+
+The whole network is ONE node in torch's autograd graph (``model.unidefense._NetFunction``): its forward
+runs these operators while recording backward closures on a ``Tape``; its backward replays the tape in
+reverse.  Compared with ~2000 ``torch.autograd.Function`` nodes per step this keeps the host path short
+and gives the executor full control over buffer lifetime and gradient accumulation.
+
+Every operator takes pixel-major fp32 CUDA tensors (see kernels.py) and cites the reference op it replaces.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import kernels as K
+
+
+class Tape:
+    """Records backward closures; gradients are keyed by tensor identity."""
+
+    def __init__(self):
+        self.nodes = []
+        self.grads = {}
+        self.param_grads = {}
+        self._keep = []          # keep keyed tensors alive so ids stay unique
+
+    # -- recording -------------------------------------------------------------------------
+    def record(self, fn):
+        self.nodes.append(fn)
+
+    def add_grad(self, t: torch.Tensor, g: torch.Tensor):
+        """Accumulate g into the gradient slot of activation t (functional: never mutates g)."""
+        k = id(t)
+        cur = self.grads.get(k)
+        if cur is None:
+            self.grads[k] = g
+            self._keep.append(t)
+        else:
+            self.grads[k] = K.axpby(cur, 1.0, g.reshape(cur.shape), 1.0)
+
+    def pop_grad(self, t: torch.Tensor) -> Optional[torch.Tensor]:
+        return self.grads.pop(id(t), None)
+
+    def add_param_grad(self, p, g: torch.Tensor):
+        cur = self.param_grads.get(p)
+        g = g.reshape(p.shape)
+        self.param_grads[p] = g if cur is None else K.axpby(cur, 1.0, g, 1.0)
+
+    # -- replay ----------------------------------------------------------------------------
+    def backward(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes = []
+        self.grads = {}
+        self._keep = []
+
+
+def _needs(tape):
+    return tape is not None
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM-shaped ops
+# ---------------------------------------------------------------------------------------------
+def conv1x1(tape, x, w, need_dx=True):
+    """F.conv2d with a [Cout,Cin,1,1] weight on pixel-major x[...,Cin] (model/efficientnet/model.py:108,125;
+    exp.py:57; model/modules.py:82).  Backward = convolution_backward: dX = dY W, dW = dY^T X."""
+    Co, Ci = w.shape[0], w.shape[1]
+    w2 = w.view(Co, Ci)
+    x2 = x.view(-1, Ci)
+    y = K.gemm_nt(x2, w2).view(*x.shape[:-1], Co)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dy2 = dy.view(-1, Co)
+            if need_dx:
+                tape.add_grad(x, K.gemm_nn(dy2, w2).view(x.shape))
+            tape.add_param_grad(w, K.gemm_tn(dy2, x2))
+        tape.record(bwd)
+    return y
+
+
+def conv_dense(tape, x, w, stride, pad_t, pad_l, Hout, Wout, need_dx=True):
+    """Dense k x k F.conv2d (weight [Cout,Cin,kh,kw]) as an implicit GEMM (model/unidefense.py:60,67,...;
+    model/modules.py:111; stem conv model/efficientnet/model.py:185 with its static asymmetric pad)."""
+    N, Hin, Win, Ci = x.shape
+    Co, _, KH, KW = w.shape
+    g = K.conv_geom(N, Hin, Win, Ci, Hout, Wout, KH, KW, stride, pad_t, pad_l, 0)
+    wmat = w.permute(0, 2, 3, 1).reshape(Co, KH * KW * Ci).contiguous()
+    y = K.conv_gather_nt(x, wmat, g)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            if need_dx:
+                assert stride == 1 and Hout == Hin and Wout == Win, "data gradient implemented for stride 1 'same'"
+                # dX = conv(dY, W flipped & transposed), pad = k-1-pad
+                wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, KH * KW * Co).contiguous()
+                gd = K.conv_geom(N, Hout, Wout, Co, Hin, Win, KH, KW, 1, KH - 1 - pad_t, KW - 1 - pad_l, 0)
+                tape.add_grad(x, K.conv_gather_nt(dy, wd, gd))
+            dw = K.conv_gather_wgrad(dy.view(-1, Co), x, g)            # [Co, KH*KW*Ci]
+            tape.add_param_grad(w, dw.view(Co, KH, KW, Ci).permute(0, 3, 1, 2).contiguous())
+        tape.record(bwd)
+    return y
+
+
+def conv_transpose_s2(tape, x, w):
+    """nn.ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1), weight [Cin,Cout,3,3]
+    (model/unidefense.py:63-64,77-78,91-92)."""
+    N, H, W, Ci = x.shape
+    _, Co, KH, KW = w.shape
+    Ho, Wo = 2 * H, 2 * W
+    g = K.conv_geom(N, H, W, Ci, Ho, Wo, KH, KW, 2, 1, 1, 1)
+    wmat = w.permute(1, 2, 3, 0).reshape(Co, KH * KW * Ci).contiguous()
+    y = K.conv_gather_nt(x, wmat, g)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            # dX[n,ih,iw,ci] = sum dY[n,2ih-1+kh,2iw-1+kw,co] W[ci,co,kh,kw]: a stride-2 conv over dY
+            gd = K.conv_geom(N, Ho, Wo, Co, H, W, KH, KW, 2, 1, 1, 0)
+            wd = w.permute(0, 2, 3, 1).reshape(Ci, KH * KW * Co).contiguous()
+            tape.add_grad(x, K.conv_gather_nt(dy, wd, gd))
+            dw = K.conv_gather_wgrad(x.view(-1, Ci), dy, gd)           # [Ci, KH*KW*Co]
+            tape.add_param_grad(w, dw.view(Ci, KH, KW, Co).permute(0, 3, 1, 2).contiguous())
+        tape.record(bwd)
+    return y
+
+
+def linear(tape, x, w, b):
+    """nn.Linear (model/modules.py:27,31)."""
+    y = K.fc_fwd(x, w, b, 0)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dx, dW, db = K.fc_bwd(dy, w, x, 0)
+            tape.add_grad(x, dx)
+            tape.add_param_grad(w, dW)
+            tape.add_param_grad(b, db)
+        tape.record(bwd)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# depthwise conv, FFT, SFConv
+# ---------------------------------------------------------------------------------------------
+def dwconv(tape, x, w, stride, pad):
+    """Depthwise Conv2dStaticSamePadding (model/efficientnet/utils.py:277-280; exp.py:49-51).
+    pad = (left, right, top, bottom) as in nn.ZeroPad2d."""
+    N, H, W, Cc = x.shape
+    k = w.shape[-1]
+    pl, pr, pt, pb = pad
+    Ho = (H + pt + pb - k) // stride + 1
+    Wo = (W + pl + pr - k) // stride + 1
+    wt = w.view(Cc, k * k).t().contiguous()
+    y = K.dwconv_fwd(x, wt, k, stride, pt, pl, Ho, Wo)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(x, K.dwconv_bwd_data(dy, wt, k, stride, pt, pl, H, W))
+            dwt = K.dwconv_bwd_weight(x, dy, k, stride, pt, pl)
+            tape.add_param_grad(w, dwt.t().contiguous())
+        tape.record(bwd)
+    return y
+
+
+def _fft_scales(S, norm):
+    if norm == "ortho":
+        return 1.0 / S, 1.0 / S
+    if norm is None or norm == "backward":
+        return 1.0, 1.0 / (S * S)
+    raise ValueError(f"unsupported fft norm {norm!r}")
+
+
+def rfft2_cat(tape, x, norm):
+    """torch.fft.rfft2 + cat([re, im], channel)  (exp.py:55-56; unidefense.py:130-136)."""
+    S = x.shape[1]
+    sf, _ = _fft_scales(S, norm)
+    y = K.rfft2(x, sf, 1.0)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(x, K.irfft2(dy, sf, 0.5))
+        tape.record(bwd)
+    return y
+
+
+def irfft2_split(tape, y, norm):
+    """tensor_split + torch.complex + torch.fft.irfft2(s=(S,S))  (exp.py:59-60; unidefense.py:142-145)."""
+    S = y.shape[1]
+    _, si = _fft_scales(S, norm)
+    x = K.irfft2(y, si, 1.0)
+    if _needs(tape):
+        def bwd():
+            dx = tape.pop_grad(x)
+            if dx is None:
+                return
+            tape.add_grad(y, K.rfft2(dx, si, 2.0))
+        tape.record(bwd)
+    return x
+
+
+def sfmix(tape, spat, freq, alpha):
+    """(1 - sigmoid(a)) * spat + sigmoid(a) * [avg-pooled] freq  (exp.py:61-65)."""
+    pool = freq.shape[1] != spat.shape[1]
+    if pool:
+        assert freq.shape[1] == 2 * spat.shape[1] and freq.shape[2] == 2 * spat.shape[2]
+    y = K.sfmix_fwd(spat, freq, alpha, pool)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            ds, df, da = K.sfmix_bwd(spat, freq, alpha, dy, pool)
+            tape.add_grad(spat, ds)
+            tape.add_grad(freq, df)
+            tape.add_param_grad(alpha, da)
+        tape.record(bwd)
+    return y
+
+
+def sfconv_dw(tape, x, w, w_freq, alpha, stride, pad, norm):
+    """SFConv2dStaticSamePadding.forward (model/efficientnet/exp.py:46-65)."""
+    spat = dwconv(tape, x, w, stride, pad)
+    xf = rfft2_cat(tape, x, norm)
+    yf = conv1x1(tape, xf, w_freq)
+    fr = irfft2_split(tape, yf, norm)
+    return sfmix(tape, spat, fr, alpha)
+
+
+# ---------------------------------------------------------------------------------------------
+# normalisation + activation
+# ---------------------------------------------------------------------------------------------
+def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentum, training, act):
+    """nn.BatchNorm2d/1d (+ MemoryEfficientSwish when act=1) on pixel-major x[..., C]
+    (model/efficientnet/model.py:109-114,126; utils.py:66-82)."""
+    Cc = x.shape[-1]
+    x2 = x.view(-1, Cc)
+    R = x2.shape[0]
+    if training:
+        mean, invstd = K.norm_stats(x2, 1, R, eps, momentum, running_mean, running_var)
+    else:
+        mean = running_mean.view(1, Cc)
+        invstd = torch.rsqrt(running_var + eps).view(1, Cc)
+    y = K.norm_apply(x2, 1, R, mean, invstd, weight, bias, act).view(x.shape)
+    if _needs(tape):
+        if not training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
+
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
+            tape.add_grad(x, dx.view(x.shape))
+            tape.add_param_grad(weight, dg)
+            if bias.requires_grad:
+                tape.add_param_grad(bias, db)
+        tape.record(bwd)
+    return y
+
+
+def instancenorm_act(tape, x, weight, bias, eps, act):
+    """nn.InstanceNorm2d(affine=True) (+swish) on x[N,H,W,C]  (model/unidefense.py:61-70)."""
+    N, H, W, Cc = x.shape
+    x2 = x.view(-1, Cc)
+    mean, invstd = K.norm_stats(x2, N, H * W, eps)
+    y = K.norm_apply(x2, N, H * W, mean, invstd, weight, bias, act).view(x.shape)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), N, H * W, mean, invstd, weight, bias, act)
+            tape.add_grad(x, dx.view(x.shape))
+            tape.add_param_grad(weight, dg)
+            tape.add_param_grad(bias, db)
+        tape.record(bwd)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# pooling, SE, residual, dropout
+# ---------------------------------------------------------------------------------------------
+def mean_hw(tape, x):
+    """x.mean([-2,-1]) / adaptive_avg_pool2d(x, 1) -> [N, C]  (unidefense.py:226,232-236)."""
+    N, H, W, Cc = x.shape
+    y = K.group_colsum(x.view(-1, Cc), N, H * W, 1.0 / (H * W))
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(x, K.bcast_rows(dy, H * W, 1.0 / (H * W)).view(x.shape))
+        tape.record(bwd)
+    return y
+
+
+def squeeze_excite(tape, x, w_r, b_r, w_e, b_e):
+    """model/efficientnet/model.py:117-122."""
+    N, H, W, Cc = x.shape
+    Cs = w_r.shape[0]
+    wr2, we2 = w_r.view(Cs, Cc), w_e.view(Cc, Cs)
+    pool = K.group_colsum(x.view(-1, Cc), N, H * W, 1.0 / (H * W))
+    s1 = K.fc_fwd(pool, wr2, b_r, 0)
+    s2 = K.fc_fwd(s1, we2, b_e, 1)          # swish on the input side
+    y = K.se_scale_fwd(x, s2)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            ds2 = K.group_coldot(dy.view(-1, Cc), x.view(-1, Cc), N, H * W)
+            K.sigmoid_grad_mul_(s2, ds2)
+            ds1, dWe, dbe = K.fc_bwd(ds2, we2, s1, 1)
+            dpool, dWr, dbr = K.fc_bwd(ds1, wr2, pool, 0)
+            tape.add_grad(x, K.se_scale_bwd(dy, s2, dpool))
+            tape.add_param_grad(w_e, dWe)
+            tape.add_param_grad(b_e, dbe)
+            tape.add_param_grad(w_r, dWr)
+            tape.add_param_grad(b_r, dbr)
+        tape.record(bwd)
+    return y
+
+
+def residual(tape, x, skip, keep=None, keep_prob=1.0):
+    """drop_connect + skip: x / keep_prob * keep[n] + skip  (model.py:130-134; utils.py:131-156)."""
+    inv = 1.0 / keep_prob
+    y = K.residual(x, skip, keep, inv)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(skip, dy)
+            tape.add_grad(x, dy if keep is None else K.residual(dy, None, keep, inv))
+        tape.record(bwd)
+    return y
+
+
+def add(tape, a, b):
+    y = K.axpby(a, 1.0, b, 1.0)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(a, dy)
+            tape.add_grad(b, dy)
+        tape.record(bwd)
+    return y
+
+
+def dropout_mask(tape, x, keep, p):
+    """F.dropout with an explicit keep-mask: x * keep / (1 - p)."""
+    sc = 1.0 / (1.0 - p)
+    y = K.mask_scale(x, keep, sc)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(x, K.mask_scale(dy, keep, sc))
+        tape.record(bwd)
+    return y
+
+
+def gate_mix(tape, p, q, alpha):
+    """(1 - sigmoid(a)) p + sigmoid(a) q   (fuse_coef, model/unidefense.py:153-154)."""
+    y = K.gate_mix_fwd(p, q, alpha)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dp, dq, da = K.gate_mix_bwd(p, q, alpha, dy)
+            tape.add_grad(p, dp)
+            tape.add_grad(q, dq)
+            tape.add_param_grad(alpha, da)
+        tape.record(bwd)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# image-domain tail
+# ---------------------------------------------------------------------------------------------
+def tanh_to_planes(tape, x):
+    """nn.Tanh on [N,H,W,3] and move to planes [N,3,H,W]  (model/unidefense.py:101)."""
+    y = K.pix_to_planes(x, tanh=True)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(x, K.planes_to_pix(dy, tanh_out=y))
+        tape.record(bwd)
+    return y
+
+
+def bilinear(tape, x, Ho, Wo):
+    """F.interpolate(mode='bilinear', align_corners=True) on planes (model/unidefense.py:16,244)."""
+    Hi, Wi = x.shape[-2:]
+    y = K.bilinear_fwd(x, Ho, Wo)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(x, K.bilinear_bwd(dy, Hi, Wi))
+        tape.record(bwd)
+    return y
+
+
+def rec_losses(tape, rec, x, norm):
+    """spatial = mean|rec - x| ; freq = mean(|Re D| + |Im D|), D = rfft2(rec) - rfft2(x) = rfft2(rec - x)
+    (model/unidefense.py:245-253), per sample.  rec, x: planes [N,3,S,S].
+    `rec` itself is also a model output, so its external gradient is added in the same backward."""
+    N, Cc, S, _ = rec.shape
+    assert norm == "ortho", "frequency reconstruction loss implemented for freq_norm='ortho'"
+    cnt_s = Cc * S * S
+    Wh = S // 2 + 1
+    cnt_f = Cc * S * Wh
+    spatial = K.l1_fwd(rec, x, 1.0 / cnt_s)
+    d = K.axpby(rec, 1.0, x, -1.0)
+    Y = K.dft_rfft2_planes(d.view(N * Cc, S, S))            # zero padding columns contribute |0| = 0
+    freq = K.l1_fwd(Y.view(N, -1), None, 1.0 / cnt_f)
+    if _needs(tape):
+        def bwd():
+            gs = tape.pop_grad(spatial)
+            gf = tape.pop_grad(freq)
+            grec = tape.pop_grad(rec)
+            if gs is None and gf is None and grec is None:
+                return
+            total = None
+            if gf is not None:
+                dY = K.l1_bwd(Y.view(N, -1), None, gf, 1.0 / cnt_f).view(Y.shape)
+                total = K.dft_rfft2_planes_adjoint(dY, S).view(rec.shape)
+            if gs is not None:
+                total = K.l1_bwd(rec, x, gs, 1.0 / cnt_s, out=total)
+            if grec is not None:
+                total = grec if total is None else K.axpby(total, 1.0, grec, 1.0)
+            tape.grads[id(rec)] = total      # hand the summed gradient to rec's producer
+            tape._keep.append(rec)
+        tape.record(bwd)
+    return spatial, freq
+
+
+def dynamic_filter(tape, x, proj, diff, w2):
+    """mask = sigmoid(conv1x1([mean_c proj, max_c proj, diff])), out = mask * x
+    (model/modules.py:94-104, 123-133).  x, proj: [N,h,w,*]; diff: [N,h,w,D] (no grad); w2: [1,2+D,1,1]."""
+    Cx, Cp, D = x.shape[-1], proj.shape[-1], diff.shape[-1]
+    x2, p2, d2 = x.view(-1, Cx), proj.view(-1, Cp), diff.view(-1, D)
+    w2f = w2.view(-1)
+    out2, mask, pre, argmax = K.dynfilter_fwd(p2, d2, w2f, x2)
+    out = out2.view(x.shape)
+    mask4 = mask.view(*x.shape[:-1], 1)
+    if _needs(tape):
+        def bwd():
+            dout = tape.pop_grad(out)
+            dmask = tape.pop_grad(mask4)
+            if dout is None and dmask is None:
+                return
+            if dout is None:
+                dout = torch.zeros_like(out)
+            dx, dlogit, dproj = K.dynfilter_bwd(dout.view(-1, Cx), None if dmask is None else dmask.view(-1),
+                                                x2, mask, argmax, w2f, Cp)
+            tape.add_grad(x, dx.view(x.shape))
+            tape.add_grad(proj, dproj.view(proj.shape))
+            # dw2[j] = sum_m dlogit[m] * pre[m][j]   (8 or 5 numbers)
+            tape.add_param_grad(w2, K.gemm_tn(dlogit.view(-1, 1), pre).view(w2.shape))
+        tape.record(bwd)
+    return out, mask4
