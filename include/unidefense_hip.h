@@ -9,10 +9,14 @@
  * Conventions
  *   - every tensor is fp32, contiguous, "pixel-major" (NHWC): [N][H][W][C], i.e. a row-major
  *     matrix [M = N*H*W][C]; image-domain tensors with C = 3 are planes [N*C][H][W] (NCHW).
- *   - plain pointers + sizes; the caller owns every buffer (no allocation, no sync inside).
- *   - all work is enqueued on `stream` (a hipStream_t passed as void*); functions are
- *     graph-capture safe.  Return 0 on success, a negative hipError_t on launch failure,
- *     UD_EINVAL (-1000) on invalid arguments.
+ *     "[G][R][C]" below means G groups of R rows (G = 1: batch norm; G = N, R = H*W: per sample).
+ *   - plain pointers + sizes; the caller owns every buffer, including the scratch buffers
+ *     ("part*") whose sizes the *_chunks / *_parts / *_blocks helpers return.  No allocation, no
+ *     host synchronisation inside: every function only enqueues kernels on `stream` (a hipStream_t
+ *     passed as void*) and is safe to capture into a hipGraph.
+ *   - return 0 on success, a negative hipError_t on launch failure, UD_EINVAL on invalid arguments
+ *     (the helpers return a non-negative count).
+ *   - act / act_in: 0 = identity, 1 = swish x*sigmoid(x) (model/efficientnet/utils.py:66-82).
  */
 #ifndef UNIDEFENSE_HIP_H
 #define UNIDEFENSE_HIP_H
@@ -43,10 +47,12 @@ typedef struct {
  * b_mode 0: B[n][k] at B + n*ldb + k          (weights [Cout][K])
  *        1: B[k][n] at B + k*ldb + n          (weights for the data gradient, X for the weight gradient)
  *        2: conv gather with k = (n,oh,ow) and n = (kh*KW+kw)*Cin + ci        (weight gradient of a conv)
- * out_mode 0: store, 1: C += result, 2: atomicAdd (used when split_k > 1; C must be pre-zeroed)
+ * supported (a_mode, b_mode): (0,0) (0,1) (1,1) (2,0) (1,2).
+ * out_mode 0: store, 1: C += result, 2: atomicAdd (required when split_k > 1; C must be pre-zeroed)
  * Serves: F.conv2d 1x1 in model/efficientnet/model.py:108,125 and exp.py:57 (freq_conv),
  *         nn.Conv2d 3x3 / nn.ConvTranspose2d in model/unidefense.py:59-102, model/modules.py:82,111,
- *         nn.Linear in model/modules.py:27, and their autograd backward (convolution_backward). */
+ *         the stem conv model/efficientnet/model.py:185, torch.fft.rfft2 at 256x256 (as DFT-matrix
+ *         GEMMs, model/unidefense.py:246-249), and their autograd backward (convolution_backward). */
 typedef struct {
     const float* A; const float* B; float* C;
     int M, N, K;
@@ -56,6 +62,132 @@ typedef struct {
     ud_conv_geom g;
 } ud_gemm_desc;
 int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
+
+/* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------
+ * P = ud_reduce_chunks(G, R, C) row-chunks per group; part buffers hold G*P*C DOUBLES each (fp64 accumulation).
+ * Serves nn.BatchNorm2d/1d in training mode (model/efficientnet/model.py:67,77,91,186,222;
+ * model/unidefense.py:104; model/modules.py:83,112), nn.InstanceNorm2d (model/unidefense.py:54),
+ * MemoryEfficientSwish (utils.py:66-82), adaptive_avg_pool2d(x,1) / mean([-2,-1]). */
+int ud_reduce_chunks(int G, int R, int C);
+/* mean[G][C], invstd[G][C] = 1/sqrt(biased var + eps); var_out optional; when running_mean != NULL and
+ * G == 1 the running statistics are updated in place (momentum, unbiased variance) like nn.BatchNorm. */
+int ud_norm_stats(const float* x, int G, int R, int C, int P, float eps, double* part1, double* part2,
+                  float* mean, float* invstd, float* var_out, float momentum, float* running_mean,
+                  float* running_var, ud_stream_t stream);
+/* y = act(gamma * (x - mean[g]) * invstd[g] + beta) */
+int ud_norm_apply_fwd(const float* x, int G, int R, int C, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int act, float* y, ud_stream_t stream);
+/* dz = dy * act'(z); s1 = sum dz, s2 = sum dz*xhat per (g,c); dgamma = sum_g s2, dbeta = sum_g s1;
+ * dx = gamma*invstd*(dz - s1/R - xhat*s2/R)   (dx may be NULL: reductions only) */
+int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, int P, const float* mean,
+                const float* invstd, const float* gamma, const float* beta, int act, double* part1,
+                double* part2, float* s1, float* s2, float* dgamma, float* dbeta, float* dx,
+                ud_stream_t stream);
+/* the elementwise half of ud_norm_bwd with caller-provided sums (already all-reduced over the ranks) and
+ * inv_count = 1 / (rows of all ranks): SyncBatchNorm backward (engine/forgery_engine.py:142) */
+int ud_norm_bwd_apply(const float* x, const float* dy, int G, int R, int C, const float* mean,
+                      const float* invstd, const float* gamma, const float* beta, const float* s1,
+                      const float* s2, float inv_count, int act, float* dx, ud_stream_t stream);
+/* out[g][c] = scale * sum_r x[g][r][c] ;  out[g][c] = scale * sum_r a*b */
+int ud_group_colsum(const float* x, int G, int R, int C, int P, float scale, double* part1, float* out,
+                    ud_stream_t stream);
+int ud_group_coldot(const float* a, const float* b, int G, int R, int C, int P, float scale, double* part1,
+                    float* out, ud_stream_t stream);
+/* out[n][p][c] = g[n][c] * scale   (gradient of the mean over the HW rows) */
+int ud_bcast_rows(const float* g, float scale, float* out, int N, int HW, int C, ud_stream_t stream);
+
+/* ---- depthwise k x k conv, k in {3,5}, stride in {1,2}; weights tap-major wt[k*k][C] ------------
+ * Serves the depthwise Conv2dStaticSamePadding / the spatial branch of SFConv2dStaticSamePadding
+ * (model/efficientnet/utils.py:277-280, exp.py:49-51); pad_t/pad_l = top/left of the static ZeroPad2d. */
+int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W, int C, int Ho, int Wo,
+                  int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
+int ud_dwconv_bwd_data(const float* dy, const float* wt, float* dx, int N, int H, int W, int C, int Ho,
+                       int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
+int ud_dwconv_bwd_weight_parts(int C, int chunks);   /* rows of K*K*C floats that `part` must hold */
+int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* part, int chunks, int N,
+                         int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l,
+                         ud_stream_t stream);
+
+/* ---- batched real 2-D FFT, S x S planes, S in {8,16,32,64}, channel = lane --------------------
+ * ud_rfft2 : x[N][S][S][C] -> Y[N][S][S/2+1][2C]  (Re in channels [0,C), Im in [C,2C)),
+ *            Y = f(kx) * DFT2(x), f = scale for kx in {0,S/2}, scale*w_interior otherwise
+ * ud_irfft2: Y -> x = scale * C2R(f(kx) * Y), f = 1 / w_interior likewise
+ * torch.fft.rfft2/irfft2 (model/efficientnet/exp.py:55,60; model/unidefense.py:130-145):
+ *   forward rfft2 = (scale,1), its adjoint = ud_irfft2(scale, 0.5);
+ *   forward irfft2 = (scale,1), its adjoint = ud_rfft2(scale, 2). */
+int ud_rfft2(const float* x, float* Y, int N, int S, int C, float scale, float w_interior,
+             ud_stream_t stream);
+int ud_irfft2(const float* Y, float* x, int N, int S, int C, float scale, float w_interior,
+              ud_stream_t stream);
+
+/* ---- small FC: y[n][o] = sum_i act_in(x[n][i]) W[o][i] + b[o]  (SE 1x1 convs, classifier) ------
+ * model/efficientnet/model.py:119-121; model/modules.py:27.  Any of dx / dW / db may be NULL. */
+int ud_fc_fwd(const float* x, const float* W, const float* b, float* y, int N, int I, int O, int act_in,
+              ud_stream_t stream);
+int ud_fc_bwd(const float* dy, const float* W, const float* x, float* dx, float* dW, float* db, int N,
+              int I, int O, int act_in, ud_stream_t stream);
+
+/* ---- SE gating (model/efficientnet/model.py:122): y = x * sigmoid(s[n][c]);
+ *      dx = dy * sigmoid(s) + dpool[n][c] / HW;   v *= sigmoid'(s) */
+int ud_se_scale_fwd(const float* x, const float* s, float* y, int N, int HW, int C, ud_stream_t stream);
+int ud_se_scale_bwd(const float* dy, const float* s, const float* dpool, float* dx, int N, int HW, int C,
+                    ud_stream_t stream);
+int ud_sigmoid_grad_mul(const float* s, float* v, long n, ud_stream_t stream);
+
+/* ---- SFConv mixing (model/efficientnet/exp.py:61-65): y = (1-a) spat + a P(freq), a = sigmoid(*alpha),
+ *      P = identity or the 2x2 average pool (pool = 1: freq is [N][2Ho][2Wo][C]).
+ *      bwd: part holds ud_sfmix_blocks() DOUBLES; dalpha[0] = sigmoid'(alpha) * sum dy (P(freq) - spat) */
+int ud_sfmix_blocks(int N, int Ho, int Wo, int C);
+int ud_sfmix_fwd(const float* spat, const float* freq, const float* alpha, float* y, int N, int Ho, int Wo,
+                 int C, int pool, ud_stream_t stream);
+int ud_sfmix_bwd(const float* spat, const float* freq, const float* alpha, const float* dy, float* dspat,
+                 float* dfreq, double* part, float* dalpha, int N, int Ho, int Wo, int C, int pool,
+                 ud_stream_t stream);
+/* same for two equal-shape tensors (fuse_coef, model/unidefense.py:153-154) */
+int ud_gate_mix_blocks(long total);
+int ud_gate_mix_fwd(const float* p, const float* q, const float* alpha, float* y, long total,
+                    ud_stream_t stream);
+int ud_gate_mix_bwd(const float* p, const float* q, const float* alpha, const float* dy, float* dp, float* dq,
+                    double* part, float* dalpha, long total, ud_stream_t stream);
+
+/* ---- elementwise --------------------------------------------------------------------------------
+ * ud_residual_fwd: out = x * (keep[n] * inv_keep) + skip   (drop_connect + skip, model.py:130-134;
+ *                  skip / keep may be NULL)
+ * ud_axpby: out = alpha*a + beta*b (b may be NULL); ud_mask_scale: out = x*mask*scale (dropout by mask);
+ * ud_absdiff: out = |a - b| (b may be NULL) */
+int ud_residual_fwd(const float* x, const float* skip, const float* keep, float inv_keep, float* out,
+                    long total, long per_sample, ud_stream_t stream);
+int ud_axpby(const float* a, float alpha, const float* b, float beta, float* out, long total,
+             ud_stream_t stream);
+int ud_mask_scale(const float* x, const float* mask, float scale, float* out, long total,
+                  ud_stream_t stream);
+int ud_absdiff(const float* a, const float* b, float* out, long total, ud_stream_t stream);
+
+/* ---- layout + image-domain tail --------------------------------------------------------------------
+ * ud_pix_to_planes: [N][HW][C] -> [N][C][HW], mode 1 applies tanh (nn.Tanh, model/unidefense.py:101)
+ * ud_planes_to_pix: reverse; mode 2 multiplies by (1 - aux^2), aux = saved tanh output (planes)
+ * ud_bilinear_*   : F.interpolate(mode='bilinear', align_corners=True) on P planes (unidefense.py:16)
+ * ud_l1_*         : out[n] = scale * sum |a - b| per sample and its gradient g[n]*scale*sign(a-b)
+ *                   (torch.abs(...).mean(dim=[-3,-2,-1]), unidefense.py:245,251-253); b may be NULL */
+int ud_pix_to_planes(const float* in, float* out, int N, int C, int HW, int mode, ud_stream_t stream);
+int ud_planes_to_pix(const float* in, const float* aux, float* out, int N, int C, int HW, int mode,
+                     ud_stream_t stream);
+int ud_bilinear_fwd(const float* x, float* y, int P, int Hi, int Wi, int Ho, int Wo, ud_stream_t stream);
+int ud_bilinear_bwd(const float* dy, float* dx, int P, int Hi, int Wi, int Ho, int Wo, ud_stream_t stream);
+int ud_l1_chunks(long per_sample);
+int ud_l1_fwd(const float* a, const float* b, float* part, float* out, int N, long per_sample, float scale,
+              ud_stream_t stream);
+int ud_l1_bwd(const float* a, const float* b, const float* g, float scale, int accumulate, float* da, int N,
+              long per_sample, ud_stream_t stream);
+
+/* ---- dynamic-filter mask (model/modules.py:94-104, 123-133), rows m over pixels:
+ *      pre[m] = [mean_c proj, max_c proj, diff[m][0..D)], mask = sigmoid(w2 . pre), out = mask * x
+ *      bwd: dx = mask*dout; dlogit[m]; dproj[m][c] = dlogit*(w2[0]/C + w2[1]*[c == argmax]) */
+int ud_dynfilter_fwd(const float* proj, const float* diff, const float* w2, const float* x, float* pre,
+                     int* argmax, float* mask, float* out, int M, int C, int D, int Cx, ud_stream_t stream);
+int ud_dynfilter_bwd(const float* dout, const float* dmask_ext, const float* x, const float* mask,
+                     const int* argmax, const float* w2, float* dx, float* dlogit, float* dproj, int M,
+                     int C, int Cx, ud_stream_t stream);
 
 #ifdef __cplusplus
 }

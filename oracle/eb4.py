@@ -215,7 +215,7 @@ def dynamic_filter(x: Tensor, diff: Tensor, sd: Dict[str, Tensor], prefix: str, 
     p = swish(batch_norm(p, sd, prefix + ".layer1.1", training, 1e-5))
     pre = torch.cat([p.mean(1, keepdim=True), p.max(1, keepdim=True).values, diff], dim=1)
     mask = torch.sigmoid(F.conv2d(pre, sd[prefix + ".layer2.0.weight"]))
-    return {"mask": mask, "out": mask * x}
+    return {"mask": mask, "out": mask * x, "proj": p}
 
 
 def attention(pred: Tensor, x: Tensor, emb: Tensor, sd: Dict[str, Tensor], training: bool,
@@ -238,7 +238,12 @@ def attention(pred: Tensor, x: Tensor, emb: Tensor, sd: Dict[str, Tensor], train
         assert emb_keep is not None, "training with drop_rate>0 needs an explicit emb_keep mask"
         e = emb * emb_keep.to(emb.dtype) / (1.0 - drop_rate)
     out = out + e
-    return {"out": out, "freq_mask": ff["mask"], "spat_mask": sf["mask"]}
+
+    def top2_gap(p):   # torch.max's gradient is discontinuous where the two largest channels (nearly) tie
+        t = p.detach().topk(2, dim=1).values
+        return ((t[:, 0] - t[:, 1]) / t[:, 0].abs().clamp_min(1e-30)).min()
+    return {"out": out, "freq_mask": ff["mask"], "spat_mask": sf["mask"],
+            "max_gap": torch.minimum(top2_gap(ff["proj"]), top2_gap(sf["proj"]))}
 
 
 def forward_eb4(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_rate: float = 0.2,
@@ -290,12 +295,12 @@ def forward_eb4(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
     x_b5 = run(x_b4, delim[4], delim[5])
     att = attention(dec3.detach(), x, x_b5, sd, training, freq_norm,
                     rng.get("emb_keep"), drop_rate if rng.get("emb_keep") is not None else 0.0)
-    h = run(att["out"], delim[5], delim[6])
+    x_b6 = run(att["out"], delim[5], delim[6])
 
-    h = F.conv2d(h, sd["backbone._conv_head.weight"])
+    h = F.conv2d(x_b6, sd["backbone._conv_head.weight"])
     h = swish(batch_norm(h, sd, "backbone._bn1", training, eps))
-    h = h.mean((2, 3))
-    h = batch_norm(h, sd, "bottleneck", training, 1e-5)
+    pooled = h.mean((2, 3))
+    h = batch_norm(pooled, sd, "bottleneck", training, 1e-5)
     if training and rng.get("feat_keep") is not None:
         h = h * rng["feat_keep"].to(h.dtype) / (1.0 - drop_rate)   # in-place in the reference
     loss_dict = {"factorization": h}
@@ -309,9 +314,10 @@ def forward_eb4(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
     tmp = torch.abs(rfft2_cat(rec, freq_norm) - rfft2_cat(x, freq_norm))
     t_re, t_im = tmp.tensor_split(2, dim=1)
     loss_dict["freq"] = (t_re + t_im).mean((1, 2, 3))
-    return {"cls_out": cls_out, "rec": rec, "loss_dict": loss_dict,
+    return {"cls_out": cls_out, "rec": rec, "loss_dict": loss_dict, "_max_gap": att["max_gap"],
             "_feats": {"x_b0": x_b0, "x_b1": x_b1, "x_b2": x_b2, "x_b3": x_b3, "x_b4": x_b4,
-                       "x_b5": x_b5, "dec1": dec1, "dec2": dec2, "dec3": dec3}}
+                       "x_b5": x_b5, "dec1": dec1, "dec2": dec2, "dec3": dec3, "att_out": att["out"],
+                       "x_b6": x_b6, "pooled": pooled}}
 
 
 # --------------------------------------------------------------------------------------

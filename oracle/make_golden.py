@@ -137,32 +137,41 @@ def main():
     print("wrote udeb4_eval_n2_init.npz")
 
     # ---------------- fixture 2: train mode fwd + pass-1 loss + bwd, N=4, masks injected ------
-    store = {}
+    # Seeds (38, 138): the smallest relative gap between the two largest channels entering torch.max in
+    # the dynamic filters is 1.2e-3 for this batch (oracle.eb4 "_max_gap"), so the arg-max — whose
+    # gradient is discontinuous — cannot flip under fp32 rounding differences.
+    # Two loss variants: "full" = the reference's pass-1 loss; "smooth" = the same with
+    # lambda_recons = lambda_freq = 0 (the two L1 terms have sign() gradients, see tests/test_model_gpu.py).
+    n, in_seed, mask_seed = 4, 38, 138
     param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
-    n = 4
-    x = param_fill.make_input(n, 256, seed=2)
+    x = param_fill.make_input(n, 256, seed=in_seed)
     tgt = param_fill.make_labels(n)
-    rng = make_rng(n, seed=3, drop_rate=drop_rate)
-    out, losses = run_reference_train(m, ref_loss, x, tgt, rng, drop_rate, LAMBDAS)
-    pack_outputs(out, "", store)
-    for k, v in losses.items():
-        store["loss_" + k] = np.array(v.item(), dtype=np.float64)
-    names, norms, heads = [], [], []
-    for k, p in m.named_parameters():
-        if p.grad is None:
-            continue
-        names.append(k)
-        norms.append(p.grad.double().norm().item())
-        h = torch.zeros(8)
-        f = p.grad.flatten()[:8]
-        h[: f.numel()] = f
-        heads.append(h.numpy())
-    store["grad_names"] = np.array(names)
-    store["grad_norms"] = np.array(norms, dtype=np.float64)
-    store["grad_heads"] = np.stack(heads)
-    store["meta"] = np.array([n, 256, 2, 3], dtype=np.int64)   # n, size, input seed, mask seed
+    rng = make_rng(n, seed=mask_seed, drop_rate=drop_rate)
+    store = {}
+    for variant, lam in (("full", LAMBDAS), ("smooth", dict(LAMBDAS, lambda_recons=0.0, lambda_freq=0.0))):
+        out, losses = run_reference_train(m, ref_loss, x, tgt, rng, drop_rate, lam)
+        if variant == "full":
+            pack_outputs(out, "", store)
+        for k, v in losses.items():
+            store[f"{variant}_loss_" + k] = np.array(v.item(), dtype=np.float64)
+        names, norms, heads, maxabs = [], [], [], []
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(k)
+            norms.append(p.grad.double().norm().item())
+            maxabs.append(p.grad.abs().max().item())
+            h = torch.zeros(8)
+            f = p.grad.flatten()[:8]
+            h[: f.numel()] = f
+            heads.append(h.numpy())
+        store["grad_names"] = np.array(names)
+        store[f"{variant}_grad_norms"] = np.array(norms, dtype=np.float64)
+        store[f"{variant}_grad_maxabs"] = np.array(maxabs, dtype=np.float64)
+        store[f"{variant}_grad_heads"] = np.stack(heads)
+    store["meta"] = np.array([n, 256, in_seed, mask_seed], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "udeb4_train_n4.npz"), **store)
-    print("wrote udeb4_train_n4.npz  (%d grads)" % len(names))
+    print("wrote udeb4_train_n4.npz  (%d grads x 2 variants)" % len(names))
 
 
 if __name__ == "__main__":

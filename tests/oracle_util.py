@@ -32,9 +32,12 @@ def oracle_state(sf_coef=0.0, fuse_coef=0.3, dtype=torch.float32, requires_grad=
     return sd
 
 
-def oracle_train_pass1(sd, x, tgt, rng, drop_rate=0.5):
+SMOOTH_LAMBDAS = dict(LAMBDAS, lambda_recons=0.0, lambda_freq=0.0)   # drops the two L1 (sign-gradient) terms
+
+
+def oracle_train_pass1(sd, x, tgt, rng, drop_rate=0.5, lam=None):
     out = eb4.forward_eb4(sd, x, training=True, drop_rate=drop_rate, rng=rng)
     n_real = int((tgt == 0).sum())
-    ls = losses.pass1_loss(out, tgt, n_real, len(tgt) - n_real, LAMBDAS)
+    ls = losses.pass1_loss(out, tgt, n_real, len(tgt) - n_real, lam or LAMBDAS)
     ls["total_loss"].backward()
     return out, ls

@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library loads and exports every symbol include/unidefense_hip.h declares, the ctypes
+binding (unidefense_amd/lib.py) covers the same set, and the product fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "unidefense_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(ud_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from unidefense_amd import lib
+    names = _declared()
+    assert len(names) >= 38
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    assert sorted(lib.EXPORTED) == names, (set(lib.EXPORTED) ^ set(names))
+    lib.load()
+
+
+def test_invalid_arguments_are_rejected_without_gpu():
+    from unidefense_amd import lib
+    # argument validation happens before any HIP call
+    assert lib.load().ud_gemm(None, None) == -1000
+    assert lib.load().ud_reduce_chunks(1, 10, 6) == -1000      # C % 4 != 0
+    assert lib.load().ud_rfft2(None, None, 1, 12, 4, 1.0, 1.0, None) == -1000   # unsupported size
+    with pytest.raises(lib.UDLibraryError):
+        lib.call("ud_reduce_chunks", 1, 10, 6)
+
+
+def test_model_refuses_cpu_tensors():
+    from unidefense_amd.model import load_model
+    m = load_model("udeb4")(extractor="efficientnet-b4", num_classes=2)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m.eval()(torch.zeros(1, 3, 256, 256))
+
+
+def test_state_dict_keys_match_reference_layout():
+    """802 keys / 505 parameters / 128.3 M values with the reference's names."""
+    from oracle import eb4
+    from unidefense_amd.model import load_model
+    m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5)
+    sd = m.state_dict()
+    want = eb4.eb4_state_shapes(2)
+    assert set(sd) == set(want)
+    assert all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+    assert len(list(m.parameters())) == 505
+    assert not m.bottleneck.bias.requires_grad

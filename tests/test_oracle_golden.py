@@ -43,24 +43,27 @@ def test_eval_matches_reference(golden_dir, fname, sf, fuse):
     _check_outputs(out, g)
 
 
-def test_train_fwd_bwd_matches_reference(golden_dir):
+@pytest.mark.parametrize("variant", ["full", "smooth"])
+def test_train_fwd_bwd_matches_reference(golden_dir, variant):
     g = np.load(os.path.join(golden_dir, "udeb4_train_n4.npz"))
     n, size, seed, mseed = [int(v) for v in g["meta"]]
+    lam = ou.LAMBDAS if variant == "full" else ou.SMOOTH_LAMBDAS
     sd = ou.oracle_state(0.0, 0.3, requires_grad=True)
     x = param_fill.make_input(n, size, seed)
     tgt = param_fill.make_labels(n)
     rng = ou.make_rng(n, mseed, 0.5)
-    out, ls = ou.oracle_train_pass1(sd, x, tgt, rng, drop_rate=0.5)
+    out, ls = ou.oracle_train_pass1(sd, x, tgt, rng, drop_rate=0.5, lam=lam)
     _check_outputs(out, g)
+    assert out["_max_gap"].item() > 1e-3     # the fixture's batch has no near-tie in torch.max
     for k in ("total_loss", "cls_loss", "triplet_loss", "real_rec_loss", "real_freq_loss"):
-        _close(ls[k].item(), g["loss_" + k], k)
+        _close(ls[k].item(), g[f"{variant}_loss_" + k], k)
     names = [str(s) for s in g["grad_names"]]
     assert len(names) == 504
     worst = 0.0
     for i, k in enumerate(names):
         gr = sd[k].grad
         assert gr is not None, k
-        ref_norm = float(g["grad_norms"][i])
+        ref_norm = float(g[f"{variant}_grad_norms"][i])
         got = gr.double().norm().item()
         # allclose-style bound (rtol on the tensor's norm + atol).  The atol matters for the bias of a
         # BN whose output only feeds (via 1x1 convs) other batch-stat BNs: its gradient is
@@ -68,7 +71,7 @@ def test_train_fwd_bwd_matches_reference(golden_dir):
         tol = GRAD_RTOL * ref_norm + GRAD_ATOL
         err = abs(got - ref_norm)
         head = gr.flatten()[:8].numpy()
-        herr = np.abs(head - g["grad_heads"][i][: head.size]).max()
+        herr = np.abs(head - g[f"{variant}_grad_heads"][i][: head.size]).max()
         worst = max(worst, err / tol, herr / tol)
         assert err < tol and herr < tol, f"{k}: norm err {err:.2e} head err {herr:.2e} tol {tol:.2e}"
     print("worst grad err / tol", worst)

@@ -137,12 +137,21 @@ __global__ __launch_bounds__(NT) void dw_bwd_weight_partial(DwGeom q, int rpi, i
     for (int i = 0; i < K * K; ++i) out[(long)i * q.C4 + c4] = acc[i];
 }
 
-__global__ void dw_bwd_weight_finalize(int nparts, int KKC, const float* __restrict__ part, float* __restrict__ dwt) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= KKC) return;
-    float a = 0.f;
-    for (int p = 0; p < nparts; ++p) a += part[(long)p * KKC + i];
-    dwt[i] = a;
+// 16 outputs x 16 part-lanes per block; fp64 accumulation of the per-chunk partial sums
+__global__ __launch_bounds__(NT) void dw_bwd_weight_finalize(int nparts, int KKC, const float* __restrict__ part,
+                                                             float* __restrict__ dwt) {
+    __shared__ double sm[NT];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;
+    double a = 0.0;
+    if (i < KKC)
+        for (int p = pl; p < nparts; p += 16) a += (double)part[(long)p * KKC + i];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (i < KKC && pl == 0) {
+        for (int k = 1; k < 16; ++k) a += sm[k * 16 + cl];
+        dwt[i] = (float)a;
+    }
 }
 
 int ew_blocks(long total) {
@@ -207,7 +216,7 @@ int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* par
     else hipLaunchKernelGGL(dw_bwd_weight_partial<5>, grid, dim3(NT), 0, s, q, rpi, ppc, x, dy, part);
     UD_LAUNCH_CHECK();
     int KKC = K * K * C;
-    hipLaunchKernelGGL(dw_bwd_weight_finalize, dim3(ud_cdiv(KKC, 256)), dim3(256), 0, s, chunks * rpi, KKC, part, dwt);
+    hipLaunchKernelGGL(dw_bwd_weight_finalize, dim3(ud_cdiv(KKC, 16)), dim3(NT), 0, s, chunks * rpi, KKC, part, dwt);
     UD_LAUNCH_CHECK();
     return 0;
 }

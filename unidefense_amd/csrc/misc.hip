@@ -47,6 +47,22 @@ __global__ __launch_bounds__(NT) void fc_bwd_x(const float* __restrict__ dy, con
     dx[e] = acc;
 }
 
+// same result, one wave per (n, i) with the lanes striding over o: for wide O (SE expand: O = C up to 2688)
+__global__ __launch_bounds__(NT) void fc_bwd_x_wave(const float* __restrict__ dy, const float* __restrict__ W,
+                                                    const float* __restrict__ x, float* __restrict__ dx, int N, int I,
+                                                    int O, int act_in) {
+    const int wave = (blockIdx.x * NT + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= N * I) return;
+    const int n = wave / I, i = wave % I;
+    float acc = 0.f;
+    for (int o = lane; o < O; o += 64) acc += dy[(long)n * O + o] * W[(long)o * I + i];
+    acc = ud_wave_sum(acc);
+    if (lane == 0) {
+        if (act_in == 1) acc *= ud_swish_grad(x[(long)n * I + i]);
+        dx[(long)n * I + i] = acc;
+    }
+}
+
 // dW[o][i] = sum_n dy[n][o] * act_in(x[n][i]);  db[o] = sum_n dy[n][o]
 __global__ __launch_bounds__(NT) void fc_bwd_w(const float* __restrict__ dy, const float* __restrict__ x,
                                                float* __restrict__ dW, float* __restrict__ db, int N, int I, int O,
@@ -148,14 +164,14 @@ __global__ __launch_bounds__(NT) void sfmix_bwd(long total4, int Ho, int Wo, int
                                                 const float* __restrict__ spat, const float* __restrict__ freq,
                                                 const float* __restrict__ alpha, const float* __restrict__ dy,
                                                 float* __restrict__ dspat, float* __restrict__ dfreq,
-                                                float* __restrict__ part) {
+                                                double* __restrict__ part) {
     const float a = ud_sigmoid(alpha[0]);
     const f32x4* s4 = reinterpret_cast<const f32x4*>(spat);
     const f32x4* f4 = reinterpret_cast<const f32x4*>(freq);
     const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
     f32x4* ds4 = reinterpret_cast<f32x4*>(dspat);
     f32x4* df4 = reinterpret_cast<f32x4*>(dfreq);
-    float acc = 0.f;
+    double acc = 0.0;   // fp64: the sum cancels heavily (sf_coef gradient)
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total4; e += (long)gridDim.x * NT) {
         int c4 = (int)(e % C4);
         long pix = e / C4;
@@ -175,33 +191,33 @@ __global__ __launch_bounds__(NT) void sfmix_bwd(long total4, int Ho, int Wo, int
             df4[b] = g; df4[b + C4] = g; df4[b + (long)W * C4] = g; df4[b + (long)W * C4 + C4] = g;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc += d[k] * (fp[k] - s[k]);
+        for (int k = 0; k < 4; ++k) acc += (double)d[k] * ((double)fp[k] - (double)s[k]);
     }
-    __shared__ float sm[NT / 64];
-    acc = ud_wave_sum(acc);
+    __shared__ double sm[NT / 64];
+    acc = ud_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float tot = 0.f;
+        double tot = 0.0;
         for (int i = 0; i < NT / 64; ++i) tot += sm[i];
         part[blockIdx.x] = tot;
     }
 }
 
 // out[0] (+)= sigmoid'(alpha) * sum(part[0..n))        (gradient of a sigmoid-gated scalar coefficient)
-__global__ __launch_bounds__(NT) void gate_grad_finalize(int n, const float* __restrict__ part,
+__global__ __launch_bounds__(NT) void gate_grad_finalize(int n, const double* __restrict__ part,
                                                          const float* __restrict__ alpha, float* __restrict__ out) {
-    float acc = 0.f;
+    double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += NT) acc += part[i];
-    __shared__ float sm[NT / 64];
-    acc = ud_wave_sum(acc);
+    __shared__ double sm[NT / 64];
+    acc = ud_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float tot = 0.f;
+        double tot = 0.0;
         for (int i = 0; i < NT / 64; ++i) tot += sm[i];
-        float a = ud_sigmoid(alpha[0]);
-        out[0] = tot * a * (1.f - a);
+        double a = 1.0 / (1.0 + exp(-(double)alpha[0]));
+        out[0] = (float)(tot * a * (1.0 - a));
     }
 }
 
@@ -276,21 +292,21 @@ __global__ __launch_bounds__(NT) void gate_mix_fwd(long total, const float* __re
 __global__ __launch_bounds__(NT) void gate_mix_bwd(long total, const float* __restrict__ p, const float* __restrict__ q,
                                                    const float* __restrict__ alpha, const float* __restrict__ dy,
                                                    float* __restrict__ dp, float* __restrict__ dq,
-                                                   float* __restrict__ part) {
+                                                   double* __restrict__ part) {
     const float a = ud_sigmoid(alpha[0]);
-    float acc = 0.f;
+    double acc = 0.0;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
         float d = dy[e];
         dp[e] = (1.f - a) * d;
         dq[e] = a * d;
-        acc += d * (q[e] - p[e]);
+        acc += (double)d * ((double)q[e] - (double)p[e]);
     }
-    __shared__ float sm[NT / 64];
-    acc = ud_wave_sum(acc);
+    __shared__ double sm[NT / 64];
+    acc = ud_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float tot = 0.f;
+        double tot = 0.0;
         for (int i = 0; i < NT / 64; ++i) tot += sm[i];
         part[blockIdx.x] = tot;
     }
@@ -508,7 +524,11 @@ int ud_fc_bwd(const float* dy, const float* W, const float* x, float* dx, float*
               int act_in, ud_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (dx) {
-        hipLaunchKernelGGL(fc_bwd_x, dim3(ud_cdiv((long)N * I, NT)), dim3(NT), 0, s, dy, W, x, dx, N, I, O, act_in);
+        if (O >= 256)
+            hipLaunchKernelGGL(fc_bwd_x_wave, dim3(ud_cdiv((long)N * I * 64, NT)), dim3(NT), 0, s, dy, W, x, dx, N, I,
+                               O, act_in);
+        else
+            hipLaunchKernelGGL(fc_bwd_x, dim3(ud_cdiv((long)N * I, NT)), dim3(NT), 0, s, dy, W, x, dx, N, I, O, act_in);
         UD_LAUNCH_CHECK();
     }
     if (dW) {
@@ -557,7 +577,7 @@ int ud_sfmix_fwd(const float* spat, const float* freq, const float* alpha, float
 
 // part must hold ud_sfmix_blocks(...) floats; dalpha receives sigmoid'(alpha) * sum dy (P(freq) - spat)
 int ud_sfmix_bwd(const float* spat, const float* freq, const float* alpha, const float* dy, float* dspat, float* dfreq,
-                 float* part, float* dalpha, int N, int Ho, int Wo, int C, int pool, ud_stream_t stream) {
+                 double* part, float* dalpha, int N, int Ho, int Wo, int C, int pool, ud_stream_t stream) {
     if (C % 4) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     long total4 = (long)N * Ho * Wo * (C / 4);
@@ -579,7 +599,7 @@ int ud_gate_mix_fwd(const float* p, const float* q, const float* alpha, float* y
 }
 
 int ud_gate_mix_bwd(const float* p, const float* q, const float* alpha, const float* dy, float* dp, float* dq,
-                    float* part, float* dalpha, long total, ud_stream_t stream) {
+                    double* part, float* dalpha, long total, ud_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     int nb = ew_blocks(total, 1024);
     hipLaunchKernelGGL(gate_mix_bwd, dim3(nb), dim3(NT), 0, s, total, p, q, alpha, dy, dp, dq, part);

@@ -7,8 +7,10 @@
 //
 // All of these are HBM-bound: one coalesced 16-B-per-lane pass over the tensor per kernel.  A reduction
 // is two launches: a partial pass (grid = chunks x channel-slabs x groups; every thread owns 4 adjacent
-// channels and strides over rows, then the block folds its row-lanes through LDS) and a tiny finalize.
-// Deterministic (no atomics).
+// channels and strides over rows, then the block folds its row-lanes through LDS) and a finalize that
+// sums the chunk partials with 16 lanes per channel.  Accumulation is in fp64 (the kernels are bandwidth
+// bound, so it is free) — batch statistics over millions of rows and the cancelling sums of the backward
+// then carry no summation error of their own.  Deterministic (no atomics).
 #include "ud_common.h"
 
 namespace {
@@ -33,35 +35,35 @@ __device__ __forceinline__ bool thread_coords(const RedGeom& q, int& ri, int& c4
     return c4 < q.C4;
 }
 
-// fold the row-lanes of a block: vals[8] per thread -> thread (ri == 0) holds the block total
+// fold the row-lanes of a block: v[NQ] per thread -> thread (ri == 0) holds the block total
 template <int NQ>
-__device__ __forceinline__ void block_fold(const RedGeom& q, int ri, int c4, bool active, float (&v)[8]) {
+__device__ __forceinline__ void block_fold(const RedGeom& q, int ri, int c4, bool active, double (&v)[8]) {
     if (q.C4 > NT || q.rpi == 1) return;
-    __shared__ float sm[NT * 8];
+    __shared__ double sm[NT * NQ];
     if (active) {
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) sm[threadIdx.x * 8 + i] = v[i];
+        for (int i = 0; i < NQ; ++i) sm[threadIdx.x * NQ + i] = v[i];
     }
     __syncthreads();
     if (active && ri == 0) {
         for (int r = 1; r < q.rpi; ++r) {
             int t = r * q.C4 + c4;
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) v[i] += sm[t * 8 + i];
+            for (int i = 0; i < NQ; ++i) v[i] += sm[t * NQ + i];
         }
     }
 }
 
 enum { RED_STATS = 0, RED_NORMBWD = 1, RED_SUM = 2, RED_DOT = 3 };
 
-// part1/part2: [(g*P + p)][C]
+// part1/part2: double [(g*P + p)][C]
 template <int MODE>
 __global__ __launch_bounds__(NT) void colreduce_partial(RedGeom q, const float* __restrict__ x,
                                                         const float* __restrict__ y2,      // dy (NORMBWD) / b (DOT)
                                                         const float* __restrict__ mean,    // [G][C]
                                                         const float* __restrict__ invstd,  // [G][C]
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        int act, float* __restrict__ part1, float* __restrict__ part2) {
+                                                        int act, double* __restrict__ part1, double* __restrict__ part2) {
     int ri, c4;
     bool active = thread_coords(q, ri, c4);
     const int g = blockIdx.z, p = blockIdx.x;
@@ -71,10 +73,9 @@ __global__ __launch_bounds__(NT) void colreduce_partial(RedGeom q, const float* 
     const long gbase = (long)g * q.R * q.C4;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     const f32x4* y4 = reinterpret_cast<const f32x4*>(y2);
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
-        f32x4 sh = {0, 0, 0, 0}, mu = sh, is = sh, ga = sh, be = sh;
-        if (MODE == RED_STATS) sh = x4[gbase + c4];   // shift = first row of the group (conditioning)
+        f32x4 mu = {0, 0, 0, 0}, is = mu, ga = mu, be = mu;
         if (MODE == RED_NORMBWD) {
             mu = reinterpret_cast<const f32x4*>(mean)[(long)g * q.C4 + c4];
             is = reinterpret_cast<const f32x4*>(invstd)[(long)g * q.C4 + c4];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(NT) void colreduce_partial(RedGeom q, const float* 
             if (MODE == RED_STATS) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float d = a[e] - sh[e];
+                    double d = (double)a[e];
                     v[e] += d;
                     v[4 + e] += d * d;
                 }
@@ -98,91 +99,117 @@ __global__ __launch_bounds__(NT) void colreduce_partial(RedGeom q, const float* 
                     float xh = (a[e] - mu[e]) * is[e];
                     float dz = dy[e];
                     if (act == 1) dz *= ud_swish_grad(ga[e] * xh + be[e]);
-                    v[e] += dz;
-                    v[4 + e] += dz * xh;
+                    v[e] += (double)dz;
+                    v[4 + e] += (double)dz * (double)xh;
                 }
             } else if (MODE == RED_SUM) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += a[e];
+                for (int e = 0; e < 4; ++e) v[e] += (double)a[e];
             } else {
                 f32x4 b = y4[idx];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += a[e] * b[e];
+                for (int e = 0; e < 4; ++e) v[e] += (double)a[e] * (double)b[e];
             }
         }
     }
     constexpr int NQ = (MODE == RED_STATS || MODE == RED_NORMBWD) ? 8 : 4;
     block_fold<NQ>(q, ri, c4, active, v);
     if (active && ri == 0) {
-        const long o = ((long)g * q.P + p) * q.C4 + c4;
-        f32x4 o1 = {v[0], v[1], v[2], v[3]};
-        reinterpret_cast<f32x4*>(part1)[o] = o1;
+        const long o = (((long)g * q.P + p) * q.C4 + c4) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part1[o + e] = v[e];
         if (NQ == 8) {
-            f32x4 o2 = {v[4], v[5], v[6], v[7]};
-            reinterpret_cast<f32x4*>(part2)[o] = o2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part2[o + e] = v[4 + e];
         }
     }
 }
 
-// ---- finalize kernels: one thread per (g, c) -------------------------------------------------
-__global__ void stats_finalize(int G, int R, int C, int P, const float* __restrict__ x, const float* __restrict__ part1,
-                               const float* __restrict__ part2, float eps, float* __restrict__ mean,
-                               float* __restrict__ invstd, float* __restrict__ var_out, float momentum,
-                               float* __restrict__ running_mean, float* __restrict__ running_var) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G * C) return;
-    int g = i / C, c = i % C;
-    float s1 = 0.f, s2 = 0.f;
-    for (int p = 0; p < P; ++p) {
-        s1 += part1[((long)g * P + p) * C + c];
-        s2 += part2[((long)g * P + p) * C + c];
+// ---- finalize: 16 channels x 16 chunk-lanes per block -----------------------------------------------
+// returns (in lane pl == 0) the sums over the P chunks of part1/part2 for entry idx = (g, c)
+__device__ __forceinline__ void chunk_sums(int G, int C, int P, const double* __restrict__ part1,
+                                           const double* __restrict__ part2, int& idx, bool& lead, double& s1,
+                                           double& s2) {
+    __shared__ double sm1[NT], sm2[NT];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    idx = blockIdx.x * 16 + cl;
+    const bool ok = idx < G * C;
+    double a = 0.0, b = 0.0;
+    if (ok) {
+        const int g = idx / C, c = idx % C;
+        for (int p = pl; p < P; p += 16) {
+            const long o = ((long)g * P + p) * C + c;
+            a += part1[o];
+            if (part2) b += part2[o];
+        }
     }
-    float sh = x[(long)g * R * C + c];
-    float n = (float)R;
-    float m1 = s1 / n;
-    float var = s2 / n - m1 * m1;
-    if (var < 0.f) var = 0.f;
-    float mu = sh + m1;
-    mean[i] = mu;
-    invstd[i] = rsqrtf(var + eps);
-    if (var_out) var_out[i] = var;
-    if (running_mean && G == 1) {   // nn.BatchNorm: unbiased variance goes into the running estimate
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-        float unb = (R > 1) ? var * n / (n - 1.f) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    sm1[threadIdx.x] = a;
+    sm2[threadIdx.x] = b;
+    __syncthreads();
+    lead = ok && pl == 0;
+    if (lead) {
+        for (int k = 1; k < 16; ++k) {
+            a += sm1[k * 16 + cl];
+            b += sm2[k * 16 + cl];
+        }
+    }
+    s1 = a;
+    s2 = b;
+}
+
+__global__ __launch_bounds__(NT) void stats_finalize(int G, int R, int C, int P, const double* __restrict__ part1,
+                                                     const double* __restrict__ part2, float eps,
+                                                     float* __restrict__ mean, float* __restrict__ invstd,
+                                                     float* __restrict__ var_out, float momentum,
+                                                     float* __restrict__ running_mean, float* __restrict__ running_var) {
+    int idx; bool lead; double s1, s2;
+    chunk_sums(G, C, P, part1, part2, idx, lead, s1, s2);
+    if (!lead) return;
+    const double n = (double)R;
+    const double mu = s1 / n;
+    double var = s2 / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[idx] = (float)mu;
+    invstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
+    if (var_out) var_out[idx] = (float)var;
+    if (running_mean && G == 1) {   // nn.BatchNorm: the unbiased variance goes into the running estimate
+        const int c = idx;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        const double unb = (R > 1) ? var * n / (n - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
 }
 
-// s1,s2: [G][C] sums over chunks; dgamma/dbeta: [C] sums over groups too (may be null)
-__global__ void normbwd_finalize(int G, int C, int P, const float* __restrict__ part1, const float* __restrict__ part2,
-                                 float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ dgamma,
-                                 float* __restrict__ dbeta) {
+// s1,s2: float [G][C] sums over chunks
+__global__ __launch_bounds__(NT) void normbwd_finalize(int G, int C, int P, const double* __restrict__ part1,
+                                                       const double* __restrict__ part2, float* __restrict__ s1o,
+                                                       float* __restrict__ s2o) {
+    int idx; bool lead; double s1, s2;
+    chunk_sums(G, C, P, part1, part2, idx, lead, s1, s2);
+    if (!lead) return;
+    s1o[idx] = (float)s1;
+    s2o[idx] = (float)s2;
+}
+
+// dgamma[c] = sum_g s2[g][c], dbeta[c] = sum_g s1[g][c]
+__global__ void group_sum(int G, int C, const float* __restrict__ s1, const float* __restrict__ s2,
+                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float tg = 0.f, tb = 0.f;
+    double a = 0.0, b = 0.0;
     for (int g = 0; g < G; ++g) {
-        float a = 0.f, b = 0.f;
-        for (int p = 0; p < P; ++p) {
-            a += part1[((long)g * P + p) * C + c];
-            b += part2[((long)g * P + p) * C + c];
-        }
-        s1[(long)g * C + c] = a;
-        s2[(long)g * C + c] = b;
-        tb += a;
-        tg += b;
+        a += (double)s1[(long)g * C + c];
+        b += (double)s2[(long)g * C + c];
     }
-    if (dgamma) dgamma[c] = tg;
-    if (dbeta) dbeta[c] = tb;
+    if (dbeta) dbeta[c] = (float)a;
+    if (dgamma) dgamma[c] = (float)b;
 }
 
-__global__ void partial_sum_finalize(int G, int C, int P, const float* __restrict__ part1, float scale,
-                                     float* __restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G * C) return;
-    int g = i / C, c = i % C;
-    float a = 0.f;
-    for (int p = 0; p < P; ++p) a += part1[((long)g * P + p) * C + c];
-    out[i] = a * scale;
+__global__ __launch_bounds__(NT) void partial_sum_finalize(int G, int C, int P, const double* __restrict__ part1,
+                                                           float scale, float* __restrict__ out) {
+    int idx; bool lead; double s1, s2;
+    chunk_sums(G, C, P, part1, nullptr, idx, lead, s1, s2);
+    if (lead) out[idx] = (float)(s1 * (double)scale);
 }
 
 // ---- elementwise passes -----------------------------------------------------------------------
@@ -212,17 +239,16 @@ __global__ __launch_bounds__(NT) void norm_apply_fwd(long total4, int R, int C4,
     }
 }
 
-// dx = gamma*invstd*(dz - s1/R - xhat*s2/R),  dz = dy*act'(z)          (batch statistics)
-// with s1 == nullptr: dx = gamma*invstd*dz                               (fixed statistics, eval mode)
+// dx = gamma*invstd*(dz - s1*invR - xhat*s2*invR),  dz = dy*act'(z)
 __global__ __launch_bounds__(NT) void norm_apply_bwd(long total4, int R, int C4, const float* __restrict__ x,
                                                      const float* __restrict__ dy, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ s1,
-                                                     const float* __restrict__ s2, int act, float* __restrict__ dx) {
+                                                     const float* __restrict__ s2, float invR, int act,
+                                                     float* __restrict__ dx) {
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
     f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
-    const float invR = 1.f / (float)R;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total4; e += (long)gridDim.x * NT) {
         long row = e / C4;
         int c4 = (int)(e - row * C4);
@@ -232,11 +258,8 @@ __global__ __launch_bounds__(NT) void norm_apply_bwd(long total4, int R, int C4,
         f32x4 is = reinterpret_cast<const f32x4*>(invstd)[g * C4 + c4];
         f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
         f32x4 be = reinterpret_cast<const f32x4*>(beta)[c4];
-        f32x4 t1 = {0, 0, 0, 0}, t2 = t1;
-        if (s1) {
-            t1 = reinterpret_cast<const f32x4*>(s1)[g * C4 + c4];
-            t2 = reinterpret_cast<const f32x4*>(s2)[g * C4 + c4];
-        }
+        f32x4 t1 = reinterpret_cast<const f32x4*>(s1)[g * C4 + c4];
+        f32x4 t2 = reinterpret_cast<const f32x4*>(s2)[g * C4 + c4];
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -266,6 +289,8 @@ int ew_blocks(long total4) {
     return (int)b;
 }
 
+inline dim3 fin_grid(int G, int C) { return dim3((unsigned)ud_cdiv((long)G * C, 16)); }
+
 }  // namespace
 
 extern "C" {
@@ -275,16 +300,16 @@ int ud_reduce_chunks(int G, int R, int C) {
     int C4 = C / 4;
     int rpi = (C4 <= NT) ? NT / C4 : 1;
     int slabs = (C4 + NT - 1) / NT;
-    long want = 2048 / ((long)G * slabs);        // aim at ~2048 blocks in flight
+    long want = 1024 / ((long)G * slabs);        // aim at ~1024 blocks in flight
     if (want < 1) want = 1;
     long maxp = (R + (long)rpi * 4 - 1) / ((long)rpi * 4);   // at least 4 iterations per block
     if (maxp < 1) maxp = 1;
     long P = want < maxp ? want : maxp;
-    if (P > 1024) P = 1024;
+    if (P > 256) P = 256;
     return (int)P;
 }
 
-int ud_norm_stats(const float* x, int G, int R, int C, int P, float eps, float* part1, float* part2, float* mean,
+int ud_norm_stats(const float* x, int G, int R, int C, int P, float eps, double* part1, double* part2, float* mean,
                   float* invstd, float* var_out, float momentum, float* running_mean, float* running_var,
                   ud_stream_t stream) {
     if (C % 4 || G < 1 || R < 1 || P < 1) return UD_EINVAL;
@@ -293,8 +318,8 @@ int ud_norm_stats(const float* x, int G, int R, int C, int P, float eps, float* 
     hipLaunchKernelGGL(colreduce_partial<RED_STATS>, red_grid(q), dim3(NT), 0, s, q, x, nullptr, nullptr, nullptr,
                        nullptr, nullptr, 0, part1, part2);
     UD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stats_finalize, dim3(ud_cdiv((long)G * C, 256)), dim3(256), 0, s, G, R, C, P, x, part1, part2,
-                       eps, mean, invstd, var_out, momentum, running_mean, running_var);
+    hipLaunchKernelGGL(stats_finalize, fin_grid(G, C), dim3(NT), 0, s, G, R, C, P, part1, part2, eps, mean, invstd,
+                       var_out, momentum, running_mean, running_var);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -310,7 +335,7 @@ int ud_norm_apply_fwd(const float* x, int G, int R, int C, const float* mean, co
 }
 
 int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, int P, const float* mean, const float* invstd,
-                const float* gamma, const float* beta, int act, float* part1, float* part2, float* s1, float* s2,
+                const float* gamma, const float* beta, int act, double* part1, double* part2, float* s1, float* s2,
                 float* dgamma, float* dbeta, float* dx, ud_stream_t stream) {
     if (C % 4 || G < 1 || R < 1 || P < 1) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -318,20 +343,36 @@ int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, int P, con
     hipLaunchKernelGGL(colreduce_partial<RED_NORMBWD>, red_grid(q), dim3(NT), 0, s, q, x, dy, mean, invstd, gamma, beta,
                        act, part1, part2);
     UD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(normbwd_finalize, dim3(ud_cdiv(C, 256)), dim3(256), 0, s, G, C, P, part1, part2, s1, s2, dgamma,
-                       dbeta);
+    hipLaunchKernelGGL(normbwd_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, P, part1, part2, s1, s2);
     UD_LAUNCH_CHECK();
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(group_sum, dim3(ud_cdiv(C, 256)), dim3(256), 0, s, G, C, s1, s2, dgamma, dbeta);
+        UD_LAUNCH_CHECK();
+    }
     if (dx) {
         long total4 = (long)G * R * (C / 4);
         hipLaunchKernelGGL(norm_apply_bwd, dim3(ew_blocks(total4)), dim3(NT), 0, s, total4, R, C / 4, x, dy, mean,
-                           invstd, gamma, beta, s1, s2, act, dx);
+                           invstd, gamma, beta, s1, s2, 1.f / (float)R, act, dx);
         UD_LAUNCH_CHECK();
     }
     return 0;
 }
 
+// The elementwise half of ud_norm_bwd alone, with caller-provided sums and 1/count: used when s1/s2 were
+// summed over all ranks first (SyncBatchNorm backward; count = rows of ALL ranks).
+int ud_norm_bwd_apply(const float* x, const float* dy, int G, int R, int C, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, const float* s1, const float* s2, float inv_count,
+                      int act, float* dx, ud_stream_t stream) {
+    if (C % 4 || G < 1 || R < 1) return UD_EINVAL;
+    long total4 = (long)G * R * (C / 4);
+    hipLaunchKernelGGL(norm_apply_bwd, dim3(ew_blocks(total4)), dim3(NT), 0, (hipStream_t)stream, total4, R, C / 4, x,
+                       dy, mean, invstd, gamma, beta, s1, s2, inv_count, act, dx);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
 // out[g][c] = scale * sum_r x[g][r][c]
-int ud_group_colsum(const float* x, int G, int R, int C, int P, float scale, float* part1, float* out,
+int ud_group_colsum(const float* x, int G, int R, int C, int P, float scale, double* part1, float* out,
                     ud_stream_t stream) {
     if (C % 4 || G < 1 || R < 1 || P < 1) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -339,14 +380,13 @@ int ud_group_colsum(const float* x, int G, int R, int C, int P, float scale, flo
     hipLaunchKernelGGL(colreduce_partial<RED_SUM>, red_grid(q), dim3(NT), 0, s, q, x, nullptr, nullptr, nullptr,
                        nullptr, nullptr, 0, part1, nullptr);
     UD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_finalize, dim3(ud_cdiv((long)G * C, 256)), dim3(256), 0, s, G, C, P, part1, scale,
-                       out);
+    hipLaunchKernelGGL(partial_sum_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, P, part1, scale, out);
     UD_LAUNCH_CHECK();
     return 0;
 }
 
 // out[g][c] = scale * sum_r a[g][r][c] * b[g][r][c]
-int ud_group_coldot(const float* a, const float* b, int G, int R, int C, int P, float scale, float* part1, float* out,
+int ud_group_coldot(const float* a, const float* b, int G, int R, int C, int P, float scale, double* part1, float* out,
                     ud_stream_t stream) {
     if (C % 4 || G < 1 || R < 1 || P < 1) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -354,8 +394,7 @@ int ud_group_coldot(const float* a, const float* b, int G, int R, int C, int P, 
     hipLaunchKernelGGL(colreduce_partial<RED_DOT>, red_grid(q), dim3(NT), 0, s, q, a, b, nullptr, nullptr, nullptr,
                        nullptr, 0, part1, nullptr);
     UD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_finalize, dim3(ud_cdiv((long)G * C, 256)), dim3(256), 0, s, G, C, P, part1, scale,
-                       out);
+    hipLaunchKernelGGL(partial_sum_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, P, part1, scale, out);
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -15,7 +15,8 @@ static inline int ud_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float ud_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// accurate expf (not the __expf fast intrinsic): these kernels are bandwidth bound, the ALU work is free
+__device__ __forceinline__ float ud_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float ud_swish(float x) { return x * ud_sigmoid(x); }
 // d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))      (model/efficientnet/utils.py:73-77)
 __device__ __forceinline__ float ud_swish_grad(float x) {
@@ -25,6 +26,11 @@ __device__ __forceinline__ float ud_swish_grad(float x) {
 
 // wave64 all-reduce (sum) via DPP-free shuffles
 __device__ __forceinline__ float ud_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double ud_wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;

@@ -1,5 +1,136 @@
-"""Placeholder — filled in below (train_unidefense_model)."""
+"""AbstractEngine: the two-pass UniDefense train step on the HIP model.
+
+Mirror of the reference's ``engine/abstract_engine.py`` for the hot path only: ``train_unidefense_model``
+(:207-381) keeps its signature, return dict, loss weights and optimizer/scheduler/scaler call order, including
+the reference's quirk that gradients are NOT zeroed between the two passes (``zero_grad`` is the caller's,
+once per step: engine/forgery_engine.py:241).  Dataset plumbing, wandb, checkpoints and evaluation are out
+of scope.
+"""
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def _zero(device):
+    return torch.tensor(0.0, device=device)
 
 
 class AbstractEngine(object):
     path = "engine/abstract_engine.py"
+
+    # Concrete engines (or tests) provide: model, optimizer, scheduler, loss_criterion
+    # {"softmax","triplet","kl_div","fac"}, config, num_steps, warmup_step, device.
+    def __init__(self, config=None, stage="Train"):
+        feasible_stage = ["Train", "Test"]
+        if stage not in feasible_stage:
+            raise ValueError(f"stage should be in {feasible_stage}, but found '{stage}'")
+        self.config = config or {}
+        self.model = self.optimizer = self.scheduler = self.loss_criterion = None
+        self.num_steps, self.warmup_step, self.device = 1, 0, None
+
+    @staticmethod
+    def fixed_randomness(seed=42):
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+
+    def to_device(self, items):
+        return [obj.to(self.device) for obj in items]
+
+    # ------------------------------------------------------------------------------------------
+    def _lam(self, key):
+        return self.config["config"].get(key, 1.0)
+
+    def _common_terms(self, out_dict, in_tgt, sum_real, sum_fake):
+        """Loss terms both passes share (engine/abstract_engine.py:232-259 and :301-328)."""
+        cls_out = out_dict["cls_out"]
+        loss_dict = out_dict.get("loss_dict", dict())
+        t = {}
+        if loss_dict.get("triplet") is not None:
+            crit = self.loss_criterion["triplet"]
+            if hasattr(crit, "n_real"):
+                crit.n_real = sum_real                  # avoids a device read-back per feature
+            t["triplet"] = sum(crit(feat, in_tgt) for feat in loss_dict["triplet"])
+        else:
+            t["triplet"] = _zero(self.device)
+        for key, name in (("spatial", "rec"), ("freq", "freq")):
+            if loss_dict.get(key) is not None:
+                t["real_" + name] = torch.mean(loss_dict[key].narrow(0, 0, sum_real))
+                t["fake_" + name] = torch.mean(loss_dict[key].narrow(0, sum_real, sum_fake))
+            else:
+                t["real_" + name] = t["fake_" + name] = _zero(self.device)
+        if cls_out.shape[-1] == 1:
+            t["cls"] = self.loss_criterion["softmax"](cls_out.squeeze(), in_tgt.float())
+        else:
+            t["cls"] = self.loss_criterion["softmax"](cls_out, in_tgt)
+        return t
+
+    def _backward_and_step(self, total_loss, grad_scalar):
+        grad_scalar.scale(total_loss).backward()
+        grad_scalar.step(self.optimizer)
+        grad_scalar.update()
+
+    @staticmethod
+    def _barrier():
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+
+    def train_unidefense_model(self, in_data, in_tgt, cur_step, grad_scalar, sum_real=None, sum_fake=None):
+        """One train step = clean pass + perturbed/consistency pass, each with its own backward and optimizer
+        step.  Batch order must be [real...; fake...]."""
+        # ---------------- pass 1: clean input ------------------------------------------------------
+        out_dict = self.model(in_data)
+        loss_dict = out_dict.get("loss_dict", dict())
+        has_fm = loss_dict.get("freq_mask") is not None
+        has_sm = loss_dict.get("spat_mask") is not None
+        freq_mask_gt = loss_dict["freq_mask"].clone().detach() if has_fm else None
+        spat_mask_gt = loss_dict["spat_mask"].clone().detach() if has_sm else None
+        freq_mask_loss = torch.mean(loss_dict["freq_mask"]) if has_fm else _zero(self.device)
+        spat_mask_loss = torch.mean(loss_dict["spat_mask"]) if has_sm else _zero(self.device)
+        fac_gt = loss_dict["factorization"].clone().detach()
+        t = self._common_terms(out_dict, in_tgt, sum_real, sum_fake)
+        total_loss = t["cls"] + self._lam("lambda_mask") * freq_mask_loss + self._lam("lambda_mask") * spat_mask_loss \
+            + self._lam("lambda_triplet") * t["triplet"] + self._lam("lambda_recons") * t["real_rec"] \
+            + self._lam("lambda_freq") * t["real_freq"]
+        ret_dict = {
+            "total_loss": total_loss, "cls_out": out_dict["cls_out"], "cls_loss": t["cls"],
+            "triplet_loss": t["triplet"], "real_rec_loss": t["real_rec"], "fake_rec_loss": t["fake_rec"],
+            "real_freq_loss": t["real_freq"], "fake_freq_loss": t["fake_freq"],
+        }
+        self._backward_and_step(total_loss, grad_scalar)
+        self._barrier()
+
+        # ---------------- pass 2: perturbed input + consistency with pass 1 -----------------------
+        pert_real_list = torch.arange(sum_real)[torch.randperm(sum_real)]
+        pert_fake_list = torch.arange(sum_fake)[torch.randperm(sum_fake)]
+        out_dict = self.model(in_data, pert_real_list=pert_real_list, pert_fake_list=pert_fake_list,
+                              preserve_color=True)
+        loss_dict = out_dict.get("loss_dict", dict())
+        t = self._common_terms(out_dict, in_tgt, sum_real, sum_fake)
+        zero_like = torch.zeros_like(t["cls"])
+        if cur_step > self.num_steps * 0.1:
+            # mask alignment: KL between the log-softmaxed flattened masks of the two passes
+            def kld(pred, gt):
+                pred = torch.log_softmax(pred.reshape(pred.shape[0], -1), dim=-1)
+                gt = torch.log_softmax(gt.reshape(gt.shape[0], -1), dim=-1)
+                return self.loss_criterion["kl_div"](pred, gt)
+            freq_mask_loss = kld(loss_dict["freq_mask"], freq_mask_gt) if has_fm else zero_like
+            spat_mask_loss = kld(loss_dict["spat_mask"], spat_mask_gt) if has_sm else zero_like
+        else:
+            freq_mask_loss = torch.mean(loss_dict["freq_mask"]) if has_fm else zero_like
+            spat_mask_loss = torch.mean(loss_dict["spat_mask"]) if has_sm else zero_like
+        fac_loss = self.loss_criterion["fac"](loss_dict["factorization"], fac_gt)
+        ret_dict.update({"freq_mask_loss": freq_mask_loss, "spat_mask_loss": spat_mask_loss, "fac_loss": fac_loss})
+        total_loss = 0.1 * t["cls"] + self._lam("lambda_mask") * freq_mask_loss \
+            + self._lam("lambda_mask") * spat_mask_loss + self._lam("lambda_triplet") * t["triplet"] \
+            + self._lam("lambda_recons") * 0.1 * t["real_rec"] + self._lam("lambda_freq") * 0.1 * t["real_freq"] \
+            + self._lam("lambda_fac") * fac_loss
+        self._backward_and_step(total_loss, grad_scalar)
+        if self.warmup_step == 0 or cur_step > self.warmup_step:
+            self.scheduler.step()
+        self._barrier()
+        return ret_dict

@@ -1,9 +1,13 @@
-"""Data parallelism for the HIP model: one process per GPU, gradients averaged with RCCL over xGMI
-(reference: DistributedDataParallel + SyncBatchNorm, engine/forgery_engine.py:142-146).
+"""Data parallelism for the HIP model: one process per GPU, RCCL over xGMI
+(reference: SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel, engine/forgery_engine.py:142-146).
 
-The whole network is a single autograd node, so the gradient exchange is driven from inside that node's
-backward (see model/unidefense.py:_NetFunction): bucketed flat all-reduces (sum / world) of the parameter
-gradients.  No data-path collective exists besides this and the SyncBN statistics.
+The path shards over the batch only.  Exchanges per backward:
+  * parameter gradients — bucketed flat all-reduce (sum / world).  The whole network is a single autograd
+    node, so the exchange is driven from inside that node's backward (model/unidefense.py:_NetFunction):
+    gradients are packed in the order backward produced them (reverse parameter order) into ~64 MB buckets.
+  * SyncBatchNorm statistics — one all_gather of (mean, var) per BN forward and one all_reduce of
+    (sum dz, sum dz*xhat) per BN backward (tape.batchnorm_act), enabled by ``sync_bn=True``.
+No other collective exists on the data path.
 """
 import torch
 import torch.distributed as dist
@@ -13,22 +17,25 @@ import torch.nn as nn
 class HipDataParallel(nn.Module):
     """Minimal DDP replacement exposing ``.module`` like torch's wrapper."""
 
-    def __init__(self, module: nn.Module, process_group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, module: nn.Module, process_group=None, bucket_bytes: int = 64 << 20, sync_bn: bool = True):
         super().__init__()
         self.module = module
         self.process_group = process_group
         self.bucket_bytes = bucket_bytes
         self.world = dist.get_world_size(process_group)
         # same initial state on every rank (DDP broadcasts rank 0's parameters and buffers)
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, 0, group=process_group)
-        module._grad_sync = self._sync_grads
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, 0, group=process_group)
+        module._grad_sync = self.sync_grads
+        if sync_bn and self.world > 1:
+            module._sync_bn_group = process_group if process_group is not None else dist.group.WORLD
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
-    def _sync_grads(self, grads):
-        """grads: list of tensors (or None) in parameter order -> averaged over ranks, in place."""
+    def sync_grads(self, grads):
+        """grads: list of tensors (or None) in parameter order -> averaged over ranks (in place)."""
         if self.world == 1:
             return grads
         bucket, size = [], 0
@@ -47,14 +54,14 @@ class HipDataParallel(nn.Module):
                 off += n
             bucket, size = [], 0
 
-        for g in reversed([g for g in grads if g is not None]):     # roughly the order backward produced them
+        for g in reversed([g for g in grads if g is not None]):
             bucket.append(g)
-            size += g.numel() * 4
+            size += g.numel() * g.element_size()
             if size >= self.bucket_bytes:
                 flush()
         flush()
         return grads
 
 
-def wrap_data_parallel(model: nn.Module, local_rank: int, process_group=None):
-    return HipDataParallel(model, process_group)
+def wrap_data_parallel(model: nn.Module, local_rank: int = 0, process_group=None, sync_bn: bool = True):
+    return HipDataParallel(model, process_group, sync_bn=sync_bn)

@@ -166,12 +166,48 @@ def norm_stats(x2, G, R, eps, momentum=0.0, running_mean=None, running_var=None)
     _chk(x2)
     Cc = x2.shape[-1]
     P = _chunks(G, R, Cc)
-    part = empty((2, G * P, Cc), x2)
+    part = torch.empty((2, G * P, Cc), dtype=torch.float64, device=x2.device)
     mean = empty((G, Cc), x2)
     invstd = empty((G, Cc), x2)
     _call("ud_norm_stats", _p(x2), G, R, Cc, P, eps, _p(part[0]), _p(part[1]), _p(mean), _p(invstd), None,
           momentum, _p(running_mean), _p(running_var), _stream())
     return mean, invstd
+
+
+def norm_stats_local(x2, G, R, eps):
+    """(mean, biased var) per (g, c) — the per-rank half of a SyncBatchNorm forward."""
+    _chk(x2)
+    Cc = x2.shape[-1]
+    P = _chunks(G, R, Cc)
+    part = torch.empty((2, G * P, Cc), dtype=torch.float64, device=x2.device)
+    mean = empty((G, Cc), x2)
+    invstd = empty((G, Cc), x2)
+    var = empty((G, Cc), x2)
+    _call("ud_norm_stats", _p(x2), G, R, Cc, P, eps, _p(part[0]), _p(part[1]), _p(mean), _p(invstd), _p(var),
+          0.0, None, None, _stream())
+    return mean, var
+
+
+def norm_bwd_sums(x2, dy, G, R, mean, invstd, gamma, beta, act):
+    """Reductions of the norm backward only: returns (s[2,G,C], dgamma[C], dbeta[C])."""
+    _chk(x2, dy)
+    Cc = x2.shape[-1]
+    P = _chunks(G, R, Cc)
+    part = torch.empty((2, G * P, Cc), dtype=torch.float64, device=x2.device)
+    s = empty((2, G, Cc), x2)
+    dg = empty((Cc,), x2)
+    db = empty((Cc,), x2)
+    _call("ud_norm_bwd", _p(x2), _p(dy), G, R, Cc, P, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
+          _p(part[0]), _p(part[1]), _p(s[0]), _p(s[1]), _p(dg), _p(db), None, _stream())
+    return s, dg, db
+
+
+def norm_bwd_apply(x2, dy, G, R, mean, invstd, gamma, beta, s, inv_count, act):
+    _chk(x2, dy, s)
+    dx = torch.empty_like(x2)
+    _call("ud_norm_bwd_apply", _p(x2), _p(dy), G, R, x2.shape[-1], _p(mean), _p(invstd), _p(gamma), _p(beta),
+          _p(s[0]), _p(s[1]), inv_count, int(act), _p(dx), _stream())
+    return dx
 
 
 def norm_apply(x2, G, R, mean, invstd, gamma, beta, act):
@@ -187,7 +223,7 @@ def norm_bwd(x2, dy, G, R, mean, invstd, gamma, beta, act):
     _chk(x2, dy)
     Cc = x2.shape[-1]
     P = _chunks(G, R, Cc)
-    part = empty((2, G * P, Cc), x2)
+    part = torch.empty((2, G * P, Cc), dtype=torch.float64, device=x2.device)
     s = empty((2, G, Cc), x2)
     dg = empty((Cc,), x2)
     db = empty((Cc,), x2)
@@ -201,7 +237,7 @@ def group_colsum(x2, G, R, scale):
     _chk(x2)
     Cc = x2.shape[-1]
     P = _chunks(G, R, Cc)
-    part = empty((G * P, Cc), x2)
+    part = torch.empty((G * P, Cc), dtype=torch.float64, device=x2.device)
     out = empty((G, Cc), x2)
     _call("ud_group_colsum", _p(x2), G, R, Cc, P, scale, _p(part), _p(out), _stream())
     return out
@@ -211,7 +247,7 @@ def group_coldot(a2, b2, G, R, scale=1.0):
     _chk(a2, b2)
     Cc = a2.shape[-1]
     P = _chunks(G, R, Cc)
-    part = empty((G * P, Cc), a2)
+    part = torch.empty((G * P, Cc), dtype=torch.float64, device=a2.device)
     out = empty((G, Cc), a2)
     _call("ud_group_coldot", _p(a2), _p(b2), G, R, Cc, P, scale, _p(part), _p(out), _stream())
     return out
@@ -251,7 +287,8 @@ def dwconv_bwd_weight(x, dy, K, stride, pad_t, pad_l):
     _, Ho, Wo, _ = dy.shape
     npix = N * Ho * Wo
     slabs = -(-(Cc // 4) // 256)
-    chunks = max(1, min(npix // 64 if npix >= 64 else 1, max(1, 1024 // slabs)))
+    rpi = max(1, 256 // (Cc // 4))
+    chunks = max(1, min(npix // 64 if npix >= 64 else 1, max(1, 512 // rpi)))
     parts = _call("ud_dwconv_bwd_weight_parts", Cc, chunks)
     part = empty((parts, K * K, Cc), x)
     dwt = empty((K * K, Cc), x)
@@ -340,7 +377,7 @@ def sfmix_bwd(spat, freq, alpha, dy, pool):
     _chk(spat, freq, alpha, dy)
     N, Ho, Wo, Cc = spat.shape
     nb = _call("ud_sfmix_blocks", N, Ho, Wo, Cc)
-    part = empty((nb,), spat)
+    part = torch.empty((nb,), dtype=torch.float64, device=spat.device)
     dspat = torch.empty_like(spat)
     dfreq = torch.empty_like(freq)
     dalpha = empty((), spat)
@@ -359,7 +396,7 @@ def gate_mix_fwd(p, q, alpha):
 def gate_mix_bwd(p, q, alpha, dy):
     _chk(p, q, alpha, dy)
     nb = _call("ud_gate_mix_blocks", p.numel())
-    part = empty((nb,), p)
+    part = torch.empty((nb,), dtype=torch.float64, device=p.device)
     dp = torch.empty_like(p)
     dq = torch.empty_like(p)
     dalpha = empty((), p)

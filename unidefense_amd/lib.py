@@ -37,6 +37,7 @@ _SIGNATURES = {
     "ud_norm_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "ud_norm_apply_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "ud_norm_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ud_norm_bwd_apply": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P],
     "ud_group_colsum": [_P, _I, _I, _I, _I, _F, _P, _P, _P],
     "ud_group_coldot": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "ud_dwconv_fwd": [_P, _P, _P] + [_I] * 10 + [_P],

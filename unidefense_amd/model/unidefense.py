@@ -104,6 +104,9 @@ class _NetFunction(torch.autograd.Function):
     def forward(ctx, model, x, rng, *params):
         tape = T.Tape()
         outs = model._run(x, tape, rng)
+        if getattr(model, "_debug_watch", False):            # tests: capture activation gradients
+            tape.watch = {id(t): k for k, t in outs["_feats"].items()}
+            model._debug_tape = tape
         ctx.tape = tape
         ctx.outs = outs
         ctx.params = params
@@ -223,8 +226,13 @@ class UniDefenseModelEb4(nn.Module):
         training = self.training
         if training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
+        # SyncBatchNorm semantics when a data-parallel wrapper set a process group, or when the container was
+        # converted by torch.nn.SyncBatchNorm.convert_sync_batchnorm (engine/forgery_engine.py:142)
+        group = getattr(self, "_sync_bn_group", None)
+        if group is None and isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_initialized():
+            group = bn.process_group or torch.distributed.group.WORLD
         return T.batchnorm_act(tape, x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                               bn.momentum if bn.momentum is not None else 0.1, training, act)
+                               bn.momentum if bn.momentum is not None else 0.1, training, act, group)
 
     def _mbconv(self, tape, x, blk, keep, keep_prob):
         """MBConvBlock.forward (model/efficientnet/model.py:94-135)."""
@@ -363,12 +371,12 @@ class UniDefenseModelEb4(nn.Module):
 
         x_b5 = self._blocks(tape, x_b4, 5, rng)
         att, freq_mask, spat_mask = self._attention(tape, dec3, x, x_b5, rng)
-        h = self._blocks(tape, att, 6, rng)
+        x_b6 = self._blocks(tape, att, 6, rng)
 
-        h = T.conv1x1(tape, h, bb._conv_head.weight)
+        h = T.conv1x1(tape, x_b6, bb._conv_head.weight)
         h = self._bn(tape, h, bb._bn1, 1)
-        feat = T.mean_hw(tape, h)                                        # [N,1792]
-        feat = self._bn(tape, feat, self.bottleneck, 0)
+        pooled = T.mean_hw(tape, h)                                      # [N,1792]
+        feat = self._bn(tape, pooled, self.bottleneck, 0)
         if self.training and self.drop_rate > 0:
             # in-place dropout in the reference: 'factorization' aliases the dropped tensor (:229-230)
             feat = T.dropout_mask(tape, feat, self._keep_mask(rng, "feat_keep", feat, 1.0 - self.drop_rate),
@@ -384,4 +392,6 @@ class UniDefenseModelEb4(nn.Module):
         return {"cls_out": cls_out, "rec": rec, "factorization": feat, "triplet0": t0, "triplet1": t1,
                 "triplet2": t2, "freq_mask": freq_mask, "spat_mask": spat_mask,
                 "spatial": spatial, "freq": freq,
-                "_feats": {"x_b4": x_b4, "x_b5": x_b5, "dec1": dec1, "dec2": dec2, "dec3": dec3}}
+                "_feats": {"x_b0": x_b0, "x_b1": x_b1, "x_b2": x_b2, "x_b3": x_b3, "x_b4": x_b4, "x_b5": x_b5,
+                           "dec1": dec1, "dec2": dec2, "dec3": dec3, "att_out": att, "x_b6": x_b6,
+                           "pooled": pooled}}

@@ -23,6 +23,8 @@ class Tape:
         self.grads = {}
         self.param_grads = {}
         self._keep = []          # keep keyed tensors alive so ids stay unique
+        self.watch = None        # debug: {id(tensor): name} -> gradients captured into self.captured
+        self.captured = {}
 
     # -- recording -------------------------------------------------------------------------
     def record(self, fn):
@@ -39,7 +41,10 @@ class Tape:
             self.grads[k] = K.axpby(cur, 1.0, g.reshape(cur.shape), 1.0)
 
     def pop_grad(self, t: torch.Tensor) -> Optional[torch.Tensor]:
-        return self.grads.pop(id(t), None)
+        g = self.grads.pop(id(t), None)
+        if self.watch is not None and id(t) in self.watch:
+            self.captured[self.watch[id(t)]] = g
+        return g
 
     def add_param_grad(self, p, g: torch.Tensor):
         cur = self.param_grads.get(p)
@@ -241,13 +246,42 @@ def sfconv_dw(tape, x, w, w_freq, alpha, stride, pad, norm):
 # ---------------------------------------------------------------------------------------------
 # normalisation + activation
 # ---------------------------------------------------------------------------------------------
-def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentum, training, act):
+def sync_batch_stats(mean_l, var_l, eps, group):
+    """Combine per-rank (mean, biased var) over equally sized shards into the global statistics:
+    mean = avg_r mean_r ;  var = avg_r (var_r + (mean_r - mean)^2).  One all_gather of 2C floats
+    (torch.nn.SyncBatchNorm's forward exchange; RCCL on GPU, gloo in the CPU tests)."""
+    import torch.distributed as dist
+    ws = dist.get_world_size(group)
+    mine = torch.cat([mean_l.reshape(-1), var_l.reshape(-1)])
+    flat = torch.empty(ws * mine.numel(), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    allst = flat.view(ws, mine.numel())
+    Cc = mean_l.numel()
+    means, vars_ = allst[:, :Cc], allst[:, Cc:]
+    mean = means.mean(0)
+    var = (vars_ + (means - mean) ** 2).mean(0)
+    return mean.view(1, Cc).contiguous(), var.view(1, Cc), torch.rsqrt(var + eps).view(1, Cc).contiguous()
+
+
+def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentum, training, act, sync_group=None):
     """nn.BatchNorm2d/1d (+ MemoryEfficientSwish when act=1) on pixel-major x[..., C]
-    (model/efficientnet/model.py:109-114,126; utils.py:66-82)."""
+    (model/efficientnet/model.py:109-114,126; utils.py:66-82).  With sync_group: SyncBatchNorm semantics
+    (statistics over the batches of all ranks; engine/forgery_engine.py:142)."""
     Cc = x.shape[-1]
     x2 = x.view(-1, Cc)
     R = x2.shape[0]
-    if training:
+    world = 1
+    if training and sync_group is not None:
+        import torch.distributed as dist
+        world = dist.get_world_size(sync_group)
+    if training and world > 1:
+        mean_l, var_l = K.norm_stats_local(x2, 1, R, eps)
+        mean, var, invstd = sync_batch_stats(mean_l, var_l, eps, sync_group)
+        if running_mean is not None:
+            n = float(R * world)
+            running_mean.mul_(1.0 - momentum).add_(mean.view(-1), alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_(var.view(-1), alpha=momentum * n / max(n - 1.0, 1.0))
+    elif training:
         mean, invstd = K.norm_stats(x2, 1, R, eps, momentum, running_mean, running_var)
     else:
         mean = running_mean.view(1, Cc)
@@ -261,7 +295,14 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
             dy = tape.pop_grad(y)
             if dy is None:
                 return
-            dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
+            if world > 1:
+                import torch.distributed as dist
+                s, dg, db = K.norm_bwd_sums(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
+                dist.all_reduce(s, group=sync_group)           # sum_dz, sum_dz_xhat over all ranks
+                dx = K.norm_bwd_apply(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, s,
+                                      1.0 / float(R * world), act)
+            else:
+                dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
             tape.add_grad(x, dx.view(x.shape))
             tape.add_param_grad(weight, dg)
             if bias.requires_grad:
