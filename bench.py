@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM timing table to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,30 +108,74 @@ def main():
         loss.backward()
         return loss
 
+    # ---- execution mode: the whole step (zero grads, forward, loss, backward [, gradient exchange]) is
+    # captured once into a hipGraph and replayed — ~2000 kernel launches per step with no host work between
+    # them.  Any capture failure falls back to eager launches (reported in "exec").
+    exec_mode = "eager"
+    run = step
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(1, min(args.warmup, 2))):      # eager warm-up (also sets kernel attributes, caches)
+            loss = step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if not args.eager:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step()
+            torch.cuda.synchronize()
+
+            def run():
+                graph.replay()
+                return static_loss
+            exec_mode = "hipgraph"
+        except Exception as e:      # noqa: BLE001 — keep the bench alive, say what happened
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            run = step
     for _ in range(args.warmup):
-        step()
+        loss = run()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    K.GEMM_PROFILE = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+    # ---- roofline of the dominant kernel: the same step, eager, every ud_gemm launch bracketed by HIP events
+    # on its launch stream (events cannot be read back from inside a replayed graph)
+    prof_steps = min(args.steps, 3)
+    K.GEMM_PROFILE = []
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
 
+    if rank == 0 and args.gemm_table:
+        agg = {}
+        for e0, e1, f, key in prof:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        with open(args.gemm_table, "w") as fh:
+            fh.write("M N K a_mode b_mode split batch | calls ms_total ms_per_step TFLOP/s\n")
+            for key, (cnt, ms, fl) in rows:
+                fh.write("%7d %5d %6d %d %d %3d %3d | %4d %8.3f %8.3f %7.1f\n" %
+                         (*key, cnt, ms, ms / prof_steps, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
     if rank == 0:
-        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-        gemm_flops = sum(f for _, _, f in prof)
+        gemm_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+        gemm_flops = sum(p[2] for p in prof)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         line = {
             "metric": "images/sec fwd+bwd (256x256, EffNet-b4)", "value": world * bs * args.steps / elapsed,
@@ -138,13 +184,15 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "UDEB4 (EfficientNet-b4 + SFConv) 256x256 fwd + pass-1 loss + bwd, "
                                    "spatial+frequency branches on, bs=32/GPU (BASELINE configs[1]/[2])",
-                       "global_batch": world * bs, "parallelism": f"dp{world}", "final_loss": float(loss)},
+                       "global_batch": world * bs, "parallelism": f"dp{world}", "exec": exec_mode,
+                       "final_loss": float(loss)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (ud_gemm, v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "launches_per_step": len(prof) / max(args.steps, 1),
-                         "gemm_ms_per_step": gemm_ms / max(args.steps, 1),
-                         "gemm_gflop_per_step": gemm_flops / 1e9 / max(args.steps, 1)},
+                         "launches_per_step": len(prof) / prof_steps,
+                         "gemm_ms_per_step": gemm_ms / prof_steps,
+                         "gemm_gflop_per_step": gemm_flops / 1e9 / prof_steps,
+                         "measured": f"{prof_steps} eager steps after the timed region, HIP events per launch"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

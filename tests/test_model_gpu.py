@@ -164,6 +164,8 @@ def test_train_grads_vs_oracle_elementwise(variant, n, seeds):
     dev = _dev()
     lam = ou.SMOOTH_LAMBDAS if variant == "smooth" else ou.LAMBDAS
     rtol = GRAD_RTOL if variant == "smooth" else FULL_RTOL
+    if n == 2:
+        rtol = max(rtol, 2e-3)      # batch statistics over TWO samples: the worst-conditioned case (see header)
     x = param_fill.make_input(n, 256, seeds[0])
     tgt = param_fill.make_labels(n)
     rng = ou.make_rng(n, seeds[1], 0.5)

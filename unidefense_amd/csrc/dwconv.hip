@@ -137,6 +137,66 @@ __global__ __launch_bounds__(NT) void dw_bwd_weight_partial(DwGeom q, int rpi, i
     for (int i = 0; i < K * K; ++i) out[(long)i * q.C4 + c4] = acc[i];
 }
 
+// Weight gradient, sliding-window form: one thread = one channel (lane = channel, 4-B coalesced accesses) and
+// a group of output rows.  Walking along an output row it keeps the K x K input window in registers, so each
+// output pixel costs 1 dy load + K*S new window loads instead of K*K.  part[(p * K*K + tap)][C].
+template <int K, int S>
+__global__ void dw_bwd_weight_rows(DwGeom q, int C, int rows_per_group, const float* __restrict__ x,
+                                   const float* __restrict__ dy, float* __restrict__ part) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int p = blockIdx.x;
+    const int rows_total = q.N * q.Ho;
+    const int row0 = p * rows_per_group;
+    int row1 = row0 + rows_per_group;
+    if (row1 > rows_total) row1 = rows_total;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int row = row0; row < row1; ++row) {
+        const int n = row / q.Ho, ho = row % q.Ho;
+        const int ih0 = ho * S - q.pad_t;
+        const float* xr[K];
+        bool vh[K];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = ih0 + kh;
+            vh[kh] = (ih >= 0) && (ih < q.H);
+            xr[kh] = x + (((long)n * q.H + (vh[kh] ? ih : 0)) * q.W) * C + c;
+        }
+        float w[K][K];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int iw = kw - q.pad_l;
+                w[kh][kw] = (vh[kh] && iw >= 0 && iw < q.W) ? xr[kh][(long)iw * C] : 0.f;
+            }
+        const float* dyr = dy + ((long)row * q.Wo) * C + c;
+        for (int wo = 0; wo < q.Wo; ++wo) {
+            const float g = dyr[(long)wo * C];
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) acc[kh * K + kw] += g * w[kh][kw];
+            // slide the window by S columns
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw + S < K; ++kw) w[kh][kw] = w[kh][kw + S];
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+                    const int iw = (wo + 1) * S - q.pad_l + (K - S) + j;
+                    w[kh][K - S + j] = (vh[kh] && iw >= 0 && iw < q.W) ? xr[kh][(long)iw * C] : 0.f;
+                }
+            }
+        }
+    }
+    float* out = part + (long)p * (K * K) * C + c;
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) out[(long)i * C] = acc[i];
+}
+
 // 16 outputs x 16 part-lanes per block; fp64 accumulation of the per-chunk partial sums
 __global__ __launch_bounds__(NT) void dw_bwd_weight_finalize(int nparts, int KKC, const float* __restrict__ part,
                                                              float* __restrict__ dwt) {
@@ -196,9 +256,8 @@ int ud_dwconv_bwd_data(const float* dy, const float* wt, float* dx, int N, int H
 
 // number of float partial rows (each K*K*C floats) the weight-gradient pass needs for `chunks` chunks
 int ud_dwconv_bwd_weight_parts(int C, int chunks) {
-    int C4 = C / 4;
-    int rpi = (C4 <= NT) ? NT / C4 : 1;
-    return chunks * rpi;
+    (void)C;
+    return chunks;      // one partial row of K*K*C floats per row-group
 }
 
 int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* part, int chunks, int N, int H, int W,
@@ -207,16 +266,19 @@ int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* par
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!geom_ok(q, K)) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    int rpi = (q.C4 <= NT) ? NT / q.C4 : 1;
-    long npix = (long)N * Ho * Wo;
-    int ppc = (int)((npix + chunks - 1) / chunks);
-    dim3 grid((unsigned)chunks, (unsigned)((q.C4 + NT - 1) / NT), 1);
-    // chunks beyond the pixel range write zeros (their loops are empty), so the finalize can sum all parts
-    if (K == 3) hipLaunchKernelGGL(dw_bwd_weight_partial<3>, grid, dim3(NT), 0, s, q, rpi, ppc, x, dy, part);
-    else hipLaunchKernelGGL(dw_bwd_weight_partial<5>, grid, dim3(NT), 0, s, q, rpi, ppc, x, dy, part);
+    const int rows_total = N * Ho;
+    if (chunks > rows_total) return UD_EINVAL;
+    const int rpg = (rows_total + chunks - 1) / chunks;     // output rows per group; trailing groups may be empty
+    int bt = ((C < NT ? C : NT) + 63) / 64 * 64;             // threads per block: whole waves covering min(C, 256)
+    dim3 grid((unsigned)chunks, (unsigned)ud_cdiv(C, bt), 1);
+    // groups beyond the row range write zeros (their loops are empty), so the finalize can sum all parts
+    if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_bwd_weight_rows<3, 1>), grid, dim3(bt), 0, s, q, C, rpg, x, dy, part);
+    else if (K == 3) hipLaunchKernelGGL((dw_bwd_weight_rows<3, 2>), grid, dim3(bt), 0, s, q, C, rpg, x, dy, part);
+    else if (stride == 1) hipLaunchKernelGGL((dw_bwd_weight_rows<5, 1>), grid, dim3(bt), 0, s, q, C, rpg, x, dy, part);
+    else hipLaunchKernelGGL((dw_bwd_weight_rows<5, 2>), grid, dim3(bt), 0, s, q, C, rpg, x, dy, part);
     UD_LAUNCH_CHECK();
     int KKC = K * K * C;
-    hipLaunchKernelGGL(dw_bwd_weight_finalize, dim3(ud_cdiv(KKC, 16)), dim3(NT), 0, s, chunks * rpi, KKC, part, dwt);
+    hipLaunchKernelGGL(dw_bwd_weight_finalize, dim3(ud_cdiv(KKC, 16)), dim3(NT), 0, s, chunks, KKC, part, dwt);
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -18,6 +18,7 @@ namespace {
 
 constexpr int BK = 16;
 constexpr int NTHREADS = 256;
+constexpr int PATCH_M = 4, PATCH_N = 8;   // output-tile patch owned by one XCD's 32 consecutive workgroups
 
 __device__ __forceinline__ void decode_row(const ud_conv_geom& g, int m, int M, int& nbase, int& ih0,
                                            int& iw0, bool& valid) {
@@ -88,7 +89,7 @@ struct Loader {
     int c_nbase[NV], c_ih0[NV], c_iw0[NV];
     bool c_valid[NV];
     int c_kh[NV], c_kw[NV], c_ci[NV];
-    f32x4 regs[NV];
+    f32x4 regs[2][NV];      // two prefetch stages (statically indexed: template <S>)
 
     __device__ __forceinline__ void init(const float* p, long ld_, int dim_, int K_, bool vec_,
                                          const ud_conv_geom& g_, int row0, int tid) {
@@ -118,7 +119,8 @@ struct Loader {
         }
     }
 
-    // issue the global loads of the tile whose first k is k0 (rows start at row0)
+    // issue the global loads of the tile whose first k is k0 (rows start at row0) into register stage S
+    template <int S>
     __device__ __forceinline__ void load(int row0, int k0, int k_end, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -191,12 +193,13 @@ struct Loader {
                     }
                 }
             }
-            regs[i] = v;
+            regs[S][i] = v;
         }
     }
 
-    // write the registers into the K-major LDS image  S[k][row]
-    __device__ __forceinline__ void store(float* S, int tid) const {
+    // write register stage S into the K-major LDS image  Sm[k][row]
+    template <int S>
+    __device__ __forceinline__ void store(float* Sm, int tid) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int f = tid + i * NTHREADS;
@@ -204,10 +207,10 @@ struct Loader {
                 if constexpr (KCONTIG) {
                     int row = f >> 2, kq = f & 3;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * LDS_LD + row] = regs[i][e];
+                    for (int e = 0; e < 4; ++e) Sm[(kq * 4 + e) * LDS_LD + row] = regs[S][i][e];
                 } else {
                     int kr = f / (ROWS / 4), q = f % (ROWS / 4);
-                    *reinterpret_cast<f32x4*>(&S[kr * LDS_LD + q * 4]) = regs[i];
+                    *reinterpret_cast<f32x4*>(&Sm[kr * LDS_LD + q * 4]) = regs[S][i];
                 }
             }
         }
@@ -215,7 +218,8 @@ struct Loader {
 };
 
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, int tiles_m, int a_vec, int b_vec) {
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, int tiles_m, int tiles_n, int a_vec,
+                                                        int b_vec) {
     static_assert(WGM * WGN == 4, "4 waves");
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     static_assert(TM >= 1 && TN >= 1, "tile");
@@ -229,7 +233,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    // XCD-aware rasterisation (speed only, never correctness): workgroups are dealt round-robin over the 8
+    // XCDs, each with a private 4 MiB L2.  The 32 consecutive workgroups that land on one XCD get a 4 x 8
+    // patch of output tiles, so they share 4 A-panels and 8 B-panels through that L2 instead of 32 + 32.
+    int tile_m, tile_n;
+    if (gridDim.x == (unsigned)(tiles_m * tiles_n)) {      // small grid: plain order (launcher decides)
+        tile_m = blockIdx.x % tiles_m;
+        tile_n = blockIdx.x / tiles_m;
+    } else {
+        const int patches_m = (tiles_m + PATCH_M - 1) / PATCH_M;
+        const int patches_n = (tiles_n + PATCH_N - 1) / PATCH_N;
+        const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+        const int patch = (i / (PATCH_M * PATCH_N)) * 8 + xcd, within = i % (PATCH_M * PATCH_N);
+        if (patch >= patches_m * patches_n) return;
+        tile_m = (patch % patches_m) * PATCH_M + (within % PATCH_M);
+        tile_n = (patch / patches_m) * PATCH_N + (within / PATCH_M);
+        if (tile_m >= tiles_m || tile_n >= tiles_n) return;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.y, bz = blockIdx.z;
 
@@ -257,25 +277,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Two-deep register prefetch: while tile t is multiplied out of LDS, the global loads of tiles t+1 and
+    // t+2 are in flight (each load has two K-tiles of MFMA time to land; with ~2 workgroups per CU one tile
+    // of lead did not cover an L2/MALL miss).  Stage (t & 1) holds tile t; the loop is unrolled by two so the
+    // stages stay statically indexed.
     if (nkt > 0) {
-        la.load(m0, k_begin, k_end, tid);
-        lb.load(n0, k_begin, k_end, tid);
-        la.store(As[0], tid);
-        lb.store(Bs[0], tid);
+        la.template load<0>(m0, k_begin, k_end, tid);
+        lb.template load<0>(n0, k_begin, k_end, tid);
+        la.template store<0>(As[0], tid);
+        lb.template store<0>(Bs[0], tid);
+        if (nkt > 1) {
+            la.template load<1>(m0, k_begin + BK, k_end, tid);
+            lb.template load<1>(n0, k_begin + BK, k_end, tid);
+        }
+        if (nkt > 2) {
+            la.template load<0>(m0, k_begin + 2 * BK, k_end, tid);
+            lb.template load<0>(n0, k_begin + 2 * BK, k_end, tid);
+        }
     }
     __syncthreads();
 
     const int a_col = wm * (TM * 32) + l31;
     const int b_col = wn * (TN * 32) + l31;
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = (kt + 1 < nkt);
-        if (more) {
-            la.load(m0, k_begin + (kt + 1) * BK, k_end, tid);
-            lb.load(n0, k_begin + (kt + 1) * BK, k_end, tid);
-        }
-        const float* Ab = As[cur];
-        const float* Bb = Bs[cur];
+    auto multiply = [&](const float* Ab, const float* Bb) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[TM], b[TN];
@@ -289,12 +313,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            la.store(As[cur ^ 1], tid);
-            lb.store(Bs[cur ^ 1], tid);
+    };
+    for (int kt = 0; kt < nkt;) {
+        // even tile: multiply LDS buffer 0; stage 1 (tile kt+1) -> LDS buffer 1; refill stage 1 with tile kt+3
+        multiply(As[0], Bs[0]);
+        if (kt + 1 < nkt) {
+            la.template store<1>(As[1], tid);
+            lb.template store<1>(Bs[1], tid);
+        }
+        if (kt + 3 < nkt) {
+            la.template load<1>(m0, k_begin + (kt + 3) * BK, k_end, tid);
+            lb.template load<1>(n0, k_begin + (kt + 3) * BK, k_end, tid);
         }
         __syncthreads();
-        cur ^= 1;
+        if (++kt >= nkt) break;
+        // odd tile: multiply LDS buffer 1; stage 0 (tile kt+1) -> LDS buffer 0; refill stage 0 with tile kt+3
+        multiply(As[1], Bs[1]);
+        if (kt + 1 < nkt) {
+            la.template store<0>(As[0], tid);
+            lb.template store<0>(Bs[0], tid);
+        }
+        if (kt + 3 < nkt) {
+            la.template load<0>(m0, k_begin + (kt + 3) * BK, k_end, tid);
+            lb.template load<0>(n0, k_begin + (kt + 3) * BK, k_end, tid);
+        }
+        __syncthreads();
+        ++kt;
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -322,18 +366,56 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
 int launch_cfg(const ud_gemm_desc& d, int a_vec, int b_vec, hipStream_t s) {
     int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
-    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, (unsigned)d.batch);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, AMODE, BMODE>), grid, dim3(NTHREADS), 0, s, d, tiles_m,
+    // XCD patch order only pays (and only keeps its padding small) on grids of several hundred tiles
+    unsigned gx = (unsigned)(tiles_m * tiles_n);
+    if (tiles_m * tiles_n >= 256) {
+        int patches = ud_cdiv(tiles_m, PATCH_M) * ud_cdiv(tiles_n, PATCH_N);
+        unsigned padded = (unsigned)(ud_cdiv(patches, 8) * 8 * PATCH_M * PATCH_N);
+        if (padded != gx) gx = padded;      // (equal sizes would be read as 'plain order' by the kernel: fine too)
+    }
+    dim3 grid(gx, (unsigned)d.split_k, (unsigned)d.batch);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, AMODE, BMODE>), grid, dim3(NTHREADS), 0, s, d, tiles_m, tiles_n,
                        a_vec, b_vec);
     UD_LAUNCH_CHECK();
     return 0;
 }
 
+// Tile choice.  The fp32 matrix pipe is the bound, so a launch lasts about
+//   ceil(tiles / 256 CUs) x (padded work of one tile) x (relative inefficiency of that tile shape).
+// E.g. M=1280, N=3264 is 260 tiles of 128x128 (two rounds, 51 % of the chip) but 510 tiles of 128x64 (one
+// round of two co-resident blocks per CU); a weight gradient with Cout = 3..32 rows wants a 32-row tile.
+struct TileCfg { int bm, bn; double penalty; };
+// penalties fitted to tools/bench_gemm.py on MI355X: the half-size tiles run as fast per flop as 128x128 at
+// 4096^3 and up to 25 % faster on the mid-size shapes of this model (more workgroups per CU hide the loads)
+constexpr TileCfg kCfgs[5] = {{128, 128, 1.00}, {128, 64, 0.93}, {256, 32, 1.10}, {32, 256, 1.10}, {64, 128, 0.93}};
+
+inline int choose_cfg(const ud_gemm_desc& d) {
+    static const int forced = [] {            // tuning aid: UD_GEMM_CFG=0..4 pins the tile configuration
+        const char* e = getenv("UD_GEMM_CFG");
+        return (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : -1;
+    }();
+    if (forced >= 0) return forced;
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < 5; ++i) {
+        const TileCfg& c = kCfgs[i];
+        long tiles = (long)ud_cdiv(d.M, c.bm) * ud_cdiv(d.N, c.bn) * d.split_k * d.batch;
+        long rounds = (tiles + 255) / 256;
+        double cost = (double)rounds * c.bm * c.bn * c.penalty;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
+}
+
 template <int AMODE, int BMODE>
 int launch_modes(const ud_gemm_desc& d, int a_vec, int b_vec, hipStream_t s) {
-    if (d.N <= 32) return launch_cfg<256, 32, 4, 1, AMODE, BMODE>(d, a_vec, b_vec, s);
-    if (d.N <= 64) return launch_cfg<128, 64, 2, 2, AMODE, BMODE>(d, a_vec, b_vec, s);
-    return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(d, a_vec, b_vec, s);
+    switch (choose_cfg(d)) {
+        case 1: return launch_cfg<128, 64, 2, 2, AMODE, BMODE>(d, a_vec, b_vec, s);
+        case 2: return launch_cfg<256, 32, 4, 1, AMODE, BMODE>(d, a_vec, b_vec, s);
+        case 3: return launch_cfg<32, 256, 1, 4, AMODE, BMODE>(d, a_vec, b_vec, s);
+        case 4: return launch_cfg<64, 128, 2, 2, AMODE, BMODE>(d, a_vec, b_vec, s);
+        default: return launch_cfg<128, 128, 2, 2, AMODE, BMODE>(d, a_vec, b_vec, s);
+    }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -63,7 +63,7 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
         e0.record()
         _call("ud_gemm", C.byref(d), _stream())
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch))
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, a_mode, b_mode, split_k, batch)))
         return Cout
     _call("ud_gemm", C.byref(d), _stream())
     return Cout
@@ -76,6 +76,10 @@ def gemm_nt(a, w, out=None, accumulate=False):
     N = w.shape[0]
     assert w.shape[1] == K
     if out is None:
+        split = _fwd_split(M, N, K)
+        if split > 1:
+            out = torch.zeros((M, N), dtype=torch.float32, device=a.device)
+            return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 2, split)
         out = empty((M, N), a)
     return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 1 if accumulate else 0)
 
@@ -87,22 +91,44 @@ def gemm_nn(a, w, out=None, accumulate=False):
     N = w.shape[1]
     assert w.shape[0] == K
     if out is None:
+        split = _fwd_split(M, N, K)
+        if split > 1:
+            out = torch.zeros((M, N), dtype=torch.float32, device=a.device)
+            return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 2, split)
         out = empty((M, N), a)
     return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if accumulate else 0)
 
 
 def _pick_split(tiles, K):
-    """split-K factor for a weight-gradient GEMM whose reduction runs over K pixels."""
-    if tiles >= 512 or K < 1024:
+    """split-K factor for a weight-gradient GEMM whose reduction runs over K pixels: enough workgroups to
+    fill 256 CUs about three times over, at least 256 reduction rows per split."""
+    if tiles >= 512 or K < 512:
         return 1
-    s = min(max(1, K // 512), -(-768 // tiles))
-    return max(1, min(s, 256))
+    s = min(max(1, K // 256), -(-768 // tiles))
+    return max(1, min(s, 1024))
+
+
+_TILE_CFGS = ((128, 128, 1.00), (128, 64, 0.93), (256, 32, 1.10), (32, 256, 1.10), (64, 128, 0.93))
+
+
+def _fwd_split(M, N, K):
+    """split-K for a forward / data-gradient GEMM too small to fill the chip (e.g. the 8x8-resolution
+    expand/project convs: M = 2048, 80 tiles for 256 CUs)."""
+    t = _tiles(M, N)
+    if t >= 128 or K < 1024:
+        return 1
+    return max(1, min(K // 256, -(-320 // t)))
 
 
 def _tiles(M, N):
-    bn = 32 if N <= 32 else (64 if N <= 64 else 128)
-    bm = 256 if N <= 32 else 128
-    return -(-M // bm) * -(-N // bn)
+    """Tile count of the configuration gemm.hip:choose_cfg picks for an unsplit launch."""
+    best, best_tiles = None, 1
+    for bm, bn, pen in _TILE_CFGS:
+        t = -(-M // bm) * -(-N // bn)
+        cost = -(-t // 256) * bm * bn * pen
+        if best is None or cost < best:
+            best, best_tiles = cost, t
+    return best_tiles
 
 
 def gemm_tn(a, b):
@@ -285,10 +311,8 @@ def dwconv_bwd_weight(x, dy, K, stride, pad_t, pad_l):
     _chk(x, dy)
     N, H, W, Cc = x.shape
     _, Ho, Wo, _ = dy.shape
-    npix = N * Ho * Wo
-    slabs = -(-(Cc // 4) // 256)
-    rpi = max(1, 256 // (Cc // 4))
-    chunks = max(1, min(npix // 64 if npix >= 64 else 1, max(1, 512 // rpi)))
+    # one thread per (channel, group of output rows): aim at >= ~128k threads, at most one group per row
+    chunks = max(1, min(N * Ho, -(-131072 // Cc)))
     parts = _call("ud_dwconv_bwd_weight_parts", Cc, chunks)
     part = empty((parts, K * K, Cc), x)
     dwt = empty((K * K, Cc), x)
