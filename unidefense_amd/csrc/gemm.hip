@@ -16,7 +16,8 @@
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;                 // K-tile depth (two K-tiles of MFMA work cover one prefetch)
+constexpr int KQ = BK / 4;             // float4 per K-contiguous tile row
 constexpr int NTHREADS = 256;
 constexpr int PATCH_M = 4, PATCH_N = 8;   // output-tile patch owned by one XCD's 32 consecutive workgroups
 
@@ -77,28 +78,33 @@ struct Loader {
     static constexpr bool KCONTIG = (MODE == 0) || (MODE == 2 && !IS_B);
     static constexpr int TOTAL_V = ROWS * BK / 4;                     // float4 in one tile
     static constexpr int NV = (TOTAL_V + NTHREADS - 1) / NTHREADS;    // per thread
-    static constexpr int LDS_LD = ROWS + 4;
+    // LDS row stride of the K-major image S[k][row].  K-contiguous operands are transposed on the way in with
+    // 4-byte stores  S[4*kq + e][row]  (kq = 0..7 across lanes): a stride == 1 (mod 8) puts the 32 lanes of a
+    // store on 32 different banks (stride ROWS + 4 was a 4-way conflict: SQ_LDS_BANK_CONFLICT = 50 % of the
+    // LDS cycles).  Row-contiguous operands are stored 16 bytes at a time and need a multiple of 4.
+    static constexpr int LDS_LD = KCONTIG ? ROWS + 1 : ROWS + 4;
 
     const float* base;
     long ld;
     int dim;        // number of valid rows (M or N)
     int K;
     bool vec;       // 16-byte loads allowed
+    bool skip;      // tuning aid (UD_GEMM_NOLOAD): issue no global loads, feed zeros
     ud_conv_geom g;
     // per-thread cached gather state
     int c_nbase[NV], c_ih0[NV], c_iw0[NV];
     bool c_valid[NV];
     int c_kh[NV], c_kw[NV], c_ci[NV];
-    f32x4 regs[2][NV];      // two prefetch stages (statically indexed: template <S>)
+    f32x4 regs[NV];
 
     __device__ __forceinline__ void init(const float* p, long ld_, int dim_, int K_, bool vec_,
                                          const ud_conv_geom& g_, int row0, int tid) {
-        base = p; ld = ld_; dim = dim_; K = K_; vec = vec_; g = g_;
+        base = p; ld = ld_; dim = dim_; K = K_; vec = vec_; g = g_; skip = false;
         if constexpr (MODE == 2 && !IS_B) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 int f = tid + i * NTHREADS;
-                int row = f >> 2;
+                int row = f / KQ;
                 decode_row(g, row0 + row, dim, c_nbase[i], c_ih0[i], c_iw0[i], c_valid[i]);
                 c_valid[i] = c_valid[i] && (f < TOTAL_V);
             }
@@ -119,15 +125,15 @@ struct Loader {
         }
     }
 
-    // issue the global loads of the tile whose first k is k0 (rows start at row0) into register stage S
-    template <int S>
+    // issue the global loads of the tile whose first k is k0 (rows start at row0)
     __device__ __forceinline__ void load(int row0, int k0, int k_end, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int f = tid + i * NTHREADS;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (skip) { regs[i] = v; continue; }
             if constexpr (MODE == 0) {
-                int row = f >> 2, kq = f & 3;
+                int row = f / KQ, kq = f % KQ;
                 int r = row0 + row, k = k0 + kq * 4;
                 if (f < TOTAL_V && r < dim && k < k_end) {
                     const float* p = base + (long)r * ld + k;
@@ -149,7 +155,7 @@ struct Loader {
                     }
                 }
             } else if constexpr (MODE == 2 && !IS_B) {
-                int kq = f & 3;
+                int kq = f % KQ;
                 int k = k0 + kq * 4;
                 if (c_valid[i] && k < k_end) {
                     if (vec) {   // Cin % 4 == 0: the 4 k's share one tap
@@ -193,24 +199,23 @@ struct Loader {
                     }
                 }
             }
-            regs[S][i] = v;
+            regs[i] = v;
         }
     }
 
-    // write register stage S into the K-major LDS image  Sm[k][row]
-    template <int S>
-    __device__ __forceinline__ void store(float* Sm, int tid) const {
+    // write the registers into the K-major LDS image  S[k][row]
+    __device__ __forceinline__ void store(float* S, int tid) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int f = tid + i * NTHREADS;
             if (f < TOTAL_V) {
                 if constexpr (KCONTIG) {
-                    int row = f >> 2, kq = f & 3;
+                    int row = f / KQ, kq = f % KQ;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) Sm[(kq * 4 + e) * LDS_LD + row] = regs[S][i][e];
+                    for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * LDS_LD + row] = regs[i][e];
                 } else {
                     int kr = f / (ROWS / 4), q = f % (ROWS / 4);
-                    *reinterpret_cast<f32x4*>(&Sm[kr * LDS_LD + q * 4]) = regs[S][i];
+                    *reinterpret_cast<f32x4*>(&S[kr * LDS_LD + q * 4]) = regs[i];
                 }
             }
         }
@@ -266,8 +271,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
     float* Cp = d.C + (long)bz * d.strideC;
 
     LA la; LB lb;
-    la.init(Ap, d.lda, d.M, d.K, a_vec != 0, d.g, m0, tid);
-    lb.init(Bp, d.ldb, d.N, d.K, b_vec != 0, d.g, n0, tid);
+    la.init(Ap, d.lda, d.M, d.K, (a_vec & 1) != 0, d.g, m0, tid);
+    la.skip = (a_vec & 2) != 0;
+    lb.init(Bp, d.ldb, d.N, d.K, (b_vec & 1) != 0, d.g, n0, tid);
+    lb.skip = (a_vec & 2) != 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -277,68 +284,62 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Two-deep register prefetch: while tile t is multiplied out of LDS, the global loads of tiles t+1 and
-    // t+2 are in flight (each load has two K-tiles of MFMA time to land; with ~2 workgroups per CU one tile
-    // of lead did not cover an L2/MALL miss).  Stage (t & 1) holds tile t; the loop is unrolled by two so the
-    // stages stay statically indexed.
     if (nkt > 0) {
-        la.template load<0>(m0, k_begin, k_end, tid);
-        lb.template load<0>(n0, k_begin, k_end, tid);
-        la.template store<0>(As[0], tid);
-        lb.template store<0>(Bs[0], tid);
-        if (nkt > 1) {
-            la.template load<1>(m0, k_begin + BK, k_end, tid);
-            lb.template load<1>(n0, k_begin + BK, k_end, tid);
-        }
-        if (nkt > 2) {
-            la.template load<0>(m0, k_begin + 2 * BK, k_end, tid);
-            lb.template load<0>(n0, k_begin + 2 * BK, k_end, tid);
-        }
+        la.load(m0, k_begin, k_end, tid);
+        lb.load(n0, k_begin, k_end, tid);
+        la.store(As[0], tid);
+        lb.store(Bs[0], tid);
     }
     __syncthreads();
 
     const int a_col = wm * (TM * 32) + l31;
     const int b_col = wn * (TN * 32) + l31;
-    auto multiply = [&](const float* Ab, const float* Bb) {
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1 < nkt);
+        if (more) {
+            la.load(m0, k_begin + (kt + 1) * BK, k_end, tid);
+            lb.load(n0, k_begin + (kt + 1) * BK, k_end, tid);
+        }
+        const float* Ab = As[cur];
+        const float* Bb = Bs[cur];
+        // The MFMA operands of k-pair p + FD are read from LDS while k-pair p is multiplied (a ring of FD
+        // fragment sets, statically indexed): without it every pair of MFMAs waited out a full LDS round trip
+        // (rocprofv3: matrix pipe 43 % busy, SQ_WAIT_INST_ANY 58 %).
+        constexpr int NP = BK / 2, FD = 4;
+        float fa[FD][TM], fb[FD][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+        for (int p = 0; p < FD; ++p) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ab[(kk + half) * LA::LDS_LD + a_col + i * 32];
+            for (int i = 0; i < TM; ++i) fa[p][i] = Ab[(2 * p + half) * LA::LDS_LD + a_col + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bb[(kk + half) * LB::LDS_LD + b_col + j * 32];
+            for (int j = 0; j < TN; ++j) fb[p][j] = Bb[(2 * p + half) * LB::LDS_LD + b_col + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int s = p % FD;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+            if (p + FD < NP) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[s][i] = Ab[(2 * (p + FD) + half) * LA::LDS_LD + a_col + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[s][j] = Bb[(2 * (p + FD) + half) * LB::LDS_LD + b_col + j * 32];
+                // scheduling barrier: keeps these ds_reads HERE (hipcc otherwise sinks each read down to its
+                // first use, which re-serialises read -> wait -> MFMA)
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-    };
-    for (int kt = 0; kt < nkt;) {
-        // even tile: multiply LDS buffer 0; stage 1 (tile kt+1) -> LDS buffer 1; refill stage 1 with tile kt+3
-        multiply(As[0], Bs[0]);
-        if (kt + 1 < nkt) {
-            la.template store<1>(As[1], tid);
-            lb.template store<1>(Bs[1], tid);
-        }
-        if (kt + 3 < nkt) {
-            la.template load<1>(m0, k_begin + (kt + 3) * BK, k_end, tid);
-            lb.template load<1>(n0, k_begin + (kt + 3) * BK, k_end, tid);
-        }
-        __syncthreads();
-        if (++kt >= nkt) break;
-        // odd tile: multiply LDS buffer 1; stage 0 (tile kt+1) -> LDS buffer 0; refill stage 0 with tile kt+3
-        multiply(As[1], Bs[1]);
-        if (kt + 1 < nkt) {
-            la.template store<0>(As[0], tid);
-            lb.template store<0>(Bs[0], tid);
-        }
-        if (kt + 3 < nkt) {
-            la.template load<0>(m0, k_begin + (kt + 3) * BK, k_end, tid);
-            lb.template load<0>(n0, k_begin + (kt + 3) * BK, k_end, tid);
+        if (more) {
+            la.store(As[cur ^ 1], tid);
+            lb.store(Bs[cur ^ 1], tid);
         }
         __syncthreads();
-        ++kt;
+        cur ^= 1;
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -445,6 +446,8 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         if (d.a_mode == 2 && (rows != d.M || cols != d.K)) return UD_EINVAL;
         if (d.b_mode == 2 && (rows != d.K || cols != d.N)) return UD_EINVAL;
     }
+    static const bool noload = getenv("UD_GEMM_NOLOAD") != nullptr;
+    if (noload) a_vec |= 2;
     if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0>(d, a_vec, b_vec, s);
     if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1>(d, a_vec, b_vec, s);
     if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1>(d, a_vec, b_vec, s);
