@@ -189,6 +189,23 @@ int ud_dynfilter_bwd(const float* dout, const float* dmask_ext, const float* x, 
                      const int* argmax, const float* w2, float* dx, float* dlogit, float* dproj, int M,
                      int C, int Cx, ud_stream_t stream);
 
+/* ---- ResNet-variant helpers (model/resnet/module_exp.py, model/resnet/exp.py) ------------------------
+ * ud_avgpool_*    : k x k average pool to [N][Ho][Wo][C] (F.adaptive_avg_pool2d to size/k, module_exp.py:30-31)
+ * ud_maxpool3s2_* : nn.MaxPool2d(3, 2, 1) with the winning tap per output in arg (module_exp.py:73-75)
+ * ud_add_act_fwd  : y = act(a + b) (act 0 / 2 = ReLU) — `x += shortcut; act(x)` (resnet/exp.py:146-147)
+ * ud_relu_bwd     : g = dy * [y > 0]
+ * ud_copy_cols    : dir 0: wide[m][off..off+Cn) = narrow[m][:] (torch.cat(dim=1), module_exp.py:32);
+ *                   dir 1: the reverse (slice = gradient of the concat) */
+int ud_avgpool_fwd(const float* x, float* y, int N, int Ho, int Wo, int C, int k, ud_stream_t stream);
+int ud_avgpool_bwd(const float* dy, float* dx, int N, int Ho, int Wo, int C, int k, ud_stream_t stream);
+int ud_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int N, int H, int W, int C,
+                      ud_stream_t stream);
+int ud_maxpool3s2_bwd(const float* dy, const unsigned char* arg, float* dx, int N, int H, int W, int C,
+                      ud_stream_t stream);
+int ud_add_act_fwd(const float* a, const float* b, int act, float* y, long total, ud_stream_t stream);
+int ud_relu_bwd(const float* dy, const float* y, float* g, long total, ud_stream_t stream);
+int ud_copy_cols(float* narrow, float* wide, long M, int Cn, int Cw, int off, int dir, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

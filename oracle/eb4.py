@@ -209,10 +209,16 @@ def decoder_block(x: Tensor, sd: Dict[str, Tensor], prefix: str, last: bool) -> 
 
 def dynamic_filter(x: Tensor, diff: Tensor, sd: Dict[str, Tensor], prefix: str, training: bool,
                    pad: int) -> Dict[str, Tensor]:
+    """The EfficientNet model's filters use MemoryEfficientSwish (model/unidefense.py:56,115-118)."""
+    return dynamic_filter_generic(x, diff, sd, prefix, training, pad, swish)
+
+
+def dynamic_filter_generic(x: Tensor, diff: Tensor, sd: Dict[str, Tensor], prefix: str, training: bool,
+                           pad: int, act) -> Dict[str, Tensor]:
     """FrequencyDynamicFilter / SpatialDynamicFilter .forward (model/modules.py:91-105, 120-134).
     att_norm = nn.BatchNorm2d with default eps 1e-5 (unidefense.py:55)."""
     p = F.conv2d(x, sd[prefix + ".layer1.0.weight"], None, 1, pad)
-    p = swish(batch_norm(p, sd, prefix + ".layer1.1", training, 1e-5))
+    p = act(batch_norm(p, sd, prefix + ".layer1.1", training, 1e-5))
     pre = torch.cat([p.mean(1, keepdim=True), p.max(1, keepdim=True).values, diff], dim=1)
     mask = torch.sigmoid(F.conv2d(pre, sd[prefix + ".layer2.0.weight"]))
     return {"mask": mask, "out": mask * x, "proj": p}

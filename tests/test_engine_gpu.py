@@ -1,0 +1,84 @@
+"""GPU parity, step level: AbstractEngine.train_unidefense_model (two passes, two AdamW(amsgrad) steps) on the
+HIP model against the vectors recorded from the REFERENCE's engine (tests/golden/udeb4_step_n4.npz,
+oracle/make_golden_step.py): same seeded inputs / parameters / Bernoulli masks, pass-2 perturbation forced
+to `downscale`.
+
+Compared: the ten returned loss scalars and the pass-1 logits (1e-3 relative), and the parameter updates.
+The first Adam steps are sign-like (update ~ lr * g/|g|), so a parameter whose gradient is rounding noise
+(e.g. the bias of a BN that only feeds other batch-stat BNs: true gradient 0) moves by +-lr with a random
+sign in ANY implementation; the update check therefore asks for >= 97 % of the recorded leading elements to
+agree within 1e-3 * lr-scale and for the update norms to agree within 2e-3 on >= 97 % of the tensors.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import param_fill
+from tests import oracle_util as ou
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag,cur_step", [("early", 1), ("kl", 50)])
+def test_two_pass_step_vs_reference_golden(golden_dir, tag, cur_step):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    from unidefense_amd.engine import AbstractEngine
+    from unidefense_amd.engine.optim import build_optimizer
+    from unidefense_amd.loss import LOSSES
+    from unidefense_amd.model import load_model, perturb
+
+    g = np.load(os.path.join(golden_dir, "udeb4_step_n4.npz"))
+    n, size, in_seed, mask_seed, num_steps = [int(v) for v in g["meta"]]
+    m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev).train()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    x = param_fill.make_input(n, size, in_seed).to(dev)
+    tgt = param_fill.make_labels(n).to(dev)
+    m.rng_queue = [ou.make_rng(n, mask_seed, 0.5), ou.make_rng(n, mask_seed + 1, 0.5)]
+
+    eng = AbstractEngine({"config": dict(ou.LAMBDAS)})
+    eng.model, eng.device = m, dev
+    eng.num_steps, eng.warmup_step = num_steps, 0
+    eng.optimizer = build_optimizer(m, dict(name="adamw", lr=1e-4, betas=[0.9, 0.999], weight_decay=5e-6, amsgrad=True))
+    eng.scheduler = torch.optim.lr_scheduler.StepLR(eng.optimizer, step_size=22500, gamma=0.5)
+    eng.loss_criterion = {"softmax": LOSSES["cross_entropy"], "triplet": LOSSES["aw_triplet"],
+                          "kl_div": LOSSES["kl_div"], "fac": LOSSES["factorization"]}
+    orig = perturb.perturb_input
+    perturb.perturb_input = lambda x_, a, b, c: perturb.downscale(x_)      # forced choice, like the golden
+    try:
+        scaler = torch.amp.GradScaler("cuda", init_scale=2 ** 10, enabled=False)
+        eng.optimizer.zero_grad()
+        ret = eng.train_unidefense_model(x, tgt, cur_step, scaler, n // 2, n // 2)
+    finally:
+        perturb.perturb_input = orig
+    bad = []
+    for k, v in ret.items():
+        key = ("out_" if k == "cls_out" else "loss_") + k
+        ref = np.asarray(g[f"{tag}_{key}"], dtype=np.float64)
+        got = v.detach().double().cpu().numpy()
+        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+        print(f"  {k}: rel err {err:.3e}")
+        if not err <= 1e-3:
+            bad.append((k, err))
+    assert not bad, bad
+    names = [str(s) for s in g[f"{tag}_names"]]
+    params = dict(m.named_parameters())
+    norm_ok, elem_ok, elem_tot = 0, 0, 0
+    for i, k in enumerate(names):
+        d = (params[k].detach() - before[k]).double().cpu()
+        rn = float(g[f"{tag}_delta_norms"][i])
+        if abs(d.norm().item() - rn) <= 2e-3 * rn + 1e-12:
+            norm_ok += 1
+        head = d.flatten()[:8].numpy()
+        ref = g[f"{tag}_delta_heads"][i][: head.size]
+        scale = max(np.abs(ref).max(), 1e-12)
+        elem_ok += int((np.abs(head - ref) <= 1e-3 * scale + 1e-9).sum())
+        elem_tot += head.size
+    print(f"  update norms within 2e-3: {norm_ok}/{len(names)};  leading elements within 1e-3: {elem_ok}/{elem_tot}")
+    assert norm_ok >= 0.97 * len(names)
+    assert elem_ok >= 0.97 * elem_tot

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NT) void colreduce_partial(RedGeom q, const float* 
                 for (int e = 0; e < 4; ++e) {
                     float xh = (a[e] - mu[e]) * is[e];
                     float dz = dy[e];
-                    if (act == 1) dz *= ud_swish_grad(ga[e] * xh + be[e]);
+                    if (act) dz *= ud_act_grad(ga[e] * xh + be[e], act);
                     v[e] += (double)dz;
                     v[4 + e] += (double)dz * (double)xh;
                 }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT) void norm_apply_fwd(long total4, int R, int C4,
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float z = ga[k] * ((a[k] - mu[k]) * is[k]) + be[k];
-            o[k] = (act == 1) ? ud_swish(z) : z;
+            o[k] = ud_act(z, act);
         }
         y4[e] = o;
     }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NT) void norm_apply_bwd(long total4, int R, int C4,
         for (int k = 0; k < 4; ++k) {
             float xh = (a[k] - mu[k]) * is[k];
             float dz = d[k];
-            if (act == 1) dz *= ud_swish_grad(ga[k] * xh + be[k]);
+            if (act) dz *= ud_act_grad(ga[k] * xh + be[k], act);
             o[k] = ga[k] * is[k] * (dz - t1[k] * invR - xh * t2[k] * invR);
         }
         dx4[e] = o;

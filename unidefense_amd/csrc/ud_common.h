@@ -24,6 +24,14 @@ __device__ __forceinline__ float ud_swish_grad(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 
+// act: 0 identity, 1 swish, 2 ReLU
+__device__ __forceinline__ float ud_act(float z, int act) {
+    return act == 1 ? ud_swish(z) : (act == 2 ? fmaxf(z, 0.f) : z);
+}
+__device__ __forceinline__ float ud_act_grad(float z, int act) {
+    return act == 1 ? ud_swish_grad(z) : (act == 2 ? (z > 0.f ? 1.f : 0.f) : 1.f);
+}
+
 // wave64 all-reduce (sum) via DPP-free shuffles
 __device__ __forceinline__ float ud_wave_sum(float v) {
 #pragma unroll

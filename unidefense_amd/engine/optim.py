@@ -1,0 +1,37 @@
+"""Optimizer wiring of the reference's engines (engine/forgery_engine.py:149-156): weight-decay parameter
+groups as timm's ``param_groups_weight_decay`` builds them, AdamW(amsgrad) and StepLR from the YAML keys.
+The optimizer itself stays torch's (host-side torch AdamW is acceptable; a fused
+multi-tensor HIP AdamW is row (f)2)."""
+import torch
+
+
+def param_groups_weight_decay(model, weight_decay=1e-5, no_weight_decay_list=()):
+    """No decay for 1-D / scalar tensors, '.bias' and listed names; frozen parameters are skipped
+    (timm 0.9.16 semantics)."""
+    no_weight_decay_list = set(no_weight_decay_list)
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.ndim <= 1 or name.endswith(".bias") or name in no_weight_decay_list:
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+OPTIMIZERS = {"adamw": torch.optim.AdamW, "adam": torch.optim.Adam, "sgd": torch.optim.SGD}
+
+
+def get_optimizer(name, params, **kwargs):
+    return OPTIMIZERS[name.lower()](params, **kwargs)
+
+
+def build_optimizer(model, opt_cfg):
+    """opt_cfg: the YAML's config.optimizer dict (name, weight_decay, lr, betas, amsgrad, ...)."""
+    cfg = dict(opt_cfg)
+    name = cfg.pop("name")
+    wd = cfg.pop("weight_decay", 0.0)
+    if "betas" in cfg:
+        cfg["betas"] = tuple(cfg["betas"])
+    return get_optimizer(name, param_groups_weight_decay(model, wd), **cfg)

@@ -609,3 +609,78 @@ def dft_rfft2_planes_adjoint(dY, S, ortho=True):
     dd = gemm_nn(dt_re, fw_cos)                     # [P*S, Whp] @ [Whp, S]
     gemm_nn(dt_im, fw_sin, out=dd, accumulate=True)
     return dd.view(P, S, S)
+
+
+# ---------------------------------------------------------------------------------------------
+# ResNet-variant helpers (pool.hip)
+# ---------------------------------------------------------------------------------------------
+def avgpool_fwd(x, k):
+    _chk(x)
+    N, H, W, Cc = x.shape
+    assert H % k == 0 and W % k == 0
+    y = empty((N, H // k, W // k, Cc), x)
+    _call("ud_avgpool_fwd", _p(x), _p(y), N, H // k, W // k, Cc, k, _stream())
+    return y
+
+
+def avgpool_bwd(dy, k):
+    _chk(dy)
+    N, Ho, Wo, Cc = dy.shape
+    dx = empty((N, Ho * k, Wo * k, Cc), dy)
+    _call("ud_avgpool_bwd", _p(dy), _p(dx), N, Ho, Wo, Cc, k, _stream())
+    return dx
+
+
+def maxpool3s2_fwd(x):
+    _chk(x)
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = empty((N, Ho, Wo, Cc), x)
+    arg = torch.empty((N, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
+    _call("ud_maxpool3s2_fwd", _p(x), _p(y), C.c_void_p(arg.data_ptr()), N, H, W, Cc, _stream())
+    return y, arg
+
+
+def maxpool3s2_bwd(dy, arg, H, W):
+    _chk(dy)
+    N, _, _, Cc = dy.shape
+    dx = empty((N, H, W, Cc), dy)
+    _call("ud_maxpool3s2_bwd", _p(dy), C.c_void_p(arg.data_ptr()), _p(dx), N, H, W, Cc, _stream())
+    return dx
+
+
+def add_act(a, b, act):
+    _chk(a, b)
+    y = torch.empty_like(a)
+    _call("ud_add_act_fwd", _p(a), _p(b), int(act), _p(y), a.numel(), _stream())
+    return y
+
+
+def relu_bwd(dy, y):
+    _chk(dy, y)
+    g = torch.empty_like(dy)
+    _call("ud_relu_bwd", _p(dy), _p(y), _p(g), dy.numel(), _stream())
+    return g
+
+
+def concat_channels(parts):
+    """torch.cat(parts, dim=-1) for pixel-major tensors with equal leading dims."""
+    _chk(*parts)
+    lead = parts[0].shape[:-1]
+    Cw = sum(p.shape[-1] for p in parts)
+    M = parts[0].numel() // parts[0].shape[-1]
+    out = empty((*lead, Cw), parts[0])
+    off = 0
+    for p in parts:
+        _call("ud_copy_cols", _p(p), _p(out), M, p.shape[-1], Cw, off, 0, _stream())
+        off += p.shape[-1]
+    return out
+
+
+def slice_channels(wide, off, Cn):
+    _chk(wide)
+    lead = wide.shape[:-1]
+    M = wide.numel() // wide.shape[-1]
+    out = empty((*lead, Cn), wide)
+    _call("ud_copy_cols", _p(out), _p(wide), M, Cn, wide.shape[-1], off, 1, _stream())
+    return out

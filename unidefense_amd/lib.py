@@ -71,6 +71,13 @@ _SIGNATURES = {
     "ud_l1_bwd": [_P, _P, _P, _F, _I, _P, _I, _L, _P],
     "ud_dynfilter_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ud_dynfilter_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "ud_avgpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ud_avgpool_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ud_maxpool3s2_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ud_maxpool3s2_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ud_add_act_fwd": [_P, _P, _I, _P, _L, _P],
+    "ud_relu_bwd": [_P, _P, _P, _L, _P],
+    "ud_copy_cols": [_P, _P, _L, _I, _I, _I, _I, _P],
 }
 
 # helpers that return a count rather than a status code

@@ -111,12 +111,13 @@ class _NetFunction(torch.autograd.Function):
         ctx.outs = outs
         ctx.params = params
         ctx.model = model
-        return tuple(outs[k] for k in _OUT_KEYS)
+        ctx.keys = model._out_keys
+        return tuple(outs[k] for k in ctx.keys)
 
     @staticmethod
     def backward(ctx, *gouts):
         tape, outs = ctx.tape, ctx.outs
-        for k, g in zip(_OUT_KEYS, gouts):
+        for k, g in zip(ctx.keys, gouts):
             if g is not None:
                 tape.add_grad(outs[k], g.contiguous().to(torch.float32))
         tape.backward()
@@ -133,6 +134,8 @@ class UniDefenseModelEb4(nn.Module):
     """UniDefense model with EfficientNet backbone (reference: model/unidefense.py:28-256)."""
 
     path = "model/unidefense.py"
+    _out_keys = _OUT_KEYS
+    _triplet_keys = ("triplet0", "triplet1", "triplet2")
 
     def __init__(self,
                  extractor,
@@ -199,21 +202,23 @@ class UniDefenseModelEb4(nn.Module):
         rng: optional dict of explicit keep-masks (NCHW-shaped like the reference's tensors):
         'drop_connect' {block: [N]}, 'dec_keep' [N,160,h,w], 'emb_keep' [N,272,h,w], 'feat_keep' [N,F]."""
         if self.training and pert_real_list is not None and pert_fake_list is not None:
-            from .perturb import perturb_input
-            x = perturb_input(x, pert_real_list, pert_fake_list, preserve_color)
+            from . import perturb
+            x = perturb.perturb_input(x, pert_real_list, pert_fake_list, preserve_color)
+        if rng is None and getattr(self, "rng_queue", None):
+            rng = self.rng_queue.pop(0)        # parity tests: explicit masks for successive forward calls
         if not x.is_cuda:
             raise RuntimeError("unidefense_amd runs on the GPU only (no CPU path); move the model and input to cuda")
         x = x.contiguous().to(torch.float32)
         if self.training and torch.is_grad_enabled():
             params = tuple(self.parameters())
             vals = _NetFunction.apply(self, x, rng, *params)
-            outs = dict(zip(_OUT_KEYS, vals))
+            outs = dict(zip(self._out_keys, vals))
         else:
             with torch.no_grad():
                 outs = self._run(x, None, rng)
         loss_dict = {
             "factorization": outs["factorization"],
-            "triplet": [outs["triplet0"], outs["triplet1"], outs["triplet2"]],
+            "triplet": [outs[k] for k in self._triplet_keys],
             "freq_mask": outs["freq_mask"].permute(0, 3, 1, 2),      # [N,h,w,1] -> [N,1,h,w]
             "spat_mask": outs["spat_mask"].permute(0, 3, 1, 2),
             "spatial": outs["spatial"],

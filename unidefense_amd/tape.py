@@ -521,3 +521,101 @@ def dynamic_filter(tape, x, proj, diff, w2):
             tape.add_param_grad(w2, K.gemm_tn(dlogit.view(-1, 1), pre).view(w2.shape))
         tape.record(bwd)
     return out, mask4
+
+
+# ---------------------------------------------------------------------------------------------
+# ResNet-variant operators
+# ---------------------------------------------------------------------------------------------
+def conv_dense_any(tape, x, w, stride, pad, need_dx=True):
+    """Dense k x k F.conv2d with symmetric padding and any stride (ResNet convs, model/resnet/exp.py:95-111;
+    7x7/2 stem :395; 1x1/2 downsample :235-246).  The data gradient is the transposed-conv gather
+    (t = ih + pad - kh, oh = t / stride) with the un-flipped weights."""
+    N, Hin, Win, Ci = x.shape
+    Co, _, KH, KW = w.shape
+    Hout = (Hin + 2 * pad - KH) // stride + 1
+    Wout = (Win + 2 * pad - KW) // stride + 1
+    g = K.conv_geom(N, Hin, Win, Ci, Hout, Wout, KH, KW, stride, pad, pad, 0)
+    wmat = w.permute(0, 2, 3, 1).reshape(Co, KH * KW * Ci).contiguous()
+    y = K.conv_gather_nt(x, wmat, g)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            if need_dx:
+                gd = K.conv_geom(N, Hout, Wout, Co, Hin, Win, KH, KW, stride, pad, pad, 1)
+                wd = w.permute(1, 2, 3, 0).reshape(Ci, KH * KW * Co).contiguous()
+                tape.add_grad(x, K.conv_gather_nt(dy, wd, gd))
+            dw = K.conv_gather_wgrad(dy.view(-1, Co), x, g)
+            tape.add_param_grad(w, dw.view(Co, KH, KW, Ci).permute(0, 3, 1, 2).contiguous())
+        tape.record(bwd)
+    return y
+
+
+def sfconv_dense(tape, x, w, w_freq, alpha, stride, norm):
+    """SFConv2d.forward (model/resnet/exp.py:36-54): dense 3x3 conv (padding 1) + spectral 1x1 branch."""
+    spat = conv_dense_any(tape, x, w, stride, 1)
+    xf = rfft2_cat(tape, x, norm)
+    yf = conv1x1(tape, xf, w_freq)
+    fr = irfft2_split(tape, yf, norm)
+    return sfmix(tape, spat, fr, alpha)
+
+
+def add_relu(tape, a, b):
+    """`x += shortcut; x = relu(x)` (model/resnet/exp.py:146-147)."""
+    y = K.add_act(a, b, 2)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            g = K.relu_bwd(dy, y)
+            tape.add_grad(a, g)
+            tape.add_grad(b, g)
+        tape.record(bwd)
+    return y
+
+
+def avgpool(tape, x, k):
+    """F.adaptive_avg_pool2d to (H/k, W/k) (model/resnet/module_exp.py:30-31)."""
+    if k == 1:
+        return x
+    y = K.avgpool_fwd(x, k)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(x, K.avgpool_bwd(dy, k))
+        tape.record(bwd)
+    return y
+
+
+def maxpool3s2(tape, x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (model/resnet/module_exp.py:73-75)."""
+    H, W = x.shape[1], x.shape[2]
+    y, arg = K.maxpool3s2_fwd(x)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            tape.add_grad(x, K.maxpool3s2_bwd(dy, arg, H, W))
+        tape.record(bwd)
+    return y
+
+
+def concat_channels(tape, parts):
+    """torch.cat(dim=1) in NCHW = channel concat in pixel-major (model/resnet/module_exp.py:32)."""
+    y = K.concat_channels(parts)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            off = 0
+            for p in parts:
+                tape.add_grad(p, K.slice_channels(dy, off, p.shape[-1]))
+                off += p.shape[-1]
+        tape.record(bwd)
+    return y
