@@ -9,7 +9,8 @@ config_template/uniatt/Prot1/model_udeb4.yml), with every random draw pinned:
 
 Run:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_step
 Writes tests/golden/udeb4_step_n4.npz: the returned loss scalars, pass-1 cls_out, and per-parameter
-update norms |p_after - p_before| with the first 8 elements of the new parameter values.
+update norms |p_after - p_before| with the first 8 elements of the update; plus the same quantities of a
+float64 run of the reference ('<tag>64_*'), the yardstick for how ill-conditioned each quantity is.
 """
 import os
 import sys
@@ -42,7 +43,7 @@ def param_groups_weight_decay(named_params, weight_decay):
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
-def run(cur_step):
+def run(cur_step, dtype=torch.float32):
     ref_model, ref_loss = ref_import.import_reference()
     engmod = ref_import.import_abstract_engine()
     import model.efficientnet.model as effmod
@@ -51,8 +52,9 @@ def run(cur_step):
     drop_rate = 0.5
     m = ref_model.load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=drop_rate)
     param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dtype)
     before = {k: v.detach().clone() for k, v in m.named_parameters()}
-    x = param_fill.make_input(N, 256, seed=IN_SEED)
+    x = param_fill.make_input(N, 256, seed=IN_SEED).to(dtype)
     tgt = param_fill.make_labels(N)
     rngs = [make_rng(N, MASK_SEED, drop_rate), make_rng(N, MASK_SEED + 1, drop_rate)]
 
@@ -119,7 +121,7 @@ def run(cur_step):
             continue
         names.append(k)
         dn.append((p.detach() - before[k]).double().norm().item())
-        h = torch.zeros(8)
+        h = torch.zeros(8, dtype=dtype)
         f = (p.detach() - before[k]).flatten()[:8]
         h[: f.numel()] = f
         heads.append(h.numpy())
@@ -140,6 +142,13 @@ def main():
         for k, v in st.items():
             out[f"{tag}_{k}"] = v
         print(tag, {k: float(v) for k, v in st.items() if k.startswith("loss_")})
+        # the same step in float64: |fp32 - fp64| of the reference itself is the conditioning yardstick the
+        # parity test scales its tolerances with (the first Adam steps are sign-like, see tests/test_engine_gpu.py)
+        st64 = run(step, torch.float64)
+        for k, v in st64.items():
+            if k.startswith(("loss_", "out_", "delta_")):
+                out[f"{tag}64_{k}"] = v
+        print(tag + "64", {k: float(v) for k, v in st64.items() if k.startswith("loss_")})
     out["meta"] = np.array([N, 256, IN_SEED, MASK_SEED, NUM_STEPS], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "udeb4_step_n4.npz"), **out)
     print("wrote udeb4_step_n4.npz")

@@ -60,7 +60,23 @@ def extractor(x: Tensor, sd, training: bool, norm):
     return p3, torch.cat([F.adaptive_avg_pool2d(p1, size), F.adaptive_avg_pool2d(p2, size), p3], dim=1)
 
 
-def emb_block1(x: Tensor, sd, training: bool) -> Tensor:
+def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 2e-5) -> Tensor:
+    """F.max_pool2d(z, 3, 2, 1) with the winner of every window pinned to `sel` ([N,C,Ho,Wo], value kh*3+kw).
+    A 3x3 max over ~2.6e5 windows always holds a few top-2 gaps near 1e-6, which two correct fp32
+    evaluations resolve differently; pinning the selection (after checking that every pinned winner IS a maximum
+    up to tie_tol) lets the gradients of both sides be compared for the same piecewise-linear branch."""
+    n, c, h, w = z.shape
+    u = F.unfold(z, 3, padding=1, stride=2).view(n, c, 9, -1)
+    valid = F.unfold(torch.ones(1, 1, h, w, dtype=z.dtype), 3, padding=1, stride=2).view(1, 1, 9, -1) > 0
+    u = torch.where(valid, u, torch.full_like(u, -1e30))
+    y = u.gather(2, sel.reshape(n, c, 1, -1).long()).squeeze(2)
+    worst = (u.max(2).values - y).max().item()
+    assert worst <= tie_tol, f"pinned max-pool selection is not an arg-max (off by {worst:.3e})"
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    return y.view(n, c, ho, wo)
+
+
+def emb_block1(x: Tensor, sd, training: bool, pool_sel: Optional[Tensor] = None) -> Tensor:
     """EmbedderRes18Layer1.forward (module_exp.py:77-89); its SFConv2d has freq_norm=None (:68)."""
     o = F.conv2d(x, sd["emb_block1.conv1.weight"], None, 2, 1)
     o = F.relu(batch_norm(o, sd, "emb_block1.norm1", training, 1e-5))
@@ -68,7 +84,7 @@ def emb_block1(x: Tensor, sd, training: bool) -> Tensor:
     o = batch_norm(o, sd, "emb_block1.norm2", training, 1e-5)
     idt = F.conv2d(x, sd["emb_block1.downsample.0.weight"])
     idt = batch_norm(idt, sd, "emb_block1.downsample.1", training, 1e-5)
-    idt = F.max_pool2d(idt, 3, 2, 1)
+    idt = F.max_pool2d(idt, 3, 2, 1) if pool_sel is None else max_pool_3s2_pinned(idt, pool_sel)
     return F.relu(o + idt)
 
 
@@ -105,7 +121,7 @@ def forward_r18(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
     d = _dec(d, sd, "dec_block2", 6)
     dec2 = torch.tanh(F.conv2d(d, sd["dec_block2.9.weight"], None, 1, 1))
 
-    emb = emb_block1(ext, sd, training)
+    emb = emb_block1(ext, sd, training, rng.get("pool_sel"))
     # attention (model/unidefense.py:326-361): ReLU filters, att_depth 512
     size = emb.shape[-2:]
     pred = interpolate(dec2.detach(), size)

@@ -367,12 +367,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
 int launch_cfg(const ud_gemm_desc& d, int a_vec, int b_vec, hipStream_t s) {
     int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
-    // XCD patch order only pays (and only keeps its padding small) on grids of several hundred tiles
+    // XCD patch order only pays on grids of >= 4 waves of tiles whose padding to whole patches stays small:
+    // measured (tools/bench_gemm.py) 1280x3264x3264 = 510 tiles pads to 768 workgroups and drops from 94 to
+    // 72 TFLOP/s when patched, while 4096^3 (1024 tiles, no padding) gains ~3 %
     unsigned gx = (unsigned)(tiles_m * tiles_n);
-    if (tiles_m * tiles_n >= 256) {
+    static const bool nopatch = getenv("UD_GEMM_NOPATCH") != nullptr;     // tuning aid
+    if (tiles_m * tiles_n >= 1024 && !nopatch) {
         int patches = ud_cdiv(tiles_m, PATCH_M) * ud_cdiv(tiles_n, PATCH_N);
         unsigned padded = (unsigned)(ud_cdiv(patches, 8) * 8 * PATCH_M * PATCH_N);
-        if (padded != gx) gx = padded;      // (equal sizes would be read as 'plain order' by the kernel: fine too)
+        if (padded != gx && padded <= gx + gx / 16) gx = padded;   // (equal sizes read as 'plain order': fine too)
     }
     dim3 grid(gx, (unsigned)d.split_k, (unsigned)d.batch);
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, AMODE, BMODE>), grid, dim3(NTHREADS), 0, s, d, tiles_m, tiles_n,

@@ -107,6 +107,7 @@ class _NetFunction(torch.autograd.Function):
         if getattr(model, "_debug_watch", False):            # tests: capture activation gradients
             tape.watch = {id(t): k for k, t in outs["_feats"].items()}
             model._debug_tape = tape
+            model._debug_feats = outs["_feats"]
         ctx.tape = tape
         ctx.outs = outs
         ctx.params = params

@@ -207,7 +207,7 @@ class UniDefenseModelRes18(nn.Module):
         o = self._bn(tape, o, e1.norm2, 0)
         idt = T.conv1x1(tape, ext, e1.downsample[0].weight)
         idt = self._bn(tape, idt, e1.downsample[1], 0)
-        idt = T.maxpool3s2(tape, idt)
+        idt, pool_sel = T.maxpool3s2(tape, idt, return_arg=True)
         emb = T.add_relu(tape, o, idt)
 
         # attention (model/unidefense.py:326-361) with ReLU filters
@@ -255,4 +255,4 @@ class UniDefenseModelRes18(nn.Module):
         spatial, freq = T.rec_losses(tape, rec, x, self.freq_norm)
         return {"cls_out": cls_out, "rec": rec, "factorization": fac, "triplet0": t0, "triplet1": t1,
                 "freq_mask": freq_mask, "spat_mask": spat_mask, "spatial": spatial, "freq": freq,
-                "_feats": {"ext": ext, "emb": emb, "dec1": dec1, "dec2": dec2, "att_out": att}}
+                "_feats": {"ext": ext, "emb": emb, "dec1": dec1, "dec2": dec2, "att_out": att, "pool_sel": pool_sel}}

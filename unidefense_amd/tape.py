@@ -591,8 +591,9 @@ def avgpool(tape, x, k):
     return y
 
 
-def maxpool3s2(tape, x):
-    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (model/resnet/module_exp.py:73-75)."""
+def maxpool3s2(tape, x, return_arg=False):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (model/resnet/module_exp.py:73-75).
+    return_arg: also hand back the uint8 winner map (kh*3+kw per window) for the parity tests."""
     H, W = x.shape[1], x.shape[2]
     y, arg = K.maxpool3s2_fwd(x)
     if _needs(tape):
@@ -602,7 +603,7 @@ def maxpool3s2(tape, x):
                 return
             tape.add_grad(x, K.maxpool3s2_bwd(dy, arg, H, W))
         tape.record(bwd)
-    return y
+    return (y, arg) if return_arg else y
 
 
 def concat_channels(tape, parts):
