@@ -80,8 +80,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force = os.environ.get("UD_FORCE_COLLECTIVES", "0") == "1"     # 1-GPU exercise of the RCCL path (tape.py)
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from unidefense_amd import kernels as K
@@ -91,7 +95,7 @@ def main():
 
     torch.manual_seed(1234)
     model = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5).to(dev).train()
-    model = wrap_data_parallel(model, local_rank) if world > 1 else model
+    model = wrap_data_parallel(model, local_rank) if (world > 1 or force) else model
     bs = args.batch
     g = torch.Generator().manual_seed(100 + rank)
     x = (2.0 * torch.rand(bs, 3, 256, 256, generator=g) - 1.0).to(dev)
@@ -123,7 +127,16 @@ def main():
     if not args.eager:
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # With a process group alive, its watchdog thread polls hipEventQuery on the work items of earlier
+            # collectives; under the default "global" capture mode that call is illegal while ANY thread captures
+            # and takes the process down.  thread_local restricts the check to this thread; draining the
+            # outstanding work first keeps the watchdog's list empty during the capture anyway.
+            mode = "thread_local" if dist.is_initialized() else "global"
+            if dist.is_initialized():
+                dist.barrier()
+                torch.cuda.synchronize()
+                time.sleep(1.0)
+            with torch.cuda.graph(graph, capture_error_mode=mode):
                 static_loss = step()
             torch.cuda.synchronize()
 
@@ -197,7 +210,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

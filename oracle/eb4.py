@@ -270,7 +270,9 @@ def forward_eb4(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
     rng = rng or {}
     eps = arch["bn_eps"]
     st = arch["stem"]
-    h = conv_static_same(x, sd["backbone._conv_stem.weight"], st["s"], st["pad"])
+    # rng['noise_x']: the perturbed input of the second pass; it feeds the stem only, the attention residuals
+    # and the reconstruction losses keep the clean x (model/unidefense.py:200, :219, :243-248)
+    h = conv_static_same(rng.get("noise_x", x), sd["backbone._conv_stem.weight"], st["s"], st["pad"])
     h = swish(batch_norm(h, sd, "backbone._bn0", training, eps))
     nblk = len(arch["blocks"])
     delim = arch["delimiter"]

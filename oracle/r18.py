@@ -109,7 +109,9 @@ def forward_r18(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
     rng (training): 'dec_keep' like ext_feat (F.dropout p=0.2, :391), 'emb_keep' like emb_feat (:359),
     'feat_keep' [N,512] (:406; NOT in place here, so 'factorization' is the un-dropped feature)."""
     rng = rng or {}
-    _, ext = extractor(x, sd, training, freq_norm)
+    # rng['noise_x']: perturbed encoder input of the second pass (model/unidefense.py:372-392); the clean x
+    # stays the target of the attention residuals and of the reconstruction losses
+    _, ext = extractor(rng.get("noise_x", x), sd, training, freq_norm)
     d_in = ext
     if training and rng.get("dec_keep") is not None:
         d_in = ext * rng["dec_keep"].to(x.dtype) / 0.8

@@ -1,0 +1,40 @@
+"""GPU, one device: the data-parallel code path (RCCL process group, SyncBatchNorm statistics exchange, bucketed
+gradient all-reduce, their capture into the step's hipGraph) exercised in a world of ONE process with
+UD_FORCE_COLLECTIVES=1.  With a single rank every collective is the identity, so the step must reproduce the plain
+single-GPU step: same loss after the same number of steps.  (The N>1 semantics are covered on CPU with gloo in
+tests/test_parallel_cpu.py; N>1 on GPUs is only ever run by the driver's scaling bench.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(extra_env, *flags):
+    env = dict(os.environ, **extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", *flags]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line), r.stderr
+
+
+@pytest.mark.parametrize("flags", [(), ("--eager",)])
+def test_forced_collectives_match_plain_step(flags):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    plain, _ = _bench({"UD_FORCE_COLLECTIVES": "0"}, *flags)
+    forced, err = _bench({"UD_FORCE_COLLECTIVES": "1", "MASTER_PORT": "29541"}, *flags)
+    print("  plain :", plain["config"]["exec"], plain["config"]["final_loss"], "%.1f ms" % plain["ms_per_step"])
+    print("  forced:", forced["config"]["exec"], forced["config"]["final_loss"], "%.1f ms" % forced["ms_per_step"])
+    a, b = plain["config"]["final_loss"], forced["config"]["final_loss"]
+    assert abs(a - b) <= 1e-4 * abs(a), (a, b)
+    if not flags:      # the RCCL calls must survive hipGraph capture, else the 8-GPU bench would run eagerly
+        assert forced["config"]["exec"] == "hipgraph", err[-2000:]

@@ -13,6 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .. import tape as T
+
 
 class HipDataParallel(nn.Module):
     """Minimal DDP replacement exposing ``.module`` like torch's wrapper."""
@@ -28,7 +30,8 @@ class HipDataParallel(nn.Module):
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=process_group)
         module._grad_sync = self.sync_grads
-        if sync_bn and self.world > 1:
+        self.force = T.FORCE_COLLECTIVES           # single-GPU exercise of the RCCL calls (tape.py)
+        if sync_bn and (self.world > 1 or self.force):
             module._sync_bn_group = process_group if process_group is not None else dist.group.WORLD
 
     def forward(self, *args, **kwargs):
@@ -36,7 +39,7 @@ class HipDataParallel(nn.Module):
 
     def sync_grads(self, grads):
         """grads: list of tensors (or None) in parameter order -> averaged over ranks (in place)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return grads
         bucket, size = [], 0
 

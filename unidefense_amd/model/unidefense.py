@@ -101,9 +101,9 @@ _OUT_KEYS = ("cls_out", "rec", "factorization", "triplet0", "triplet1", "triplet
 
 class _NetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, x, rng, *params):
+    def forward(ctx, model, x, noise_x, rng, *params):
         tape = T.Tape()
-        outs = model._run(x, tape, rng)
+        outs = model._run(x, tape, rng, noise_x)
         if getattr(model, "_debug_watch", False):            # tests: capture activation gradients
             tape.watch = {id(t): k for k, t in outs["_feats"].items()}
             model._debug_tape = tape
@@ -128,7 +128,7 @@ class _NetFunction(torch.autograd.Function):
             grads = sync(grads)
         grads = tuple(grads)
         ctx.tape = ctx.outs = ctx.model = None
-        return (None, None, None) + grads
+        return (None, None, None, None) + grads
 
 
 class UniDefenseModelEb4(nn.Module):
@@ -202,9 +202,13 @@ class UniDefenseModelEb4(nn.Module):
         """Returns {'cls_out','rec','loss_dict'} like the reference (model/unidefense.py:174-256).
         rng: optional dict of explicit keep-masks (NCHW-shaped like the reference's tensors):
         'drop_connect' {block: [N]}, 'dec_keep' [N,160,h,w], 'emb_keep' [N,272,h,w], 'feat_keep' [N,F]."""
+        noise_x = None       # the perturbed copy feeds the encoder only; the attention residuals and the
+        # reconstruction losses keep the clean input (model/unidefense.py:200, :219, :243-248)
         if self.training and pert_real_list is not None and pert_fake_list is not None:
             from . import perturb
-            x = perturb.perturb_input(x, pert_real_list, pert_fake_list, preserve_color)
+            with torch.no_grad():
+                noise_x = perturb.perturb_input(x, pert_real_list, pert_fake_list, preserve_color)
+            noise_x = noise_x.contiguous().to(torch.float32)
         if rng is None and getattr(self, "rng_queue", None):
             rng = self.rng_queue.pop(0)        # parity tests: explicit masks for successive forward calls
         if not x.is_cuda:
@@ -212,7 +216,7 @@ class UniDefenseModelEb4(nn.Module):
         x = x.contiguous().to(torch.float32)
         if self.training and torch.is_grad_enabled():
             params = tuple(self.parameters())
-            vals = _NetFunction.apply(self, x, rng, *params)
+            vals = _NetFunction.apply(self, x, noise_x, rng, *params)
             outs = dict(zip(self._out_keys, vals))
         else:
             with torch.no_grad():
@@ -347,8 +351,8 @@ class UniDefenseModelEb4(nn.Module):
             return m
         return (torch.rand(like.shape, device=like.device) < keep_p).to(torch.float32)
 
-    def _run(self, x, tape, rng):
-        """The whole forward on HIP kernels.  x: [N,3,H,W] planes."""
+    def _run(self, x, tape, rng, noise_x=None):
+        """The whole forward on HIP kernels.  x: [N,3,H,W] planes; noise_x: perturbed encoder input or None."""
         N, _, H, W = x.shape
         arch = self.arch
         bb = self.backbone
@@ -358,7 +362,7 @@ class UniDefenseModelEb4(nn.Module):
         Wo = (W + pl + pr - 3) // 2 + 1
         rng = self._prepare_rng(rng, N, x.device)
 
-        x_pix = K.planes_to_pix(x)                                       # [N,H,W,3]
+        x_pix = K.planes_to_pix(x if noise_x is None else noise_x)       # [N,H,W,3]
         h = T.conv_dense(tape, x_pix, bb._conv_stem.weight, 2, pt, pl, Ho, Wo, need_dx=False)
         h = self._bn(tape, h, bb._bn0, 1)
         x_b0 = self._blocks(tape, h, 0, rng)

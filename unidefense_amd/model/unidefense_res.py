@@ -173,12 +173,13 @@ class UniDefenseModelRes18(nn.Module):
     def _prepare_rng(self, rng):
         return {"drop_connect": {}, "_given": rng or {}}
 
-    def _run(self, x, tape, rng):
-        """The whole forward (model/unidefense.py:389-436) on HIP kernels.  x: [N,3,H,W] planes."""
+    def _run(self, x, tape, rng, noise_x=None):
+        """The whole forward (model/unidefense.py:389-436) on HIP kernels.  x: [N,3,H,W] planes; noise_x: the
+        perturbed encoder input (the clean x stays the target of the attention residuals and the losses)."""
         N, _, H, W = x.shape
         rng = self._prepare_rng(rng)
         ex = self.extractor
-        x_pix = K.planes_to_pix(x)
+        x_pix = K.planes_to_pix(x if noise_x is None else noise_x)
         h = T.conv_dense_any(tape, x_pix, ex.conv1.weight, 2, 3, need_dx=False)
         h = self._bn(tape, h, ex.bn1, 2)
         p1 = self._basic_block(tape, self._basic_block(tape, h, ex.layer1[0]), ex.layer1[1])

@@ -10,6 +10,8 @@ Every operator takes pixel-major fp32 CUDA tensors (see kernels.py) and cites th
 import math
 from typing import Optional
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -246,6 +248,11 @@ def sfconv_dw(tape, x, w, w_freq, alpha, stride, pad, norm):
 # ---------------------------------------------------------------------------------------------
 # normalisation + activation
 # ---------------------------------------------------------------------------------------------
+# UD_FORCE_COLLECTIVES=1: issue the data-parallel collectives (SyncBN statistics, gradient all-reduce) even in a
+# world of one process, so that a single-GPU box exercises the RCCL calls and their hipGraph capture
+FORCE_COLLECTIVES = os.environ.get("UD_FORCE_COLLECTIVES", "0") == "1"
+
+
 def sync_batch_stats(mean_l, var_l, eps, group):
     """Combine per-rank (mean, biased var) over equally sized shards into the global statistics:
     mean = avg_r mean_r ;  var = avg_r (var_r + (mean_r - mean)^2).  One all_gather of 2C floats
@@ -270,11 +277,12 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
     Cc = x.shape[-1]
     x2 = x.view(-1, Cc)
     R = x2.shape[0]
-    world = 1
+    world, synced = 1, False
     if training and sync_group is not None:
         import torch.distributed as dist
         world = dist.get_world_size(sync_group)
-    if training and world > 1:
+        synced = world > 1 or FORCE_COLLECTIVES
+    if synced:
         mean_l, var_l = K.norm_stats_local(x2, 1, R, eps)
         mean, var, invstd = sync_batch_stats(mean_l, var_l, eps, sync_group)
         if running_mean is not None:
@@ -295,7 +303,7 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
             dy = tape.pop_grad(y)
             if dy is None:
                 return
-            if world > 1:
+            if synced:
                 import torch.distributed as dist
                 s, dg, db = K.norm_bwd_sums(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
                 dist.all_reduce(s, group=sync_group)           # sum_dz, sum_dz_xhat over all ranks
