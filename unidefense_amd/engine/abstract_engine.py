@@ -52,9 +52,14 @@ class AbstractEngine(object):
         t = {}
         if loss_dict.get("triplet") is not None:
             crit = self.loss_criterion["triplet"]
-            if hasattr(crit, "n_real"):
+            hint = hasattr(crit, "n_real")
+            if hint:
                 crit.n_real = sum_real                  # avoids a device read-back per feature
-            t["triplet"] = sum(crit(feat, in_tgt) for feat in loss_dict["triplet"])
+            try:
+                t["triplet"] = sum(crit(feat, in_tgt) for feat in loss_dict["triplet"])
+            finally:
+                if hint:                                # the criterion object is shared (loss.LOSSES): no leak
+                    crit.n_real = None
         else:
             t["triplet"] = _zero(self.device)
         for key, name in (("spatial", "rec"), ("freq", "freq")):
