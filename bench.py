@@ -235,7 +235,12 @@ def main():
                                    "spatial+frequency branches on, bs=32/GPU (BASELINE configs[1]/[2])",
                        "global_batch": world * bs, "parallelism": f"dp{world}", "exec": exec_mode,
                        "final_loss": float(loss.detach())},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (ud_gemm, v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "ud_gemm: gemm_x3_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 "
+                                   "v_mfma_f32_32x32x16_bf16 per fp32 K=16 step, fp32-GEMM accuracy) for the large plain "
+                                   "GEMMs + gemm_kernel (v_mfma_f32_32x32x2_f32) for gather modes / small shapes; "
+                                   "achieved = algorithmic fp32 FLOPs (2MNK) per second over all launches, priced "
+                                   "against the fp32 matrix peak",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                          "launches_per_step": len(prof) / prof_steps,

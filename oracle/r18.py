@@ -14,6 +14,25 @@ from .eb4 import batch_norm, instance_norm, rfft2_cat, irfft2_split, interpolate
 Tensor = torch.Tensor
 
 
+def relu_site(x: Tensor, name: str, pins: Optional[dict], tie_tol: float = 1e-4) -> Tensor:
+    """F.relu — or, when `pins` holds a recorded on/off pattern for this site, x * pattern after checking that the
+    pattern departs from (x > 0) only on near-ties (|x| <= tie_tol * max|x|).  A ReLU network's gradient is
+    piecewise constant in the activations' signs; two correct fp32 evaluations of a batch with ~1e7 units always
+    disagree on a few units that sit within rounding of 0, and each such flip moves some weight gradients by
+    ~1e-2.  Pinning the pattern to the implementation under test compares both gradients on the same linear piece
+    (same idea as the injected dropout masks and the pinned max-pool winners)."""
+    if not pins or name not in pins:
+        return F.relu(x)
+    m = pins[name].to(torch.bool)
+    assert m.shape == x.shape, (name, m.shape, x.shape)
+    pins.setdefault("_used", set()).add(name)
+    dis = m != (x > 0)
+    if bool(dis.any()):
+        worst = (x.detach().abs()[dis].max() / x.detach().abs().max()).item()
+        assert worst <= tie_tol, f"pinned ReLU pattern at {name} flips a unit that is not a near-tie ({worst:.3e})"
+    return x * m.to(x.dtype)
+
+
 def sfconv2d(x: Tensor, sd: Dict[str, Tensor], prefix: str, stride: int, norm) -> Tensor:
     """SFConv2d.forward (model/resnet/exp.py:36-54): dense 3x3 conv (pad 1) + spectral 1x1 branch."""
     spat = F.conv2d(x, sd[prefix + ".weight"], None, stride, 1)
@@ -32,30 +51,30 @@ def _conv(x, sd, prefix, stride, norm):
     return F.conv2d(x, sd[prefix + ".weight"], None, stride, 1)
 
 
-def basic_block(x: Tensor, sd, prefix: str, stride: int, training: bool, norm) -> Tensor:
+def basic_block(x: Tensor, sd, prefix: str, stride: int, training: bool, norm, pins=None) -> Tensor:
     """BasicBlock.forward (model/resnet/exp.py:127-149)."""
     sc = x
     y = _conv(x, sd, prefix + ".conv1", stride, norm)
-    y = F.relu(batch_norm(y, sd, prefix + ".bn1", training, 1e-5))
+    y = relu_site(batch_norm(y, sd, prefix + ".bn1", training, 1e-5), prefix + ".bn1", pins)
     y = _conv(y, sd, prefix + ".conv2", 1, norm)
     y = batch_norm(y, sd, prefix + ".bn2", training, 1e-5)
     if prefix + ".downsample.0.weight" in sd:
         sc = F.conv2d(x, sd[prefix + ".downsample.0.weight"], None, stride, 0)
         sc = batch_norm(sc, sd, prefix + ".downsample.1", training, 1e-5)
-    return F.relu(y + sc)
+    return relu_site(y + sc, prefix + ".add", pins)
 
 
-def extractor(x: Tensor, sd, training: bool, norm):
+def extractor(x: Tensor, sd, training: bool, norm, pins=None):
     """ExtractorRes18.forward (model/resnet/module_exp.py:22-32): 7x7/2 stem WITHOUT max-pool, layer1..3,
     concat of the avg-pooled layer1/layer2 outputs with layer3."""
     h = F.conv2d(x, sd["extractor.conv1.weight"], None, 2, 3)
-    h = F.relu(batch_norm(h, sd, "extractor.bn1", training, 1e-5))
-    p1 = basic_block(basic_block(h, sd, "extractor.layer1.0", 1, training, None), sd, "extractor.layer1.1", 1,
-                     training, None)
-    p2 = basic_block(basic_block(p1, sd, "extractor.layer2.0", 2, training, norm), sd, "extractor.layer2.1", 1,
-                     training, norm)
-    p3 = basic_block(basic_block(p2, sd, "extractor.layer3.0", 2, training, norm), sd, "extractor.layer3.1", 1,
-                     training, norm)
+    h = relu_site(batch_norm(h, sd, "extractor.bn1", training, 1e-5), "extractor.bn1", pins)
+    p1 = basic_block(basic_block(h, sd, "extractor.layer1.0", 1, training, None, pins), sd, "extractor.layer1.1", 1,
+                     training, None, pins)
+    p2 = basic_block(basic_block(p1, sd, "extractor.layer2.0", 2, training, norm, pins), sd, "extractor.layer2.1", 1,
+                     training, norm, pins)
+    p3 = basic_block(basic_block(p2, sd, "extractor.layer3.0", 2, training, norm, pins), sd, "extractor.layer3.1", 1,
+                     training, norm, pins)
     size = p3.shape[-2:]
     return p3, torch.cat([F.adaptive_avg_pool2d(p1, size), F.adaptive_avg_pool2d(p2, size), p3], dim=1)
 
@@ -76,31 +95,32 @@ def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 2e-5) -> Tensor
     return y.view(n, c, ho, wo)
 
 
-def emb_block1(x: Tensor, sd, training: bool, pool_sel: Optional[Tensor] = None) -> Tensor:
+def emb_block1(x: Tensor, sd, training: bool, pool_sel: Optional[Tensor] = None, pins=None) -> Tensor:
     """EmbedderRes18Layer1.forward (module_exp.py:77-89); its SFConv2d has freq_norm=None (:68)."""
     o = F.conv2d(x, sd["emb_block1.conv1.weight"], None, 2, 1)
-    o = F.relu(batch_norm(o, sd, "emb_block1.norm1", training, 1e-5))
+    o = relu_site(batch_norm(o, sd, "emb_block1.norm1", training, 1e-5), "emb_block1.norm1", pins)
     o = sfconv2d(o, sd, "emb_block1.conv2", 1, None)
     o = batch_norm(o, sd, "emb_block1.norm2", training, 1e-5)
     idt = F.conv2d(x, sd["emb_block1.downsample.0.weight"])
     idt = batch_norm(idt, sd, "emb_block1.downsample.1", training, 1e-5)
     idt = F.max_pool2d(idt, 3, 2, 1) if pool_sel is None else max_pool_3s2_pinned(idt, pool_sel)
-    return F.relu(o + idt)
+    return relu_site(o + idt, "emb_block1.add", pins)
 
 
-def emb_block2(x: Tensor, sd, training: bool) -> Tensor:
+def emb_block2(x: Tensor, sd, training: bool, pins=None) -> Tensor:
     """EmbedderRes18Layer2.forward (module_exp.py:100-111)."""
     o = sfconv2d(x, sd, "emb_block2.conv1", 1, None)
-    o = F.relu(batch_norm(o, sd, "emb_block2.norm1", training, 1e-5))
+    o = relu_site(batch_norm(o, sd, "emb_block2.norm1", training, 1e-5), "emb_block2.norm1", pins)
     o = F.conv2d(o, sd["emb_block2.conv2.weight"], None, 1, 1)
     o = batch_norm(o, sd, "emb_block2.norm2", training, 1e-5)
-    return F.relu(o + x)
+    return relu_site(o + x, "emb_block2.add", pins)
 
 
-def _dec(x, sd, prefix, idx_conv, transposed=False):
+def _dec(x, sd, prefix, idx_conv, transposed=False, pins=None):
     w = sd[f"{prefix}.{idx_conv}.weight"]
     x = F.conv_transpose2d(x, w, None, 2, 1, 1) if transposed else F.conv2d(x, w, None, 1, 1)
-    return F.relu(instance_norm(x, sd[f"{prefix}.{idx_conv + 1}.weight"], sd[f"{prefix}.{idx_conv + 1}.bias"]))
+    return relu_site(instance_norm(x, sd[f"{prefix}.{idx_conv + 1}.weight"], sd[f"{prefix}.{idx_conv + 1}.bias"]),
+                     f"{prefix}.{idx_conv + 1}", pins)
 
 
 def forward_r18(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_rate: float = 0.2,
@@ -111,28 +131,31 @@ def forward_r18(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
     rng = rng or {}
     # rng['noise_x']: perturbed encoder input of the second pass (model/unidefense.py:372-392); the clean x
     # stays the target of the attention residuals and of the reconstruction losses
-    _, ext = extractor(rng.get("noise_x", x), sd, training, freq_norm)
+    pins = rng.get("relu_masks")        # optional {site: bool pattern} recorded from the implementation under test
+    _, ext = extractor(rng.get("noise_x", x), sd, training, freq_norm, pins)
     d_in = ext
     if training and rng.get("dec_keep") is not None:
         d_in = ext * rng["dec_keep"].to(x.dtype) / 0.8
-    d = _dec(d_in, sd, "dec_block1", 0)
-    d = _dec(d, sd, "dec_block1", 3, transposed=True)
-    dec1 = _dec(d, sd, "dec_block1", 6)
-    d = _dec(dec1, sd, "dec_block2", 0)
-    d = _dec(d, sd, "dec_block2", 3, transposed=True)
-    d = _dec(d, sd, "dec_block2", 6)
+    d = _dec(d_in, sd, "dec_block1", 0, pins=pins)
+    d = _dec(d, sd, "dec_block1", 3, transposed=True, pins=pins)
+    dec1 = _dec(d, sd, "dec_block1", 6, pins=pins)
+    d = _dec(dec1, sd, "dec_block2", 0, pins=pins)
+    d = _dec(d, sd, "dec_block2", 3, transposed=True, pins=pins)
+    d = _dec(d, sd, "dec_block2", 6, pins=pins)
     dec2 = torch.tanh(F.conv2d(d, sd["dec_block2.9.weight"], None, 1, 1))
 
-    emb = emb_block1(ext, sd, training, rng.get("pool_sel"))
+    emb = emb_block1(ext, sd, training, rng.get("pool_sel"), pins)
     # attention (model/unidefense.py:326-361): ReLU filters, att_depth 512
     size = emb.shape[-2:]
     pred = interpolate(dec2.detach(), size)
     xs = interpolate(x, size)
     freq_diff = torch.abs(rfft2_cat(pred, freq_norm) - rfft2_cat(xs, freq_norm))
     emb_freq = rfft2_cat(emb, freq_norm)
-    ff = dynamic_filter_generic(emb_freq, freq_diff, sd, "freq_filter", training, 0, F.relu)
+    ff = dynamic_filter_generic(emb_freq, freq_diff, sd, "freq_filter", training, 0,
+                                lambda t: relu_site(t, "freq_filter.layer1.1", pins))
     freq_filtered = irfft2_split(ff["out"], size, freq_norm)
-    sf = dynamic_filter_generic(emb, torch.abs(pred - xs), sd, "spat_filter", training, 1, F.relu)
+    sf = dynamic_filter_generic(emb, torch.abs(pred - xs), sd, "spat_filter", training, 1,
+                                lambda t: relu_site(t, "spat_filter.layer1.1", pins))
     a = torch.sigmoid(sd["fuse_coef"])
     att = (1.0 - a) * sf["out"] + a * freq_filtered
     e = emb
@@ -140,7 +163,7 @@ def forward_r18(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
         e = emb * rng["emb_keep"].to(x.dtype) / (1.0 - drop_rate)
     att = att + e
 
-    h = emb_block2(att, sd, training)
+    h = emb_block2(att, sd, training, pins)
     h = h.mean((2, 3))
     fac = batch_norm(h, sd, "bottleneck", training, 1e-5)
     h = fac

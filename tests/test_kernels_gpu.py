@@ -85,6 +85,37 @@ def test_gemm_nt_nn_tn(M, N, K):
     check("tn", Kk.gemm_tn(at.to(dev), bt.to(dev)), at.double().t() @ bt.double())
 
 
+@pytest.mark.parametrize("kind,M,N,K", [("nt", 1280, 3264, 3264), ("nn", 1152, 256, 256), ("tn", 672, 672, 17408),
+                                        ("nt", 200, 72, 100), ("nn", 132, 68, 36), ("tn", 68, 76, 1001)])
+def test_gemm_split_bf16_path_has_fp32_accuracy(kind, M, N, K):
+    """csrc/gemm_x3.hip (three exact bf16 pieces per operand, six products on the BF16 matrix pipe) against the
+    v_mfma_f32_32x32x2_f32 kernel and float64: the error relative to sum|a||b| must not exceed the fp32 kernel's
+    (x1.5 + 1e-7 slack), on wide-dynamic-range random operands and on same-sign operands (linearly growing sums)."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk, lib
+    g = torch.Generator().manual_seed(7)
+    for same_sign in (False, True):
+        sa, sb = ((K, M) if kind == "tn" else (M, K)), ((N, K) if kind == "nt" else (K, N))
+        a, b = torch.randn(sa, generator=g), torch.randn(sb, generator=g)
+        a, b = a * torch.exp(2 * torch.randn(sa, generator=g)), b * torch.exp(2 * torch.randn(sb, generator=g))
+        if same_sign:
+            a, b = a.abs(), b.abs()
+        A = a.double().t() if kind == "tn" else a.double()
+        B = b.double().t() if kind == "nt" else b.double()
+        ref, scale = A @ B, A.abs() @ B.abs()
+        errs = []
+        try:
+            for path in (1, 2):
+                lib.call("ud_gemm_set_path", path)
+                y = {"nt": Kk.gemm_nt, "nn": Kk.gemm_nn, "tn": Kk.gemm_tn}[kind](a.to(dev), b.to(dev))
+                errs.append(((y.double().cpu() - ref).abs() / scale).max().item())
+        finally:
+            lib.call("ud_gemm_set_path", 0)
+        print(f"  {kind} {M}x{N}x{K} same_sign={same_sign}: fp32-mfma {errs[0]:.3e}  split-bf16 {errs[1]:.3e}")
+        assert errs[1] <= 1.5 * errs[0] + 1e-7, errs
+        assert errs[1] <= 2e-5
+
+
 def test_gemm_tn_splitk_and_accumulate():
     dev = _dev()
     from unidefense_amd import kernels as Kk

@@ -192,11 +192,30 @@ def test_r18_vs_reference_golden_and_oracle(golden_dir):
     # the HIP path's (the oracle asserts each pinned winner is a maximum within 2e-5) so that the gradients
     # are compared on the same branch; the float32 CPU run keeps its own arg-max and shows the effect of a flip
     sel = m._debug_feats["pool_sel"].permute(0, 3, 1, 2).cpu()
+    # ... and likewise the on/off pattern of every ReLU (oracle/r18.py:relu_site checks that the pattern departs
+    # from the oracle's own only on units within 1e-4 of zero): a ReLU network's gradient is piecewise constant in
+    # those signs, ~10 of the ~1e7 units of this batch sit within fp32 rounding of 0, and each flip moves some
+    # weight gradients by ~1e-2 — two correct fp32 evaluations that round differently land on different pieces
+    masks = {k: v.permute(0, 3, 1, 2).cpu() for k, v in m._debug_kinks.items()}
+    pinned = dict(rng, pool_sel=sel, relu_masks=masks)
     sd64 = r18_state(torch.float64, requires_grad=True)
-    o64 = r18.forward_r18(sd64, x.double(), training=True, drop_rate=0.5, rng=dict(rng, pool_sel=sel))
+    o64 = r18.forward_r18(sd64, x.double(), training=True, drop_rate=0.5, rng=pinned)
+    assert masks["_used"] == set(masks) - {"_used"}, sorted(set(masks) - {"_used"} - masks["_used"])
+    print(f"  pinned {len(masks) - 1} ReLU sites + the max-pool winners to the HIP path's pattern")
     _loss(o64, tgt, lam).backward()
     sd32 = r18_state(requires_grad=True)
-    _loss(r18.forward_r18(sd32, x, training=True, drop_rate=0.5, rng=dict(rng, pool_sel=sel)), tgt, lam).backward()
+    _loss(r18.forward_r18(sd32, x, training=True, drop_rate=0.5, rng=pinned), tgt, lam).backward()
+    # Conditioning yardstick, independent of any implementation: how far the EXACT (float64) gradient moves, on the
+    # same pinned piece, when the input is perturbed by one fp32 ulp (1e-7 relative).
+    sens = {}
+    for pseed in (1, 2):
+        gp = torch.Generator().manual_seed(pseed)
+        xp = x.double() * (1.0 + 1e-7 * torch.randn(x.shape, generator=gp, dtype=torch.float64))
+        sdp = r18_state(torch.float64, requires_grad=True)
+        _loss(r18.forward_r18(sdp, xp, training=True, drop_rate=0.5, rng=pinned), tgt, lam).backward()
+        for k, v in sdp.items():
+            if v.grad is not None:
+                sens[k] = max(sens.get(k, 0.0), (v.grad - sd64[k].grad).abs().max().item())
     ld, t = out["loss_dict"], tgt.to(dev)
     trip = sum(LOSSES["aw_triplet"](f, t) for f in ld["triplet"])
     total = LOSSES["cross_entropy"](out["cls_out"], t) + lam["lambda_mask"] * (ld["freq_mask"].mean() + ld["spat_mask"].mean()) \
@@ -212,9 +231,11 @@ def test_r18_vs_reference_golden_and_oracle(golden_dir):
         d = (p.grad.detach().double().cpu() - ref).abs().max().item()
         s = ref.abs().max().item()
         d32 = (sd32[k].grad.double() - ref).abs().max().item()
-        rows.append((d / max(GRAD_RTOL * s + GRAD_ATOL, 5.0 * d32), k, d, s, d32))
+        # on the pinned piece the problem is smooth: 1e-4 of the tensor's scale (observed: <= 2e-5), never looser
+        # than 5x what the CPU fp32 run or a one-ulp input perturbation do to the same gradient
+        rows.append((d / max(1e-4 * s + 2e-6, 5.0 * d32, 5.0 * sens.get(k, 0.0)), k, d, s, d32, sens.get(k, 0.0)))
     rows.sort(reverse=True)
     for r in rows[:10]:
-        print("  %.3f  %-50s maxerr %.3e  maxref %.3e  cpu-fp32-err %.3e" % r)
+        print("  %.3f  %-50s maxerr %.3e  maxref %.3e  cpu-fp32-err %.3e  ulp-sensitivity %.3e" % r)
     bad = [r for r in rows if not r[0] < 1.0]
     assert not bad, bad[:10]

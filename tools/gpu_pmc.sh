@@ -13,13 +13,13 @@ import csv, glob, collections
 for f in sorted(glob.glob("gpurun_out/$tag/*counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "gemm_kernel" in r["Kernel_Name"]:
+        if "gemm_" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f)
     for k, v in agg.items():
         print("  %-28s n=%d  last=%.4g" % (k, len(v), v[-1]))
 for f in sorted(glob.glob("gpurun_out/$tag/*kernel_trace.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "gemm_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "gemm_" in r["Kernel_Name"]]
     if rows:
         r = rows[-1]
         print(f, "dur_us", (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, "vgpr", r.get("VGPR_Count"), "lds", r.get("LDS_Block_Size"), "grid", r.get("Grid_Size"), r["Kernel_Name"][:60])

@@ -12,7 +12,10 @@
 // 32 consecutive floats).  Register prefetch of tile t+1 overlaps the MFMAs of tile t; one barrier
 // per K-tile.  fp32 MFMA is exact f32 FMA chaining (k ascending), the same arithmetic as the reference's
 // fp32 path up to summation order.
+#include "gemm_internal.h"
 #include "ud_common.h"
+
+#include <atomic>
 
 namespace {
 
@@ -424,7 +427,19 @@ int launch_modes(const ud_gemm_desc& d, int a_vec, int b_vec, hipStream_t s) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// 0 auto, 1 fp32 MFMA only (v_mfma_f32_32x32x2_f32), 2 split-bf16 wherever eligible (gemm_x3.hip)
+std::atomic<int> g_path{[] {
+    const char* e = getenv("UD_GEMM_PATH");
+    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+}()};
+
 }  // namespace
+
+extern "C" int ud_gemm_set_path(int path) {
+    if (path < 0 || path > 2) return UD_EINVAL;
+    g_path.store(path);
+    return 0;
+}
 
 extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
     if (!dp) return UD_EINVAL;
@@ -448,6 +463,12 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         long rows = (long)g.N * g.Hout * g.Wout, cols = (long)g.KH * g.KW * g.Cin;
         if (d.a_mode == 2 && (rows != d.M || cols != d.K)) return UD_EINVAL;
         if (d.b_mode == 2 && (rows != d.K || cols != d.N)) return UD_EINVAL;
+    }
+    const int path = g_path.load();
+    if (path != 1 && ud_gemm_x3_eligible(d, a_vec != 0, b_vec != 0)) {
+        // auto: the bf16-pipe kernel pays once a launch has whole 64-wide tiles in both dimensions and enough
+        // K to amortise its 3-tile prologue; skinny outputs stay on the 256x32 / 32x256 fp32 tiles
+        if (path == 2 || (d.M >= 64 && d.N >= 64 && d.K >= 64)) return ud_gemm_x3_launch(d, s);
     }
     static const bool noload = getenv("UD_GEMM_NOLOAD") != nullptr;
     if (noload) a_vec |= 2;

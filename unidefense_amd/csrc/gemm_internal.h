@@ -1,0 +1,8 @@
+// Internal interface between gemm.hip (ud_gemm entry point, fp32-MFMA kernel) and gemm_x3.hip (split-bf16 kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/unidefense_hip.h"
+
+// plain GEMM modes with 16-byte-loadable operands and no ragged vector tails
+bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec);
+int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s);

@@ -1,0 +1,353 @@
+// fp32 GEMM on the gfx950 BF16 matrix pipe: every fp32 operand is split EXACTLY into three bf16 pieces
+//   x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)      (8 + 8 + 8 significand bits)
+// and a*b is accumulated in fp32 from the six piece products of order <= 2^-16
+//   a0b0 + (a0b1 + a1b0) + (a1b1 + a0b2 + a2b0);
+// the dropped terms (a1b2, a2b1, a2b2) are below 2^-26 |ab|, i.e. under the rounding of an fp32 FMA chain.  Each
+// piece product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result has fp32 GEMM
+// accuracy (tests/test_kernels_gpu.py compares both kernels with float64) while six bf16 MFMAs (6 x 32 cycles per
+// 32x32x16) replace eight fp32 MFMAs (8 x 64 cycles): 2.67x the fp32 matrix rate.
+//
+// Used by ud_gemm for the large plain GEMMs (a_mode, b_mode in {0,1}); the gather modes and the small / skinny
+// shapes stay on gemm.hip's v_mfma_f32_32x32x2_f32 kernel.
+//
+// Structure: 256 threads = 4 wave64, block tile BM x BN x 16, wave tile (TM x TN) x 32x32.  Operand tiles go
+// global -> registers (3 K-tiles in flight) -> split -> LDS as three bf16 planes per operand, each plane
+// [k-group h = 0,1][row][8 bf16 = 16 B], so that lane (r = l&31, h = l>>5) fetches its whole MFMA operand
+// (row r, k = 8h..8h+7) with ONE conflict-free ds_read_b128.  Two LDS stages, one barrier per K-tile.
+#include "gemm_internal.h"
+#include "ud_common.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+constexpr int PD = 3;                    // K-tiles of global loads in flight per thread (register ring)
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (lo = bf16(x), hi = bf16(y)), round-to-nearest-even: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
+    bf16x2 v = {(__bf16)x, (__bf16)y};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// exact three-way split of two floats; p[i] packs piece i of (x, y)
+__device__ __forceinline__ void split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = pack_bf16(x, y);
+    float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pack_bf16(rx, ry);
+    float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16(sx, sy);
+}
+
+// issue-order pipeline for one K-tile: (1 MFMA, 6 VALU, NW/NM LDS writes) x NM   (sched_group_barrier wants
+// literal constants, hence the recursion)
+template <int N, int NM, int NW>
+struct SchedPipe {
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        constexpr int W = (N + 1) * NW / NM - N * NW / NM;
+        if constexpr (W > 0) __builtin_amdgcn_sched_group_barrier(0x200, W, 0);
+        SchedPipe<N + 1, NM, NW>::run();
+    }
+};
+template <int NM, int NW>
+struct SchedPipe<NM, NM, NW> {
+    static __device__ __forceinline__ void run() {}
+};
+
+// rows 8..15 of every 16 swap neighbours: keeps the 32-lane operand reads contiguous and spreads the 4-byte
+// transposing stores of the row-contiguous operands over all banks
+__device__ __forceinline__ int phys_row(int row) { return row ^ ((row >> 3) & 1); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Operand tile: ROWS x 16.  MODE 0: source [row][k], K-contiguous.  MODE 1: source [k][row], row-contiguous.
+// Loads are branch-free (addresses clamped into the operand, validity re-derived at store time): a load under a
+// branch made hipcc wait for it on the spot, which serialised the whole prefetch ring.
+// ---------------------------------------------------------------------------------------------------------
+template <int ROWS, int MODE>
+struct XLoader {
+    static constexpr int GS = ROWS * 16 + 32;          // bytes of one (plane, k-group) image
+    static constexpr int STAGE = 6 * GS;               // 3 planes x 2 k-groups
+    static constexpr int NV0 = ROWS / 64;              // MODE 0: float4 (4 k of one row) per thread
+    static constexpr int VEC = ROWS / 32;              // MODE 1: rows per thread (x 2 consecutive k)
+    static constexpr int NV = MODE == 0 ? NV0 : 2;
+    static constexpr int NWRITE = MODE == 0 ? 3 * NV0 : 3 * VEC;    // ds_write instructions per stage
+    using V = typename std::conditional<(MODE == 0 || VEC == 4), f32x4, f32x2>::type;
+
+    const float* base;
+    long ld;
+    int k_last;           // last valid k of this workgroup's K range
+    long off[NV0 > 2 ? NV0 : 2];   // MODE 0: element offset of (clamped row, kq*4); MODE 1: [0] = clamped row offset
+    bool rowok[NV0 > 2 ? NV0 : 2];
+    int kloc;             // this thread's k offset inside a tile: MODE 0: 4*kq; MODE 1: 2*kb
+    V regs[PD][NV];
+
+    __device__ __forceinline__ void init(const float* p, long ld_, int dim, int row0, int k_end, int tid) {
+        base = p; ld = ld_; k_last = k_end - 1;
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < NV0; ++i) {
+                int f = tid + i * NTHREADS;
+                int r = row0 + (f >> 2);
+                rowok[i] = r < dim;
+                off[i] = (long)(rowok[i] ? r : 0) * ld;
+            }
+            kloc = (tid & 3) * 4;          // (tid + i*256) & 3 == tid & 3
+        } else {
+            const int q = (tid >> 5) * 4 + (tid & 3);
+            int r = row0 + q * VEC;
+            rowok[0] = r < dim;
+            off[0] = rowok[0] ? r : 0;
+            kloc = 2 * ((tid >> 2) & 7);
+        }
+    }
+
+    // tile whose first k is k0 (k0 < k_end; k0 % 16 == 0)
+    template <int S>
+    __device__ __forceinline__ void load(int k0) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < NV0; ++i) {
+                // K % 4 == 0: the float4 at k0 + kq4 is entirely inside or entirely outside [.., k_end); an outside
+                // one is redirected to the last inside one (k_last - 3) and zeroed at store time
+                regs[S][i] = *reinterpret_cast<const V*>(base + off[i] + min(k0 + kloc, k_last - 3));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int k = min(k0 + kloc + i, k_last);
+                regs[S][i] = *reinterpret_cast<const V*>(base + (long)k * ld + off[0]);
+            }
+        }
+    }
+
+    template <int S>
+    __device__ __forceinline__ void store(char* L, int tid, int k0) const {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < NV0; ++i) {
+                int f = tid + i * NTHREADS;
+                int row = f >> 2, kq = f & 3;
+                const bool ok = rowok[i] && (k0 + kq * 4 <= k_last);
+                V v = regs[S][i];
+                uint32_t a0, a1, a2, b0, b1, b2;
+                split2(ok ? v[0] : 0.f, ok ? v[1] : 0.f, a0, a1, a2);
+                split2(ok ? v[2] : 0.f, ok ? v[3] : 0.f, b0, b1, b2);
+                char* p = L + (kq >> 1) * GS + phys_row(row) * 16 + (kq & 1) * 8;
+                *reinterpret_cast<u32x2*>(p) = u32x2{a0, b0};
+                *reinterpret_cast<u32x2*>(p + 2 * GS) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2*>(p + 4 * GS) = u32x2{a2, b2};
+            }
+        } else {
+            const int q = (tid >> 5) * 4 + (tid & 3), kb = (tid >> 2) & 7;
+            const bool ok0 = rowok[0] && (k0 + kloc <= k_last), ok1 = rowok[0] && (k0 + kloc + 1 <= k_last);
+            char* p0 = L + (kb >> 2) * GS + (kb & 3) * 4;
+            V v0 = regs[S][0], v1 = regs[S][1];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                uint32_t a0, a1, a2;
+                split2(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f, a0, a1, a2);
+                char* p = p0 + phys_row(q * VEC + e) * 16;
+                *reinterpret_cast<uint32_t*>(p) = a0;
+                *reinterpret_cast<uint32_t*>(p + 2 * GS) = a1;
+                *reinterpret_cast<uint32_t*>(p + 4 * GS) = a2;
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc d, int tiles_m, int tiles_n) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+    using LA = XLoader<BM, AMODE>;
+    using LB = XLoader<BN, BMODE>;
+    __shared__ __attribute__((aligned(16))) char As[2][LA::STAGE];
+    __shared__ __attribute__((aligned(16))) char Bs[2][LB::STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y, bz = blockIdx.z;
+
+    const int kt_total = (d.K + BK - 1) / BK;
+    const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
+    const int k_begin = split * kt_per * BK;
+    int k_end = k_begin + kt_per * BK;
+    if (k_end > d.K) k_end = d.K;
+    const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
+    float* Cp = d.C + (long)bz * d.strideC;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nkt > 0) {
+        LA la; LB lb;
+        la.init(d.A + (long)bz * d.strideA, d.lda, d.M, m0, k_end, tid);
+        lb.init(d.B + (long)bz * d.strideB, d.ldb, d.N, n0, k_end, tid);
+        const int kt_max = nkt - 1;
+        auto k0_of = [&](int kt) { return k_begin + min(kt, kt_max) * BK; };   // clamped: surplus prefetches re-read the last tile
+
+        // prologue: K-tiles 0..PD-1 in flight, tile 0 into LDS stage 0, then tile PD into the freed slot
+        la.template load<0>(k0_of(0)); lb.template load<0>(k0_of(0));
+        la.template load<1>(k0_of(1)); lb.template load<1>(k0_of(1));
+        la.template load<2>(k0_of(2)); lb.template load<2>(k0_of(2));
+        la.template store<0>(As[0], tid, k0_of(0));
+        lb.template store<0>(Bs[0], tid, k0_of(0));
+        la.template load<0>(k0_of(PD)); lb.template load<0>(k0_of(PD));
+        __syncthreads();
+
+        const int pr = phys_row(l31);
+        const int a_off = half * LA::GS + (wm * TM * 32 + pr) * 16;
+        const int b_off = half * LB::GS + (wn * TN * 32 + pr) * 16;
+        constexpr int NM = TM * TN * 6;                    // MFMAs per K-tile and wave
+        constexpr int NW = LA::NWRITE + LB::NWRITE;        // LDS writes per K-tile and thread
+
+        // one K-tile: operands of tile kt from LDS stage kt&1 -> NM MFMAs; meanwhile (STAGE_NEXT) the register
+        // slot S holding tile kt+1 is split and written to the other LDS stage, then refilled with tile kt+1+PD
+        auto stage = [&](auto slot_c, auto stage_next_c, int kt) {
+            constexpr int S = decltype(slot_c)::value;
+            constexpr bool STAGE_NEXT = decltype(stage_next_c)::value;
+            const char* Ab = As[kt & 1] + a_off;
+            const char* Bb = Bs[kt & 1] + b_off;
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i][p] = *reinterpret_cast<const bf16x8*>(Ab + 2 * p * LA::GS + i * 512);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j][p] = *reinterpret_cast<const bf16x8*>(Bb + 2 * p * LB::GS + j * 512);
+            }
+            if constexpr (STAGE_NEXT) {
+                la.template store<S>(As[(kt + 1) & 1], tid, k0_of(kt + 1));
+                lb.template store<S>(Bs[(kt + 1) & 1], tid, k0_of(kt + 1));
+            }
+            // smallest terms first into the running sum
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+            if constexpr (STAGE_NEXT) {
+                // issue order: the split / LDS-write work rides in the issue slots between the MFMAs (an MFMA
+                // holds the vector issue port for 8 of its 32 cycles): 1 MFMA, 6 VALU, NW/NM LDS writes, repeat
+                SchedPipe<0, NM, NW>::run();
+                la.template load<S>(k0_of(kt + 1 + PD));
+                lb.template load<S>(k0_of(kt + 1 + PD));
+            }
+            __syncthreads();
+        };
+        using std::integral_constant;
+        int kt = 0;
+        for (; kt + PD <= kt_max; kt += PD) {          // steady state: branch-free body, register slots static
+            stage(integral_constant<int, 1>{}, integral_constant<bool, true>{}, kt);
+            stage(integral_constant<int, 2>{}, integral_constant<bool, true>{}, kt + 1);
+            stage(integral_constant<int, 0>{}, integral_constant<bool, true>{}, kt + 2);
+        }
+        // tail: kt is a multiple of PD, at most PD-1 staging iterations and the final compute-only one remain
+        if (kt < kt_max) { stage(integral_constant<int, 1>{}, integral_constant<bool, true>{}, kt); ++kt; }
+        if (kt < kt_max) { stage(integral_constant<int, 2>{}, integral_constant<bool, true>{}, kt); ++kt; }
+        stage(integral_constant<int, 0>{}, integral_constant<bool, false>{}, kt);
+    }
+
+    // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (nkt == 0 && d.out_mode != 0) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < d.M && col < d.N) {
+                    float* p = Cp + (long)row * d.ldc + col;
+                    float v = acc[i][j][r];
+                    if (d.out_mode == 0) *p = v;
+                    else if (d.out_mode == 1) *p += v;
+                    else atomicAdd(p, v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int AMODE, int BMODE>
+int launch_tile(const ud_gemm_desc& d, hipStream_t s) {
+    int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
+    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, (unsigned)d.batch);
+    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, 2, 2, AMODE, BMODE>), grid, dim3(NTHREADS), 0, s, d, tiles_m, tiles_n);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+struct XCfg { int bm, bn; double penalty; };
+constexpr XCfg kX[3] = {{128, 128, 1.00}, {128, 64, 1.10}, {64, 128, 1.10}};
+
+template <int AMODE, int BMODE>
+int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
+    static const int forced = [] {
+        const char* e = getenv("UD_GEMM_X3_CFG");
+        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
+    }();
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < 3; ++i) {
+        long tiles = (long)ud_cdiv(d.M, kX[i].bm) * ud_cdiv(d.N, kX[i].bn) * d.split_k * d.batch;
+        long rounds = (tiles + 511) / 512;                 // two workgroups per CU
+        double cost = (double)rounds * kX[i].bm * kX[i].bn * kX[i].penalty;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    if (forced >= 0) best = forced;
+    switch (best) {
+        case 1: return launch_tile<128, 64, AMODE, BMODE>(d, s);
+        case 2: return launch_tile<64, 128, AMODE, BMODE>(d, s);
+        default: return launch_tile<128, 128, AMODE, BMODE>(d, s);
+    }
+}
+
+}  // namespace
+
+bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
+    if (d.a_mode > 1 || d.b_mode > 1) return false;
+    if (!(d.a_mode == 0 && d.b_mode == 0) && !(d.a_mode == 0 && d.b_mode == 1) && !(d.a_mode == 1 && d.b_mode == 1))
+        return false;
+    if (!a_vec || !b_vec) return false;
+    if ((d.a_mode == 0 || d.b_mode == 0) && d.K % 4 != 0) return false;
+    if (d.a_mode == 1 && d.M % 4 != 0) return false;
+    if (d.b_mode == 1 && d.N % 4 != 0) return false;
+    return true;
+}
+
+int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s) {
+    if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0>(d, s);
+    if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1>(d, s);
+    if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1>(d, s);
+    return UD_EINVAL;
+}

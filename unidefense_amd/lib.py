@@ -33,6 +33,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 # name -> argtypes (the trailing stream argument included); every function returns int
 _SIGNATURES = {
     "ud_gemm": [C.POINTER(GemmDesc), _P],
+    "ud_gemm_set_path": [C.c_int],
     "ud_reduce_chunks": [_I, _I, _I],
     "ud_norm_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "ud_norm_apply_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],

@@ -103,11 +103,16 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, noise_x, rng, *params):
         tape = T.Tape()
+        debug = getattr(model, "_debug_watch", False)
+        if debug:
+            tape.kinks = {}
         outs = model._run(x, tape, rng, noise_x)
-        if getattr(model, "_debug_watch", False):            # tests: capture activation gradients
+        if debug:                                            # tests: capture activation gradients / ReLU patterns
             tape.watch = {id(t): k for k, t in outs["_feats"].items()}
             model._debug_tape = tape
             model._debug_feats = outs["_feats"]
+            names = {id(p): n[: -len(".weight")] for n, p in model.named_parameters() if n.endswith(".weight")}
+            model._debug_kinks = {names.get(k, k): (y > 0) for k, y in tape.kinks.items()}
         ctx.tape = tape
         ctx.outs = outs
         ctx.params = params

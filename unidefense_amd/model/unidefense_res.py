@@ -163,7 +163,13 @@ class UniDefenseModelRes18(nn.Module):
         if blk.downsample is not None:
             sc = T.conv_dense_any(tape, x, blk.downsample[0].weight, blk.stride, 0)
             sc = self._bn(tape, sc, blk.downsample[1], 0)
-        return T.add_relu(tape, y, sc)
+        return T.add_relu(tape, y, sc, site=self._block_name(blk) + ".add")
+
+    def _block_name(self, mod):
+        names = getattr(self, "_mod_names", None)
+        if names is None:
+            names = self._mod_names = {id(m): n for n, m in self.named_modules()}
+        return names[id(mod)]
 
     def _dec(self, tape, x, dec, idx, transposed=False):
         x = T.conv_transpose_s2(tape, x, dec[idx].weight) if transposed else \
@@ -209,7 +215,7 @@ class UniDefenseModelRes18(nn.Module):
         idt = T.conv1x1(tape, ext, e1.downsample[0].weight)
         idt = self._bn(tape, idt, e1.downsample[1], 0)
         idt, pool_sel = T.maxpool3s2(tape, idt, return_arg=True)
-        emb = T.add_relu(tape, o, idt)
+        emb = T.add_relu(tape, o, idt, site="emb_block1.add")
 
         # attention (model/unidefense.py:326-361) with ReLU filters
         n_, hh, ww, Cc = emb.shape
@@ -241,7 +247,7 @@ class UniDefenseModelRes18(nn.Module):
         o = self._bn(tape, o, e2.norm1, 2)
         o = T.conv_dense_any(tape, o, e2.conv2.weight, 1, 1)
         o = self._bn(tape, o, e2.norm2, 0)
-        h = T.add_relu(tape, o, att)
+        h = T.add_relu(tape, o, att, site="emb_block2.add")
 
         pooled = T.mean_hw(tape, h)
         fac = self._bn(tape, pooled, self.bottleneck, 0)

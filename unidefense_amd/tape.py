@@ -27,6 +27,7 @@ class Tape:
         self._keep = []          # keep keyed tensors alive so ids stay unique
         self.watch = None        # debug: {id(tensor): name} -> gradients captured into self.captured
         self.captured = {}
+        self.kinks = None        # parity tests: {site: ReLU output} (site = id(norm weight) or an explicit name)
 
     # -- recording -------------------------------------------------------------------------
     def record(self, fn):
@@ -295,6 +296,8 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
         mean = running_mean.view(1, Cc)
         invstd = torch.rsqrt(running_var + eps).view(1, Cc)
     y = K.norm_apply(x2, 1, R, mean, invstd, weight, bias, act).view(x.shape)
+    if act == 2 and tape is not None and tape.kinks is not None:
+        tape.kinks[id(weight)] = y
     if _needs(tape):
         if not training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
@@ -325,6 +328,8 @@ def instancenorm_act(tape, x, weight, bias, eps, act):
     x2 = x.view(-1, Cc)
     mean, invstd = K.norm_stats(x2, N, H * W, eps)
     y = K.norm_apply(x2, N, H * W, mean, invstd, weight, bias, act).view(x.shape)
+    if act == 2 and tape is not None and tape.kinks is not None:
+        tape.kinks[id(weight)] = y
     if _needs(tape):
         def bwd():
             dy = tape.pop_grad(y)
@@ -569,9 +574,12 @@ def sfconv_dense(tape, x, w, w_freq, alpha, stride, norm):
     return sfmix(tape, spat, fr, alpha)
 
 
-def add_relu(tape, a, b):
-    """`x += shortcut; x = relu(x)` (model/resnet/exp.py:146-147)."""
+def add_relu(tape, a, b, site=None):
+    """`x += shortcut; x = relu(x)` (model/resnet/exp.py:146-147).  site: name under which the parity tests find
+    this ReLU's on/off pattern (tape.kinks)."""
     y = K.add_act(a, b, 2)
+    if tape is not None and tape.kinks is not None and site is not None:
+        tape.kinks[site] = y
     if _needs(tape):
         def bwd():
             dy = tape.pop_grad(y)
