@@ -71,35 +71,39 @@ int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
 int ud_gemm_set_path(int path);
 
 /* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------
- * P = ud_reduce_chunks(G, R, C) row-chunks per group; part buffers hold G*P*C DOUBLES each (fp64 accumulation).
+ * Every reduction is a partial pass (fp64 per-workgroup totals stored into the scratch `ws`) plus a small
+ * finalize launch; deterministic, no atomics.  ws: ud_reduce_ws_doubles(G, R, C) doubles of scratch, no
+ * initialisation needed, contents undefined afterwards (one buffer can serve all calls issued in order on a stream).
  * Serves nn.BatchNorm2d/1d in training mode (model/efficientnet/model.py:67,77,91,186,222;
  * model/unidefense.py:104; model/modules.py:83,112), nn.InstanceNorm2d (model/unidefense.py:54),
  * MemoryEfficientSwish (utils.py:66-82), adaptive_avg_pool2d(x,1) / mean([-2,-1]). */
-int ud_reduce_chunks(int G, int R, int C);
+int ud_reduce_ws_doubles(int G, int R, int C);
 /* mean[G][C], invstd[G][C] = 1/sqrt(biased var + eps); var_out optional; when running_mean != NULL and
  * G == 1 the running statistics are updated in place (momentum, unbiased variance) like nn.BatchNorm. */
-int ud_norm_stats(const float* x, int G, int R, int C, int P, float eps, double* part1, double* part2,
-                  float* mean, float* invstd, float* var_out, float momentum, float* running_mean,
-                  float* running_var, ud_stream_t stream);
+int ud_norm_stats(const float* x, int G, int R, int C, float eps, double* ws, float* mean, float* invstd,
+                  float* var_out, float momentum, float* running_mean, float* running_var, ud_stream_t stream);
+/* torch.nn.SyncBatchNorm forward exchange (engine/forgery_engine.py:142), after an all_gather of every rank's
+ * (mean, biased var) over `rows_per_rank` rows each: gathered[world][2][C] -> global mean / invstd, running
+ * statistics updated with the unbiased variance over world*rows_per_rank rows (running_* may be NULL). */
+int ud_syncbn_combine(const float* gathered, int world, int C, long rows_per_rank, float eps, float momentum,
+                      float* running_mean, float* running_var, float* mean, float* invstd, ud_stream_t stream);
 /* y = act(gamma * (x - mean[g]) * invstd[g] + beta) */
 int ud_norm_apply_fwd(const float* x, int G, int R, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act, float* y, ud_stream_t stream);
 /* dz = dy * act'(z); s1 = sum dz, s2 = sum dz*xhat per (g,c); dgamma = sum_g s2, dbeta = sum_g s1;
  * dx = gamma*invstd*(dz - s1/R - xhat*s2/R)   (dx may be NULL: reductions only) */
-int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, int P, const float* mean,
-                const float* invstd, const float* gamma, const float* beta, int act, double* part1,
-                double* part2, float* s1, float* s2, float* dgamma, float* dbeta, float* dx,
-                ud_stream_t stream);
+int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, const float* mean, const float* invstd,
+                const float* gamma, const float* beta, int act, double* ws, float* s1, float* s2, float* dgamma,
+                float* dbeta, float* dx, ud_stream_t stream);
 /* the elementwise half of ud_norm_bwd with caller-provided sums (already all-reduced over the ranks) and
  * inv_count = 1 / (rows of all ranks): SyncBatchNorm backward (engine/forgery_engine.py:142) */
 int ud_norm_bwd_apply(const float* x, const float* dy, int G, int R, int C, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* s1,
                       const float* s2, float inv_count, int act, float* dx, ud_stream_t stream);
 /* out[g][c] = scale * sum_r x[g][r][c] ;  out[g][c] = scale * sum_r a*b */
-int ud_group_colsum(const float* x, int G, int R, int C, int P, float scale, double* part1, float* out,
+int ud_group_colsum(const float* x, int G, int R, int C, float scale, double* ws, float* out, ud_stream_t stream);
+int ud_group_coldot(const float* a, const float* b, int G, int R, int C, float scale, double* ws, float* out,
                     ud_stream_t stream);
-int ud_group_coldot(const float* a, const float* b, int G, int R, int C, int P, float scale, double* part1,
-                    float* out, ud_stream_t stream);
 /* out[n][p][c] = g[n][c] * scale   (gradient of the mean over the HW rows) */
 int ud_bcast_rows(const float* g, float scale, float* out, int N, int HW, int C, ud_stream_t stream);
 

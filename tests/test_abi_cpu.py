@@ -31,10 +31,10 @@ def test_invalid_arguments_are_rejected_without_gpu():
     from unidefense_amd import lib
     # argument validation happens before any HIP call
     assert lib.load().ud_gemm(None, None) == -1000
-    assert lib.load().ud_reduce_chunks(1, 10, 6) == -1000      # C % 4 != 0
+    assert lib.load().ud_reduce_ws_doubles(0, 16, 8) == -1000      # G < 1
     assert lib.load().ud_rfft2(None, None, 1, 12, 4, 1.0, 1.0, None) == -1000   # unsupported size
     with pytest.raises(lib.UDLibraryError):
-        lib.call("ud_reduce_chunks", 1, 10, 6)
+        lib.call("ud_reduce_ws_doubles", 0, 16, 8)
 
 
 def test_model_refuses_cpu_tensors():

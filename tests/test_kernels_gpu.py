@@ -116,6 +116,26 @@ def test_gemm_split_bf16_path_has_fp32_accuracy(kind, M, N, K):
         assert errs[1] <= 2e-5
 
 
+def test_syncbn_combine_matches_gloo_tested_formula():
+    """ud_syncbn_combine (the product's SyncBatchNorm fold) against tape.sync_batch_stats' math — the function the
+    world_size-2 gloo test (tests/test_parallel_cpu.py) checks against torch.nn.SyncBatchNorm semantics."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    world, C, rows = 4, 272, 2048
+    full = rnd(world * rows, C, seed=3) * 2.0 + 0.7
+    shards = full.view(world, rows, C)
+    gathered = torch.stack([torch.stack([s.mean(0), s.var(0, unbiased=False)]) for s in shards])      # [world, 2, C]
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean, invstd = Kk.syncbn_combine(gathered.to(dev).contiguous(), world, C, rows, 1e-3, 0.1, rm, rv)
+    ref_mean = full.double().mean(0)
+    ref_var = full.double().var(0, unbiased=False)
+    check("syncbn mean", mean.view(-1), ref_mean, 1e-5)
+    check("syncbn invstd", invstd.view(-1), 1.0 / torch.sqrt(ref_var + 1e-3), 1e-5)
+    n = world * rows
+    check("syncbn running_mean", rm, 0.1 * ref_mean, 1e-5)
+    check("syncbn running_var", rv, 0.9 + 0.1 * ref_var * n / (n - 1), 1e-5)
+
+
 def test_gemm_tn_splitk_and_accumulate():
     dev = _dev()
     from unidefense_amd import kernels as Kk

@@ -5,12 +5,14 @@
 // their backward, the fused swish (model/efficientnet/utils.py:66-82), F.adaptive_avg_pool2d(x, 1) and
 // x.mean([-2,-1]) (G = N; model/efficientnet/model.py:118, model/unidefense.py:226,232-236).
 //
-// All of these are HBM-bound: one coalesced 16-B-per-lane pass over the tensor per kernel.  A reduction
-// is two launches: a partial pass (grid = chunks x channel-slabs x groups; every thread owns 4 adjacent
-// channels and strides over rows, then the block folds its row-lanes through LDS) and a finalize that
-// sums the chunk partials with 16 lanes per channel.  Accumulation is in fp64 (the kernels are bandwidth
-// bound, so it is free) — batch statistics over millions of rows and the cancelling sums of the backward
-// then carry no summation error of their own.  Deterministic (no atomics).
+// All of these are HBM-bound: one coalesced 16-B-per-lane pass over the tensor per kernel.  A reduction is two
+// launches.  Partial pass: grid = row-chunks x channel-groups x groups; a workgroup owns <= 32 float4 columns
+// (<= 512 contiguous bytes of a row) and one row-chunk, every thread strides over rows with four independent
+// 16-byte loads in flight, the block folds its row-lanes through LDS and stores its totals as fp64 partials.
+// Finalize: 16 lanes per channel sum the chunk partials and produce the op's outputs.  fp64 accumulation (free:
+// the kernels are bandwidth bound), no atomics: deterministic.
+// A single-launch variant (fp64 atomics + "last workgroup finalizes" ticket) was measured and dropped: on this
+// multi-XCD part the device-scope fence every workgroup needs costs more than the second launch (3-6x slower).
 #include "ud_common.h"
 
 namespace {
@@ -18,27 +20,23 @@ namespace {
 constexpr int NT = 256;
 
 struct RedGeom {
-    int G, R, C4, P;      // groups, rows per group, float4 channels, chunks per group
-    int rpi;              // rows per block iteration
+    int G, R, C4, P;      // groups, rows per group, float4 channels, row-chunks per group
+    int CW;               // float4 columns per workgroup (<= 32)
+    int rpi;              // rows per block iteration = NT / CW
     int rows_per_chunk;
 };
 
 __device__ __forceinline__ bool thread_coords(const RedGeom& q, int& ri, int& c4) {
     int t = threadIdx.x;
-    if (q.C4 <= NT) {
-        ri = t / q.C4;
-        c4 = t % q.C4;
-        return ri < q.rpi;
-    }
-    ri = 0;
-    c4 = blockIdx.y * NT + t;
-    return c4 < q.C4;
+    ri = t / q.CW;
+    c4 = blockIdx.y * q.CW + t % q.CW;
+    return ri < q.rpi && c4 < q.C4;
 }
 
 // fold the row-lanes of a block: v[NQ] per thread -> thread (ri == 0) holds the block total
 template <int NQ>
-__device__ __forceinline__ void block_fold(const RedGeom& q, int ri, int c4, bool active, double (&v)[8]) {
-    if (q.C4 > NT || q.rpi == 1) return;
+__device__ __forceinline__ void block_fold(const RedGeom& q, int ri, bool active, double (&v)[8]) {
+    if (q.rpi == 1) return;
     __shared__ double sm[NT * NQ];
     if (active) {
 #pragma unroll
@@ -47,7 +45,7 @@ __device__ __forceinline__ void block_fold(const RedGeom& q, int ri, int c4, boo
     __syncthreads();
     if (active && ri == 0) {
         for (int r = 1; r < q.rpi; ++r) {
-            int t = r * q.C4 + c4;
+            int t = r * q.CW + (int)threadIdx.x;          // ri == 0: threadIdx.x is the column lane
 #pragma unroll
             for (int i = 0; i < NQ; ++i) v[i] += sm[t * NQ + i];
         }
@@ -55,6 +53,29 @@ __device__ __forceinline__ void block_fold(const RedGeom& q, int ri, int c4, boo
 }
 
 enum { RED_STATS = 0, RED_NORMBWD = 1, RED_SUM = 2, RED_DOT = 3 };
+
+template <int MODE>
+__device__ __forceinline__ void accumulate(const f32x4& a, const f32x4& b, const f32x4& mu, const f32x4& is,
+                                           const f32x4& ga, const f32x4& be, int act, double (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (MODE == RED_STATS) {
+            double d = (double)a[e];
+            v[e] += d;
+            v[4 + e] += d * d;
+        } else if (MODE == RED_NORMBWD) {
+            float xh = (a[e] - mu[e]) * is[e];
+            float dz = b[e];
+            if (act) dz *= ud_act_grad(ga[e] * xh + be[e], act);
+            v[e] += (double)dz;
+            v[4 + e] += (double)dz * (double)xh;
+        } else if (MODE == RED_SUM) {
+            v[e] += (double)a[e];
+        } else {
+            v[e] += (double)a[e] * (double)b[e];
+        }
+    }
+}
 
 // part1/part2: double [(g*P + p)][C]
 template <int MODE>
@@ -64,6 +85,8 @@ __global__ __launch_bounds__(NT) void colreduce_partial(RedGeom q, const float* 
                                                         const float* __restrict__ invstd,  // [G][C]
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int act, double* __restrict__ part1, double* __restrict__ part2) {
+    constexpr bool HAS_Y = (MODE == RED_NORMBWD || MODE == RED_DOT);
+    constexpr int NQ = (MODE == RED_STATS || MODE == RED_NORMBWD) ? 8 : 4;
     int ri, c4;
     bool active = thread_coords(q, ri, c4);
     const int g = blockIdx.z, p = blockIdx.x;
@@ -82,38 +105,26 @@ __global__ __launch_bounds__(NT) void colreduce_partial(RedGeom q, const float* 
             ga = reinterpret_cast<const f32x4*>(gamma)[c4];
             be = reinterpret_cast<const f32x4*>(beta)[c4];
         }
-        for (int r = r_begin + ri; r < r_end; r += q.rpi) {
-            const long idx = gbase + (long)r * q.C4 + c4;
+        const long step = (long)q.rpi * q.C4;
+        int r = r_begin + ri;
+        long idx = gbase + (long)r * q.C4 + c4;
+        for (; r + 3 * q.rpi < r_end; r += 4 * q.rpi, idx += 4 * step) {     // four loads in flight per thread
+            f32x4 a0 = x4[idx], a1 = x4[idx + step], a2 = x4[idx + 2 * step], a3 = x4[idx + 3 * step];
+            f32x4 b0 = a0, b1 = a0, b2 = a0, b3 = a0;
+            if (HAS_Y) { b0 = y4[idx]; b1 = y4[idx + step]; b2 = y4[idx + 2 * step]; b3 = y4[idx + 3 * step]; }
+            accumulate<MODE>(a0, b0, mu, is, ga, be, act, v);
+            accumulate<MODE>(a1, b1, mu, is, ga, be, act, v);
+            accumulate<MODE>(a2, b2, mu, is, ga, be, act, v);
+            accumulate<MODE>(a3, b3, mu, is, ga, be, act, v);
+        }
+        for (; r < r_end; r += q.rpi, idx += step) {
             f32x4 a = x4[idx];
-            if (MODE == RED_STATS) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    double d = (double)a[e];
-                    v[e] += d;
-                    v[4 + e] += d * d;
-                }
-            } else if (MODE == RED_NORMBWD) {
-                f32x4 dy = y4[idx];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float xh = (a[e] - mu[e]) * is[e];
-                    float dz = dy[e];
-                    if (act) dz *= ud_act_grad(ga[e] * xh + be[e], act);
-                    v[e] += (double)dz;
-                    v[4 + e] += (double)dz * (double)xh;
-                }
-            } else if (MODE == RED_SUM) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (double)a[e];
-            } else {
-                f32x4 b = y4[idx];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (double)a[e] * (double)b[e];
-            }
+            f32x4 b = a;
+            if (HAS_Y) b = y4[idx];
+            accumulate<MODE>(a, b, mu, is, ga, be, act, v);
         }
     }
-    constexpr int NQ = (MODE == RED_STATS || MODE == RED_NORMBWD) ? 8 : 4;
-    block_fold<NQ>(q, ri, c4, active, v);
+    block_fold<NQ>(q, ri, active, v);
     if (active && ri == 0) {
         const long o = (((long)g * q.P + p) * q.C4 + c4) * 4;
 #pragma unroll
@@ -180,18 +191,23 @@ __global__ __launch_bounds__(NT) void stats_finalize(int G, int R, int C, int P,
     }
 }
 
-// s1,s2: float [G][C] sums over chunks
+// s1,s2: float [G][C] sums over chunks; for G == 1 also dgamma = s2, dbeta = s1 (saves the group_sum launch)
 __global__ __launch_bounds__(NT) void normbwd_finalize(int G, int C, int P, const double* __restrict__ part1,
                                                        const double* __restrict__ part2, float* __restrict__ s1o,
-                                                       float* __restrict__ s2o) {
+                                                       float* __restrict__ s2o, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta) {
     int idx; bool lead; double s1, s2;
     chunk_sums(G, C, P, part1, part2, idx, lead, s1, s2);
     if (!lead) return;
     s1o[idx] = (float)s1;
     s2o[idx] = (float)s2;
+    if (G == 1) {
+        if (dbeta) dbeta[idx] = (float)s1;
+        if (dgamma) dgamma[idx] = (float)s2;
+    }
 }
 
-// dgamma[c] = sum_g s2[g][c], dbeta[c] = sum_g s1[g][c]
+// dgamma[c] = sum_g s2[g][c], dbeta[c] = sum_g s1[g][c]   (G > 1: InstanceNorm)
 __global__ void group_sum(int G, int C, const float* __restrict__ s1, const float* __restrict__ s2,
                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,6 +226,31 @@ __global__ __launch_bounds__(NT) void partial_sum_finalize(int G, int C, int P, 
     int idx; bool lead; double s1, s2;
     chunk_sums(G, C, P, part1, nullptr, idx, lead, s1, s2);
     if (lead) out[idx] = (float)(s1 * (double)scale);
+}
+
+// ---- SyncBatchNorm: combine the gathered per-rank (mean, biased var) of equally sized shards ------------------
+// st: [ws][2][C];  mean = avg_r mean_r;  var = avg_r (var_r + (mean_r - mean)^2)
+__global__ void syncbn_combine(const float* __restrict__ st, int world, int C, double n_total, float eps,
+                               float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                               float* __restrict__ mean, float* __restrict__ invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double m = 0.0;
+    for (int r = 0; r < world; ++r) m += (double)st[((long)r * 2) * C + c];
+    m /= (double)world;
+    double var = 0.0;
+    for (int r = 0; r < world; ++r) {
+        double d = (double)st[((long)r * 2) * C + c] - m;
+        var += (double)st[((long)r * 2 + 1) * C + c] + d * d;
+    }
+    var /= (double)world;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        const double unb = (n_total > 1.0) ? var * n_total / (n_total - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
 }
 
 // ---- elementwise passes -----------------------------------------------------------------------
@@ -272,15 +313,26 @@ __global__ __launch_bounds__(NT) void norm_apply_bwd(long total4, int R, int C4,
     }
 }
 
-RedGeom make_geom(int G, int R, int C, int P) {
+// Decomposition: a workgroup owns CW float4 columns (<= 128 channels) and one row-chunk; ~2048 workgroups,
+// >= 8 rows per thread where the tensor allows.
+RedGeom make_geom(int G, int R, int C) {
     RedGeom q;
-    q.G = G; q.R = R; q.C4 = C / 4; q.P = P;
-    q.rpi = (q.C4 <= NT) ? (NT / q.C4) : 1;
-    q.rows_per_chunk = (R + P - 1) / P;
+    q.G = G; q.R = R; q.C4 = C / 4;
+    q.CW = q.C4 < 32 ? q.C4 : 32;
+    q.rpi = NT / q.CW;
+    const int cgroups = (q.C4 + q.CW - 1) / q.CW;
+    long want = 2048 / ((long)G * cgroups);
+    if (want < 1) want = 1;
+    long maxp = (R + (long)q.rpi * 8 - 1) / ((long)q.rpi * 8);
+    if (maxp < 1) maxp = 1;
+    long P = want < maxp ? want : maxp;
+    if (P > 1024) P = 1024;
+    q.P = (int)P;
+    q.rows_per_chunk = (R + q.P - 1) / q.P;
     return q;
 }
 
-dim3 red_grid(const RedGeom& q) { return dim3((unsigned)q.P, (unsigned)((q.C4 + NT - 1) / NT), (unsigned)q.G); }
+dim3 red_grid(const RedGeom& q) { return dim3((unsigned)q.P, (unsigned)((q.C4 + q.CW - 1) / q.CW), (unsigned)q.G); }
 
 int ew_blocks(long total4) {
     long b = (total4 + NT - 1) / NT;
@@ -295,31 +347,35 @@ inline dim3 fin_grid(int G, int C) { return dim3((unsigned)ud_cdiv((long)G * C, 
 
 extern "C" {
 
-int ud_reduce_chunks(int G, int R, int C) {
-    if (C <= 0 || C % 4) return UD_EINVAL;
-    int C4 = C / 4;
-    int rpi = (C4 <= NT) ? NT / C4 : 1;
-    int slabs = (C4 + NT - 1) / NT;
-    long want = 1024 / ((long)G * slabs);        // aim at ~1024 blocks in flight
-    if (want < 1) want = 1;
-    long maxp = (R + (long)rpi * 4 - 1) / ((long)rpi * 4);   // at least 4 iterations per block
-    if (maxp < 1) maxp = 1;
-    long P = want < maxp ? want : maxp;
-    if (P > 256) P = 256;
-    return (int)P;
+// scratch doubles a reduction over [G][R][C] needs (two partial arrays of G*P*C); contents need no initialisation
+int ud_reduce_ws_doubles(int G, int R, int C) {
+    if (G < 1 || R < 1 || C < 4 || C % 4) return UD_EINVAL;
+    RedGeom q = make_geom(G, R, C);
+    const long n = 2L * G * q.P * C;
+    return n > 0x7fffffffL ? UD_EINVAL : (int)n;
 }
 
-int ud_norm_stats(const float* x, int G, int R, int C, int P, float eps, double* part1, double* part2, float* mean,
-                  float* invstd, float* var_out, float momentum, float* running_mean, float* running_var,
-                  ud_stream_t stream) {
-    if (C % 4 || G < 1 || R < 1 || P < 1) return UD_EINVAL;
+int ud_norm_stats(const float* x, int G, int R, int C, float eps, double* ws, float* mean, float* invstd,
+                  float* var_out, float momentum, float* running_mean, float* running_var, ud_stream_t stream) {
+    if (C % 4 || G < 1 || R < 1 || !ws) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    RedGeom q = make_geom(G, R, C, P);
+    RedGeom q = make_geom(G, R, C);
+    double* part1 = ws;
+    double* part2 = ws + (long)G * q.P * C;
     hipLaunchKernelGGL(colreduce_partial<RED_STATS>, red_grid(q), dim3(NT), 0, s, q, x, nullptr, nullptr, nullptr,
                        nullptr, nullptr, 0, part1, part2);
     UD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stats_finalize, fin_grid(G, C), dim3(NT), 0, s, G, R, C, P, part1, part2, eps, mean, invstd,
+    hipLaunchKernelGGL(stats_finalize, fin_grid(G, C), dim3(NT), 0, s, G, R, C, q.P, part1, part2, eps, mean, invstd,
                        var_out, momentum, running_mean, running_var);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_syncbn_combine(const float* gathered, int world, int C, long rows_per_rank, float eps, float momentum,
+                      float* running_mean, float* running_var, float* mean, float* invstd, ud_stream_t stream) {
+    if (world < 1 || C < 1 || rows_per_rank < 1) return UD_EINVAL;
+    hipLaunchKernelGGL(syncbn_combine, dim3(ud_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world, C,
+                       (double)rows_per_rank * world, eps, momentum, running_mean, running_var, mean, invstd);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -334,18 +390,20 @@ int ud_norm_apply_fwd(const float* x, int G, int R, int C, const float* mean, co
     return 0;
 }
 
-int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, int P, const float* mean, const float* invstd,
-                const float* gamma, const float* beta, int act, double* part1, double* part2, float* s1, float* s2,
-                float* dgamma, float* dbeta, float* dx, ud_stream_t stream) {
-    if (C % 4 || G < 1 || R < 1 || P < 1) return UD_EINVAL;
+int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, const float* mean, const float* invstd,
+                const float* gamma, const float* beta, int act, double* ws, float* s1, float* s2, float* dgamma,
+                float* dbeta, float* dx, ud_stream_t stream) {
+    if (C % 4 || G < 1 || R < 1 || !ws || !s1 || !s2) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    RedGeom q = make_geom(G, R, C, P);
+    RedGeom q = make_geom(G, R, C);
+    double* part1 = ws;
+    double* part2 = ws + (long)G * q.P * C;
     hipLaunchKernelGGL(colreduce_partial<RED_NORMBWD>, red_grid(q), dim3(NT), 0, s, q, x, dy, mean, invstd, gamma, beta,
                        act, part1, part2);
     UD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(normbwd_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, P, part1, part2, s1, s2);
+    hipLaunchKernelGGL(normbwd_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, q.P, part1, part2, s1, s2, dgamma, dbeta);
     UD_LAUNCH_CHECK();
-    if (dgamma || dbeta) {
+    if (G > 1 && (dgamma || dbeta)) {
         hipLaunchKernelGGL(group_sum, dim3(ud_cdiv(C, 256)), dim3(256), 0, s, G, C, s1, s2, dgamma, dbeta);
         UD_LAUNCH_CHECK();
     }
@@ -372,29 +430,28 @@ int ud_norm_bwd_apply(const float* x, const float* dy, int G, int R, int C, cons
 }
 
 // out[g][c] = scale * sum_r x[g][r][c]
-int ud_group_colsum(const float* x, int G, int R, int C, int P, float scale, double* part1, float* out,
-                    ud_stream_t stream) {
-    if (C % 4 || G < 1 || R < 1 || P < 1) return UD_EINVAL;
+int ud_group_colsum(const float* x, int G, int R, int C, float scale, double* ws, float* out, ud_stream_t stream) {
+    if (C % 4 || G < 1 || R < 1 || !ws) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    RedGeom q = make_geom(G, R, C, P);
+    RedGeom q = make_geom(G, R, C);
     hipLaunchKernelGGL(colreduce_partial<RED_SUM>, red_grid(q), dim3(NT), 0, s, q, x, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, 0, part1, nullptr);
+                       nullptr, nullptr, 0, ws, nullptr);
     UD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, P, part1, scale, out);
+    hipLaunchKernelGGL(partial_sum_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, q.P, ws, scale, out);
     UD_LAUNCH_CHECK();
     return 0;
 }
 
 // out[g][c] = scale * sum_r a[g][r][c] * b[g][r][c]
-int ud_group_coldot(const float* a, const float* b, int G, int R, int C, int P, float scale, double* part1, float* out,
+int ud_group_coldot(const float* a, const float* b, int G, int R, int C, float scale, double* ws, float* out,
                     ud_stream_t stream) {
-    if (C % 4 || G < 1 || R < 1 || P < 1) return UD_EINVAL;
+    if (C % 4 || G < 1 || R < 1 || !ws) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    RedGeom q = make_geom(G, R, C, P);
+    RedGeom q = make_geom(G, R, C);
     hipLaunchKernelGGL(colreduce_partial<RED_DOT>, red_grid(q), dim3(NT), 0, s, q, a, b, nullptr, nullptr, nullptr,
-                       nullptr, 0, part1, nullptr);
+                       nullptr, 0, ws, nullptr);
     UD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partial_sum_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, P, part1, scale, out);
+    hipLaunchKernelGGL(partial_sum_finalize, fin_grid(G, C), dim3(NT), 0, s, G, C, q.P, ws, scale, out);
     UD_LAUNCH_CHECK();
     return 0;
 }

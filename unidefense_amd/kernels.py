@@ -183,48 +183,63 @@ def conv_gather_wgrad(a, x, g):
 # ---------------------------------------------------------------------------------------------
 # normalisation / column reductions
 # ---------------------------------------------------------------------------------------------
-def _chunks(G, R, Cc):
-    return _call("ud_reduce_chunks", G, R, Cc)
+_REDUCE_WS = {}          # device -> fp64 scratch shared by every column reduction
+_REDUCE_WS_MIN = 1 << 20
+
+
+def _reduce_ws(ref, G, R, Cc):
+    """Scratch for the per-workgroup partial sums (include/unidefense_hip.h): a reduction's finalize launch has
+    consumed it before the next reduction on the stream starts, so one buffer per device serves all calls."""
+    need = _call("ud_reduce_ws_doubles", G, R, Cc)
+    ws = _REDUCE_WS.get(ref.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, _REDUCE_WS_MIN), dtype=torch.float64, device=ref.device)
+        _REDUCE_WS[ref.device] = ws
+    return ws
 
 
 def norm_stats(x2, G, R, eps, momentum=0.0, running_mean=None, running_var=None):
     """x2: [G*R, C].  Returns (mean[G,C], invstd[G,C]); updates running stats in place when given."""
     _chk(x2)
     Cc = x2.shape[-1]
-    P = _chunks(G, R, Cc)
-    part = torch.empty((2, G * P, Cc), dtype=torch.float64, device=x2.device)
     mean = empty((G, Cc), x2)
     invstd = empty((G, Cc), x2)
-    _call("ud_norm_stats", _p(x2), G, R, Cc, P, eps, _p(part[0]), _p(part[1]), _p(mean), _p(invstd), None,
+    _call("ud_norm_stats", _p(x2), G, R, Cc, eps, _p(_reduce_ws(x2, G, R, Cc)), _p(mean), _p(invstd), None,
           momentum, _p(running_mean), _p(running_var), _stream())
     return mean, invstd
 
 
 def norm_stats_local(x2, G, R, eps):
-    """(mean, biased var) per (g, c) — the per-rank half of a SyncBatchNorm forward."""
+    """mv[2, G, C] = (mean, biased var) per (g, c) — the per-rank half of a SyncBatchNorm forward, laid out as the
+    all_gather payload."""
     _chk(x2)
     Cc = x2.shape[-1]
-    P = _chunks(G, R, Cc)
-    part = torch.empty((2, G * P, Cc), dtype=torch.float64, device=x2.device)
-    mean = empty((G, Cc), x2)
+    mv = empty((2, G, Cc), x2)
     invstd = empty((G, Cc), x2)
-    var = empty((G, Cc), x2)
-    _call("ud_norm_stats", _p(x2), G, R, Cc, P, eps, _p(part[0]), _p(part[1]), _p(mean), _p(invstd), _p(var),
+    _call("ud_norm_stats", _p(x2), G, R, Cc, eps, _p(_reduce_ws(x2, G, R, Cc)), _p(mv[0]), _p(invstd), _p(mv[1]),
           0.0, None, None, _stream())
-    return mean, var
+    return mv
+
+
+def syncbn_combine(gathered, world, Cc, rows_per_rank, eps, momentum, running_mean, running_var):
+    """gathered [world, 2, C] -> (mean[1,C], invstd[1,C]); running statistics updated in place when given."""
+    _chk(gathered)
+    mean = empty((1, Cc), gathered)
+    invstd = empty((1, Cc), gathered)
+    _call("ud_syncbn_combine", _p(gathered), world, Cc, rows_per_rank, eps, momentum, _p(running_mean),
+          _p(running_var), _p(mean), _p(invstd), _stream())
+    return mean, invstd
 
 
 def norm_bwd_sums(x2, dy, G, R, mean, invstd, gamma, beta, act):
     """Reductions of the norm backward only: returns (s[2,G,C], dgamma[C], dbeta[C])."""
     _chk(x2, dy)
     Cc = x2.shape[-1]
-    P = _chunks(G, R, Cc)
-    part = torch.empty((2, G * P, Cc), dtype=torch.float64, device=x2.device)
     s = empty((2, G, Cc), x2)
     dg = empty((Cc,), x2)
     db = empty((Cc,), x2)
-    _call("ud_norm_bwd", _p(x2), _p(dy), G, R, Cc, P, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
-          _p(part[0]), _p(part[1]), _p(s[0]), _p(s[1]), _p(dg), _p(db), None, _stream())
+    _call("ud_norm_bwd", _p(x2), _p(dy), G, R, Cc, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
+          _p(_reduce_ws(x2, G, R, Cc)), _p(s[0]), _p(s[1]), _p(dg), _p(db), None, _stream())
     return s, dg, db
 
 
@@ -248,34 +263,28 @@ def norm_bwd(x2, dy, G, R, mean, invstd, gamma, beta, act):
     """Returns (dx, dgamma[C], dbeta[C])."""
     _chk(x2, dy)
     Cc = x2.shape[-1]
-    P = _chunks(G, R, Cc)
-    part = torch.empty((2, G * P, Cc), dtype=torch.float64, device=x2.device)
     s = empty((2, G, Cc), x2)
     dg = empty((Cc,), x2)
     db = empty((Cc,), x2)
     dx = torch.empty_like(x2)
-    _call("ud_norm_bwd", _p(x2), _p(dy), G, R, Cc, P, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
-          _p(part[0]), _p(part[1]), _p(s[0]), _p(s[1]), _p(dg), _p(db), _p(dx), _stream())
+    _call("ud_norm_bwd", _p(x2), _p(dy), G, R, Cc, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act),
+          _p(_reduce_ws(x2, G, R, Cc)), _p(s[0]), _p(s[1]), _p(dg), _p(db), _p(dx), _stream())
     return dx, dg, db
 
 
 def group_colsum(x2, G, R, scale):
     _chk(x2)
     Cc = x2.shape[-1]
-    P = _chunks(G, R, Cc)
-    part = torch.empty((G * P, Cc), dtype=torch.float64, device=x2.device)
     out = empty((G, Cc), x2)
-    _call("ud_group_colsum", _p(x2), G, R, Cc, P, scale, _p(part), _p(out), _stream())
+    _call("ud_group_colsum", _p(x2), G, R, Cc, scale, _p(_reduce_ws(x2, G, R, Cc)), _p(out), _stream())
     return out
 
 
 def group_coldot(a2, b2, G, R, scale=1.0):
     _chk(a2, b2)
     Cc = a2.shape[-1]
-    P = _chunks(G, R, Cc)
-    part = torch.empty((G * P, Cc), dtype=torch.float64, device=a2.device)
     out = empty((G, Cc), a2)
-    _call("ud_group_coldot", _p(a2), _p(b2), G, R, Cc, P, scale, _p(part), _p(out), _stream())
+    _call("ud_group_coldot", _p(a2), _p(b2), G, R, Cc, scale, _p(_reduce_ws(a2, G, R, Cc)), _p(out), _stream())
     return out
 
 

@@ -34,13 +34,14 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGNATURES = {
     "ud_gemm": [C.POINTER(GemmDesc), _P],
     "ud_gemm_set_path": [C.c_int],
-    "ud_reduce_chunks": [_I, _I, _I],
-    "ud_norm_stats": [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "ud_reduce_ws_doubles": [_I, _I, _I],
+    "ud_norm_stats": [_P, _I, _I, _I, _F, _P, _P, _P, _P, _F, _P, _P, _P],
+    "ud_syncbn_combine": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
     "ud_norm_apply_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
-    "ud_norm_bwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ud_norm_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "ud_norm_bwd_apply": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P],
-    "ud_group_colsum": [_P, _I, _I, _I, _I, _F, _P, _P, _P],
-    "ud_group_coldot": [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "ud_group_colsum": [_P, _I, _I, _I, _F, _P, _P, _P],
+    "ud_group_coldot": [_P, _P, _I, _I, _I, _F, _P, _P, _P],
     "ud_dwconv_fwd": [_P, _P, _P] + [_I] * 10 + [_P],
     "ud_dwconv_bwd_data": [_P, _P, _P] + [_I] * 10 + [_P],
     "ud_dwconv_bwd_weight_parts": [_I, _I],
@@ -82,7 +83,7 @@ _SIGNATURES = {
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_reduce_chunks", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks"}
 
 EXPORTED = tuple(_SIGNATURES)

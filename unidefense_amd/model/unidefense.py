@@ -226,6 +226,9 @@ class UniDefenseModelEb4(nn.Module):
         else:
             with torch.no_grad():
                 outs = self._run(x, None, rng)
+        pending = self.__dict__.pop("_nbt_pending", None)
+        if pending:
+            torch._foreach_add_(pending, 1)
         loss_dict = {
             "factorization": outs["factorization"],
             "triplet": [outs[k] for k in self._triplet_keys],
@@ -240,7 +243,8 @@ class UniDefenseModelEb4(nn.Module):
     def _bn(self, tape, x, bn, act):
         training = self.training
         if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            # bumped once per forward with ONE multi-tensor launch (forward()), not one launch per BatchNorm
+            self.__dict__.setdefault("_nbt_pending", []).append(bn.num_batches_tracked)
         # SyncBatchNorm semantics when a data-parallel wrapper set a process group, or when the container was
         # converted by torch.nn.SyncBatchNorm.convert_sync_batchnorm (engine/forgery_engine.py:142)
         group = getattr(self, "_sync_bn_group", None)
@@ -338,13 +342,19 @@ class UniDefenseModelEb4(nn.Module):
         rate0 = self.arch["drop_connect_rate"]
         nblk = len(self.arch["blocks"])
         given = out["_given"].get("drop_connect", {})
-        for idx, b in enumerate(self.arch["blocks"]):
-            rate = rate0 * float(idx) / nblk if rate0 else 0.0
-            if b.skip and rate:
-                k_ = given.get(idx)
-                out["drop_connect"][idx] = (
-                    k_.to(device=device, dtype=torch.float32).contiguous() if k_ is not None
-                    else (torch.rand((n,), device=device) < 1.0 - rate).to(torch.float32))
+        todo = [(idx, rate0 * float(idx) / nblk) for idx, b in enumerate(self.arch["blocks"])
+                if b.skip and rate0 and idx > 0]
+        fresh = None
+        if any(given.get(idx) is None for idx, _ in todo):
+            # all Bernoulli draws of the step in three launches (rand, compare, cast) instead of three per block
+            keep_p = getattr(self, "_dc_keep_p", None)
+            if keep_p is None or keep_p.device != device:
+                keep_p = self._dc_keep_p = torch.tensor([1.0 - r for _, r in todo], device=device).view(-1, 1)
+            fresh = (torch.rand((len(todo), n), device=device) < keep_p).to(torch.float32)
+        for j, (idx, rate) in enumerate(todo):
+            k_ = given.get(idx)
+            out["drop_connect"][idx] = k_.to(device=device, dtype=torch.float32).contiguous() if k_ is not None \
+                else fresh[j]
         return out
 
     def _keep_mask(self, rng, name, like, keep_p):

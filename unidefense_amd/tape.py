@@ -284,12 +284,12 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
         world = dist.get_world_size(sync_group)
         synced = world > 1 or FORCE_COLLECTIVES
     if synced:
-        mean_l, var_l = K.norm_stats_local(x2, 1, R, eps)
-        mean, var, invstd = sync_batch_stats(mean_l, var_l, eps, sync_group)
-        if running_mean is not None:
-            n = float(R * world)
-            running_mean.mul_(1.0 - momentum).add_(mean.view(-1), alpha=momentum)
-            running_var.mul_(1.0 - momentum).add_(var.view(-1), alpha=momentum * n / max(n - 1.0, 1.0))
+        # 3 launches + 1 collective: local (mean, var) written straight into the all_gather payload, then one
+        # kernel folds the world's statistics (same formula as sync_batch_stats above) and updates the running ones
+        mv = K.norm_stats_local(x2, 1, R, eps)                               # [2, 1, C]
+        gathered = torch.empty((world, 2, Cc), dtype=mv.dtype, device=mv.device)
+        dist.all_gather_into_tensor(gathered.view(-1), mv.view(-1), group=sync_group)
+        mean, invstd = K.syncbn_combine(gathered, world, Cc, R, eps, momentum, running_mean, running_var)
     elif training:
         mean, invstd = K.norm_stats(x2, 1, R, eps, momentum, running_mean, running_var)
     else:
