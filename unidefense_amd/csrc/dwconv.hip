@@ -88,6 +88,105 @@ __global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const float* __restr
     }
 }
 
+// ---- strip forms: one thread = 4 channels x TW consecutive output columns ---------------------------------------
+// A row of the window is loaded once ((TW-1)*S + K float4) and serves all TW outputs, the K taps of the row are
+// loaded once per thread: (TW-1)*S+K + K loads per TW*K multiply-adds instead of 2 per multiply-add.  The plain
+// kernels above issue K*K (9 / 25) 16-byte loads per output and sit at ~30 % of their HBM roofline (L1-bound).
+constexpr int TW = 4;
+
+template <int K, int S>
+__global__ __launch_bounds__(NT) void dw_fwd_strip(DwGeom q, const float* __restrict__ x, const float* __restrict__ wt,
+                                                   float* __restrict__ y) {
+    constexpr int NCOL = (TW - 1) * S + K;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const int WoB = (q.Wo + TW - 1) / TW;
+    const long total = (long)q.N * q.Ho * WoB * q.C4;
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
+        int c4 = (int)(e % q.C4);
+        long r = e / q.C4;
+        int wb = (int)(r % WoB);
+        long t2 = r / WoB;
+        int ho = (int)(t2 % q.Ho);
+        int n = (int)(t2 / q.Ho);
+        const int wo0 = wb * TW;
+        const int ih0 = ho * S - q.pad_t, iw0 = wo0 * S - q.pad_l;
+        f32x4 acc[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = ih0 + kh;
+            if (ih < 0 || ih >= q.H) continue;
+            const f32x4* row = x4 + (((long)n * q.H + ih) * q.W) * q.C4 + c4;
+            f32x4 in[NCOL], w[K];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int iw = iw0 + j;
+                in[j] = (iw >= 0 && iw < q.W) ? row[(long)iw * q.C4] : f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) w[kw] = w4[(kh * K + kw) * q.C4 + c4];
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) acc[t] += in[t * S + kw] * w[kw];
+        }
+        f32x4* out = y4 + (((long)n * q.Ho + ho) * q.Wo + wo0) * q.C4 + c4;
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+            if (wo0 + t < q.Wo) out[(long)t * q.C4] = acc[t];
+    }
+}
+
+// data gradient, stride 1: dx[h][w] = sum dy[h + pad_t - kh][w + pad_l - kw] * w[kh][kw]
+template <int K>
+__global__ __launch_bounds__(NT) void dw_bwd_data_strip(DwGeom q, const float* __restrict__ dy,
+                                                        const float* __restrict__ wt, float* __restrict__ dx) {
+    constexpr int NCOL = TW + K - 1;
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
+    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    const int WB = (q.W + TW - 1) / TW;
+    const long total = (long)q.N * q.H * WB * q.C4;
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
+        int c4 = (int)(e % q.C4);
+        long r = e / q.C4;
+        int wb = (int)(r % WB);
+        long t2 = r / WB;
+        int h = (int)(t2 % q.H);
+        int n = (int)(t2 / q.H);
+        const int w0 = wb * TW;
+        const int col0 = w0 + q.pad_l - (K - 1);          // dy column of window slot 0
+        f32x4 acc[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int ho = h + q.pad_t - kh;
+            if (ho < 0 || ho >= q.Ho) continue;
+            const f32x4* row = dy4 + (((long)n * q.Ho + ho) * q.Wo) * q.C4 + c4;
+            f32x4 g[NCOL], w[K];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int wo = col0 + j;
+                g[j] = (wo >= 0 && wo < q.Wo) ? row[(long)wo * q.C4] : f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) w[kw] = w4[(kh * K + kw) * q.C4 + c4];
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) acc[t] += g[t - kw + K - 1] * w[kw];
+        }
+        f32x4* out = dx4 + (((long)n * q.H + h) * q.W + w0) * q.C4 + c4;
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+            if (w0 + t < q.W) out[(long)t * q.C4] = acc[t];
+    }
+}
+
 // partial weight gradient: part[(p * rpi + ri)][tap][C]
 template <int K>
 __global__ __launch_bounds__(NT) void dw_bwd_weight_partial(DwGeom q, int rpi, int pix_per_chunk,
@@ -173,6 +272,7 @@ __global__ void dw_bwd_weight_rows(DwGeom q, int C, int rows_per_group, const fl
                 w[kh][kw] = (vh[kh] && iw >= 0 && iw < q.W) ? xr[kh][(long)iw * C] : 0.f;
             }
         const float* dyr = dy + ((long)row * q.Wo) * C + c;
+#pragma unroll 4
         for (int wo = 0; wo < q.Wo; ++wo) {
             const float g = dyr[(long)wo * C];
 #pragma unroll
@@ -235,9 +335,20 @@ int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W
     if (C % 4) return UD_EINVAL;
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!geom_ok(q, K)) return UD_EINVAL;
-    long total = (long)N * Ho * Wo * q.C4;
-    if (K == 3) hipLaunchKernelGGL(dw_fwd<3>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, q, x, wt, y);
-    else hipLaunchKernelGGL(dw_fwd<5>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, q, x, wt, y);
+    static const bool plain = getenv("UD_DW_PLAIN") != nullptr;       // tuning aid: the one-output-per-thread kernels
+    hipStream_t s = (hipStream_t)stream;
+    if (plain) {
+        long total = (long)N * Ho * Wo * q.C4;
+        if (K == 3) hipLaunchKernelGGL(dw_fwd<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, x, wt, y);
+        else hipLaunchKernelGGL(dw_fwd<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, x, wt, y);
+    } else {
+        long total = (long)N * Ho * ((Wo + TW - 1) / TW) * q.C4;
+        dim3 g(ew_blocks(total));
+        if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_fwd_strip<3, 1>), g, dim3(NT), 0, s, q, x, wt, y);
+        else if (K == 3) hipLaunchKernelGGL((dw_fwd_strip<3, 2>), g, dim3(NT), 0, s, q, x, wt, y);
+        else if (stride == 1) hipLaunchKernelGGL((dw_fwd_strip<5, 1>), g, dim3(NT), 0, s, q, x, wt, y);
+        else hipLaunchKernelGGL((dw_fwd_strip<5, 2>), g, dim3(NT), 0, s, q, x, wt, y);
+    }
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -247,9 +358,17 @@ int ud_dwconv_bwd_data(const float* dy, const float* wt, float* dx, int N, int H
     if (C % 4) return UD_EINVAL;
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!geom_ok(q, K)) return UD_EINVAL;
-    long total = (long)N * H * W * q.C4;
-    if (K == 3) hipLaunchKernelGGL(dw_bwd_data<3>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, q, dy, wt, dx);
-    else hipLaunchKernelGGL(dw_bwd_data<5>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, q, dy, wt, dx);
+    static const bool plain = getenv("UD_DW_PLAIN") != nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1 && !plain) {
+        long total = (long)N * H * ((W + TW - 1) / TW) * q.C4;
+        if (K == 3) hipLaunchKernelGGL(dw_bwd_data_strip<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, dx);
+        else hipLaunchKernelGGL(dw_bwd_data_strip<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, dx);
+    } else {       // stride 2 (4 of the 32 blocks): one output per thread
+        long total = (long)N * H * W * q.C4;
+        if (K == 3) hipLaunchKernelGGL(dw_bwd_data<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, dx);
+        else hipLaunchKernelGGL(dw_bwd_data<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, dx);
+    }
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -7,6 +7,7 @@ image-domain 3-channel tensors are planes [N, 3, H, W].
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -316,12 +317,15 @@ def dwconv_bwd_data(dy, wt, K, stride, pad_t, pad_l, H, W):
     return dx
 
 
+_DW_WGRAD_THREADS = int(os.environ.get("UD_DW_WGRAD_THREADS", "131072"))      # tuning aid
+
+
 def dwconv_bwd_weight(x, dy, K, stride, pad_t, pad_l):
     _chk(x, dy)
     N, H, W, Cc = x.shape
     _, Ho, Wo, _ = dy.shape
     # one thread per (channel, group of output rows): aim at >= ~128k threads, at most one group per row
-    chunks = max(1, min(N * Ho, -(-131072 // Cc)))
+    chunks = max(1, min(N * Ho, -(-_DW_WGRAD_THREADS // Cc)))
     parts = _call("ud_dwconv_bwd_weight_parts", Cc, chunks)
     part = empty((parts, K * K, Cc), x)
     dwt = empty((K * K, Cc), x)
