@@ -217,6 +217,13 @@ int ud_add_act_fwd(const float* a, const float* b, int act, float* y, long total
 int ud_relu_bwd(const float* dy, const float* y, float* g, long total, ud_stream_t stream);
 int ud_copy_cols(float* narrow, float* wide, long M, int Cn, int Cw, int off, int dir, ud_stream_t stream);
 
+/* ---- asymmetrical weighted triplet loss (loss/triplet_loss.py:16-82) on feat[N][D]; anchors = the first n_real
+ * rows (the batch is ordered [real...; fake...], triplet_loss.py:46-53).  Writes the scalar loss and
+ * dfeat[N][D] = d loss / d feat in two launches (as torch ops: ~90 tiny kernels per feature).
+ * ws: n_real * (N + 1) floats of scratch. */
+int ud_aw_triplet(const float* feat, int N, int D, int n_real, float* loss, float* dfeat, float* ws,
+                  ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

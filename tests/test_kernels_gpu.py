@@ -136,6 +136,27 @@ def test_syncbn_combine_matches_gloo_tested_formula():
     check("syncbn running_var", rv, 0.9 + 0.1 * ref_var * n / (n - 1), 1e-5)
 
 
+@pytest.mark.parametrize("N,D,R", [(32, 160, 16), (8, 448, 4), (64, 1792, 32), (6, 40, 3)])
+def test_fused_aw_triplet_value_and_gradient(N, D, R):
+    """ud_aw_triplet (loss + d loss/d feat in two launches) against the oracle's restatement of
+    loss/triplet_loss.py in float64, through the loss module the engine uses (n_real hint set)."""
+    dev = _dev()
+    from oracle import losses as OL
+    from unidefense_amd.loss.triplet_loss import AsymmetricalWeightedTripletLoss
+    feat = rnd(N, D, seed=11) * 0.3
+    labels = torch.tensor([0] * R + [1] * (N - R))
+    fr = feat.double().requires_grad_()
+    ref = OL.aw_triplet(fr, labels)
+    ref.backward()
+    crit = AsymmetricalWeightedTripletLoss()
+    crit.n_real = R
+    f = feat.to(dev).requires_grad_()
+    loss = crit(f, labels.to(dev))
+    (3.0 * loss).backward()
+    check("aw_triplet loss", loss.reshape(1), ref.detach().reshape(1), 1e-5)
+    check("aw_triplet dfeat", f.grad / 3.0, fr.grad, 1e-4)
+
+
 def test_gemm_tn_splitk_and_accumulate():
     dev = _dev()
     from unidefense_amd import kernels as Kk

@@ -697,3 +697,17 @@ def slice_channels(wide, off, Cn):
     out = empty((*lead, Cn), wide)
     _call("ud_copy_cols", _p(out), _p(wide), M, Cn, wide.shape[-1], off, 1, _stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# losses on [N, d] feature vectors
+# ---------------------------------------------------------------------------------------------
+def aw_triplet(feat, n_real):
+    """Asymmetrical weighted triplet loss (loss/triplet_loss.py:16-82): returns (loss[], dloss/dfeat[N,D])."""
+    _chk(feat)
+    N, D = feat.shape
+    loss = empty((), feat)
+    dfeat = torch.empty_like(feat)
+    ws = empty((n_real * (N + 1),), feat)
+    _call("ud_aw_triplet", _p(feat), N, D, int(n_real), _p(loss), _p(dfeat), _p(ws), _stream())
+    return loss, dfeat

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "ud_add_act_fwd": [_P, _P, _I, _P, _L, _P],
     "ud_relu_bwd": [_P, _P, _P, _L, _P],
     "ud_copy_cols": [_P, _P, _L, _I, _I, _I, _I, _P],
+    "ud_aw_triplet": [_P, _I, _I, _I, _P, _P, _P, _P],
 }
 
 # helpers that return a count rather than a status code

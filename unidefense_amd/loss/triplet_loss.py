@@ -19,6 +19,23 @@ def pairwise_distance(x: torch.Tensor) -> torch.Tensor:
     return d2.clamp(min=1e-12).sqrt()
 
 
+class _FusedAWTriplet(torch.autograd.Function):
+    """The whole loss and its feature gradient in two HIP launches (csrc/loss.hip, ud_aw_triplet) instead of ~90
+    tiny torch kernels per feature."""
+
+    @staticmethod
+    def forward(ctx, feat, n_real):
+        from .. import kernels as K
+        loss, dfeat = K.aw_triplet(feat.detach().contiguous(), n_real)
+        ctx.save_for_backward(dfeat)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dfeat,) = ctx.saved_tensors
+        return dfeat * g, None
+
+
 class AsymmetricalWeightedTripletLoss(nn.Module):
     """Anchors are the real samples (label 0), which come first in the batch (loss/triplet_loss.py:46-53).
     Per anchor: positives weighted by softmax(+d), negatives by softmax(-d); SoftMargin(wn - wp, +1)."""
@@ -31,6 +48,9 @@ class AsymmetricalWeightedTripletLoss(nn.Module):
         if normalize_feature:
             global_feat = global_feat / (global_feat.norm(2, dim=-1, keepdim=True) + 1e-12)
         n = global_feat.shape[0]
+        if self.n_real is not None and global_feat.is_cuda and global_feat.dtype == torch.float32 \
+                and 0 < self.n_real < n:
+            return _FusedAWTriplet.apply(global_feat, self.n_real)
         n_real = self.n_real if self.n_real is not None else int((labels == 0).sum().item())
         dist = pairwise_distance(global_feat)[:n_real]                        # [R, N]
         same = labels[:n_real].unsqueeze(1) == labels.unsqueeze(0)              # [R, N]
