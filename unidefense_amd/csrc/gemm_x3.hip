@@ -308,7 +308,9 @@ int launch_tile(const ud_gemm_desc& d, hipStream_t s) {
 }
 
 struct XCfg { int bm, bn; double penalty; };
-constexpr XCfg kX[3] = {{128, 128, 1.00}, {128, 64, 1.10}, {64, 128, 1.10}};
+// Half-size tiles split every A (or B) row twice as often: 19-23 % more time per flop (tools/check_gemm_paths.py
+// with UD_GEMM_X3_CFG=0/1/2: 4096^3 179 vs 150 TFLOP/s), so they only win where they fill the chip better.
+constexpr XCfg kX[3] = {{128, 128, 1.00}, {128, 64, 1.20}, {64, 128, 1.20}};
 
 template <int AMODE, int BMODE>
 int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
@@ -320,7 +322,9 @@ int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
     double best_cost = 1e300;
     for (int i = 0; i < 3; ++i) {
         long tiles = (long)ud_cdiv(d.M, kX[i].bm) * ud_cdiv(d.N, kX[i].bn) * d.split_k * d.batch;
-        long rounds = (tiles + 511) / 512;                 // two workgroups per CU
+        // a CU's matrix pipe is shared by its resident workgroups, so a launch lasts about ceil(tiles / 256 CUs)
+        // single-workgroup tile times whether the workgroups of a CU run side by side or one after the other
+        long rounds = (tiles + 255) / 256;
         double cost = (double)rounds * kX[i].bm * kX[i].bn * kX[i].penalty;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }

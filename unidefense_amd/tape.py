@@ -17,6 +17,20 @@ import torch
 from . import kernels as K
 
 
+# Off by default: measured on MI355X (bs 32, whole step replayed as a hipGraph) the forked weight-gradient branch
+# made the step SLOWER (46.3 vs 43.6 ms) — the large GEMMs already fill the chip and the extra graph edges cost
+# more than the overlap with the bandwidth-bound kernels returns.  UD_WGRAD_STREAM=1 enables it (tests pass).
+WGRAD_SIDE_STREAM = os.environ.get("UD_WGRAD_STREAM", "0") == "1"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 class Tape:
     """Records backward closures; gradients are keyed by tensor identity."""
 
@@ -28,6 +42,8 @@ class Tape:
         self.watch = None        # debug: {id(tensor): name} -> gradients captured into self.captured
         self.captured = {}
         self.kinks = None        # parity tests: {site: ReLU output} (site = id(norm weight) or an explicit name)
+        self._side = None        # second stream carrying the weight-gradient kernels of this backward
+        self._side_keep = []
 
     # -- recording -------------------------------------------------------------------------
     def record(self, fn):
@@ -54,10 +70,34 @@ class Tape:
         g = g.reshape(p.shape)
         self.param_grads[p] = g if cur is None else K.axpby(cur, 1.0, g, 1.0)
 
+    # -- side stream for weight gradients --------------------------------------------------
+    def wgrad(self, p, fn, *inputs):
+        """Enqueue `fn()` (the weight-gradient kernels of parameter p) on a second stream, ordered after everything
+        enqueued so far on the current one.  Nothing on the backward's critical path reads a weight gradient, so
+        these launches (a third of the GEMM time) overlap the data-gradient chain — the bandwidth-bound norm /
+        depthwise / SE kernels leave the matrix cores idle.  `inputs` are kept alive until the streams re-join
+        in backward() (their memory must not be recycled by the main stream meanwhile)."""
+        if not WGRAD_SIDE_STREAM:
+            self.add_param_grad(p, fn())
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = _side_stream(main.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            self.add_param_grad(p, fn())
+        self._side_keep.extend(inputs)
+
     # -- replay ----------------------------------------------------------------------------
     def backward(self):
         for fn in reversed(self.nodes):
             fn()
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side = None
+            self._side_keep = []
         self.nodes = []
         self.grads = {}
         self._keep = []
@@ -83,9 +123,9 @@ def conv1x1(tape, x, w, need_dx=True):
             if dy is None:
                 return
             dy2 = dy.view(-1, Co)
+            tape.wgrad(w, lambda: K.gemm_tn(dy2, x2), dy2, x2)
             if need_dx:
                 tape.add_grad(x, K.gemm_nn(dy2, w2).view(x.shape))
-            tape.add_param_grad(w, K.gemm_tn(dy2, x2))
         tape.record(bwd)
     return y
 
