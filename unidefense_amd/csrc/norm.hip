@@ -148,8 +148,19 @@ __device__ __forceinline__ void chunk_sums(int G, int C, int P, const double* __
     double a = 0.0, b = 0.0;
     if (ok) {
         const int g = idx / C, c = idx % C;
-        for (int p = pl; p < P; p += 16) {
-            const long o = ((long)g * P + p) * C + c;
+        const long base = (long)g * P * C + c, step = 16L * C;
+        int p = pl;
+        // four independent chunk partials in flight per lane (the kernel is pure load latency)
+        for (; p + 48 < P; p += 64) {
+            const long o = base + (long)p * C;
+            double a0 = part1[o], a1 = part1[o + step], a2 = part1[o + 2 * step], a3 = part1[o + 3 * step];
+            double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+            if (part2) { b0 = part2[o]; b1 = part2[o + step]; b2 = part2[o + 2 * step]; b3 = part2[o + 3 * step]; }
+            a += (a0 + a1) + (a2 + a3);
+            b += (b0 + b1) + (b2 + b3);
+        }
+        for (; p < P; p += 16) {
+            const long o = base + (long)p * C;
             a += part1[o];
             if (part2) b += part2[o];
         }
@@ -326,7 +337,7 @@ RedGeom make_geom(int G, int R, int C) {
     long maxp = (R + (long)q.rpi * 8 - 1) / ((long)q.rpi * 8);
     if (maxp < 1) maxp = 1;
     long P = want < maxp ? want : maxp;
-    if (P > 1024) P = 1024;
+    if (P > 512) P = 512;         // the finalize folds P partials per channel: keep its chain short
     q.P = (int)P;
     q.rows_per_chunk = (R + q.P - 1) / q.P;
     return q;
