@@ -153,6 +153,9 @@ def conv_geom(N, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_t, pad_l, transp
     return g
 
 
+_CONV_SPLITK = os.environ.get("UD_CONV_SPLITK", "1") == "1"
+
+
 def conv_gather_nt(x, wmat, g):
     """Implicit-GEMM conv: rows (n,oh,ow) x k=(tap,ci) gathered from x[N,Hin,Win,Cin]; wmat[Cout, KH*KW*Cin].
     Returns [N, Hout, Wout, Cout]."""
@@ -161,6 +164,13 @@ def conv_gather_nt(x, wmat, g):
     K = g.KH * g.KW * g.Cin
     Co = wmat.shape[0]
     assert wmat.shape[1] == K and x.numel() == g.N * g.Hin * g.Win * g.Cin
+    # split-K for the under-filled launches (e.g. the 3x3 filter conv at 8x8: M = 2048, K = 2448 -> 80 tiles);
+    # an A/B inside one gpurun call decides (UD_CONV_SPLITK=0 disables)
+    split = _fwd_split(M, Co, K) if _CONV_SPLITK else 1
+    if split > 1:
+        out = torch.zeros((g.N, g.Hout, g.Wout, Co), dtype=torch.float32, device=x.device)
+        _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, 2, split, geom=g)
+        return out
     out = empty((g.N, g.Hout, g.Wout, Co), x)
     _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, geom=g)
     return out
