@@ -115,6 +115,7 @@ int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W
 int ud_dwconv_bwd_data(const float* dy, const float* wt, float* dx, int N, int H, int W, int C, int Ho,
                        int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
 int ud_dwconv_bwd_weight_parts(int C, int chunks);   /* rows of K*K*C floats that `part` must hold */
+/* dwt: the gradient in the PARAMETER's layout [C][K*K] (nn.Conv2d weight [C,1,K,K]), not tap-major */
 int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* part, int chunks, int N,
                          int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l,
                          ud_stream_t stream);

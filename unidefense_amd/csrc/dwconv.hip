@@ -298,9 +298,11 @@ __global__ void dw_bwd_weight_rows(DwGeom q, int C, int rows_per_group, const fl
 }
 
 // 16 outputs x 16 part-lanes per block; fp64 accumulation of the per-chunk partial sums
-__global__ __launch_bounds__(NT) void dw_bwd_weight_finalize(int nparts, int KKC, const float* __restrict__ part,
-                                                             float* __restrict__ dwt) {
+// partials are tap-major [tap][C]; the result is written in the PARAMETER's layout dw[C][K*K] (weight [C,1,k,k])
+__global__ __launch_bounds__(NT) void dw_bwd_weight_finalize(int nparts, int KK, int C, const float* __restrict__ part,
+                                                             float* __restrict__ dw) {
     __shared__ double sm[NT];
+    const int KKC = KK * C;
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + cl;
     double a = 0.0;
@@ -310,7 +312,8 @@ __global__ __launch_bounds__(NT) void dw_bwd_weight_finalize(int nparts, int KKC
     __syncthreads();
     if (i < KKC && pl == 0) {
         for (int k = 1; k < 16; ++k) a += sm[k * 16 + cl];
-        dwt[i] = (float)a;
+        const int tap = i / C, c = i % C;
+        dw[(long)c * KK + tap] = (float)a;
     }
 }
 
@@ -397,7 +400,7 @@ int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* par
     else hipLaunchKernelGGL((dw_bwd_weight_rows<5, 2>), grid, dim3(bt), 0, s, q, C, rpg, x, dy, part);
     UD_LAUNCH_CHECK();
     int KKC = K * K * C;
-    hipLaunchKernelGGL(dw_bwd_weight_finalize, dim3(ud_cdiv(KKC, 16)), dim3(NT), 0, s, chunks, KKC, part, dwt);
+    hipLaunchKernelGGL(dw_bwd_weight_finalize, dim3(ud_cdiv(KKC, 16)), dim3(NT), 0, s, chunks, K * K, C, part, dwt);
     UD_LAUNCH_CHECK();
     return 0;
 }

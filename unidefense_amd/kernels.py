@@ -338,7 +338,7 @@ def dwconv_bwd_weight(x, dy, K, stride, pad_t, pad_l):
     chunks = max(1, min(N * Ho, -(-_DW_WGRAD_THREADS // Cc)))
     parts = _call("ud_dwconv_bwd_weight_parts", Cc, chunks)
     part = empty((parts, K * K, Cc), x)
-    dwt = empty((K * K, Cc), x)
+    dwt = empty((Cc, K * K), x)        # the parameter's own layout (weight [C,1,K,K])
     _call("ud_dwconv_bwd_weight", _p(x), _p(dy), _p(dwt), _p(part), chunks, N, H, W, Cc, Ho, Wo, K, stride, pad_t,
           pad_l, _stream())
     return dwt

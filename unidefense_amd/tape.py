@@ -214,8 +214,7 @@ def dwconv(tape, x, w, stride, pad):
             if dy is None:
                 return
             tape.add_grad(x, K.dwconv_bwd_data(dy, wt, k, stride, pt, pl, H, W))
-            dwt = K.dwconv_bwd_weight(x, dy, k, stride, pt, pl)
-            tape.add_param_grad(w, dwt.t().contiguous())
+            tape.add_param_grad(w, K.dwconv_bwd_weight(x, dy, k, stride, pt, pl))     # already [C, k*k]
         tape.record(bwd)
     return y
 
