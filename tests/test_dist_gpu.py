@@ -26,6 +26,25 @@ def _bench(extra_env, *flags):
     return json.loads(line), r.stderr
 
 
+def test_bench_line_contract():
+    """The ONE JSON line bench.py prints: keys and types the driver reads, the roofline object, exec mode."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    line, err = _bench({}, )
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
+                   ("data", str), ("config", dict), ("roofline", dict)):
+        assert isinstance(line[k], typ), (k, line.get(k))
+    assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["dtype"] == "f32"
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
+    assert "workload" in line["config"] and line["config"]["exec"] == "hipgraph", err[-1500:]
+    assert abs(line["value"] - 8 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]          # bs 8 in _bench
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 3.0
+    assert "traffic" in r
+
+
 @pytest.mark.parametrize("flags", [(), ("--eager",)])
 def test_forced_collectives_match_plain_step(flags):
     if not torch.cuda.is_available():

@@ -101,6 +101,13 @@ def load():
         raise UDLibraryError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C unidefense_amd/csrc`. unidefense_amd has no fallback path.")
+    # The library is linked against /opt/rocm's libamdhip64 while torch ships its own copy.  Loading it BEFORE torch
+    # has initialised its HIP runtime leaves this library's kernels registered with a runtime that owns no device
+    # (every launch then fails with hipErrorNoDevice) — measured with build() followed by smoke() in one process.
+    # So: let torch bring the GPU up first (a no-op on a box without one, where only the symbol table is checked).
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name, None)
