@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunidefense_hip.so")
+LIB_PATH = os.environ.get("UD_LIB_PATH") or os.path.join(_HERE, "libunidefense_hip.so")   # env: A/B of kernel builds
 
 
 class UDLibraryError(RuntimeError):
