@@ -157,6 +157,38 @@ def test_fused_aw_triplet_value_and_gradient(N, D, R):
     check("aw_triplet dfeat", f.grad / 3.0, fr.grad, 1e-4)
 
 
+@pytest.mark.parametrize("world,R,C,act", [(2, 2048, 272, 1), (4, 512, 24, 0), (8, 64, 1792, 1)])
+def test_syncbn_shards_equal_full_batch(world, R, C, act):
+    """The SyncBatchNorm data path of tape.batchnorm_act on ONE GPU: the batch is cut into `world` shards, every
+    shard runs the per-rank kernels (norm_stats_local, norm_apply, norm_bwd_sums, norm_bwd_apply) and the collectives
+    are emulated in place (all_gather = stack, all_reduce = sum).  Must equal plain BatchNorm over the whole batch,
+    forward and backward — the N > 1 arithmetic that only the driver's multi-GPU run would otherwise exercise."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    eps = 1e-3
+    x = (rnd(world * R, C, seed=1) * 1.5 + 0.3).to(dev)
+    dy = rnd(world * R, C, seed=2).to(dev)
+    g, b = (rnd(C, seed=3) * 0.1 + 1).to(dev), (rnd(C, seed=4) * 0.1).to(dev)
+    mean, invstd = Kk.norm_stats(x, 1, world * R, eps)
+    y_ref = Kk.norm_apply(x, 1, world * R, mean, invstd, g, b, act)
+    dx_ref, dg_ref, db_ref = Kk.norm_bwd(x, dy, 1, world * R, mean, invstd, g, b, act)
+    xs, dys = x.view(world, R, C), dy.view(world, R, C)
+    gathered = torch.stack([Kk.norm_stats_local(xs[r].contiguous(), 1, R, eps).view(2, C) for r in range(world)])
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean2, invstd2 = Kk.syncbn_combine(gathered.contiguous(), world, C, R, eps, 0.1, rm, rv)
+    check("syncbn mean", mean2, mean, 1e-5)
+    check("syncbn invstd", invstd2, invstd, 1e-5)
+    y = torch.cat([Kk.norm_apply(xs[r].contiguous(), 1, R, mean2, invstd2, g, b, act) for r in range(world)])
+    check("syncbn y", y, y_ref, 1e-5)
+    sums = [Kk.norm_bwd_sums(xs[r].contiguous(), dys[r].contiguous(), 1, R, mean2, invstd2, g, b, act) for r in range(world)]
+    s = sum(t[0] for t in sums)                                   # all_reduce of [2, 1, C]
+    dx = torch.cat([Kk.norm_bwd_apply(xs[r].contiguous(), dys[r].contiguous(), 1, R, mean2, invstd2, g, b, s,
+                                      1.0 / (world * R), act) for r in range(world)])
+    check("syncbn dx", dx, dx_ref, 2e-5)
+    check("syncbn dgamma", sum(t[1] for t in sums), dg_ref, 2e-5)
+    check("syncbn dbeta", sum(t[2] for t in sums), db_ref, 2e-5)
+
+
 def test_gemm_tn_splitk_and_accumulate():
     dev = _dev()
     from unidefense_amd import kernels as Kk
