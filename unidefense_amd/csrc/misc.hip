@@ -377,23 +377,46 @@ __global__ __launch_bounds__(NT) void bilinear_fwd(long total, int Hi, int Wi, i
     }
 }
 
-// dx must be zero-filled by the caller
+// output positions o in [lo, hi] whose interpolation may touch input position i (a superset; the weight test below
+// is exact because it re-derives (i0, i1, l) with bil_coord)
+__device__ __forceinline__ void bil_sources(int i, int in, int out, int& lo, int& hi) {
+    if (in <= 1 || out <= 1) { lo = 0; hi = out - 1; return; }
+    const float inv = (float)(out - 1) / (float)(in - 1);
+    lo = (int)floorf((float)(i - 1) * inv) - 1;
+    hi = (int)ceilf((float)(i + 1) * inv) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+
+__device__ __forceinline__ float bil_weight(int o, int i, int in, int out) {
+    int i0, i1; float l;
+    bil_coord(o, in, out, i0, i1, l);
+    return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+}
+
+// gather form (deterministic, no atomics, no zero fill): one thread per INPUT pixel sums the <= ~5x5 output pixels
+// that interpolate from it.  The atomic scatter form took 609 us for the 128 -> 256 upsample of the loss tail
+// (25 M atomics); this one moves 6.3 M + 1.6 M floats.
 __global__ __launch_bounds__(NT) void bilinear_bwd(long total, int Hi, int Wi, int Ho, int Wo,
                                                    const float* __restrict__ dy, float* __restrict__ dx) {
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
-        int wo = (int)(e % Wo);
-        long t = e / Wo;
-        int ho = (int)(t % Ho);
-        long p = t / Ho;
-        int h0, h1, w0, w1; float lh, lw;
-        bil_coord(ho, Hi, Ho, h0, h1, lh);
-        bil_coord(wo, Wi, Wo, w0, w1, lw);
-        float* b = dx + p * Hi * Wi;
-        float g = dy[e];
-        atomicAdd(&b[h0 * Wi + w0], g * (1.f - lh) * (1.f - lw));
-        atomicAdd(&b[h0 * Wi + w1], g * (1.f - lh) * lw);
-        atomicAdd(&b[h1 * Wi + w0], g * lh * (1.f - lw));
-        atomicAdd(&b[h1 * Wi + w1], g * lh * lw);
+        int w = (int)(e % Wi);
+        long t = e / Wi;
+        int h = (int)(t % Hi);
+        long p = t / Hi;
+        int ho_lo, ho_hi, wo_lo, wo_hi;
+        bil_sources(h, Hi, Ho, ho_lo, ho_hi);
+        bil_sources(w, Wi, Wo, wo_lo, wo_hi);
+        const float* g = dy + p * Ho * Wo;
+        float acc = 0.f;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            const float wh = bil_weight(ho, h, Hi, Ho);
+            if (wh == 0.f) continue;
+            float row = 0.f;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) row += bil_weight(wo, w, Wi, Wo) * g[(long)ho * Wo + wo];
+            acc += wh * row;
+        }
+        dx[e] = acc;
     }
 }
 
@@ -673,9 +696,7 @@ int ud_bilinear_fwd(const float* x, float* y, int P, int Hi, int Wi, int Ho, int
 
 int ud_bilinear_bwd(const float* dy, float* dx, int P, int Hi, int Wi, int Ho, int Wo, ud_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dx, 0, (size_t)P * Hi * Wi * sizeof(float), s);
-    if (e != hipSuccess) return -(int)e;
-    long total = (long)P * Ho * Wo;
+    long total = (long)P * Hi * Wi;
     hipLaunchKernelGGL(bilinear_bwd, dim3(ew_blocks(total)), dim3(NT), 0, s, total, Hi, Wi, Ho, Wo, dy, dx);
     UD_LAUNCH_CHECK();
     return 0;
