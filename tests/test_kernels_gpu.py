@@ -189,6 +189,23 @@ def test_syncbn_shards_equal_full_batch(world, R, C, act):
     check("syncbn dbeta", sum(t[2] for t in sums), db_ref, 2e-5)
 
 
+@pytest.mark.parametrize("Hi,Ho", [(7, 19), (16, 5), (128, 256), (1, 4), (9, 9), (12, 1)])
+def test_bilinear_backward_gather(Hi, Ho):
+    """ud_bilinear_bwd (gather over the output pixels that interpolate from each input pixel) vs torch autograd of
+    F.interpolate(mode='bilinear', align_corners=True), up- and down-sampling, degenerate sizes."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    Wi, Wo = Hi + 3, Ho + 2
+    x = rnd(2, 3, Hi, Wi, seed=1).double().requires_grad_()
+    y = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    gy = rnd(2, 3, Ho, Wo, seed=2)
+    y.backward(gy.double())
+    dx = Kk.bilinear_bwd(gy.to(dev), Hi, Wi)
+    # 1e-4: the source coordinate o*(in-1)/(out-1) is evaluated in fp32 (torch: same formula, other rounding)
+    check(f"bilinear bwd {Hi}->{Ho}", dx, x.grad, 1e-4)
+    check(f"bilinear fwd {Hi}->{Ho}", Kk.bilinear_fwd(x.detach().float().to(dev), Ho, Wo), y.detach(), 1e-4)
+
+
 def test_gemm_tn_splitk_and_accumulate():
     dev = _dev()
     from unidefense_amd import kernels as Kk
