@@ -89,8 +89,9 @@ def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 2e-5) -> Tensor
     valid = F.unfold(torch.ones(1, 1, h, w, dtype=z.dtype), 3, padding=1, stride=2).view(1, 1, 9, -1) > 0
     u = torch.where(valid, u, torch.full_like(u, -1e30))
     y = u.gather(2, sel.reshape(n, c, 1, -1).long()).squeeze(2)
-    worst = (u.max(2).values - y).max().item()
-    assert worst <= tie_tol, f"pinned max-pool selection is not an arg-max (off by {worst:.3e})"
+    # relative to the activations' scale: after ~50 layers the fp32 path's values carry ~1e-5 relative error
+    worst = (u.max(2).values - y).max().item() / max(z.detach().abs().max().item(), 1e-30)
+    assert worst <= tie_tol, f"pinned max-pool selection is not an arg-max (off by {worst:.3e} of max|z|)"
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     return y.view(n, c, ho, wo)
 

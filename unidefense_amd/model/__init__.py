@@ -1,11 +1,13 @@
 """Mirror of the reference's ``model`` package surface (model/__init__.py:1-17).
-UDR50 (model/unidefense.py:439-631) is not built yet (needs the 2^k*5 FFT sizes of the 320-pixel config)."""
+UDR50 runs at power-of-two inputs (256, 512); the 320-pixel config needs the 2^k*5 FFT sizes (not built yet)."""
 from .unidefense import UniDefenseModelEb4
 from .unidefense_res import UniDefenseModelRes18
+from .unidefense_res50 import UniDefenseModelRes50
 
 MODEL = {
     "UDEB4": UniDefenseModelEb4,
     "UDR18": UniDefenseModelRes18,
+    "UDR50": UniDefenseModelRes50,
 }
 
 
