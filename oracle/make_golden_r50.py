@@ -2,8 +2,9 @@
 (this container only).  BASELINE configs[3] names 320x320, whose 2^k*5 FFT sizes the HIP path does not cover
 yet: recorded at 256x256, bs 4.
 
-Run:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_r50
-Writes tests/golden/udr50_n4.npz: eval-mode outputs, train-mode outputs + pass-1 losses + all parameter gradient
+Run:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_r50 [size]     (256 -> udr50_n4.npz, 320 -> udr50_n4_s320.npz:
+BASELINE configs[3]'s resolution, feature maps 80/40/20/10 = the 5*2^k FFT sizes)
+Writes tests/golden/udr50_n4*.npz: eval-mode outputs, train-mode outputs + pass-1 losses + all parameter gradient
 norms/heads ('full' and 'smooth' loss variants, like make_golden.py) — once with the reference in float32 (keys as
 in udr18_n8.npz) and once in FLOAT64 (keys prefixed 'f64_').  The float64 record is the tight pin: a 53-layer
 ReLU network with batch-4 statistics amplifies fp32 rounding (and the ReLU / max-pool near-tie flips it causes) to
@@ -30,12 +31,13 @@ OUT = os.path.join(ROOT, "tests", "golden")
 N, SIZE, IN_SEED, MASK_SEED, DROP = 4, 256, 46, 146, 0.5
 
 
-def make_rng_r50(n, seed, drop_rate=DROP):
+def make_rng_r50(n, seed, drop_rate=DROP, size=256):
     g = torch.Generator().manual_seed(seed)
 
     def bern(shape, keep):
         return (torch.rand(shape, generator=g) < keep).float()
-    return {"dec_keep": bern((n, 1024, 16, 16), 0.8), "emb_keep": bern((n, 2048, 8, 8), 1.0 - drop_rate),
+    return {"dec_keep": bern((n, 1024, size // 16, size // 16), 0.8),
+            "emb_keep": bern((n, 2048, size // 32, size // 32), 1.0 - drop_rate),
             "feat_keep": bern((n, 2048), 1.0 - drop_rate)}
 
 
@@ -103,24 +105,25 @@ def record(m, ref_loss, x, tgt, rng, store, pre):
     return len(names)
 
 
-def main():
+def main(size=SIZE):
     os.makedirs(OUT, exist_ok=True)
     ref_model, ref_loss = ref_import.import_reference()
     torch.manual_seed(0)
     m = ref_model.load_model("UDR50")(extractor="resnet50", num_classes=2, drop_rate=DROP)
     param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
-    x = param_fill.make_input(N, SIZE, seed=IN_SEED)
+    x = param_fill.make_input(N, size, seed=IN_SEED)
     tgt = param_fill.make_labels(N)
-    rng = make_rng_r50(N, MASK_SEED)
+    rng = make_rng_r50(N, MASK_SEED, size=size)
     store = {}
     n = record(m, ref_loss, x, tgt, rng, store, "")
     m = m.double()
     param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)      # also resets the BN running statistics the fp32 passes moved
     record(m, ref_loss, x.double(), tgt, rng, store, "f64_")
-    store["meta"] = np.array([N, SIZE, IN_SEED, MASK_SEED], dtype=np.int64)
-    np.savez_compressed(os.path.join(OUT, "udr50_n4.npz"), **store)
-    print("wrote udr50_n4.npz", n, "grads")
+    store["meta"] = np.array([N, size, IN_SEED, MASK_SEED], dtype=np.int64)
+    name = "udr50_n4.npz" if size == SIZE else f"udr50_n4_s{size}.npz"
+    np.savez_compressed(os.path.join(OUT, name), **store)
+    print("wrote", name, n, "grads")
 
 
 if __name__ == "__main__":
-    main()
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else SIZE)

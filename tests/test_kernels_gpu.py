@@ -354,7 +354,10 @@ def test_instancenorm_swish(N, H, C):
 
 
 @pytest.mark.parametrize("S,C,norm", [(8, 1632, "ortho"), (8, 3, "ortho"), (8, 272, "ortho"), (16, 672, "ortho"),
-                                      (16, 40, None), (32, 336, "ortho"), (64, 192, "ortho"), (32, 20, None)])
+                                      (16, 40, None), (32, 336, "ortho"), (64, 192, "ortho"), (32, 20, None),
+                                      # 5 * 2^k sizes (ResNet50 variant at 320 x 320): mixed-radix in-register DFT
+                                      (10, 512, "ortho"), (10, 3, None), (20, 256, "ortho"), (40, 128, None),
+                                      (80, 128, "ortho"), (80, 7, "ortho")])
 def test_rfft2_irfft2(S, C, norm):
     dev = _dev()
     from unidefense_amd import tape as T

@@ -1,6 +1,7 @@
-"""UniDefenseModelRes50 (ResNet50 backbone, 256x256, bs 4; BASELINE configs[3] names 320x320: needs 2^k*5 FFT sizes).
-CPU: the oracle restatement (oracle/r50.py) vs the vectors recorded from the REFERENCE (tests/golden/udr50_n4.npz).
-GPU: the HIP model and its new operators vs those vectors and vs the oracle in float64."""
+"""UniDefenseModelRes50 (ResNet50 backbone, bs 4) at 256x256 and at BASELINE configs[3]'s 320x320 (feature maps
+80/40/20/10: the mixed-radix 5*2^k FFT kernels).
+CPU: the oracle restatement (oracle/r50.py) vs the vectors recorded from the REFERENCE in float32 and float64
+(tests/golden/udr50_n4*.npz).  GPU: the HIP model vs those vectors and vs the oracle in float64."""
 import os
 
 import numpy as np
@@ -15,12 +16,16 @@ from tests import oracle_util as ou
 GRAD_RTOL, GRAD_ATOL = 1e-3, 2e-5
 
 
-def make_rng_r50(n, seed, drop_rate=0.5):
+FIXTURES = ["udr50_n4.npz", "udr50_n4_s320.npz"]      # 256x256, and BASELINE configs[3]'s 320x320 (5*2^k FFT sizes)
+
+
+def make_rng_r50(n, seed, drop_rate=0.5, size=256):
     g = torch.Generator().manual_seed(seed)
 
     def bern(shape, keep):
         return (torch.rand(shape, generator=g) < keep).float()
-    return {"dec_keep": bern((n, 1024, 16, 16), 0.8), "emb_keep": bern((n, 2048, 8, 8), 1.0 - drop_rate),
+    return {"dec_keep": bern((n, 1024, size // 16, size // 16), 0.8),
+            "emb_keep": bern((n, 2048, size // 32, size // 32), 1.0 - drop_rate),
             "feat_keep": bern((n, 2048), 1.0 - drop_rate)}
 
 
@@ -60,12 +65,13 @@ def _loss(out, tgt, lam, losses_mod=None):
 
 
 # ------------------------------------------------------------------------------------------------ CPU
-def test_oracle_r50_matches_reference_golden(golden_dir):
-    g = np.load(os.path.join(golden_dir, "udr50_n4.npz"))
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_oracle_r50_matches_reference_golden(golden_dir, fixture):
+    g = np.load(os.path.join(golden_dir, fixture))
     n, size, seed, mseed = [int(v) for v in g["meta"]]
     x = param_fill.make_input(n, size, seed)
     tgt = param_fill.make_labels(n)
-    rng = make_rng_r50(n, mseed)
+    rng = make_rng_r50(n, mseed, size=size)
     # float32 oracle vs float32 reference: forward outputs (the gradients of two fp32 evaluations of this 53-layer
     # ReLU network with batch-4 statistics already differ by ~2e-3 — rounding plus the near-tie flips it causes)
     sd = r50_state()
@@ -109,15 +115,16 @@ def to_nchw(t):
 
 
 @pytest.mark.gpu
-def test_r50_vs_reference_golden_and_oracle(golden_dir):
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
     dev = _dev()
     from unidefense_amd.loss import LOSSES
     from unidefense_amd.model import load_model
-    g = np.load(os.path.join(golden_dir, "udr50_n4.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     n, size, seed, mseed = [int(v) for v in g["meta"]]
     x = param_fill.make_input(n, size, seed)
     tgt = param_fill.make_labels(n)
-    rng = make_rng_r50(n, mseed)
+    rng = make_rng_r50(n, mseed, size=size)
     m = load_model("UDR50")(num_classes=2, drop_rate=0.5)
     param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
     m = m.to(dev)
@@ -174,7 +181,9 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir):
         d32 = (sd32[k].grad.double() - ref).abs().max().item()
         # on the pinned piece the problem is smooth: 1e-4 of the tensor's scale (observed: <= 2e-5), never looser
         # than 5x what the CPU fp32 run or a one-ulp input perturbation do to the same gradient
-        rows.append((d / max(1e-4 * s + 2e-6, 5.0 * d32, 5.0 * sens.get(k, 0.0)), k, d, s, d32, sens.get(k, 0.0)))
+        # (the scalar mixing coefficients are global sums with heavy cancellation: 1e-3 of their magnitude)
+        floor = (1e-3 if k.endswith(("sf_coef", "fuse_coef")) else 1e-4) * s + 2e-6
+        rows.append((d / max(floor, 5.0 * d32, 5.0 * sens.get(k, 0.0)), k, d, s, d32, sens.get(k, 0.0)))
     rows.sort(reverse=True)
     for r in rows[:10]:
         print("  %.3f  %-50s maxerr %.3e  maxref %.3e  cpu-fp32-err %.3e  ulp-sensitivity %.3e" % r)

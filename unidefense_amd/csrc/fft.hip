@@ -1,4 +1,4 @@
-// Batched small real 2-D FFT (S x S, S = 8, 16, 32, 64) on pixel-major [N][S][S][C] fp32, and its inverse.
+// Batched small real 2-D FFT (S x S, S = 8, 16, 32, 64 and 10, 20, 40, 80) on pixel-major [N][S][S][C] fp32, and its inverse.
 //
 // Serves torch.fft.rfft2 / irfft2 of SFConv2dStaticSamePadding.forward (model/efficientnet/exp.py:55,60),
 // of UniDefenseModelEb4.attention (model/unidefense.py:130-145), and both autograd adjoints:
@@ -39,7 +39,7 @@ __device__ constexpr float TW_IM[32] = {
     -1.950903220e-01f, -9.801714033e-02f};
 
 template <int S>
-__device__ __forceinline__ constexpr int brev(int i) {
+__device__ __forceinline__ constexpr int brev2(int i) {
     int r = 0;
     for (int b = 1; b < S; b <<= 1) {
         r = (r << 1) | (i & 1);
@@ -48,28 +48,118 @@ __device__ __forceinline__ constexpr int brev(int i) {
     return r;
 }
 
-// In-register radix-2 DIT.  Input in bit-reversed slots, output in natural order.  Fully unrolled: every
+// exp(-2*pi*i*j/80), j = 0..79  (mixed-radix sizes 10, 20, 40, 80)
+__device__ constexpr float TW80_RE[80] = {
+    1.000000000e+00f, 9.969173337e-01f, 9.876883406e-01f, 9.723699204e-01f, 9.510565163e-01f, 9.238795325e-01f,
+    8.910065242e-01f, 8.526401644e-01f, 8.090169944e-01f, 7.604059656e-01f, 7.071067812e-01f, 6.494480483e-01f,
+    5.877852523e-01f, 5.224985647e-01f, 4.539904997e-01f, 3.826834324e-01f, 3.090169944e-01f, 2.334453639e-01f,
+    1.564344650e-01f, 7.845909573e-02f, 6.123233996e-17f, -7.845909573e-02f, -1.564344650e-01f, -2.334453639e-01f,
+    -3.090169944e-01f, -3.826834324e-01f, -4.539904997e-01f, -5.224985647e-01f, -5.877852523e-01f, -6.494480483e-01f,
+    -7.071067812e-01f, -7.604059656e-01f, -8.090169944e-01f, -8.526401644e-01f, -8.910065242e-01f, -9.238795325e-01f,
+    -9.510565163e-01f, -9.723699204e-01f, -9.876883406e-01f, -9.969173337e-01f, -1.000000000e+00f, -9.969173337e-01f,
+    -9.876883406e-01f, -9.723699204e-01f, -9.510565163e-01f, -9.238795325e-01f, -8.910065242e-01f, -8.526401644e-01f,
+    -8.090169944e-01f, -7.604059656e-01f, -7.071067812e-01f, -6.494480483e-01f, -5.877852523e-01f, -5.224985647e-01f,
+    -4.539904997e-01f, -3.826834324e-01f, -3.090169944e-01f, -2.334453639e-01f, -1.564344650e-01f, -7.845909573e-02f,
+    -1.836970199e-16f, 7.845909573e-02f, 1.564344650e-01f, 2.334453639e-01f, 3.090169944e-01f, 3.826834324e-01f,
+    4.539904997e-01f, 5.224985647e-01f, 5.877852523e-01f, 6.494480483e-01f, 7.071067812e-01f, 7.604059656e-01f,
+    8.090169944e-01f, 8.526401644e-01f, 8.910065242e-01f, 9.238795325e-01f, 9.510565163e-01f, 9.723699204e-01f,
+    9.876883406e-01f, 9.969173337e-01f};
+__device__ constexpr float TW80_IM[80] = {
+    -0.000000000e+00f, -7.845909573e-02f, -1.564344650e-01f, -2.334453639e-01f, -3.090169944e-01f, -3.826834324e-01f,
+    -4.539904997e-01f, -5.224985647e-01f, -5.877852523e-01f, -6.494480483e-01f, -7.071067812e-01f, -7.604059656e-01f,
+    -8.090169944e-01f, -8.526401644e-01f, -8.910065242e-01f, -9.238795325e-01f, -9.510565163e-01f, -9.723699204e-01f,
+    -9.876883406e-01f, -9.969173337e-01f, -1.000000000e+00f, -9.969173337e-01f, -9.876883406e-01f, -9.723699204e-01f,
+    -9.510565163e-01f, -9.238795325e-01f, -8.910065242e-01f, -8.526401644e-01f, -8.090169944e-01f, -7.604059656e-01f,
+    -7.071067812e-01f, -6.494480483e-01f, -5.877852523e-01f, -5.224985647e-01f, -4.539904997e-01f, -3.826834324e-01f,
+    -3.090169944e-01f, -2.334453639e-01f, -1.564344650e-01f, -7.845909573e-02f, -1.224646799e-16f, 7.845909573e-02f,
+    1.564344650e-01f, 2.334453639e-01f, 3.090169944e-01f, 3.826834324e-01f, 4.539904997e-01f, 5.224985647e-01f,
+    5.877852523e-01f, 6.494480483e-01f, 7.071067812e-01f, 7.604059656e-01f, 8.090169944e-01f, 8.526401644e-01f,
+    8.910065242e-01f, 9.238795325e-01f, 9.510565163e-01f, 9.723699204e-01f, 9.876883406e-01f, 9.969173337e-01f,
+    1.000000000e+00f, 9.969173337e-01f, 9.876883406e-01f, 9.723699204e-01f, 9.510565163e-01f, 9.238795325e-01f,
+    8.910065242e-01f, 8.526401644e-01f, 8.090169944e-01f, 7.604059656e-01f, 7.071067812e-01f, 6.494480483e-01f,
+    5.877852523e-01f, 5.224985647e-01f, 4.539904997e-01f, 3.826834324e-01f, 3.090169944e-01f, 2.334453639e-01f,
+    1.564344650e-01f, 7.845909573e-02f};
+
+// S = 2^k, or 5 * 2^k (10, 20, 40, 80: the feature maps of the ResNet50 variant at 320 x 320 inputs)
+template <int S>
+struct Radix {
+    static constexpr bool MIXED = (S % 5 == 0);
+    static constexpr int P = MIXED ? S / 5 : S;            // length of the radix-2 part
+};
+
+// register slot of input element i: bit reversal for 2^k; for 5*P the decimated sequence r = i % 5 occupies slots
+// [r*P, (r+1)*P) in bit-reversed order of n2 = i / 5
+template <int S>
+__device__ __forceinline__ constexpr int brev(int i) {
+    if (Radix<S>::MIXED) return (i % 5) * Radix<S>::P + brev2<Radix<S>::P>(i / 5);
+    return brev2<S>(i);
+}
+
+// In-register radix-2 DIT on slots [OFF, OFF + P).  Input bit-reversed, output natural.  Fully unrolled: every
 // index and twiddle is a compile-time constant, so re[]/im[] live in VGPRs.
-template <int S, bool INV>
-__device__ __forceinline__ void fft_inreg(float (&re)[S], float (&im)[S]) {
+template <int S, int P, int OFF, bool INV>
+__device__ __forceinline__ void fft_pow2(float (&re)[S], float (&im)[S]) {
 #pragma unroll
-    for (int len = 2; len <= S; len <<= 1) {
+    for (int len = 2; len <= P; len <<= 1) {
         const int hl = len >> 1;
         const int tstep = 64 / len;
 #pragma unroll
-        for (int i = 0; i < S; i += len) {
+        for (int i = 0; i < P; i += len) {
 #pragma unroll
             for (int j = 0; j < hl; ++j) {
                 const float wr = TW_RE[j * tstep];
                 const float wi = INV ? -TW_IM[j * tstep] : TW_IM[j * tstep];
-                const float xr = re[i + j + hl], xi = im[i + j + hl];
+                const float xr = re[OFF + i + j + hl], xi = im[OFF + i + j + hl];
                 const float tr = wr * xr - wi * xi;
                 const float ti = wr * xi + wi * xr;
-                const float ur = re[i + j], ui = im[i + j];
-                re[i + j] = ur + tr;
-                im[i + j] = ui + ti;
-                re[i + j + hl] = ur - tr;
-                im[i + j + hl] = ui - ti;
+                const float ur = re[OFF + i + j], ui = im[OFF + i + j];
+                re[OFF + i + j] = ur + tr;
+                im[OFF + i + j] = ui + ti;
+                re[OFF + i + j + hl] = ur - tr;
+                im[OFF + i + j + hl] = ui - ti;
+            }
+        }
+    }
+}
+
+// S-point DFT in registers, input in brev<S> slots, output in natural order.  5*P sizes: Cooley-Tukey with N1 = 5:
+// five P-point FFTs of the decimated sequences, twiddles W_S^(r*k2), then a 5-point DFT across r for every k2 —
+// X[k2 + P*k1] = sum_r W_5^(r*k1) W_S^(r*k2) Y_r[k2] lands in the slots its inputs came from.
+template <int S, bool INV>
+__device__ __forceinline__ void fft_inreg(float (&re)[S], float (&im)[S]) {
+    constexpr int P = Radix<S>::P;
+    if constexpr (!Radix<S>::MIXED) {
+        fft_pow2<S, P, 0, INV>(re, im);
+    } else {
+        fft_pow2<S, P, 0 * P, INV>(re, im);
+        fft_pow2<S, P, 1 * P, INV>(re, im);
+        fft_pow2<S, P, 2 * P, INV>(re, im);
+        fft_pow2<S, P, 3 * P, INV>(re, im);
+        fft_pow2<S, P, 4 * P, INV>(re, im);
+        constexpr int TS = 80 / S;                         // W_S^m = W_80^(m*TS)
+#pragma unroll
+        for (int k2 = 0; k2 < P; ++k2) {
+            float yr[5], yi[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int m = (r * k2 * TS) % 80;
+                const float wr = TW80_RE[m], wi = INV ? -TW80_IM[m] : TW80_IM[m];
+                const float xr = re[r * P + k2], xi = im[r * P + k2];
+                yr[r] = wr * xr - wi * xi;
+                yi[r] = wr * xi + wi * xr;
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < 5; ++k1) {
+                float ar = yr[0], ai = yi[0];
+#pragma unroll
+                for (int r = 1; r < 5; ++r) {
+                    const int m = (16 * r * k1) % 80;      // W_5^(r*k1)
+                    const float wr = TW80_RE[m], wi = INV ? -TW80_IM[m] : TW80_IM[m];
+                    ar += wr * yr[r] - wi * yi[r];
+                    ai += wr * yi[r] + wi * yr[r];
+                }
+                re[k1 * P + k2] = ar;
+                im[k1 * P + k2] = ai;
             }
         }
     }
@@ -98,8 +188,8 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, 
     const int ch = blockIdx.x * CB + c;
     const bool cok = ch < C;
     float re[S], im[S];
-    // ---- pass 1: rows
-    {
+    // ---- pass 1: rows   (S * CB may be < 512 for the 5*2^k sizes: q >= S idles)
+    if (q < S) {
         const float* src = x + (((long)n * S + q) * S) * C + ch;
 #pragma unroll
         for (int w = 0; w < S; ++w) {
@@ -164,7 +254,7 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y,
     }
     __syncthreads();
     // ---- pass 2: Hermitian-extended inverse transform along kx, real part only
-    if (cok) {
+    if (cok && q < S) {
 #pragma unroll
         for (int kx = 0; kx <= S / 2; ++kx) {
             const float zr = Lre[kx * L::KSTRIDE + q * CB + c];
@@ -227,6 +317,10 @@ int ud_rfft2(const float* x, float* Y, int N, int S, int C, float scale, float w
         case 16: return launch_rfft2<16, 32>(x, Y, N, C, scale, w_interior, s);
         case 32: return launch_rfft2<32, 16>(x, Y, N, C, scale, w_interior, s);
         case 64: return launch_rfft2<64, 8>(x, Y, N, C, scale, w_interior, s);
+        case 10: return launch_rfft2<10, 51>(x, Y, N, C, scale, w_interior, s);
+        case 20: return launch_rfft2<20, 25>(x, Y, N, C, scale, w_interior, s);
+        case 40: return launch_rfft2<40, 12>(x, Y, N, C, scale, w_interior, s);
+        case 80: return launch_rfft2<80, 5>(x, Y, N, C, scale, w_interior, s);
         default: return UD_EINVAL;
     }
 }
@@ -239,6 +333,10 @@ int ud_irfft2(const float* Y, float* x, int N, int S, int C, float scale, float 
         case 16: return launch_irfft2<16, 32>(Y, x, N, C, scale, w_interior, s);
         case 32: return launch_irfft2<32, 16>(Y, x, N, C, scale, w_interior, s);
         case 64: return launch_irfft2<64, 8>(Y, x, N, C, scale, w_interior, s);
+        case 10: return launch_irfft2<10, 51>(Y, x, N, C, scale, w_interior, s);
+        case 20: return launch_irfft2<20, 25>(Y, x, N, C, scale, w_interior, s);
+        case 40: return launch_irfft2<40, 12>(Y, x, N, C, scale, w_interior, s);
+        case 80: return launch_irfft2<80, 5>(Y, x, N, C, scale, w_interior, s);
         default: return UD_EINVAL;
     }
 }

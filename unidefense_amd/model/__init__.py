@@ -1,5 +1,5 @@
 """Mirror of the reference's ``model`` package surface (model/__init__.py:1-17).
-UDR50 runs at power-of-two inputs (256, 512); the 320-pixel config needs the 2^k*5 FFT sizes (not built yet)."""
+UDR50 runs at 256x256 and at 320x320 (BASELINE configs[3]: 5*2^k FFT sizes)."""
 from .unidefense import UniDefenseModelEb4
 from .unidefense_res import UniDefenseModelRes18
 from .unidefense_res50 import UniDefenseModelRes50

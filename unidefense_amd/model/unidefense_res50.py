@@ -5,9 +5,8 @@ Bottleneck of ``model/resnet/exp.py:150-228``): same constructor kwargs, forward
 374 state-dict keys.  The torch.nn modules are parameter containers only; compute runs through
 ``unidefense_amd.tape`` on the HIP kernels, activations are pixel-major [N,H,W,C].
 
-Input sizes: the spectral branches use the in-register FFT kernels (sizes 8..64), i.e. inputs whose /4, /8, /16 and
-/32 maps are powers of two (256x256, 512x512).  BASELINE configs[3] (320x320 -> 2^k*5 FFT sizes) needs the
-mixed-radix kernels that are not built yet; the constructor accepts it and the forward raises a clear error.
+Input sizes: the spectral branches use the in-register FFT kernels (sizes 8..64 and the mixed-radix 10/20/40/80),
+i.e. 256x256 and 320x320 (BASELINE configs[3]) inputs; other sizes raise a clear error.
 """
 from typing import Optional
 
@@ -162,9 +161,9 @@ class UniDefenseModelRes50(UniDefenseModelRes18):
         """The whole forward (model/unidefense.py:556-631) on HIP kernels.  x: [N,3,H,W] planes; noise_x: the
         perturbed encoder input (the clean x stays the target of the attention residuals and the losses)."""
         N, _, H, W = x.shape
-        if H != W or H < 256 or (H & (H - 1)):
-            raise NotImplementedError(f"UDR50 on the HIP path needs a square power-of-two input >= 256 (FFT sizes "
-                                      f"8..64); got {H}x{W} (320x320 needs the 2^k*5 FFT kernels, not built yet)")
+        if H != W or H not in (256, 320):
+            raise NotImplementedError(f"UDR50 on the HIP path runs at 256x256 (FFT sizes 64/32/16/8) and 320x320 "
+                                      f"(80/40/20/10, BASELINE configs[3]); got {H}x{W}")
         rng = self._prepare_rng(rng)
         ex = self.extractor
         x_pix = K.planes_to_pix(x if noise_x is None else noise_x)
