@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--model", default="UDEB4", choices=["UDEB4", "UDR18", "UDR50"],
+                    help="informational runs of the other BASELINE configs (the contract line is UDEB4)")
+    ap.add_argument("--size", type=int, default=256, help="input resolution (UDR18: 128, UDR50: 256 or 320)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM timing table to this file")
@@ -130,11 +133,12 @@ def main():
     from unidefense_amd.engine.parallel import wrap_data_parallel
 
     torch.manual_seed(1234)
-    model = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5).to(dev).train()
+    ctor = dict(extractor="efficientnet-b4") if args.model == "UDEB4" else {}
+    model = load_model(args.model)(num_classes=2, drop_rate=0.5, **ctor).to(dev).train()
     model = wrap_data_parallel(model, local_rank) if (world > 1 or force) else model
     bs = args.batch
     g = torch.Generator().manual_seed(100 + rank)
-    x = (2.0 * torch.rand(bs, 3, 256, 256, generator=g) - 1.0).to(dev)
+    x = (2.0 * torch.rand(bs, 3, args.size, args.size, generator=g) - 1.0).to(dev)
     tgt = torch.tensor([0] * (bs // 2) + [1] * (bs // 2), device=dev)
     for k_ in ("aw_triplet",):
         LOSSES[k_].n_real = bs // 2
@@ -227,12 +231,16 @@ def main():
         gemm_flops = sum(p[2] for p in prof)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         line = {
-            "metric": "images/sec fwd+bwd (256x256, EffNet-b4)", "value": world * bs * args.steps / elapsed,
+            "metric": "images/sec fwd+bwd (256x256, EffNet-b4)" if (args.model, args.size) == ("UDEB4", 256)
+            else f"images/sec fwd+bwd ({args.size}x{args.size}, {args.model})",
+            "value": world * bs * args.steps / elapsed,
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "UDEB4 (EfficientNet-b4 + SFConv) 256x256 fwd + pass-1 loss + bwd, "
-                                   "spatial+frequency branches on, bs=32/GPU (BASELINE configs[1]/[2])",
+            "config": {"workload": ("UDEB4 (EfficientNet-b4 + SFConv) 256x256 fwd + pass-1 loss + bwd, "
+                                    "spatial+frequency branches on, bs=32/GPU (BASELINE configs[1]/[2])")
+                       if (args.model, args.size, bs) == ("UDEB4", 256, 32) else
+                       f"{args.model} {args.size}x{args.size} fwd + pass-1 loss + bwd, bs={bs}/GPU (informational)",
                        "global_batch": world * bs, "parallelism": f"dp{world}", "exec": exec_mode,
                        "final_loss": float(loss.detach())},
             "roofline": {"bound": "mfma",
