@@ -34,4 +34,11 @@ def build_optimizer(model, opt_cfg):
     wd = cfg.pop("weight_decay", 0.0)
     if "betas" in cfg:
         cfg["betas"] = tuple(cfg["betas"])
-    return get_optimizer(name, param_groups_weight_decay(model, wd), **cfg)
+    groups = param_groups_weight_decay(model, wd)
+    # torch's fused multi-tensor Adam(W) streams the 128 M parameters + 3 state tensors at 3.8 TB/s on MI355X
+    # (1.2 ms per step vs 3.1 ms for the foreach implementation; tools/bench_optim.py): SURVEY row (f)2 needs no
+    # custom kernel beyond it
+    if name.lower() in ("adamw", "adam") and "fused" not in cfg and "foreach" not in cfg \
+            and all(p.is_cuda for g in groups for p in g["params"]):
+        cfg["fused"] = True
+    return get_optimizer(name, groups, **cfg)
