@@ -69,3 +69,65 @@ def test_two_pass_step_vs_reference_golden(golden_dir, tag, cur_step):
     assert not bad, bad
     from tests.test_step_cpu import check_updates
     check_updates(g, tag, {k: (p.detach() - before[k]).cpu() for k, p in m.named_parameters()})
+
+
+def _make_engine(dev, use_graphs):
+    from unidefense_amd.engine import AbstractEngine
+    from unidefense_amd.engine.optim import build_optimizer
+    from unidefense_amd.loss import LOSSES
+    from unidefense_amd.model import load_model
+    m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.0, drop_connect_rate=0.0)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev).train()
+    m._dec_dropout = False                    # no random draw left in the forward: both engines see the same function
+    eng = AbstractEngine({"config": dict(ou.LAMBDAS)})
+    eng.model, eng.device, eng.num_steps, eng.warmup_step = m, dev, 100, 0
+    eng.use_graphs = use_graphs
+    eng.optimizer = build_optimizer(m, dict(name="adamw", lr=1e-4, betas=[0.9, 0.999], weight_decay=5e-6, amsgrad=True))
+    eng.scheduler = torch.optim.lr_scheduler.StepLR(eng.optimizer, step_size=22500, gamma=0.5)
+    eng.loss_criterion = {"softmax": LOSSES["cross_entropy"], "triplet": LOSSES["aw_triplet"],
+                          "kl_div": LOSSES["kl_div"], "fac": LOSSES["factorization"]}
+    return eng
+
+
+def test_graph_captured_step_equals_eager_step():
+    """engine.use_graphs: the two passes replayed from hipGraphs (perturbation / optimizer / scaler outside) must
+    reproduce the eager step over several steps with changing inputs — same losses, same parameters.  Dropout is
+    switched off so that both executions evaluate the same function; the perturbation is forced to `downscale`."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    from unidefense_amd.model import perturb
+    n = 4
+    tgt = param_fill.make_labels(n).to(dev)
+    xs = [param_fill.make_input(n, 256, 50 + i).to(dev) for i in range(4)]
+    orig = perturb.perturb_input
+    perturb.perturb_input = lambda x_, a, b, c: perturb.downscale(x_)
+    try:
+        results = {}
+        for use_graphs in (False, True):
+            eng = _make_engine(dev, use_graphs)
+            scaler = torch.amp.GradScaler("cuda", init_scale=2 ** 10, enabled=True)     # the reference's GradScaler(2**10)
+            rets = []
+            for i, x in enumerate(xs):
+                eng.optimizer.zero_grad()
+                rets.append({k: v.detach().float().cpu() for k, v in
+                             eng.train_unidefense_model(x, tgt, 50 + i, scaler, n // 2, n // 2).items()})
+            results[use_graphs] = (rets, {k: v.detach().cpu().clone() for k, v in eng.model.named_parameters()})
+            if use_graphs:
+                assert any("g2" in st for st in eng._graphs.values()), "the graphed path did not capture"
+    finally:
+        perturb.perturb_input = orig
+    (r0, p0), (r1, p1) = results[False], results[True]
+    for i, (a, b) in enumerate(zip(r0, r1)):
+        for k in a:
+            err = (a[k] - b[k]).abs().max().item() / max(a[k].abs().max().item(), 1e-30)
+            # the KL mask terms (~1e-3, a second-order difference of two nearly equal masks) amplify the run-to-run
+            # rounding of the split-K atomics: two EAGER runs of step 0 already differ by 1.6e-4 there
+            assert err <= (2e-2 if k in ("freq_mask_loss", "spat_mask_loss") else 1e-3), (i, k, err)
+    # parameters after 8 Adam steps: sign-like first steps move a parameter whose gradient is rounding noise by
+    # +-lr per step in ANY two runs (tests/test_step_cpu.py), so compare the distribution, not the worst tensor
+    devs = sorted(((p0[k] - p1[k]).abs().max() / (p0[k].abs().max() + 1e-12)).item() for k in p0)
+    med, p90, worst = devs[len(devs) // 2], devs[int(0.9 * len(devs))], devs[-1]
+    print(f"  4 steps, relative parameter deviation eager vs graphed: median {med:.2e}  90% {p90:.2e}  worst {worst:.2e}")
+    assert med <= 1e-4 and p90 <= 5e-3 and worst <= 0.5      # observed: 3e-6 / 8e-4 / 5e-2

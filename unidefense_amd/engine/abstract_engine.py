@@ -6,6 +6,7 @@ the reference's quirk that gradients are NOT zeroed between the two passes (``ze
 once per step: engine/forgery_engine.py:241).  Dataset plumbing, wandb, checkpoints and evaluation are out
 of scope.
 """
+import os
 import random
 
 import numpy as np
@@ -29,6 +30,8 @@ class AbstractEngine(object):
         self.config = config or {}
         self.model = self.optimizer = self.scheduler = self.loss_criterion = None
         self.num_steps, self.warmup_step, self.device = 1, 0, None
+        self.use_graphs = os.environ.get("UD_ENGINE_GRAPH", "0") == "1"    # hipGraph replay of the two passes
+        self._graphs = {}
 
     @staticmethod
     def fixed_randomness(seed=42):
@@ -84,19 +87,18 @@ class AbstractEngine(object):
         if dist.is_available() and dist.is_initialized():
             dist.barrier()
 
-    def train_unidefense_model(self, in_data, in_tgt, cur_step, grad_scalar, sum_real=None, sum_fake=None):
-        """One train step = clean pass + perturbed/consistency pass, each with its own backward and optimizer
-        step.  Batch order must be [real...; fake...]."""
-        # ---------------- pass 1: clean input ------------------------------------------------------
+    # ---- the two passes, shared by the eager and the graph-captured step ---------------------------------------
+    def _pass1(self, in_data, in_tgt, sum_real, sum_fake):
+        """Clean pass (engine/abstract_engine.py:210-281): returns (ret_dict, targets for pass 2, total_loss)."""
         out_dict = self.model(in_data)
         loss_dict = out_dict.get("loss_dict", dict())
         has_fm = loss_dict.get("freq_mask") is not None
         has_sm = loss_dict.get("spat_mask") is not None
-        freq_mask_gt = loss_dict["freq_mask"].clone().detach() if has_fm else None
-        spat_mask_gt = loss_dict["spat_mask"].clone().detach() if has_sm else None
+        gts = {"freq_mask": loss_dict["freq_mask"].clone().detach() if has_fm else None,
+               "spat_mask": loss_dict["spat_mask"].clone().detach() if has_sm else None,
+               "fac": loss_dict["factorization"].clone().detach()}
         freq_mask_loss = torch.mean(loss_dict["freq_mask"]) if has_fm else _zero(self.device)
         spat_mask_loss = torch.mean(loss_dict["spat_mask"]) if has_sm else _zero(self.device)
-        fac_gt = loss_dict["factorization"].clone().detach()
         t = self._common_terms(out_dict, in_tgt, sum_real, sum_fake)
         total_loss = t["cls"] + self._lam("lambda_mask") * freq_mask_loss + self._lam("lambda_mask") * spat_mask_loss \
             + self._lam("lambda_triplet") * t["triplet"] + self._lam("lambda_recons") * t["real_rec"] \
@@ -106,36 +108,115 @@ class AbstractEngine(object):
             "triplet_loss": t["triplet"], "real_rec_loss": t["real_rec"], "fake_rec_loss": t["fake_rec"],
             "real_freq_loss": t["real_freq"], "fake_freq_loss": t["fake_freq"],
         }
-        self._backward_and_step(total_loss, grad_scalar)
-        self._barrier()
+        return ret_dict, gts, total_loss
 
-        # ---------------- pass 2: perturbed input + consistency with pass 1 -----------------------
-        pert_real_list = torch.arange(sum_real)[torch.randperm(sum_real)]
-        pert_fake_list = torch.arange(sum_fake)[torch.randperm(sum_fake)]
-        out_dict = self.model(in_data, pert_real_list=pert_real_list, pert_fake_list=pert_fake_list,
-                              preserve_color=True)
+    def _pass2(self, out_dict, in_tgt, sum_real, sum_fake, gts, kl):
+        """Loss assembly of the perturbed pass (engine/abstract_engine.py:294-371); kl = cur_step > 0.1 num_steps."""
         loss_dict = out_dict.get("loss_dict", dict())
+        has_fm, has_sm = gts["freq_mask"] is not None, gts["spat_mask"] is not None
         t = self._common_terms(out_dict, in_tgt, sum_real, sum_fake)
         zero_like = torch.zeros_like(t["cls"])
-        if cur_step > self.num_steps * 0.1:
+        if kl:
             # mask alignment: KL between the log-softmaxed flattened masks of the two passes
             def kld(pred, gt):
                 pred = torch.log_softmax(pred.reshape(pred.shape[0], -1), dim=-1)
                 gt = torch.log_softmax(gt.reshape(gt.shape[0], -1), dim=-1)
                 return self.loss_criterion["kl_div"](pred, gt)
-            freq_mask_loss = kld(loss_dict["freq_mask"], freq_mask_gt) if has_fm else zero_like
-            spat_mask_loss = kld(loss_dict["spat_mask"], spat_mask_gt) if has_sm else zero_like
+            freq_mask_loss = kld(loss_dict["freq_mask"], gts["freq_mask"]) if has_fm else zero_like
+            spat_mask_loss = kld(loss_dict["spat_mask"], gts["spat_mask"]) if has_sm else zero_like
         else:
             freq_mask_loss = torch.mean(loss_dict["freq_mask"]) if has_fm else zero_like
             spat_mask_loss = torch.mean(loss_dict["spat_mask"]) if has_sm else zero_like
-        fac_loss = self.loss_criterion["fac"](loss_dict["factorization"], fac_gt)
-        ret_dict.update({"freq_mask_loss": freq_mask_loss, "spat_mask_loss": spat_mask_loss, "fac_loss": fac_loss})
+        fac_loss = self.loss_criterion["fac"](loss_dict["factorization"], gts["fac"])
         total_loss = 0.1 * t["cls"] + self._lam("lambda_mask") * freq_mask_loss \
             + self._lam("lambda_mask") * spat_mask_loss + self._lam("lambda_triplet") * t["triplet"] \
             + self._lam("lambda_recons") * 0.1 * t["real_rec"] + self._lam("lambda_freq") * 0.1 * t["real_freq"] \
             + self._lam("lambda_fac") * fac_loss
+        return {"freq_mask_loss": freq_mask_loss, "spat_mask_loss": spat_mask_loss, "fac_loss": fac_loss}, total_loss
+
+    def train_unidefense_model(self, in_data, in_tgt, cur_step, grad_scalar, sum_real=None, sum_fake=None):
+        """One train step = clean pass + perturbed/consistency pass, each with its own backward and optimizer
+        step.  Batch order must be [real...; fake...].
+        With ``self.use_graphs`` (env UD_ENGINE_GRAPH=1) the forward + loss + backward of each pass is captured into a
+        hipGraph on the second call with a given shape and replayed afterwards; perturbation, optimizer, scaler and
+        scheduler calls stay outside the graphs (host-side randomness / synchronisation)."""
+        kl = cur_step > self.num_steps * 0.1
+        if self.use_graphs and not getattr(self.model, "rng_queue", None) and in_data.is_cuda:
+            return self._train_graphed(in_data, in_tgt, cur_step, grad_scalar, sum_real, sum_fake, kl)
+        # ---------------- pass 1: clean input ------------------------------------------------------
+        ret_dict, gts, total_loss = self._pass1(in_data, in_tgt, sum_real, sum_fake)
+        self._backward_and_step(total_loss, grad_scalar)
+        self._barrier()
+        # ---------------- pass 2: perturbed input + consistency with pass 1 -----------------------
+        pert_real_list = torch.arange(sum_real)[torch.randperm(sum_real)]
+        pert_fake_list = torch.arange(sum_fake)[torch.randperm(sum_fake)]
+        out_dict = self.model(in_data, pert_real_list=pert_real_list, pert_fake_list=pert_fake_list,
+                              preserve_color=True)
+        ret2, total_loss = self._pass2(out_dict, in_tgt, sum_real, sum_fake, gts, kl)
+        ret_dict.update(ret2)
         self._backward_and_step(total_loss, grad_scalar)
         if self.warmup_step == 0 or cur_step > self.warmup_step:
             self.scheduler.step()
         self._barrier()
         return ret_dict
+
+    # ---- graph-captured step ------------------------------------------------------------------------------------
+    def _perturbed(self, in_data, sum_real, sum_fake):
+        from ..model import perturb
+        pert_real_list = torch.arange(sum_real)[torch.randperm(sum_real)]
+        pert_fake_list = torch.arange(sum_fake)[torch.randperm(sum_fake)]
+        with torch.no_grad():
+            return perturb.perturb_input(in_data, pert_real_list, pert_fake_list, True).contiguous().to(torch.float32)
+
+    def _train_graphed(self, in_data, in_tgt, cur_step, grad_scalar, sum_real, sum_fake, kl):
+        key = (tuple(in_data.shape), int(sum_real), int(sum_fake), bool(kl))
+        st = self._graphs.setdefault(key, {"calls": 0})
+        st["calls"] += 1
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        if st["calls"] == 1:
+            # eager first call: warms up every lazily created buffer (scaler state, workspaces, optimizer state)
+            saved, self.use_graphs = self.use_graphs, False
+            try:
+                return self.train_unidefense_model(in_data, in_tgt, cur_step, grad_scalar, sum_real, sum_fake)
+            finally:
+                self.use_graphs = saved
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        if "g1" not in st:
+            st["x"], st["tgt"] = in_data.clone(), in_tgt.clone()
+            st["noise"] = torch.empty_like(st["x"])
+            for p in params:
+                p.grad = None
+            torch.cuda.synchronize()
+            st["g1"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st["g1"], capture_error_mode=mode):
+                ret1, gts, total1 = self._pass1(st["x"], st["tgt"], sum_real, sum_fake)
+                grad_scalar.scale(total1).backward()
+            st["ret1"], st["gts"] = ret1, gts
+            st["grads"] = [p.grad for p in params]          # static buffers the replays write
+            st["pool"] = st["g1"].pool()
+        st["x"].copy_(in_data)
+        st["tgt"].copy_(in_tgt)
+        st["g1"].replay()
+        for p, g in zip(params, st["grads"]):
+            p.grad = g
+        grad_scalar.step(self.optimizer)
+        grad_scalar.update()
+        self._barrier()
+        st["noise"].copy_(self._perturbed(in_data, sum_real, sum_fake))
+        if "g2" not in st:
+            torch.cuda.synchronize()
+            st["g2"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(st["g2"], pool=st["pool"], capture_error_mode=mode):
+                out_dict = self.model(st["x"], noise_x=st["noise"])
+                ret2, total2 = self._pass2(out_dict, st["tgt"], sum_real, sum_fake, st["gts"], kl)
+                grad_scalar.scale(total2).backward()       # accumulates in place onto the pass-1 gradient buffers
+            st["ret2"] = ret2
+        st["g2"].replay()
+        grad_scalar.step(self.optimizer)
+        grad_scalar.update()
+        if self.warmup_step == 0 or cur_step > self.warmup_step:
+            self.scheduler.step()
+        self._barrier()
+        ret = {k: v.detach().clone() for k, v in st["ret1"].items()}
+        ret.update({k: v.detach().clone() for k, v in st["ret2"].items()})
+        return ret

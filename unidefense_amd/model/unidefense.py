@@ -207,9 +207,13 @@ class UniDefenseModelEb4(nn.Module):
         """Returns {'cls_out','rec','loss_dict'} like the reference (model/unidefense.py:174-256).
         rng: optional dict of explicit keep-masks (NCHW-shaped like the reference's tensors):
         'drop_connect' {block: [N]}, 'dec_keep' [N,160,h,w], 'emb_keep' [N,272,h,w], 'feat_keep' [N,F]."""
-        noise_x = None       # the perturbed copy feeds the encoder only; the attention residuals and the
-        # reconstruction losses keep the clean input (model/unidefense.py:200, :219, :243-248)
-        if self.training and pert_real_list is not None and pert_fake_list is not None:
+        # the perturbed copy feeds the encoder only; the attention residuals and the reconstruction losses keep the
+        # clean input (model/unidefense.py:200, :219, :243-248).  kwargs['noise_x']: an already perturbed copy (the
+        # graph-captured engine step perturbs outside the captured region, engine/abstract_engine.py)
+        noise_x = kwargs.get("noise_x") if self.training else None
+        if noise_x is not None:
+            noise_x = noise_x.contiguous().to(torch.float32)
+        elif self.training and pert_real_list is not None and pert_fake_list is not None:
             from . import perturb
             with torch.no_grad():
                 noise_x = perturb.perturb_input(x, pert_real_list, pert_fake_list, preserve_color)
@@ -387,7 +391,9 @@ class UniDefenseModelEb4(nn.Module):
         x_b4 = self._blocks(tape, x_b3, 4, rng)
 
         d_in = x_b4
-        if self.training:                                                # F.dropout(x_b4, 0.2), unidefense.py:213
+        # F.dropout(x_b4, 0.2), unidefense.py:213 (hard-coded rate; `_dec_dropout = False` lets a test switch the
+        # only draw that drop_rate = 0 / drop_connect_rate = 0 leave, to compare two executions bit for bit)
+        if self.training and getattr(self, "_dec_dropout", True):
             d_in = T.dropout_mask(tape, x_b4, self._keep_mask(rng, "dec_keep", x_b4, 0.8), 0.2)
         dec1 = self._decoder(tape, d_in, self.dec_block1, False)
         dec2 = self._decoder(tape, dec1, self.dec_block2, False)
