@@ -93,6 +93,24 @@ def cpu_baseline(timeout_s=300):
                 "sample": f"not finished within {timeout_s} s"}
 
 
+def _pmc_traffic(args, bs):
+    """roofline.traffic: HBM bytes per GEMM launch from the committed PMC summary of this same workload
+    (tools/gpu_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 half-count correction).  PMC passes
+    cannot run inside the timed bench, so the number is read from profiles/; None when no summary matches."""
+    if (args.model, args.size, bs) != ("UDEB4", 256, 32):
+        return None, None
+    import glob
+    root = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*", "hbm_traffic_gemm.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+            return float(d["gemm_family"]["hbm_bytes_per_launch"]), os.path.relpath(f, root)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +248,9 @@ def main():
         gemm_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
         gemm_flops = sum(p[2] for p in prof)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # operand + result bytes of each launch (fp32, every matrix touched once), to set beside the PMC traffic
+        alg_bytes = sum(4.0 * max(k[6], 1) * (k[0] * k[2] + k[2] * k[1] + k[0] * k[1]) for *_, k in prof) / max(len(prof), 1)
+        traffic, traffic_src = _pmc_traffic(args, bs)
         line = {
             "metric": "images/sec fwd+bwd (256x256, EffNet-b4)" if (args.model, args.size) == ("UDEB4", 256)
             else f"images/sec fwd+bwd ({args.size}x{args.size}, {args.model})",
@@ -250,12 +271,20 @@ def main():
                                    "achieved = algorithmic fp32 FLOPs (2MNK) per second over all launches, priced "
                                    "against the fp32 matrix peak",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (mean over the GEMM launches of a step)",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                          "launches_per_step": len(prof) / prof_steps,
                          "gemm_ms_per_step": gemm_ms / prof_steps,
                          "gemm_gflop_per_step": gemm_flops / 1e9 / prof_steps,
                          "measured": f"{prof_steps} eager steps after the timed region, HIP events per launch"},
         }
+        if (args.model, args.size) == ("UDEB4", 256):
+            # whole-step fractions from the algorithmic work per image (fwd+bwd, fp32):
+            # 68.9 GFLOP and 1044 MB at bs 32 — per GPU, against the fp32 matrix peak and 8 TB/s
+            ips = bs * args.steps / elapsed
+            line["roofline"]["step_achieved_mfma_frac"] = 68.9e9 * ips / (MFMA_F32_PEAK_TFLOPS * 1e12)
+            line["roofline"]["step_achieved_hbm_frac"] = 1044e6 * ips / 8e12
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -225,6 +225,33 @@ int ud_copy_cols(float* narrow, float* wide, long M, int Cn, int Cw, int off, in
 int ud_aw_triplet(const float* feat, int N, int D, int n_real, float* loss, float* dfeat, float* ws,
                   ud_stream_t stream);
 
+/* ---- pass-2 input perturbations (model/unidefense.py:177-198), NCHW planes x[planes][H][W], no gradients --------
+ * ud_gather2d      : out[p][y][x] = in[p][iy[y]][ix[x]] — downscale (model/modules.py:19-21): the two nearest
+ *                    F.interpolate calls composed into one gather (index vectors from ATen's float32 rule)
+ * ud_blur5_reflect : torchvision gaussian_blur(k=5), model/modules.py:15-16: reflect pad 2, taps (k0,k1,k2,k1,k0)^2
+ * ud_amp_mix       : FrequencyStyleTransfer's spectrum step (model/modules.py:44-52) on spectra laid out
+ *                    [planes][2S][Whp] (rows [0,S) Re, [S,2S) Im; columns [0,S/2] valid):
+ *                    out = w(kx) * (l|A| + (1-l)|B|) * exp(i angle(A)), l = lmda[plane / planes_per_sample],
+ *                    w = 2 on the interior columns so the forward transform's adjoint yields irfft2
+ * ud_efdm          : SpatialStyleTransfer (model/modules.py:58-76) on rows of L values:
+ *                    out = (c + (1-l) * style_sorted[rank(c)]) - (1-l) * c ; ws from ud_efdm_ws_bytes (bytes, <0: bad
+ *                    sizes); equal content values take the equal-rank style values in index order
+ * ud_coral_moments : CORAL statistics (utils/operation.py:7-13,24-34) of x[N][3][HW]: per (sample, chunk) partial
+ *                    sums part[N][chunks][9] = (sum x_c (3), sum x_c x_d for 00 01 02 11 12 22), fp64
+ * ud_affine3       : out[n][c][i] = sum_k M[n][c][k] x[n][k][i] + M[n][c][3]   (M[N][3][4]; CORAL's transfer,
+ *                    utils/operation.py:36-45, folded into one affine colour map per sample) */
+int ud_gather2d(const float* in, float* out, const int* iy, const int* ix, long planes, int H, int W,
+                ud_stream_t stream);
+int ud_blur5_reflect(const float* in, float* out, long planes, int H, int W, float k0, float k1, float k2,
+                     ud_stream_t stream);
+int ud_amp_mix(const float* A, const float* B, const float* lmda, float* out, long planes, int S, int Whp,
+               int planes_per_sample, ud_stream_t stream);
+long ud_efdm_ws_bytes(int rows, int L);
+int ud_efdm(const float* content, const float* style, const float* lmda, float* out, int rows, int L,
+            int rows_per_sample, void* ws, long ws_bytes, ud_stream_t stream);
+int ud_coral_moments(const float* x, double* part, int N, int HW, int chunks, ud_stream_t stream);
+int ud_affine3(const float* x, const float* M, float* out, int N, int HW, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

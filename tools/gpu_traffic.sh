@@ -1,0 +1,46 @@
+#!/bin/bash
+# HBM traffic of the GEMM family from the PMC counters, as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
+# prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), with --kernel-trace only; both are in
+# KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> doubled.
+# Output: gpurun_out/$1/hbm_traffic_gemm.json  (copy to profiles/<round>/; bench.py reports it as roofline.traffic)
+tag=${1:-traffic}
+out=gpurun_out/$tag
+mkdir -p $out
+export PYTHONDONTWRITEBYTECODE=1
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -o $c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --eager > $out/$c.log 2>&1
+  echo "$c pass exit $?"
+done
+python3 - <<PY
+import csv, glob, json, collections
+tot = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob("$out/**/%s_counter_collection.csv" % c, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != c:
+                continue
+            name = r["Kernel_Name"]
+            fam = "gemm_x3_kernel" if "gemm_x3_kernel" in name else "gemm_kernel" if "gemm_kernel" in name else "other"
+            a = agg[fam]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    tot[c] = {k: v for k, v in agg.items()}
+res = {"recipe": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
+                 "--warmup 1 --no-cpu-baseline --eager; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE "
+                 "half-count correction of MI355X_MICROARCH.md)", "families": {}}
+for fam in ("gemm_x3_kernel", "gemm_kernel", "other"):
+    f, w = tot["FETCH_SIZE"].get(fam, [0, 0.0]), tot["WRITE_SIZE"].get(fam, [0, 0.0])
+    if not f[0] or not w[0]:
+        continue
+    res["families"][fam] = {"launches": f[0], "fetch_kib_raw_per_launch": f[1] / f[0], "write_kib_per_launch": w[1] / w[0],
+                            "hbm_bytes_per_launch": (2 * f[1] / f[0] + w[1] / w[0]) * 1024}
+g = [res["families"][k] for k in ("gemm_x3_kernel", "gemm_kernel") if k in res["families"]]
+if g:
+    n = sum(x["launches"] for x in g)
+    res["gemm_family"] = {"launches": n, "hbm_bytes_per_launch": sum(x["hbm_bytes_per_launch"] * x["launches"] for x in g) / n}
+json.dump(res, open("$out/hbm_traffic_gemm.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+find $out -name "*kernel_trace.csv" -delete
+find $out -name "*counter_collection.csv" -size +8M -delete

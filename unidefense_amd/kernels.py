@@ -721,3 +721,71 @@ def aw_triplet(feat, n_real):
     ws = empty((n_real * (N + 1),), feat)
     _call("ud_aw_triplet", _p(feat), N, D, int(n_real), _p(loss), _p(dfeat), _p(ws), _stream())
     return loss, dfeat
+
+
+# ---------------------------------------------------------------------------------------------
+# pass-2 input perturbations on NCHW planes (perturb.hip; model/unidefense.py:177-198 of the reference)
+# ---------------------------------------------------------------------------------------------
+_PERTURB_WS = {}
+
+
+def gather2d(x, iy, ix):
+    """x [.., H, W] -> out[.., y, x] = x[.., iy[y], ix[x]]  (iy, ix: int32 device vectors)."""
+    _chk(x)
+    H, W = x.shape[-2:]
+    out = torch.empty_like(x)
+    _call("ud_gather2d", _p(x), _p(out), _p(iy), _p(ix), x.numel() // (H * W), H, W, _stream())
+    return out
+
+
+def blur5_reflect(x, taps):
+    _chk(x)
+    H, W = x.shape[-2:]
+    out = torch.empty_like(x)
+    _call("ud_blur5_reflect", _p(x), _p(out), x.numel() // (H * W), H, W, float(taps[0]), float(taps[1]),
+          float(taps[2]), _stream())
+    return out
+
+
+def amp_mix(Ya, Yb, lmda, S, planes_per_sample):
+    """Spectra [P, 2S, Whp] (dft_rfft2_planes layout) -> w * (l|A| + (1-l)|B|) * exp(i angle(A))."""
+    _chk(Ya, Yb, lmda)
+    P, S2, Whp = Ya.shape
+    assert S2 == 2 * S and Yb.shape == Ya.shape and lmda.numel() * planes_per_sample == P
+    out = torch.empty_like(Ya)
+    _call("ud_amp_mix", _p(Ya), _p(Yb), _p(lmda), _p(out), P, S, Whp, planes_per_sample, _stream())
+    return out
+
+
+def efdm(content, style, lmda, rows_per_sample):
+    """content/style [rows, L]; lmda [rows / rows_per_sample] -> rank-matched mix (model/modules.py:58-76)."""
+    _chk(content, style, lmda)
+    rows, L = content.shape
+    assert style.shape == content.shape and lmda.numel() * rows_per_sample == rows
+    need = _call("ud_efdm_ws_bytes", rows, L)
+    key = content.device.index
+    ws = _PERTURB_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _PERTURB_WS[key] = torch.empty(need, dtype=torch.uint8, device=content.device)
+    out = torch.empty_like(content)
+    _call("ud_efdm", _p(content), _p(style), _p(lmda), _p(out), rows, L, rows_per_sample, _p(ws), ws.numel(), _stream())
+    return out
+
+
+def coral_moments(x, chunks=16):
+    """x [N, 3, H, W] -> fp64 [N, 9]: sum x_c (3), sum x_c x_d (00 01 02 11 12 22)."""
+    _chk(x)
+    N = x.shape[0]
+    HW = x.shape[-1] * x.shape[-2]
+    part = torch.empty((N, chunks, 9), dtype=torch.float64, device=x.device)
+    _call("ud_coral_moments", _p(x), _p(part), N, HW, chunks, _stream())
+    return part.sum(1)
+
+
+def affine3(x, M):
+    """out[n, c] = sum_k M[n, c, k] x[n, k] + M[n, c, 3]  on [N, 3, H, W]."""
+    _chk(x, M)
+    assert M.shape == (x.shape[0], 3, 4)
+    out = torch.empty_like(x)
+    _call("ud_affine3", _p(x), _p(M), _p(out), x.shape[0], x.shape[-1] * x.shape[-2], _stream())
+    return out

@@ -81,11 +81,19 @@ _SIGNATURES = {
     "ud_relu_bwd": [_P, _P, _P, _L, _P],
     "ud_copy_cols": [_P, _P, _L, _I, _I, _I, _I, _P],
     "ud_aw_triplet": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "ud_gather2d": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "ud_blur5_reflect": [_P, _P, _L, _I, _I, _F, _F, _F, _P],
+    "ud_amp_mix": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "ud_efdm_ws_bytes": [_I, _I],
+    "ud_efdm": [_P, _P, _P, _P, _I, _I, _I, _P, _L, _P],
+    "ud_coral_moments": [_P, _P, _I, _I, _I, _P],
+    "ud_affine3": [_P, _P, _P, _I, _I, _P],
 }
 
 # helpers that return a count rather than a status code
 _COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
-                "ud_l1_chunks"}
+                "ud_l1_chunks", "ud_efdm_ws_bytes"}
+_LONG_FUNCS = {"ud_efdm_ws_bytes"}        # return a C long
 
 EXPORTED = tuple(_SIGNATURES)
 
@@ -114,7 +122,7 @@ def load():
         if fn is None:
             raise UDLibraryError(f"{LIB_PATH} does not export {name}; rebuild it")
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_long if name in _LONG_FUNCS else C.c_int
     _lib = lib
     return lib
 
