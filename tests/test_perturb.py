@@ -144,5 +144,5 @@ def test_spatial_transfer_with_ties():
     matched = ((out - l_ * x.double()) / (1 - l_)).reshape(4, 3, -1)
     assert torch.allclose(matched.sort(-1).values, st.double().reshape(4, 3, -1).sort(-1).values, atol=1e-5)
     xv = x.reshape(4, 3, -1)
-    order = xv.argsort(-1, stable=True)
+    order = torch.sort(xv, dim=-1, stable=True).indices
     assert (matched.gather(-1, order).diff(dim=-1) >= -1e-5).all()

@@ -6,9 +6,10 @@
 //             model/modules.py:35-55 (frequency amplitude transfer), :58-76 (exact feature-distribution matching),
 //             utils/operation.py:7-45 (CORAL colour transfer).
 // The 2-D FFTs of the amplitude transfer run as DFT-matrix GEMMs on ud_gemm (kernels.dft_rfft2_planes); this file
-// holds the spectrum mixing between them.  The segmented sorts of the distribution matching use rocPRIM's radix
-// sort (ROCm's device-wide primitive — there is nothing UniDefense-specific to gain by re-writing it); the rank
-// gather of the reference (argsort of argsort + gather) is folded into one scatter pass.
+// holds the spectrum mixing between them.  The per-(sample, channel) sorts of the distribution matching are ONE
+// device-wide rocPRIM radix sort over composite (row, value) keys (ROCm's primitive — there is nothing
+// UniDefense-specific to gain by re-writing it); the rank gather of the reference (argsort of argsort + gather) is
+// folded into one scatter pass.
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -90,41 +91,60 @@ __global__ __launch_bounds__(NT) void amp_mix(const float* __restrict__ A, const
     }
 }
 
-__global__ __launch_bounds__(NT) void iota_mod(unsigned* __restrict__ v, long total, unsigned L) {
-    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) v[e] = (unsigned)(e % L);
+// Order-preserving map float -> uint32 (negative: all bits flipped, else sign bit set) and back.
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// sorted position j of row r holds content index i = sidx[r][j] and the style value of the same rank sv[r][j]:
+// 96 rows of 65 536 values: a segmented sort keeps one workgroup per row (96 of 256 CUs busy).  Instead ONE
+// device-wide radix sort over composite 64-bit keys (row << 32 | ordered value bits), 32 + ceil(log2 rows) bits.
+__global__ __launch_bounds__(NT) void efdm_keys(const float* __restrict__ content, const float* __restrict__ style,
+                                                unsigned long long* __restrict__ ck, unsigned long long* __restrict__ sk,
+                                                unsigned* __restrict__ idx, long total, unsigned L) {
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
+        const unsigned long long r = (unsigned long long)(e / L) << 32;
+        ck[e] = r | f2key(content[e]);
+        sk[e] = r | f2key(style[e]);
+        idx[e] = (unsigned)(e % L);
+    }
+}
+
+// sorted position j of row r holds content index i = sidx[r][j] and the style value of the same rank:
 // out[r][i] = (c + (1-l) * sv) - (1-l) * c      (model/modules.py:70-73, same operation order, no contraction)
 __global__ __launch_bounds__(NT) void efdm_scatter(const float* __restrict__ content, const unsigned* __restrict__ sidx,
-                                                   const float* __restrict__ sv, const float* __restrict__ lmda,
-                                                   float* __restrict__ out, long total, unsigned L,
-                                                   int rows_per_sample) {
+                                                   const unsigned long long* __restrict__ sk_sorted,
+                                                   const float* __restrict__ lmda, float* __restrict__ out, long total,
+                                                   unsigned L, int rows_per_sample) {
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
         const long r = e / L;
         const long i = r * L + sidx[e];
         const float om = __fsub_rn(1.0f, lmda[r / rows_per_sample]);
-        const float c = content[i];
-        out[i] = __fsub_rn(__fadd_rn(c, __fmul_rn(om, sv[e])), __fmul_rn(om, c));
+        const float c = content[i], sv = key2f((unsigned)sk_sorted[e]);
+        out[i] = __fsub_rn(__fadd_rn(c, __fmul_rn(om, sv)), __fmul_rn(om, c));
     }
 }
 
-struct TimesL {
-    unsigned L;
-    __host__ __device__ unsigned operator()(unsigned i) const { return i * L; }
-};
-
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+inline unsigned key_bits(unsigned rows) {
+    unsigned b = 0;
+    while ((1u << b) < rows) ++b;
+    return 32 + b;
+}
+
 hipError_t sort_temp_bytes(unsigned rows, unsigned L, size_t* pairs, size_t* keys) {
-    auto b = rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), TimesL{L});
-    auto e = rocprim::make_transform_iterator(rocprim::make_counting_iterator(1u), TimesL{L});
-    hipError_t err = rocprim::segmented_radix_sort_pairs(nullptr, *pairs, (const float*)nullptr, (float*)nullptr,
-                                                         (const unsigned*)nullptr, (unsigned*)nullptr, rows * L, rows,
-                                                         b, e, 0, 32, (hipStream_t)0);
+    typedef unsigned long long u64;
+    const unsigned bits = key_bits(rows);
+    hipError_t err = rocprim::radix_sort_pairs(nullptr, *pairs, (const u64*)nullptr, (u64*)nullptr,
+                                               (const unsigned*)nullptr, (unsigned*)nullptr, (size_t)rows * L, 0, bits,
+                                               (hipStream_t)0);
     if (err != hipSuccess) return err;
-    return rocprim::segmented_radix_sort_keys(nullptr, *keys, (const float*)nullptr, (float*)nullptr, rows * L, rows, b,
-                                              e, 0, 32, (hipStream_t)0);
+    return rocprim::radix_sort_keys(nullptr, *keys, (const u64*)nullptr, (u64*)nullptr, (size_t)rows * L, 0, bits,
+                                    (hipStream_t)0);
 }
 
 // per (sample, chunk): sum x_c (3) and sum x_c x_d (6: 00 01 02 11 12 22) over the chunk's pixels, fp64
@@ -210,33 +230,34 @@ long ud_efdm_ws_bytes(int rows, int L) {
     size_t tp = 0, tk = 0;
     if (sort_temp_bytes((unsigned)rows, (unsigned)L, &tp, &tk) != hipSuccess) return UD_EINVAL - 1;
     const size_t n = (size_t)rows * L;
-    return (long)(4 * align256(n * 4) + align256(tp > tk ? tp : tk));
+    // content keys, style keys, one sorted-key buffer (reused), index in / out, rocPRIM's temporary storage
+    return (long)(3 * align256(n * 8) + 2 * align256(n * 4) + align256(tp > tk ? tp : tk));
 }
 
 int ud_efdm(const float* content, const float* style, const float* lmda, float* out, int rows, int L,
             int rows_per_sample, void* ws, long ws_bytes, ud_stream_t sh) {
+    typedef unsigned long long u64;
     hipStream_t stream = (hipStream_t)sh;
     const long need = ud_efdm_ws_bytes(rows, L);
     if (need < 0 || ws_bytes < need || rows_per_sample < 1) return UD_EINVAL;
-    const size_t n = (size_t)rows * L, seg = align256(n * 4);
+    const size_t n = (size_t)rows * L, s8 = align256(n * 8), s4 = align256(n * 4);
     char* base = (char*)ws;
-    unsigned* iota = (unsigned*)base;
-    unsigned* sidx = (unsigned*)(base + seg);
-    float* ckeys = (float*)(base + 2 * seg);
-    float* sv = (float*)(base + 3 * seg);
-    void* temp = base + 4 * seg;
-    size_t temp_bytes = (size_t)ws_bytes - 4 * seg;
-    iota_mod<<<blocks_for((long)n), NT, 0, stream>>>(iota, (long)n, (unsigned)L);
+    u64* ck = (u64*)base;
+    u64* sk = (u64*)(base + s8);
+    u64* sorted = (u64*)(base + 2 * s8);
+    unsigned* idx = (unsigned*)(base + 3 * s8);
+    unsigned* sidx = (unsigned*)(base + 3 * s8 + s4);
+    void* temp = base + 3 * s8 + 2 * s4;
+    size_t temp_bytes = (size_t)ws_bytes - (3 * s8 + 2 * s4);
+    const unsigned bits = key_bits((unsigned)rows);
+    efdm_keys<<<blocks_for((long)n), NT, 0, stream>>>(content, style, ck, sk, idx, (long)n, (unsigned)L);
     UD_LAUNCH_CHECK();
-    auto b = rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), TimesL{(unsigned)L});
-    auto e = rocprim::make_transform_iterator(rocprim::make_counting_iterator(1u), TimesL{(unsigned)L});
-    hipError_t err = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, content, ckeys, (const unsigned*)iota, sidx,
-                                                         (unsigned)n, (unsigned)rows, b, e, 0, 32, stream);
+    hipError_t err = rocprim::radix_sort_pairs(temp, temp_bytes, (const u64*)ck, sorted, (const unsigned*)idx, sidx, n,
+                                               0, bits, stream);
     if (err != hipSuccess) return -(int)err;
-    err = rocprim::segmented_radix_sort_keys(temp, temp_bytes, style, sv, (unsigned)n, (unsigned)rows, b, e, 0, 32,
-                                             stream);
+    err = rocprim::radix_sort_keys(temp, temp_bytes, (const u64*)sk, sorted, n, 0, bits, stream);   // content's sorted keys are dead
     if (err != hipSuccess) return -(int)err;
-    efdm_scatter<<<blocks_for((long)n), NT, 0, stream>>>(content, sidx, sv, lmda, out, (long)n, (unsigned)L,
+    efdm_scatter<<<blocks_for((long)n), NT, 0, stream>>>(content, sidx, sorted, lmda, out, (long)n, (unsigned)L,
                                                          rows_per_sample);
     UD_LAUNCH_CHECK();
     return 0;
