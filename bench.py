@@ -263,7 +263,10 @@ def main():
                        if (args.model, args.size, bs) == ("UDEB4", 256, 32) else
                        f"{args.model} {args.size}x{args.size} fwd + pass-1 loss + bwd, bs={bs}/GPU (informational)",
                        "global_batch": world * bs, "parallelism": f"dp{world}", "exec": exec_mode,
-                       "final_loss": float(loss.detach())},
+                       "final_loss": float(loss.detach()),
+                       # checksum of the step's result (tests: the data-parallel path at world size 1 must give
+                       # the plain step's gradients)
+                       "grad_l1": float(sum(p.grad.double().abs().sum() for p in params if p.grad is not None))},
             "roofline": {"bound": "mfma",
                          "kernel": "ud_gemm: gemm_x3_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 "
                                    "v_mfma_f32_32x32x16_bf16 per fp32 K=16 step, fp32-GEMM accuracy) for the large plain "

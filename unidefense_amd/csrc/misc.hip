@@ -29,6 +29,7 @@ __global__ __launch_bounds__(NT) void fc_fwd(const float* __restrict__ x, const 
     if (wave >= N * O) return;
     const int n = wave / O, o = wave % O;
     float acc = 0.f;
+#pragma unroll 4
     for (int i = lane; i < I; i += 64) acc += act_in_f(x[(long)n * I + i], act_in) * W[(long)o * I + i];
     acc = ud_wave_sum(acc);
     if (lane == 0) y[(long)n * O + o] = acc + (b ? b[o] : 0.f);
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(NT) void fc_bwd_x(const float* __restrict__ dy, con
     if (e >= (long)N * I) return;
     const int n = (int)(e / I), i = (int)(e % I);
     float acc = 0.f;
+#pragma unroll 8
     for (int o = 0; o < O; ++o) acc += dy[(long)n * O + o] * W[(long)o * I + i];
     if (act_in == 1) acc *= ud_swish_grad(x[e]);
     dx[e] = acc;
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(NT) void fc_bwd_w(const float* __restrict__ dy, con
     if (e >= (long)O * I) return;
     const int o = (int)(e / I), i = (int)(e % I);
     float acc = 0.f, accb = 0.f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) {
         float g = dy[(long)n * O + o];
         acc += g * act_in_f(x[(long)n * I + i], act_in);

@@ -2,9 +2,14 @@
 (reference: SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel, engine/forgery_engine.py:142-146).
 
 The path shards over the batch only.  Exchanges per backward:
-  * parameter gradients — bucketed flat all-reduce (sum / world).  The whole network is a single autograd
-    node, so the exchange is driven from inside that node's backward (model/unidefense.py:_NetFunction):
-    gradients are packed in the order backward produced them (reverse parameter order) into ~64 MB buckets.
+  * parameter gradients — bucketed flat all-reduce.  The whole network is a single autograd node, so the exchange
+    is driven from inside that node's backward (model/unidefense.py:_NetFunction): the tape hands every parameter
+    gradient to the GradReducer the moment it is final (reverse parameter order); a full ~64 MB bucket is packed
+    and its all-reduce launched ASYNCHRONOUSLY (it runs on the process group's own stream), so the exchange of
+    the deep layers' gradients overlaps the backward of the shallow ones; the backward waits for all buckets at its
+    end and returns views of the reduced flat buffers (no copy back).  The mean over ranks comes for free: the
+    incoming loss gradient is scaled by 1/world before the tape runs (everything downstream is linear in it,
+    including the SyncBN sums).
   * SyncBatchNorm statistics — one all_gather of (mean, var) per BN forward and one all_reduce of
     (sum dz, sum dz*xhat) per BN backward (tape.batchnorm_act), enabled by ``sync_bn=True``.
 No other collective exists on the data path.
@@ -14,6 +19,49 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .. import tape as T
+
+
+class GradReducer:
+    """Sums gradients over the ranks of `group`, bucket by bucket, asynchronously.
+
+    begin() -> ready(key, g) in the order gradients become final -> finish() -> {key: reduced g (a view of its
+    bucket's flat buffer)}.  Device-agnostic (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, group, bucket_bytes):
+        self.group = group
+        self.bucket_bytes = bucket_bytes
+        self.begin()
+
+    def begin(self):
+        self.bucket, self.size, self.pending, self.done = [], 0, [], set()
+
+    def ready(self, key, g):
+        self.bucket.append((key, g))
+        self.done.add(key)
+        self.size += g.numel() * g.element_size()
+        if self.size >= self.bucket_bytes:
+            self.flush()
+
+    def flush(self):
+        if not self.bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for _, g in self.bucket])
+        work = dist.all_reduce(flat, group=self.group, async_op=True)
+        self.pending.append((work, flat, self.bucket))
+        self.bucket, self.size = [], 0
+
+    def finish(self):
+        self.flush()
+        out = {}
+        for work, flat, bucket in self.pending:
+            work.wait()                      # GPU: the current stream waits for the collective's stream
+            off = 0
+            for key, g in bucket:
+                n = g.numel()
+                out[key] = flat[off:off + n].view(g.shape)
+                off += n
+        self.pending = []
+        return out
 
 
 class HipDataParallel(nn.Module):
@@ -29,8 +77,10 @@ class HipDataParallel(nn.Module):
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=process_group)
-        module._grad_sync = self.sync_grads
         self.force = T.FORCE_COLLECTIVES           # single-GPU exercise of the RCCL calls (tape.py)
+        if self.world > 1 or self.force:
+            module._grad_reducer = GradReducer(process_group, bucket_bytes)
+            module._grad_prescale = 1.0 / self.world
         if sync_bn and (self.world > 1 or self.force):
             module._sync_bn_group = process_group if process_group is not None else dist.group.WORLD
 
@@ -38,32 +88,16 @@ class HipDataParallel(nn.Module):
         return self.module(*args, **kwargs)
 
     def sync_grads(self, grads):
-        """grads: list of tensors (or None) in parameter order -> averaged over ranks (in place)."""
+        """grads: list of tensors (or None) in parameter order -> averaged over ranks (a new list; the one-shot
+        form of what _NetFunction.backward streams)."""
         if self.world == 1 and not self.force:
             return grads
-        bucket, size = [], 0
-
-        def flush():
-            nonlocal bucket, size
-            if not bucket:
-                return
-            flat = torch.cat([g.reshape(-1) for g in bucket])
-            dist.all_reduce(flat, group=self.process_group)
-            flat.mul_(1.0 / self.world)
-            off = 0
-            for g in bucket:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
-                off += n
-            bucket, size = [], 0
-
-        for g in reversed([g for g in grads if g is not None]):
-            bucket.append(g)
-            size += g.numel() * g.element_size()
-            if size >= self.bucket_bytes:
-                flush()
-        flush()
-        return grads
+        red = GradReducer(self.process_group, self.bucket_bytes)
+        for i in reversed(range(len(grads))):
+            if grads[i] is not None:
+                red.ready(i, grads[i])
+        out = red.finish()
+        return [None if g is None else out[i].mul_(1.0 / self.world) for i, g in enumerate(grads)]
 
 
 def wrap_data_parallel(model: nn.Module, local_rank: int = 0, process_group=None, sync_bn: bool = True):

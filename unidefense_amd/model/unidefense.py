@@ -122,15 +122,34 @@ class _NetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        tape, outs = ctx.tape, ctx.outs
+        tape, outs, model = ctx.tape, ctx.outs, ctx.model
+        # data parallel (engine/parallel.py): scaling the incoming gradient by 1/world turns the reducer's SUM into
+        # the mean; gradients are handed over as they become final so that their all-reduce overlaps the rest of
+        # this backward (use counts per parameter are learned on the first backward, which reduces at its end)
+        reducer = getattr(model, "_grad_reducer", None)
+        scale = getattr(model, "_grad_prescale", 1.0) if reducer is not None else 1.0
+        uses = getattr(model, "_param_uses", None)
+        if reducer is not None:
+            reducer.begin()
+            if uses is not None and not T.WGRAD_SIDE_STREAM:
+                tape.param_uses, tape.param_ready = uses, reducer.ready
         for k, g in zip(ctx.keys, gouts):
             if g is not None:
-                tape.add_grad(outs[k], g.contiguous().to(torch.float32))
+                g = g.contiguous().to(torch.float32)
+                tape.add_grad(outs[k], g if scale == 1.0 else g * scale)
         tape.backward()
         grads = [tape.param_grads.get(p) if p.requires_grad else None for p in ctx.params]
-        sync = getattr(ctx.model, "_grad_sync", None)
-        if sync is not None:                       # data parallel: average over ranks (engine/parallel.py)
-            grads = sync(grads)
+        if reducer is not None:
+            if uses is None:
+                model._param_uses = dict(tape.param_seen)
+            elif uses != tape.param_seen:
+                raise RuntimeError("data parallel: the set of parameter-gradient contributions changed between "
+                                   "backward passes; streamed buckets would hold partial gradients")
+            for p, g in zip(reversed(ctx.params), reversed(grads)):
+                if g is not None and id(p) not in reducer.done:
+                    reducer.ready(id(p), g)
+            red = reducer.finish()
+            grads = [None if g is None else red[id(p)] for p, g in zip(ctx.params, grads)]
         grads = tuple(grads)
         ctx.tape = ctx.outs = ctx.model = None
         return (None, None, None, None) + grads

@@ -44,6 +44,11 @@ class Tape:
         self.kinks = None        # parity tests: {site: ReLU output} (site = id(norm weight) or an explicit name)
         self._side = None        # second stream carrying the weight-gradient kernels of this backward
         self._side_keep = []
+        # data parallel (engine/parallel.py): param_ready(id(p), g) is called the moment p's gradient is final, i.e.
+        # after its param_uses[id(p)]-th contribution (counts learned from the first backward: param_seen)
+        self.param_ready = None
+        self.param_uses = None
+        self.param_seen = {}
 
     # -- recording -------------------------------------------------------------------------
     def record(self, fn):
@@ -68,7 +73,11 @@ class Tape:
     def add_param_grad(self, p, g: torch.Tensor):
         cur = self.param_grads.get(p)
         g = g.reshape(p.shape)
-        self.param_grads[p] = g if cur is None else K.axpby(cur, 1.0, g, 1.0)
+        g = g if cur is None else K.axpby(cur, 1.0, g, 1.0)
+        self.param_grads[p] = g
+        n = self.param_seen[id(p)] = self.param_seen.get(id(p), 0) + 1
+        if self.param_ready is not None and n == self.param_uses.get(id(p)):
+            self.param_ready(id(p), g)
 
     # -- side stream for weight gradients --------------------------------------------------
     def wgrad(self, p, fn, *inputs):
