@@ -57,6 +57,7 @@ __global__ __launch_bounds__(NT) void fc_bwd_x_wave(const float* __restrict__ dy
     if (wave >= N * I) return;
     const int n = wave / I, i = wave % I;
     float acc = 0.f;
+#pragma unroll 4
     for (int o = lane; o < O; o += 64) acc += dy[(long)n * O + o] * W[(long)o * I + i];
     acc = ud_wave_sum(acc);
     if (lane == 0) {
