@@ -85,6 +85,22 @@ def test_gemm_nt_nn_tn(M, N, K):
     check("tn", Kk.gemm_tn(at.to(dev), bt.to(dev)), at.double().t() @ bt.double())
 
 
+@pytest.mark.parametrize("kind", ["nt", "nn"])
+def test_gemm_tail_split_plan(kind):
+    """kernels._tail_plan: 36 x 15 = 540 tiles -> 34 row-tiles in one plain launch + 2 row-tiles split-K (atomic
+    accumulation into the zeroed tail rows); the assembled result must be the plain GEMM."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    M, N, K = 4608, 1920, 768
+    assert Kk._tail_plan(M, N, K) == (4352, 3)
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn((N, K) if kind == "nt" else (K, N), generator=g)
+    ref = a.double() @ (w.double().t() if kind == "nt" else w.double())
+    got = (Kk.gemm_nt if kind == "nt" else Kk.gemm_nn)(a.to(dev), w.to(dev))
+    check(f"tail-split {kind}", got, ref, 1e-5)
+
+
 @pytest.mark.parametrize("kind,M,N,K", [("nt", 1280, 3264, 3264), ("nn", 1152, 256, 256), ("tn", 672, 672, 17408),
                                         ("nt", 200, 72, 100), ("nn", 132, 68, 36), ("tn", 68, 76, 1001)])
 def test_gemm_split_bf16_path_has_fp32_accuracy(kind, M, N, K):

@@ -70,6 +70,31 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     return Cout
 
 
+_TAIL_SPLIT = os.environ.get("UD_GEMM_TAIL_SPLIT", "1") == "1"
+
+
+def _tail_plan(M, N, K):
+    """Tile quantisation: 540 tiles of 128x128 on 256 CUs take 3 rounds of which the last is 11 % full (the
+    4608x1920x1920 spectral convs: 131 instead of ~180 TFLOP/s).  Plan: the leading row-tiles that fill whole
+    rounds run as one plain launch, the few remaining row-tiles as a second, split-K launch whose blocks are 1/s as
+    long.  Returns (rows of the plain part, split) or None.  (Assumes the 128x128 configuration gemm_x3.hip picks
+    for shapes this large; a different pick only costs the gain.)"""
+    if not _TAIL_SPLIT or M < 1024 or N < 128 or K < 512:
+        return None
+    mt, nt = -(-M // 128), -(-N // 128)
+    full, tail = divmod(mt * nt, 256)
+    if full < 1 or tail == 0:
+        return None
+    rows_tail = -(-tail // nt)
+    tail_tiles = rows_tail * nt
+    if tail_tiles > 64 or rows_tail >= mt:
+        return None
+    split = min(8, 256 // tail_tiles, K // 256)
+    if split < 2:
+        return None
+    return (mt - rows_tail) * 128, split
+
+
 def gemm_nt(a, w, out=None, accumulate=False):
     """out[M,N] (+)= a[M,K] @ w[N,K]^T     (1x1 conv / linear forward)"""
     _chk(a, w)
@@ -77,6 +102,15 @@ def gemm_nt(a, w, out=None, accumulate=False):
     N = w.shape[0]
     assert w.shape[1] == K
     if out is None:
+        plan = _tail_plan(M, N, K)
+        if plan is not None:
+            m1, split = plan
+            out = empty((M, N), a)
+            _gemm(a, w, out, m1, N, K, K, K, N, 0, 0, 0)
+            tail = out[m1:]
+            tail.zero_()
+            _gemm(a[m1:], w, tail, M - m1, N, K, K, K, N, 0, 0, 2, split)
+            return out
         split = _fwd_split(M, N, K)
         if split > 1:
             out = torch.zeros((M, N), dtype=torch.float32, device=a.device)
@@ -92,6 +126,15 @@ def gemm_nn(a, w, out=None, accumulate=False):
     N = w.shape[1]
     assert w.shape[0] == K
     if out is None:
+        plan = _tail_plan(M, N, K)
+        if plan is not None:
+            m1, split = plan
+            out = empty((M, N), a)
+            _gemm(a, w, out, m1, N, K, K, N, N, 0, 1, 0)
+            tail = out[m1:]
+            tail.zero_()
+            _gemm(a[m1:], w, tail, M - m1, N, K, K, N, N, 0, 1, 2, split)
+            return out
         split = _fwd_split(M, N, K)
         if split > 1:
             out = torch.zeros((M, N), dtype=torch.float32, device=a.device)
