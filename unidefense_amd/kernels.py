@@ -155,11 +155,15 @@ def _pick_split(tiles, K):
 _TILE_CFGS = ((128, 128, 1.00), (128, 64, 0.93), (256, 32, 1.10), (32, 256, 1.10), (64, 128, 0.93))
 
 
+_FWD_SPLIT_T = int(os.environ.get("UD_FWD_SPLIT_T", "224"))      # A/B on the bench: 128/1024 -> 224/512 = -0.6 % step time
+_FWD_SPLIT_K = int(os.environ.get("UD_FWD_SPLIT_K", "512"))
+
+
 def _fwd_split(M, N, K):
     """split-K for a forward / data-gradient GEMM too small to fill the chip (e.g. the 8x8-resolution
     expand/project convs: M = 2048, 80 tiles for 256 CUs)."""
     t = _tiles(M, N)
-    if t >= 128 or K < 1024:
+    if t >= _FWD_SPLIT_T or K < _FWD_SPLIT_K:
         return 1
     return max(1, min(K // 256, -(-320 // t)))
 
