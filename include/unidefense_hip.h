@@ -112,8 +112,10 @@ int ud_bcast_rows(const float* g, float scale, float* out, int N, int HW, int C,
  * (model/efficientnet/utils.py:277-280, exp.py:49-51); pad_t/pad_l = top/left of the static ZeroPad2d. */
 int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W, int C, int Ho, int Wo,
                   int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
-int ud_dwconv_bwd_data(const float* dy, const float* wt, float* dx, int N, int H, int W, int C, int Ho,
-                       int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
+/* add (may be NULL): another contribution to the same gradient, [N][H][W][C]; dx = conv-transpose(dy) + add
+ * (the input of SFConv's spatial branch also feeds its frequency branch, exp.py:49-55) */
+int ud_dwconv_bwd_data(const float* dy, const float* wt, const float* add, float* dx, int N, int H, int W,
+                       int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
 int ud_dwconv_bwd_weight_parts(int C, int chunks);   /* rows of K*K*C floats that `part` must hold */
 /* dwt: the gradient in the PARAMETER's layout [C][K*K] (nn.Conv2d weight [C,1,K,K]), not tap-major */
 int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* part, int chunks, int N,

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NT) void dw_fwd(DwGeom q, const float* __restrict__
 
 template <int K>
 __global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const float* __restrict__ dy, const float* __restrict__ wt,
-                                                  float* __restrict__ dx) {
+                                                  const float* __restrict__ add, float* __restrict__ dx) {
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
     f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const float* __restr
                 acc += g * ww;
             }
         }
+        if (add) acc += reinterpret_cast<const f32x4*>(add)[e];
         dx4[e] = acc;
     }
 }
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(NT) void dw_fwd_strip(DwGeom q, const float* __rest
 // data gradient, stride 1: dx[h][w] = sum dy[h + pad_t - kh][w + pad_l - kw] * w[kh][kw]
 template <int K>
 __global__ __launch_bounds__(NT) void dw_bwd_data_strip(DwGeom q, const float* __restrict__ dy,
-                                                        const float* __restrict__ wt, float* __restrict__ dx) {
+                                                        const float* __restrict__ wt, const float* __restrict__ add,
+                                                        float* __restrict__ dx) {
     constexpr int NCOL = TW + K - 1;
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
@@ -180,10 +182,12 @@ __global__ __launch_bounds__(NT) void dw_bwd_data_strip(DwGeom q, const float* _
 #pragma unroll
                 for (int kw = 0; kw < K; ++kw) acc[t] += g[t - kw + K - 1] * w[kw];
         }
-        f32x4* out = dx4 + (((long)n * q.H + h) * q.W + w0) * q.C4 + c4;
+        const long o0 = (((long)n * q.H + h) * q.W + w0) * q.C4 + c4;
+        f32x4* out = dx4 + o0;
+        const f32x4* add4 = reinterpret_cast<const f32x4*>(add) + o0;
 #pragma unroll
         for (int t = 0; t < TW; ++t)
-            if (w0 + t < q.W) out[(long)t * q.C4] = acc[t];
+            if (w0 + t < q.W) out[(long)t * q.C4] = add ? acc[t] + add4[(long)t * q.C4] : acc[t];
     }
 }
 
@@ -356,8 +360,8 @@ int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W
     return 0;
 }
 
-int ud_dwconv_bwd_data(const float* dy, const float* wt, float* dx, int N, int H, int W, int C, int Ho, int Wo, int K,
-                       int stride, int pad_t, int pad_l, ud_stream_t stream) {
+int ud_dwconv_bwd_data(const float* dy, const float* wt, const float* add, float* dx, int N, int H, int W, int C, int Ho,
+                       int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream) {
     if (C % 4) return UD_EINVAL;
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!geom_ok(q, K)) return UD_EINVAL;
@@ -365,12 +369,12 @@ int ud_dwconv_bwd_data(const float* dy, const float* wt, float* dx, int N, int H
     hipStream_t s = (hipStream_t)stream;
     if (stride == 1 && !plain) {
         long total = (long)N * H * ((W + TW - 1) / TW) * q.C4;
-        if (K == 3) hipLaunchKernelGGL(dw_bwd_data_strip<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, dx);
-        else hipLaunchKernelGGL(dw_bwd_data_strip<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, dx);
+        if (K == 3) hipLaunchKernelGGL(dw_bwd_data_strip<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, add, dx);
+        else hipLaunchKernelGGL(dw_bwd_data_strip<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, add, dx);
     } else {       // stride 2 (4 of the 32 blocks): one output per thread
         long total = (long)N * H * W * q.C4;
-        if (K == 3) hipLaunchKernelGGL(dw_bwd_data<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, dx);
-        else hipLaunchKernelGGL(dw_bwd_data<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, dx);
+        if (K == 3) hipLaunchKernelGGL(dw_bwd_data<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, add, dx);
+        else hipLaunchKernelGGL(dw_bwd_data<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, add, dx);
     }
     UD_LAUNCH_CHECK();
     return 0;

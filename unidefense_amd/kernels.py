@@ -366,11 +366,13 @@ def dwconv_fwd(x, wt, K, stride, pad_t, pad_l, Ho, Wo):
     return y
 
 
-def dwconv_bwd_data(dy, wt, K, stride, pad_t, pad_l, H, W):
-    _chk(dy, wt)
+def dwconv_bwd_data(dy, wt, K, stride, pad_t, pad_l, H, W, add=None):
+    """add: another contribution to the same input gradient, summed in the store (saves an axpby pass)."""
+    _chk(dy, wt, add)
     N, Ho, Wo, Cc = dy.shape
     dx = empty((N, H, W, Cc), dy)
-    _call("ud_dwconv_bwd_data", _p(dy), _p(wt), _p(dx), N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+    assert add is None or add.shape == dx.shape
+    _call("ud_dwconv_bwd_data", _p(dy), _p(wt), _p(add), _p(dx), N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
     return dx
 
 

@@ -207,6 +207,9 @@ def linear(tape, x, w, b):
 # ---------------------------------------------------------------------------------------------
 # depthwise conv, FFT, SFConv
 # ---------------------------------------------------------------------------------------------
+_DW_FUSED_ADD = os.environ.get("UD_DW_FUSED_ADD", "1") == "1"
+
+
 def dwconv(tape, x, w, stride, pad):
     """Depthwise Conv2dStaticSamePadding (model/efficientnet/utils.py:277-280; exp.py:49-51).
     pad = (left, right, top, bottom) as in nn.ZeroPad2d."""
@@ -222,7 +225,12 @@ def dwconv(tape, x, w, stride, pad):
             dy = tape.pop_grad(y)
             if dy is None:
                 return
-            tape.add_grad(x, K.dwconv_bwd_data(dy, wt, k, stride, pt, pl, H, W))
+            # x usually has a second consumer whose gradient is already there (SFConv's frequency branch, exp.py:55;
+            # the SE pool): the data-gradient kernel adds it in its store instead of a separate axpby pass
+            cur = tape.grads.pop(id(x), None) if _DW_FUSED_ADD else None
+            if cur is not None and not (cur.is_contiguous() and cur.shape == x.shape and cur.dtype == torch.float32):
+                tape.grads[id(x)], cur = cur, None
+            tape.add_grad(x, K.dwconv_bwd_data(dy, wt, k, stride, pt, pl, H, W, add=cur))
             tape.add_param_grad(w, K.dwconv_bwd_weight(x, dy, k, stride, pt, pl))     # already [C, k*k]
         tape.record(bwd)
     return y
