@@ -227,6 +227,14 @@ int ud_copy_cols(float* narrow, float* wide, long M, int Cn, int Cw, int off, in
 int ud_aw_triplet(const float* feat, int N, int D, int n_real, float* loss, float* dfeat, float* ws,
                   ud_stream_t stream);
 
+/* ---- direct 3x3 conv for small channel counts (csrc/conv_small.hip): the image-resolution end of the decoder
+ * (model/unidefense.py:59-102: 40 -> 20 -> 3 channels at 64x64 / 128x128), its data gradients / transposed conv, and
+ * the stem conv (model/efficientnet/model.py:185).  Same operation and geometry as ud_gemm with a_mode 2:
+ * y[N][Hout][Wout][Cout] = gather-conv(x[N][Hin][Win][Cin], wmat[Cout][9*Cin]); one thread per output pixel.
+ * ud_conv_small_supported: 1 if a kernel exists for (Cin, Cout, KH, KW), else 0 (use ud_gemm). */
+int ud_conv_small_supported(int Cin, int Cout, int KH, int KW);
+int ud_conv_small(const ud_conv_geom* g, const float* x, const float* wmat, float* y, int Cout, ud_stream_t stream);
+
 /* ---- pass-2 input perturbations (model/unidefense.py:177-198), NCHW planes x[planes][H][W], no gradients --------
  * ud_gather2d      : out[p][y][x] = in[p][iy[y]][ix[x]] — downscale (model/modules.py:19-21): the two nearest
  *                    F.interpolate calls composed into one gather (index vectors from ATen's float32 rule)

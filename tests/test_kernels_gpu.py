@@ -85,6 +85,53 @@ def test_gemm_nt_nn_tn(M, N, K):
     check("tn", Kk.gemm_tn(at.to(dev), bt.to(dev)), at.double().t() @ bt.double())
 
 
+@pytest.mark.parametrize("ci,co", [(20, 20), (20, 3), (3, 20), (3, 48)])
+@pytest.mark.parametrize("geom", ["same", "stem_s2", "transposed_s2", "dgrad_of_convT"])
+def test_conv_small_direct_kernel_equals_implicit_gemm(ci, co, geom):
+    """csrc/conv_small.hip (one thread per output pixel, scalar-loaded weights) against F.conv2d / F.conv_transpose2d
+    in float64 and against the implicit-GEMM path it replaces, for every geometry the decoder / stem use."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    g_ = torch.Generator().manual_seed(ci * 100 + co)
+    n, h = 3, 80                                             # 3 * 80 * 80 = 19200 output pixels >= the dispatch threshold
+    if geom == "same":
+        x = torch.randn(n, ci, h, h, generator=g_)
+        w = torch.randn(co, ci, 3, 3, generator=g_)
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+        gm = Kk.conv_geom(n, h, h, ci, h, h, 3, 3, 1, 1, 1, 0)
+        wmat = w.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    elif geom == "stem_s2":                                  # static same padding (0,1,0,1), stride 2
+        x = torch.randn(n, ci, 2 * h, 2 * h, generator=g_)
+        w = torch.randn(co, ci, 3, 3, generator=g_)
+        ref = F.conv2d(F.pad(x.double(), [0, 1, 0, 1]), w.double(), stride=2)
+        gm = Kk.conv_geom(n, 2 * h, 2 * h, ci, h, h, 3, 3, 2, 0, 0, 0)
+        wmat = w.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    elif geom == "transposed_s2":                            # ConvTranspose2d(k3, s2, p1, op1): 40 -> 80
+        x = torch.randn(n, ci, h // 2, h // 2, generator=g_)
+        w = torch.randn(ci, co, 3, 3, generator=g_)
+        ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1, output_padding=1)
+        gm = Kk.conv_geom(n, h // 2, h // 2, ci, h, h, 3, 3, 2, 1, 1, 1)
+        wmat = w.permute(1, 2, 3, 0).reshape(co, 9 * ci)
+    else:                                                    # data gradient of that ConvTranspose2d: stride-2 conv over dY
+        x = torch.randn(n, ci, 2 * h, 2 * h, generator=g_)  # dY with `ci` channels
+        w = torch.randn(co, ci, 3, 3, generator=g_)         # ConvTranspose weight [Cin_T = co, Cout_T = ci]
+        ref = F.conv2d(x.double(), w.double(), stride=2, padding=1)
+        gm = Kk.conv_geom(n, 2 * h, 2 * h, ci, h, h, 3, 3, 2, 1, 1, 0)
+        wmat = w.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    xp, wm = to_pix(x).to(dev), wmat.contiguous().to(dev)
+    assert Kk._conv_small_supported(ci, co, 3, 3)
+    saved = Kk._CONV_SMALL, Kk._CONV_SMALL_MIN_M
+    try:
+        Kk._CONV_SMALL, Kk._CONV_SMALL_MIN_M = True, 1
+        direct = Kk.conv_gather_nt(xp, wm, gm)
+        Kk._CONV_SMALL = False
+        gemm = Kk.conv_gather_nt(xp, wm, gm)
+    finally:
+        Kk._CONV_SMALL, Kk._CONV_SMALL_MIN_M = saved
+    check(f"conv_small {geom} {ci}->{co} vs fp64", to_nchw(direct), ref, 1e-5)
+    check(f"conv_small {geom} {ci}->{co} vs implicit GEMM", direct, gemm, 1e-5)
+
+
 @pytest.mark.parametrize("kind", ["nt", "nn"])
 def test_gemm_tail_split_plan(kind):
     """kernels._tail_plan: 36 x 15 = 540 tiles -> 34 row-tiles in one plain launch + 2 row-tiles split-K (atomic

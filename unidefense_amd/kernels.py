@@ -203,6 +203,18 @@ def conv_geom(N, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_t, pad_l, transp
 _CONV_SPLITK = os.environ.get("UD_CONV_SPLITK", "1") == "1"
 
 
+_CONV_SMALL = os.environ.get("UD_CONV_SMALL", "1") == "1"
+_CONV_SMALL_MIN_M = 262144          # one thread per output pixel: below ~1 wave per SIMD x 4 the GEMM path wins
+_CONV_SMALL_OK = {}
+
+
+def _conv_small_supported(Ci, Co, KH, KW):
+    key = (Ci, Co, KH, KW)
+    if key not in _CONV_SMALL_OK:
+        _CONV_SMALL_OK[key] = _call("ud_conv_small_supported", Ci, Co, KH, KW) == 1
+    return _CONV_SMALL_OK[key]
+
+
 def conv_gather_nt(x, wmat, g):
     """Implicit-GEMM conv: rows (n,oh,ow) x k=(tap,ci) gathered from x[N,Hin,Win,Cin]; wmat[Cout, KH*KW*Cin].
     Returns [N, Hout, Wout, Cout]."""
@@ -211,6 +223,11 @@ def conv_gather_nt(x, wmat, g):
     K = g.KH * g.KW * g.Cin
     Co = wmat.shape[0]
     assert wmat.shape[1] == K and x.numel() == g.N * g.Hin * g.Win * g.Cin
+    if _CONV_SMALL and M >= _CONV_SMALL_MIN_M and _conv_small_supported(g.Cin, Co, g.KH, g.KW):
+        # few channels at image resolution (decoder tail, stem): direct conv, one thread per output pixel
+        out = empty((g.N, g.Hout, g.Wout, Co), x)
+        _call("ud_conv_small", C.byref(g), _p(x), _p(wmat), _p(out), Co, _stream())
+        return out
     # split-K for the under-filled launches (e.g. the 3x3 filter conv at 8x8: M = 2048, K = 2448 -> 80 tiles);
     # an A/B inside one gpurun call decides (UD_CONV_SPLITK=0 disables)
     split = _fwd_split(M, Co, K) if _CONV_SPLITK else 1
