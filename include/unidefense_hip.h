@@ -234,6 +234,13 @@ int ud_aw_triplet(const float* feat, int N, int D, int n_real, float* loss, floa
  * ud_conv_small_supported: 1 if a kernel exists for (Cin, Cout, KH, KW), else 0 (use ud_gemm). */
 int ud_conv_small_supported(int Cin, int Cout, int KH, int KW);
 int ud_conv_small(const ud_conv_geom* g, const float* x, const float* wmat, float* y, int Cout, ud_stream_t stream);
+/* weight gradient of the same convs (ud_gemm's b_mode 2): out[Ma][9*Cin] = sum over the rows m = (n,oh,ow) of g's
+ * output grid of a[m][Ma] (x) patch(x)[m][9*Cin].  part: ud_conv_small_wgrad_ws_floats(Cin, Ma) floats of scratch
+ * (per-workgroup partial results, summed by a second launch; deterministic, no atomics). */
+int ud_conv_small_wgrad_supported(int Cin, int Ma, int KH, int KW);
+long ud_conv_small_wgrad_ws_floats(int Cin, int Ma);
+int ud_conv_small_wgrad(const ud_conv_geom* g, const float* a, const float* x, float* part, float* out, int Ma,
+                        ud_stream_t stream);
 
 /* ---- pass-2 input perturbations (model/unidefense.py:177-198), NCHW planes x[planes][H][W], no gradients --------
  * ud_gather2d      : out[p][y][x] = in[p][iy[y]][ix[x]] — downscale (model/modules.py:19-21): the two nearest

@@ -132,6 +132,44 @@ def test_conv_small_direct_kernel_equals_implicit_gemm(ci, co, geom):
     check(f"conv_small {geom} {ci}->{co} vs implicit GEMM", direct, gemm, 1e-5)
 
 
+@pytest.mark.parametrize("ci,ma", [(20, 20), (20, 3), (3, 48), (3, 20)])
+@pytest.mark.parametrize("geom", ["same", "stem_s2", "stride2_pad1"])
+def test_conv_small_wgrad_equals_implicit_gemm(ci, ma, geom):
+    """csrc/conv_small.hip weight gradient (LDS-staged rows, 4x4 register blocks, partials + sum) against the
+    autograd weight gradient of F.conv2d in float64 and the split-K implicit GEMM it replaces; the row count is not a
+    multiple of the tile (ragged last tile and last workgroup)."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    g_ = torch.Generator().manual_seed(ci * 100 + ma + 7)
+    n, h = 3, 37
+    if geom == "same":
+        hin, stride, pt, pads = h, 1, 1, [1, 1, 1, 1]
+    elif geom == "stem_s2":
+        hin, stride, pt, pads = 2 * h, 2, 0, [0, 1, 0, 1]
+    else:
+        hin, stride, pt, pads = 2 * h, 2, 1, [1, 1, 1, 1]
+    x = torch.randn(n, ci, hin, hin, generator=g_, dtype=torch.float64)
+    w = torch.zeros(ma, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(n, ma, h, h, generator=g_, dtype=torch.float64)
+    y = F.conv2d(F.pad(x, pads), w, stride=stride)
+    assert y.shape == dy.shape
+    (ref,) = torch.autograd.grad(y, w, dy)                                  # [ma, ci, 3, 3]
+    ref = ref.permute(0, 2, 3, 1).reshape(ma, 9 * ci)
+    gm = Kk.conv_geom(n, hin, hin, ci, h, h, 3, 3, stride, pt, pt, 0)
+    a = to_pix(dy.float()).reshape(-1, ma).to(dev)
+    xp = to_pix(x.float()).to(dev)
+    saved = Kk._CONV_SMALL, Kk._CONV_SMALL_MIN_M
+    try:
+        Kk._CONV_SMALL, Kk._CONV_SMALL_MIN_M = True, 1
+        direct = Kk.conv_gather_wgrad(a, xp, gm)
+        Kk._CONV_SMALL = False
+        gemm = Kk.conv_gather_wgrad(a, xp, gm)
+    finally:
+        Kk._CONV_SMALL, Kk._CONV_SMALL_MIN_M = saved
+    check(f"conv_small wgrad {geom} {ci}x{ma} vs fp64", direct, ref, 1e-5)
+    check(f"conv_small wgrad {geom} {ci}x{ma} vs implicit GEMM", direct, gemm, 1e-5)
+
+
 @pytest.mark.parametrize("kind", ["nt", "nn"])
 def test_gemm_tail_split_plan(kind):
     """kernels._tail_plan: 36 x 15 = 540 tiles -> 34 row-tiles in one plain launch + 2 row-tiles split-K (atomic

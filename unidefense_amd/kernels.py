@@ -215,6 +215,17 @@ def _conv_small_supported(Ci, Co, KH, KW):
     return _CONV_SMALL_OK[key]
 
 
+_CONV_SMALL_WS = {}
+_CONV_SMALL_WGRAD_OK = {}
+
+
+def _conv_small_wgrad_supported(Ci, Ma, KH, KW):
+    key = (Ci, Ma, KH, KW)
+    if key not in _CONV_SMALL_WGRAD_OK:
+        _CONV_SMALL_WGRAD_OK[key] = _call("ud_conv_small_wgrad_supported", Ci, Ma, KH, KW) == 1
+    return _CONV_SMALL_WGRAD_OK[key]
+
+
 def conv_gather_nt(x, wmat, g):
     """Implicit-GEMM conv: rows (n,oh,ow) x k=(tap,ci) gathered from x[N,Hin,Win,Cin]; wmat[Cout, KH*KW*Cin].
     Returns [N, Hout, Wout, Cout]."""
@@ -247,6 +258,15 @@ def conv_gather_wgrad(a, x, g):
     Ma = a.shape[-1]
     assert a.numel() == Kdim * Ma
     Ncols = g.KH * g.KW * g.Cin
+    if _CONV_SMALL and Kdim >= _CONV_SMALL_MIN_M and _conv_small_wgrad_supported(g.Cin, Ma, g.KH, g.KW):
+        # a 20 x 180 (3 x 180, 48 x 27) result reduced over 524 288 rows: streamed through LDS, register-blocked
+        need = _call("ud_conv_small_wgrad_ws_floats", g.Cin, Ma)
+        ws = _CONV_SMALL_WS.get(a.device.index)
+        if ws is None or ws.numel() < need:
+            ws = _CONV_SMALL_WS[a.device.index] = empty((need,), a)
+        out = empty((Ma, Ncols), a)
+        _call("ud_conv_small_wgrad", C.byref(g), _p(a), _p(x), _p(ws), _p(out), Ma, _stream())
+        return out
     split = _pick_split(_tiles(Ma, Ncols), Kdim)
     if split > 1:
         out = torch.zeros((Ma, Ncols), dtype=torch.float32, device=a.device)

@@ -83,6 +83,9 @@ _SIGNATURES = {
     "ud_aw_triplet": [_P, _I, _I, _I, _P, _P, _P, _P],
     "ud_conv_small_supported": [_I, _I, _I, _I],
     "ud_conv_small": [C.POINTER(ConvGeom), _P, _P, _P, _I, _P],
+    "ud_conv_small_wgrad_supported": [_I, _I, _I, _I],
+    "ud_conv_small_wgrad_ws_floats": [_I, _I],
+    "ud_conv_small_wgrad": [C.POINTER(ConvGeom), _P, _P, _P, _P, _I, _P],
     "ud_gather2d": [_P, _P, _P, _P, _L, _I, _I, _P],
     "ud_blur5_reflect": [_P, _P, _L, _I, _I, _F, _F, _F, _P],
     "ud_amp_mix": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
@@ -94,8 +97,9 @@ _SIGNATURES = {
 
 # helpers that return a count rather than a status code
 _COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
-                "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported"}
-_LONG_FUNCS = {"ud_efdm_ws_bytes"}        # return a C long
+                "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
+                "ud_conv_small_wgrad_ws_floats"}
+_LONG_FUNCS = {"ud_efdm_ws_bytes", "ud_conv_small_wgrad_ws_floats"}        # return a C long
 
 EXPORTED = tuple(_SIGNATURES)
 
