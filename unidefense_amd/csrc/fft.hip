@@ -236,14 +236,38 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y,
     const int ch = blockIdx.x * CB + c;
     const bool cok = ch < C;
     float re[S], im[S];
-    // ---- pass 1: inverse transform along ky for each kept column kx
-    if (q <= S / 2) {
-        const float f = (q == 0 || q == S / 2) ? 1.f : w_int;
+    // ---- pass 1: inverse transform along ky for each kept column kx.  Only S/2+1 of the S thread-rows own a column;
+    // the others would idle while the column owners issue 2S dependent-latency loads each.  So thread-row
+    // q > S/2 fetches the IMAGINARY halves for column q - (S/2+1) and hands them over through LDS (the slot the
+    // owner overwrites with its own result afterwards): every thread issues S loads, twice the bytes in flight.
+    constexpr int NHELP = S - (S / 2 + 1);               // columns [0, NHELP) have a helper row
+    if (q > S / 2 && q < S) {
+        const int kx = q - (S / 2 + 1);
+        const float* src = Y + (((long)n * S) * L::WH + kx) * (2L * C) + ch + C;
+#pragma unroll
+        for (int ky = 0; ky < S; ++ky) re[ky] = cok ? src[(long)ky * L::WH * 2 * C] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < S; ++ky) Lim[kx * L::KSTRIDE + ky * CB + c] = re[ky];
+    } else if (q <= S / 2) {
         const float* src = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
 #pragma unroll
-        for (int ky = 0; ky < S; ++ky) {
-            re[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C] * f : 0.f;
-            im[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C + C] * f : 0.f;
+        for (int ky = 0; ky < S; ++ky) re[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C] : 0.f;
+        if (q >= NHELP) {
+#pragma unroll
+            for (int ky = 0; ky < S; ++ky) im[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C + C] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (q <= S / 2) {
+        const float f = (q == 0 || q == S / 2) ? 1.f : w_int;
+        if (q < NHELP) {
+#pragma unroll
+            for (int ky = 0; ky < S; ++ky) im[brev<S>(ky)] = Lim[q * L::KSTRIDE + ky * CB + c];
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            re[k] *= f;
+            im[k] *= f;
         }
         fft_inreg<S, true>(re, im);
 #pragma unroll
