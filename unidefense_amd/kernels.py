@@ -43,6 +43,37 @@ def empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+# Zero-initialised outputs of the split-K launches (atomic accumulation): ~180 per step, each a 5 us fill launch of
+# its own.  They are carved instead from a few large zero blocks (one fill per 32 MB); a block is never reused, so
+# every carve is still zero.  reset_zero_pool() at the start of a forward / backward makes a step captured into a
+# hipGraph contain the fills of every block it carves from.
+_ZERO_POOL_ON = os.environ.get("UD_ZERO_POOL", "1") == "1"
+_ZERO_BLOCK = 8 << 20            # floats per block (32 MB)
+_ZERO_OWN = 2 << 20              # tensors of at least this many floats get their own torch.zeros
+_ZERO_POOL = {}
+
+
+def reset_zero_pool():
+    _ZERO_POOL.clear()
+
+
+def zeros(shape, like):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if not _ZERO_POOL_ON or n >= _ZERO_OWN or n == 0:
+        return torch.zeros(shape, dtype=torch.float32, device=like.device)
+    key = like.device.index
+    st = _ZERO_POOL.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    # a block filled outside a capture must not serve carves inside one (the replay would not re-zero it), nor vice versa
+    if st is None or st[1] + n > _ZERO_BLOCK or st[2] != capturing:
+        st = _ZERO_POOL[key] = [torch.zeros(_ZERO_BLOCK, dtype=torch.float32, device=like.device), 0, capturing]
+    out = st[0][st[1]:st[1] + n].view(shape)
+    st[1] += (n + 63) // 64 * 64
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # GEMM family
 # ---------------------------------------------------------------------------------------------
@@ -113,7 +144,7 @@ def gemm_nt(a, w, out=None, accumulate=False):
             return out
         split = _fwd_split(M, N, K)
         if split > 1:
-            out = torch.zeros((M, N), dtype=torch.float32, device=a.device)
+            out = zeros((M, N), a)
             return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 2, split)
         out = empty((M, N), a)
     return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 1 if accumulate else 0)
@@ -137,7 +168,7 @@ def gemm_nn(a, w, out=None, accumulate=False):
             return out
         split = _fwd_split(M, N, K)
         if split > 1:
-            out = torch.zeros((M, N), dtype=torch.float32, device=a.device)
+            out = zeros((M, N), a)
             return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 2, split)
         out = empty((M, N), a)
     return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if accumulate else 0)
@@ -187,7 +218,7 @@ def gemm_tn(a, b):
     assert b.shape[0] == K
     split = _pick_split(_tiles(M, N), K)
     if split > 1:
-        out = torch.zeros((M, N), dtype=torch.float32, device=a.device)
+        out = zeros((M, N), a)
         return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 2, split)
     out = empty((M, N), a)
     return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 0, 1)
@@ -243,7 +274,7 @@ def conv_gather_nt(x, wmat, g):
     # an A/B inside one gpurun call decides (UD_CONV_SPLITK=0 disables)
     split = _fwd_split(M, Co, K) if _CONV_SPLITK else 1
     if split > 1:
-        out = torch.zeros((g.N, g.Hout, g.Wout, Co), dtype=torch.float32, device=x.device)
+        out = zeros((g.N, g.Hout, g.Wout, Co), x)
         _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, 2, split, geom=g)
         return out
     out = empty((g.N, g.Hout, g.Wout, Co), x)
@@ -269,7 +300,7 @@ def conv_gather_wgrad(a, x, g):
         return out
     split = _pick_split(_tiles(Ma, Ncols), Kdim)
     if split > 1:
-        out = torch.zeros((Ma, Ncols), dtype=torch.float32, device=a.device)
+        out = zeros((Ma, Ncols), a)
         return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2, split, geom=g)
     out = empty((Ma, Ncols), a)
     return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 0, 1, geom=g)

@@ -102,6 +102,7 @@ _OUT_KEYS = ("cls_out", "rec", "factorization", "triplet0", "triplet1", "triplet
 class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, noise_x, rng, *params):
+        K.reset_zero_pool()          # a (possibly graph-captured) step zero-fills every block it carves outputs from
         tape = T.Tape()
         debug = getattr(model, "_debug_watch", False)
         if debug:
@@ -123,6 +124,7 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         tape, outs, model = ctx.tape, ctx.outs, ctx.model
+        K.reset_zero_pool()
         # data parallel (engine/parallel.py): scaling the incoming gradient by 1/world turns the reducer's SUM into
         # the mean; gradients are handed over as they become final so that their all-reduce overlaps the rest of
         # this backward (use counts per parameter are learned on the first backward, which reduces at its end)
