@@ -1,0 +1,129 @@
+"""GPU, BASELINE.json's FULL size (UDEB4, bs 32, 256x256 — the bench workload): the oracle cannot run this in
+seconds, so the HIP path is held to size-independent properties of the reference's step instead.
+
+  1. sample independence (eval mode, running statistics): the bs-32 forward equals the concatenation of two bs-16
+     forwards — no kernel leaks data across samples at the full grid sizes (tile tails, split-K, tail-split plans);
+  2. gradient linearity: backward of 2*loss gives 2*gradients (every kernel of the backward is linear in dy);
+  3. replay determinism: the same step with the same injected masks twice -> equal loss, gradients equal up to the
+     summation order of the split-K atomics;
+  4. rfft2 -> irfft2 (norm='ortho') is the identity on the SFConv activations' shapes at bs 32, and Parseval holds
+     with the half-spectrum weights (exp.py:55,60);
+  5. train-mode BatchNorm over the full batch equals the statistics of the concatenated half batches combined the
+     SyncBN way (tape.sync_batch_stats formula) — what the 8-GPU run relies on.
+"""
+import pytest
+import torch
+
+from oracle import param_fill
+from tests import oracle_util as ou
+
+pytestmark = pytest.mark.gpu
+N, SIZE = 32, 256
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _model(dev, drop=0.0):
+    from unidefense_amd.model import load_model
+    m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=drop, drop_connect_rate=0.0)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev)
+    m._dec_dropout = False
+    return m
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def _loss(out, tgt):
+    from unidefense_amd.loss import LOSSES
+    from tests.test_model_gpu import _pass1_loss
+    LOSSES["aw_triplet"].n_real = None
+    return _pass1_loss(out, tgt, dict(ou.LAMBDAS))["total_loss"]
+
+
+def test_samples_are_independent_in_eval_mode():
+    dev = _dev()
+    m = _model(dev).eval()
+    x = param_fill.make_input(N, SIZE, seed=91).to(dev)
+    with torch.no_grad():
+        full = m(x)
+        a, b = m(x[:16].contiguous()), m(x[16:].contiguous())
+    for k in ("cls_out", "rec"):
+        e = _rel(full[k], torch.cat([a[k], b[k]], 0))
+        print(f"  {k}: {e:.2e}")
+        assert e <= 3e-4, (k, e)        # different batch -> different split-K / tile plans -> different rounding; a leak is O(1)
+    for k in ("spatial", "freq", "freq_mask", "spat_mask", "factorization"):
+        e = _rel(full["loss_dict"][k], torch.cat([a["loss_dict"][k], b["loss_dict"][k]], 0))
+        print(f"  {k}: {e:.2e}")
+        assert e <= 3e-4, (k, e)        # different batch -> different split-K / tile plans -> different rounding; a leak is O(1)
+
+
+def test_backward_is_linear_and_replay_is_deterministic():
+    dev = _dev()
+    m = _model(dev).train()
+    x = param_fill.make_input(N, SIZE, seed=92).to(dev)
+    tgt = param_fill.make_labels(N).to(dev)
+    named = [(k, p) for k, p in m.named_parameters() if p.requires_grad]
+    params = [p for _, p in named]
+
+    def run(scale):
+        for p in params:
+            p.grad = None
+        loss = _loss(m(x), tgt)
+        (loss * scale).backward()
+        return loss.detach().clone(), [p.grad.detach().clone() for p in params]
+
+    l1, g1 = run(1.0)
+    l1b, g1b = run(1.0)
+    l2, g2 = run(2.0)
+    assert abs(l1.item() - l1b.item()) <= 1e-6 * abs(l1.item()) and abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
+    # Some parameters have a TRUE gradient of (nearly) zero — the bias of a BatchNorm whose output only reaches other
+    # batch-statistics norms: what the step returns for them is rounding noise, different on every run.  Errors are
+    # therefore measured against max|g_tensor| + 3e-3 * (largest gradient entry of the whole model).
+    gmax = max(g.abs().max().item() for g in g1)
+    det, lin = [], []
+    for (name, _), a, ab, a2 in zip(named, g1, g1b, g2):
+        scale = a.abs().max().item() + 3e-3 * gmax
+        det.append(((a - ab).abs().max().item() / scale, name))
+        lin.append(((a2 - 2.0 * a).abs().max().item() / (2 * scale), name))
+    print(f"  {len(det)} tensors: replay worst {max(det)[0]:.2e} ({max(det)[1]}), "
+          f"2x loss vs 2x gradients worst {max(lin)[0]:.2e} ({max(lin)[1]})")
+    assert max(det)[0] <= 1e-3 and max(lin)[0] <= 1e-3      # typical 1e-6
+
+
+@pytest.mark.parametrize("S,C", [(64, 192), (32, 336), (16, 960), (8, 1632)])
+def test_rfft2_irfft2_round_trip_full_batch(S, C):
+    dev = _dev()
+    from unidefense_amd import kernels as K
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(N, S, S, C, generator=g).to(dev)
+    y = K.rfft2(x, 1.0 / S)                       # ortho: 1/sqrt(S*S)
+    back = K.irfft2(y, 1.0 / S)
+    e = _rel(back, x)
+    # Parseval with the half-spectrum weights: interior columns count twice
+    w = torch.full((S // 2 + 1,), 2.0, device=dev)
+    w[0] = w[-1] = 1.0
+    re, im = y[..., :C], y[..., C:]
+    energy = ((re.double() ** 2 + im.double() ** 2) * w.view(1, 1, -1, 1).double()).sum()
+    p = abs(energy.item() / (x.double() ** 2).sum().item() - 1.0)
+    print(f"  S={S} C={C}: round trip {e:.2e}, Parseval {p:.2e}")
+    assert e <= 2e-6 and p <= 1e-6
+
+
+def test_full_batch_bn_equals_syncbn_combination_of_halves():
+    dev = _dev()
+    from unidefense_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(N * 64 * 64, 192, generator=g) * 2 + 0.5).to(dev)
+    mean, invstd = K.norm_stats(x, 1, x.shape[0], 1e-3)
+    half = x.shape[0] // 2
+    mv = torch.stack([K.norm_stats_local(x[:half].contiguous(), 1, half, 1e-3).view(2, -1),
+                      K.norm_stats_local(x[half:].contiguous(), 1, half, 1e-3).view(2, -1)])      # [world, 2, C]
+    m2, i2 = K.syncbn_combine(mv.contiguous(), 2, 192, half, 1e-3, 0.0, None, None)
+    assert _rel(m2.view(-1), mean.view(-1)) <= 1e-6 and _rel(i2.view(-1), invstd.view(-1)) <= 1e-6
