@@ -48,7 +48,7 @@ def empty(shape, like):
 # every carve is still zero.  reset_zero_pool() at the start of a forward / backward makes a step captured into a
 # hipGraph contain the fills of every block it carves from.
 _ZERO_POOL_ON = os.environ.get("UD_ZERO_POOL", "1") == "1"
-_ZERO_BLOCK = 8 << 20            # floats per block (32 MB)
+_ZERO_BLOCK = int(os.environ.get("UD_ZERO_BLOCK", str(8 << 20)))            # floats per block (32 MB)
 _ZERO_OWN = 2 << 20              # tensors of at least this many floats get their own torch.zeros
 _ZERO_POOL = {}
 
