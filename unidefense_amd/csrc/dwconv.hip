@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const float* __restr
 // A row of the window is loaded once ((TW-1)*S + K float4) and serves all TW outputs, the K taps of the row are
 // loaded once per thread: (TW-1)*S+K + K loads per TW*K multiply-adds instead of 2 per multiply-add.  The plain
 // kernels above issue K*K (9 / 25) 16-byte loads per output and sit at ~30 % of their HBM roofline (L1-bound).
-constexpr int TW = 4;
+constexpr int TW = 8;
 
 template <int K, int S>
 __global__ __launch_bounds__(NT) void dw_fwd_strip(DwGeom q, const float* __restrict__ x, const float* __restrict__ wt,
