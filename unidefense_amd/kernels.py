@@ -174,12 +174,17 @@ def gemm_nn(a, w, out=None, accumulate=False):
     return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if accumulate else 0)
 
 
+_WG_SPLIT_MAXT = int(os.environ.get("UD_WG_SPLIT_MAXT", "512"))
+_WG_SPLIT_TARGET = int(os.environ.get("UD_WG_SPLIT_TARGET", "768"))
+_WG_SPLIT_ROWS = int(os.environ.get("UD_WG_SPLIT_ROWS", "256"))
+
+
 def _pick_split(tiles, K):
     """split-K factor for a weight-gradient GEMM whose reduction runs over K pixels: enough workgroups to
     fill 256 CUs about three times over, at least 256 reduction rows per split."""
-    if tiles >= 512 or K < 512:
+    if tiles >= _WG_SPLIT_MAXT or K < 512:
         return 1
-    s = min(max(1, K // 256), -(-768 // tiles))
+    s = min(max(1, K // _WG_SPLIT_ROWS), -(-_WG_SPLIT_TARGET // tiles))
     return max(1, min(s, 1024))
 
 
