@@ -117,6 +117,10 @@ int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W
 int ud_dwconv_bwd_data(const float* dy, const float* wt, const float* add, float* dx, int N, int H, int W,
                        int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
 int ud_dwconv_bwd_weight_parts(int C, int chunks);   /* rows of K*K*C floats that `part` must hold */
+/* every depthwise weight of the network to the tap-major layout in one launch.  table: layers x 4 int64 in DEVICE
+ * memory (source pointer [C][K*K], C, K*K, destination offset in floats); dst[off + tap*C + c] = src[c*K*K + tap];
+ * max_elems = the largest C*K*K */
+int ud_dw_weights_tapmajor(const void* table, int layers, long max_elems, float* dst, ud_stream_t stream);
 /* dwt: the gradient in the PARAMETER's layout [C][K*K] (nn.Conv2d weight [C,1,K,K]), not tap-major */
 int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* part, int chunks, int N,
                          int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l,

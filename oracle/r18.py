@@ -79,7 +79,7 @@ def extractor(x: Tensor, sd, training: bool, norm, pins=None):
     return p3, torch.cat([F.adaptive_avg_pool2d(p1, size), F.adaptive_avg_pool2d(p2, size), p3], dim=1)
 
 
-def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 2e-5) -> Tensor:
+def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 1e-4) -> Tensor:
     """F.max_pool2d(z, 3, 2, 1) with the winner of every window pinned to `sel` ([N,C,Ho,Wo], value kh*3+kw).
     A 3x3 max over ~2.6e5 windows always holds a few top-2 gaps near 1e-6, which two correct fp32
     evaluations resolve differently; pinning the selection (after checking that every pinned winner IS a maximum
@@ -89,7 +89,9 @@ def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 2e-5) -> Tensor
     valid = F.unfold(torch.ones(1, 1, h, w, dtype=z.dtype), 3, padding=1, stride=2).view(1, 1, 9, -1) > 0
     u = torch.where(valid, u, torch.full_like(u, -1e30))
     y = u.gather(2, sel.reshape(n, c, 1, -1).long()).squeeze(2)
-    # relative to the activations' scale: after ~50 layers the fp32 path's values carry ~1e-5 relative error
+    # relative to the activations' scale: after ~50 layers the fp32 path's values carry ~1e-5 relative error (observed
+    # 1e-5 .. 2e-5 of max|z| on the UDR50 embedder pool, depending on the summation order of the kernels before it);
+    # same near-tie tolerance as relu_site
     worst = (u.max(2).values - y).max().item() / max(z.detach().abs().max().item(), 1e-30)
     assert worst <= tie_tol, f"pinned max-pool selection is not an arg-max (off by {worst:.3e} of max|z|)"
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1

@@ -189,7 +189,7 @@ def test_r18_vs_reference_golden_and_oracle(golden_dir):
     out = m(x.to(dev), rng=rng)
     _check_outputs(out, g, "train_", 1e-3)
     # the 3x3 max-pool of emb_block1 has top-2 gaps down to ~1e-6 in every batch: pin the oracle's winners to
-    # the HIP path's (the oracle asserts each pinned winner is a maximum within 2e-5) so that the gradients
+    # the HIP path's (the oracle asserts each pinned winner is a maximum within 1e-4 of max|z|) so that the gradients
     # are compared on the same branch; the float32 CPU run keeps its own arg-max and shows the effect of a flip
     sel = m._debug_feats["pool_sel"].permute(0, 3, 1, 2).cpu()
     # ... and likewise the on/off pattern of every ReLU (oracle/r18.py:relu_site checks that the pattern departs

@@ -136,7 +136,7 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
     out = m(x.to(dev), rng=rng)
     _check_outputs(out, g, "train_", 1e-3)
     # the two 3x3 max-pools (stem, emb_block1) have top-2 gaps down to ~1e-6 in every batch: pin the oracle's winners to
-    # the HIP path's (the oracle asserts each pinned winner is a maximum within 2e-5) so that the gradients
+    # the HIP path's (the oracle asserts each pinned winner is a maximum within 1e-4 of max|z|) so that the gradients
     # are compared on the same branch; the float32 CPU run keeps its own arg-max and shows the effect of a flip
     sel = {"stem": m._debug_feats["pool_sel_stem"].permute(0, 3, 1, 2).cpu(),
            "emb": m._debug_feats["pool_sel_emb"].permute(0, 3, 1, 2).cpu()}

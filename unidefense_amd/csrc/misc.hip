@@ -534,6 +534,19 @@ __global__ __launch_bounds__(NT) void dynfilter_bwd(int M, int C, int Cx, const 
     for (int c = lane; c < C; c += 64) dproj[(long)m * C + c] = gm + ((c == am) ? gx : 0.f);
 }
 
+// All depthwise weights of the network to tap-major in ONE launch: table[l] = (src pointer, C, KK, dst offset);
+// dst[off + tap*C + c] = src[c*KK + tap]   (the [C,1,k,k] parameter -> wt[k*k][C] of the dw kernels).  Replaces 32
+// per-layer transpose copies per step.
+struct DwWtEntry { const float* src; long C, KK, dst_off; };
+__global__ __launch_bounds__(NT) void dw_wt_tapmajor(const DwWtEntry* __restrict__ tab, float* __restrict__ dst) {
+    const DwWtEntry e = tab[blockIdx.y];
+    const long n = e.C * e.KK;
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const long tap = i / e.C, c = i - tap * e.C;
+    dst[e.dst_off + i] = e.src[c * e.KK + tap];
+}
+
 }  // namespace
 
 extern "C" {
@@ -742,6 +755,15 @@ int ud_dynfilter_bwd(const float* dout, const float* dmask_ext, const float* x, 
                      ud_stream_t stream) {
     hipLaunchKernelGGL(dynfilter_bwd, dim3(ud_cdiv((long)M * 64, NT)), dim3(NT), 0, (hipStream_t)stream, M, C, Cx, dout,
                        dmask_ext, x, mask, argmax, w2, dx, dlogit, dproj);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+// table: layers x 4 int64 on the DEVICE (source pointer, C, K*K, destination offset in floats)
+int ud_dw_weights_tapmajor(const void* table, int layers, long max_elems, float* dst, ud_stream_t stream) {
+    if (layers < 1 || max_elems < 1 || !table || !dst) return UD_EINVAL;
+    hipLaunchKernelGGL(dw_wt_tapmajor, dim3((unsigned)ud_cdiv(max_elems, NT), (unsigned)layers), dim3(NT), 0,
+                       (hipStream_t)stream, reinterpret_cast<const DwWtEntry*>(table), dst);
     UD_LAUNCH_CHECK();
     return 0;
 }

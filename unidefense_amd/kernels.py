@@ -439,6 +439,31 @@ def dwconv_fwd(x, wt, K, stride, pad_t, pad_l, Ho, Wo):
     return y
 
 
+_DW_WT_TABLES = {}
+
+
+def dw_weights_tapmajor(weights):
+    """[C,1,k,k] depthwise parameters -> {id(w): wt[k*k][C]} (views of one flat buffer), one launch for all of them.
+    The pointer table lives on the device and is rebuilt only when a parameter's storage moved."""
+    if not weights:
+        return {}
+    _chk(*weights)
+    key = tuple(w.data_ptr() for w in weights)
+    ent = _DW_WT_TABLES.get(id(weights[0]))
+    if ent is None or ent[0] != key:
+        rows, off = [], 0
+        for w in weights:
+            Cc, kk = w.shape[0], w.shape[-1] * w.shape[-2]
+            rows.append([w.data_ptr(), Cc, kk, off])
+            off += (Cc * kk + 63) // 64 * 64
+        table = torch.tensor(rows, dtype=torch.int64).to(weights[0].device)
+        ent = _DW_WT_TABLES[id(weights[0])] = (key, table, rows, off, max(r[1] * r[2] for r in rows))
+    _, table, rows, total, max_elems = ent
+    flat = empty((total,), weights[0])
+    _call("ud_dw_weights_tapmajor", _p(table), len(rows), max_elems, _p(flat), _stream())
+    return {id(w): flat[r[3]:r[3] + r[1] * r[2]].view(r[2], r[1]) for w, r in zip(weights, rows)}
+
+
 def dwconv_bwd_data(dy, wt, K, stride, pad_t, pad_l, H, W, add=None):
     """add: another contribution to the same input gradient, summed in the store (saves an axpby pass)."""
     _chk(dy, wt, add)

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "ud_group_coldot": [_P, _P, _I, _I, _I, _F, _P, _P, _P],
     "ud_dwconv_fwd": [_P, _P, _P] + [_I] * 10 + [_P],
     "ud_dwconv_bwd_data": [_P, _P, _P, _P] + [_I] * 10 + [_P],
+    "ud_dw_weights_tapmajor": [_P, _I, _L, _P, _P],
     "ud_dwconv_bwd_weight_parts": [_I, _I],
     "ud_dwconv_bwd_weight": [_P, _P, _P, _P, _I] + [_I] * 10 + [_P],
     "ud_rfft2": [_P, _P, _I, _I, _I, _F, _F, _P],

@@ -6,6 +6,7 @@ CONTAINERS (they give the reference's key names, shapes and default initialisers
 never called — all compute goes through ``unidefense_amd.tape`` operators, i.e. the hand-written HIP kernels.
 Internally every activation is pixel-major [N,H,W,C]; the public tensors keep the reference's NCHW shapes.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -97,6 +98,9 @@ def _decoder(cin, cout, affine, bias, last):
 # ---------------------------------------------------------------------------------------------
 _OUT_KEYS = ("cls_out", "rec", "factorization", "triplet0", "triplet1", "triplet2", "freq_mask", "spat_mask",
              "spatial", "freq")
+
+
+_DW_WT_BATCH = os.environ.get("UD_DW_WT_BATCH", "1") == "1"
 
 
 class _NetFunction(torch.autograd.Function):
@@ -401,6 +405,10 @@ class UniDefenseModelEb4(nn.Module):
         Ho = (H + pt + pb - 3) // 2 + 1
         Wo = (W + pl + pr - 3) // 2 + 1
         rng = self._prepare_rng(rng, N, x.device)
+        if _DW_WT_BATCH:
+            ws = [blk._depthwise_conv.weight for blk in bb._blocks]
+            wts = K.dw_weights_tapmajor(ws)
+            T.DW_WT = {id(w): (w, w._version, wts[id(w)]) for w in ws}
 
         x_pix = K.planes_to_pix(x if noise_x is None else noise_x)       # [N,H,W,3]
         h = T.conv_dense(tape, x_pix, bb._conv_stem.weight, 2, pt, pl, Ho, Wo, need_dx=False)

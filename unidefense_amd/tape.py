@@ -208,6 +208,7 @@ def linear(tape, x, w, b):
 # depthwise conv, FFT, SFConv
 # ---------------------------------------------------------------------------------------------
 _DW_FUSED_ADD = os.environ.get("UD_DW_FUSED_ADD", "1") == "1"
+DW_WT = {}            # {id(w): (w, w._version, tap-major wt)} for the forward in flight (kernels.dw_weights_tapmajor)
 
 
 def dwconv(tape, x, w, stride, pad):
@@ -218,7 +219,11 @@ def dwconv(tape, x, w, stride, pad):
     pl, pr, pt, pb = pad
     Ho = (H + pt + pb - k) // stride + 1
     Wo = (W + pl + pr - k) // stride + 1
-    wt = w.view(Cc, k * k).t().contiguous()
+    ent = DW_WT.get(id(w))                      # tap-major copy made for all layers at once (model._run), if any
+    if ent is not None and ent[0] is w and ent[1] == w._version:
+        wt = ent[2]
+    else:
+        wt = w.view(Cc, k * k).t().contiguous()
     y = K.dwconv_fwd(x, wt, k, stride, pt, pl, Ho, Wo)
     if _needs(tape):
         def bwd():
