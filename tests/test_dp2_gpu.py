@@ -1,0 +1,137 @@
+"""GPU, TWO ranks on ONE device: the data-parallel semantics of the full HIP model at world size 2.
+
+The 1-GPU box cannot run RCCL with two ranks (NCCL refuses two ranks on one device), but the gloo backend moves CUDA
+tensors through the host — slow, and exactly the same torch.distributed calls the RCCL path issues (broadcast,
+all_gather_into_tensor, all_reduce incl. async_op).  So two processes, both on cuda:0, each with HALF of a batch,
+wrapped in HipDataParallel (SyncBN + streamed gradient buckets), must reproduce what ONE process computes on the
+whole batch with plain BatchNorm:
+    * SyncBN statistics over both shards == full-batch statistics  -> same forward outputs per sample;
+    * mean of the ranks' gradients of their local mean-losses == gradient of the full-batch mean loss.
+The loss leaves the AW-triplet terms out (pairwise over the batch: not decomposable over ranks — the reference's DDP run
+has the same property) and orders each shard [real; fake] like the reference's two samplers (forgery_engine.py:67-86).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+N_RANK, SIZE = 4, 256
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(dev):
+    from oracle import param_fill
+    from unidefense_amd.model import load_model
+    m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.0, drop_connect_rate=0.0)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev).train()
+    m._dec_dropout = False
+    return m
+
+
+def _loss(out, tgt):
+    from tests import oracle_util as ou
+    lam = dict(ou.LAMBDAS)
+    ld = out["loss_dict"]
+    n_real = tgt.numel() // 2
+    cls = torch.nn.functional.cross_entropy(out["cls_out"], tgt)
+    return cls + lam["lambda_mask"] * (ld["freq_mask"].mean() + ld["spat_mask"].mean()) + \
+        lam["lambda_recons"] * ld["spatial"].narrow(0, 0, n_real).mean() + \
+        lam["lambda_freq"] * ld["freq"].narrow(0, 0, n_real).mean()
+
+
+def _digest(g):
+    """What travels between processes for a gradient: its first 4096 entries, its L2 norm and its max."""
+    g = g.detach()
+    return g.reshape(-1)[:4096].cpu().numpy(), g.double().norm().item(), g.abs().max().item()     # numpy: pickled by value
+
+
+def _shards():
+    """Two [real, real, fake, fake] shards and the equivalent full batch [4 real; 4 fake]."""
+    from oracle import param_fill
+    x = param_fill.make_input(2 * N_RANK, SIZE, seed=123)                 # rows 0-3 real, 4-7 fake
+    h = N_RANK // 2
+    idx = [list(range(r * h, (r + 1) * h)) + list(range(N_RANK + r * h, N_RANK + (r + 1) * h)) for r in range(2)]
+    return x, idx
+
+
+def _worker(rank, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=rank, world_size=2)
+        from unidefense_amd.engine.parallel import HipDataParallel
+        m = _build(dev)
+        dp = HipDataParallel(m, bucket_bytes=32 << 20)
+        x, idx = _shards()
+        xs = x[idx[rank]].contiguous().to(dev)
+        tgt = torch.tensor([0] * (N_RANK // 2) + [1] * (N_RANK // 2), device=dev)
+        res = None
+        for _ in range(2):                     # 1st backward learns the use counts (reduce at the end), 2nd streams
+            for p in m.parameters():
+                p.grad = None
+            out = dp(xs)
+            _loss(out, tgt).backward()
+            res = ({k: _digest(p.grad) for k, p in m.named_parameters() if p.grad is not None},
+                   out["cls_out"].detach().cpu().numpy(), out["rec"].detach().cpu().numpy())
+        q.put((rank, idx[rank], res, None))
+    except Exception as e:                      # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_full_batch():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+    for rank, _, _, err in got:
+        assert err is None, f"rank {rank}:\n{err}"
+    got.sort(key=lambda t: t[0])
+    # single process, whole batch, plain BatchNorm
+    dev = torch.device("cuda:0")
+    m = _build(dev)
+    x, idx = _shards()
+    tgt = torch.tensor([0] * N_RANK + [1] * N_RANK, device=dev)
+    out = m(x.to(dev))
+    _loss(out, tgt).backward()
+    ref_g = {k: _digest(p.grad) for k, p in m.named_parameters() if p.grad is not None}
+    # forward: every sample's outputs agree (SyncBN == full-batch BN)
+    for rank, ids, (g, cls, rec), _ in got:
+        e1 = abs(cls - out["cls_out"].detach().cpu().numpy()[ids]).max() / out["cls_out"].abs().max().item()
+        e2 = abs(rec - out["rec"].detach().cpu().numpy()[ids]).max() / out["rec"].abs().max().item()
+        print(f"  rank {rank}: cls_out {e1:.2e}  rec {e2:.2e}")
+        assert e1 <= 1e-4 and e2 <= 1e-3, (rank, e1, e2)
+    # both ranks hold the same averaged gradients, equal to the full-batch gradients
+    g0, g1 = got[0][2][0], got[1][2][0]
+    assert set(g0) == set(ref_g) == set(g1)
+    gmax = max(v[2] for v in ref_g.values())
+    worst, worst_norm, worst_rr = (0.0, ""), (0.0, ""), 0.0
+    for k, (head, norm, mx) in ref_g.items():
+        scale = mx + 3e-3 * gmax                     # zero-true-gradient tensors hold rounding noise (test_fullsize_gpu.py)
+        worst = max(worst, (float(abs(g0[k][0] - head).max()) / scale, k))
+        worst_norm = max(worst_norm, (abs(g0[k][1] - norm) / (norm + 3e-3 * gmax * head.size ** 0.5), k))
+        worst_rr = max(worst_rr, float(abs(g0[k][0] - g1[k][0]).max()) / scale)
+    print(f"  {len(ref_g)} gradients: 2 ranks vs full batch: worst entry {worst[0]:.2e} ({worst[1]}), worst norm "
+          f"{worst_norm[0]:.2e} ({worst_norm[1]}); rank 0 vs rank 1 {worst_rr:.2e}")
+    assert worst_rr <= 1e-6 and worst[0] <= 2e-3 and worst_norm[0] <= 2e-3
