@@ -63,7 +63,7 @@ typedef struct {
 } ud_gemm_desc;
 int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
 /* Arithmetic path of ud_gemm (process-wide; initial value from env UD_GEMM_PATH):
- *   0 auto (default): large plain GEMMs (a_mode, b_mode in {0,1}, 16-byte aligned, M,N,K >= 64) run on the BF16
+ *   0 auto (default): plain GEMMs (a_mode, b_mode in {0,1}, 16-byte aligned, M,N,K >= 16) run on the BF16
  *     matrix pipe with every fp32 operand split exactly into three bf16 pieces and six piece products
  *     accumulated in fp32 (csrc/gemm_x3.hip: fp32-GEMM accuracy, error terms < 2^-26 |a||b|); all other shapes
  *     and the gather modes run on v_mfma_f32_32x32x2_f32;

@@ -189,6 +189,7 @@ def _pick_split(tiles, K):
 
 
 _TILE_CFGS = ((128, 128, 1.00), (128, 64, 0.93), (256, 32, 1.10), (32, 256, 1.10), (64, 128, 0.93))
+_X3_TILE_MODEL = os.environ.get("UD_X3_TILE_MODEL", "0") == "1"      # A/B: the fp32-kernel tile model (more split-K) is 0.4 % faster
 
 
 _FWD_SPLIT_T = int(os.environ.get("UD_FWD_SPLIT_T", "224"))      # A/B on the bench: 128/1024 -> 224/512 = -0.6 % step time
@@ -198,16 +199,22 @@ _FWD_SPLIT_K = int(os.environ.get("UD_FWD_SPLIT_K", "512"))
 def _fwd_split(M, N, K):
     """split-K for a forward / data-gradient GEMM too small to fill the chip (e.g. the 8x8-resolution
     expand/project convs: M = 2048, 80 tiles for 256 CUs)."""
-    t = _tiles(M, N)
+    t = _tiles(M, N, K)
     if t >= _FWD_SPLIT_T or K < _FWD_SPLIT_K:
         return 1
     return max(1, min(K // 256, -(-320 // t)))
 
 
-def _tiles(M, N):
-    """Tile count of the configuration gemm.hip:choose_cfg picks for an unsplit launch."""
+_X3_CFGS = ((128, 128, 1.00), (128, 64, 1.20), (64, 128, 1.20))          # gemm_x3.hip kX
+_X3_MINDIM = int(os.environ.get("UD_GEMM_X3_MINDIM", "16"))                 # gemm.hip's auto rule
+
+
+def _tiles(M, N, K=None):
+    """Tile count of the configuration the library picks for an unsplit launch: gemm_x3.hip's for plain GEMMs whose
+    dimensions all reach the auto rule's minimum (K given), gemm.hip:choose_cfg's otherwise."""
+    x3 = _X3_TILE_MODEL and K is not None and min(M, N, K) >= _X3_MINDIM
     best, best_tiles = None, 1
-    for bm, bn, pen in _TILE_CFGS:
+    for bm, bn, pen in (_X3_CFGS if x3 else _TILE_CFGS):
         t = -(-M // bm) * -(-N // bn)
         cost = -(-t // 256) * bm * bn * pen
         if best is None or cost < best:
@@ -221,7 +228,7 @@ def gemm_tn(a, b):
     K, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == K
-    split = _pick_split(_tiles(M, N), K)
+    split = _pick_split(_tiles(M, N, K), K)
     if split > 1:
         out = zeros((M, N), a)
         return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 2, split)
