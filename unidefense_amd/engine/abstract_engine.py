@@ -160,7 +160,10 @@ class AbstractEngine(object):
         if self.warmup_step == 0 or cur_step > self.warmup_step:
             self.scheduler.step()
         self._barrier()
-        return ret_dict
+        # detached: a caller that keeps the dict must not keep this step's autograd graph (and its AccumulateGrad nodes,
+        # bound to this stream) alive — the next step may be captured into a hipGraph on another stream, and a backward
+        # that meets those stale nodes makes the capture depend on a non-capturing stream (crash at capture end)
+        return {k: v.detach() for k, v in ret_dict.items()}
 
     # ---- graph-captured step ------------------------------------------------------------------------------------
     def _perturbed(self, in_data, sum_real, sum_fake):

@@ -42,3 +42,32 @@ def build_optimizer(model, opt_cfg):
             and all(p.is_cuda for g in groups for p in g["params"]):
         cfg["fused"] = True
     return get_optimizer(name, groups, **cfg)
+
+
+class ConstantLR(torch.optim.lr_scheduler.LRScheduler):
+    """scheduler/__init__.py:13-18 of the reference: what an absent `scheduler:` block means."""
+
+    def get_lr(self):
+        return list(self.base_lrs)
+
+
+SCHEDULERS = {
+    "ConstantLR": ConstantLR,
+    "StepLR": torch.optim.lr_scheduler.StepLR,
+    "MultiStepLR": torch.optim.lr_scheduler.MultiStepLR,
+    "ExponentialLR": torch.optim.lr_scheduler.ExponentialLR,
+    "CosineAnnealingLR": torch.optim.lr_scheduler.CosineAnnealingLR,
+    "CosineAnnealingWarmRestarts": torch.optim.lr_scheduler.CosineAnnealingWarmRestarts,
+}
+
+
+def build_scheduler(optimizer, sched_cfg):
+    """scheduler.get_scheduler (scheduler/__init__.py:33-40): the YAML's config.scheduler dict (name + kwargs) or None.
+    The timm schedulers of the reference's table (TimmStepLR, TimmCosineLR) are not available in this image."""
+    if sched_cfg is None:
+        return ConstantLR(optimizer)
+    cfg = dict(sched_cfg)
+    name = cfg.pop("name")
+    if name not in SCHEDULERS:
+        raise KeyError(f"scheduler '{name}' is not available here; known: {sorted(SCHEDULERS)}")
+    return SCHEDULERS[name](optimizer, **cfg)

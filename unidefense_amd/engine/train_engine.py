@@ -1,0 +1,132 @@
+"""Concrete engine behind ``engine.get_engine`` (reference: engine/forgery_engine.py, ocim_engine.py,
+uniattack_engine.py — three copies of one train loop around AbstractEngine.train_unidefense_model that differ in
+their dataset / metric / wandb plumbing, which is out of scope here, SURVEY.md §8 b / §5).
+
+What this mirrors of the reference (file:line of forgery_engine.py):
+  * config layout: ``config['model']`` = model name + ctor kwargs (:141), ``config['config']`` = optimizer / scheduler /
+    warmup_step / lambda_* / local_rank (:133-160), ``config['data']['train_batch_size']`` = samples per class and rank;
+  * model -> SyncBN + data parallel (:142-146; here HipDataParallel over RCCL when a process group exists),
+    timm weight-decay groups + optimizer (:149-154), scheduler (:156), the four loss criteria (:157-162);
+  * train(): zero_grad, one [real...; fake...] batch per step from two sources, linear lr warm-up (:271-274),
+    train_unidefense_model, loss / accuracy trackers reduced over ranks (:279-287), a log line every log_steps.
+What replaces the dataset classes: ``config['data']['iterator']`` — a callable ``(step, batch, size, device) ->
+(images_real, labels_real, images_fake, labels_fake)``; without one, seeded synthetic batches of the configured size
+(there is no dataset in this image).  test(): accuracy / real-class scores over ``config['data']['test_iterator']``
+(or synthetic batches) with the inference forward — the ROC metrics and checkpoint I/O of the reference stay out.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from ..loss import get_loss
+from ..model import load_model
+from .abstract_engine import AbstractEngine
+from .optim import build_optimizer, build_scheduler
+from .parallel import wrap_data_parallel
+
+
+def synthetic_batches(seed=0):
+    """Default data source: x = 2*U(0,1)-1 faces, labels 0 = real, 1 = fake."""
+    def it(step, batch, size, device):
+        g = torch.Generator().manual_seed(seed * 1000003 + step)
+        real = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+        fake = torch.rand(batch, 3, size, size, generator=g) * 2 - 1
+        return (real.to(device), torch.zeros(batch, dtype=torch.long, device=device),
+                fake.to(device), torch.ones(batch, dtype=torch.long, device=device))
+    return it
+
+
+class TrainEngine(AbstractEngine):
+    path = "engine/train_engine.py"
+
+    def __init__(self, config, stage="Train"):
+        super().__init__(config, stage)
+        if not torch.cuda.is_available():
+            raise RuntimeError("unidefense_amd engines run on an MI355X GPU only (no CPU path)")
+        cfg = config["config"]
+        self.local_rank = int(cfg.get("local_rank", os.environ.get("LOCAL_RANK", 0)))
+        self.device = torch.device(f"cuda:{self.local_rank}")
+        torch.cuda.set_device(self.device)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+            dist.init_process_group(cfg.get("distribute", {}).get("backend", "nccl"), device_id=self.device)
+        model_cfg = dict(config["model"])
+        self.model_name = model_cfg.pop("name")
+        data_cfg = config.get("data", {})
+        self.batch = int(data_cfg.get("train_batch_size", 16))
+        self.size = int(data_cfg.get("size", 256))
+        self.num_steps = int(cfg.get("num_steps", data_cfg.get("num_steps", 100)))
+        self.log_steps = int(cfg.get("log_steps", data_cfg.get("log_steps", 50)))
+        self.warmup_step = int(cfg.get("warmup_step", 0))
+        self.train_iterator = data_cfg.get("iterator") or synthetic_batches(self.local_rank)
+        self.test_iterator = data_cfg.get("test_iterator") or synthetic_batches(10007 + self.local_rank)
+
+        self.model = load_model(self.model_name)(**model_cfg).to(self.device)
+        self.model_without_ddp = self.model
+        if dist.is_available() and dist.is_initialized():
+            self.model = wrap_data_parallel(self.model, self.local_rank)           # SyncBN + gradient exchange
+        if stage == "Train":
+            self.base_lr = float(cfg["optimizer"]["lr"])
+            self.optimizer = build_optimizer(self.model_without_ddp, cfg["optimizer"])
+            self.scheduler = build_scheduler(self.optimizer, cfg.get("scheduler"))
+            self.loss_criterion = {"softmax": get_loss("cross_entropy", self.device),
+                                   "triplet": get_loss("aw_triplet", self.device),
+                                   "kl_div": get_loss("kl_div", self.device),
+                                   "fac": get_loss("factorization", self.device)}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _mean_over_ranks(self, values):
+        t = torch.stack([v.detach().float().reshape(()) for v in values])
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(t)                      # one packed metric exchange per log step
+            t /= dist.get_world_size()
+        return t.tolist()
+
+    def train(self):
+        try:
+            grad_scalar = torch.amp.GradScaler("cuda", init_scale=2 ** 10)        # forgery_engine.py:228
+            sums, count, correct, seen, last = {}, 0, 0, 0, {}
+            for cur_step in range(1, self.num_steps + 1):
+                self.model.train()
+                self.optimizer.zero_grad()
+                xr, yr, xf, yf = self.train_iterator(cur_step, self.batch, self.size, self.device)
+                in_data, in_tgt = torch.cat([xr, xf], 0).contiguous(), torch.cat([yr, yf], 0)
+                if self.warmup_step != 0 and cur_step <= self.warmup_step:           # :271-274
+                    for group in self.optimizer.param_groups:
+                        group["lr"] = self.base_lr * float(cur_step) / self.warmup_step
+                out = self.train_unidefense_model(in_data, in_tgt, cur_step, grad_scalar, yr.shape[0], yf.shape[0])
+                for k, v in out.items():
+                    if "loss" in k:
+                        sums[k] = sums.get(k, 0.0) + v.detach()
+                count += 1
+                correct += (out["cls_out"].argmax(1) == in_tgt).sum()
+                seen += in_tgt.numel()
+                if cur_step % self.log_steps == 0 or cur_step == self.num_steps:
+                    keys = sorted(sums)
+                    vals = self._mean_over_ranks([sums[k] / count for k in keys] + [correct / seen])
+                    last = dict(zip(keys, vals[:-1]))
+                    last["acc"], last["lr"], last["step"] = vals[-1], self.optimizer.param_groups[0]["lr"], cur_step
+                    if self.local_rank == 0:
+                        print("Train Iter (%d/%d), Loss %.4f, Triplet %.4f, Spat %.4f, Freq %.4f, ACC %.4f, LR %.6f" % (
+                            cur_step, self.num_steps, last.get("total_loss", 0.0), last.get("triplet_loss", 0.0),
+                            last.get("real_rec_loss", 0.0), last.get("real_freq_loss", 0.0), last["acc"], last["lr"]))
+            return last
+        except Exception:
+            if dist.is_available() and dist.is_initialized():                          # :315-318
+                dist.destroy_process_group()
+            raise
+
+    @torch.no_grad()
+    def test(self, batches=4):
+        """Inference forward (model(x)['cls_out'] -> softmax[:, 0], forgery_engine.py:320-452 without the ROC metrics)."""
+        self.model.eval()
+        scores, labels = [], []
+        for step in range(1, batches + 1):
+            xr, yr, xf, yf = self.test_iterator(step, self.batch, self.size, self.device)
+            out = self.model(torch.cat([xr, xf], 0).contiguous())
+            scores.append(torch.softmax(out["cls_out"], 1)[:, 0])
+            labels.append(torch.cat([yr, yf], 0))
+        scores, labels = torch.cat(scores), torch.cat(labels)
+        acc = ((scores < 0.5).long() == labels).float().mean()
+        acc, = self._mean_over_ranks([acc])
+        return {"acc": acc, "scores": scores.cpu(), "labels": labels.cpu()}
