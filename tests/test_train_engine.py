@@ -32,7 +32,9 @@ def test_scheduler_factory():
     for _ in range(2):
         opt.step(); s.step()
     assert abs(opt.param_groups[0]["lr"] - 0.05) < 1e-12
-    c = build_scheduler(torch.optim.SGD([p], lr=0.3), None)
+    opt2 = torch.optim.SGD([p], lr=0.3)
+    c = build_scheduler(opt2, None)
+    opt2.step()
     c.step()
     assert c.get_last_lr() == [0.3]
     with pytest.raises(KeyError):
