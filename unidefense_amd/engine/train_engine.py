@@ -22,6 +22,7 @@ import torch.distributed as dist
 from ..loss import get_loss
 from ..model import load_model
 from .abstract_engine import AbstractEngine
+from .checkpoint import load_checkpoint, save_checkpoint
 from .optim import build_optimizer, build_scheduler
 from .parallel import wrap_data_parallel
 
@@ -65,6 +66,8 @@ class TrainEngine(AbstractEngine):
         self.model_without_ddp = self.model
         if dist.is_available() and dist.is_initialized():
             self.model = wrap_data_parallel(self.model, self.local_rank)           # SyncBN + gradient exchange
+        if self.config["config"].get("resume") and os.path.exists(self._ckpt_path()):
+            self._load_ckpt(train=stage == "Train")
         if stage == "Train":
             self.base_lr = float(cfg["optimizer"]["lr"])
             self.optimizer = build_optimizer(self.model_without_ddp, cfg["optimizer"])
@@ -73,6 +76,17 @@ class TrainEngine(AbstractEngine):
                                    "triplet": get_loss("aw_triplet", self.device),
                                    "kl_div": get_loss("kl_div", self.device),
                                    "fac": get_loss("factorization", self.device)}
+
+    # ---- checkpoints in the reference's file names / format (forgery_engine.py:215-223) ------------------------------
+    def _ckpt_path(self, best=False):
+        return os.path.join(self.config["config"].get("dir", "."), "best_model.bin" if best else "latest_model.bin")
+
+    def _save_ckpt(self, step, best=False):
+        if self.local_rank == 0:
+            save_checkpoint(self.model_without_ddp, self._ckpt_path(best), step)
+
+    def _load_ckpt(self, best=False, train=False):
+        return load_checkpoint(self.model_without_ddp, self._ckpt_path(best))
 
     # ------------------------------------------------------------------------------------------------------------
     def _mean_over_ranks(self, values):
@@ -110,6 +124,8 @@ class TrainEngine(AbstractEngine):
                         print("Train Iter (%d/%d), Loss %.4f, Triplet %.4f, Spat %.4f, Freq %.4f, ACC %.4f, LR %.6f" % (
                             cur_step, self.num_steps, last.get("total_loss", 0.0), last.get("triplet_loss", 0.0),
                             last.get("real_rec_loss", 0.0), last.get("real_freq_loss", 0.0), last["acc"], last["lr"]))
+            if self.config["config"].get("dir"):
+                self._save_ckpt(self.num_steps)
             return last
         except Exception:
             if dist.is_available() and dist.is_initialized():                          # :315-318
