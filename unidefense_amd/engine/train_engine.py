@@ -12,7 +12,9 @@ What this mirrors of the reference (file:line of forgery_engine.py):
 What replaces the dataset classes: ``config['data']['iterator']`` — a callable ``(step, batch, size, device) ->
 (images_real, labels_real, images_fake, labels_fake)``; without one, seeded synthetic batches of the configured size
 (there is no dataset in this image).  test(): accuracy / real-class scores over ``config['data']['test_iterator']``
-(or synthetic batches) with the inference forward — the ROC metrics and checkpoint I/O of the reference stay out.
+(or synthetic batches) with the inference forward — the reference's ROC metrics stay out.  Checkpoints: the reference's
+file names and format (engine/checkpoint.py); ``config['config']['dir']`` enables the save at the end of train(),
+``resume`` the load at construction.
 """
 import os
 
