@@ -55,3 +55,18 @@ def test_state_dict_keys_match_reference_layout():
     assert all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
     assert len(list(m.parameters())) == 505
     assert not m.bottleneck.bias.requires_grad
+
+
+def test_dropin_shims_resolve_the_reference_import_names():
+    """`from engine import get_engine`, `from model import load_model`, `from loss import get_loss`
+    (main.py:5-6 and the engines of the reference) with unidefense_amd/dropin first on sys.path — in a fresh interpreter."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from engine import get_engine\nfrom model import load_model\nfrom loss import get_loss\n"
+            "import unidefense_amd.engine as e, unidefense_amd.model as m\n"
+            "assert get_engine is e.get_engine and load_model is m.load_model\n"
+            "assert get_engine('UE').__name__ == 'TrainEngine' and load_model('udr50').__name__ == 'UniDefenseModelRes50'\n"
+            "print('ok')" % (os.path.join(ROOT, "unidefense_amd", "dropin"), ROOT))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp", timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
