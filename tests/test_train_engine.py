@@ -60,3 +60,25 @@ def test_engine_trains_and_tests_on_synthetic_batches():
     res = eng.test(batches=2)
     assert res["scores"].shape == (8,) and 0.0 <= res["acc"] <= 1.0
     assert torch.isfinite(res["scores"]).all()
+
+
+@pytest.mark.gpu
+def test_engine_with_prefetched_host_batches():
+    """config['data']['iterator'] = RealFakePrefetcher over two host-side sources: pinned copies on a side stream one
+    step ahead; the engine consumes them (graph-captured from the 2nd step on) and the batches arrive intact."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import copy
+    from unidefense_amd.engine import get_engine
+    from unidefense_amd.engine.data import RealFakePrefetcher
+    g = torch.Generator().manual_seed(3)
+    real = [(torch.rand(2, 3, 256, 256, generator=g) * 2 - 1, torch.zeros(2, dtype=torch.long)) for _ in range(2)]
+    fake = [(torch.rand(2, 3, 256, 256, generator=g) * 2 - 1, torch.ones(2, dtype=torch.long)) for _ in range(3)]
+    pf = RealFakePrefetcher(real, fake)
+    xr, yr, xf, yf = pf(1, 2, 256, "cuda:0")
+    assert torch.equal(xr.cpu(), real[0][0]) and torch.equal(xf.cpu(), fake[0][0]) and yr.eq(0).all() and yf.eq(1).all()
+    cfg = copy.deepcopy(CONFIG)
+    cfg["config"]["num_steps"], cfg["config"]["log_steps"] = 3, 3
+    cfg["data"]["iterator"] = pf
+    log = get_engine("UE")(cfg, "Train").train()
+    assert log["step"] == 3 and all(torch.isfinite(torch.tensor(v)) for v in log.values())
