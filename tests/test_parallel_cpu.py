@@ -46,6 +46,22 @@ def _worker(rank, world, port, q):
                                              1e-5, None)
         ok_bn = torch.allclose(mean.view(-1), full.mean(0)) and torch.allclose(var.view(-1), full.var(0, unbiased=False)) \
             and torch.allclose(invstd.view(-1), torch.rsqrt(full.var(0, unbiased=False) + 1e-5))
+        # 4. the streaming protocol of _NetFunction.backward: the tape hands each gradient to the reducer when its
+        #    use count is reached (here 1 each), buckets flush mid-way (async all_reduce), finish() returns views;
+        #    the caller pre-scales by 1/world so the SUM is the mean
+        from unidefense_amd import tape as T
+        tp = T.Tape()
+        red = dp.module._grad_reducer
+        red.begin()
+        tp.param_uses = {id(p): 1 for p in params}
+        tp.param_ready = red.ready
+        locals_ = {id(p): torch.full_like(p, float(rank + 1) * (i + 1)) / world for i, p in enumerate(params)}
+        for p in reversed(params):
+            tp.add_param_grad(p, locals_[id(p)])
+        out2 = red.finish()
+        ok_stream = set(out2) == {id(p) for p in params} and tp.param_seen == tp.param_uses and all(
+            torch.allclose(out2[id(p)], torch.full_like(p, (i + 1) * (1 + world) / 2.0)) for i, p in enumerate(params))
+        ok_avg = ok_avg and ok_stream and dp.module._grad_prescale == 1.0 / world
         q.put((rank, ok_bcast, ok_avg, ok_bn, hasattr(net, "_sync_bn_group")))
     except Exception as e:          # surface the failure instead of letting the parent time out
         q.put((rank, False, False, False, repr(e)))
