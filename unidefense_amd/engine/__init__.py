@@ -1,16 +1,13 @@
-"""Mirror of the reference's ``engine`` package surface (engine/__init__.py:1-14)."""
+"""Engine lookup with the reference's surface (its engine/__init__.py: `get_engine(name)` -> class, names FE / OCIM /
+UE, KeyError otherwise, one "Using engine" line).  The reference's three concrete engines share the train step and differ
+in dataset / metric / wandb plumbing (out of scope): all three names resolve to the one concrete engine built here."""
 from .abstract_engine import AbstractEngine
 from .train_engine import TrainEngine
 
-# the reference's three concrete engines share the train step and differ in dataset / metric plumbing (out of scope):
-# all three names resolve to the one concrete engine built here
-ENGINE = {
-    "FE": TrainEngine,
-    "OCIM": TrainEngine,
-    "UE": TrainEngine,
-}
+ENGINE = dict.fromkeys(("FE", "OCIM", "UE"), TrainEngine)
 
 
 def get_engine(name='UE'):
+    cls = ENGINE[name]
     print(f"Using engine: '{name}'")
-    return ENGINE[name]
+    return cls
