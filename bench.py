@@ -206,6 +206,13 @@ def main():
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
             run = step
+        if world > 1:
+            # all ranks must issue the same sequence of collectives: if the capture failed anywhere, everyone runs eagerly
+            ok = torch.tensor([1.0 if exec_mode == "hipgraph" else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1.0 and exec_mode == "hipgraph":
+                print("[bench] another rank could not capture the step; running eagerly", file=sys.stderr)
+                run, exec_mode = step, "eager"
     for _ in range(args.warmup):
         loss = run()
     torch.cuda.synchronize()
