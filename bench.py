@@ -93,6 +93,27 @@ def cpu_baseline(timeout_s=300):
                 "sample": f"not finished within {timeout_s} s"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N` over
+    this same command line as a CHILD process (never exec; nothing in this process has touched the GPU yet), relay its
+    output (rank 0 prints the JSON line) and return its exit code.  Fails with a clear message when the box has fewer
+    than N GPUs (torch.cuda.device_count() does not initialise the GPU)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but this box exposes {have} GPU(s); nothing was run", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def _pmc_traffic(args, bs):
     """roofline.traffic: HBM bytes per GEMM launch from the committed PMC summary of this same workload
     (tools/gpu_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 half-count correction).  PMC passes
@@ -129,12 +150,14 @@ def main():
         print(json.dumps(cpu_baseline_measure()), flush=True)
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force = os.environ.get("UD_FORCE_COLLECTIVES", "0") == "1"     # 1-GPU exercise of the RCCL path (tape.py)
@@ -227,10 +250,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    n_ranks_seen = 1
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+    if dist.is_initialized():
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                  # every rank that really took part adds 1 (over RCCL)
+        n_ranks_seen = int(ones.item())
     # ---- roofline of the dominant kernel: the same step, eager, every ud_gemm launch bracketed by HIP events
     # on its launch stream (events cannot be read back from inside a replayed graph)
     prof_steps = min(args.steps, 3)
@@ -270,6 +298,7 @@ def main():
                        if (args.model, args.size, bs) == ("UDEB4", 256, 32) else
                        f"{args.model} {args.size}x{args.size} fwd + pass-1 loss + bwd, bs={bs}/GPU (informational)",
                        "global_batch": world * bs, "parallelism": f"dp{world}", "exec": exec_mode,
+                       "n_ranks_seen": n_ranks_seen,
                        "final_loss": float(loss.detach()),
                        # checksum of the step's result (tests: the data-parallel path at world size 1 must give
                        # the plain step's gradients)

@@ -472,8 +472,10 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         static const int min_dim = getenv("UD_GEMM_X3_MINDIM") ? atoi(getenv("UD_GEMM_X3_MINDIM")) : 16;
         if (path == 2 || (d.M >= min_dim && d.N >= min_dim && d.K >= min_dim)) return ud_gemm_x3_launch(d, s);
     }
+#ifdef UD_GEMM_DEBUG_NOLOAD      // tuning aid, debug builds only: issue no global loads (results are WRONG)
     static const bool noload = getenv("UD_GEMM_NOLOAD") != nullptr;
     if (noload) a_vec |= 2;
+#endif
     if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0>(d, a_vec, b_vec, s);
     if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1>(d, a_vec, b_vec, s);
     if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1>(d, a_vec, b_vec, s);

@@ -34,6 +34,7 @@ class AbstractEngine(object):
         # engine.use_graphs = False runs every launch eagerly
         self.use_graphs = os.environ.get("UD_ENGINE_GRAPH", "1") == "1"
         self._graphs = {}
+        self.max_graph_sets = 4          # distinct (shape, split, kl) sets kept captured at a time
 
     @staticmethod
     def fixed_randomness(seed=42):
@@ -174,8 +175,19 @@ class AbstractEngine(object):
             return perturb.perturb_input(in_data, pert_real_list, pert_fake_list, True).contiguous().to(torch.float32)
 
     def _train_graphed(self, in_data, in_tgt, cur_step, grad_scalar, sum_real, sum_fake, kl):
-        key = (tuple(in_data.shape), int(sum_real), int(sum_fake), bool(kl))
-        st = self._graphs.setdefault(key, {"calls": 0})
+        # Everything a capture bakes in is part of the key: shapes, the real/fake split, the KL branch, the loss
+        # weights, and the GradScaler whose scale tensor `grad_scalar.scale(total)` reads inside the graph (a fresh
+        # scaler per train() call must not replay graphs that multiply by the previous scaler's buffer).
+        lam = tuple(self._lam(k) for k in ("lambda_mask", "lambda_triplet", "lambda_recons", "lambda_freq", "lambda_fac"))
+        key = (tuple(in_data.shape), int(sum_real), int(sum_fake), bool(kl), id(grad_scalar), lam)
+        if key not in self._graphs:
+            # evict sets that can no longer be hit: other scalers / loss weights, and the kl=False twin once the step
+            # counter passed the threshold (each set pins a private memory pool with a full step of activations)
+            for k_ in [k_ for k_ in self._graphs if k_[4:] != key[4:] or (k_[:3] == key[:3] and kl and not k_[3])]:
+                del self._graphs[k_]
+            while len(self._graphs) >= self.max_graph_sets:
+                del self._graphs[next(iter(self._graphs))]
+        st = self._graphs.setdefault(key, {"calls": 0, "scaler": grad_scalar})     # keeps the scaler's id unique
         st["calls"] += 1
         params = [p for p in self.model.parameters() if p.requires_grad]
         if st["calls"] == 1:

@@ -9,9 +9,11 @@ a DistributedDataParallel wrapper) is tolerated on load.
 import torch
 
 
-def save_checkpoint(model, path, step, best_step=None, best_auc=None, best_acc=None):
+def save_checkpoint(model, path, step, best_step=1, best_auc=0., best_acc=0.):
+    """best_* default to the reference's initial values (forgery_engine.py:159-161: 1, 0., 0.): its readers call
+    round(ckpt['best_auc'], 4) on the file (forgery_engine.py:205-207), which a None would break."""
     module = getattr(model, "module", model)
-    torch.save({"step": int(step), "best_step": best_step, "best_auc": best_auc, "best_acc": best_acc,
+    torch.save({"step": int(step), "best_step": int(best_step), "best_auc": float(best_auc), "best_acc": float(best_acc),
                 "model": {k: v.detach().cpu() for k, v in module.state_dict().items()}}, path)
 
 

@@ -64,6 +64,7 @@ class TrainEngine(AbstractEngine):
         self.train_iterator = data_cfg.get("iterator") or synthetic_batches(self.local_rank)
         self.test_iterator = data_cfg.get("test_iterator") or synthetic_batches(10007 + self.local_rank)
 
+        self.best_step, self.best_auc, self.best_acc = 1, 0., 0.                    # forgery_engine.py:159-161
         self.model = load_model(self.model_name)(**model_cfg).to(self.device)
         self.model_without_ddp = self.model
         if dist.is_available() and dist.is_initialized():
@@ -85,7 +86,8 @@ class TrainEngine(AbstractEngine):
 
     def _save_ckpt(self, step, best=False):
         if self.local_rank == 0:
-            save_checkpoint(self.model_without_ddp, self._ckpt_path(best), step)
+            save_checkpoint(self.model_without_ddp, self._ckpt_path(best), step, self.best_step, self.best_auc,
+                            self.best_acc)
 
     def _load_ckpt(self, best=False, train=False):
         return load_checkpoint(self.model_without_ddp, self._ckpt_path(best))
@@ -127,6 +129,12 @@ class TrainEngine(AbstractEngine):
                             cur_step, self.num_steps, last.get("total_loss", 0.0), last.get("triplet_loss", 0.0),
                             last.get("real_rec_loss", 0.0), last.get("real_freq_loss", 0.0), last["acc"], last["lr"]))
             if self.config["config"].get("dir"):
+                # the train loop has no validation pass (evaluation metrics are out of scope), so the best-so-far
+                # record is the train accuracy of the last log window; best_model.bin is what the reference's test
+                # stage reads (forgery_engine.py:202-207)
+                if last.get("acc", 0.0) >= self.best_acc:
+                    self.best_step, self.best_acc = self.num_steps, float(last.get("acc", 0.0))
+                    self._save_ckpt(self.num_steps, best=True)
                 self._save_ckpt(self.num_steps)
             return last
         except Exception:
