@@ -273,6 +273,115 @@ int ud_efdm(const float* content, const float* style, const float* lmda, float* 
 int ud_coral_moments(const float* x, double* part, int N, int HW, int chunks, ud_stream_t stream);
 int ud_affine3(const float* x, const float* M, float* out, int N, int HW, ud_stream_t stream);
 
+/* ---- deferred normalisation: the fused MBConv path (csrc/fused.hip) ------------------------------------------------
+ * MBConvBlock.forward (model/efficientnet/model.py:94-135) alternates 1x1 convs / depthwise or SF convs with
+ * BatchNorm + swish, squeeze-excite and the residual.  Here a BatchNorm is never applied as a pass of its own: its
+ * batch statistics live as fp64 sums (sum x, sum x^2 per channel) in a zero-initialised accumulator that the
+ * PRODUCING side fills with atomic adds (ud_colstats, ud_irfft2_mix), and every CONSUMER applies
+ * act(gamma (x - mean) invstd + beta) while it loads x (ud_bn_ref).  The same holds for the backward sums
+ * (sum dz, sum dz xhat).  No finalize launches, no normalised copy of the activation in HBM.
+ * The accumulators are caller-owned fp64 buffers that must be zero before the producing kernel runs.
+ * Data shape arguments (G, R, C): G samples x R pixels x C channels (C % 4 == 0).
+ * gate_alpha / gate_mode: an optional scalar factor read on the device: 0 none, 1 sigmoid(alpha[0]),
+ * 2 1 - sigmoid(alpha[0])  (the sf_coef mix of exp.py:61-65 carried into the backward kernels). */
+typedef struct {
+    const double* sum;       /* [G][C] sum of x over the rows (and ranks) the statistics cover */
+    const double* sumsq;     /* [G][C] sum of x^2 */
+    const float* gamma;      /* [C] */
+    const float* beta;       /* [C] */
+    double inv_count;        /* 1 / (number of values behind each sum) */
+    double unbias;           /* count / (count - 1): running_var takes the unbiased variance (nn.BatchNorm) */
+    float eps;
+    float momentum;
+    int act;                 /* activation applied after the affine map: 0 none, 1 swish */
+    int G;                   /* groups of the STATISTICS: 1 = batch norm (one set for all samples) */
+    float* running_mean;     /* optional [C]: updated once by the consuming kernel that is handed them */
+    float* running_var;
+} ud_bn_ref;
+
+/* Reducing entry points take `ws`: fp64 scratch of ud_fused_reduce_ws_doubles(G, R, C, per_group, min_rows) doubles
+ * (per_group = 1 for [G][C] outputs, 0 for one [C] set; min_rows = 8) — they run as ONE launch with fp64 atomic adds
+ * while at most 64 workgroups would add to the same addresses (ws unused, the helper returns 0) and as partials +
+ * finalize otherwise.  ws may be NULL (always atomics). */
+long ud_fused_reduce_ws_doubles(int G, int R, int C, int per_group, int min_rows);
+/* sum[g][c] += sum_r x, sumsq[g][c] += sum_r x^2   (training-mode BatchNorm statistics, model.py:109,114,126) */
+int ud_colstats(const float* x, int G, int R, int C, double* sum, double* sumsq, double* ws, ud_stream_t stream);
+/* out[g][c] += sum_r act(bn(x))            (SE squeeze: adaptive_avg_pool2d of the activated tensor, model.py:118;
+ *                                           head pooling unidefense.py:226)  — bn->running_* are updated here */
+int ud_colsum_bn(const float* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
+                 ud_stream_t stream);
+/* out[g][c] += sum_r dy * act(bn(x))       (gradient of the SE gate) */
+int ud_coldot_bn(const float* dy, const float* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
+                 ud_stream_t stream);
+/* y[n][o] = sum_i (xsum[n][i] * xscale) W[o][i] + b[o]      (SE reduce conv on the pooled sums) */
+int ud_fc_fwd_d(const double* xsum, float xscale, const float* W, const float* b, float* y, int N, int I, int O,
+                ud_stream_t stream);
+/* y = act(bn(x)) * sigmoid(s[g][c])        (BN1 + swish + SE gate in one pass, model.py:114-122) */
+int ud_se_scale_bn(const float* x, const ud_bn_ref* bn, const float* s, float* y, int G, int R, int C,
+                   ud_stream_t stream);
+/* out = bn(x) * (keep[g] * inv_keep) + skip   (BN2 + drop_connect + residual, model.py:126-134; keep / skip may be
+ * NULL; bn->running_* are updated here) */
+int ud_residual_bn(const float* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const float* skip,
+                   float* out, int G, int R, int C, ud_stream_t stream);
+/* BatchNorm backward, reductions: dz = dy * (keep[g] * inv_keep) * act'(z)  (dy_is_dz: dz = dy);
+ * s1[c] += sum dz, s2[c] += sum dz * xhat */
+int ud_normbwd_sums(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                    int dy_is_dz, int G, int R, int C, double* s1, double* s2, double* ws, ud_stream_t stream);
+/* dx = gamma invstd (dz - s1 inv_count - xhat s2 inv_count); s1/s2: sums over ALL ranks, s1_local/s2_local: this
+ * rank's sums -> dbeta / dgamma (NULL: not written) */
+int ud_normbwd_apply(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                     int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
+                     const double* s2_local, int G, int R, int C, float* dx, float* dgamma, float* dbeta,
+                     ud_stream_t stream);
+/* SE backward, the two small FC layers (model.py:119-121) in two launches:
+ *   a: dpre = dgate[n][c] * sigmoid'(s2);  ds1[n][i] = swish'(s1) sum_c dpre W_e[c][i];
+ *      dW_e[c][i] = sum_n dpre swish(s1[n][i]);  db_e[c] = sum_n dpre
+ *   b: dpool[n][c] = sum_i ds1 W_r[i][c];  dW_r[i][c] = sum_n ds1[n][i] pool[n][c] * pool_scale;  db_r[i] = sum_n ds1 */
+int ud_se_bwd_a(const double* dgate, const float* s2, const float* s1, const float* We, double* ds1_acc, float* dWe,
+                float* dbe, int N, int C, int Cs, ud_stream_t stream);
+int ud_se_bwd_b(const double* ds1_acc, const float* s1, const float* Wr, const double* pool, float pool_scale,
+                float* dpool, float* dWr, float* dbr, int N, int C, int Cs, ud_stream_t stream);
+/* db = dc * sigmoid(s[g][c]) + dpool[g][c] * inv_hw;  dz = db * act'(bn(x));  s1 += sum dz, s2 += sum dz xhat
+ * (gradient through the SE gate and the swish of BN1, with BN1's backward sums) */
+int ud_se_scale_bwd_bn(const float* dc, const float* x, const ud_bn_ref* bn, const float* s, const float* dpool,
+                       float inv_hw, float* dz, double* s1, double* s2, double* ws, int G, int R, int C,
+                       ud_stream_t stream);
+/* ud_normbwd_apply (dy_is_dz) fused with the gradient of the SF mix y = (1-a) spat + a freq (exp.py:61-65):
+ * writes dd = dL/dy and accumulates sum dd * (freq - spat) into the 64 slots dalpha_acc[0..64) (zeroed by the caller) */
+int ud_normbwd_apply_mix(const float* x, const float* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
+                         const double* s1_local, const double* s2_local, const float* spat, const float* freq,
+                         int G, int R, int C, float* dd, double* dalpha_acc, float* dgamma, float* dbeta,
+                         ud_stream_t stream);
+/* out[0] = sigmoid'(alpha[0]) * sum(acc[0..64))      (sf_coef gradient from the accumulator above) */
+int ud_gate_grad_from_acc(const double* acc, const float* alpha, float* out, ud_stream_t stream);
+/* y = act(bn(x)): the materialised form for consumers that re-read their input per tap (a plain depthwise conv and its
+ * weight gradient: re-evaluating the swish per window load costs more than this pass); bn->running_* are updated here */
+int ud_bn_apply(const float* x, const ud_bn_ref* bn, float* y, int G, int R, int C, ud_stream_t stream);
+/* data gradient of the depthwise conv, scaled by the gate, plus `add`, pushed through the swish of the deferred
+ * BatchNorm of its INPUT x:  da = gate * dwconv_bwd_data(dy) + add;  dz = da * act'(bn(x));  s1/s2 as above */
+int ud_dwconv_bwd_data_bn(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
+                          const float* x, const ud_bn_ref* bn, float* dz, double* s1, double* s2, double* ws, int N,
+                          int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l,
+                          ud_stream_t stream);
+long ud_dwconv_bwd_data_bn_ws_doubles(int N, int H, int W, int C, int stride);
+/* ud_dwconv_bwd_data with the gate factor on dy */
+int ud_dwconv_bwd_data_ex(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
+                          float* dx, int N, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t,
+                          int pad_l, ud_stream_t stream);
+/* ud_dwconv_bwd_weight with the gate factor on dy */
+int ud_dwconv_bwd_weight_ex(const float* x, const float* dy, const float* gate_alpha, int gate_mode, float* dwt,
+                            float* part, int chunks, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                            int pad_t, int pad_l, ud_stream_t stream);
+/* ud_rfft2 of act(bn(x)) (bn may be NULL), optionally also writing the activated input (act_out) and scaling the
+ * result by the gate:  SFConv's spectral branch reading the expand conv's raw output (exp.py:55) and, as the
+ * adjoint of irfft2, its backward (gate = sigmoid(sf_coef)) */
+int ud_rfft2_ex(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
+                float* act_out, const float* gate_alpha, int gate_mode, ud_stream_t stream);
+/* irfft2 + SF mix + BN1 statistics (exp.py:60-65, stride 1):  freq_out = irfft2(Y) * scale;
+ * y = (1 - a) spat + a freq_out, a = sigmoid(alpha[0]);  sum[c] += sum y, sumsq[c] += sum y^2 */
+int ud_irfft2_mix(const float* Y, float* y, int N, int S, int C, float scale, float w_interior, const float* spat,
+                  const float* alpha, float* freq_out, double* sum, double* sumsq, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,9 +175,13 @@ struct Lds {
 
 // Y[n][ky][kx][c] = f(kx) * sum_{h,w} x[n][h][w][c] e^{-2 pi i (ky h + kx w)/S};  Re at channel c, Im at C + c.
 // f(kx) = scale for kx in {0, S/2}, scale * w_int otherwise.
-template <int S, int CB>
+// EX: the input is act(bn(x)) of a deferred BatchNorm (coefficients from the fp64 sums, one channel per thread),
+// optionally also written out (act_out), and the result carries the gate factor (include/unidefense_hip.h).
+template <int S, int CB, bool EX>
 __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, float* __restrict__ Y, int C,
-                                                   float scale, float w_int) {
+                                                   float scale, float w_int, ud_bn_ref bn, int has_bn,
+                                                   float* __restrict__ act_out, const float* __restrict__ gate_alpha,
+                                                   int gate_mode) {
     using L = Lds<S, CB>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Lre = lds;
@@ -191,9 +195,29 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, 
     // ---- pass 1: rows   (S * CB may be < 512 for the 5*2^k sizes: q >= S idles)
     if (q < S) {
         const float* src = x + (((long)n * S + q) * S) * C + ch;
+        float mu = 0.f, is = 1.f, ga = 1.f, be = 0.f;
+        if (EX && has_bn && cok) {
+            const double m = bn.sum[ch] * bn.inv_count;
+            double vv = bn.sumsq[ch] * bn.inv_count - m * m;
+            if (vv < 0.0) vv = 0.0;
+            mu = (float)m;
+            is = (float)(1.0 / sqrt(vv + (double)bn.eps));
+            ga = bn.gamma[ch];
+            be = bn.beta[ch];
+            if (n == 0 && q == 0 && bn.running_mean) {          // one thread per channel
+                bn.running_mean[ch] = (1.f - bn.momentum) * bn.running_mean[ch] + bn.momentum * (float)m;
+                bn.running_var[ch] = (1.f - bn.momentum) * bn.running_var[ch] + bn.momentum * (float)(vv * bn.unbias);
+            }
+        }
+        float* aout = (EX && act_out) ? act_out + (((long)n * S + q) * S) * C + ch : nullptr;
 #pragma unroll
         for (int w = 0; w < S; ++w) {
-            re[brev<S>(w)] = cok ? src[(long)w * C] : 0.f;
+            float v = cok ? src[(long)w * C] : 0.f;
+            if (EX && has_bn) {
+                v = ud_act(ga * ((v - mu) * is) + be, bn.act);
+                if (aout && cok) aout[(long)w * C] = v;
+            }
+            re[brev<S>(w)] = v;
             im[brev<S>(w)] = 0.f;
         }
         fft_inreg<S, false>(re, im);
@@ -212,7 +236,11 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, 
             im[brev<S>(h)] = Lim[q * L::KSTRIDE + h * CB + c];
         }
         fft_inreg<S, false>(re, im);
-        const float f = (q == 0 || q == S / 2) ? scale : scale * w_int;
+        float f = (q == 0 || q == S / 2) ? scale : scale * w_int;
+        if (EX && gate_mode != 0) {
+            const float a = ud_sigmoid(gate_alpha[0]);
+            f *= (gate_mode == 1) ? a : 1.f - a;
+        }
         float* dst = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
 #pragma unroll
         for (int ky = 0; ky < S; ++ky) {
@@ -223,9 +251,13 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, 
 }
 
 // x[n][h][w][c] = scale * C2R( f(kx) * Y[n][ky][kx][c] )   with the Hermitian extension along kx
-template <int S, int CB>
+// MIX: freq_out = irfft2(Y) * scale;  x = (1 - a) spat + a freq_out, a = sigmoid(alpha[0]);  per-channel sums of x and
+// x^2 folded over the workgroup's rows through LDS and added (fp64 atomics) to sum / sumsq  (exp.py:60-65 + BN1 stats)
+template <int S, int CB, bool MIX>
 __global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y, float* __restrict__ x, int C,
-                                                    float scale, float w_int) {
+                                                    float scale, float w_int, const float* __restrict__ spat,
+                                                    const float* __restrict__ alpha, float* __restrict__ freq_out,
+                                                    double* __restrict__ sum, double* __restrict__ sumsq) {
     using L = Lds<S, CB>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Lre = lds;
@@ -278,6 +310,7 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y,
     }
     __syncthreads();
     // ---- pass 2: Hermitian-extended inverse transform along kx, real part only
+    double tot1 = 0.0, tot2 = 0.0;          // MIX: this thread's row totals of y and y^2
     if (cok && q < S) {
 #pragma unroll
         for (int kx = 0; kx <= S / 2; ++kx) {
@@ -291,42 +324,139 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y,
             }
         }
         fft_inreg<S, true>(re, im);
-        float* dst = x + (((long)n * S + q) * S) * C + ch;
+        const long o0 = (((long)n * S + q) * S) * C + ch;
+        float* dst = x + o0;
+        if (!MIX) {
 #pragma unroll
-        for (int w = 0; w < S; ++w) dst[(long)w * C] = re[w] * scale;
+            for (int w = 0; w < S; ++w) dst[(long)w * C] = re[w] * scale;
+        } else {
+            const float a = ud_sigmoid(alpha[0]);
+            const float* sp = spat + o0;
+            float* fo = freq_out + o0;
+#pragma unroll
+            for (int w = 0; w < S; ++w) {
+                const float fr = re[w] * scale;
+                const float y = sp[(long)w * C] * (1.f - a) + fr * a;
+                fo[(long)w * C] = fr;
+                dst[(long)w * C] = y;
+                tot1 += (double)y;
+                tot2 += (double)y * (double)y;
+            }
+        }
+    }
+    if (MIX) {
+        // fold the S row-threads of every channel: the FFT's LDS planes are free now
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);
+        const bool own = cok && q < S;
+        if (own) {
+            red[(q * CB + c) * 2] = tot1;
+            red[(q * CB + c) * 2 + 1] = tot2;
+        }
+        __syncthreads();
+        if (cok && q == 0) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int r = 0; r < S; ++r) {
+                t1 += red[(r * CB + c) * 2];
+                t2 += red[(r * CB + c) * 2 + 1];
+            }
+            unsafeAtomicAdd(sum + ch, t1);
+            unsafeAtomicAdd(sumsq + ch, t2);
+        }
     }
 }
 
-template <int S, int CB>
-int launch_rfft2(const float* x, float* Y, int N, int C, float scale, float w_int, hipStream_t s) {
+struct RfftEx {
+    const ud_bn_ref* bn;
+    float* act_out;
+    const float* gate_alpha;
+    int gate_mode;
+};
+
+template <int S, int CB, bool EX>
+int launch_rfft2_t(const float* x, float* Y, int N, int C, float scale, float w_int, const RfftEx& ex, hipStream_t s) {
     using L = Lds<S, CB>;
     static bool attr_set = false;
     if (L::BYTES > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfft2_kernel<S, CB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfft2_kernel<S, CB, EX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
-    hipLaunchKernelGGL((rfft2_kernel<S, CB>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int);
+    ud_bn_ref none{};
+    hipLaunchKernelGGL((rfft2_kernel<S, CB, EX>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
+                       ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, ex.act_out, ex.gate_alpha, ex.gate_mode);
     UD_LAUNCH_CHECK();
     return 0;
 }
 
 template <int S, int CB>
-int launch_irfft2(const float* Y, float* x, int N, int C, float scale, float w_int, hipStream_t s) {
+int launch_rfft2(const float* x, float* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
+    if (ex) return launch_rfft2_t<S, CB, true>(x, Y, N, C, scale, w_int, *ex, s);
+    return launch_rfft2_t<S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0}, s);
+}
+
+struct IrfftMix {
+    const float* spat;
+    const float* alpha;
+    float* freq_out;
+    double* sum;
+    double* sumsq;
+};
+
+template <int S, int CB, bool MIX>
+int launch_irfft2_t(const float* Y, float* x, int N, int C, float scale, float w_int, const IrfftMix& m, hipStream_t s) {
     using L = Lds<S, CB>;
+    static_assert(!MIX || L::BYTES >= (size_t)S * CB * 2 * sizeof(double), "LDS planes hold the row totals");
     static bool attr_set = false;
     if (L::BYTES > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&irfft2_kernel<S, CB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&irfft2_kernel<S, CB, MIX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
-    hipLaunchKernelGGL((irfft2_kernel<S, CB>), grid, dim3(NT), L::BYTES, s, Y, x, C, scale, w_int);
+    hipLaunchKernelGGL((irfft2_kernel<S, CB, MIX>), grid, dim3(NT), L::BYTES, s, Y, x, C, scale, w_int, m.spat, m.alpha,
+                       m.freq_out, m.sum, m.sumsq);
     UD_LAUNCH_CHECK();
     return 0;
+}
+
+template <int S, int CB>
+int launch_irfft2(const float* Y, float* x, int N, int C, float scale, float w_int, const IrfftMix* m, hipStream_t s) {
+    if (m) return launch_irfft2_t<S, CB, true>(Y, x, N, C, scale, w_int, *m, s);
+    return launch_irfft2_t<S, CB, false>(Y, x, N, C, scale, w_int, IrfftMix{nullptr, nullptr, nullptr, nullptr, nullptr}, s);
+}
+
+int rfft2_dispatch(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, const RfftEx* ex,
+                   hipStream_t s) {
+    switch (S) {
+        case 8: return launch_rfft2<8, 64>(x, Y, N, C, scale, w_interior, ex, s);
+        case 16: return launch_rfft2<16, 32>(x, Y, N, C, scale, w_interior, ex, s);
+        case 32: return launch_rfft2<32, 16>(x, Y, N, C, scale, w_interior, ex, s);
+        case 64: return launch_rfft2<64, 8>(x, Y, N, C, scale, w_interior, ex, s);
+        case 10: return launch_rfft2<10, 51>(x, Y, N, C, scale, w_interior, ex, s);
+        case 20: return launch_rfft2<20, 25>(x, Y, N, C, scale, w_interior, ex, s);
+        case 40: return launch_rfft2<40, 12>(x, Y, N, C, scale, w_interior, ex, s);
+        case 80: return launch_rfft2<80, 5>(x, Y, N, C, scale, w_interior, ex, s);
+        default: return UD_EINVAL;
+    }
+}
+
+int irfft2_dispatch(const float* Y, float* x, int N, int S, int C, float scale, float w_interior, const IrfftMix* m,
+                    hipStream_t s) {
+    switch (S) {
+        case 8: return launch_irfft2<8, 64>(Y, x, N, C, scale, w_interior, m, s);
+        case 16: return launch_irfft2<16, 32>(Y, x, N, C, scale, w_interior, m, s);
+        case 32: return launch_irfft2<32, 16>(Y, x, N, C, scale, w_interior, m, s);
+        case 64: return launch_irfft2<64, 8>(Y, x, N, C, scale, w_interior, m, s);
+        case 10: return launch_irfft2<10, 51>(Y, x, N, C, scale, w_interior, m, s);
+        case 20: return launch_irfft2<20, 25>(Y, x, N, C, scale, w_interior, m, s);
+        case 40: return launch_irfft2<40, 12>(Y, x, N, C, scale, w_interior, m, s);
+        case 80: return launch_irfft2<80, 5>(Y, x, N, C, scale, w_interior, m, s);
+        default: return UD_EINVAL;
+    }
 }
 
 }  // namespace
@@ -335,34 +465,29 @@ extern "C" {
 
 int ud_rfft2(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, ud_stream_t stream) {
     if (N < 1 || C < 1) return UD_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    switch (S) {
-        case 8: return launch_rfft2<8, 64>(x, Y, N, C, scale, w_interior, s);
-        case 16: return launch_rfft2<16, 32>(x, Y, N, C, scale, w_interior, s);
-        case 32: return launch_rfft2<32, 16>(x, Y, N, C, scale, w_interior, s);
-        case 64: return launch_rfft2<64, 8>(x, Y, N, C, scale, w_interior, s);
-        case 10: return launch_rfft2<10, 51>(x, Y, N, C, scale, w_interior, s);
-        case 20: return launch_rfft2<20, 25>(x, Y, N, C, scale, w_interior, s);
-        case 40: return launch_rfft2<40, 12>(x, Y, N, C, scale, w_interior, s);
-        case 80: return launch_rfft2<80, 5>(x, Y, N, C, scale, w_interior, s);
-        default: return UD_EINVAL;
-    }
+    return rfft2_dispatch(x, Y, N, S, C, scale, w_interior, nullptr, (hipStream_t)stream);
 }
 
 int ud_irfft2(const float* Y, float* x, int N, int S, int C, float scale, float w_interior, ud_stream_t stream) {
     if (N < 1 || C < 1) return UD_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    switch (S) {
-        case 8: return launch_irfft2<8, 64>(Y, x, N, C, scale, w_interior, s);
-        case 16: return launch_irfft2<16, 32>(Y, x, N, C, scale, w_interior, s);
-        case 32: return launch_irfft2<32, 16>(Y, x, N, C, scale, w_interior, s);
-        case 64: return launch_irfft2<64, 8>(Y, x, N, C, scale, w_interior, s);
-        case 10: return launch_irfft2<10, 51>(Y, x, N, C, scale, w_interior, s);
-        case 20: return launch_irfft2<20, 25>(Y, x, N, C, scale, w_interior, s);
-        case 40: return launch_irfft2<40, 12>(Y, x, N, C, scale, w_interior, s);
-        case 80: return launch_irfft2<80, 5>(Y, x, N, C, scale, w_interior, s);
-        default: return UD_EINVAL;
-    }
+    return irfft2_dispatch(Y, x, N, S, C, scale, w_interior, nullptr, (hipStream_t)stream);
+}
+
+int ud_rfft2_ex(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
+                float* act_out, const float* gate_alpha, int gate_mode, ud_stream_t stream) {
+    if (N < 1 || C < 1 || !x || !Y) return UD_EINVAL;
+    if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
+    if (bn && bn->G != 1) return UD_EINVAL;
+    if (act_out && !bn) return UD_EINVAL;
+    RfftEx ex{bn, act_out, gate_alpha, gate_mode};
+    return rfft2_dispatch(x, Y, N, S, C, scale, w_interior, &ex, (hipStream_t)stream);
+}
+
+int ud_irfft2_mix(const float* Y, float* y, int N, int S, int C, float scale, float w_interior, const float* spat,
+                  const float* alpha, float* freq_out, double* sum, double* sumsq, ud_stream_t stream) {
+    if (N < 1 || C < 1 || !Y || !y || !spat || !alpha || !freq_out || !sum || !sumsq) return UD_EINVAL;
+    IrfftMix m{spat, alpha, freq_out, sum, sumsq};
+    return irfft2_dispatch(Y, y, N, S, C, scale, w_interior, &m, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,1003 @@
+// Deferred-normalisation kernels of the fused MBConv path (model/efficientnet/model.py:94-135 of the reference).
+//
+// A training-mode BatchNorm costs the unfused path three passes over the expanded activation (statistics, apply +
+// swish, and the consumer's own read) plus two tiny finalize launches, forward and backward each.  Here the
+// statistics are fp64 sums accumulated with atomic adds into a zeroed accumulator by whoever produces / first reads
+// the tensor, and every consumer applies act(gamma (x - mean) invstd + beta) while loading x (ud_bn_ref): no finalize
+// launches, no normalised copy.  All kernels use the column-owning decomposition of colgeom.h: a thread keeps one
+// channel quad for its whole life, so the per-channel coefficients are derived once per thread from the sums.
+//
+// HBM-bound; 16-byte accesses, one contiguous run of channels per wave access.  fp64 atomics execute at the memory
+// side (global_atomic_add_f64): one wave-instruction of 64 lanes per quantity and workgroup.
+#include "colgeom.h"
+
+namespace {
+
+constexpr int NT = UD_COL_NT;
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+struct Bn4 { f32x4 mu, is, ga, be; };
+
+// Coefficients of channel quad c4 from the fp64 sums; the designated thread of a kernel (update == true for exactly
+// one thread per channel quad per launch) also moves the running statistics (nn.BatchNorm2d training forward).
+__device__ __forceinline__ Bn4 bn_load(const ud_bn_ref& b, int g, int C4, int c4, bool update) {
+    Bn4 o;
+    const long i0 = ((long)(b.G == 1 ? 0 : g) * C4 + c4) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double m = b.sum[i0 + e] * b.inv_count;
+        double v = b.sumsq[i0 + e] * b.inv_count - m * m;
+        if (v < 0.0) v = 0.0;
+        o.mu[e] = (float)m;
+        o.is[e] = rsqrtf((float)(v + (double)b.eps));
+        if (update && b.running_mean) {
+            const int c = c4 * 4 + e;
+            b.running_mean[c] = (1.f - b.momentum) * b.running_mean[c] + b.momentum * (float)m;
+            b.running_var[c] = (1.f - b.momentum) * b.running_var[c] + b.momentum * (float)(v * b.unbias);
+        }
+    }
+    o.ga = reinterpret_cast<const f32x4*>(b.gamma)[c4];
+    o.be = reinterpret_cast<const f32x4*>(b.beta)[c4];
+    return o;
+}
+
+__device__ __forceinline__ f32x4 bn_apply(const f32x4& a, const Bn4& b, int act) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = ud_act_fast(b.ga[e] * ((a[e] - b.mu[e]) * b.is[e]) + b.be[e], act);
+    return o;
+}
+
+__device__ __forceinline__ float gate_factor(const float* alpha, int mode) {
+    if (mode == 0 || !alpha) return 1.f;
+    const float a = ud_sigmoid(alpha[0]);          // accurate: a is 4.5e-5 at the initial sf_coef = -10
+    return mode == 1 ? a : 1.f - a;
+}
+
+// rows [r_begin, r_end) of this workgroup's chunk, float4 index of (g, r, c4) = gbase + r * C4 + c4
+struct Rows {
+    int r, r_end;
+    long idx, step;
+};
+__device__ __forceinline__ Rows rows_of(const RedGeom& q, int ri, int c4) {
+    Rows w;
+    const int g = blockIdx.z, p = blockIdx.x;
+    const int r_begin = p * q.rows_per_chunk;
+    w.r_end = r_begin + q.rows_per_chunk;
+    if (w.r_end > q.R) w.r_end = q.R;
+    w.step = (long)q.rpi * q.C4;
+    w.r = r_begin + ri;
+    w.idx = (long)g * q.R * q.C4 + (long)w.r * q.C4 + c4;
+    return w;
+}
+
+__device__ __forceinline__ bool is_updater(int ri) { return blockIdx.x == 0 && blockIdx.z == 0 && ri == 0; }
+
+// Epilogue of every reducing kernel: fold the block's row-lanes, then either add the totals atomically into the
+// accumulators (few contributors per address: ~12 ns per fp64 add and address, serialised) or store them as fp64
+// partials part[q][(g * P + p)][C] for a finalize launch (partials_to_acc) when hundreds of workgroups would queue on
+// the same addresses.  per_group: accumulators are [G][C] (else one [C] set for all groups).
+template <int NQ>
+__device__ __forceinline__ void red_out(const RedGeom& q, int ri, bool active, int c4, double (&v)[8], double* a1,
+                                        double* a2, double* part, bool per_group) {
+    block_fold<NQ>(q, ri, active, v);
+    if (!(active && ri == 0)) return;
+    if (part) {
+        const long o = (((long)blockIdx.z * q.P + blockIdx.x) * q.C4 + c4) * 4;
+        const long plane = (long)q.G * q.P * q.C4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            part[o + e] = v[e];
+            if (NQ == 8) part[plane + o + e] = v[4 + e];
+        }
+    } else {
+        const long o = ((long)(per_group ? blockIdx.z : 0) * q.C4 + c4) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomic_add_f64(a1 + o + e, v[e]);
+            if (NQ == 8) atomic_add_f64(a2 + o + e, v[4 + e]);
+        }
+    }
+}
+
+// acc[q][o] += sum_p part[q][(o / C) * P + p][o % C]   (16 chunk-lanes per output, four partials in flight per lane)
+__global__ __launch_bounds__(NT) void partials_to_acc(int nq, int G, int C, int P, const double* __restrict__ part,
+                                                      double* __restrict__ a1, double* __restrict__ a2) {
+    __shared__ double sm[2][NT];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + cl;
+    const bool ok = idx < G * C;
+    const long plane = (long)G * P * C;
+    double a = 0.0, b = 0.0;
+    if (ok) {
+        const int g = idx / C, c = idx % C;
+        const long base = (long)g * P * C + c, step = 16L * C;
+        int p = pl;
+        for (; p + 48 < P; p += 64) {
+            const long o = base + (long)p * C;
+            a += (part[o] + part[o + step]) + (part[o + 2 * step] + part[o + 3 * step]);
+            if (nq == 2) b += (part[plane + o] + part[plane + o + step]) + (part[plane + o + 2 * step] + part[plane + o + 3 * step]);
+        }
+        for (; p < P; p += 16) {
+            const long o = base + (long)p * C;
+            a += part[o];
+            if (nq == 2) b += part[plane + o];
+        }
+    }
+    sm[0][threadIdx.x] = a;
+    sm[1][threadIdx.x] = b;
+    __syncthreads();
+    if (ok && pl == 0) {
+        for (int k = 1; k < 16; ++k) {
+            a += sm[0][k * 16 + cl];
+            b += sm[1][k * 16 + cl];
+        }
+        a1[idx] += a;
+        if (nq == 2) a2[idx] += b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// statistics and lazy reductions
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void colstats_kernel(RedGeom q, const float* __restrict__ x, double* __restrict__ sum,
+                                                      double* __restrict__ sumsq, double* __restrict__ part) {
+    int ri, c4;
+    const bool active = thread_coords(q, ri, c4);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        Rows w = rows_of(q, ri, c4);
+        for (; w.r + 3 * q.rpi < w.r_end; w.r += 4 * q.rpi, w.idx += 4 * w.step) {
+            f32x4 a0 = x4[w.idx], a1 = x4[w.idx + w.step], a2 = x4[w.idx + 2 * w.step], a3 = x4[w.idx + 3 * w.step];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d0 = a0[e], d1 = a1[e], d2 = a2[e], d3 = a3[e];
+                v[e] += (d0 + d1) + (d2 + d3);
+                v[4 + e] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+            f32x4 a = x4[w.idx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d = a[e];
+                v[e] += d;
+                v[4 + e] += d * d;
+            }
+        }
+    }
+    red_out<8>(q, ri, active, c4, v, sum, sumsq, part, true);
+}
+
+// DOT = false: out[g][c] += sum_r act(bn(x));  DOT = true: out[g][c] += sum_r dy * act(bn(x))
+template <bool DOT>
+__global__ __launch_bounds__(NT) void colsum_bn_kernel(RedGeom q, const float* __restrict__ x,
+                                                       const float* __restrict__ dy, ud_bn_ref bn,
+                                                       double* __restrict__ out, double* __restrict__ part) {
+    int ri, c4;
+    const bool active = thread_coords(q, ri, c4);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, !DOT && is_updater(ri));
+        Rows w = rows_of(q, ri, c4);
+#pragma unroll 4
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+            f32x4 a = bn_apply(x4[w.idx], cb, bn.act);
+            if (DOT) {
+                f32x4 d = d4[w.idx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (double)d[e] * (double)a[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (double)a[e];
+            }
+        }
+    }
+    red_out<4>(q, ri, active, c4, v, out, nullptr, part, true);
+}
+
+// y[n][o] = sum_i (xsum[n][i] * xscale) W[o][i] + b[o]; one wave per output
+__global__ __launch_bounds__(NT) void fc_fwd_d_kernel(const double* __restrict__ xsum, float xscale,
+                                                      const float* __restrict__ W, const float* __restrict__ b,
+                                                      float* __restrict__ y, int N, int I, int O) {
+    const int wave = (blockIdx.x * NT + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= N * O) return;
+    const int n = wave / O, o = wave % O;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int i = lane; i < I; i += 64) acc += ((float)xsum[(long)n * I + i] * xscale) * W[(long)o * I + i];
+    acc = ud_wave_sum(acc);
+    if (lane == 0) y[(long)n * O + o] = acc + (b ? b[o] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// elementwise consumers
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void se_scale_bn_kernel(RedGeom q, const float* __restrict__ x, ud_bn_ref bn,
+                                                         const float* __restrict__ s, float* __restrict__ y) {
+    int ri, c4;
+    if (!thread_coords(q, ri, c4)) return;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
+    f32x4 gate = reinterpret_cast<const f32x4*>(s)[(long)blockIdx.z * q.C4 + c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gate[e] = ud_sigmoid_fast(gate[e]);
+    Rows w = rows_of(q, ri, c4);
+#pragma unroll 4
+    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) y4[w.idx] = bn_apply(x4[w.idx], cb, bn.act) * gate;
+}
+
+__global__ __launch_bounds__(NT) void residual_bn_kernel(RedGeom q, const float* __restrict__ x, ud_bn_ref bn,
+                                                         const float* __restrict__ keep, float inv_keep,
+                                                         const float* __restrict__ skip, float* __restrict__ out) {
+    int ri, c4;
+    if (!thread_coords(q, ri, c4)) return;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* k4 = reinterpret_cast<const f32x4*>(skip);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, is_updater(ri));
+    const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
+    Rows w = rows_of(q, ri, c4);
+#pragma unroll 4
+    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+        f32x4 v = bn_apply(x4[w.idx], cb, bn.act) * sc;
+        if (skip) v += k4[w.idx];
+        o4[w.idx] = v;
+    }
+}
+
+// y = act(bn(x)): the materialised form, for consumers that re-read their input many times (plain depthwise convs
+// and their weight gradient: re-evaluating the swish per tap costs more than this pass)
+__global__ __launch_bounds__(NT) void bn_apply_kernel(RedGeom q, const float* __restrict__ x, ud_bn_ref bn,
+                                                      float* __restrict__ y) {
+    int ri, c4;
+    if (!thread_coords(q, ri, c4)) return;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, is_updater(ri));
+    Rows w = rows_of(q, ri, c4);
+#pragma unroll 4
+    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) y4[w.idx] = bn_apply(x4[w.idx], cb, bn.act);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm backward
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dz_terms(const f32x4& a, const f32x4& d, const Bn4& cb, int act, bool is_dz, float sc,
+                                         f32x4& dz, f32x4& xh) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xh[e] = (a[e] - cb.mu[e]) * cb.is[e];
+        float g = d[e];
+        if (!is_dz) {
+            g *= sc;
+            if (act) g *= ud_act_grad_fast(cb.ga[e] * xh[e] + cb.be[e], act);
+        }
+        dz[e] = g;
+    }
+}
+
+__global__ __launch_bounds__(NT) void normbwd_sums_kernel(RedGeom q, const float* __restrict__ x,
+                                                          const float* __restrict__ dy, const float* __restrict__ keep,
+                                                          float inv_keep, ud_bn_ref bn, int dy_is_dz,
+                                                          double* __restrict__ s1, double* __restrict__ s2,
+                                                          double* __restrict__ part) {
+    int ri, c4;
+    const bool active = thread_coords(q, ri, c4);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
+        const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
+        Rows w = rows_of(q, ri, c4);
+#pragma unroll 4
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+            f32x4 dz, xh;
+            dz_terms(x4[w.idx], d4[w.idx], cb, bn.act, dy_is_dz != 0, sc, dz, xh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += (double)dz[e];
+                v[4 + e] += (double)dz[e] * (double)xh[e];
+            }
+        }
+    }
+    red_out<8>(q, ri, active, c4, v, s1, s2, part, false);      // batch-norm sums: one set for all groups
+}
+
+// MIX: also the SF-mix gradient: acc += dd * (freq - spat)
+template <bool MIX>
+__global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const float* __restrict__ x,
+                                                           const float* __restrict__ dy, const float* __restrict__ keep,
+                                                           float inv_keep, ud_bn_ref bn, int dy_is_dz,
+                                                           const double* __restrict__ s1, const double* __restrict__ s2,
+                                                           const double* __restrict__ s1l, const double* __restrict__ s2l,
+                                                           const float* __restrict__ spat, const float* __restrict__ freq,
+                                                           float* __restrict__ dx, double* __restrict__ dalpha_acc,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    int ri, c4;
+    const bool active = thread_coords(q, ri, c4);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* sp4 = reinterpret_cast<const f32x4*>(spat);
+    const f32x4* fr4 = reinterpret_cast<const f32x4*>(freq);
+    f32x4* o4 = reinterpret_cast<f32x4*>(dx);
+    double acc = 0.0;
+    if (active) {
+        const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
+        const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
+        f32x4 t1, t2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t1[e] = (float)s1[c4 * 4 + e] * (float)bn.inv_count;
+            t2[e] = (float)s2[c4 * 4 + e] * (float)bn.inv_count;
+        }
+        if (is_updater(ri)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (dbeta) dbeta[c4 * 4 + e] = (float)s1l[c4 * 4 + e];
+                if (dgamma) dgamma[c4 * 4 + e] = (float)s2l[c4 * 4 + e];
+            }
+        }
+        Rows w = rows_of(q, ri, c4);
+#pragma unroll 4
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+            f32x4 dz, xh, o;
+            dz_terms(x4[w.idx], d4[w.idx], cb, bn.act, dy_is_dz != 0, sc, dz, xh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = cb.ga[e] * cb.is[e] * (dz[e] - t1[e] - xh[e] * t2[e]);
+            o4[w.idx] = o;
+            if (MIX) {
+                f32x4 s = sp4[w.idx], f = fr4[w.idx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc += (double)o[e] * ((double)f[e] - (double)s[e]);
+            }
+        }
+    }
+    if (MIX) {
+        __shared__ double sm[NT / 64];
+        acc = ud_wave_sum_d(acc);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < NT / 64; ++i) tot += sm[i];
+            // 64 slots: ~13 workgroups per address instead of ~800 queued on one
+            atomic_add_f64(dalpha_acc + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & 63), tot);
+        }
+    }
+}
+
+__global__ void gate_grad_from_acc_kernel(const double* __restrict__ acc, const float* __restrict__ alpha,
+                                          float* __restrict__ out) {
+    double t = ud_wave_sum_d(acc[threadIdx.x]);          // 64 slots, one lane each
+    if (threadIdx.x == 0) {
+        const double a = 1.0 / (1.0 + exp(-(double)alpha[0]));
+        out[0] = (float)(t * a * (1.0 - a));
+    }
+}
+
+// db = dc * sigmoid(s) + dpool * inv_hw;  dz = db * act'(bn(x));  sums
+__global__ __launch_bounds__(NT) void se_scale_bwd_bn_kernel(RedGeom q, const float* __restrict__ dc,
+                                                             const float* __restrict__ x, ud_bn_ref bn,
+                                                             const float* __restrict__ s, const float* __restrict__ dpool,
+                                                             float inv_hw, float* __restrict__ dzo,
+                                                             double* __restrict__ s1, double* __restrict__ s2,
+                                                             double* __restrict__ part) {
+    int ri, c4;
+    const bool active = thread_coords(q, ri, c4);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dc);
+    f32x4* o4 = reinterpret_cast<f32x4*>(dzo);
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
+        f32x4 gate = reinterpret_cast<const f32x4*>(s)[(long)blockIdx.z * q.C4 + c4];
+        f32x4 dp = reinterpret_cast<const f32x4*>(dpool)[(long)blockIdx.z * q.C4 + c4] * inv_hw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gate[e] = ud_sigmoid_fast(gate[e]);
+        Rows w = rows_of(q, ri, c4);
+#pragma unroll 4
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+            f32x4 a = x4[w.idx], d = d4[w.idx], dz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (a[e] - cb.mu[e]) * cb.is[e];
+                float g = d[e] * gate[e] + dp[e];
+                if (bn.act) g *= ud_act_grad_fast(cb.ga[e] * xh + cb.be[e], bn.act);
+                dz[e] = g;
+                v[e] += (double)g;
+                v[4 + e] += (double)g * (double)xh;
+            }
+            o4[w.idx] = dz;
+        }
+    }
+    red_out<8>(q, ri, active, c4, v, s1, s2, part, false);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SE backward FCs
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpre_of(const double* dgate, const float* s2, long i) {
+    const float g = ud_sigmoid_fast(s2[i]);
+    return (float)dgate[i] * g * (1.f - g);
+}
+
+// blocks [0, N * chunks): sample n, chunk of 256 channels: ds1_acc[n][i] += sum_{c in chunk} dpre[n][c] We[c][i]
+//            (dpre of the chunk staged in LDS; threads = (i, channel slice); fp64 atomics, C / 256 adds per address)
+// blocks beyond: dW_e[c][i] = sum_n dpre[n][c] swish(s1[n][i]), db_e[c] = sum_n dpre[n][c] for NT / IP channels each
+template <int IP>
+__global__ __launch_bounds__(NT) void se_bwd_a_kernel(const double* __restrict__ dgate, const float* __restrict__ s2,
+                                                      const float* __restrict__ s1, const float* __restrict__ We,
+                                                      double* __restrict__ ds1_acc, float* __restrict__ dWe,
+                                                      float* __restrict__ dbe, int N, int C, int Cs) {
+    constexpr int NSL = NT / IP;
+    __shared__ float sh[NT];
+    __shared__ float red[NT];
+    const int i = threadIdx.x % IP, sl = threadIdx.x / IP;
+    const int chunks = (C + NT - 1) / NT;
+    if ((int)blockIdx.x < N * chunks) {
+        const int n = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * NT;
+        const int cn = min(NT, C - c0);
+        if ((int)threadIdx.x < cn) sh[threadIdx.x] = dpre_of(dgate, s2, (long)n * C + c0 + threadIdx.x);
+        __syncthreads();
+        float acc = 0.f;
+        if (i < Cs) {
+#pragma unroll 4
+            for (int c = sl; c < cn; c += NSL) acc += sh[c] * We[(long)(c0 + c) * Cs + i];
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (sl == 0 && i < Cs) {
+            for (int k = 1; k < NSL; ++k) acc += red[k * IP + i];
+            unsafeAtomicAdd(ds1_acc + (long)n * Cs + i, (double)acc);
+        }
+        return;
+    }
+    // weight gradient: the block's NSL channels x all i
+    const int wb = blockIdx.x - N * chunks;
+    const int c = wb * NSL + sl;
+    const bool own = c < C && i < Cs;
+    float acc = 0.f, accb = 0.f;
+    for (int n0 = 0; n0 < N; n0 += IP) {                          // IP samples per round: sh[channel slot][sample]
+        const int nn = min(IP, N - n0);
+        __syncthreads();
+        {
+            const int cc = c;                                     // thread (i, sl) stages sample n0 + i of channel slot sl
+            sh[sl * IP + i] = (cc < C && i < nn) ? dpre_of(dgate, s2, (long)(n0 + i) * C + cc) : 0.f;
+        }
+        __syncthreads();
+        if (own) {
+#pragma unroll 8
+            for (int n = 0; n < nn; ++n) {
+                const float g = sh[sl * IP + n];
+                acc += g * ud_act_fast(s1[(long)(n0 + n) * Cs + i], 1);
+                accb += g;
+            }
+        }
+    }
+    if (!own) return;
+    dWe[(long)c * Cs + i] = acc;
+    if (i == 0) dbe[c] = accb;
+}
+
+// ds1[n][i] = ds1_acc[n][i] * swish'(s1[n][i]).  grid (x, y):
+//   y <  N : dpool[n][c] = sum_i ds1[n][i] Wr[i][c] for sample n = y, channels x * 256 ..
+//   y >= N : i = y - N: dW_r[i][c] = sum_n ds1[n][i] pool[n][c] * pool_scale;  db_r[i] = sum_n ds1[n][i]
+__global__ __launch_bounds__(NT) void se_bwd_b_kernel(const double* __restrict__ ds1_acc, const float* __restrict__ s1,
+                                                      const float* __restrict__ Wr, const double* __restrict__ pool,
+                                                      float pool_scale, float* __restrict__ dpool,
+                                                      float* __restrict__ dWr, float* __restrict__ dbr, int N, int C,
+                                                      int Cs) {
+    __shared__ float sh[NT];
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if ((int)blockIdx.y < N) {
+        const int n = blockIdx.y;
+        if ((int)threadIdx.x < Cs)
+            sh[threadIdx.x] = (float)ds1_acc[(long)n * Cs + threadIdx.x] * ud_act_grad_fast(s1[(long)n * Cs + threadIdx.x], 1);
+        __syncthreads();
+        if (c >= C) return;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < Cs; ++i) acc += sh[i] * Wr[(long)i * C + c];
+        dpool[(long)n * C + c] = acc;
+        return;
+    }
+    const int i = blockIdx.y - N;
+    if ((int)threadIdx.x < N)
+        sh[threadIdx.x] = (float)ds1_acc[(long)threadIdx.x * Cs + i] * ud_act_grad_fast(s1[(long)threadIdx.x * Cs + i], 1);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float b = 0.f;
+        for (int n = 0; n < N; ++n) b += sh[n];
+        dbr[i] = b;
+    }
+    if (c >= C) return;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) acc += sh[n] * ((float)pool[(long)n * C + c] * pool_scale);
+    dWr[(long)i * C + c] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// depthwise conv with a deferred BatchNorm on its input (forward) / behind its data gradient (backward)
+// Column-owning decomposition over "items": forward items = (n, ho, strip of TW output columns).
+// ---------------------------------------------------------------------------------------------------------
+struct DwGeom {
+    int N, H, W, C4, Ho, Wo, stride, pad_t, pad_l;
+};
+constexpr int TW = 8;
+
+// Data gradient.  STRIP (stride 1): items = (n, h, strip of TW input columns); otherwise one input pixel per item.
+// BN: push the result through act'(bn(x)) of the conv's input and accumulate the BatchNorm backward sums.
+template <int K, bool STRIP, bool BN>
+__global__ __launch_bounds__(NT) void dw_bwd_data_ex_kernel(RedGeom q, DwGeom d, const float* __restrict__ dy,
+                                                            const float* __restrict__ gate_alpha, int gate_mode,
+                                                            const float* __restrict__ wt, const float* __restrict__ add,
+                                                            const float* __restrict__ x, ud_bn_ref bn,
+                                                            float* __restrict__ out, double* __restrict__ s1,
+                                                            double* __restrict__ s2, double* __restrict__ part) {
+    constexpr int TWB = STRIP ? TW : 1;
+    constexpr int NCOL = TWB + K - 1;
+    int ri, c4;
+    const bool active = thread_coords(q, ri, c4);
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
+    const f32x4* add4 = reinterpret_cast<const f32x4*>(add);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        Bn4 cb;
+        if (BN) cb = bn_load(bn, 0, q.C4, c4, false);
+        const float gs = gate_factor(gate_alpha, gate_mode);
+        const int WB = (d.W + TWB - 1) / TWB;
+        Rows it = rows_of(q, ri, c4);
+        for (; it.r < it.r_end; it.r += q.rpi) {
+            const int wb = it.r % WB;
+            const int t2 = it.r / WB;
+            const int h = t2 % d.H, n = t2 / d.H;
+            const int w0 = wb * TWB;
+            f32x4 acc[TWB];
+#pragma unroll
+            for (int t = 0; t < TWB; ++t) acc[t] = f32x4{0, 0, 0, 0};
+            if (STRIP) {
+                const int col0 = w0 + d.pad_l - (K - 1);          // dy column of window slot 0
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    const int ho = h + d.pad_t - kh;
+                    if (ho < 0 || ho >= d.Ho) continue;
+                    const f32x4* row = dy4 + (((long)n * d.Ho + ho) * d.Wo) * q.C4 + c4;
+                    f32x4 g[NCOL], w[K];
+#pragma unroll
+                    for (int j = 0; j < NCOL; ++j) {
+                        const int wo = col0 + j;
+                        g[j] = (wo >= 0 && wo < d.Wo) ? row[(long)wo * q.C4] : f32x4{0, 0, 0, 0};
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) w[kw] = w4[(kh * K + kw) * q.C4 + c4];
+#pragma unroll
+                    for (int t = 0; t < TWB; ++t)
+#pragma unroll
+                        for (int kw = 0; kw < K; ++kw) acc[t] += g[t - kw + K - 1] * w[kw];
+                }
+            } else {
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    const int th = h + d.pad_t - kh;
+                    if (th < 0 || (th % d.stride) != 0) continue;
+                    const int ho = th / d.stride;
+                    if (ho >= d.Ho) continue;
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) {
+                        const int tw = w0 + d.pad_l - kw;
+                        if (tw < 0 || (tw % d.stride) != 0) continue;
+                        const int wo = tw / d.stride;
+                        if (wo >= d.Wo) continue;
+                        acc[0] += dy4[(((long)n * d.Ho + ho) * d.Wo + wo) * q.C4 + c4] * w4[(kh * K + kw) * q.C4 + c4];
+                    }
+                }
+            }
+            const long o0 = (((long)n * d.H + h) * d.W + w0) * q.C4 + c4;
+#pragma unroll
+            for (int t = 0; t < TWB; ++t) {
+                if (w0 + t >= d.W) continue;
+                const long o = o0 + (long)t * q.C4;
+                f32x4 da = acc[t] * gs;
+                if (add) da += add4[o];
+                if (BN) {
+                    const f32x4 a = x4[o];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (a[e] - cb.mu[e]) * cb.is[e];
+                        float g = da[e];
+                        if (bn.act) g *= ud_act_grad_fast(cb.ga[e] * xh + cb.be[e], bn.act);
+                        da[e] = g;
+                        v[e] += (double)g;
+                        v[4 + e] += (double)g * (double)xh;
+                    }
+                }
+                o4[o] = da;
+            }
+        }
+    }
+    if (BN) red_out<8>(q, ri, active, c4, v, s1, s2, part, false);
+}
+
+// Weight gradient, sliding-window form (as dwconv.hip:dw_bwd_weight_rows; its finalize below applies the gate factor).
+// x is the MATERIALISED activated input: re-evaluating a deferred swish for every window load made this kernel 5x slower.
+template <int K, int S>
+__global__ void dw_bwd_weight_rows_ex(DwGeom q, int C, int rows_per_group, const float* __restrict__ x,
+                                      const float* __restrict__ dy, float* __restrict__ part) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int p = blockIdx.x;
+    const int rows_total = q.N * q.Ho;
+    const int row0 = p * rows_per_group;
+    int row1 = row0 + rows_per_group;
+    if (row1 > rows_total) row1 = rows_total;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int row = row0; row < row1; ++row) {
+        const int n = row / q.Ho, ho = row % q.Ho;
+        const int ih0 = ho * S - q.pad_t;
+        const float* xr[K];
+        bool vh[K];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = ih0 + kh;
+            vh[kh] = (ih >= 0) && (ih < q.H);
+            xr[kh] = x + (((long)n * q.H + (vh[kh] ? ih : 0)) * q.W) * C + c;
+        }
+        float w[K][K];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int iw = kw - q.pad_l;
+                w[kh][kw] = (vh[kh] && iw >= 0 && iw < q.W) ? xr[kh][(long)iw * C] : 0.f;
+            }
+        const float* dyr = dy + ((long)row * q.Wo) * C + c;
+#pragma unroll 4
+        for (int wo = 0; wo < q.Wo; ++wo) {
+            const float g = dyr[(long)wo * C];
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) acc[kh * K + kw] += g * w[kh][kw];
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw + S < K; ++kw) w[kh][kw] = w[kh][kw + S];
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+                    const int iw = (wo + 1) * S - q.pad_l + (K - S) + j;
+                    w[kh][K - S + j] = (vh[kh] && iw >= 0 && iw < q.W) ? xr[kh][(long)iw * C] : 0.f;
+                }
+            }
+        }
+    }
+    float* out = part + (long)p * (K * K) * C + c;
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) out[(long)i * C] = acc[i];
+}
+
+// 64 lanes per output (4 partials in flight per lane), fp64 accumulation; result in the parameter's layout
+// dw[C][K*K], scaled by the gate
+__global__ __launch_bounds__(NT) void dw_bwd_weight_finalize_ex(int nparts, int KK, int C, const float* __restrict__ part,
+                                                                const float* __restrict__ gate_alpha, int gate_mode,
+                                                                float* __restrict__ dw) {
+    const int KKC = KK * C;
+    // a wave owns 64 consecutive outputs for a slice of the parts; 4 waves = 4 slices, folded through LDS
+    __shared__ double sm[NT];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    double a = 0.0;
+    if (i < KKC) {
+        int p = sl;
+        for (; p + 12 < nparts; p += 16) {
+            const float a0 = part[(long)p * KKC + i], a1 = part[(long)(p + 4) * KKC + i];
+            const float a2 = part[(long)(p + 8) * KKC + i], a3 = part[(long)(p + 12) * KKC + i];
+            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        }
+        for (; p < nparts; p += 4) a += (double)part[(long)p * KKC + i];
+    }
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (sl == 0 && i < KKC) {
+        a += sm[64 + lane] + sm[128 + lane] + sm[192 + lane];
+        const int tap = i / C, c = i % C;
+        dw[(long)c * KK + tap] = (float)(a * (double)gate_factor(gate_alpha, gate_mode));
+    }
+}
+
+inline bool dw_geom_ok(const DwGeom& q, int K) {
+    return q.N > 0 && q.H > 0 && q.W > 0 && q.C4 > 0 && q.Ho > 0 && q.Wo > 0 && (q.stride == 1 || q.stride == 2) &&
+           (K == 3 || K == 5);
+}
+
+inline bool shape_ok(int G, int R, int C) { return G >= 1 && R >= 1 && C >= 4 && C % 4 == 0; }
+
+// Reducing kernels: one launch with fp64 atomics while at most 64 workgroups add to the same addresses (about
+// 12 ns per add and address, serialised: a sub-microsecond tail); otherwise the two-launch form with fp64 partials in
+// the caller's scratch `ws` (ud_fused_reduce_ws_doubles) — on the large early-stage tensors the finalize launch is
+// noise, on the small late-stage ones the single launch halves the launch count.
+struct RedPlan {
+    RedGeom q;
+    bool use_part;
+};
+inline RedPlan plan_reduce(int G, int R, int C, bool per_group, const double* ws, int min_rows = 8) {
+    RedGeom qa = make_geom_ex(G, R, C, 1024, 64, min_rows);
+    const long contrib = per_group ? qa.P : (long)qa.G * qa.P;
+    // >= 16 MB: the pass is bandwidth-bound and wants ~2000 workgroups; its finalize launch is noise
+    const bool big = (long)G * R * (C / 4) >= (1L << 20);
+    if ((contrib <= 64 && !big) || !ws) return RedPlan{qa, false};
+    return RedPlan{make_geom_ex(G, R, C, 2048, 512, min_rows), true};
+}
+inline int finish_reduce(const RedPlan& pl, int nq, bool per_group, int C, const double* ws, double* a1, double* a2,
+                         hipStream_t s) {
+    if (!pl.use_part) return 0;
+    const int G = per_group ? pl.q.G : 1;
+    const int P = per_group ? pl.q.P : pl.q.G * pl.q.P;
+    hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv((long)G * C, 16)), dim3(NT), 0, s, nq, G, C, P, ws, a1, a2);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+inline RedGeom geom_ew(int G, int R, int C, int min_rows = 4) { return make_geom_ex(G, R, C, 2048, 4096, min_rows); }
+
+}  // namespace
+
+extern "C" {
+
+// doubles of scratch the reducing entry points below may need for their two-launch form (0: single launch)
+long ud_fused_reduce_ws_doubles(int G, int R, int C, int per_group, int min_rows) {
+    if (!shape_ok(G, R, C) || min_rows < 1) return UD_EINVAL;
+    static double dummy;
+    RedPlan pl = plan_reduce(G, R, C, per_group != 0, &dummy, min_rows);
+    return pl.use_part ? 2L * pl.q.G * pl.q.P * C : 0;
+}
+
+int ud_colstats(const float* x, int G, int R, int C, double* sum, double* sumsq, double* ws, ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !sum || !sumsq) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    RedPlan pl = plan_reduce(G, R, C, true, ws);
+    hipLaunchKernelGGL(colstats_kernel, red_grid(pl.q), dim3(NT), 0, s, pl.q, x, sum, sumsq, pl.use_part ? ws : nullptr);
+    UD_LAUNCH_CHECK();
+    return finish_reduce(pl, 2, true, C, ws, sum, sumsq, s);
+}
+
+int ud_colsum_bn(const float* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
+                 ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !bn || !out) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    RedPlan pl = plan_reduce(G, R, C, true, ws);
+    hipLaunchKernelGGL(colsum_bn_kernel<false>, red_grid(pl.q), dim3(NT), 0, s, pl.q, x, nullptr, *bn, out,
+                       pl.use_part ? ws : nullptr);
+    UD_LAUNCH_CHECK();
+    return finish_reduce(pl, 1, true, C, ws, out, nullptr, s);
+}
+
+int ud_coldot_bn(const float* dy, const float* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
+                 ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !dy || !bn || !out) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    RedPlan pl = plan_reduce(G, R, C, true, ws);
+    hipLaunchKernelGGL(colsum_bn_kernel<true>, red_grid(pl.q), dim3(NT), 0, s, pl.q, x, dy, *bn, out,
+                       pl.use_part ? ws : nullptr);
+    UD_LAUNCH_CHECK();
+    return finish_reduce(pl, 1, true, C, ws, out, nullptr, s);
+}
+
+int ud_fc_fwd_d(const double* xsum, float xscale, const float* W, const float* b, float* y, int N, int I, int O,
+                ud_stream_t stream) {
+    if (N < 1 || I < 1 || O < 1 || !xsum || !W || !y) return UD_EINVAL;
+    long waves = (long)N * O;
+    hipLaunchKernelGGL(fc_fwd_d_kernel, dim3(ud_cdiv(waves * 64, NT)), dim3(NT), 0, (hipStream_t)stream, xsum, xscale, W,
+                       b, y, N, I, O);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_bn_apply(const float* x, const ud_bn_ref* bn, float* y, int G, int R, int C, ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !bn || !y) return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL(bn_apply_kernel, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, *bn, y);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_se_scale_bn(const float* x, const ud_bn_ref* bn, const float* s, float* y, int G, int R, int C,
+                   ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !bn || !s || !y) return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL(se_scale_bn_kernel, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, *bn, s, y);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_residual_bn(const float* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const float* skip,
+                   float* out, int G, int R, int C, ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !bn || !out) return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL(residual_bn_kernel, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, *bn, keep, inv_keep,
+                       skip, out);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_normbwd_sums(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                    int dy_is_dz, int G, int R, int C, double* s1, double* s2, double* ws, ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !dy || !bn || !s1 || !s2 || bn->G != 1) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    RedPlan pl = plan_reduce(G, R, C, false, ws);
+    hipLaunchKernelGGL(normbwd_sums_kernel, red_grid(pl.q), dim3(NT), 0, s, pl.q, x, dy, keep, inv_keep, *bn, dy_is_dz,
+                       s1, s2, pl.use_part ? ws : nullptr);
+    UD_LAUNCH_CHECK();
+    return finish_reduce(pl, 2, false, C, ws, s1, s2, s);
+}
+
+int ud_normbwd_apply(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                     int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
+                     const double* s2_local, int G, int R, int C, float* dx, float* dgamma, float* dbeta,
+                     ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !dy || !bn || !s1 || !s2 || !dx || bn->G != 1) return UD_EINVAL;
+    if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL(normbwd_apply_kernel<false>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, dy, keep,
+                       inv_keep, *bn, dy_is_dz, s1, s2, s1_local, s2_local, nullptr, nullptr, dx, nullptr, dgamma,
+                       dbeta);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_normbwd_apply_mix(const float* x, const float* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
+                         const double* s1_local, const double* s2_local, const float* spat, const float* freq,
+                         int G, int R, int C, float* dd, double* dalpha_acc, float* dgamma, float* dbeta,
+                         ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !dz || !bn || !s1 || !s2 || !dd || !spat || !freq || !dalpha_acc || bn->G != 1)
+        return UD_EINVAL;
+    if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
+    RedGeom q = make_geom_ex(G, R, C, 512, 4096, 4);      // one fp64 atomic per workgroup onto dalpha_acc
+    hipLaunchKernelGGL(normbwd_apply_kernel<true>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, dz, nullptr,
+                       1.f, *bn, 1, s1, s2, s1_local, s2_local, spat, freq, dd, dalpha_acc, dgamma, dbeta);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_gate_grad_from_acc(const double* acc, const float* alpha, float* out, ud_stream_t stream) {
+    if (!acc || !alpha || !out) return UD_EINVAL;
+    hipLaunchKernelGGL(gate_grad_from_acc_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, alpha, out);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_se_bwd_a(const double* dgate, const float* s2, const float* s1, const float* We, double* ds1_acc, float* dWe,
+                float* dbe, int N, int C, int Cs, ud_stream_t stream) {
+    if (N < 1 || C < 1 || Cs < 1 || Cs > 128 || !dgate || !s2 || !s1 || !We || !ds1_acc || !dWe || !dbe) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int role1 = N * ud_cdiv(C, NT);
+    if (Cs <= 64) {
+        dim3 grid((unsigned)(role1 + ud_cdiv(C, NT / 64)));
+        hipLaunchKernelGGL(se_bwd_a_kernel<64>, grid, dim3(NT), 0, s, dgate, s2, s1, We, ds1_acc, dWe, dbe, N, C, Cs);
+    } else {
+        dim3 grid((unsigned)(role1 + ud_cdiv(C, NT / 128)));
+        hipLaunchKernelGGL(se_bwd_a_kernel<128>, grid, dim3(NT), 0, s, dgate, s2, s1, We, ds1_acc, dWe, dbe, N, C, Cs);
+    }
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_se_bwd_b(const double* ds1_acc, const float* s1, const float* Wr, const double* pool, float pool_scale,
+                float* dpool, float* dWr, float* dbr, int N, int C, int Cs, ud_stream_t stream) {
+    if (N < 1 || N > NT || C < 1 || Cs < 1 || Cs > NT || !ds1_acc || !s1 || !Wr || !pool || !dpool || !dWr || !dbr)
+        return UD_EINVAL;
+    dim3 grid((unsigned)ud_cdiv(C, NT), (unsigned)(N + Cs));
+    hipLaunchKernelGGL(se_bwd_b_kernel, grid, dim3(NT), 0, (hipStream_t)stream, ds1_acc, s1, Wr, pool, pool_scale, dpool,
+                       dWr, dbr, N, C, Cs);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_se_scale_bwd_bn(const float* dc, const float* x, const ud_bn_ref* bn, const float* s, const float* dpool,
+                       float inv_hw, float* dz, double* s1, double* s2, double* ws, int G, int R, int C,
+                       ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !dc || !x || !bn || !s || !dpool || !dz || !s1 || !s2 || bn->G != 1) return UD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    RedPlan pl = plan_reduce(G, R, C, false, ws);
+    hipLaunchKernelGGL(se_scale_bwd_bn_kernel, red_grid(pl.q), dim3(NT), 0, st, pl.q, dc, x, *bn, s, dpool, inv_hw, dz,
+                       s1, s2, pl.use_part ? ws : nullptr);
+    UD_LAUNCH_CHECK();
+    return finish_reduce(pl, 2, false, C, ws, s1, s2, st);
+}
+
+// items of the depthwise data-gradient kernels (rows of their column-owning decomposition) and its scratch need
+static long dw_bwd_items(int N, int H, int W, int stride) {
+    return stride == 1 ? (long)N * H * ((W + TW - 1) / TW) : (long)N * H * W;
+}
+long ud_dwconv_bwd_data_bn_ws_doubles(int N, int H, int W, int C, int stride) {
+    const long items = dw_bwd_items(N, H, W, stride);
+    if (items < 1 || items > 0x7fffffffL || C % 4) return UD_EINVAL;
+    return ud_fused_reduce_ws_doubles(1, (int)items, C, 0, stride == 1 ? 1 : 4);
+}
+
+static int dw_bwd_data_launch(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
+                              const float* x, const ud_bn_ref* bn, float* out, double* s1, double* s2, double* ws, int N,
+                              int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, hipStream_t s) {
+    if (C % 4 || !dy || !wt || !out) return UD_EINVAL;
+    DwGeom d{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
+    if (!dw_geom_ok(d, K)) return UD_EINVAL;
+    const bool strip = stride == 1;
+    const long items = dw_bwd_items(N, H, W, stride);
+    if (items > 0x7fffffffL) return UD_EINVAL;
+    ud_bn_ref none{};
+    const bool has_bn = bn != nullptr;
+    if (has_bn && (!x || !s1 || !s2 || bn->G != 1)) return UD_EINVAL;
+    RedPlan pl{make_geom_ex(1, (int)items, C, 2048, 8192, strip ? 1 : 4), false};
+    if (has_bn) pl = plan_reduce(1, (int)items, C, false, ws, strip ? 1 : 4);
+    const RedGeom& q = pl.q;
+    double* part = pl.use_part ? ws : nullptr;
+    const ud_bn_ref& b = has_bn ? *bn : none;
+#define UD_DW_BWD(KK, ST, BB)                                                                                        \
+    hipLaunchKernelGGL((dw_bwd_data_ex_kernel<KK, ST, BB>), red_grid(q), dim3(NT), 0, s, q, d, dy, gate_alpha,       \
+                       gate_mode, wt, add, x, b, out, s1, s2, part)
+    if (K == 3) {
+        if (strip) { if (has_bn) UD_DW_BWD(3, true, true); else UD_DW_BWD(3, true, false); }
+        else { if (has_bn) UD_DW_BWD(3, false, true); else UD_DW_BWD(3, false, false); }
+    } else {
+        if (strip) { if (has_bn) UD_DW_BWD(5, true, true); else UD_DW_BWD(5, true, false); }
+        else { if (has_bn) UD_DW_BWD(5, false, true); else UD_DW_BWD(5, false, false); }
+    }
+#undef UD_DW_BWD
+    UD_LAUNCH_CHECK();
+    return has_bn ? finish_reduce(pl, 2, false, C, ws, s1, s2, s) : 0;
+}
+
+int ud_dwconv_bwd_data_bn(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
+                          const float* x, const ud_bn_ref* bn, float* dz, double* s1, double* s2, double* ws, int N,
+                          int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l,
+                          ud_stream_t stream) {
+    if (!bn) return UD_EINVAL;
+    return dw_bwd_data_launch(dy, gate_alpha, gate_mode, wt, add, x, bn, dz, s1, s2, ws, N, H, W, C, Ho, Wo, K, stride,
+                              pad_t, pad_l, (hipStream_t)stream);
+}
+
+int ud_dwconv_bwd_data_ex(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
+                          float* dx, int N, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t,
+                          int pad_l, ud_stream_t stream) {
+    return dw_bwd_data_launch(dy, gate_alpha, gate_mode, wt, add, nullptr, nullptr, dx, nullptr, nullptr, nullptr, N, H, W,
+                              C, Ho, Wo, K, stride, pad_t, pad_l, (hipStream_t)stream);
+}
+
+int ud_dwconv_bwd_weight_ex(const float* x, const float* dy, const float* gate_alpha, int gate_mode, float* dwt,
+                            float* part, int chunks, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                            int pad_t, int pad_l, ud_stream_t stream) {
+    if (C % 4 || chunks < 1 || !x || !dy || !dwt || !part) return UD_EINVAL;
+    DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
+    if (!dw_geom_ok(q, K)) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows_total = N * Ho;
+    if (chunks > rows_total) return UD_EINVAL;
+    const int rpg = (rows_total + chunks - 1) / chunks;
+    int bt = ((C < NT ? C : NT) + 63) / 64 * 64;
+    dim3 grid((unsigned)chunks, (unsigned)ud_cdiv(C, bt), 1);
+#define UD_DW_WG(KK, SS) hipLaunchKernelGGL((dw_bwd_weight_rows_ex<KK, SS>), grid, dim3(bt), 0, s, q, C, rpg, x, dy, part)
+    if (K == 3 && stride == 1) UD_DW_WG(3, 1);
+    else if (K == 3) UD_DW_WG(3, 2);
+    else if (stride == 1) UD_DW_WG(5, 1);
+    else UD_DW_WG(5, 2);
+#undef UD_DW_WG
+    UD_LAUNCH_CHECK();
+    const int KKC = K * K * C;
+    hipLaunchKernelGGL(dw_bwd_weight_finalize_ex, dim3(ud_cdiv(KKC, 64)), dim3(NT), 0, s, chunks, K * K, C, part,
+                       gate_alpha, gate_mode, dwt);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

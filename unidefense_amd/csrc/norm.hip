@@ -13,46 +13,11 @@
 // the kernels are bandwidth bound), no atomics: deterministic.
 // A single-launch variant (fp64 atomics + "last workgroup finalizes" ticket) was measured and dropped: on this
 // multi-XCD part the device-scope fence every workgroup needs costs more than the second launch (3-6x slower).
-#include <stdlib.h>
-
-#include "ud_common.h"
+#include "colgeom.h"
 
 namespace {
 
-constexpr int NT = 256;
-
-struct RedGeom {
-    int G, R, C4, P;      // groups, rows per group, float4 channels, row-chunks per group
-    int CW;               // float4 columns per workgroup (<= 16 by default)
-    int rpi;              // rows per block iteration = NT / CW
-    int rows_per_chunk;
-};
-
-__device__ __forceinline__ bool thread_coords(const RedGeom& q, int& ri, int& c4) {
-    int t = threadIdx.x;
-    ri = t / q.CW;
-    c4 = blockIdx.y * q.CW + t % q.CW;
-    return ri < q.rpi && c4 < q.C4;
-}
-
-// fold the row-lanes of a block: v[NQ] per thread -> thread (ri == 0) holds the block total
-template <int NQ>
-__device__ __forceinline__ void block_fold(const RedGeom& q, int ri, bool active, double (&v)[8]) {
-    if (q.rpi == 1) return;
-    __shared__ double sm[NT * NQ];
-    if (active) {
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) sm[threadIdx.x * NQ + i] = v[i];
-    }
-    __syncthreads();
-    if (active && ri == 0) {
-        for (int r = 1; r < q.rpi; ++r) {
-            int t = r * q.CW + (int)threadIdx.x;          // ri == 0: threadIdx.x is the column lane
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) v[i] += sm[t * NQ + i];
-        }
-    }
-}
+constexpr int NT = UD_COL_NT;
 
 enum { RED_STATS = 0, RED_NORMBWD = 1, RED_SUM = 2, RED_DOT = 3 };
 
@@ -325,30 +290,6 @@ __global__ __launch_bounds__(NT) void norm_apply_bwd(long total4, int R, int C4,
         dx4[e] = o;
     }
 }
-
-// Decomposition: a workgroup owns CW float4 columns (<= 128 channels) and one row-chunk; ~2048 workgroups,
-// >= 8 rows per thread where the tensor allows.
-RedGeom make_geom(int G, int R, int C) {
-    RedGeom q;
-    q.G = G; q.R = R; q.C4 = C / 4;
-    // float4 columns per workgroup: 16 (256-byte row segments, 16 rows per iteration) measured best on the bench
-    // (8: +0.4 %, 32: +0.4 %, 64: +0.5 %, 128: +1.1 % step time); UD_RED_CW overrides
-    static const int cw_max = getenv("UD_RED_CW") ? atoi(getenv("UD_RED_CW")) : 16;
-    q.CW = q.C4 < cw_max ? q.C4 : cw_max;
-    q.rpi = NT / q.CW;
-    const int cgroups = (q.C4 + q.CW - 1) / q.CW;
-    long want = 2048 / ((long)G * cgroups);
-    if (want < 1) want = 1;
-    long maxp = (R + (long)q.rpi * 8 - 1) / ((long)q.rpi * 8);
-    if (maxp < 1) maxp = 1;
-    long P = want < maxp ? want : maxp;
-    if (P > 512) P = 512;         // the finalize folds P partials per channel: keep its chain short
-    q.P = (int)P;
-    q.rows_per_chunk = (R + q.P - 1) / q.P;
-    return q;
-}
-
-dim3 red_grid(const RedGeom& q) { return dim3((unsigned)q.P, (unsigned)((q.C4 + q.CW - 1) / q.CW), (unsigned)q.G); }
 
 int ew_blocks(long total4) {
     long b = (total4 + NT - 1) / NT;

@@ -24,6 +24,22 @@ __device__ __forceinline__ float ud_swish_grad(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 
+// Fast forms for the fused kernels, where the activation is RE-evaluated by every consumer of a deferred BatchNorm and
+// the ALU work is no longer free: v_exp_f32 + v_rcp_f32 (about 1e-6 relative) instead of expf + an IEEE division.
+__device__ __forceinline__ float ud_sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+}
+__device__ __forceinline__ float ud_act_fast(float z, int act) {
+    return act == 1 ? z * ud_sigmoid_fast(z) : (act == 2 ? fmaxf(z, 0.f) : z);
+}
+__device__ __forceinline__ float ud_act_grad_fast(float z, int act) {
+    if (act == 1) {
+        const float s = ud_sigmoid_fast(z);
+        return s * (1.0f + z * (1.0f - s));
+    }
+    return act == 2 ? (z > 0.f ? 1.f : 0.f) : 1.f;
+}
+
 // act: 0 identity, 1 swish, 2 ReLU
 __device__ __forceinline__ float ud_act(float z, int act) {
     return act == 1 ? ud_swish(z) : (act == 2 ? fmaxf(z, 0.f) : z);

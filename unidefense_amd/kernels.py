@@ -55,6 +55,27 @@ _ZERO_POOL = {}
 
 def reset_zero_pool():
     _ZERO_POOL.clear()
+    _ZERO64_POOL.clear()
+
+
+# fp64 accumulators of the fused path (BatchNorm sums, SE pooling sums, gate gradients): carved from zero blocks the
+# same way — one fill per block instead of one per accumulator (~10 accumulators per MBConv block and pass).
+_ZERO64_BLOCK = int(os.environ.get("UD_ZERO64_BLOCK", str(1 << 20)))        # doubles per block (8 MB)
+_ZERO64_POOL = {}
+
+
+def zeros64(n, like):
+    """n zero-initialised doubles (a view; never recycled within a forward / backward)."""
+    n = int(n)
+    key = like.device.index
+    st = _ZERO64_POOL.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if st is None or st[1] + n > st[0].numel() or st[2] != capturing:
+        st = _ZERO64_POOL[key] = [torch.zeros(max(_ZERO64_BLOCK, n), dtype=torch.float64, device=like.device), 0,
+                                  capturing]
+    out = st[0][st[1]:st[1] + n]
+    st[1] += (n + 31) // 32 * 32
+    return out
 
 
 def zeros(shape, like):
@@ -156,22 +177,30 @@ def gemm_nn(a, w, out=None, accumulate=False):
     M, K = a.shape
     N = w.shape[1]
     assert w.shape[0] == K
-    if out is None:
+    if out is None or accumulate:
+        # accumulate: `out` already holds a term of the same gradient (the skip branch's): the plain part adds into
+        # it (out_mode 1), the split-K parts add atomically onto it — no zero fill, no separate axpby pass
+        acc = out is not None
         plan = _tail_plan(M, N, K)
         if plan is not None:
             m1, split = plan
-            out = empty((M, N), a)
-            _gemm(a, w, out, m1, N, K, K, N, N, 0, 1, 0)
+            if not acc:
+                out = empty((M, N), a)
+            _gemm(a, w, out, m1, N, K, K, N, N, 0, 1, 1 if acc else 0)
             tail = out[m1:]
-            tail.zero_()
+            if not acc:
+                tail.zero_()
             _gemm(a[m1:], w, tail, M - m1, N, K, K, N, N, 0, 1, 2, split)
             return out
         split = _fwd_split(M, N, K)
         if split > 1:
-            out = zeros((M, N), a)
+            if not acc:
+                out = zeros((M, N), a)
             return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 2, split)
-        out = empty((M, N), a)
-    return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if accumulate else 0)
+        if not acc:
+            out = empty((M, N), a)
+        return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if acc else 0)
+    return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 0)
 
 
 _WG_SPLIT_MAXT = int(os.environ.get("UD_WG_SPLIT_MAXT", "512"))
@@ -943,3 +972,231 @@ def affine3(x, M):
     out = torch.empty_like(x)
     _call("ud_affine3", _p(x), _p(M), _p(out), x.shape[0], x.shape[-1] * x.shape[-2], _stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# fused MBConv path: deferred BatchNorm (csrc/fused.hip; include/unidefense_hip.h "deferred normalisation")
+# ---------------------------------------------------------------------------------------------
+from .lib import BnRef      # noqa: E402
+
+
+class DeferredBN:
+    """A training-mode BatchNorm that is never applied as a pass of its own: `acc` holds [sum | sumsq] (2C doubles,
+    zero until the producer's kernels add into it), consumers apply act(gamma (x - mean) invstd + beta) on load."""
+
+    def __init__(self, acc, C, count, gamma, beta, eps, act, momentum=0.0, running_mean=None, running_var=None):
+        self.acc, self.C, self.count = acc, C, float(count)
+        self.gamma, self.beta, self.eps, self.act = gamma, beta, float(eps), int(act)
+        self.momentum, self.running_mean, self.running_var = float(momentum), running_mean, running_var
+        self._update_pending = running_mean is not None
+
+    def ref(self, update=False):
+        """ctypes struct for a kernel call.  update=True hands the running statistics to THIS call (the kernel moves
+        them once); every BatchNorm's first consumer does so, later ones must not."""
+        r = BnRef()
+        r.sum, r.sumsq = self.acc.data_ptr(), self.acc.data_ptr() + 8 * self.C
+        r.gamma, r.beta = self.gamma.data_ptr(), self.beta.data_ptr()
+        r.inv_count = 1.0 / self.count
+        r.unbias = self.count / (self.count - 1.0) if self.count > 1 else 1.0
+        r.eps, r.momentum, r.act, r.G = self.eps, self.momentum, self.act, 1
+        if update and self._update_pending:
+            r.running_mean, r.running_var = self.running_mean.data_ptr(), self.running_var.data_ptr()
+            self._update_pending = False
+        else:
+            r.running_mean = r.running_var = None
+        return r
+
+
+def _pd(t, off_doubles=0):
+    return C.c_void_p(t.data_ptr() + 8 * off_doubles)
+
+
+def _fused_ws(ref, G, R, C_, per_group, min_rows=8):
+    """Scratch pointer for the two-launch form of a fused reduction (None when it runs as one launch of atomics)."""
+    need = _call("ud_fused_reduce_ws_doubles", G, R, C_, int(per_group), min_rows)
+    return _ws64(ref, need)
+
+
+def _ws64(ref, need):
+    if need <= 0:
+        return None
+    ws = _REDUCE_WS.get(ref.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, _REDUCE_WS_MIN), dtype=torch.float64, device=ref.device)
+        _REDUCE_WS[ref.device] = ws
+    return C.c_void_p(ws.data_ptr())
+
+
+def colstats(x2, acc, G=1, R=None):
+    """acc[0:G*C] += column sums of x2 [G*R, C], acc[G*C:2*G*C] += column sums of squares."""
+    _chk(x2)
+    Cc = x2.shape[-1]
+    R = x2.numel() // (G * Cc) if R is None else R
+    _call("ud_colstats", _p(x2), G, R, Cc, _pd(acc), _pd(acc, G * Cc), _fused_ws(x2, G, R, Cc, True), _stream())
+
+
+def colsum_bn(x, bn, G, R, out, update=False):
+    _chk(x)
+    Cc = x.shape[-1]
+    _call("ud_colsum_bn", _p(x), C.byref(bn.ref(update)), G, R, Cc, _pd(out), _fused_ws(x, G, R, Cc, True), _stream())
+
+
+def coldot_bn(dy, x, bn, G, R, out):
+    _chk(dy, x)
+    Cc = x.shape[-1]
+    _call("ud_coldot_bn", _p(dy), _p(x), C.byref(bn.ref()), G, R, Cc, _pd(out), _fused_ws(x, G, R, Cc, True), _stream())
+
+
+def fc_fwd_d(xsum, xscale, W, b, N):
+    _chk(W, b)
+    O, I = W.shape
+    y = empty((N, O), W)
+    _call("ud_fc_fwd_d", _pd(xsum), float(xscale), _p(W), _p(b), _p(y), N, I, O, _stream())
+    return y
+
+
+def bn_apply(x, bn, G, R, update=False):
+    """y = act(bn(x)), materialised."""
+    _chk(x)
+    y = torch.empty_like(x)
+    _call("ud_bn_apply", _p(x), C.byref(bn.ref(update)), _p(y), G, R, x.shape[-1], _stream())
+    return y
+
+
+def se_scale_bn(x, bn, s, G, R):
+    _chk(x, s)
+    y = torch.empty_like(x)
+    _call("ud_se_scale_bn", _p(x), C.byref(bn.ref()), _p(s), _p(y), G, R, x.shape[-1], _stream())
+    return y
+
+
+def residual_bn(x, bn, keep, inv_keep, skip, G, R, update=False):
+    _chk(x, keep, skip)
+    out = torch.empty_like(x)
+    _call("ud_residual_bn", _p(x), C.byref(bn.ref(update)), _p(keep), float(inv_keep), _p(skip), _p(out), G, R,
+          x.shape[-1], _stream())
+    return out
+
+
+def normbwd_sums(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc):
+    """sacc[0:C] += sum dz, sacc[C:2C] += sum dz * xhat."""
+    _chk(x, dy, keep)
+    Cc = x.shape[-1]
+    _call("ud_normbwd_sums", _p(x), _p(dy), _p(keep), float(inv_keep), C.byref(bn.ref()), int(dy_is_dz), G, R, Cc,
+          _pd(sacc), _pd(sacc, Cc), _fused_ws(x, G, R, Cc, False), _stream())
+
+
+def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=None, want_dbeta=True):
+    """Returns (dx, dgamma, dbeta).  sacc: sums over all ranks; sacc_local: this rank's (default: the same)."""
+    _chk(x, dy, keep)
+    Cc = x.shape[-1]
+    loc = sacc if sacc_local is None else sacc_local
+    dx = torch.empty_like(x)
+    dg = empty((Cc,), x)
+    db = empty((Cc,), x) if want_dbeta else None
+    _call("ud_normbwd_apply", _p(x), _p(dy), _p(keep), float(inv_keep), C.byref(bn.ref()), int(dy_is_dz), _pd(sacc),
+          _pd(sacc, Cc), _pd(loc), _pd(loc, Cc), G, R, Cc, _p(dx), _p(dg), _p(db), _stream())
+    return dx, dg, db
+
+
+def normbwd_apply_mix(x, dz, bn, G, R, sacc, spat, freq, dalpha_acc, sacc_local=None):
+    _chk(x, dz, spat, freq)
+    Cc = x.shape[-1]
+    loc = sacc if sacc_local is None else sacc_local
+    dd = torch.empty_like(x)
+    dg = empty((Cc,), x)
+    db = empty((Cc,), x)
+    _call("ud_normbwd_apply_mix", _p(x), _p(dz), C.byref(bn.ref()), _pd(sacc), _pd(sacc, Cc), _pd(loc), _pd(loc, Cc),
+          _p(spat), _p(freq), G, R, Cc, _p(dd), _pd(dalpha_acc), _p(dg), _p(db), _stream())
+    return dd, dg, db
+
+
+def gate_grad_from_acc(acc, alpha):
+    out = empty((), alpha)
+    _call("ud_gate_grad_from_acc", _pd(acc), _p(alpha), _p(out), _stream())
+    return out
+
+
+def se_bwd(dgate, s2, s1, We, Wr, pool, pool_scale):
+    """Backward of the two SE FCs (model.py:119-121) in two launches.  dgate: fp64 [N, C] (gradient of the gate
+    sigmoid(s2)); pool: fp64 pooled SUMS.  Returns (dpool, dWe, dbe, dWr, dbr)."""
+    _chk(s2, s1, We, Wr)
+    N, Cc = s2.shape
+    Cs = s1.shape[1]
+    ds1_acc = zeros64(N * Cs, s2)
+    dWe = empty((Cc, Cs), s2)
+    dbe = empty((Cc,), s2)
+    _call("ud_se_bwd_a", _pd(dgate), _p(s2), _p(s1), _p(We), _pd(ds1_acc), _p(dWe), _p(dbe), N, Cc, Cs, _stream())
+    dpool = empty((N, Cc), s2)
+    dWr = empty((Cs, Cc), s2)
+    dbr = empty((Cs,), s2)
+    _call("ud_se_bwd_b", _pd(ds1_acc), _p(s1), _p(Wr), _pd(pool), float(pool_scale), _p(dpool), _p(dWr), _p(dbr), N, Cc,
+          Cs, _stream())
+    return dpool, dWe, dbe, dWr, dbr
+
+
+def se_scale_bwd_bn(dc, x, bn, s, dpool, inv_hw, G, R, sacc):
+    _chk(dc, x, s, dpool)
+    Cc = x.shape[-1]
+    dz = torch.empty_like(x)
+    _call("ud_se_scale_bwd_bn", _p(dc), _p(x), C.byref(bn.ref()), _p(s), _p(dpool), float(inv_hw), _p(dz), _pd(sacc),
+          _pd(sacc, Cc), _fused_ws(x, G, R, Cc, False), G, R, Cc, _stream())
+    return dz
+
+
+def dwconv_bwd_data_bn(dy, gate_alpha, gate_mode, wt, add, x, bn, K, stride, pad_t, pad_l, sacc):
+    """dz = (gate * dwconv_bwd_data(dy) + add) * act'(bn(x)); sacc += BatchNorm backward sums.  x: the conv's input."""
+    _chk(dy, wt, add, x)
+    N, H, W, Cc = x.shape
+    _, Ho, Wo, _ = dy.shape
+    dz = torch.empty_like(x)
+    ws = _ws64(x, _call("ud_dwconv_bwd_data_bn_ws_doubles", N, H, W, Cc, stride))
+    _call("ud_dwconv_bwd_data_bn", _p(dy), _p(gate_alpha), int(gate_mode), _p(wt), _p(add), _p(x), C.byref(bn.ref()),
+          _p(dz), _pd(sacc), _pd(sacc, Cc), ws, N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+    return dz
+
+
+def dwconv_bwd_data_ex(dy, gate_alpha, gate_mode, wt, add, K, stride, pad_t, pad_l, H, W):
+    _chk(dy, wt, add)
+    N, Ho, Wo, Cc = dy.shape
+    dx = empty((N, H, W, Cc), dy)
+    _call("ud_dwconv_bwd_data_ex", _p(dy), _p(gate_alpha), int(gate_mode), _p(wt), _p(add), _p(dx), N, H, W, Cc, Ho, Wo,
+          K, stride, pad_t, pad_l, _stream())
+    return dx
+
+
+def dwconv_bwd_weight_ex(x, dy, gate_alpha, gate_mode, K, stride, pad_t, pad_l):
+    _chk(x, dy)
+    N, H, W, Cc = x.shape
+    _, Ho, Wo, _ = dy.shape
+    chunks = max(1, min(N * Ho, -(-_DW_WGRAD_THREADS // Cc)))
+    part = empty((chunks, K * K, Cc), x)
+    dwt = empty((Cc, K * K), x)
+    _call("ud_dwconv_bwd_weight_ex", _p(x), _p(dy), _p(gate_alpha), int(gate_mode), _p(dwt), _p(part), chunks, N, H, W,
+          Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+    return dwt
+
+
+def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None, gate_mode=0, update=False):
+    """rfft2 of act(bn(x)) (bn optional) [* gate].  Returns (Y, activated input or None)."""
+    _chk(x)
+    N, S, S2, Cc = x.shape
+    assert S == S2
+    Y = empty((N, S, S // 2 + 1, 2 * Cc), x)
+    act = torch.empty_like(x) if (want_act and bn is not None) else None
+    _call("ud_rfft2_ex", _p(x), _p(Y), N, S, Cc, float(scale), float(w_interior),
+          C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode), _stream())
+    return Y, act
+
+
+def irfft2_mix(Y, scale, spat, alpha, acc):
+    """(y, freq) = SF mix of spat with irfft2(Y); acc += [sum y | sum y^2]."""
+    _chk(Y, spat, alpha)
+    N, S, Wh, C2 = Y.shape
+    Cc = C2 // 2
+    assert spat.shape == (N, S, S, Cc)
+    y = torch.empty_like(spat)
+    fr = torch.empty_like(spat)
+    _call("ud_irfft2_mix", _p(Y), _p(y), N, S, Cc, float(scale), 1.0, _p(spat), _p(alpha), _p(fr), _pd(acc),
+          _pd(acc, Cc), _stream())
+    return y, fr

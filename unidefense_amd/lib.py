@@ -28,7 +28,15 @@ class GemmDesc(C.Structure):
                 ("g", ConvGeom)]
 
 
+class BnRef(C.Structure):
+    """ud_bn_ref: a deferred BatchNorm (fp64 sums + affine parameters) applied by the consuming kernel."""
+    _fields_ = [("sum", C.c_void_p), ("sumsq", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("inv_count", C.c_double), ("unbias", C.c_double), ("eps", C.c_float), ("momentum", C.c_float),
+                ("act", C.c_int), ("G", C.c_int), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
+_BN = C.POINTER(BnRef)
 
 # name -> argtypes (the trailing stream argument included); every function returns int
 _SIGNATURES = {
@@ -94,13 +102,36 @@ _SIGNATURES = {
     "ud_efdm": [_P, _P, _P, _P, _I, _I, _I, _P, _L, _P],
     "ud_coral_moments": [_P, _P, _I, _I, _I, _P],
     "ud_affine3": [_P, _P, _P, _I, _I, _P],
+    # fused MBConv path (csrc/fused.hip, csrc/fft.hip)
+    "ud_fused_reduce_ws_doubles": [_I, _I, _I, _I, _I],
+    "ud_colstats": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "ud_colsum_bn": [_P, _BN, _I, _I, _I, _P, _P, _P],
+    "ud_coldot_bn": [_P, _P, _BN, _I, _I, _I, _P, _P, _P],
+    "ud_fc_fwd_d": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
+    "ud_se_scale_bn": [_P, _BN, _P, _P, _I, _I, _I, _P],
+    "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _P],
+    "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _P],
+    "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "ud_gate_grad_from_acc": [_P, _P, _P, _P],
+    "ud_se_bwd_a": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "ud_se_bwd_b": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P],
+    "ud_se_scale_bwd_bn": [_P, _P, _BN, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
+    "ud_bn_apply": [_P, _BN, _P, _I, _I, _I, _P],
+    "ud_dwconv_bwd_data_bn": [_P, _P, _I, _P, _P, _P, _BN, _P, _P, _P, _P] + [_I] * 10 + [_P],
+    "ud_dwconv_bwd_data_bn_ws_doubles": [_I, _I, _I, _I, _I],
+    "ud_dwconv_bwd_data_ex": [_P, _P, _I, _P, _P, _P] + [_I] * 10 + [_P],
+    "ud_dwconv_bwd_weight_ex": [_P, _P, _P, _I, _P, _P, _I] + [_I] * 10 + [_P],
+    "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P],
+    "ud_irfft2_mix": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P],
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
                 "ud_conv_small_wgrad_ws_floats"}
-_LONG_FUNCS = {"ud_efdm_ws_bytes", "ud_conv_small_wgrad_ws_floats"}        # return a C long
+_LONG_FUNCS = {"ud_efdm_ws_bytes", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
+               "ud_dwconv_bwd_data_bn_ws_doubles"}        # return a C long
 
 EXPORTED = tuple(_SIGNATURES)
 

@@ -100,7 +100,9 @@ _OUT_KEYS = ("cls_out", "rec", "factorization", "triplet0", "triplet1", "triplet
              "spatial", "freq")
 
 
-_DW_WT_BATCH = os.environ.get("UD_DW_WT_BATCH", "1") == "1"
+# training mode: MBConv blocks as fused tape nodes with deferred BatchNorms (tape.mbconv_fused); UD_FUSED_MBCONV=0
+# runs the operator-by-operator path (same results: tests/test_fused_gpu.py compares the two)
+_FUSED_MBCONV = os.environ.get("UD_FUSED_MBCONV", "1") == "1"
 
 
 class _NetFunction(torch.autograd.Function):
@@ -254,7 +256,7 @@ class UniDefenseModelEb4(nn.Module):
             outs = dict(zip(self._out_keys, vals))
         else:
             with torch.no_grad():
-                outs = self._run(x, None, rng)
+                outs = self._run(x, None, rng, noise_x)
         pending = self.__dict__.pop("_nbt_pending", None)
         if pending:
             torch._foreach_add_(pending, 1)
@@ -276,9 +278,7 @@ class UniDefenseModelEb4(nn.Module):
             self.__dict__.setdefault("_nbt_pending", []).append(bn.num_batches_tracked)
         # SyncBatchNorm semantics when a data-parallel wrapper set a process group, or when the container was
         # converted by torch.nn.SyncBatchNorm.convert_sync_batchnorm (engine/forgery_engine.py:142)
-        group = getattr(self, "_sync_bn_group", None)
-        if group is None and isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_initialized():
-            group = bn.process_group or torch.distributed.group.WORLD
+        group = self._sync_group(bn)
         return T.batchnorm_act(tape, x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                bn.momentum if bn.momentum is not None else 0.1, training, act, group)
 
@@ -306,17 +306,33 @@ class UniDefenseModelEb4(nn.Module):
                 x = T.residual(tape, x, inp)
         return x
 
-    def _blocks(self, tape, x, stage, rng):
+    def _blocks(self, tape, x, stage, rng, lazy_in=None):
         """forward_backbone_block (model/unidefense.py:159-172)."""
         start = self.delimiter[stage - 1] if stage > 0 else 0
         end = self.delimiter[stage]
         nblk = len(self.backbone._blocks)
         rate0 = self.arch["drop_connect_rate"]
+        fused = rng.get("_fused")
         for idx in range(start, end):
             rate = rate0 * float(idx) / nblk if rate0 else 0.0
             keep = rng["drop_connect"].get(idx) if (self.training and rate) else None
-            x = self._mbconv(tape, x, self.backbone._blocks[idx], keep, 1.0 - rate)
+            blk = self.backbone._blocks[idx]
+            if fused is not None:
+                # training mode: one tape node per block, BatchNorms deferred into their consumers (tape.mbconv_fused)
+                pend = self.__dict__.setdefault("_nbt_pending", [])
+                pend.extend(b.num_batches_tracked for b in (getattr(blk, "_bn0", None), blk._bn1, blk._bn2)
+                            if b is not None and b.num_batches_tracked is not None)
+                x = T.mbconv_fused(tape, x, blk, keep, 1.0 - rate, fused["wt"][id(blk._depthwise_conv.weight)],
+                                   fused["dp"], lazy_in if idx == 0 else None)
+            else:
+                x = self._mbconv(tape, x, blk, keep, 1.0 - rate)
         return x
+
+    def _sync_group(self, bn):
+        group = getattr(self, "_sync_bn_group", None)
+        if group is None and isinstance(bn, nn.SyncBatchNorm) and torch.distributed.is_initialized():
+            group = bn.process_group or torch.distributed.group.WORLD
+        return group
 
     def _decoder(self, tape, x, dec, last):
         x = T.conv_dense(tape, x, dec[0].weight, 1, 1, 1, x.shape[1], x.shape[2])
@@ -405,15 +421,22 @@ class UniDefenseModelEb4(nn.Module):
         Ho = (H + pt + pb - 3) // 2 + 1
         Wo = (W + pl + pr - 3) // 2 + 1
         rng = self._prepare_rng(rng, N, x.device)
-        if _DW_WT_BATCH:
-            ws = [blk._depthwise_conv.weight for blk in bb._blocks]
-            wts = K.dw_weights_tapmajor(ws)
-            T.DW_WT = {id(w): (w, w._version, wts[id(w)]) for w in ws}
+        ws = [blk._depthwise_conv.weight for blk in bb._blocks]
+        wts = K.dw_weights_tapmajor(ws)                                  # all depthwise weights to tap-major, one launch
+        T.DW_WT = {id(w): (w, w._version, wts[id(w)]) for w in ws}       # looked up by the unfused tape.dwconv
 
         x_pix = K.planes_to_pix(x if noise_x is None else noise_x)       # [N,H,W,3]
-        h = T.conv_dense(tape, x_pix, bb._conv_stem.weight, 2, pt, pl, Ho, Wo, need_dx=False)
-        h = self._bn(tape, h, bb._bn0, 1)
-        x_b0 = self._blocks(tape, h, 0, rng)
+        if self.training and _FUSED_MBCONV:
+            dp = T.DataParallelCtx(self._sync_group(bb._bn0))
+            rng["_fused"] = {"wt": wts, "dp": dp}
+            if bb._bn0.num_batches_tracked is not None:
+                self.__dict__.setdefault("_nbt_pending", []).append(bb._bn0.num_batches_tracked)
+            h, lazy = T.stem_fused(tape, x_pix, bb._conv_stem.weight, bb._bn0, 2, pt, pl, Ho, Wo, dp)
+            x_b0 = self._blocks(tape, h, 0, rng, lazy)
+        else:
+            h = T.conv_dense(tape, x_pix, bb._conv_stem.weight, 2, pt, pl, Ho, Wo, need_dx=False)
+            h = self._bn(tape, h, bb._bn0, 1)
+            x_b0 = self._blocks(tape, h, 0, rng)
         x_b1 = self._blocks(tape, x_b0, 1, rng)
         x_b2 = self._blocks(tape, x_b1, 2, rng)
         x_b3 = self._blocks(tape, x_b2, 3, rng)

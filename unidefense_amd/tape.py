@@ -697,3 +697,239 @@ def concat_channels(tape, parts):
                 off += p.shape[-1]
         tape.record(bwd)
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused MBConv block: deferred BatchNorm, one tape node per block (csrc/fused.hip)
+# ---------------------------------------------------------------------------------------------
+class DataParallelCtx:
+    """SyncBatchNorm context of the fused path: the fp64 accumulators are summed over the ranks in place (one
+    all_reduce between the producing and the consuming kernels), counts are multiplied by the world size."""
+
+    def __init__(self, group=None):
+        self.group, self.world, self.synced = group, 1, False
+        if group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(group)
+            self.synced = self.world > 1 or FORCE_COLLECTIVES
+
+    def reduce(self, acc, keep_local=False):
+        """Sum `acc` over the ranks in place; returns this rank's own sums (a copy) when keep_local, else None."""
+        if not self.synced:
+            return None
+        import torch.distributed as dist
+        loc = acc.clone() if keep_local else None
+        dist.all_reduce(acc, group=self.group)
+        return loc
+
+
+class LazyInput:
+    """A block input that is still a raw conv output + deferred BatchNorm (the stem in front of block 0):
+    backward(dz, sacc) receives the gradient already pushed through the activation and the BatchNorm sums."""
+
+    def __init__(self, bn, backward):
+        self.bn, self.backward = bn, backward
+
+
+def _bn_of(mod, acc, count, act):
+    return K.DeferredBN(acc, mod.num_features, count, mod.weight, mod.bias, mod.eps, act,
+                        mod.momentum if mod.momentum is not None else 0.1, mod.running_mean, mod.running_var)
+
+
+def stem_fused(tape, x_pix, w, bn_mod, stride, pad_t, pad_l, Ho, Wo, dp):
+    """Stem conv (model/efficientnet/model.py:185-186) whose BatchNorm + swish is left to block 0's depthwise conv."""
+    h = conv_dense(tape, x_pix, w, stride, pad_t, pad_l, Ho, Wo, need_dx=False)
+    Cc = h.shape[-1]
+    M = h.numel() // Cc
+    acc = K.zeros64(2 * Cc, h)
+    K.colstats(h.view(M, Cc), acc)
+    dp.reduce(acc)
+    bn = _bn_of(bn_mod, acc, M * dp.world, 1)
+
+    def backward(dz, sacc, is_dz):
+        loc = dp.reduce(sacc, keep_local=True)
+        dh, dg, db = K.normbwd_apply(h, dz, None, 1.0, bn, is_dz, 1, M, sacc, loc)
+        tape.add_param_grad(bn_mod.weight, dg)
+        tape.add_param_grad(bn_mod.bias, db)
+        tape.add_grad(h, dh)
+    return h, LazyInput(bn, backward)
+
+
+def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
+    """MBConvBlock.forward (model/efficientnet/model.py:94-135) in training mode as ONE tape node.
+    x [N,H,W,Cin]: the block input (for block 0: the raw stem output, lazy_in its deferred BatchNorm);
+    wt: the depthwise weight in tap-major layout [k*k][C]; keep: drop-connect keep vector [N] or None.
+
+    Forward (SF block, stride 1):  expand GEMM -> colstats -> rfft2 of swish(bn0(e)) (also writes the activated
+    tensor) -> depthwise conv | spectral GEMM -> irfft2 + SF mix + BN1 statistics -> SE pooling of swish(bn1(d)) ->
+    2 small FCs -> BN1 + swish + gate -> project GEMM -> colstats -> BN2 + drop-connect + skip.
+    Backward mirrors it with the BatchNorm backward sums accumulated by the kernel that produces the gradient."""
+    sp = blk.spec
+    N, H, W, Cin = x.shape
+    M = N * H * W
+    k, stride = sp.k, sp.stride
+    pl, pr, pt, pb = sp.pad
+    Ho = (H + pt + pb - k) // stride + 1
+    Wo = (W + pl + pr - k) // stride + 1
+    HWo, Mo = Ho * Wo, N * Ho * Wo
+    Ce, Co = sp.cexp, sp.cout
+    inv_keep = 1.0 / keep_prob
+    dwm = blk._depthwise_conv
+    sf = sp.sf_norm is not None
+    assert not (sp.skip and lazy_in is not None)
+
+    # ---- expand + BN0 (deferred)
+    if sp.expand != 1:
+        We = blk._expand_conv.weight.view(Ce, Cin)
+        x2 = x.view(M, Cin)
+        e = K.gemm_nt(x2, We).view(N, H, W, Ce)
+        acc0 = K.zeros64(2 * Ce, x)
+        K.colstats(e.view(M, Ce), acc0)
+        dp.reduce(acc0)
+        bn0 = _bn_of(blk._bn0, acc0, M * dp.world, 1)
+        src, src_bn = e, bn0
+    else:
+        e = bn0 = None
+        src, src_bn = x, (lazy_in.bn if lazy_in is not None else None)
+
+    # ---- depthwise / SF conv -> d (pre-BN1), BN1 statistics
+    acc1 = K.zeros64(2 * Ce, x)
+    spat = fr = xf = None
+    if sf:
+        S = H
+        s_f, s_i = _fft_scales(S, sp.sf_norm)
+        alpha = dwm.sf_coef
+        if src_bn is not None:
+            xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=True, update=True)   # also writes a = swish(bn0(e))
+        else:
+            xf, a = K.rfft2(src, s_f, 1.0), src
+        spat = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
+        Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
+        yf = K.gemm_nt(xf.view(-1, 2 * Ce), Wf).view(xf.shape)
+        if stride == 1:
+            d, fr = K.irfft2_mix(yf, s_i, spat, alpha, acc1)
+        else:
+            fr = K.irfft2(yf, s_i, 1.0)
+            d = K.sfmix_fwd(spat, fr, alpha, True)
+            K.colstats(d.view(Mo, Ce), acc1)
+        del yf
+    else:
+        alpha = None
+        # a plain depthwise conv (and its weight gradient) re-reads its input per tap: materialise the activation
+        a = K.bn_apply(src, src_bn, 1, M, update=True) if src_bn is not None else src
+        d = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
+        K.colstats(d.view(Mo, Ce), acc1)
+    dp.reduce(acc1)
+    bn1 = _bn_of(blk._bn1, acc1, Mo * dp.world, 1)
+
+    # ---- squeeze-excite on swish(bn1(d)), BN1 + swish + gate -> c
+    Cs = sp.cse
+    wr2, we2 = blk._se_reduce.weight.view(Cs, Ce), blk._se_expand.weight.view(Ce, Cs)
+    pool = K.zeros64(N * Ce, x)
+    K.colsum_bn(d, bn1, N, HWo, pool, update=True)
+    s1 = K.fc_fwd_d(pool, 1.0 / HWo, wr2, blk._se_reduce.bias, N)
+    s2 = K.fc_fwd(s1, we2, blk._se_expand.bias, 1)
+    c = K.se_scale_bn(d, bn1, s2, N, HWo)
+
+    # ---- project + BN2 + drop-connect + skip
+    Wp = blk._project_conv.weight.view(Co, Ce)
+    c2 = c.view(Mo, Ce)
+    p = K.gemm_nt(c2, Wp)
+    acc2 = K.zeros64(2 * Co, x)
+    K.colstats(p, acc2)
+    dp.reduce(acc2)
+    bn2 = _bn_of(blk._bn2, acc2, Mo * dp.world, 0)
+    p4 = p.view(N, Ho, Wo, Co)
+    out = K.residual_bn(p4, bn2, keep, inv_keep, x if sp.skip else None, N, HWo, update=True)
+    if not _needs(tape):
+        return out
+
+    def bwd():
+        dout = tape.pop_grad(out)
+        if dout is None:
+            return
+        if not (dout.is_contiguous() and dout.shape == out.shape):
+            dout = dout.reshape(out.shape).contiguous()
+        # ---- BN2 (+ drop-connect scale) backward
+        sb2 = K.zeros64(2 * Co, x)
+        K.normbwd_sums(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2)
+        loc2 = dp.reduce(sb2, keep_local=True)
+        dp_, dg2, db2 = K.normbwd_apply(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2, loc2)
+        tape.add_param_grad(blk._bn2.weight, dg2)
+        tape.add_param_grad(blk._bn2.bias, db2)
+        dp2 = dp_.view(Mo, Co)
+        tape.wgrad(blk._project_conv.weight, lambda: K.gemm_tn(dp2, c2), dp2, c2)
+        dc = K.gemm_nn(dp2, Wp).view(N, Ho, Wo, Ce)
+        # ---- squeeze-excite backward
+        dgate = K.zeros64(N * Ce, x)
+        K.coldot_bn(dc, d, bn1, N, HWo, dgate)
+        dpool, dWe2, dbe2, dWr, dbr = K.se_bwd(dgate, s2, s1, we2, wr2, pool, 1.0 / HWo)
+        tape.add_param_grad(blk._se_expand.weight, dWe2)
+        tape.add_param_grad(blk._se_expand.bias, dbe2)
+        tape.add_param_grad(blk._se_reduce.weight, dWr)
+        tape.add_param_grad(blk._se_reduce.bias, dbr)
+        # ---- gate + swish + BN1 backward sums in one pass
+        sb1 = K.zeros64(2 * Ce, x)
+        dz1 = K.se_scale_bwd_bn(dc, d, bn1, s2, dpool, 1.0 / HWo, N, HWo, sb1)
+        loc1 = dp.reduce(sb1, keep_local=True)
+        g_alpha, g_mode, da_f = None, 0, None
+        if sf:
+            if stride == 1:
+                dacc = K.zeros64(64, x)
+                dd, dg1, db1 = K.normbwd_apply_mix(d, dz1, bn1, N, HWo, sb1, spat, fr, dacc, loc1)
+                tape.add_param_grad(alpha, K.gate_grad_from_acc(dacc, alpha))
+                dyf, _ = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1)       # adjoint of irfft2, x sigmoid(a)
+                g_sp, g_alpha, g_mode = dd, alpha, 2                                   # spatial branch: x (1 - sigmoid(a))
+            else:
+                dd, dg1, db1 = K.normbwd_apply(d, dz1, None, 1.0, bn1, True, N, HWo, sb1, loc1)
+                g_sp, dfr, dalpha = K.sfmix_bwd(spat, fr, alpha, dd, True)
+                tape.add_param_grad(alpha, dalpha)
+                dyf = K.rfft2(dfr, s_i, 2.0)
+            dyf2, xf2 = dyf.view(-1, 2 * Ce), xf.view(-1, 2 * Ce)
+            tape.wgrad(dwm.freq_conv.weight, lambda: K.gemm_tn(dyf2, xf2), dyf2, xf2)
+            dxf = K.gemm_nn(dyf2, Wf).view(xf.shape)
+            da_f = K.irfft2(dxf, s_f, 0.5)                                             # adjoint of rfft2
+        else:
+            dd, dg1, db1 = K.normbwd_apply(d, dz1, None, 1.0, bn1, True, N, HWo, sb1, loc1)
+            g_sp = dd
+        tape.add_param_grad(blk._bn1.weight, dg1)
+        tape.add_param_grad(blk._bn1.bias, db1)
+        tape.add_param_grad(dwm.weight, K.dwconv_bwd_weight_ex(a, g_sp, g_alpha, g_mode, k, stride, pt, pl))
+        # ---- depthwise data gradient (+ spectral branch), through swish(bn0(.)) when the input is deferred
+        if src_bn is not None:
+            sb0 = K.zeros64(2 * src.shape[-1], x)
+            if stride == 1:
+                dz0 = K.dwconv_bwd_data_bn(g_sp, g_alpha, g_mode, wt, da_f, src, src_bn, k, stride, pt, pl, sb0)
+                is_dz = True
+            else:       # stride 2 (4 of 32 blocks): gather kernel, then the sums as a pass of their own
+                dz0 = K.dwconv_bwd_data(g_sp, wt, k, stride, pt, pl, H, W, add=da_f)
+                K.normbwd_sums(src, dz0, None, 1.0, src_bn, False, 1, M, sb0)
+                is_dz = False
+            if lazy_in is not None:
+                lazy_in.backward(dz0, sb0, is_dz)
+                return
+            loc0 = dp.reduce(sb0, keep_local=True)
+            de, dg0, db0 = K.normbwd_apply(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0)
+            tape.add_param_grad(blk._bn0.weight, dg0)
+            tape.add_param_grad(blk._bn0.bias, db0)
+            de2 = de.view(M, Ce)
+            tape.wgrad(blk._expand_conv.weight, lambda: K.gemm_tn(de2, x2), de2, x2)
+            if sp.skip and tape.watch is None and getattr(dout, "_ud_owned", False):
+                dx = K.gemm_nn(de2, We, out=dout.view(M, Cin), accumulate=True).view(x.shape)    # + skip gradient
+            else:
+                dx = K.gemm_nn(de2, We).view(x.shape)
+                if sp.skip:
+                    dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
+        else:
+            add = da_f
+            if sp.skip and add is None:
+                add, skip_done = dout, True
+            else:
+                skip_done = not sp.skip
+            dx = K.dwconv_bwd_data_ex(g_sp, g_alpha, g_mode, wt, add, k, stride, pt, pl, H, W)
+            if not skip_done:
+                dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
+        dx._ud_owned = True
+        tape.add_grad(x, dx)
+    tape.record(bwd)
+    return out
