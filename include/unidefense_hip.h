@@ -382,6 +382,17 @@ int ud_rfft2_ex(const float* x, float* Y, int N, int S, int C, float scale, floa
 int ud_irfft2_mix(const float* Y, float* y, int N, int S, int C, float scale, float w_interior, const float* spat,
                   const float* alpha, float* freq_out, double* sum, double* sumsq, ud_stream_t stream);
 
+/* ---- multi-tensor AdamW (csrc/optim.hip) ------------------------------------------------------------------------
+ * torch.optim.AdamW(amsgrad) over timm's weight-decay groups (engine/forgery_engine.py:149-156) with GradScaler's
+ * unscale and found_inf skip (engine/abstract_engine.py:281-283) folded in: ONE launch for all parameter tensors.
+ * table: device array of entries of 8 x int64 {p, g, m, v, vmax (0: no amsgrad) pointers, numel, group, 0}; chunk_map: device array of int32 pairs (tensor, chunk of ud_adamw_chunk_elems() elements),
+ * one workgroup each; lr / wd: host arrays per group (<= 8); grad_scale, found_inf: device scalars or NULL;
+ * step_in / step_out: device int32 counters (out = in + 1, or in when found_inf != 0 and nothing is updated). */
+int ud_adamw_chunk_elems(void);
+int ud_adamw_multi(const void* table, const void* chunk_map, int n_chunks, const float* lr, const float* wd, int n_groups,
+                   double beta1, double beta2, double eps, int amsgrad, int maximize, const float* grad_scale,
+                   const float* found_inf, const int* step_in, int* step_out, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

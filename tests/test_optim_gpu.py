@@ -1,0 +1,85 @@
+"""GPU: HipAdamW (csrc/optim.hip, one multi-tensor launch) against torch.optim.AdamW on the same tensors: two weight-decay
+groups with their own lr (timm's grouping, engine/forgery_engine.py:149-156), amsgrad on / off, GradScaler's grad_scale and
+a skipped (found_inf) step, ragged tensor sizes incl. scalars and lengths that are not multiples of 4 / of the chunk.
+Bar: parameters and optimizer state agree to 2e-6 of each tensor's largest entry after 6 steps (fp32 rounding of one
+fused expression vs ATen's sequence of foreach ops)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(), (1,), (3,), (7, 5), (1000,), (65536,), (65537,), (300, 331), (3264, 96), (48, 3, 3, 3), (131075,)]
+
+
+def _params(dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in SHAPES]
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+@pytest.mark.parametrize("amsgrad", [True, False])
+def test_hip_adamw_matches_torch(amsgrad):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidefense_amd.engine.optim import HipAdamW
+    dev = torch.device("cuda:0")
+    pa, pb = _params(dev, 1), _params(dev, 1)
+
+    def groups(ps):
+        return [{"params": [p for p in ps if p.ndim <= 1], "weight_decay": 0.0, "lr": 2e-3},
+                {"params": [p for p in ps if p.ndim > 1], "weight_decay": 5e-2}]
+    ref = torch.optim.AdamW(groups(pa), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, amsgrad=amsgrad, foreach=True)
+    hip = HipAdamW(groups(pb), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, amsgrad=amsgrad)
+    scale = torch.tensor(1024.0, device=dev)
+    gen = torch.Generator().manual_seed(7)
+    for it in range(7):
+        skip = it == 3
+        for a, b in zip(pa, pb):
+            g = torch.randn(a.shape, generator=gen).to(dev) * (10.0 ** (it % 3 - 2))
+            a.grad = g.clone()                      # torch: already unscaled gradients
+            b.grad = g * scale                      # ours: scaled gradients + grad_scale on the device
+        if not skip:
+            ref.step()
+        hip.grad_scale, hip.found_inf = scale, torch.tensor(1.0 if skip else 0.0, device=dev)
+        hip.step()
+        # a scheduler moves the lr between steps
+        for o in (ref, hip):
+            for gr in o.param_groups:
+                gr["lr"] *= 0.9
+    torch.cuda.synchronize()
+    assert hip.step_count() == 6
+    bad = []
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        e = _rel(b, a)
+        if e > 2e-6:
+            bad.append(("param", SHAPES[i], e))
+        for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if amsgrad else ()):
+            e = _rel(hip.state[b][k], ref.state[a][k])
+            if e > 2e-6:
+                bad.append((k, SHAPES[i], e))
+    assert not bad, bad
+
+
+def test_grad_scaler_drives_hip_adamw():
+    """torch.amp.GradScaler.step hands grad_scale / found_inf to the optimizer (no unscale pass); an inf gradient
+    skips the update and halves the scale."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidefense_amd.engine.optim import HipAdamW
+    dev = torch.device("cuda:0")
+    p = torch.ones(1000, device=dev, requires_grad=True)
+    opt = HipAdamW([p], lr=0.1, weight_decay=0.0, amsgrad=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2 ** 10)
+    loss = (p * 3.0).sum()
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    assert torch.allclose(p, torch.full_like(p, 0.9), atol=1e-5)          # first Adam step moves by lr * sign(g)
+    p.grad = torch.full_like(p, float("inf"))
+    before = p.detach().clone()
+    scaler.step(opt)
+    scaler.update()
+    assert torch.equal(p, before) and opt.step_count() == 1 and scaler.get_scale() == 2 ** 9

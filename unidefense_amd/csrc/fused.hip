@@ -101,25 +101,26 @@ __device__ __forceinline__ void red_out(const RedGeom& q, int ri, bool active, i
     }
 }
 
-// acc[q][o] += sum_p part[q][(o / C) * P + p][o % C]   (16 chunk-lanes per output, four partials in flight per lane)
+// acc[q][o] += sum_p part[q][(o / C) * P + p][o % C]   (8 outputs x 32 chunk-lanes per block, four partials in flight
+// per lane: 512 partials per output are four rounds of loads)
 __global__ __launch_bounds__(NT) void partials_to_acc(int nq, int G, int C, int P, const double* __restrict__ part,
                                                       double* __restrict__ a1, double* __restrict__ a2) {
     __shared__ double sm[2][NT];
-    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + cl;
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int idx = blockIdx.x * 8 + cl;
     const bool ok = idx < G * C;
     const long plane = (long)G * P * C;
     double a = 0.0, b = 0.0;
     if (ok) {
         const int g = idx / C, c = idx % C;
-        const long base = (long)g * P * C + c, step = 16L * C;
+        const long base = (long)g * P * C + c, step = 32L * C;
         int p = pl;
-        for (; p + 48 < P; p += 64) {
+        for (; p + 96 < P; p += 128) {
             const long o = base + (long)p * C;
             a += (part[o] + part[o + step]) + (part[o + 2 * step] + part[o + 3 * step]);
             if (nq == 2) b += (part[plane + o] + part[plane + o + step]) + (part[plane + o + 2 * step] + part[plane + o + 3 * step]);
         }
-        for (; p < P; p += 16) {
+        for (; p < P; p += 32) {
             const long o = base + (long)p * C;
             a += part[o];
             if (nq == 2) b += part[plane + o];
@@ -129,9 +130,9 @@ __global__ __launch_bounds__(NT) void partials_to_acc(int nq, int G, int C, int 
     sm[1][threadIdx.x] = b;
     __syncthreads();
     if (ok && pl == 0) {
-        for (int k = 1; k < 16; ++k) {
-            a += sm[0][k * 16 + cl];
-            b += sm[1][k * 16 + cl];
+        for (int k = 1; k < 32; ++k) {
+            a += sm[0][k * 8 + cl];
+            b += sm[1][k * 8 + cl];
         }
         a1[idx] += a;
         if (nq == 2) a2[idx] += b;
@@ -732,11 +733,13 @@ struct RedPlan {
     RedGeom q;
     bool use_part;
 };
-inline RedPlan plan_reduce(int G, int R, int C, bool per_group, const double* ws, int min_rows = 8) {
+inline RedPlan plan_reduce(int G, int R, int C, bool per_group, const double* ws, int min_rows = 8,
+                           int row_elems = 1) {
     RedGeom qa = make_geom_ex(G, R, C, 1024, 64, min_rows);
     const long contrib = per_group ? qa.P : (long)qa.G * qa.P;
-    // >= 16 MB: the pass is bandwidth-bound and wants ~2000 workgroups; its finalize launch is noise
-    const bool big = (long)G * R * (C / 4) >= (1L << 20);
+    // >= 16 MB (row_elems pixels per row item): the pass is bandwidth-bound and wants ~2000 workgroups; its finalize
+    // launch is noise
+    const bool big = (long)G * R * row_elems * (C / 4) >= (1L << 20);
     if ((contrib <= 64 && !big) || !ws) return RedPlan{qa, false};
     return RedPlan{make_geom_ex(G, R, C, 2048, 512, min_rows), true};
 }
@@ -745,7 +748,7 @@ inline int finish_reduce(const RedPlan& pl, int nq, bool per_group, int C, const
     if (!pl.use_part) return 0;
     const int G = per_group ? pl.q.G : 1;
     const int P = per_group ? pl.q.P : pl.q.G * pl.q.P;
-    hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv((long)G * C, 16)), dim3(NT), 0, s, nq, G, C, P, ws, a1, a2);
+    hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv((long)G * C, 8)), dim3(NT), 0, s, nq, G, C, P, ws, a1, a2);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -922,8 +925,10 @@ static long dw_bwd_items(int N, int H, int W, int stride) {
 }
 long ud_dwconv_bwd_data_bn_ws_doubles(int N, int H, int W, int C, int stride) {
     const long items = dw_bwd_items(N, H, W, stride);
-    if (items < 1 || items > 0x7fffffffL || C % 4) return UD_EINVAL;
-    return ud_fused_reduce_ws_doubles(1, (int)items, C, 0, stride == 1 ? 1 : 4);
+    if (items < 1 || items > 0x7fffffffL || C % 4 || C < 4) return UD_EINVAL;
+    static double dummy;
+    RedPlan pl = plan_reduce(1, (int)items, C, false, &dummy, stride == 1 ? 1 : 4, stride == 1 ? TW : 1);
+    return pl.use_part ? 2L * pl.q.G * pl.q.P * C : 0;
 }
 
 static int dw_bwd_data_launch(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
@@ -939,7 +944,7 @@ static int dw_bwd_data_launch(const float* dy, const float* gate_alpha, int gate
     const bool has_bn = bn != nullptr;
     if (has_bn && (!x || !s1 || !s2 || bn->G != 1)) return UD_EINVAL;
     RedPlan pl{make_geom_ex(1, (int)items, C, 2048, 8192, strip ? 1 : 4), false};
-    if (has_bn) pl = plan_reduce(1, (int)items, C, false, ws, strip ? 1 : 4);
+    if (has_bn) pl = plan_reduce(1, (int)items, C, false, ws, strip ? 1 : 4, strip ? TW : 1);
     const RedGeom& q = pl.q;
     double* part = pl.use_part ? ws : nullptr;
     const ud_bn_ref& b = has_bn ? *bn : none;

@@ -35,6 +35,33 @@ __global__ __launch_bounds__(NT) void fc_fwd(const float* __restrict__ x, const 
     if (lane == 0) y[(long)n * O + o] = acc + (b ? b[o] : 0.f);
 }
 
+// Same result for a short input and a wide output (SE expand: I = C/24 <= 128, O = C up to 2688): one wave per output
+// would spend 64 lanes on <= 128 products.  grid (O / 256, N): act_in(x[n][:]) staged in LDS, one thread per output
+// walking its own weight row.
+__global__ __launch_bounds__(NT) void fc_fwd_wide(const float* __restrict__ x, const float* __restrict__ W,
+                                                  const float* __restrict__ b, float* __restrict__ y, int N, int I, int O,
+                                                  int act_in) {
+    __shared__ float sx[128];
+    const int n = blockIdx.y;
+    if ((int)threadIdx.x < I) sx[threadIdx.x] = act_in_f(x[(long)n * I + threadIdx.x], act_in);
+    __syncthreads();
+    const int o = blockIdx.x * NT + threadIdx.x;
+    if (o >= O) return;
+    const float* w = W + (long)o * I;
+    float acc = 0.f;
+    if ((I & 3) == 0) {
+#pragma unroll 4
+        for (int i = 0; i < I; i += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w + i);
+            acc += sx[i] * v[0] + sx[i + 1] * v[1] + sx[i + 2] * v[2] + sx[i + 3] * v[3];
+        }
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < I; ++i) acc += sx[i] * w[i];
+    }
+    y[(long)n * O + o] = acc + (b ? b[o] : 0.f);
+}
+
 // dx[n][i] = act_in'(x[n][i]) * sum_o dy[n][o] * W[o][i]
 __global__ __launch_bounds__(NT) void fc_bwd_x(const float* __restrict__ dy, const float* __restrict__ W,
                                                const float* __restrict__ x, float* __restrict__ dx, int N, int I, int O,
@@ -553,6 +580,12 @@ extern "C" {
 
 int ud_fc_fwd(const float* x, const float* W, const float* b, float* y, int N, int I, int O, int act_in,
               ud_stream_t stream) {
+    if (I <= 128 && O >= 256) {
+        hipLaunchKernelGGL(fc_fwd_wide, dim3(ud_cdiv(O, NT), N), dim3(NT), 0, (hipStream_t)stream, x, W, b, y, N, I, O,
+                           act_in);
+        UD_LAUNCH_CHECK();
+        return 0;
+    }
     long waves = (long)N * O;
     hipLaunchKernelGGL(fc_fwd, dim3(ud_cdiv(waves * 64, NT)), dim3(NT), 0, (hipStream_t)stream, x, W, b, y, N, I, O,
                        act_in);

@@ -1,7 +1,9 @@
 """Optimizer wiring of the reference's engines (engine/forgery_engine.py:149-156): weight-decay parameter
 groups as timm's ``param_groups_weight_decay`` builds them, AdamW(amsgrad) and StepLR from the YAML keys.
-The optimizer itself stays torch's (host-side torch AdamW is acceptable; a fused
-multi-tensor HIP AdamW is row (f)2)."""
+AdamW on the GPU is the multi-tensor HIP kernel of csrc/optim.hip; other optimizers and CPU
+parameters use torch's."""
+import os
+
 import torch
 
 
@@ -20,7 +22,114 @@ def param_groups_weight_decay(model, weight_decay=1e-5, no_weight_decay_list=())
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
-OPTIMIZERS = {"adamw": torch.optim.AdamW, "adam": torch.optim.Adam, "sgd": torch.optim.SGD}
+class HipAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, optional amsgrad, param groups) with the whole parameter set
+    updated by ONE launch of the multi-tensor HIP kernel (csrc/optim.hip: ud_adamw_multi): per-group lr / weight
+    decay, bias corrections from a device-side step counter, GradScaler's 1/scale and found_inf skip read on the device
+    (`_step_supports_amp_scaling`: GradScaler.step hands both over instead of unscaling in a pass of its own).
+    Reference: engine/forgery_engine.py:149-156,228; engine/abstract_engine.py:281-283,374-378.
+    State layout: exp_avg / exp_avg_sq / max_exp_avg_sq are views of three flat buffers (16-byte aligned per tensor)."""
+
+    _step_supports_amp_scaling = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, maximize=False):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize)
+        super().__init__(params, defaults)
+        if len(self.param_groups) > 8:
+            raise ValueError("HipAdamW supports up to 8 parameter groups")
+        g0 = self.param_groups[0]
+        for g in self.param_groups:
+            if (g["betas"], g["eps"], g["amsgrad"], g["maximize"]) != (g0["betas"], g0["eps"], g0["amsgrad"], g0["maximize"]):
+                raise ValueError("HipAdamW: betas / eps / amsgrad / maximize must agree across groups")
+        self._plan = None
+        self._steps = None          # device int32 [2]: ping-pong step counter (a skipped step does not advance it)
+        self._cur = 0
+
+    def _alloc_state(self, dev):
+        import ctypes as C
+        from .. import lib
+        chunk = lib.call("ud_adamw_chunk_elems")
+        ams = self.param_groups[0]["amsgrad"]
+        total, offs = 0, {}
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                    raise ValueError("HipAdamW updates contiguous fp32 CUDA parameters")
+                offs[p] = total
+                total += (p.numel() + 3) // 4 * 4
+        names = ["exp_avg", "exp_avg_sq"] + (["max_exp_avg_sq"] if ams else [])
+        flat = {k: torch.zeros(total, dtype=torch.float32, device=dev) for k in names}
+        for p, off in offs.items():
+            st = self.state[p]
+            for k in names:
+                st[k] = flat[k][off:off + p.numel()].view_as(p)
+        self._flat, self._chunk = flat, chunk
+        self._steps = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    def _make_plan(self, active, dev):
+        """Static per set of updated tensors: chunk map and pointer table on the device."""
+        rows = []
+        for ti, (p, gi) in enumerate(active):
+            rows.extend((ti, c) for c in range(-(-p.numel() // self._chunk)))
+        chunk_map = torch.tensor(rows, dtype=torch.int32).contiguous().to(dev)
+        return {"key": tuple(id(p) for p, _ in active), "chunk_map": chunk_map, "n_chunks": len(rows),
+                "table": torch.zeros((len(active), 8), dtype=torch.int64, device=dev), "ptrs": None}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes as C
+        from .. import lib
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        active = [(p, gi) for gi, g in enumerate(self.param_groups) for p in g["params"] if p.grad is not None]
+        if not active:
+            return loss
+        dev = active[0][0].device
+        if self._steps is None:
+            self._alloc_state(dev)
+        if self._plan is None or self._plan["key"] != tuple(id(p) for p, _ in active):
+            self._plan = self._make_plan(active, dev)
+        plan = self._plan
+        ams = self.param_groups[0]["amsgrad"]
+        ptrs = []
+        for p, gi in active:
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = p.grad = g.contiguous().to(torch.float32)
+            st = self.state[p]
+            ptrs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                         st["max_exp_avg_sq"].data_ptr() if ams else 0, p.numel(), gi, 0))
+        if ptrs != plan["ptrs"]:                      # gradient buffers moved (eager backward): re-upload 64 B per tensor
+            plan["table"].copy_(torch.tensor(ptrs, dtype=torch.int64))      # synchronous staging copy, 32 KB
+            plan["ptrs"] = ptrs
+        ng = len(self.param_groups)
+        lr = (C.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
+        wd = (C.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
+        g0 = self.param_groups[0]
+        grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+
+        def dp(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        if found_inf is not None and found_inf.dtype != torch.float32:
+            found_inf = found_inf.float()
+        if grad_scale is not None and grad_scale.dtype != torch.float32:
+            grad_scale = grad_scale.float()
+        s_in = C.c_void_p(self._steps.data_ptr() + 4 * self._cur)
+        s_out = C.c_void_p(self._steps.data_ptr() + 4 * (1 - self._cur))
+        lib.call("ud_adamw_multi", dp(plan["table"]), dp(plan["chunk_map"]), plan["n_chunks"], lr, wd, ng,
+                 float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), int(bool(ams)), int(bool(g0["maximize"])),
+                 dp(grad_scale), dp(found_inf), s_in, s_out, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self._cur = 1 - self._cur
+        return loss
+
+    def step_count(self):
+        """Number of applied (not skipped) steps — one device read."""
+        return 0 if self._steps is None else int(self._steps[self._cur].item())
+
+
+OPTIMIZERS = {"adamw": torch.optim.AdamW, "adam": torch.optim.Adam, "sgd": torch.optim.SGD, "hip_adamw": HipAdamW}
 
 
 def get_optimizer(name, params, **kwargs):
@@ -35,11 +144,13 @@ def build_optimizer(model, opt_cfg):
     if "betas" in cfg:
         cfg["betas"] = tuple(cfg["betas"])
     groups = param_groups_weight_decay(model, wd)
-    # torch's fused multi-tensor Adam(W) streams the 128 M parameters + 3 state tensors at 3.8 TB/s on MI355X
-    # (1.2 ms per step vs 3.1 ms for the foreach implementation; tools/bench_optim.py): SURVEY row (f)2 needs no
-    # custom kernel beyond it
-    if name.lower() in ("adamw", "adam") and "fused" not in cfg and "foreach" not in cfg \
-            and all(p.is_cuda for g in groups for p in g["params"]):
+    on_gpu = all(p.is_cuda for g in groups for p in g["params"])
+    # AdamW on the GPU = the multi-tensor HIP kernel (one launch for the 504 tensors, GradScaler's
+    # unscale / found_inf folded in); UD_HIP_ADAMW=0 or explicit fused / foreach keys keep torch's implementation
+    if name.lower() == "adamw" and on_gpu and "fused" not in cfg and "foreach" not in cfg \
+            and os.environ.get("UD_HIP_ADAMW", "1") == "1":
+        return HipAdamW(groups, **cfg)
+    if name.lower() in ("adamw", "adam") and "fused" not in cfg and "foreach" not in cfg and on_gpu:
         cfg["fused"] = True
     return get_optimizer(name, groups, **cfg)
 
