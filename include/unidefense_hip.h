@@ -393,6 +393,16 @@ int ud_adamw_multi(const void* table, const void* chunk_map, int n_chunks, const
                    double beta1, double beta2, double eps, int amsgrad, int maximize, const float* grad_scale,
                    const float* found_inf, const int* step_in, int* step_out, ud_stream_t stream);
 
+/* ---- large real 2-D FFT of image planes (csrc/fft_large.hip), S in {128, 256, 320} ------------------------------------
+ * torch.fft.rfft2 on [N,3,S,S] images: the frequency reconstruction loss (model/unidefense.py:246-253; ResNet variants
+ * :421-431, :615-625) and FrequencyStyleTransfer (model/modules.py:35-55), with their autograd adjoint.
+ * Y[P][2S][Whp]: rows [0,S) = Re(ky), rows [S,2S) = Im(ky); columns [0, S/2] valid, the rest (Whp = ceil4(S/2+1)) zero.
+ * ws: ud_rfft2_planes_ws_floats(P, S) floats of scratch.  The adjoint maps dY back to dx[P][S][S] (transpose of the
+ * real-linear map x -> (Re Y, Im Y), same scale): with dY weighted 2 on the interior columns it is irfft2. */
+long ud_rfft2_planes_ws_floats(long P, int S);
+int ud_rfft2_planes(const float* x, float* Y, float* ws, long P, int S, float scale, ud_stream_t stream);
+int ud_rfft2_planes_adjoint(const float* dY, float* dx, float* ws, long P, int S, float scale, ud_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

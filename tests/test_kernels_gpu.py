@@ -670,3 +670,34 @@ def test_dynamic_filter(kind):
     check("dx", to_nchw(gin[0]), xr.grad)
     for p_, k_ in zip(gp, ("f.layer1.0.weight", "f.layer1.1.weight", "f.layer1.1.bias", "f.layer2.0.weight")):
         check("d " + k_, p_, sd[k_].grad)
+
+
+# ---------------------------------------------------------------------------------------------
+# large real 2-D FFT of image planes (csrc/fft_large.hip): loss tail + amplitude transfer at 128 / 256 / 320
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S", [128, 256, 320])
+@pytest.mark.parametrize("P", [1, 7])
+def test_rfft2_planes_large(S, P):
+    """ud_rfft2_planes vs torch.fft.rfft2 (float64, norm='ortho') and its adjoint vs the transpose identity
+    <Y(x), G> == <x, adj(G)> and vs autograd; <= 1e-5 of the largest entry."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(S + P)
+    x = torch.randn(P, S, S, generator=g)
+    Y = K.dft_rfft2_planes(x.to(dev).contiguous())
+    Wh, Whp = S // 2 + 1, -(-(S // 2 + 1) // 4) * 4
+    assert tuple(Y.shape) == (P, 2 * S, Whp)
+    ref = torch.fft.rfft2(x.double(), norm="ortho")                       # [P, S, Wh]
+    got_re, got_im = Y[:, :S, :Wh].double().cpu(), Y[:, S:, :Wh].double().cpu()
+    scale = float(ref.abs().max())
+    assert float((got_re - ref.real).abs().max()) <= 1e-5 * scale
+    assert float((got_im - ref.imag).abs().max()) <= 1e-5 * scale
+    assert float(Y[:, :, Wh:].abs().max()) == 0.0                          # padding columns
+    # adjoint: gradient of sum(G * Y) w.r.t. x through torch's rfft2
+    G = torch.randn(P, 2 * S, Whp, generator=g)
+    G[:, :, Wh:] = 0
+    xd = x.double().requires_grad_(True)
+    Yd = torch.fft.rfft2(xd, norm="ortho")
+    (Yd.real * G[:, :S, :Wh].double()).sum().add((Yd.imag * G[:, S:, :Wh].double()).sum()).backward()
+    adj = K.dft_rfft2_planes_adjoint(G.to(dev).contiguous(), S).double().cpu()
+    assert float((adj - xd.grad).abs().max()) <= 1e-5 * float(xd.grad.abs().max())

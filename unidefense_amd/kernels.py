@@ -780,11 +780,28 @@ def _dft_mats(S, device, ortho=True):
     return mats
 
 
+_FFT_PLANES_WS = {}
+_FFT_PLANES_SIZES = (128, 256, 320)          # csrc/fft_large.hip
+
+
+def _fft_planes_ws(ref, P, S):
+    need = _call("ud_rfft2_planes_ws_floats", P, S)
+    ws = _FFT_PLANES_WS.get(ref.device)
+    if ws is None or ws.numel() < need:
+        ws = _FFT_PLANES_WS[ref.device] = empty((need,), ref)
+    return ws
+
+
 def dft_rfft2_planes(d, ortho=True):
     """d: [P, S, S] real planes -> Y [P, 2S, Whp]: rows [0,S) = Re(ky), rows [S,2S) = Im(ky); columns
-    [0, S/2] valid, the rest zero padding (Whp = ceil4(S/2+1))."""
+    [0, S/2] valid, the rest zero padding (Whp = ceil4(S/2+1)).  S in {128, 256, 320}: the row / column FFT kernels
+    of csrc/fft_large.hip; other sizes: three batched GEMMs against DFT matrices."""
     _chk(d)
     P, S, _ = d.shape
+    if S in _FFT_PLANES_SIZES and os.environ.get("UD_FFT_PLANES_GEMM", "0") != "1":
+        Y = empty((P, 2 * S, -(-(S // 2 + 1) // 4) * 4), d)
+        _call("ud_rfft2_planes", _p(d), _p(Y), _p(_fft_planes_ws(d, P, S)), P, S, (1.0 / S) if ortho else 1.0, _stream())
+        return Y
     fw_cos, fw_sin, fh = _dft_mats(S, d.device, ortho)
     Whp = fw_cos.shape[0]
     d2 = d.view(P * S, S)
@@ -803,6 +820,11 @@ def dft_rfft2_planes_adjoint(dY, S, ortho=True):
     """Adjoint of dft_rfft2_planes: dY [P, 2S, Whp] -> dd [P, S, S]."""
     _chk(dY)
     P = dY.shape[0]
+    if S in _FFT_PLANES_SIZES and os.environ.get("UD_FFT_PLANES_GEMM", "0") != "1":
+        dd = empty((P, S, S), dY)
+        _call("ud_rfft2_planes_adjoint", _p(dY), _p(dd), _p(_fft_planes_ws(dY, P, S)), P, S, (1.0 / S) if ortho else 1.0,
+              _stream())
+        return dd
     fw_cos, fw_sin, fh = _dft_mats(S, dY.device, ortho)
     Whp = fw_cos.shape[0]
     dt_re = empty((P * S, Whp), dY)
