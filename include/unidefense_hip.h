@@ -69,6 +69,8 @@ int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
  *     and the gather modes run on v_mfma_f32_32x32x2_f32;
  *   1 fp32 MFMA only;   2 split-bf16 wherever eligible. */
 int ud_gemm_set_path(int path);
+/* 2 if ud_gemm would run this descriptor on the BF16 matrix pipe (split-bf16 kernel), 1 for the fp32 pipe */
+int ud_gemm_query_path(const ud_gemm_desc* d);
 
 /* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------
  * Every reduction is a partial pass (fp64 per-workgroup totals stored into the scratch `ws`) plus a small

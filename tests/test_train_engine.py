@@ -60,6 +60,26 @@ def test_engine_trains_and_tests_on_synthetic_batches():
     res = eng.test(batches=2)
     assert res["scores"].shape == (8,) and 0.0 <= res["acc"] <= 1.0
     assert torch.isfinite(res["scores"]).all()
+    # the test stage's metrics (forgery_engine.py:446-452) and the checkpoint round trip ON the GPU model:
+    for k in ("AUC", "EER", "ACER", "TPR5%", "ACC", "NumP", "NumN"):
+        assert k in res, sorted(res)
+    assert res["NumP"] == 4 and res["NumN"] == 4 and 0.0 <= res["AUC"] <= 1.0
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        eng.config["config"]["dir"] = d
+        val = eng.validate(step=4, batches=2)
+        assert eng.best_step == 4 and eng.best_auc == val["AUC"] and eng.best_acc == val["ACC"]
+        import os
+        assert sorted(os.listdir(d)) == ["best_model.bin", "latest_model.bin"]
+        ck = torch.load(os.path.join(d, "best_model.bin"), map_location="cpu")
+        assert ck["step"] == 4 and round(ck["best_auc"], 4) == round(val["AUC"], 4)        # the reference's reader idiom
+        cfg2 = copy.deepcopy(CONFIG)
+        cfg2["config"].update(dir=d, resume=True)
+        eng2 = get_engine("FE")(cfg2, "Test")
+        for (k1, a), (_, b) in zip(eng.model.state_dict().items(), eng2.model.state_dict().items()):
+            assert torch.equal(a, b), k1
+        res2 = eng2.test(batches=2)
+        assert torch.equal(res2["scores"], res["scores"])          # same weights, same synthetic test batches
 
 
 @pytest.mark.gpu

@@ -1,0 +1,49 @@
+"""Recompute bench.py's `roofline` numbers from the committed profile of the same command:
+
+  python tools/roofline_from_rocprof.py profiles/r02/rocprofv3_kernel_stats_bench_bs32.csv profiles/r02/gemm_table_bs32.txt STEPS
+
+kernel_stats.csv: `rocprofv3 --kernel-trace --stats` summary (graph-replayed + eager steps of one bench run, STEPS executed
+steps in total: tools/gpu_round.sh prints the count); gemm_table: bench.py --gemm-table (algorithmic GFLOP per step and shape,
+pipe = 2 for the split-bf16 kernel).  Prints the per-step time of gemm_x3_kernel from the profiler, its algorithmic
+fp32 TFLOP/s, the executed bf16 MFMA TFLOP/s (x 6) and the fraction of the 2500 TFLOP/s dense BF16 pipe peak."""
+import csv
+import sys
+
+
+def main(stats_csv, table_txt, steps):
+    steps = float(steps)
+    x3_ns = f32_ns = total_ns = 0.0
+    with open(stats_csv) as fh:
+        for row in csv.DictReader(fh):
+            ns = float(row["TotalDurationNs"])
+            total_ns += ns
+            if "gemm_x3_kernel" in row["Name"]:
+                x3_ns += ns
+            elif "gemm_kernel" in row["Name"]:
+                f32_ns += ns
+    x3_gflop = f32_gflop = 0.0
+    with open(table_txt) as fh:
+        for ln in fh:
+            if ln.startswith("#") or ln.startswith("M "):
+                continue
+            left, right = ln.split("|")
+            pipe = int(left.split()[7])
+            gflop = float(right.split()[4])
+            if pipe == 2:
+                x3_gflop += gflop
+            else:
+                f32_gflop += gflop
+    x3_ms, f32_ms = x3_ns / steps / 1e6, f32_ns / steps / 1e6
+    alg = x3_gflop / x3_ms                      # GFLOP / ms = TFLOP/s
+    print(f"all kernels           : {total_ns / steps / 1e6:8.3f} ms/step")
+    print(f"gemm_x3_kernel        : {x3_ms:8.3f} ms/step, {x3_gflop:8.1f} GFLOP/step algorithmic -> {alg:6.1f} TFLOP/s fp32-equivalent")
+    print(f"  executed bf16 MFMA  : {6 * alg:8.1f} TFLOP/s = {6 * alg / 2500:.3f} of the 2500 TFLOP/s dense BF16 peak (roofline.frac)")
+    print(f"  as fp32 work        : {alg / 157.3:.3f} of the 157.3 TFLOP/s fp32 matrix peak (roofline.frac_fp32_equiv)")
+    if f32_ms > 0:
+        print(f"gemm_kernel (fp32 pipe): {f32_ms:8.3f} ms/step, {f32_gflop:8.1f} GFLOP/step -> {f32_gflop / f32_ms:6.1f} TFLOP/s "
+              f"= {f32_gflop / f32_ms / 157.3:.3f} of the fp32 matrix peak")
+    print(f"non-GEMM kernels      : {(total_ns - x3_ns - f32_ns) / steps / 1e6:8.3f} ms/step")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

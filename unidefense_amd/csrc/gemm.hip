@@ -441,20 +441,43 @@ extern "C" int ud_gemm_set_path(int path) {
     return 0;
 }
 
-extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
-    if (!dp) return UD_EINVAL;
-    ud_gemm_desc d = *dp;
-    if (d.M <= 0 || d.N <= 0 || d.K < 0 || d.split_k < 1 || d.batch < 1) return UD_EINVAL;
-    if (d.split_k > 1 && d.out_mode != 2) return UD_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    // vector-load eligibility
-    int a_vec = 0, b_vec = 0;
+// vector-load eligibility of the two operands
+static void vec_flags(const ud_gemm_desc& d, int& a_vec, int& b_vec) {
     if (d.a_mode == 0) a_vec = aligned16(d.A) && d.lda % 4 == 0 && d.strideA % 4 == 0;
     else if (d.a_mode == 1) a_vec = aligned16(d.A) && d.lda % 4 == 0 && d.strideA % 4 == 0;
     else a_vec = aligned16(d.A) && d.g.Cin % 4 == 0;
     if (d.b_mode == 0) b_vec = aligned16(d.B) && d.ldb % 4 == 0 && d.strideB % 4 == 0;
     else if (d.b_mode == 1) b_vec = aligned16(d.B) && d.ldb % 4 == 0 && d.strideB % 4 == 0;
     else b_vec = aligned16(d.B) && d.g.Cin % 4 == 0;
+}
+
+// the split-bf16 kernel takes every eligible plain GEMM but the tiny shapes.  The thin early-stage pointwise convs
+// (K or N = 24..56) are HBM-bound either way and stream better through its 3-deep register prefetch (A/B on the bench:
+// minimum dimension 64 -> 16: 38.33 -> 37.85 ms/step; 1: no further change)
+static bool takes_x3(const ud_gemm_desc& d, int a_vec, int b_vec) {
+    const int path = g_path.load();
+    if (path == 1 || !ud_gemm_x3_eligible(d, a_vec != 0, b_vec != 0)) return false;
+    static const int min_dim = getenv("UD_GEMM_X3_MINDIM") ? atoi(getenv("UD_GEMM_X3_MINDIM")) : 16;
+    return path == 2 || (d.M >= min_dim && d.N >= min_dim && d.K >= min_dim);
+}
+
+// 2: this descriptor runs on the BF16 matrix pipe (gemm_x3.hip: 6 v_mfma_f32_32x32x16_bf16 per fp32 product tile),
+// 1: on the fp32 pipe (v_mfma_f32_32x32x2_f32) — what bench.py prices the executed MFMA work with
+extern "C" int ud_gemm_query_path(const ud_gemm_desc* dp) {
+    if (!dp) return UD_EINVAL;
+    int a_vec = 0, b_vec = 0;
+    vec_flags(*dp, a_vec, b_vec);
+    return takes_x3(*dp, a_vec, b_vec) ? 2 : 1;
+}
+
+extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
+    if (!dp) return UD_EINVAL;
+    ud_gemm_desc d = *dp;
+    if (d.M <= 0 || d.N <= 0 || d.K < 0 || d.split_k < 1 || d.batch < 1) return UD_EINVAL;
+    if (d.split_k > 1 && d.out_mode != 2) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int a_vec = 0, b_vec = 0;
+    vec_flags(d, a_vec, b_vec);
     if (d.a_mode == 2 || d.b_mode == 2) {
         const ud_conv_geom& g = d.g;
         if (g.N <= 0 || g.Hin <= 0 || g.Win <= 0 || g.Cin <= 0 || g.Hout <= 0 || g.Wout <= 0 || g.KH <= 0 ||
@@ -464,14 +487,7 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         if (d.a_mode == 2 && (rows != d.M || cols != d.K)) return UD_EINVAL;
         if (d.b_mode == 2 && (rows != d.K || cols != d.N)) return UD_EINVAL;
     }
-    const int path = g_path.load();
-    if (path != 1 && ud_gemm_x3_eligible(d, a_vec != 0, b_vec != 0)) {
-        // auto: everything but the tiny shapes.  The thin early-stage pointwise convs (K or N = 24..56) are
-        // HBM-bound either way and stream better through this kernel's 3-deep register prefetch (A/B on the bench:
-        // minimum dimension 64 -> 16: 38.33 -> 37.85 ms/step; 1: no further change)
-        static const int min_dim = getenv("UD_GEMM_X3_MINDIM") ? atoi(getenv("UD_GEMM_X3_MINDIM")) : 16;
-        if (path == 2 || (d.M >= min_dim && d.N >= min_dim && d.K >= min_dim)) return ud_gemm_x3_launch(d, s);
-    }
+    if (takes_x3(d, a_vec, b_vec)) return ud_gemm_x3_launch(d, s);
 #ifdef UD_GEMM_DEBUG_NOLOAD      // tuning aid, debug builds only: issue no global loads (results are WRONG)
     static const bool noload = getenv("UD_GEMM_NOLOAD") != nullptr;
     if (noload) a_vec |= 2;

@@ -69,8 +69,14 @@ class TrainEngine(AbstractEngine):
         self.model_without_ddp = self.model
         if dist.is_available() and dist.is_initialized():
             self.model = wrap_data_parallel(self.model, self.local_rank)           # SyncBN + gradient exchange
-        if self.config["config"].get("resume") and os.path.exists(self._ckpt_path()):
-            self._load_ckpt(train=stage == "Train")
+        if self.config["config"].get("resume"):
+            # the test stage evaluates best_model.bin (forgery_engine.py:202), training resumes from latest_model.bin
+            best = stage == "Test" and os.path.exists(self._ckpt_path(best=True))
+            if os.path.exists(self._ckpt_path(best)):
+                meta = self._load_ckpt(best=best, train=stage == "Train")
+                self.best_step = int(meta.get("best_step", self.best_step) or self.best_step)
+                self.best_auc = float(meta.get("best_auc", self.best_auc) or self.best_auc)
+                self.best_acc = float(meta.get("best_acc", self.best_acc) or self.best_acc)
         if stage == "Train":
             self.base_lr = float(cfg["optimizer"]["lr"])
             self.optimizer = build_optimizer(self.model_without_ddp, cfg["optimizer"])
@@ -143,16 +149,41 @@ class TrainEngine(AbstractEngine):
             raise
 
     @torch.no_grad()
-    def test(self, batches=4):
-        """Inference forward (model(x)['cls_out'] -> softmax[:, 0], forgery_engine.py:320-452 without the ROC metrics)."""
+    def _score(self, batches):
+        """p(real) = softmax(cls_out)[:, 0] of `batches` test batches (forgery_engine.py:349,437), gathered over the
+        ranks with two device all_gathers (engine/metrics.py:gather_scores replaces dist.all_gather_object, :374-375)."""
+        from .metrics import gather_scores
         self.model.eval()
         scores, labels = [], []
         for step in range(1, batches + 1):
             xr, yr, xf, yf = self.test_iterator(step, self.batch, self.size, self.device)
-            out = self.model(torch.cat([xr, xf], 0).contiguous())
+            out = self.model(torch.cat([xr, xf], 0).contiguous())          # inference forward: no tape, running statistics
             scores.append(torch.softmax(out["cls_out"], 1)[:, 0])
             labels.append(torch.cat([yr, yf], 0))
-        scores, labels = torch.cat(scores), torch.cat(labels)
-        acc = ((scores < 0.5).long() == labels).float().mean()
-        acc, = self._mean_over_ranks([acc])
-        return {"acc": acc, "scores": scores.cpu(), "labels": labels.cpu()}
+        return gather_scores(torch.cat(scores), torch.cat(labels))
+
+    def test(self, batches=4):
+        """The reference's test stage (forgery_engine.py:423-452): scores -> cal_metrics (EER, HTER = ACER, TPR@5 %, AUC,
+        ACC, ...) over the frames of all ranks."""
+        from .metrics import cal_metrics
+        scores, labels = self._score(batches)
+        sc, lb = scores.float().cpu().numpy(), labels.cpu().numpy()
+        ret = {"scores": scores.cpu(), "labels": labels.cpu(), "acc": float(((sc < 0.5).astype(int) == lb).mean())}
+        if len(set(lb.tolist())) == 2:                     # a ROC needs both classes
+            ret.update(cal_metrics(lb, sc, threshold=0.5))
+            if self.local_rank == 0:
+                print("Test | EER %.4f, HTER %.4f, TPR 5%% %.4f, AUC %.4f, ACC %.4f" % (
+                    ret["EER"], ret["ACER"], ret["TPR5%"], ret["AUC"], ret["ACC"]))
+        return ret
+
+    def validate(self, step, batches=4):
+        """The reference's validate (forgery_engine.py:320-421) without the figure / wandb plumbing: metrics over all
+        ranks, best-so-far record (AUC + ACC), best_model.bin / latest_model.bin on rank 0."""
+        ret = self.test(batches)
+        if "AUC" in ret and ret["AUC"] + ret["ACC"] > self.best_auc + self.best_acc:
+            self.best_auc, self.best_acc, self.best_step = float(ret["AUC"]), float(ret["ACC"]), int(step)
+            if self.config["config"].get("dir"):
+                self._save_ckpt(step, best=True)
+        if self.config["config"].get("dir"):
+            self._save_ckpt(step, best=False)
+        return ret

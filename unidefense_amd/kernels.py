@@ -116,7 +116,8 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
         e0.record()
         _call("ud_gemm", C.byref(d), _stream())
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, a_mode, b_mode, split_k, batch)))
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, a_mode, b_mode, split_k, batch),
+                             _call("ud_gemm_query_path", C.byref(d))))
         return Cout
     _call("ud_gemm", C.byref(d), _stream())
     return Cout

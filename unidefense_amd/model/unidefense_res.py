@@ -108,6 +108,7 @@ class UniDefenseModelRes18(nn.Module):
     # the generic forward (perturbation, autograd node, return dict) and helpers are shared with the Eb4 model
     forward = UniDefenseModelEb4.forward
     _bn = UniDefenseModelEb4._bn
+    _sync_group = UniDefenseModelEb4._sync_group
     _keep_mask = UniDefenseModelEb4._keep_mask
     _to_pix_mask = staticmethod(UniDefenseModelEb4._to_pix_mask)
 
