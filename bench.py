@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--model", default="UDEB4", choices=["UDEB4", "UDR18", "UDR50"],
                     help="informational runs of the other BASELINE configs (the contract line is UDEB4)")
     ap.add_argument("--size", type=int, default=256, help="input resolution (UDR18: 128, UDR50: 256 or 320)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="f32: the contract line (fp32-accurate GEMMs).  f16: informational, BASELINE configs[4]: fp16 MFMA "
+                         "operands + fp32 accumulation in every plain GEMM (ud_gemm path 3), fp32 storage; use --batch 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM timing table to this file")
@@ -175,6 +178,9 @@ def main():
     from unidefense_amd.model import load_model
     from unidefense_amd.engine.parallel import wrap_data_parallel
 
+    if args.dtype == "f16":
+        from unidefense_amd import lib as _udlib
+        _udlib.call("ud_gemm_set_path", 3)
     torch.manual_seed(1234)
     ctor = dict(extractor="efficientnet-b4") if args.model == "UDEB4" else {}
     model = load_model(args.model)(num_classes=2, drop_rate=0.5, **ctor).to(dev).train()
@@ -285,8 +291,9 @@ def main():
                          (*key, cnt, ms, ms / prof_steps, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0, fl / 1e9 / prof_steps))
     if rank == 0:
         # the dominant kernel is gemm_x3_kernel: launches ud_gemm routes to the BF16 matrix pipe (ud_gemm_query_path == 2)
-        x3 = [p for p in prof if p[4] == 2]
-        f32 = [p for p in prof if p[4] != 2]
+        x3 = [p for p in prof if p[4] in (2, 3)]
+        f32 = [p for p in prof if p[4] not in (2, 3)]
+        mfma_per_product = 1 if args.dtype == "f16" else X3_MFMA_PER_PRODUCT
         x3_ms = sum(p[0].elapsed_time(p[1]) for p in x3)
         x3_flops = sum(p[2] for p in x3)
         f32_ms = sum(p[0].elapsed_time(p[1]) for p in f32)
@@ -298,16 +305,17 @@ def main():
         alg_bytes = sum(4.0 * max(k[6], 1) * (k[0] * k[2] + k[2] * k[1] + k[0] * k[1]) for _, _, _, k, _ in x3) / max(len(x3), 1)
         traffic, traffic_src = _pmc_traffic(args, bs)
         line = {
-            "metric": "images/sec fwd+bwd (256x256, EffNet-b4)" if (args.model, args.size) == ("UDEB4", 256)
-            else f"images/sec fwd+bwd ({args.size}x{args.size}, {args.model})",
+            "metric": ("images/sec fwd+bwd (256x256, EffNet-b4)" if (args.model, args.size) == ("UDEB4", 256)
+                       else f"images/sec fwd+bwd ({args.size}x{args.size}, {args.model})")
+            + (" [informational: fp16 MFMA operands, fp32 accumulate/storage]" if args.dtype == "f16" else ""),
             "value": world * bs * args.steps / elapsed,
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("UDEB4 (EfficientNet-b4 + SFConv) 256x256 fwd + pass-1 loss + bwd, "
                                     "spatial+frequency branches on, bs=32/GPU (BASELINE configs[1]/[2])")
-                       if (args.model, args.size, bs) == ("UDEB4", 256, 32) else
-                       f"{args.model} {args.size}x{args.size} fwd + pass-1 loss + bwd, bs={bs}/GPU (informational)",
+                       if (args.model, args.size, bs, args.dtype) == ("UDEB4", 256, 32, "f32") else
+                       f"{args.model} {args.size}x{args.size} fwd + pass-1 loss + bwd, bs={bs}/GPU, dtype {args.dtype} (informational)",
                        "global_batch": world * bs, "parallelism": f"dp{world}", "exec": exec_mode,
                        "n_ranks_seen": n_ranks_seen,
                        "final_loss": float(loss.detach()),
@@ -320,10 +328,11 @@ def main():
                                    "fp32-GEMM accuracy.  achieved = algorithmic fp32 FLOPs (2MNK) of its launches / their "
                                    "HIP-event time; peak = the pipe's dense BF16 peak (2500 TFLOP/s) / 6 executed MFMAs per "
                                    "algorithmic product, so frac = executed MFMA work / pipe peak",
-                         "achieved": achieved, "peak": BF16_PEAK_TFLOPS / X3_MFMA_PER_PRODUCT, "unit": "TFLOP/s",
-                         "frac": achieved * X3_MFMA_PER_PRODUCT / BF16_PEAK_TFLOPS,
-                         "executed_mfma_tflops": achieved * X3_MFMA_PER_PRODUCT, "pipe_peak": BF16_PEAK_TFLOPS,
-                         "frac_of_pipe": achieved * X3_MFMA_PER_PRODUCT / BF16_PEAK_TFLOPS,
+                         "achieved": achieved, "peak": BF16_PEAK_TFLOPS / mfma_per_product, "unit": "TFLOP/s",
+                         "frac": achieved * mfma_per_product / BF16_PEAK_TFLOPS,
+                         "executed_mfma_tflops": achieved * mfma_per_product, "pipe_peak": BF16_PEAK_TFLOPS,
+                         "mfma_per_product": mfma_per_product,
+                         "frac_of_pipe": achieved * mfma_per_product / BF16_PEAK_TFLOPS,
                          # the same launches priced as fp32 work against the fp32 matrix peak (bounded by 2.67, not 1)
                          "frac_fp32_equiv": achieved / MFMA_F32_PEAK_TFLOPS,
                          "traffic": traffic,

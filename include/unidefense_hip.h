@@ -67,9 +67,12 @@ int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
  *     matrix pipe with every fp32 operand split exactly into three bf16 pieces and six piece products
  *     accumulated in fp32 (csrc/gemm_x3.hip: fp32-GEMM accuracy, error terms < 2^-26 |a||b|); all other shapes
  *     and the gather modes run on v_mfma_f32_32x32x2_f32;
- *   1 fp32 MFMA only;   2 split-bf16 wherever eligible. */
+ *   1 fp32 MFMA only;   2 split-bf16 wherever eligible;
+ *   3 mixed precision (BASELINE configs[4]): wherever the split-bf16 kernel would run, the operands are rounded to fp16
+ *     and multiplied by ONE v_mfma_f32_32x32x16_f16 per product tile with fp32 accumulation (fp32 storage stays). */
 int ud_gemm_set_path(int path);
-/* 2 if ud_gemm would run this descriptor on the BF16 matrix pipe (split-bf16 kernel), 1 for the fp32 pipe */
+/* 2 if ud_gemm would run this descriptor on the BF16 matrix pipe (split-bf16 kernel), 3 for its fp16 mixed-precision
+ * mode (path 3), 1 for the fp32 pipe */
 int ud_gemm_query_path(const ud_gemm_desc* d);
 
 /* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------

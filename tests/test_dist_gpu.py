@@ -40,9 +40,12 @@ def test_bench_line_contract():
     assert "workload" in line["config"] and line["config"]["exec"] == "hipgraph", err[-1500:]
     assert abs(line["value"] - 8 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]          # bs 8 in _bench
     r = line["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 3.0
-    assert "traffic" in r
+    # the split-bf16 kernel is priced against ITS pipe: peak = 2500 TFLOP/s dense BF16 / 6 MFMAs per fp32 product
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["peak"] - 2500.0 / 6) < 1e-9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert abs(r["executed_mfma_tflops"] - 6 * r["achieved"]) < 1e-6 and r["pipe_peak"] == 2500.0
+    assert abs(r["frac_of_pipe"] - r["frac"]) < 1e-12 and abs(r["frac_fp32_equiv"] - r["achieved"] / 157.3) < 1e-9
+    assert "traffic" in r and line["config"]["n_ranks_seen"] == 1
 
 
 @pytest.mark.parametrize("flags", [(), ("--eager",)])

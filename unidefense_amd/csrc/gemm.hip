@@ -427,16 +427,17 @@ int launch_modes(const ud_gemm_desc& d, int a_vec, int b_vec, hipStream_t s) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// 0 auto, 1 fp32 MFMA only (v_mfma_f32_32x32x2_f32), 2 split-bf16 wherever eligible (gemm_x3.hip)
+// 0 auto, 1 fp32 MFMA only (v_mfma_f32_32x32x2_f32), 2 split-bf16 wherever eligible (gemm_x3.hip),
+// 3 mixed precision: fp16 MFMA operands + fp32 accumulation wherever the split-bf16 kernel would run (BASELINE configs[4])
 std::atomic<int> g_path{[] {
     const char* e = getenv("UD_GEMM_PATH");
-    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+    return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
 }()};
 
 }  // namespace
 
 extern "C" int ud_gemm_set_path(int path) {
-    if (path < 0 || path > 2) return UD_EINVAL;
+    if (path < 0 || path > 3) return UD_EINVAL;
     g_path.store(path);
     return 0;
 }
@@ -458,16 +459,16 @@ static bool takes_x3(const ud_gemm_desc& d, int a_vec, int b_vec) {
     const int path = g_path.load();
     if (path == 1 || !ud_gemm_x3_eligible(d, a_vec != 0, b_vec != 0)) return false;
     static const int min_dim = getenv("UD_GEMM_X3_MINDIM") ? atoi(getenv("UD_GEMM_X3_MINDIM")) : 16;
-    return path == 2 || (d.M >= min_dim && d.N >= min_dim && d.K >= min_dim);
+    return path == 2 || path == 3 || (d.M >= min_dim && d.N >= min_dim && d.K >= min_dim);
 }
 
 // 2: this descriptor runs on the BF16 matrix pipe (gemm_x3.hip: 6 v_mfma_f32_32x32x16_bf16 per fp32 product tile),
-// 1: on the fp32 pipe (v_mfma_f32_32x32x2_f32) — what bench.py prices the executed MFMA work with
+// 3: the same kernel with ONE v_mfma_f32_32x32x16_f16 per product tile (path 3), 1: on the fp32 pipe (v_mfma_f32_32x32x2_f32) — what bench.py prices the executed MFMA work with
 extern "C" int ud_gemm_query_path(const ud_gemm_desc* dp) {
     if (!dp) return UD_EINVAL;
     int a_vec = 0, b_vec = 0;
     vec_flags(*dp, a_vec, b_vec);
-    return takes_x3(*dp, a_vec, b_vec) ? 2 : 1;
+    return takes_x3(*dp, a_vec, b_vec) ? (g_path.load() == 3 ? 3 : 2) : 1;
 }
 
 extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
@@ -487,7 +488,7 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         if (d.a_mode == 2 && (rows != d.M || cols != d.K)) return UD_EINVAL;
         if (d.b_mode == 2 && (rows != d.K || cols != d.N)) return UD_EINVAL;
     }
-    if (takes_x3(d, a_vec, b_vec)) return ud_gemm_x3_launch(d, s);
+    if (takes_x3(d, a_vec, b_vec)) return ud_gemm_x3_launch(d, s, g_path.load() == 3);
 #ifdef UD_GEMM_DEBUG_NOLOAD      // tuning aid, debug builds only: issue no global loads (results are WRONG)
     static const bool noload = getenv("UD_GEMM_NOLOAD") != nullptr;
     if (noload) a_vec |= 2;

@@ -5,4 +5,4 @@
 
 // plain GEMM modes with 16-byte-loadable operands and no ragged vector tails
 bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec);
-int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s);
+int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s, bool f16);

@@ -37,6 +37,14 @@ __device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// (lo = fp16(x), hi = fp16(y)), round-to-nearest-even
+__device__ __forceinline__ uint32_t pack_f16(float x, float y) {
+    f16x2 v = {(_Float16)x, (_Float16)y};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 // exact three-way split of two floats; p[i] packs piece i of (x, y)
 __device__ __forceinline__ void split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
     p0 = pack_bf16(x, y);
@@ -72,14 +80,21 @@ __device__ __forceinline__ int phys_row(int row) { return row ^ ((row >> 3) & 1)
 // Loads are branch-free (addresses clamped into the operand, validity re-derived at store time): a load under a
 // branch made hipcc wait for it on the spot, which serialised the whole prefetch ring.
 // ---------------------------------------------------------------------------------------------------------
-template <int ROWS, int MODE>
+// PREC 3: the exact three-way bf16 split (fp32 GEMM accuracy).
+// PREC 1: ONE fp16 piece per operand (round to nearest even): the mixed-precision mode of BASELINE configs[4] — fp16 MFMA
+//         operands, fp32 accumulation, one v_mfma_f32_32x32x16_f16 instead of six bf16 MFMAs.
+// PREC 0: experiments only (-DUD_X3_FAKE_A / -DUD_X3_FAKE_B): three identical bf16 pieces, i.e. the split's arithmetic
+//         removed, to measure what it costs (measured: 4-8 % for B alone, 10-12 % for both: not the limiter).
+template <int ROWS, int MODE, int PREC = 3>
 struct XLoader {
+    static constexpr bool FAKE = PREC == 0;
+    static constexpr int NPL = PREC == 1 ? 1 : 3;      // bf16 / fp16 planes per operand
     static constexpr int GS = ROWS * 16 + 32;          // bytes of one (plane, k-group) image
-    static constexpr int STAGE = 6 * GS;               // 3 planes x 2 k-groups
+    static constexpr int STAGE = 2 * NPL * GS;         // planes x 2 k-groups
     static constexpr int NV0 = ROWS / 64;              // MODE 0: float4 (4 k of one row) per thread
     static constexpr int VEC = ROWS / 32;              // MODE 1: rows per thread (x 2 consecutive k)
     static constexpr int NV = MODE == 0 ? NV0 : 2;
-    static constexpr int NWRITE = MODE == 0 ? 3 * NV0 : 3 * VEC;    // ds_write instructions per stage
+    static constexpr int NWRITE = MODE == 0 ? NPL * NV0 : NPL * VEC;    // ds_write instructions per stage
     using V = typename std::conditional<(MODE == 0 || VEC == 4), f32x4, f32x2>::type;
 
     const float* base;
@@ -138,13 +153,23 @@ struct XLoader {
                 int row = f >> 2, kq = f & 3;
                 const bool ok = rowok[i] && (k0 + kq * 4 <= k_last);
                 V v = regs[S][i];
-                uint32_t a0, a1, a2, b0, b1, b2;
-                split2(ok ? v[0] : 0.f, ok ? v[1] : 0.f, a0, a1, a2);
-                split2(ok ? v[2] : 0.f, ok ? v[3] : 0.f, b0, b1, b2);
                 char* p = L + (kq >> 1) * GS + phys_row(row) * 16 + (kq & 1) * 8;
-                *reinterpret_cast<u32x2*>(p) = u32x2{a0, b0};
-                *reinterpret_cast<u32x2*>(p + 2 * GS) = u32x2{a1, b1};
-                *reinterpret_cast<u32x2*>(p + 4 * GS) = u32x2{a2, b2};
+                if constexpr (PREC == 1) {
+                    *reinterpret_cast<u32x2*>(p) = u32x2{pack_f16(ok ? v[0] : 0.f, ok ? v[1] : 0.f),
+                                                         pack_f16(ok ? v[2] : 0.f, ok ? v[3] : 0.f)};
+                } else {
+                    uint32_t a0, a1, a2, b0, b1, b2;
+                    if (FAKE) {
+                        a0 = a1 = a2 = pack_bf16(ok ? v[0] : 0.f, ok ? v[1] : 0.f);
+                        b0 = b1 = b2 = pack_bf16(ok ? v[2] : 0.f, ok ? v[3] : 0.f);
+                    } else {
+                        split2(ok ? v[0] : 0.f, ok ? v[1] : 0.f, a0, a1, a2);
+                        split2(ok ? v[2] : 0.f, ok ? v[3] : 0.f, b0, b1, b2);
+                    }
+                    *reinterpret_cast<u32x2*>(p) = u32x2{a0, b0};
+                    *reinterpret_cast<u32x2*>(p + 2 * GS) = u32x2{a1, b1};
+                    *reinterpret_cast<u32x2*>(p + 4 * GS) = u32x2{a2, b2};
+                }
             }
         } else {
             const int q = (tid >> 5) * 4 + (tid & 3), kb = (tid >> 2) & 7;
@@ -153,23 +178,37 @@ struct XLoader {
             V v0 = regs[S][0], v1 = regs[S][1];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                uint32_t a0, a1, a2;
-                split2(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f, a0, a1, a2);
                 char* p = p0 + phys_row(q * VEC + e) * 16;
-                *reinterpret_cast<uint32_t*>(p) = a0;
-                *reinterpret_cast<uint32_t*>(p + 2 * GS) = a1;
-                *reinterpret_cast<uint32_t*>(p + 4 * GS) = a2;
+                if constexpr (PREC == 1) {
+                    *reinterpret_cast<uint32_t*>(p) = pack_f16(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f);
+                } else {
+                    uint32_t a0, a1, a2;
+                    if (FAKE) a0 = a1 = a2 = pack_bf16(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f);
+                    else split2(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f, a0, a1, a2);
+                    *reinterpret_cast<uint32_t*>(p) = a0;
+                    *reinterpret_cast<uint32_t*>(p + 2 * GS) = a1;
+                    *reinterpret_cast<uint32_t*>(p + 4 * GS) = a2;
+                }
             }
         }
     }
 };
 
-template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE>
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 3>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc d, int tiles_m, int tiles_n) {
     static_assert(WGM * WGN == 4, "4 waves");
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-    using LA = XLoader<BM, AMODE>;
-    using LB = XLoader<BN, BMODE>;
+    constexpr int NPL = PREC == 1 ? 1 : 3;
+#ifdef UD_X3_FAKE_A
+    using LA = XLoader<BM, AMODE, PREC == 3 ? 0 : PREC>;
+#else
+    using LA = XLoader<BM, AMODE, PREC>;
+#endif
+#ifdef UD_X3_FAKE_B
+    using LB = XLoader<BN, BMODE, PREC == 3 ? 0 : PREC>;
+#else
+    using LB = XLoader<BN, BMODE, PREC>;
+#endif
     __shared__ __attribute__((aligned(16))) char As[2][LA::STAGE];
     __shared__ __attribute__((aligned(16))) char Bs[2][LB::STAGE];
 
@@ -216,7 +255,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
         const int pr = phys_row(l31);
         const int a_off = half * LA::GS + (wm * TM * 32 + pr) * 16;
         const int b_off = half * LB::GS + (wn * TN * 32 + pr) * 16;
-        constexpr int NM = TM * TN * 6;                    // MFMAs per K-tile and wave
+        constexpr int NM = TM * TN * (PREC == 1 ? 1 : 6);  // MFMAs per K-tile and wave
         constexpr int NW = LA::NWRITE + LB::NWRITE;        // LDS writes per K-tile and thread
 
         // one K-tile: operands of tile kt from LDS stage kt&1 -> NM MFMAs; meanwhile (STAGE_NEXT) the register
@@ -226,9 +265,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
             constexpr bool STAGE_NEXT = decltype(stage_next_c)::value;
             const char* Ab = As[kt & 1] + a_off;
             const char* Bb = Bs[kt & 1] + b_off;
-            bf16x8 fa[TM][3], fb[TN][3];
+            bf16x8 fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NPL; ++p) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     fa[i][p] = *reinterpret_cast<const bf16x8*>(Ab + 2 * p * LA::GS + i * 512);
@@ -246,12 +285,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                    if constexpr (PREC == 1) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][0]),
+                                                                   __builtin_bit_cast(f16x8, fb[j][0]), c, 0, 0, 0);
+                    } else {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                    }
                     acc[i][j] = c;
                 }
             if constexpr (STAGE_NEXT) {
@@ -298,11 +342,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE>
+template <int BM, int BN, int AMODE, int BMODE, int PREC>
 int launch_tile(const ud_gemm_desc& d, hipStream_t s) {
     int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, (unsigned)d.batch);
-    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, 2, 2, AMODE, BMODE>), grid, dim3(NTHREADS), 0, s, d, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, 2, 2, AMODE, BMODE, PREC>), grid, dim3(NTHREADS), 0, s, d, tiles_m,
+                       tiles_n);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -312,7 +357,7 @@ struct XCfg { int bm, bn; double penalty; };
 // with UD_GEMM_X3_CFG=0/1/2: 4096^3 179 vs 150 TFLOP/s), so they only win where they fill the chip better.
 constexpr XCfg kX[3] = {{128, 128, 1.00}, {128, 64, 1.20}, {64, 128, 1.20}};
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, int PREC>
 int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
     static const int forced = [] {
         const char* e = getenv("UD_GEMM_X3_CFG");
@@ -330,9 +375,9 @@ int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
     }
     if (forced >= 0) best = forced;
     switch (best) {
-        case 1: return launch_tile<128, 64, AMODE, BMODE>(d, s);
-        case 2: return launch_tile<64, 128, AMODE, BMODE>(d, s);
-        default: return launch_tile<128, 128, AMODE, BMODE>(d, s);
+        case 1: return launch_tile<128, 64, AMODE, BMODE, PREC>(d, s);
+        case 2: return launch_tile<64, 128, AMODE, BMODE, PREC>(d, s);
+        default: return launch_tile<128, 128, AMODE, BMODE, PREC>(d, s);
     }
 }
 
@@ -349,9 +394,16 @@ bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
     return true;
 }
 
-int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s) {
-    if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0>(d, s);
-    if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1>(d, s);
-    if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1>(d, s);
+// f16: one fp16 piece per operand (mixed precision) instead of the exact three-way bf16 split
+int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s, bool f16) {
+    if (f16) {
+        if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0, 1>(d, s);
+        if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1, 1>(d, s);
+        if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1, 1>(d, s);
+        return UD_EINVAL;
+    }
+    if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0, 3>(d, s);
+    if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1, 3>(d, s);
+    if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1, 3>(d, s);
     return UD_EINVAL;
 }

@@ -224,6 +224,8 @@ _X3_TILE_MODEL = os.environ.get("UD_X3_TILE_MODEL", "0") == "1"      # A/B: the 
 
 _FWD_SPLIT_T = int(os.environ.get("UD_FWD_SPLIT_T", "224"))      # A/B on the bench: 128/1024 -> 224/512 = -0.6 % step time
 _FWD_SPLIT_K = int(os.environ.get("UD_FWD_SPLIT_K", "512"))
+_FWD_SPLIT_MINK = int(os.environ.get("UD_FWD_SPLIT_MINK", "256"))     # reduction length per split, at least
+_FWD_SPLIT_WGS = int(os.environ.get("UD_FWD_SPLIT_WGS", "320"))       # workgroups the split aims at
 
 
 def _fwd_split(M, N, K):
@@ -232,7 +234,7 @@ def _fwd_split(M, N, K):
     t = _tiles(M, N, K)
     if t >= _FWD_SPLIT_T or K < _FWD_SPLIT_K:
         return 1
-    return max(1, min(K // 256, -(-320 // t)))
+    return max(1, min(K // _FWD_SPLIT_MINK, -(-_FWD_SPLIT_WGS // t)))
 
 
 _X3_CFGS = ((128, 128, 1.00), (128, 64, 1.20), (64, 128, 1.20))          # gemm_x3.hip kX
