@@ -27,10 +27,21 @@ def relu_site(x: Tensor, name: str, pins: Optional[dict], tie_tol: float = 1e-4)
     assert m.shape == x.shape, (name, m.shape, x.shape)
     pins.setdefault("_used", set()).add(name)
     dis = m != (x > 0)
+    # bookkeeping for the tests: how many units the pinned pattern moves across 0, out of how many
+    st = _dep(pins)
+    st["relu_flips"] += int(dis.sum())
+    st["relu_units"] += dis.numel()
     if bool(dis.any()):
         worst = (x.detach().abs()[dis].max() / x.detach().abs().max()).item()
         assert worst <= tie_tol, f"pinned ReLU pattern at {name} flips a unit that is not a near-tie ({worst:.3e})"
     return x * m.to(x.dtype)
+
+
+def _dep(pins):
+    """The departure counters of a pins dict (created on first use); None without pins."""
+    if not pins:
+        return None
+    return pins.setdefault("_departures", {"relu_flips": 0, "relu_units": 0, "pool_moves": 0, "pool_windows": 0})
 
 
 def sfconv2d(x: Tensor, sd: Dict[str, Tensor], prefix: str, stride: int, norm) -> Tensor:
@@ -79,7 +90,7 @@ def extractor(x: Tensor, sd, training: bool, norm, pins=None):
     return p3, torch.cat([F.adaptive_avg_pool2d(p1, size), F.adaptive_avg_pool2d(p2, size), p3], dim=1)
 
 
-def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 1e-4) -> Tensor:
+def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 1e-4, stats: Optional[dict] = None) -> Tensor:
     """F.max_pool2d(z, 3, 2, 1) with the winner of every window pinned to `sel` ([N,C,Ho,Wo], value kh*3+kw).
     A 3x3 max over ~2.6e5 windows always holds a few top-2 gaps near 1e-6, which two correct fp32
     evaluations resolve differently; pinning the selection (after checking that every pinned winner IS a maximum
@@ -89,6 +100,9 @@ def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 1e-4) -> Tensor
     valid = F.unfold(torch.ones(1, 1, h, w, dtype=z.dtype), 3, padding=1, stride=2).view(1, 1, 9, -1) > 0
     u = torch.where(valid, u, torch.full_like(u, -1e30))
     y = u.gather(2, sel.reshape(n, c, 1, -1).long()).squeeze(2)
+    if stats is not None:           # windows whose pinned winner is not this evaluation's own arg-max (near-ties only)
+        stats["pool_moves"] += int((u.argmax(2) != sel.reshape(n, c, -1).long()).sum())
+        stats["pool_windows"] += sel.numel()
     # relative to the activations' scale: after ~50 layers the fp32 path's values carry ~1e-5 relative error (observed
     # 1e-5 .. 2e-5 of max|z| on the UDR50 embedder pool, depending on the summation order of the kernels before it);
     # same near-tie tolerance as relu_site
@@ -106,7 +120,7 @@ def emb_block1(x: Tensor, sd, training: bool, pool_sel: Optional[Tensor] = None,
     o = batch_norm(o, sd, "emb_block1.norm2", training, 1e-5)
     idt = F.conv2d(x, sd["emb_block1.downsample.0.weight"])
     idt = batch_norm(idt, sd, "emb_block1.downsample.1", training, 1e-5)
-    idt = F.max_pool2d(idt, 3, 2, 1) if pool_sel is None else max_pool_3s2_pinned(idt, pool_sel)
+    idt = F.max_pool2d(idt, 3, 2, 1) if pool_sel is None else max_pool_3s2_pinned(idt, pool_sel, stats=_dep(pins))
     return relu_site(o + idt, "emb_block1.add", pins)
 
 

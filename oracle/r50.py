@@ -12,14 +12,14 @@ import torch
 import torch.nn.functional as F
 
 from .eb4 import batch_norm, rfft2_cat, irfft2_split, interpolate, dynamic_filter_generic
-from .r18 import relu_site, max_pool_3s2_pinned, _conv, _dec
+from .r18 import relu_site, max_pool_3s2_pinned, _conv, _dec, _dep
 
 Tensor = torch.Tensor
 LAYERS = ((1, 64, 3, 1), (2, 128, 4, 2), (3, 256, 6, 2))          # (stage, planes, blocks, stride of block 0)
 
 
-def _pool(z: Tensor, sel: Optional[Tensor]) -> Tensor:
-    return F.max_pool2d(z, 3, 2, 1) if sel is None else max_pool_3s2_pinned(z, sel)
+def _pool(z: Tensor, sel: Optional[Tensor], pins=None) -> Tensor:
+    return F.max_pool2d(z, 3, 2, 1) if sel is None else max_pool_3s2_pinned(z, sel, stats=_dep(pins))
 
 
 def bottleneck(x: Tensor, sd, prefix: str, stride: int, training: bool, norm, pins=None) -> Tensor:
@@ -41,7 +41,7 @@ def extractor(x: Tensor, sd, training: bool, norm, pins=None, pool_sel=None) -> 
     """ExtractorRes50.forward (model/resnet/module_exp.py:48-59)."""
     h = F.conv2d(x, sd["extractor.conv1.weight"], None, 2, 3)
     h = relu_site(batch_norm(h, sd, "extractor.bn1", training, 1e-5), "extractor.bn1", pins)
-    h = _pool(h, pool_sel)
+    h = _pool(h, pool_sel, pins)
     for li, planes, nblk, stride in LAYERS:
         for bi in range(nblk):
             h = bottleneck(h, sd, f"extractor.layer{li}.{bi}", stride if bi == 0 else 1, training,
@@ -59,7 +59,7 @@ def emb_block1(x: Tensor, sd, training: bool, pool_sel=None, pins=None) -> Tenso
     o = batch_norm(o, sd, "emb_block1.norm3", training, 1e-5)
     idt = F.conv2d(x, sd["emb_block1.downsample.0.weight"])
     idt = batch_norm(idt, sd, "emb_block1.downsample.1", training, 1e-5)
-    idt = _pool(idt, pool_sel)
+    idt = _pool(idt, pool_sel, pins)
     return relu_site(o + idt, "emb_block1.add", pins)
 
 

@@ -131,3 +131,92 @@ def test_graph_captured_step_equals_eager_step():
     med, p90, worst = devs[len(devs) // 2], devs[int(0.9 * len(devs))], devs[-1]
     print(f"  4 steps, relative parameter deviation eager vs graphed: median {med:.2e}  90% {p90:.2e}  worst {worst:.2e}")
     assert med <= 1e-4 and p90 <= 5e-3 and worst <= 0.5      # observed: 3e-6 / 8e-4 / 5e-2
+
+
+def _engine_for(m, dev, num_steps):
+    from unidefense_amd.engine import AbstractEngine
+    from unidefense_amd.engine.optim import build_optimizer
+    from unidefense_amd.loss import LOSSES
+    eng = AbstractEngine({"config": dict(ou.LAMBDAS)})
+    eng.model, eng.device = m, dev
+    eng.num_steps, eng.warmup_step = num_steps, 0
+    eng.optimizer = build_optimizer(m, dict(name="adamw", lr=1e-4, betas=[0.9, 0.999], weight_decay=5e-6, amsgrad=True))
+    eng.scheduler = torch.optim.lr_scheduler.StepLR(eng.optimizer, step_size=22500, gamma=0.5)
+    eng.loss_criterion = {"softmax": LOSSES["cross_entropy"], "triplet": LOSSES["aw_triplet"],
+                          "kl_div": LOSSES["kl_div"], "fac": LOSSES["factorization"]}
+    return eng
+
+
+def _check_step(g, tag, ret, m, before, loss_tol=1e-3):
+    bad = []
+    for k, v in ret.items():
+        key = ("out_" if k == "cls_out" else "loss_") + k
+        ref = np.asarray(g[f"{tag}_{key}"], dtype=np.float64)
+        got = v.detach().double().cpu().numpy()
+        err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+        print(f"  {k}: rel err {err:.3e}")
+        if not err <= loss_tol:
+            bad.append((k, err))
+    assert not bad, bad
+    from tests.test_step_cpu import check_updates
+    check_updates(g, tag, {k: (p.detach() - before[k]).cpu() for k, p in m.named_parameters()})
+
+
+@pytest.mark.parametrize("tag", ["freq", "efdm"])
+def test_two_pass_step_style_perturbation_vs_reference_golden(golden_dir, tag):
+    """The reference ENGINE's step with pass 2 perturbed by the style branch (permuted batch -> CORAL -> frequency
+    amplitude transfer / exact feature-distribution matching; model/unidefense.py:177-191, model/modules.py:35-76): the
+    ten returned scalars + pass-1 logits within 1e-3, parameter updates as in test_two_pass_step_vs_reference_golden.
+    oracle/pins.py replaces the global-RNG draws on both sides by the same seeded stand-ins."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pins
+    from unidefense_amd.model import load_model
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "udeb4_step_pert_n4.npz"))
+    n, size, in_seed, mask_seed, num_steps = [int(v) for v in g["meta"]]
+    m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev).train()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    x = param_fill.make_input(n, size, in_seed).to(dev)
+    tgt = param_fill.make_labels(n).to(dev)
+    m.rng_queue = [ou.make_rng(n, mask_seed, 0.5), ou.make_rng(n, mask_seed + 1, 0.5)]
+    eng = _engine_for(m, dev, num_steps)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2 ** 10, enabled=False)
+    eng.optimizer.zero_grad()
+    with pins.pinned_draws(tag) as calls:
+        ret = eng.train_unidefense_model(x, tgt, 1, scaler, n // 2, n // 2)
+    assert calls == {"perm": 2, "lmda": 1}, calls          # both permutation lists and the transfer's lmda were drawn
+    _check_step(g, tag, ret, m, before)
+
+
+@pytest.mark.parametrize("tag,cur_step", [("early", 1), ("kl", 50)])
+def test_udr18_two_pass_step_vs_reference_golden(golden_dir, tag, cur_step):
+    """BASELINE configs[0] (ResNet18, 128x128, bs 8): the reference engine's two-pass step, pass 2 perturbed by `downscale`."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import pins
+    from tests.test_r18 import make_rng_r18
+    from unidefense_amd.model import load_model, perturb
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "udr18_step_n8.npz"))
+    n, size, in_seed, mask_seed, num_steps = [int(v) for v in g["meta"]]
+    m = load_model("UDR18")(extractor="resnet18", num_classes=2, drop_rate=0.5)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev).train()
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    x = param_fill.make_input(n, size, in_seed).to(dev)
+    tgt = param_fill.make_labels(n).to(dev)
+    m.rng_queue = [make_rng_r18(n, mask_seed), make_rng_r18(n, mask_seed + 1)]
+    eng = _engine_for(m, dev, num_steps)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2 ** 10, enabled=False)
+    eng.optimizer.zero_grad()
+    orig = perturb.PERT_FUNCS
+    perturb.PERT_FUNCS = [perturb.downscale] * 3           # as the generator did with the reference's list
+    try:
+        with pins.pinned_draws("downscale"):
+            ret = eng.train_unidefense_model(x, tgt, cur_step, scaler, n // 2, n // 2)
+    finally:
+        perturb.PERT_FUNCS = orig
+    _check_step(g, tag, ret, m, before)

@@ -31,6 +31,8 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-3
 GRAD_RTOL, GRAD_ATOL = 1e-3, 2e-5
 FULL_RTOL = 2e-2
+# BN2 biases whose gradient is analytically zero (the block's output reaches nothing but BatchNorm-ed paths)
+STRUCT_ZERO_GRADS = {f"backbone._blocks.{i}._bn2.bias" for i in list(range(16)) + [30, 31]}
 
 
 def _dev():
@@ -117,14 +119,16 @@ def test_eval_intermediates_vs_oracle():
 @pytest.mark.parametrize("variant", ["smooth", "full"])
 def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant):
     """Outputs, losses and all 504 parameter gradients (norm + first 8 elements) of the train-mode step vs the
-    vectors recorded from the reference (fp32 CPU).  The reference's numbers carry their own fp32 error, so
-    the gradient bound here is 3e-3 of the tensor's norm (smooth) / 2e-2 (full); the conditioning-aware bound
-    against the float64 oracle is enforced in test_train_grads_vs_oracle_elementwise."""
+    vectors recorded from the reference (fp32 CPU): EVERY tensor within 1e-3 of its norm (+ the 2e-5 floor), both loss
+    variants (observed: 3.5e-4 smooth / 7.4e-4 full at worst).  The floor matters for exactly one family: BN2's bias in
+    the stages whose output only ever feeds another BatchNorm (blocks 0-15, 30, 31) has a gradient that is
+    analytically ZERO (1e-15 in the float64 oracle: a per-channel shift is removed by the next normalisation); the
+    reference's fp32 run and this one both hold ~5e-6 of rounding noise there."""
     dev = _dev()
     g = np.load(os.path.join(golden_dir, "udeb4_train_n4.npz"))
     n, size, seed, mseed = [int(v) for v in g["meta"]]
     lam = ou.LAMBDAS if variant == "full" else ou.SMOOTH_LAMBDAS
-    rtol = FULL_RTOL if variant == "full" else 3e-3
+    rtol = GRAD_RTOL
     m = _model(dev, 0.0, 0.3).train()
     x = param_fill.make_input(n, size, seed).to(dev)
     tgt = param_fill.make_labels(n).to(dev)
@@ -154,7 +158,10 @@ def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant):
         print("  rel %.3e  %-58s norm err %.3e head err %.3e ref norm %.3e" % r)
     bad = [r for r in rows if not r[0] <= rtol]
     assert not bad, bad[:10]
-    assert within_1e3 >= 0.9 * len(rows)
+    assert len(rows) == 504 and within_1e3 == len(rows)
+    # the structural zeros: noise of a few 1e-6 on both sides, nothing more
+    zero = [r for r in rows if r[1] in STRUCT_ZERO_GRADS]
+    assert len(zero) == len(STRUCT_ZERO_GRADS) and all(r[4] <= 2e-5 and max(r[2], r[3]) <= 2e-5 for r in zero), zero[:5]
 
 
 @pytest.mark.parametrize("variant,n,seeds", [("smooth", 2, (38, 138)), ("smooth", 4, (38, 138)), ("full", 2, (38, 138))])
@@ -194,3 +201,7 @@ def test_train_grads_vs_oracle_elementwise(variant, n, seeds):
         print("  %.3f  %-58s maxerr %.3e  maxref %.3e  cpu-fp32-err %.3e" % r)
     bad = [r for r in rows if not r[0] < 1.0]
     assert not bad, bad[:10]
+    # observed: 504/504 within the plain bound at N = 4, at most two scalar sf_coef gradients (global sums over a batch
+    # of TWO with heavy cancellation: the reference's own fp32 run misses them by as much) outside it at N = 2
+    loose = [r[1] for r in rows if not r[2] <= GRAD_RTOL * r[3] + GRAD_ATOL]
+    assert len(loose) <= (2 if n == 2 else 0) and all(k.endswith("sf_coef") for k in loose), loose

@@ -148,8 +148,14 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
     pinned = dict(rng, pool_sel=sel, relu_masks=masks)
     sd64 = r50_state(torch.float64, requires_grad=True)
     o64 = r50.forward_r50(sd64, x.double(), training=True, drop_rate=0.5, rng=pinned)
-    assert masks["_used"] == set(masks) - {"_used"}, sorted(set(masks) - {"_used"} - masks["_used"])
-    print(f"  pinned {len(masks) - 1} ReLU sites + the max-pool winners to the HIP path's pattern")
+    sites = set(masks) - {"_used", "_departures"}
+    assert masks["_used"] == sites, sorted(sites - masks["_used"])
+    dep = masks["_departures"]
+    print(f"  pinned {len(sites)} ReLU sites + the max-pool winners to the HIP path's pattern: "
+          f"{dep['relu_flips']} of {dep['relu_units']} ReLU units and {dep['pool_moves']} of {dep['pool_windows']} "
+          f"pool windows depart from the float64 evaluation's own choice (each checked to be a near-tie)")
+    # the pinning may only ever touch a vanishing share of the decisions: a wrong-sign kernel would flip a large part
+    assert dep["relu_flips"] <= 2e-5 * dep["relu_units"] + 20 and dep["pool_moves"] <= 2e-4 * dep["pool_windows"] + 20, dep
     _loss(o64, tgt, lam).backward()
     sd32 = r50_state(requires_grad=True)
     _loss(r50.forward_r50(sd32, x, training=True, drop_rate=0.5, rng=pinned), tgt, lam).backward()
