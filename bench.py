@@ -128,7 +128,8 @@ def _pmc_traffic(args, bs):
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            return float(d["gemm_family"]["hbm_bytes_per_launch"]), os.path.relpath(f, root)
+            fam = d.get("families", {}).get("gemm_x3_kernel") or d["gemm_family"]       # the roofline's kernel
+            return float(fam["hbm_bytes_per_launch"]), os.path.relpath(f, root)
         except (OSError, KeyError, ValueError):
             continue
     return None, None

@@ -159,9 +159,12 @@ def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant):
     bad = [r for r in rows if not r[0] <= rtol]
     assert not bad, bad[:10]
     assert len(rows) == 504 and within_1e3 == len(rows)
-    # the structural zeros: noise of a few 1e-6 on both sides, nothing more
-    zero = [r for r in rows if r[1] in STRUCT_ZERO_GRADS]
-    assert len(zero) == len(STRUCT_ZERO_GRADS) and all(r[4] <= 2e-5 and max(r[2], r[3]) <= 2e-5 for r in zero), zero[:5]
+    # Who needs the absolute floor at all?  Only gradients that are zero up to rounding on BOTH sides: BatchNorm biases
+    # of the STRUCT_ZERO_GRADS family, reference norm < 1e-4 (against 1e-2 .. 1e+1 for every other tensor).
+    floor_users = [r for r in rows if max(r[2], r[3]) > 1e-3 * r[4]]
+    print("  tensors outside a purely relative 1e-3:", [(r[1], "%.1e" % r[4]) for r in floor_users])
+    odd = [(r[1], r[4]) for r in floor_users if not (r[1] in STRUCT_ZERO_GRADS and r[4] < 1e-4)]
+    assert not odd, odd
 
 
 @pytest.mark.parametrize("variant,n,seeds", [("smooth", 2, (38, 138)), ("smooth", 4, (38, 138)), ("full", 2, (38, 138))])

@@ -7,8 +7,9 @@
 // accuracy (tests/test_kernels_gpu.py compares both kernels with float64) while six bf16 MFMAs (6 x 32 cycles per
 // 32x32x16) replace eight fp32 MFMAs (8 x 64 cycles): 2.67x the fp32 matrix rate.
 //
-// Used by ud_gemm for the large plain GEMMs (a_mode, b_mode in {0,1}); the gather modes and the small / skinny
-// shapes stay on gemm.hip's v_mfma_f32_32x32x2_f32 kernel.
+// Used by ud_gemm for the plain GEMMs (a_mode, b_mode in {0,1}) and for the implicit-GEMM conv gather on the A side
+// (a_mode 2: forward / data gradient of the 3x3 and transposed convs); the weight-gradient gather (b_mode 2) and the
+// tiny / skinny shapes stay on gemm.hip's v_mfma_f32_32x32x2_f32 kernel.
 //
 // Structure: 256 threads = 4 wave64, block tile BM x BN x 16, wave tile (TM x TN) x 32x32.  Operand tiles go
 // global -> registers (3 K-tiles in flight) -> split -> LDS as three bf16 planes per operand, each plane
@@ -93,21 +94,50 @@ struct XLoader {
     static constexpr int STAGE = 2 * NPL * GS;         // planes x 2 k-groups
     static constexpr int NV0 = ROWS / 64;              // MODE 0: float4 (4 k of one row) per thread
     static constexpr int VEC = ROWS / 32;              // MODE 1: rows per thread (x 2 consecutive k)
-    static constexpr int NV = MODE == 0 ? NV0 : 2;
-    static constexpr int NWRITE = MODE == 0 ? NPL * NV0 : NPL * VEC;    // ds_write instructions per stage
-    using V = typename std::conditional<(MODE == 0 || VEC == 4), f32x4, f32x2>::type;
+    static constexpr bool KC = MODE == 0 || MODE == 2;                  // K-contiguous source (MODE 2: inside a tap)
+    static constexpr int NV = KC ? NV0 : 2;
+    static constexpr int NWRITE = KC ? NPL * NV0 : NPL * VEC;           // ds_write instructions per stage
+    using V = typename std::conditional<(KC || VEC == 4), f32x4, f32x2>::type;
 
     const float* base;
     long ld;
     int k_last;           // last valid k of this workgroup's K range
     long off[NV0 > 2 ? NV0 : 2];   // MODE 0: element offset of (clamped row, kq*4); MODE 1: [0] = clamped row offset
     bool rowok[NV0 > 2 ? NV0 : 2];
-    int kloc;             // this thread's k offset inside a tile: MODE 0: 4*kq; MODE 1: 2*kb
+    int kloc;             // this thread's k offset inside a tile: MODE 0 / 2: 4*kq; MODE 1: 2*kb
     V regs[PD][NV];
+    // MODE 2 (implicit-GEMM conv gather, rows = output pixels, k = (tap, ci); Cin % 4 == 0 so a float4 never straddles
+    // taps): the (tap, ci) of the thread's NEXT load, advanced incrementally (no division in the loop), the rows'
+    // pixel origins, and one validity bit per (ring slot, row) for the store
+    ud_conv_geom g;
+    int g_k, g_ci, g_kh, g_kw;
+    int g_nbase[NV0 > 2 ? NV0 : 2], g_ih0[NV0 > 2 ? NV0 : 2], g_iw0[NV0 > 2 ? NV0 : 2];
+    unsigned vmask[PD];
 
-    __device__ __forceinline__ void init(const float* p, long ld_, int dim, int row0, int k_end, int tid) {
+    __device__ __forceinline__ void init(const float* p, long ld_, int dim, int row0, int k_end, int tid,
+                                         const ud_conv_geom& geom, int k_begin) {
         base = p; ld = ld_; k_last = k_end - 1;
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 2) {
+            g = geom;
+            kloc = (tid & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < NV0; ++i) {
+                const int f = tid + i * NTHREADS;
+                const int m = row0 + (f >> 2);
+                rowok[i] = m < dim;
+                const int mm = rowok[i] ? m : 0;
+                const int ow = mm % g.Wout, t = mm / g.Wout;
+                const int oh = t % g.Hout, n = t / g.Hout;
+                g_nbase[i] = n * g.Hin * g.Win;
+                g_ih0[i] = g.transposed ? oh + g.pad_t : oh * g.stride - g.pad_t;
+                g_iw0[i] = g.transposed ? ow + g.pad_l : ow * g.stride - g.pad_l;
+            }
+            g_k = k_begin + kloc;
+            const int tap = g_k / g.Cin;
+            g_ci = g_k - tap * g.Cin;
+            g_kh = tap / g.KW;
+            g_kw = tap - g_kh * g.KW;
+        } else if constexpr (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < NV0; ++i) {
                 int f = tid + i * NTHREADS;
@@ -128,7 +158,40 @@ struct XLoader {
     // tile whose first k is k0 (k0 < k_end; k0 % 16 == 0)
     template <int S>
     __device__ __forceinline__ void load(int k0) {
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 2) {
+            // advance (tap, ci) to this tile's k (tiles are requested in non-decreasing order; the surplus prefetches
+            // past the end repeat the last one)
+            int delta = k0 + kloc - g_k;
+            g_k += delta;
+            g_ci += delta;
+            while (g_ci >= g.Cin) {
+                g_ci -= g.Cin;
+                if (++g_kw == g.KW) { g_kw = 0; ++g_kh; }
+            }
+            const bool kok = g_k <= k_last;
+            unsigned mask = 0;
+#pragma unroll
+            for (int i = 0; i < NV0; ++i) {
+                int ih, iw;
+                bool ok;
+                if (!g.transposed) {
+                    ih = g_ih0[i] + g_kh;
+                    iw = g_iw0[i] + g_kw;
+                    ok = (ih >= 0) && (ih < g.Hin) && (iw >= 0) && (iw < g.Win);
+                } else {
+                    const int th = g_ih0[i] - g_kh, tw = g_iw0[i] - g_kw;
+                    ok = (th >= 0) && (tw >= 0) && (th % g.stride == 0) && (tw % g.stride == 0);
+                    ih = th / g.stride;
+                    iw = tw / g.stride;
+                    ok = ok && (ih < g.Hin) && (iw < g.Win);
+                }
+                ok = ok && kok && rowok[i];
+                const long o = ok ? ((long)g_nbase[i] + (long)ih * g.Win + iw) * (long)g.Cin + g_ci : 0;   // branch-free
+                regs[S][i] = *reinterpret_cast<const V*>(base + o);
+                mask |= (ok ? 1u : 0u) << i;
+            }
+            vmask[S] = mask;
+        } else if constexpr (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < NV0; ++i) {
                 // K % 4 == 0: the float4 at k0 + kq4 is entirely inside or entirely outside [.., k_end); an outside
@@ -146,12 +209,12 @@ struct XLoader {
 
     template <int S>
     __device__ __forceinline__ void store(char* L, int tid, int k0) const {
-        if constexpr (MODE == 0) {
+        if constexpr (KC) {
 #pragma unroll
             for (int i = 0; i < NV0; ++i) {
                 int f = tid + i * NTHREADS;
                 int row = f >> 2, kq = f & 3;
-                const bool ok = rowok[i] && (k0 + kq * 4 <= k_last);
+                const bool ok = MODE == 2 ? ((vmask[S] >> i) & 1u) != 0 : rowok[i] && (k0 + kq * 4 <= k_last);
                 V v = regs[S][i];
                 char* p = L + (kq >> 1) * GS + phys_row(row) * 16 + (kq & 1) * 8;
                 if constexpr (PREC == 1) {
@@ -238,8 +301,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
 
     if (nkt > 0) {
         LA la; LB lb;
-        la.init(d.A + (long)bz * d.strideA, d.lda, d.M, m0, k_end, tid);
-        lb.init(d.B + (long)bz * d.strideB, d.ldb, d.N, n0, k_end, tid);
+        la.init(d.A + (long)bz * d.strideA, d.lda, d.M, m0, k_end, tid, d.g, k_begin);
+        lb.init(d.B + (long)bz * d.strideB, d.ldb, d.N, n0, k_end, tid, d.g, k_begin);
         const int kt_max = nkt - 1;
         auto k0_of = [&](int kt) { return k_begin + min(kt, kt_max) * BK; };   // clamped: surplus prefetches re-read the last tile
 
@@ -384,6 +447,11 @@ int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
 }  // namespace
 
 bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
+    if (d.a_mode == 2 && d.b_mode == 0) {
+        // implicit-GEMM conv (forward and data gradient of the 3x3 / transposed convs): Cin % 4 == 0 (a_vec), batch 1
+        static const bool on = !getenv("UD_X3_GATHER") || atoi(getenv("UD_X3_GATHER")) != 0;
+        return on && a_vec && b_vec && d.K % 4 == 0 && d.batch == 1;
+    }
     if (d.a_mode > 1 || d.b_mode > 1) return false;
     if (!(d.a_mode == 0 && d.b_mode == 0) && !(d.a_mode == 0 && d.b_mode == 1) && !(d.a_mode == 1 && d.b_mode == 1))
         return false;
@@ -396,6 +464,7 @@ bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
 
 // f16: one fp16 piece per operand (mixed precision) instead of the exact three-way bf16 split
 int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s, bool f16) {
+    if (d.a_mode == 2 && d.b_mode == 0) return f16 ? launch_modes<2, 0, 1>(d, s) : launch_modes<2, 0, 3>(d, s);
     if (f16) {
         if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0, 1>(d, s);
         if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1, 1>(d, s);

@@ -4,14 +4,19 @@
 The path shards over the batch only.  Exchanges per backward:
   * parameter gradients — bucketed flat all-reduce.  The whole network is a single autograd node, so the exchange
     is driven from inside that node's backward (model/unidefense.py:_NetFunction): the tape hands every parameter
-    gradient to the GradReducer the moment it is final (reverse parameter order); a full ~64 MB bucket is packed
-    and its all-reduce launched ASYNCHRONOUSLY (it runs on the process group's own stream), so the exchange of
+    gradient to the GradReducer the moment it is final (reverse parameter order); large gradients (>= 2 MB: the
+    spectral 1x1 weights, 85 % of the bytes) are all-reduced in place, the small ones are packed into ~64 MB buckets;
+    every all-reduce is launched ASYNCHRONOUSLY (it runs on the process group's own stream), so the exchange of
     the deep layers' gradients overlaps the backward of the shallow ones; the backward waits for all buckets at its
     end and returns views of the reduced flat buffers (no copy back).  The mean over ranks comes for free: the
     incoming loss gradient is scaled by 1/world before the tape runs (everything downstream is linear in it,
     including the SyncBN sums).
-  * SyncBatchNorm statistics — one all_gather of (mean, var) per BN forward and one all_reduce of
-    (sum dz, sum dz*xhat) per BN backward (tape.batchnorm_act), enabled by ``sync_bn=True``.
+  * SyncBatchNorm statistics, enabled by ``sync_bn=True``.  Fused MBConv path (tape.mbconv_fused): the fp64
+    accumulators (sum x, sum x^2) of a BatchNorm are all-reduced IN PLACE between the kernel that fills them and the
+    kernels that consume them (tape.DataParallelCtx.reduce), likewise (sum dz, sum dz*xhat) in the backward — one
+    all_reduce of 2C doubles each way, ranks need not hold equal row counts.  Operator path (tape.batchnorm_act:
+    attention / head / ResNet models): one all_gather of (mean, var) per BN forward and one all_reduce of the two sums
+    per BN backward.
 No other collective exists on the data path.
 """
 import torch
@@ -27,18 +32,27 @@ class GradReducer:
     begin() -> ready(key, g) in the order gradients become final -> finish() -> {key: reduced g (a view of its
     bucket's flat buffer)}.  Device-agnostic (RCCL on GPUs, gloo in the CPU tests)."""
 
-    def __init__(self, group, bucket_bytes):
+    def __init__(self, group, bucket_bytes, direct_bytes=2 << 20):
         self.group = group
         self.bucket_bytes = bucket_bytes
+        # A gradient of at least this size is reduced IN PLACE as a collective of its own instead of being packed:
+        # the spectral 1x1 weights (1344^2 .. 3264^2: 7 - 43 MB each) are 85 % of the 513 MB of gradients, and
+        # copying them into a bucket would move them through HBM twice more for nothing.
+        self.direct_bytes = direct_bytes
         self.begin()
 
     def begin(self):
         self.bucket, self.size, self.pending, self.done = [], 0, [], set()
 
     def ready(self, key, g):
-        self.bucket.append((key, g))
         self.done.add(key)
-        self.size += g.numel() * g.element_size()
+        nbytes = g.numel() * g.element_size()
+        if nbytes >= self.direct_bytes and g.is_contiguous():
+            work = dist.all_reduce(g, group=self.group, async_op=True)
+            self.pending.append((work, g.view(-1), [(key, g)]))
+            return
+        self.bucket.append((key, g))
+        self.size += nbytes
         if self.size >= self.bucket_bytes:
             self.flush()
 
