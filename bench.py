@@ -53,29 +53,37 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline_measure(bs=8, iters=4):
-    """Oracle forward + pass-1 loss + backward on the host cores, bounded sample (runs in a child process)."""
+def cpu_baseline_measure(bs=8, warm=2, iters=5):
+    """Oracle forward + pass-1 loss + backward on the host cores, bounded sample (runs in a child process).
+    SURVEY.md §8(d) protocol: 2 warm-up + 5 timed iterations, median, all cores of the job; plus a 1-thread figure on a
+    smaller sample (bs 2, 1 + 2 iterations) so that the whole measurement stays at ~25 s of CPU work."""
     from oracle import param_fill
     from tests import oracle_util as ou
+
+    def run(threads, bs_, warm_, iters_):
+        torch.set_num_threads(threads)
+        x = param_fill.make_input(bs_, 256, seed=0)
+        tgt = param_fill.make_labels(bs_)
+        rng = ou.make_rng(bs_, 1, 0.5)
+        sd = ou.oracle_state(-10.0, 0.0, requires_grad=True)
+        ts = []
+        for it in range(warm_ + iters_):
+            for v in sd.values():
+                v.grad = None
+            t0 = time.perf_counter()
+            ou.oracle_train_pass1(sd, x, tgt, rng, 0.5)
+            if it >= warm_:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return bs_ / ts[len(ts) // 2]
     cores = host_cores()
-    torch.set_num_threads(cores)
-    x = param_fill.make_input(bs, 256, seed=0)
-    tgt = param_fill.make_labels(bs)
-    rng = ou.make_rng(bs, 1, 0.5)
-    sd = ou.oracle_state(-10.0, 0.0, requires_grad=True)
-    ou.oracle_train_pass1(sd, x, tgt, rng, 0.5)          # warm-up
-    ts = []
-    for _ in range(iters):
-        for v in sd.values():
-            v.grad = None
-        t0 = time.perf_counter()
-        ou.oracle_train_pass1(sd, x, tgt, rng, 0.5)
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    return {"value": bs / ts[len(ts) // 2], "unit": "images/sec", "cores": cores, "kind": "port",
+    v = run(cores, bs, warm, iters)
+    v1 = run(1, 2, 1, 2)
+    return {"value": v, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle (pure-torch CPU restatement of the reference) fwd + pass-1 loss + bwd, UDEB4 256x256 "
-                      f"bs={bs}, fp32, median of {iters} after 1 warm-up, torch threads={cores} "
-                      f"(= CPU quota of the job; the host shows {os.cpu_count()} logical CPUs)"}
+                      f"bs={bs}, fp32, median of {iters} after {warm} warm-ups, torch threads={cores} "
+                      f"(= CPU quota of the job; the host shows {os.cpu_count()} logical CPUs)",
+            "value_1thread": v1, "sample_1thread": "same step, bs=2, 1 torch thread, median of 2 after 1 warm-up"}
 
 
 def cpu_baseline(timeout_s=300):
@@ -184,7 +192,9 @@ def main():
         _udlib.call("ud_gemm_set_path", 3)
     torch.manual_seed(1234)
     ctor = dict(extractor="efficientnet-b4") if args.model == "UDEB4" else {}
-    model = load_model(args.model)(num_classes=2, drop_rate=0.5, **ctor).to(dev).train()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # the loader announces the model like the reference's does: keep
+        model = load_model(args.model)(num_classes=2, drop_rate=0.5, **ctor).to(dev).train()     # stdout to the ONE JSON line
     model = wrap_data_parallel(model, local_rank) if (world > 1 or force) else model
     bs = args.batch
     g = torch.Generator().manual_seed(100 + rank)

@@ -379,9 +379,11 @@ int ud_dwconv_bwd_weight_ex(const float* x, const float* dy, const float* gate_a
                             int pad_t, int pad_l, ud_stream_t stream);
 /* ud_rfft2 of act(bn(x)) (bn may be NULL), optionally also writing the activated input (act_out) and scaling the
  * result by the gate:  SFConv's spectral branch reading the expand conv's raw output (exp.py:55) and, as the
- * adjoint of irfft2, its backward (gate = sigmoid(sf_coef)) */
+ * adjoint of irfft2, its backward (gate = sigmoid(sf_coef)).  gate_grad (optional): also finishes the gate's gradient,
+ * gate_grad[0] = sigmoid'(alpha) * sum(gate_acc[0..64)), from the slots ud_normbwd_apply_mix filled just before. */
 int ud_rfft2_ex(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
-                float* act_out, const float* gate_alpha, int gate_mode, ud_stream_t stream);
+                float* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
+                ud_stream_t stream);
 /* irfft2 + SF mix + BN1 statistics (exp.py:60-65, stride 1):  freq_out = irfft2(Y) * scale;
  * y = (1 - a) spat + a freq_out, a = sigmoid(alpha[0]);  sum[c] += sum y, sumsq[c] += sum y^2 */
 int ud_irfft2_mix(const float* Y, float* y, int N, int S, int C, float scale, float w_interior, const float* spat,

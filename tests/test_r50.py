@@ -178,6 +178,8 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
     assert e <= 1e-3, e
     total.backward()
     rows = []
+    coef_scale = max(sd64[k].grad.abs().max().item() for k, p in m.named_parameters()
+                     if p.grad is not None and k.endswith("sf_coef"))
     for k, p in m.named_parameters():
         if p.grad is None:
             continue
@@ -188,7 +190,13 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
         # on the pinned piece the problem is smooth: 1e-4 of the tensor's scale (observed: <= 2e-5), never looser
         # than 5x what the CPU fp32 run or a one-ulp input perturbation do to the same gradient
         # (the scalar mixing coefficients are global sums with heavy cancellation: 1e-3 of their magnitude)
-        floor = (1e-3 if k.endswith(("sf_coef", "fuse_coef")) else 1e-4) * s + 2e-6
+        if k.endswith(("sf_coef", "fuse_coef")):
+            # each is ONE sum of ~1e6 products dd * (freq - spat) that cancels to a layer-dependent degree (|ref| from
+            # 0.05 to 3 in this model): the error scales with the terms, not with what is left of their sum — measure it
+            # against the common scale of these gradients, not only against the tensor's own remainder
+            floor = 1e-3 * max(s, 0.2 * coef_scale) + 2e-6
+        else:
+            floor = 1e-4 * s + 2e-6
         rows.append((d / max(floor, 5.0 * d32, 5.0 * sens.get(k, 0.0)), k, d, s, d32, sens.get(k, 0.0)))
     rows.sort(reverse=True)
     for r in rows[:10]:

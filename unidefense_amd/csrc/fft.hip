@@ -181,8 +181,18 @@ template <int S, int CB, bool EX>
 __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, float* __restrict__ Y, int C,
                                                    float scale, float w_int, ud_bn_ref bn, int has_bn,
                                                    float* __restrict__ act_out, const float* __restrict__ gate_alpha,
-                                                   int gate_mode) {
+                                                   int gate_mode, const double* __restrict__ gate_acc,
+                                                   float* __restrict__ gate_grad) {
     using L = Lds<S, CB>;
+    // EX, backward of the SF mix: the 64 slots a preceding kernel (ud_normbwd_apply_mix) filled with
+    // sum dd * (freq - spat) become the gate's gradient here, by one wave, instead of a launch of their own
+    if (EX && gate_grad && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        const double tot = ud_wave_sum_d(gate_acc[threadIdx.x]);
+        if (threadIdx.x == 0) {
+            const double a = 1.0 / (1.0 + exp(-(double)gate_alpha[0]));
+            gate_grad[0] = (float)(tot * a * (1.0 - a));
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Lre = lds;
     float* Lim = lds + L::PLANE;
@@ -371,6 +381,8 @@ struct RfftEx {
     float* act_out;
     const float* gate_alpha;
     int gate_mode;
+    const double* gate_acc;
+    float* gate_grad;
 };
 
 template <int S, int CB, bool EX>
@@ -386,7 +398,8 @@ int launch_rfft2_t(const float* x, float* Y, int N, int C, float scale, float w_
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
     ud_bn_ref none{};
     hipLaunchKernelGGL((rfft2_kernel<S, CB, EX>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
-                       ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, ex.act_out, ex.gate_alpha, ex.gate_mode);
+                       ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, ex.act_out, ex.gate_alpha, ex.gate_mode, ex.gate_acc,
+                       ex.gate_grad);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -394,7 +407,7 @@ int launch_rfft2_t(const float* x, float* Y, int N, int C, float scale, float w_
 template <int S, int CB>
 int launch_rfft2(const float* x, float* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
     if (ex) return launch_rfft2_t<S, CB, true>(x, Y, N, C, scale, w_int, *ex, s);
-    return launch_rfft2_t<S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0}, s);
+    return launch_rfft2_t<S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr}, s);
 }
 
 struct IrfftMix {
@@ -474,12 +487,14 @@ int ud_irfft2(const float* Y, float* x, int N, int S, int C, float scale, float 
 }
 
 int ud_rfft2_ex(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
-                float* act_out, const float* gate_alpha, int gate_mode, ud_stream_t stream) {
+                float* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
+                ud_stream_t stream) {
     if (N < 1 || C < 1 || !x || !Y) return UD_EINVAL;
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
     if (bn && bn->G != 1) return UD_EINVAL;
     if (act_out && !bn) return UD_EINVAL;
-    RfftEx ex{bn, act_out, gate_alpha, gate_mode};
+    if (gate_grad && (!gate_acc || !gate_alpha)) return UD_EINVAL;
+    RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad};
     return rfft2_dispatch(x, Y, N, S, C, scale, w_interior, &ex, (hipStream_t)stream);
 }
 

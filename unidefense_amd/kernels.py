@@ -1202,16 +1202,20 @@ def dwconv_bwd_weight_ex(x, dy, gate_alpha, gate_mode, K, stride, pad_t, pad_l):
     return dwt
 
 
-def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None, gate_mode=0, update=False):
-    """rfft2 of act(bn(x)) (bn optional) [* gate].  Returns (Y, activated input or None)."""
+def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None, gate_mode=0, update=False,
+             gate_acc=None):
+    """rfft2 of act(bn(x)) (bn optional) [* gate].  Returns (Y, activated input or None[, gate gradient when gate_acc:
+    sigmoid'(alpha) * sum of the 64 accumulator slots])."""
     _chk(x)
     N, S, S2, Cc = x.shape
     assert S == S2
     Y = empty((N, S, S // 2 + 1, 2 * Cc), x)
     act = torch.empty_like(x) if (want_act and bn is not None) else None
+    ggrad = empty((), x) if gate_acc is not None else None
     _call("ud_rfft2_ex", _p(x), _p(Y), N, S, Cc, float(scale), float(w_interior),
-          C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode), _stream())
-    return Y, act
+          C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode),
+          _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), _stream())
+    return (Y, act, ggrad) if gate_acc is not None else (Y, act)
 
 
 def irfft2_mix(Y, scale, spat, alpha, acc):

@@ -123,7 +123,7 @@ _SIGNATURES = {
     "ud_dwconv_bwd_data_bn_ws_doubles": [_I, _I, _I, _I, _I],
     "ud_dwconv_bwd_data_ex": [_P, _P, _I, _P, _P, _P] + [_I] * 10 + [_P],
     "ud_dwconv_bwd_weight_ex": [_P, _P, _P, _I, _P, _P, _I] + [_I] * 10 + [_P],
-    "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P],
+    "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _P],
     "ud_irfft2_mix": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P],
     "ud_rfft2_planes_ws_floats": [_L, _I],
     "ud_rfft2_planes": [_P, _P, _P, _L, _I, _F, _P],

@@ -877,8 +877,9 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
             if stride == 1:
                 dacc = K.zeros64(64, x)
                 dd, dg1, db1 = K.normbwd_apply_mix(d, dz1, bn1, N, HWo, sb1, spat, fr, dacc, loc1)
-                tape.add_param_grad(alpha, K.gate_grad_from_acc(dacc, alpha))
-                dyf, _ = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1)       # adjoint of irfft2, x sigmoid(a)
+                # adjoint of irfft2, x sigmoid(a); the same launch turns the accumulator slots into the gate's gradient
+                dyf, _, dalpha = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc)
+                tape.add_param_grad(alpha, dalpha)
                 g_sp, g_alpha, g_mode = dd, alpha, 2                                   # spatial branch: x (1 - sigmoid(a))
             else:
                 dd, dg1, db1 = K.normbwd_apply(d, dz1, None, 1.0, bn1, True, N, HWo, sb1, loc1)
