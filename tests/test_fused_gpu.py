@@ -109,3 +109,221 @@ def test_skip_gradient_accumulated_in_place_equals_separate_add():
     bad = [(k, float((g1[k] - g0[k]).abs().max())) for k in g0
            if float((g1[k] - g0[k]).abs().max()) > (2e-3 if k.endswith("sf_coef") else 1e-4) * float(g0[k].abs().max()) + 2e-5]
     assert not bad, bad[:10]
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel-level parity of the deferred-normalisation entry points (csrc/fused.hip, through the C ABI) against torch in
+# float64, at ragged shapes: channel counts that do not fill a column group, row counts that are not multiples of the
+# chunking, one and several samples, both forms of every reduction (fp64 atomics / partials + finalize).
+# ---------------------------------------------------------------------------------------------
+SHAPES = [(1, 37, 8), (3, 50, 24), (2, 257, 40), (4, 1024, 144), (2, 4096, 272), (32, 64, 1632), (2, 70000, 48)]
+
+
+def _mk(G, R, Cc, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(G, R, Cc, generator=g) * 1.7 + 0.3).to(dev)
+    gamma = (1.0 + 0.2 * torch.randn(Cc, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(Cc, generator=g)).to(dev)
+    return g, x, gamma, beta
+
+
+def _bn_ref(x, gamma, beta, eps, act):
+    xd = x.double()
+    mean = xd.mean((0, 1))
+    var = xd.var((0, 1), unbiased=False)
+    z = (xd - mean) / torch.sqrt(var + eps) * gamma.double() + beta.double()
+    return z * torch.sigmoid(z) if act else z
+
+
+def _deferred(K, x, gamma, beta, eps, act, rm=None, rv=None, mom=0.0):
+    G, R, Cc = x.shape
+    acc = K.zeros64(2 * Cc, x)
+    K.colstats(x.view(G * R, Cc), acc)
+    return K.DeferredBN(acc, Cc, G * R, gamma, beta, eps, act, mom, rm, rv)
+
+
+@pytest.mark.parametrize("G,R,Cc", SHAPES)
+def test_deferred_bn_forward_kernels(G, R, Cc):
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g, x, gamma, beta = _mk(G, R, Cc, 11 + Cc, dev)
+    eps = 1e-3
+    rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    bn = _deferred(K, x, gamma, beta, eps, 1, rm, rv, 0.01)
+    ref = _bn_ref(x, gamma, beta, eps, True)
+    # statistics
+    xd = x.double()
+    assert _rel(bn.acc[:Cc], xd.sum((0, 1))) < 1e-12 and _rel(bn.acc[Cc:], (xd * xd).sum((0, 1))) < 1e-12
+    # materialised apply (also moves the running statistics, once)
+    y = K.bn_apply(x, bn, G, R, update=True)
+    assert _rel(y, ref) < 5e-6
+    n = G * R
+    assert _rel(rm, 0.01 * xd.mean((0, 1))) < 1e-5
+    assert _rel(rv, 0.99 + 0.01 * xd.var((0, 1), unbiased=False) * n / max(n - 1, 1)) < 1e-5
+    # SE pooling sums, gate and gated activation
+    pool = K.zeros64(G * Cc, x)
+    K.colsum_bn(x, bn, G, R, pool)
+    assert _rel(pool.view(G, Cc), ref.sum(1)) < 5e-6
+    s = torch.randn(G, Cc, generator=g).to(dev)
+    yg = K.se_scale_bn(x, bn, s, G, R)
+    assert _rel(yg, ref * torch.sigmoid(s.double())[:, None, :]) < 5e-6
+    dy = torch.randn(G, R, Cc, generator=g).to(dev)
+    dot = K.zeros64(G * Cc, x)
+    K.coldot_bn(dy, x, bn, G, R, dot)
+    assert _rel(dot.view(G, Cc), (dy.double() * ref).sum(1)) < 5e-6
+    # BN2 + drop-connect + skip
+    bn0 = _deferred(K, x, gamma, beta, eps, 0)
+    keep = (torch.rand(G, generator=g) < 0.7).float().to(dev)
+    skip = torch.randn(G, R, Cc, generator=g).to(dev)
+    out = K.residual_bn(x, bn0, keep, 1.25, skip, G, R)
+    want = _bn_ref(x, gamma, beta, eps, False) * (keep.double() * 1.25)[:, None, None] + skip.double()
+    assert _rel(out, want) < 5e-6
+
+
+@pytest.mark.parametrize("G,R,Cc", SHAPES)
+@pytest.mark.parametrize("act", [0, 1])
+def test_deferred_bn_backward_kernels(G, R, Cc, act):
+    """normbwd_sums / normbwd_apply (with the drop-connect scale) and the fused se_scale_bwd_bn against autograd."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g, x, gamma, beta = _mk(G, R, Cc, 23 + Cc + act, dev)
+    eps = 1e-3
+    dy = torch.randn(G, R, Cc, generator=g).to(dev)
+    keep = (torch.rand(G, generator=g) < 0.7).float().to(dev)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean, var = xd.mean((0, 1)), xd.var((0, 1), unbiased=False)
+    z = (xd - mean) / torch.sqrt(var + eps) * gd + bd
+    y = z * torch.sigmoid(z) if act else z
+    (y * (keep.double() * 1.25)[:, None, None] * dy.double()).sum().backward()
+    bn = _deferred(K, x, gamma, beta, eps, act)
+    sacc = K.zeros64(2 * Cc, x)
+    K.normbwd_sums(x, dy, keep, 1.25, bn, False, G, R, sacc)
+    dx, dg, db = K.normbwd_apply(x, dy, keep, 1.25, bn, False, G, R, sacc)
+    assert _rel(dx, xd.grad) < 2e-5 and _rel(dg, gd.grad) < 2e-5 and _rel(db, bd.grad) < 2e-5
+    if act:
+        # gate path: y = swish(bn(x)) * sigmoid(s);  upstream dc;  pooled branch dpool / HW
+        s = torch.randn(G, Cc, generator=g).to(dev)
+        dpool = torch.randn(G, Cc, generator=g).to(dev)
+        dc = torch.randn(G, R, Cc, generator=g).to(dev)
+        xd2 = x.double().requires_grad_(True)
+        m2, v2 = xd2.mean((0, 1)), xd2.var((0, 1), unbiased=False)
+        z2 = (xd2 - m2) / torch.sqrt(v2 + eps) * gamma.double() + beta.double()
+        b = z2 * torch.sigmoid(z2)
+        ((b * torch.sigmoid(s.double())[:, None, :] * dc.double()).sum() + (b.mean(1) * dpool.double()).sum()).backward()
+        sacc2 = K.zeros64(2 * Cc, x)
+        dz = K.se_scale_bwd_bn(dc, x, bn, s, dpool, 1.0 / R, G, R, sacc2)
+        dx2, _, _ = K.normbwd_apply(x, dz, None, 1.0, bn, True, G, R, sacc2)
+        assert _rel(dx2, xd2.grad) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cc,Cs", [(4, 24, 6), (32, 1632, 68), (5, 448, 112), (16, 192, 8)])
+def test_se_backward_kernels(N, Cc, Cs):
+    """ud_se_bwd_a / ud_se_bwd_b: the two FC layers of the squeeze-excite backward against autograd (float64)."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N + Cc)
+    HW = 49
+    pool_sum = (torch.randn(N, Cc, generator=g) * HW).double()
+    Wr = (torch.randn(Cs, Cc, generator=g) / Cc ** 0.5)
+    br = torch.randn(Cs, generator=g) * 0.1
+    We = (torch.randn(Cc, Cs, generator=g) / Cs ** 0.5)
+    be = torch.randn(Cc, generator=g) * 0.1
+    dgate = torch.randn(N, Cc, generator=g).double()
+    Wrd, brd, Wed, bed = (t.double().requires_grad_(True) for t in (Wr, br, We, be))
+    pool = (pool_sum / HW).requires_grad_(True)
+    s1 = pool @ Wrd.t() + brd
+    s2 = (s1 * torch.sigmoid(s1)) @ Wed.t() + bed
+    (torch.sigmoid(s2) * dgate).sum().backward()
+    dpool, dWe, dbe, dWr, dbr = K.se_bwd(dgate.to(dev), s2.detach().float().to(dev), s1.detach().float().to(dev),
+                                         We.to(dev), Wr.to(dev), pool_sum.to(dev), 1.0 / HW)
+    for got, want, name in ((dpool, pool.grad, "dpool"), (dWe, Wed.grad, "dWe"), (dbe, bed.grad, "dbe"),
+                            (dWr, Wrd.grad, "dWr"), (dbr, brd.grad, "dbr")):
+        assert _rel(got, want) < 2e-5, (name, _rel(got, want))
+    # forward FCs of the same block
+    s1g = K.fc_fwd_d(pool_sum.to(dev), 1.0 / HW, Wr.to(dev), br.to(dev), N)
+    assert _rel(s1g, s1) < 1e-5
+    s2g = K.fc_fwd(s1g, We.to(dev), be.to(dev), 1)
+    assert _rel(s2g, s2) < 1e-5
+
+
+@pytest.mark.parametrize("N,H,Cc,k,stride,pad", [(2, 16, 24, 3, 1, (1, 1, 1, 1)), (2, 16, 40, 5, 1, (2, 2, 2, 2)),
+                                                 (1, 32, 48, 3, 2, (0, 1, 0, 1)), (2, 16, 144, 5, 2, (1, 2, 1, 2)),
+                                                 (3, 9, 8, 3, 1, (1, 1, 1, 1))])
+@pytest.mark.parametrize("gate_mode", [0, 2])
+def test_dwconv_backward_through_deferred_bn(N, H, Cc, k, stride, pad, gate_mode):
+    """ud_dwconv_bwd_data_bn (gate * conv^T(dy) + add, pushed through swish'(bn(x)), BN sums) and ud_dwconv_bwd_weight_ex
+    against autograd; ud_dwconv_bwd_data_ex likewise."""
+    import torch.nn.functional as F
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N * 100 + Cc + k)
+    pl, pr, pt, pb = pad
+    x = torch.randn(N, H, H, Cc, generator=g)
+    w = torch.randn(Cc, 1, k, k, generator=g) * 0.3
+    gamma, beta = 1.0 + 0.2 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    alpha = torch.tensor(0.4)
+    Ho = (H + pt + pb - k) // stride + 1
+    dy = torch.randn(N, Ho, Ho, Cc, generator=g)
+    add = torch.randn(N, H, H, Cc, generator=g)
+    gate = float(1 - torch.sigmoid(alpha)) if gate_mode == 2 else 1.0
+    xd = x.double().requires_grad_(True)
+    mean, var = xd.mean((0, 1, 2)), xd.var((0, 1, 2), unbiased=False)
+    z = (xd - mean) / torch.sqrt(var + 1e-3) * gamma.double() + beta.double()
+    a = (z * torch.sigmoid(z)).detach().requires_grad_(True)           # stop at the activated tensor: da is what we want
+    wd = w.double().requires_grad_(True)
+    yc = F.conv2d(F.pad(a.permute(0, 3, 1, 2), (pl, pr, pt, pb)), wd, stride=stride, groups=Cc).permute(0, 2, 3, 1)
+    ((yc * dy.double()).sum() * gate).backward()
+    da = a.grad + add.double()
+    zc = z.detach()
+    sg = torch.sigmoid(zc)
+    dz_ref = da * (sg * (1 + zc * (1 - sg)))
+    xh = (x.double() - mean.detach()) / torch.sqrt(var.detach() + 1e-3)
+    xg, dyg, addg = x.to(dev), dy.to(dev), add.to(dev)
+    wt = w.view(Cc, k * k).t().contiguous().to(dev)
+    bn = _deferred(K, xg.view(N, H * H, Cc), gamma.to(dev), beta.to(dev), 1e-3, 1)
+    al = alpha.to(dev)
+    if stride == 1:
+        sacc = K.zeros64(2 * Cc, xg)
+        dz = K.dwconv_bwd_data_bn(dyg, al if gate_mode else None, gate_mode, wt, addg, xg, bn, k, stride, pt, pl, sacc)
+        assert _rel(dz, dz_ref) < 2e-5
+        assert _rel(sacc[:Cc], dz_ref.sum((0, 1, 2))) < 2e-5 and _rel(sacc[Cc:], (dz_ref * xh).sum((0, 1, 2))) < 2e-5
+    dxe = K.dwconv_bwd_data_ex(dyg, al if gate_mode else None, gate_mode, wt, addg, k, stride, pt, pl, H, H)
+    assert _rel(dxe, da) < 2e-5
+    ag = a.detach().float().to(dev)
+    dw = K.dwconv_bwd_weight_ex(ag, dyg, al if gate_mode else None, gate_mode, k, stride, pt, pl)
+    assert _rel(dw.view(Cc, k, k), wd.grad.view(Cc, k, k)) < 2e-5
+
+
+@pytest.mark.parametrize("S,Cc,N", [(8, 24, 3), (16, 40, 2), (32, 48, 2), (64, 8, 1)])
+def test_fft_fused_variants(S, Cc, N):
+    """ud_rfft2_ex (deferred BN + swish on load, activated side output, gate factor) and ud_irfft2_mix (irfft2 + SF mix +
+    BN statistics) against torch.fft in float64."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(S + Cc)
+    x = torch.randn(N, S, S, Cc, generator=g).to(dev)
+    gamma, beta = (1.0 + 0.2 * torch.randn(Cc, generator=g)).to(dev), (0.1 * torch.randn(Cc, generator=g)).to(dev)
+    alpha = torch.tensor(-0.3, device=dev)
+    bn = _deferred(K, x.view(N, S * S, Cc), gamma, beta, 1e-3, 1)
+    act_ref = _bn_ref(x.view(N, S * S, Cc), gamma, beta, 1e-3, True).view(N, S, S, Cc)
+    Y, act = K.rfft2_ex(x, 1.0 / S, 1.0, bn=bn, want_act=True, gate_alpha=alpha, gate_mode=1)
+    assert _rel(act, act_ref) < 5e-6
+    F_ = torch.fft.rfft2(act_ref.permute(0, 3, 1, 2), norm="ortho").permute(0, 2, 3, 1) * torch.sigmoid(alpha.double().cpu())
+    assert _rel(Y[..., :Cc], F_.real) < 2e-5 and _rel(Y[..., Cc:], F_.imag) < 2e-5
+    # irfft2 + mix + statistics
+    Yin = torch.randn(N, S, S // 2 + 1, 2 * Cc, generator=g).to(dev)
+    spat = torch.randn(N, S, S, Cc, generator=g).to(dev)
+    acc = K.zeros64(2 * Cc, x)
+    y, fr = K.irfft2_mix(Yin, 1.0 / S, spat, alpha, acc)
+    Yc = torch.complex(Yin[..., :Cc].double().cpu(), Yin[..., Cc:].double().cpu()).permute(0, 3, 1, 2)
+    fr_ref = torch.fft.irfft2(Yc, s=(S, S), norm="ortho").permute(0, 2, 3, 1)
+    a = torch.sigmoid(alpha.double().cpu())
+    y_ref = (1 - a) * spat.double().cpu() + a * fr_ref
+    assert _rel(fr, fr_ref) < 2e-5 and _rel(y, y_ref) < 2e-5
+    assert _rel(acc[:Cc], y_ref.sum((0, 1, 2))) < 2e-5 and _rel(acc[Cc:], (y_ref * y_ref).sum((0, 1, 2))) < 2e-5
