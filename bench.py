@@ -373,9 +373,17 @@ def main():
             line["roofline"]["step_achieved_hbm_frac"] = 1044e6 * ips / 8e12
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio (buffered until exit): flush it first so that the JSON line is
+        # the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -22,8 +22,10 @@ def _bench(extra_env, *flags):
            "--no-cpu-baseline", *flags]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    return json.loads(line), r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    # stdout is the ONE JSON line, and it comes last (RCCL's version banner is flushed before it)
+    assert lines and lines[-1].startswith("{") and sum(ln.startswith("{") for ln in lines) == 1, lines[-3:]
+    return json.loads(lines[-1]), r.stderr
 
 
 def test_bench_line_contract():
