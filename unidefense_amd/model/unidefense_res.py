@@ -196,7 +196,7 @@ class UniDefenseModelRes18(nn.Module):
                                        T.avgpool(tape, p2, p2.shape[1] // p3.shape[1]), p3])      # [N,h,w,448]
 
         d_in = ext
-        if self.training:                                                # F.dropout(ext_feat, 0.2), :391
+        if self.training and getattr(self, "_dec_dropout", True):        # F.dropout(ext_feat, 0.2), :391 (tests may switch it off)
             d_in = T.dropout_mask(tape, ext, self._keep_mask(rng, "dec_keep", ext, 0.8), 0.2)
         d = self._dec(tape, d_in, self.dec_block1, 0)
         d = self._dec(tape, d, self.dec_block1, 3, transposed=True)

@@ -176,7 +176,7 @@ class UniDefenseModelRes50(UniDefenseModelRes18):
         ext = h                                                          # [N, H/16, W/16, 1024]
 
         d_in = ext
-        if self.training:                                                # F.dropout(ext_feat, 0.2), :586
+        if self.training and getattr(self, "_dec_dropout", True):        # F.dropout(ext_feat, 0.2), :586 (tests may switch it off)
             d_in = T.dropout_mask(tape, ext, self._keep_mask(rng, "dec_keep", ext, 0.8), 0.2)
         d = self._dec(tape, d_in, self.dec_block1, 0)
         d = self._dec(tape, d, self.dec_block1, 3, transposed=True)
