@@ -29,3 +29,48 @@ def test_prefetcher_surfaces_source_errors():
     pf(1, 1, 4, "cpu")
     with pytest.raises(RuntimeError, match="data source failed"):
         pf(2, 1, 4, "cpu")
+
+
+class _ToyFaces:
+    """A dataset with the reference's contract: __getitem__ -> (path, label); load_item(paths, labels, crop) decodes."""
+
+    def __init__(self, n, label):
+        self.items = [(f"vid{i // 4}/frame{i}.png", label) for i in range(n)]
+        self.decoded = 0
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    def load_item(self, paths, labels, crop=None):
+        ids = [int(p.rsplit("frame", 1)[1].split(".")[0]) for p in paths]
+        imgs = torch.stack([torch.full((3, crop or 8, crop or 8), float(i)) for i in ids])
+        return {"images": imgs, "path": paths}
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_worker_loader_decodes_off_the_main_process_and_reshuffles(workers):
+    from unidefense_amd.engine.data import RealFakePrefetcher, worker_loader
+    real, fake = _ToyFaces(12, 0), _ToyFaces(8, 1)
+    src_r = worker_loader(real, 4, workers=workers, crop=6, seed=3)
+    src_f = worker_loader(fake, 4, workers=workers, crop=6, seed=5)
+    assert len(src_r) == 3 and len(src_f) == 2
+    ep0 = [(x[:, 0, 0, 0].tolist(), y.tolist()) for x, y in src_r]
+    ep1 = [(x[:, 0, 0, 0].tolist(), y.tolist()) for x, y in src_r]
+    for ep in (ep0, ep1):                       # every epoch: each frame once, decoded at the requested crop, labels kept
+        assert sorted(int(v) for xs, _ in ep for v in xs) == list(range(12)) and all(y == [0] * 4 for _, y in ep)
+    assert ep0 != ep1                           # re-shuffled per epoch (seed + epoch)
+    x0, _ = next(iter(src_r))
+    assert x0.shape == (4, 3, 6, 6) and x0.dtype == torch.float32
+    # rank sharding like DistributedSampler: two ranks split each epoch without overlap
+    a = worker_loader(real, 2, workers=0, seed=3, rank=0, world=2)
+    b = worker_loader(real, 2, workers=0, seed=3, rank=1, world=2)
+    ia = sorted(int(v) for x, _ in a for v in x[:, 0, 0, 0].tolist())
+    ib = sorted(int(v) for x, _ in b for v in x[:, 0, 0, 0].tolist())
+    assert len(ia) == len(ib) == 6 and sorted(ia + ib) == list(range(12))
+    # and through the prefetcher, in TrainEngine's iterator signature
+    pf = RealFakePrefetcher(src_r, src_f)
+    xr, yr, xf, yf = pf(1, 4, 6, "cpu")
+    assert xr.shape == (4, 3, 6, 6) and yr.eq(0).all() and yf.eq(1).all()

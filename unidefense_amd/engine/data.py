@@ -9,6 +9,7 @@ import queue
 import threading
 
 import torch
+import torch.utils.data
 
 
 class RealFakePrefetcher:
@@ -70,3 +71,66 @@ class RealFakePrefetcher:
             for t in tensors:
                 t.record_stream(torch.cuda.current_stream(device))
         return tuple(tensors)
+
+
+class DecodedBatches(torch.utils.data.Dataset):
+    """Moves the reference's main-process decode into DataLoader workers.
+
+    The reference's datasets yield `(path, label)` from `__getitem__` and decode / augment whole batches in the MAIN
+    process through `dataset.load_item(paths, labels, crop=...)` -> `{'images': [B,3,H,W], 'path': ...}`
+    (dataset/abstract_dataset.py:101-160, called at engine/forgery_engine.py:251-266).  This wrapper indexes BATCHES:
+    item i = `load_item` of the i-th batch of a (seeded, per-epoch reshuffled) index order, run inside a worker process,
+    so that `workers` batches decode in parallel while the GPU steps.  `rank` / `world` shard the order like the
+    reference's DistributedSampler (forgery_engine.py:67-86): every rank sees its own 1/world of each epoch."""
+
+    def __init__(self, dataset, batch_size, crop=None, shuffle=True, seed=0, rank=0, world=1, drop_last=True):
+        self.dataset, self.batch_size, self.crop = dataset, int(batch_size), crop
+        self.shuffle, self.seed, self.rank, self.world, self.drop_last = shuffle, int(seed), int(rank), int(world), drop_last
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _order(self):
+        n = len(self.dataset)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(n, generator=g).tolist()
+        else:
+            idx = list(range(n))
+        return idx[self.rank::self.world]
+
+    def __len__(self):
+        n = len(range(self.rank, len(self.dataset), self.world))
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __getitem__(self, i):
+        idx = self._order()[i * self.batch_size:(i + 1) * self.batch_size]
+        items = [self.dataset[j] for j in idx]                       # (path, label) pairs
+        paths = [it[0] for it in items]
+        labels = torch.as_tensor([int(it[1]) for it in items], dtype=torch.int64)
+        kw = {} if self.crop is None else {"crop": self.crop}
+        out = self.dataset.load_item(paths, labels, **kw)
+        return out["images"].float().contiguous(), labels
+
+
+def worker_loader(dataset, batch_size, workers=4, **kw):
+    """A re-iterable source for RealFakePrefetcher: batches decoded by `workers` processes, two batches prefetched per
+    worker, re-shuffled every epoch.  workers = 0 decodes in the calling thread (the prefetcher's), still off the main one."""
+    ds = DecodedBatches(dataset, batch_size, **kw)
+
+    class _Epochs:
+        def __init__(self):
+            self.epoch = 0
+
+        def __len__(self):
+            return len(ds)
+
+        def __iter__(self):
+            ds.set_epoch(self.epoch)
+            self.epoch += 1
+            loader = torch.utils.data.DataLoader(ds, batch_size=None, shuffle=False, num_workers=workers,
+                                                 prefetch_factor=2 if workers > 0 else None,
+                                                 persistent_workers=False)
+            return iter(loader)
+    return _Epochs()
