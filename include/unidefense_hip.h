@@ -60,8 +60,20 @@ typedef struct {
     int a_mode, b_mode, out_mode, split_k;
     int batch; long strideA, strideB, strideC;   /* batch >= 1; element strides between batches */
     ud_conv_geom g;
+    /* Optional epilogue statistics of the RESULT (training-mode BatchNorm behind a 1x1 conv, model.py:108-109,125-126):
+     * stat_sum[n] += sum_m C[m][n], stat_sumsq[n] += sum_m C[m][n]^2, fp64 atomic adds — the BatchNorm's statistics pass
+     * disappears.  Honoured only where ud_gemm_stats_slots() returns > 0 (split-bf16 kernel, out_mode 0, split_k 1,
+     * batch 1); with more than 64 row tiles the adds go to slot (row tile % 64) of [64][N] arrays instead (the caller
+     * passes zeroed slot arrays as stat_sum / stat_sumsq and folds them, e.g. with ud_stat_slots_fold). */
+    double* stat_sum; double* stat_sumsq;
 } ud_gemm_desc;
 int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
+/* 0: ud_gemm would ignore stat_sum / stat_sumsq for this descriptor (the caller runs ud_colstats on the result);
+ * 1: the epilogue adds straight into [N] accumulators; 64: it adds into 64 slots of [64][N] (see ud_gemm_desc). */
+int ud_gemm_stats_slots(const ud_gemm_desc* d);
+/* acc_sum[n] += sum_s slot_sum[s][n], likewise sumsq   (slots: the 64 above) */
+int ud_stat_slots_fold(const double* slot_sum, const double* slot_sumsq, int slots, int N, double* acc_sum,
+                       double* acc_sumsq, ud_stream_t stream);
 /* Arithmetic path of ud_gemm (process-wide; initial value from env UD_GEMM_PATH):
  *   0 auto (default): plain GEMMs (a_mode, b_mode in {0,1}, 16-byte aligned, M,N,K >= 16) run on the BF16
  *     matrix pipe with every fp32 operand split exactly into three bf16 pieces and six piece products

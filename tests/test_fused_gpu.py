@@ -327,3 +327,24 @@ def test_fft_fused_variants(S, Cc, N):
     y_ref = (1 - a) * spat.double().cpu() + a * fr_ref
     assert _rel(fr, fr_ref) < 2e-5 and _rel(y, y_ref) < 2e-5
     assert _rel(acc[:Cc], y_ref.sum((0, 1, 2))) < 2e-5 and _rel(acc[Cc:], (y_ref * y_ref).sum((0, 1, 2))) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,Kd", [(2048, 1632, 272), (8192 + 40, 960, 160), (131072, 192, 32), (524288 // 4, 144, 24),
+                                   (300, 48, 24), (2048, 272, 1632)])
+def test_gemm_epilogue_statistics(M, N, Kd):
+    """ud_gemm with stat_sum / stat_sumsq: the BatchNorm sums of the GEMM's result out of its epilogue (direct adds up to
+    64 row tiles, 64 slots + fold beyond; split plans fall back to ud_colstats) against the sums of the stored result."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(M % 1000 + N)
+    a = torch.randn(M, Kd, generator=g).to(dev)
+    w = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).to(dev)
+    acc = K.zeros64(2 * N, a)
+    y, done = K.gemm_nt(a, w, stats=acc)
+    if not done:
+        K.colstats(y, acc)
+    yd = y.double()
+    assert _rel(y, a.double() @ w.double().t()) < 2e-5
+    assert _rel(acc[:N], yd.sum(0)) < 1e-9 and _rel(acc[N:], (yd * yd).sum(0)) < 1e-9
+    print(f"  {M}x{N}x{Kd}: epilogue statistics {'used' if done else 'not applicable (split plan)'}")

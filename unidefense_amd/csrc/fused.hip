@@ -766,6 +766,22 @@ long ud_fused_reduce_ws_doubles(int G, int R, int C, int per_group, int min_rows
     return pl.use_part ? 2L * pl.q.G * pl.q.P * C : 0;
 }
 
+// acc[n] += sum over the slots of the GEMM epilogue statistics (ud_gemm_desc.stat_sum with > 64 row tiles).  The two slot
+// arrays need not be adjacent: two launches of the one-quantity form.
+int ud_stat_slots_fold(const double* slot_sum, const double* slot_sumsq, int slots, int N, double* acc_sum,
+                       double* acc_sumsq, ud_stream_t stream) {
+    if (!slot_sum || !slot_sumsq || slots < 1 || N < 1 || !acc_sum || !acc_sumsq) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (slot_sumsq == slot_sum + (long)slots * N) {
+        hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv(N, 8)), dim3(NT), 0, s, 2, 1, N, slots, slot_sum, acc_sum, acc_sumsq);
+    } else {
+        hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv(N, 8)), dim3(NT), 0, s, 1, 1, N, slots, slot_sum, acc_sum, nullptr);
+        hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv(N, 8)), dim3(NT), 0, s, 1, 1, N, slots, slot_sumsq, acc_sumsq, nullptr);
+    }
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
 int ud_colstats(const float* x, int G, int R, int C, double* sum, double* sumsq, double* ws, ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !sum || !sumsq) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;

@@ -471,6 +471,19 @@ extern "C" int ud_gemm_query_path(const ud_gemm_desc* dp) {
     return takes_x3(*dp, a_vec, b_vec) ? (g_path.load() == 3 ? 3 : 2) : 1;
 }
 
+// Epilogue statistics (ud_gemm_desc.stat_sum): only the split-bf16 kernel's plain-store epilogue sees whole column sums.
+static bool stats_ok(const ud_gemm_desc& d, int a_vec, int b_vec) {
+    return d.out_mode == 0 && d.split_k == 1 && d.batch == 1 && takes_x3(d, a_vec, b_vec);
+}
+
+extern "C" int ud_gemm_stats_slots(const ud_gemm_desc* dp) {
+    if (!dp) return UD_EINVAL;
+    int a_vec = 0, b_vec = 0;
+    vec_flags(*dp, a_vec, b_vec);
+    if (!stats_ok(*dp, a_vec, b_vec)) return 0;
+    return ud_cdiv(dp->M, ud_gemm_x3_tile_rows(*dp)) > 64 ? 64 : 1;
+}
+
 extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
     if (!dp) return UD_EINVAL;
     ud_gemm_desc d = *dp;
@@ -488,6 +501,7 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         if (d.a_mode == 2 && (rows != d.M || cols != d.K)) return UD_EINVAL;
         if (d.b_mode == 2 && (rows != d.K || cols != d.N)) return UD_EINVAL;
     }
+    if (d.stat_sum && (!d.stat_sumsq || !stats_ok(d, a_vec, b_vec))) return UD_EINVAL;
     if (takes_x3(d, a_vec, b_vec)) return ud_gemm_x3_launch(d, s, g_path.load() == 3);
 #ifdef UD_GEMM_DEBUG_NOLOAD      // tuning aid, debug builds only: issue no global loads (results are WRONG)
     static const bool noload = getenv("UD_GEMM_NOLOAD") != nullptr;

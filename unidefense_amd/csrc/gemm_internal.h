@@ -6,3 +6,5 @@
 // plain GEMM modes with 16-byte-loadable operands and no ragged vector tails
 bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec);
 int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s, bool f16);
+// rows per tile of the configuration the split-bf16 kernel would run this descriptor with
+int ud_gemm_x3_tile_rows(const ud_gemm_desc& d);

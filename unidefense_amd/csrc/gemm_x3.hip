@@ -385,6 +385,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (nkt == 0 && d.out_mode != 0) return;
+    if (d.stat_sum) {
+        // per-column sums of this wave's TM*32 rows (rows beyond M hold exact zeros: their A rows were zero-filled), the
+        // two lane halves (different rows, same column) folded by one shuffle, one fp64 atomic per column and quantity;
+        // more than 64 row tiles: slot (tile_m % 64) of [64][N], so that at most ~2 * tiles/64 adds queue per address
+        const long slot = (tiles_m > 64) ? (long)(tile_m & 63) * d.N : 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double v = (double)acc[i][j][r];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+            if (half == 0 && col < d.N) {
+                unsafeAtomicAdd(d.stat_sum + slot + col, s1);
+                unsafeAtomicAdd(d.stat_sumsq + slot + col, s2);
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -460,6 +485,24 @@ bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
     if (d.a_mode == 1 && d.M % 4 != 0) return false;
     if (d.b_mode == 1 && d.N % 4 != 0) return false;
     return true;
+}
+
+// rows per tile of the configuration launch_modes picks (for the epilogue-statistics slot rule)
+int ud_gemm_x3_tile_rows(const ud_gemm_desc& d) {
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < 3; ++i) {
+        long tiles = (long)ud_cdiv(d.M, kX[i].bm) * ud_cdiv(d.N, kX[i].bn) * d.split_k * d.batch;
+        long rounds = (tiles + 255) / 256;
+        double cost = (double)rounds * kX[i].bm * kX[i].bn * kX[i].penalty;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    static const int forced = [] {
+        const char* e = getenv("UD_GEMM_X3_CFG");
+        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
+    }();
+    if (forced >= 0) best = forced;
+    return kX[best].bm;
 }
 
 // f16: one fp16 piece per operand (mixed precision) instead of the exact three-way bf16 split

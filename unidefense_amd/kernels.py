@@ -99,7 +99,9 @@ def zeros(shape, like):
 # GEMM family
 # ---------------------------------------------------------------------------------------------
 def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_k=1, geom=None,
-          batch=1, strideA=0, strideB=0, strideC=0, a_off=0, b_off=0):
+          batch=1, strideA=0, strideB=0, strideC=0, a_off=0, b_off=0, stats=None):
+    """stats: fp64 accumulator [sum | sumsq] (2N doubles) the epilogue should add the result's column sums into; returns
+    (Cout, True) when the kernel did (ud_gemm_stats_slots), (Cout, False) when the caller still has to run colstats."""
     d = GemmDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.B = B.data_ptr() + 4 * b_off
@@ -110,6 +112,17 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
     if geom is not None:
         d.g = geom
+    fold = None
+    if stats is not None:
+        slots = _call("ud_gemm_stats_slots", C.byref(d)) if _GEMM_EPILOGUE_STATS else 0
+        if slots == 0:
+            stats_done = False
+        else:
+            stats_done = True
+            tgt = stats if slots == 1 else zeros64(2 * slots * N, Cout)
+            d.stat_sum, d.stat_sumsq = tgt.data_ptr(), tgt.data_ptr() + 8 * (slots * N if slots > 1 else N)
+            if slots > 1:
+                fold = (tgt, slots)
     if GEMM_PROFILE is not None:
         # live HIP-event timing of the dominant kernel on the stream it is launched on (bench.py roofline)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -118,12 +131,20 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
         e1.record()
         GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, a_mode, b_mode, split_k, batch),
                              _call("ud_gemm_query_path", C.byref(d))))
-        return Cout
-    _call("ud_gemm", C.byref(d), _stream())
-    return Cout
+    else:
+        _call("ud_gemm", C.byref(d), _stream())
+    if fold is not None:
+        tgt, slots = fold
+        _call("ud_stat_slots_fold", _pd64(tgt), _pd64(tgt, slots * N), slots, N, _pd64(stats), _pd64(stats, N), _stream())
+    return (Cout, stats_done) if stats is not None else Cout
 
 
 _TAIL_SPLIT = os.environ.get("UD_GEMM_TAIL_SPLIT", "1") == "1"
+_GEMM_EPILOGUE_STATS = os.environ.get("UD_GEMM_EPILOGUE_STATS", "1") == "1"      # A/B switch
+
+
+def _pd64(t, off_doubles=0):
+    return C.c_void_p(t.data_ptr() + 8 * off_doubles)
 
 
 def _tail_plan(M, N, K):
@@ -148,12 +169,19 @@ def _tail_plan(M, N, K):
     return (mt - rows_tail) * 128, split
 
 
-def gemm_nt(a, w, out=None, accumulate=False):
-    """out[M,N] (+)= a[M,K] @ w[N,K]^T     (1x1 conv / linear forward)"""
+def gemm_nt(a, w, out=None, accumulate=False, stats=None):
+    """out[M,N] (+)= a[M,K] @ w[N,K]^T     (1x1 conv / linear forward).
+    stats (2N zeroed doubles): BatchNorm statistics of the result; returns (out, done) — done = the GEMM epilogue
+    accumulated them (plain launches only: a split-K or tail-split plan leaves them to ud_colstats)."""
     _chk(a, w)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
+    if stats is not None:
+        assert out is None and not accumulate
+        if _tail_plan(M, N, K) is None and _fwd_split(M, N, K) <= 1:
+            return _gemm(a, w, empty((M, N), a), M, N, K, K, K, N, 0, 0, 0, stats=stats)
+        return gemm_nt(a, w), False
     if out is None:
         plan = _tail_plan(M, N, K)
         if plan is not None:

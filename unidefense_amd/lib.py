@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_long), ("ldb", C.c_long), ("ldc", C.c_long),
                 ("a_mode", C.c_int), ("b_mode", C.c_int), ("out_mode", C.c_int), ("split_k", C.c_int),
                 ("batch", C.c_int), ("strideA", C.c_long), ("strideB", C.c_long), ("strideC", C.c_long),
-                ("g", ConvGeom)]
+                ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p)]
 
 
 class BnRef(C.Structure):
@@ -43,6 +43,8 @@ _SIGNATURES = {
     "ud_gemm": [C.POINTER(GemmDesc), _P],
     "ud_gemm_set_path": [C.c_int],
     "ud_gemm_query_path": [C.POINTER(GemmDesc)],
+    "ud_gemm_stats_slots": [C.POINTER(GemmDesc)],
+    "ud_stat_slots_fold": [_P, _P, _I, _I, _P, _P, _P],
     "ud_reduce_ws_doubles": [_I, _I, _I],
     "ud_norm_stats": [_P, _I, _I, _I, _F, _P, _P, _P, _P, _F, _P, _P, _P],
     "ud_syncbn_combine": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
@@ -133,7 +135,7 @@ _SIGNATURES = {
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
                 "ud_conv_small_wgrad_ws_floats"}
 _LONG_FUNCS = {"ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",

@@ -782,9 +782,11 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
     if sp.expand != 1:
         We = blk._expand_conv.weight.view(Ce, Cin)
         x2 = x.view(M, Cin)
-        e = K.gemm_nt(x2, We).view(N, H, W, Ce)
         acc0 = K.zeros64(2 * Ce, x)
-        K.colstats(e.view(M, Ce), acc0)
+        e, done = K.gemm_nt(x2, We, stats=acc0)            # BN0 statistics in the GEMM epilogue where the launch is plain
+        if not done:
+            K.colstats(e, acc0)
+        e = e.view(N, H, W, Ce)
         dp.reduce(acc0)
         bn0 = _bn_of(blk._bn0, acc0, M * dp.world, 1)
         src, src_bn = e, bn0
@@ -834,9 +836,10 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
     # ---- project + BN2 + drop-connect + skip
     Wp = blk._project_conv.weight.view(Co, Ce)
     c2 = c.view(Mo, Ce)
-    p = K.gemm_nt(c2, Wp)
     acc2 = K.zeros64(2 * Co, x)
-    K.colstats(p, acc2)
+    p, done = K.gemm_nt(c2, Wp, stats=acc2)
+    if not done:
+        K.colstats(p, acc2)
     dp.reduce(acc2)
     bn2 = _bn_of(blk._bn2, acc2, Mo * dp.world, 0)
     p4 = p.view(N, Ho, Wo, Co)
