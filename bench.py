@@ -154,7 +154,9 @@ def main():
     ap.add_argument("--size", type=int, default=256, help="input resolution (UDR18: 128, UDR50: 256 or 320)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the contract line (fp32-accurate GEMMs).  f16: informational, BASELINE configs[4]: fp16 MFMA "
-                         "operands + fp32 accumulation in every plain GEMM (ud_gemm path 3), fp32 storage; use --batch 64")
+                         "operands + fp32 accumulation in every plain GEMM (ud_gemm path 3); use --batch 64")
+    ap.add_argument("--storage", default="f16", choices=["f16", "f32"],
+                    help="with --dtype f16: activation storage of the MBConv trunk (f16: half storage, the full configs[4] mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM timing table to this file")
@@ -195,6 +197,8 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):       # the loader announces the model like the reference's does: keep
         model = load_model(args.model)(num_classes=2, drop_rate=0.5, **ctor).to(dev).train()     # stdout to the ONE JSON line
+    if args.dtype == "f16" and args.storage == "f16":
+        model.half_storage = True            # MBConv trunk activations / activation gradients in fp16 (configs[4])
     model = wrap_data_parallel(model, local_rank) if (world > 1 or force) else model
     bs = args.batch
     g = torch.Generator().manual_seed(100 + rank)
@@ -209,7 +213,8 @@ def main():
             p.grad = None
         out = model(x)
         loss = pass1_loss(out, tgt, bs // 2, LOSSES)
-        loss.backward()
+        # f16: the engine's GradScaler scale (forgery_engine.py:228), so that half gradients do not underflow
+        (loss * 1024.0 if args.dtype == "f16" else loss).backward()
         return loss
 
     # ---- execution mode: the whole step (zero grads, forward, loss, backward [, gradient exchange]) is
@@ -318,7 +323,7 @@ def main():
         line = {
             "metric": ("images/sec fwd+bwd (256x256, EffNet-b4)" if (args.model, args.size) == ("UDEB4", 256)
                        else f"images/sec fwd+bwd ({args.size}x{args.size}, {args.model})")
-            + (" [informational: fp16 MFMA operands, fp32 accumulate/storage]" if args.dtype == "f16" else ""),
+            + ((" [informational: fp16 MFMA operands, fp32 accumulate, %s trunk storage]" % args.storage) if args.dtype == "f16" else ""),
             "value": world * bs * args.steps / elapsed,
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",

@@ -66,6 +66,11 @@ typedef struct {
      * batch 1); with more than 64 row tiles the adds go to slot (row tile % 64) of [64][N] arrays instead (the caller
      * passes zeroed slot arrays as stat_sum / stat_sumsq and folds them, e.g. with ud_stat_slots_fold). */
     double* stat_sum; double* stat_sumsq;
+    /* Half storage (BASELINE configs[4]): bit 0 / 1 / 2 set = A / B / C point to _Float16 instead of float (element
+     * strides unchanged).  Such descriptors always run on the fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulation):
+     * plain modes only — (0,0) and (0,1) with A half (activations x fp32 weights), (1,1) with A and B half (the weight
+     * gradient), any of them with fp32 operands; batch 1; a half C takes out_mode 0 / 1 (no atomics: split_k 1). */
+    int half_mask;
 } ud_gemm_desc;
 int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
 /* 0: ud_gemm would ignore stat_sum / stat_sumsq for this descriptor (the caller runs ud_colstats on the result);
@@ -127,12 +132,12 @@ int ud_bcast_rows(const float* g, float scale, float* out, int N, int HW, int C,
 /* ---- depthwise k x k conv, k in {3,5}, stride in {1,2}; weights tap-major wt[k*k][C] ------------
  * Serves the depthwise Conv2dStaticSamePadding / the spatial branch of SFConv2dStaticSamePadding
  * (model/efficientnet/utils.py:277-280, exp.py:49-51); pad_t/pad_l = top/left of the static ZeroPad2d. */
-int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W, int C, int Ho, int Wo,
-                  int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
+int ud_dwconv_fwd(const void* x, const float* wt, void* y, int N, int H, int W, int C, int Ho, int Wo, int K,
+    int stride, int pad_t, int pad_l, int f16, ud_stream_t stream);
 /* add (may be NULL): another contribution to the same gradient, [N][H][W][C]; dx = conv-transpose(dy) + add
  * (the input of SFConv's spatial branch also feeds its frequency branch, exp.py:49-55) */
-int ud_dwconv_bwd_data(const float* dy, const float* wt, const float* add, float* dx, int N, int H, int W,
-                       int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream);
+int ud_dwconv_bwd_data(const void* dy, const float* wt, const void* add, void* dx, int N, int H, int W, int C,
+    int Ho, int Wo, int K, int stride, int pad_t, int pad_l, int f16, ud_stream_t stream);
 int ud_dwconv_bwd_weight_parts(int C, int chunks);   /* rows of K*K*C floats that `part` must hold */
 /* every depthwise weight of the network to the tap-major layout in one launch.  table: layers x 4 int64 in DEVICE
  * memory (source pointer [C][K*K], C, K*K, destination offset in floats); dst[off + tap*C + c] = src[c*K*K + tap];
@@ -150,10 +155,10 @@ int ud_dwconv_bwd_weight(const float* x, const float* dy, float* dwt, float* par
  * torch.fft.rfft2/irfft2 (model/efficientnet/exp.py:55,60; model/unidefense.py:130-145):
  *   forward rfft2 = (scale,1), its adjoint = ud_irfft2(scale, 0.5);
  *   forward irfft2 = (scale,1), its adjoint = ud_rfft2(scale, 2). */
-int ud_rfft2(const float* x, float* Y, int N, int S, int C, float scale, float w_interior,
-             ud_stream_t stream);
-int ud_irfft2(const float* Y, float* x, int N, int S, int C, float scale, float w_interior,
-              ud_stream_t stream);
+int ud_rfft2(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, int f16, ud_stream_t
+    stream);
+int ud_irfft2(const void* Y, void* x, int N, int S, int C, float scale, float w_interior, int f16, ud_stream_t
+    stream);
 
 /* ---- small FC: y[n][o] = sum_i act_in(x[n][i]) W[o][i] + b[o]  (SE 1x1 convs, classifier) ------
  * model/efficientnet/model.py:119-121; model/modules.py:27.  Any of dx / dW / db may be NULL. */
@@ -173,11 +178,10 @@ int ud_sigmoid_grad_mul(const float* s, float* v, long n, ud_stream_t stream);
  *      P = identity or the 2x2 average pool (pool = 1: freq is [N][2Ho][2Wo][C]).
  *      bwd: part holds ud_sfmix_blocks() DOUBLES; dalpha[0] = sigmoid'(alpha) * sum dy (P(freq) - spat) */
 int ud_sfmix_blocks(int N, int Ho, int Wo, int C);
-int ud_sfmix_fwd(const float* spat, const float* freq, const float* alpha, float* y, int N, int Ho, int Wo,
-                 int C, int pool, ud_stream_t stream);
-int ud_sfmix_bwd(const float* spat, const float* freq, const float* alpha, const float* dy, float* dspat,
-                 float* dfreq, double* part, float* dalpha, int N, int Ho, int Wo, int C, int pool,
-                 ud_stream_t stream);
+int ud_sfmix_fwd(const void* spat, const void* freq, const float* alpha, void* y, int N, int Ho, int Wo, int C,
+    int pool, int f16, ud_stream_t stream);
+int ud_sfmix_bwd(const void* spat, const void* freq, const float* alpha, const void* dy, void* dspat, void*
+    dfreq, double* part, float* dalpha, int N, int Ho, int Wo, int C, int pool, int f16, ud_stream_t stream);
 /* same for two equal-shape tensors (fuse_coef, model/unidefense.py:153-154) */
 int ud_gate_mix_blocks(long total);
 int ud_gate_mix_fwd(const float* p, const float* q, const float* alpha, float* y, long total,
@@ -192,8 +196,8 @@ int ud_gate_mix_bwd(const float* p, const float* q, const float* alpha, const fl
  * ud_absdiff: out = |a - b| (b may be NULL) */
 int ud_residual_fwd(const float* x, const float* skip, const float* keep, float inv_keep, float* out,
                     long total, long per_sample, ud_stream_t stream);
-int ud_axpby(const float* a, float alpha, const float* b, float beta, float* out, long total,
-             ud_stream_t stream);
+int ud_axpby(const void* a, float alpha, const void* b, float beta, void* out, long total, int f16, ud_stream_t
+    stream);
 int ud_mask_scale(const float* x, const float* mask, float scale, float* out, long total,
                   ud_stream_t stream);
 int ud_absdiff(const float* a, const float* b, float* out, long total, ud_stream_t stream);
@@ -316,40 +320,45 @@ typedef struct {
     float* running_var;
 } ud_bn_ref;
 
-/* Reducing entry points take `ws`: fp64 scratch of ud_fused_reduce_ws_doubles(G, R, C, per_group, min_rows) doubles
+/* Storage type: entry points with an `int f16` parameter take their ACTIVATION tensors (declared const void* / void*) as
+ * float (f16 = 0) or _Float16 (f16 = 1, "half storage", BASELINE configs[4]); per-channel / per-sample vectors,
+ * weights, weight gradients and the fp64 accumulators keep their types.  Arithmetic is fp32 in registers either way;
+ * half results are rounded to nearest even on store, and statistics are taken of the rounded values.
+ *
+ * Reducing entry points take `ws`: fp64 scratch of ud_fused_reduce_ws_doubles(G, R, C, per_group, min_rows) doubles
  * (per_group = 1 for [G][C] outputs, 0 for one [C] set; min_rows = 8) — they run as ONE launch with fp64 atomic adds
  * while at most 64 workgroups would add to the same addresses (ws unused, the helper returns 0) and as partials +
  * finalize otherwise.  ws may be NULL (always atomics). */
 long ud_fused_reduce_ws_doubles(int G, int R, int C, int per_group, int min_rows);
 /* sum[g][c] += sum_r x, sumsq[g][c] += sum_r x^2   (training-mode BatchNorm statistics, model.py:109,114,126) */
-int ud_colstats(const float* x, int G, int R, int C, double* sum, double* sumsq, double* ws, ud_stream_t stream);
+int ud_colstats(const void* x, int G, int R, int C, double* sum, double* sumsq, double* ws, int f16, ud_stream_t
+    stream);
 /* out[g][c] += sum_r act(bn(x))            (SE squeeze: adaptive_avg_pool2d of the activated tensor, model.py:118;
  *                                           head pooling unidefense.py:226)  — bn->running_* are updated here */
-int ud_colsum_bn(const float* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
-                 ud_stream_t stream);
+int ud_colsum_bn(const void* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws, int f16,
+    ud_stream_t stream);
 /* out[g][c] += sum_r dy * act(bn(x))       (gradient of the SE gate) */
-int ud_coldot_bn(const float* dy, const float* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
-                 ud_stream_t stream);
+int ud_coldot_bn(const void* dy, const void* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double*
+    ws, int f16, ud_stream_t stream);
 /* y[n][o] = sum_i (xsum[n][i] * xscale) W[o][i] + b[o]      (SE reduce conv on the pooled sums) */
 int ud_fc_fwd_d(const double* xsum, float xscale, const float* W, const float* b, float* y, int N, int I, int O,
                 ud_stream_t stream);
 /* y = act(bn(x)) * sigmoid(s[g][c])        (BN1 + swish + SE gate in one pass, model.py:114-122) */
-int ud_se_scale_bn(const float* x, const ud_bn_ref* bn, const float* s, float* y, int G, int R, int C,
-                   ud_stream_t stream);
+int ud_se_scale_bn(const void* x, const ud_bn_ref* bn, const float* s, void* y, int G, int R, int C, int f16,
+    ud_stream_t stream);
 /* out = bn(x) * (keep[g] * inv_keep) + skip   (BN2 + drop_connect + residual, model.py:126-134; keep / skip may be
  * NULL; bn->running_* are updated here) */
-int ud_residual_bn(const float* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const float* skip,
-                   float* out, int G, int R, int C, ud_stream_t stream);
+int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const void* skip,
+    void* out, int G, int R, int C, int f16, ud_stream_t stream);
 /* BatchNorm backward, reductions: dz = dy * (keep[g] * inv_keep) * act'(z)  (dy_is_dz: dz = dy);
  * s1[c] += sum dz, s2[c] += sum dz * xhat */
-int ud_normbwd_sums(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
-                    int dy_is_dz, int G, int R, int C, double* s1, double* s2, double* ws, ud_stream_t stream);
+int ud_normbwd_sums(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn, int
+    dy_is_dz, int G, int R, int C, double* s1, double* s2, double* ws, int f16, ud_stream_t stream);
 /* dx = gamma invstd (dz - s1 inv_count - xhat s2 inv_count); s1/s2: sums over ALL ranks, s1_local/s2_local: this
  * rank's sums -> dbeta / dgamma (NULL: not written) */
-int ud_normbwd_apply(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
-                     int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
-                     const double* s2_local, int G, int R, int C, float* dx, float* dgamma, float* dbeta,
-                     ud_stream_t stream);
+int ud_normbwd_apply(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn, int
+    dy_is_dz, const double* s1, const double* s2, const double* s1_local, const double* s2_local, int G, int R,
+    int C, void* dx, float* dgamma, float* dbeta, int f16, ud_stream_t stream);
 /* SE backward, the two small FC layers (model.py:119-121) in two launches:
  *   a: dpre = dgate[n][c] * sigmoid'(s2);  ds1[n][i] = swish'(s1) sum_c dpre W_e[c][i];
  *      dW_e[c][i] = sum_n dpre swish(s1[n][i]);  db_e[c] = sum_n dpre
@@ -360,46 +369,44 @@ int ud_se_bwd_b(const double* ds1_acc, const float* s1, const float* Wr, const d
                 float* dpool, float* dWr, float* dbr, int N, int C, int Cs, ud_stream_t stream);
 /* db = dc * sigmoid(s[g][c]) + dpool[g][c] * inv_hw;  dz = db * act'(bn(x));  s1 += sum dz, s2 += sum dz xhat
  * (gradient through the SE gate and the swish of BN1, with BN1's backward sums) */
-int ud_se_scale_bwd_bn(const float* dc, const float* x, const ud_bn_ref* bn, const float* s, const float* dpool,
-                       float inv_hw, float* dz, double* s1, double* s2, double* ws, int G, int R, int C,
-                       ud_stream_t stream);
+int ud_se_scale_bwd_bn(const void* dc, const void* x, const ud_bn_ref* bn, const float* s, const float* dpool,
+    float inv_hw, void* dz, double* s1, double* s2, double* ws, int G, int R, int C, int f16, ud_stream_t
+    stream);
 /* ud_normbwd_apply (dy_is_dz) fused with the gradient of the SF mix y = (1-a) spat + a freq (exp.py:61-65):
  * writes dd = dL/dy and accumulates sum dd * (freq - spat) into the 64 slots dalpha_acc[0..64) (zeroed by the caller) */
-int ud_normbwd_apply_mix(const float* x, const float* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
-                         const double* s1_local, const double* s2_local, const float* spat, const float* freq,
-                         int G, int R, int C, float* dd, double* dalpha_acc, float* dgamma, float* dbeta,
-                         ud_stream_t stream);
+int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
+    const double* s1_local, const double* s2_local, const void* spat, const void* freq, int G, int R, int C,
+    void* dd, double* dalpha_acc, float* dgamma, float* dbeta, int f16, ud_stream_t stream);
 /* out[0] = sigmoid'(alpha[0]) * sum(acc[0..64))      (sf_coef gradient from the accumulator above) */
 int ud_gate_grad_from_acc(const double* acc, const float* alpha, float* out, ud_stream_t stream);
 /* y = act(bn(x)): the materialised form for consumers that re-read their input per tap (a plain depthwise conv and its
  * weight gradient: re-evaluating the swish per window load costs more than this pass); bn->running_* are updated here */
-int ud_bn_apply(const float* x, const ud_bn_ref* bn, float* y, int G, int R, int C, ud_stream_t stream);
+int ud_bn_apply(const void* x, const ud_bn_ref* bn, void* y, int G, int R, int C, int f16, ud_stream_t stream);
 /* data gradient of the depthwise conv, scaled by the gate, plus `add`, pushed through the swish of the deferred
  * BatchNorm of its INPUT x:  da = gate * dwconv_bwd_data(dy) + add;  dz = da * act'(bn(x));  s1/s2 as above */
-int ud_dwconv_bwd_data_bn(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
-                          const float* x, const ud_bn_ref* bn, float* dz, double* s1, double* s2, double* ws, int N,
-                          int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l,
-                          ud_stream_t stream);
+int ud_dwconv_bwd_data_bn(const void* dy, const float* gate_alpha, int gate_mode, const float* wt, const void*
+    add, const void* x, const ud_bn_ref* bn, void* dz, double* s1, double* s2, double* ws, int N, int H, int W,
+    int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, int f16, ud_stream_t stream);
 long ud_dwconv_bwd_data_bn_ws_doubles(int N, int H, int W, int C, int stride);
 /* ud_dwconv_bwd_data with the gate factor on dy */
-int ud_dwconv_bwd_data_ex(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
-                          float* dx, int N, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t,
-                          int pad_l, ud_stream_t stream);
+int ud_dwconv_bwd_data_ex(const void* dy, const float* gate_alpha, int gate_mode, const float* wt, const void*
+    add, void* dx, int N, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, int f16,
+    ud_stream_t stream);
 /* ud_dwconv_bwd_weight with the gate factor on dy */
-int ud_dwconv_bwd_weight_ex(const float* x, const float* dy, const float* gate_alpha, int gate_mode, float* dwt,
-                            float* part, int chunks, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
-                            int pad_t, int pad_l, ud_stream_t stream);
+int ud_dwconv_bwd_weight_ex(const void* x, const void* dy, const float* gate_alpha, int gate_mode, float* dwt,
+    float* part, int chunks, int N, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int
+    pad_l, int f16, ud_stream_t stream);
 /* ud_rfft2 of act(bn(x)) (bn may be NULL), optionally also writing the activated input (act_out) and scaling the
  * result by the gate:  SFConv's spectral branch reading the expand conv's raw output (exp.py:55) and, as the
  * adjoint of irfft2, its backward (gate = sigmoid(sf_coef)).  gate_grad (optional): also finishes the gate's gradient,
  * gate_grad[0] = sigmoid'(alpha) * sum(gate_acc[0..64)), from the slots ud_normbwd_apply_mix filled just before. */
-int ud_rfft2_ex(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
-                float* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
-                ud_stream_t stream);
+int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
+    void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad, int f16,
+    ud_stream_t stream);
 /* irfft2 + SF mix + BN1 statistics (exp.py:60-65, stride 1):  freq_out = irfft2(Y) * scale;
  * y = (1 - a) spat + a freq_out, a = sigmoid(alpha[0]);  sum[c] += sum y, sumsq[c] += sum y^2 */
-int ud_irfft2_mix(const float* Y, float* y, int N, int S, int C, float scale, float w_interior, const float* spat,
-                  const float* alpha, float* freq_out, double* sum, double* sumsq, ud_stream_t stream);
+int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, float w_interior, const void* spat,
+    const float* alpha, void* freq_out, double* sum, double* sumsq, int f16, ud_stream_t stream);
 
 /* ---- multi-tensor AdamW (csrc/optim.hip) ------------------------------------------------------------------------
  * torch.optim.AdamW(amsgrad) over timm's weight-decay groups (engine/forgery_engine.py:149-156) with GradScaler's
@@ -421,6 +428,23 @@ int ud_adamw_multi(const void* table, const void* chunk_map, int n_chunks, const
 long ud_rfft2_planes_ws_floats(long P, int S);
 int ud_rfft2_planes(const float* x, float* Y, float* ws, long P, int S, float scale, ud_stream_t stream);
 int ud_rfft2_planes_adjoint(const float* dY, float* dx, float* ws, long P, int S, float scale, ud_stream_t stream);
+
+/* ---- one-shot SyncBatchNorm exchange (csrc/xchg.hip) ---------------------------------------------------------------
+ * Replaces the per-BatchNorm library collectives of nn.SyncBatchNorm (engine/forgery_engine.py:142) on one node: every
+ * rank owns a mailbox in fine-grained device memory mapped into its peers through HIP IPC; ud_xchg_allreduce is ONE
+ * single-workgroup kernel that writes the rank's doubles into every mailbox (peer writes over xGMI), raises a flag,
+ * waits for all ranks' flags and sums the rows in rank order (bit-identical on all ranks).  The sequence number is a
+ * device word advanced by the kernel (hipGraph replays keep counting); a peer that does not arrive within spin_limit
+ * polls sets *err (1 + its rank) instead of hanging.  Setup: ud_xchg_create on every rank, handles exchanged by the
+ * host (64 bytes each), ud_xchg_open on every peer's handle, the `world` pointers (own base at [rank]) copied to a
+ * device array.  max_doubles bounds n; slots >= 2 (a rank is never more than one exchange ahead of the slowest). */
+long ud_xchg_bytes(int world, int max_doubles, int slots);
+int ud_xchg_create(int world, int max_doubles, int slots, void** base, char* handle);
+int ud_xchg_open(const char* handle, void** ptr);
+int ud_xchg_close(void* ptr);
+int ud_xchg_destroy(void* base);
+int ud_xchg_allreduce(double* acc, int n, void* const* peers, int rank, int world, int max_doubles, int slots,
+                      unsigned long long* seq_counter, int* err, long spin_limit, ud_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -64,8 +64,8 @@ def _shards():
     return x, idx
 
 
-def _worker(rank, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, port, q, exchange=True):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UD_SYNCBN_EXCHANGE="1" if exchange else "0")
     try:
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
@@ -84,7 +84,10 @@ def _worker(rank, port, q):
             _loss(out, tgt).backward()
             res = ({k: _digest(p.grad) for k, p in m.named_parameters() if p.grad is not None},
                    out["cls_out"].detach().cpu().numpy(), out["rec"].detach().cpu().numpy())
-        q.put((rank, idx[rank], res, None))
+        xok = dp.bn_exchange.ok
+        if xok:
+            dp.bn_exchange.check()
+        q.put((rank, idx[rank], res + (xok,), None))
     except Exception as e:                      # noqa: BLE001
         import traceback
         q.put((rank, None, None, traceback.format_exc()))
@@ -93,13 +96,16 @@ def _worker(rank, port, q):
             dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_full_batch():
+@pytest.mark.parametrize("exchange", [True, False], ids=["peer-exchange", "all_reduce"])
+def test_two_ranks_equal_one_process_full_batch(exchange):
+    """exchange: the SyncBN sums of the fused path travel through BnExchange's peer-mapped mailboxes (csrc/xchg.hip: HIP IPC
+    between the two processes, one kernel per sum) — it must have passed its self-test and been used; False: dist.all_reduce."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=900) for _ in range(2)]
@@ -108,6 +114,7 @@ def test_two_ranks_equal_one_process_full_batch():
     for rank, _, _, err in got:
         assert err is None, f"rank {rank}:\n{err}"
     got.sort(key=lambda t: t[0])
+    assert [g[2][3] for g in got] == [exchange, exchange], "BnExchange state"
     # single process, whole batch, plain BatchNorm
     dev = torch.device("cuda:0")
     m = _build(dev)
@@ -117,7 +124,7 @@ def test_two_ranks_equal_one_process_full_batch():
     _loss(out, tgt).backward()
     ref_g = {k: _digest(p.grad) for k, p in m.named_parameters() if p.grad is not None}
     # forward: every sample's outputs agree (SyncBN == full-batch BN)
-    for rank, ids, (g, cls, rec), _ in got:
+    for rank, ids, (g, cls, rec, _xok), _ in got:
         e1 = abs(cls - out["cls_out"].detach().cpu().numpy()[ids]).max() / out["cls_out"].abs().max().item()
         e2 = abs(rec - out["rec"].detach().cpu().numpy()[ids]).max() / out["rec"].abs().max().item()
         print(f"  rank {rank}: cls_out {e1:.2e}  rec {e2:.2e}")
@@ -135,3 +142,66 @@ def test_two_ranks_equal_one_process_full_batch():
     print(f"  {len(ref_g)} gradients: 2 ranks vs full batch: worst entry {worst[0]:.2e} ({worst[1]}), worst norm "
           f"{worst_norm[0]:.2e} ({worst_norm[1]}); rank 0 vs rank 1 {worst_rr:.2e}")
     assert worst_rr <= 1e-6 and worst[0] <= 2e-3 and worst_norm[0] <= 2e-3
+
+
+def _xchg_worker(rank, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=rank, world_size=2)
+        from unidefense_amd.engine.parallel import BnExchange
+        ex = BnExchange(dist.group.WORLD, dev)
+        assert ex.ok, "self-test failed"
+        g = torch.Generator().manual_seed(7)
+        vecs = [torch.randn(2, n, generator=g, dtype=torch.float64) for n in (8, 96, 1632 * 2, 3264 * 2, 5, 8192)]
+        worst = 0.0
+        for rep in range(3):
+            for v in vecs:
+                a = (v[rank] * (rep + 1)).to(dev)
+                ex.allreduce(a)
+                want = (v[0] * (rep + 1) + v[1] * (rep + 1)).to(dev)          # rank order 0 + 1: exactly this fp64 sum
+                worst = max(worst, float((a - want).abs().max()))
+        # a captured sequence replays with the device-side sequence counter still advancing
+        a = torch.zeros(4096, dtype=torch.float64, device=dev)
+        src = torch.full((4096,), float(rank + 1), dtype=torch.float64, device=dev)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                a.copy_(src)
+                ex.allreduce(a)
+                a.mul_(0.5)
+                ex.allreduce(a)
+        for _ in range(5):
+            gr.replay()
+        torch.cuda.synchronize()
+        ex.check()
+        replay_ok = bool((a == 3.0).all())              # (1 + 2) -> 1.5 on both -> 3.0
+        ex.close()
+        q.put((rank, worst, replay_ok, None))
+    except Exception:                      # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_bn_exchange_two_processes():
+    """BnExchange alone: two processes on the one GPU, mailboxes mapped into each other through HIP IPC; sums of several
+    lengths are exact (rank-ordered fp64 adds), eager and from a replayed hipGraph."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xchg_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+    for rank, worst, replay_ok, err in got:
+        assert err is None, f"rank {rank}:\n{err}"
+        assert worst == 0.0 and replay_ok, (rank, worst, replay_ok)

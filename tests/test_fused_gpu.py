@@ -348,3 +348,143 @@ def test_gemm_epilogue_statistics(M, N, Kd):
     assert _rel(y, a.double() @ w.double().t()) < 2e-5
     assert _rel(acc[:N], yd.sum(0)) < 1e-9 and _rel(acc[N:], (yd * yd).sum(0)) < 1e-9
     print(f"  {M}x{N}x{Kd}: epilogue statistics {'used' if done else 'not applicable (split plan)'}")
+
+
+# ------------------------------------------------------------------------------------------------ half storage
+def _bn_for(Cc, acc, count, act, dev, seed=0):
+    from unidefense_amd import kernels as K
+    g = torch.Generator().manual_seed(seed)
+    gamma = (0.5 + torch.rand(Cc, generator=g)).to(dev)
+    beta = (0.2 * torch.randn(Cc, generator=g)).to(dev)
+    return K.DeferredBN(acc, Cc, count, gamma, beta, 1e-3, act)
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 16, 96), (2, 32, 32, 48), (3, 8, 8, 272)])
+def test_half_storage_kernels_match_fp32_on_rounded_inputs(shape):
+    """Every kernel of the fused MBConv path instantiated for _Float16 storage against its fp32 instantiation fed the
+    SAME (fp16-representable) inputs: the arithmetic is identical (fp32 registers), so results agree to one rounding of the
+    stored value (2^-11 relative) and the fp64 statistics to ~1e-3 of their scale (they are taken of the rounded values)."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    N, H, W, Cc = shape
+    M, HW = N * H * W, H * W
+    g = torch.Generator().manual_seed(Cc + H)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g).half().to(dev)          # fp16-representable values
+    x16, dy16 = rnd(N, H, W, Cc), rnd(N, H, W, Cc)
+    x32, dy32 = x16.float(), dy16.float()
+
+    def close(a, b, tol=2e-3, what=""):
+        e = _rel(a.double(), b.double())
+        assert e < tol, (what, e)
+
+    # statistics
+    a16, a32 = K.zeros64(2 * Cc, x16), K.zeros64(2 * Cc, x16)
+    K.colstats(x16.view(M, Cc), a16)
+    K.colstats(x32.view(M, Cc), a32)
+    close(a16, a32, 1e-12, "colstats")
+    bn16, bn32 = _bn_for(Cc, a16, M, 1, dev), _bn_for(Cc, a32, M, 1, dev)
+    # elementwise consumers
+    close(K.bn_apply(x16, bn16, 1, M), K.bn_apply(x32, bn32, 1, M), what="bn_apply")
+    s = torch.randn(N, Cc, generator=g).to(dev)
+    close(K.se_scale_bn(x16, bn16, s, N, HW), K.se_scale_bn(x32, bn32, s, N, HW), what="se_scale_bn")
+    keep = (torch.rand(N, generator=g) < 0.8).float().to(dev)
+    close(K.residual_bn(x16, bn16, keep, 1.25, dy16, N, HW), K.residual_bn(x32, bn32, keep, 1.25, dy32, N, HW),
+          what="residual_bn")
+    # reductions behind a deferred BatchNorm
+    p16, p32 = K.zeros64(N * Cc, x16), K.zeros64(N * Cc, x16)
+    K.colsum_bn(x16, bn16, N, HW, p16)
+    K.colsum_bn(x32, bn32, N, HW, p32)
+    close(p16, p32, 1e-9, "colsum_bn")
+    d16, d32 = K.zeros64(N * Cc, x16), K.zeros64(N * Cc, x16)
+    K.coldot_bn(dy16, x16, bn16, N, HW, d16)
+    K.coldot_bn(dy32, x32, bn32, N, HW, d32)
+    close(d16, d32, 1e-9, "coldot_bn")
+    # BatchNorm backward
+    sb16, sb32 = K.zeros64(2 * Cc, x16), K.zeros64(2 * Cc, x16)
+    K.normbwd_sums(x16, dy16, keep, 1.25, bn16, False, N, HW, sb16)
+    K.normbwd_sums(x32, dy32, keep, 1.25, bn32, False, N, HW, sb32)
+    close(sb16, sb32, 1e-9, "normbwd_sums")
+    r16 = K.normbwd_apply(x16, dy16, keep, 1.25, bn16, False, N, HW, sb16)
+    r32 = K.normbwd_apply(x32, dy32, keep, 1.25, bn32, False, N, HW, sb32)
+    close(r16[0], r32[0], what="normbwd_apply dx")
+    close(r16[1], r32[1], 1e-6, "dgamma")
+    dpool = (0.1 * torch.randn(N, Cc, generator=g)).to(dev)
+    z16, z32 = K.zeros64(2 * Cc, x16), K.zeros64(2 * Cc, x16)
+    dz16 = K.se_scale_bwd_bn(dy16, x16, bn16, s, dpool, 1.0 / HW, N, HW, z16)
+    dz32 = K.se_scale_bwd_bn(dy32, x32, bn32, s, dpool, 1.0 / HW, N, HW, z32)
+    close(dz16, dz32, what="se_scale_bwd_bn dz")
+    close(z16, z32, 3e-3, "se_scale_bwd_bn sums")          # sums of the ROUNDED gradient vs of the unrounded one
+    # depthwise conv, forward / data gradient (+ BatchNorm sums) / weight gradient
+    for k in (3, 5):
+        wt = (torch.randn(k * k, Cc, generator=g) / k).to(dev)
+        pad = (k - 1) // 2
+        y16, y32 = K.dwconv_fwd(x16, wt, k, 1, pad, pad, H, W), K.dwconv_fwd(x32, wt, k, 1, pad, pad, H, W)
+        close(y16, y32, what=f"dwconv_fwd k{k}")
+        q16, q32 = K.zeros64(2 * Cc, x16), K.zeros64(2 * Cc, x16)
+        alpha = torch.tensor([0.3], device=dev)
+        e16 = K.dwconv_bwd_data_bn(dy16, alpha, 2, wt, x16, x16, bn16, k, 1, pad, pad, q16)
+        e32 = K.dwconv_bwd_data_bn(dy32, alpha, 2, wt, x32, x32, bn32, k, 1, pad, pad, q32)
+        close(e16, e32, what=f"dwconv_bwd_data_bn k{k}")
+        close(q16, q32, 3e-3, "its sums")
+        close(K.dwconv_bwd_data_ex(dy16, alpha, 1, wt, None, k, 1, pad, pad, H, W),
+              K.dwconv_bwd_data_ex(dy32, alpha, 1, wt, None, k, 1, pad, pad, H, W), what="dwconv_bwd_data_ex")
+        close(K.dwconv_bwd_weight_ex(x16, dy16, alpha, 1, k, 1, pad, pad),
+              K.dwconv_bwd_weight_ex(x32, dy32, alpha, 1, k, 1, pad, pad), 1e-5, "dwconv_bwd_weight_ex")
+        close(K.dwconv_bwd_data(dy16[:, ::2, ::2].contiguous(), wt, k, 2, pad, pad, H, W, add=x16),
+              K.dwconv_bwd_data(dy32[:, ::2, ::2].contiguous(), wt, k, 2, pad, pad, H, W, add=x32), what="dwconv_bwd_data s2")
+    # FFTs (power-of-two maps)
+    if H in (8, 16, 32, 64):
+        Y16, act16 = K.rfft2_ex(x16, 1.0 / H, 1.0, bn=bn16, want_act=True)
+        Y32, act32 = K.rfft2_ex(x32, 1.0 / H, 1.0, bn=bn32, want_act=True)
+        close(act16, act32, what="rfft2_ex act")
+        close(Y16, Y32, 3e-3, "rfft2_ex Y")                 # transform of the rounded activation vs of the unrounded one
+        Yr = Y16.float()
+        alpha = torch.tensor([0.3], device=dev)
+        m16, m32 = K.zeros64(2 * Cc, x16), K.zeros64(2 * Cc, x16)
+        o16 = K.irfft2_mix(Y16, 1.0 / H, x16, alpha, m16)
+        o32 = K.irfft2_mix(Yr, 1.0 / H, x32, alpha, m32)
+        close(o16[0], o32[0], what="irfft2_mix y")
+        close(o16[1], o32[1], what="irfft2_mix freq")
+        close(m16, m32, 3e-3, "irfft2_mix sums")
+        close(K.irfft2(Y16, 1.0 / H, 0.5), K.irfft2(Yr, 1.0 / H, 0.5), what="irfft2")
+        close(K.rfft2(x16, 1.0 / H, 2.0), K.rfft2(x32, 1.0 / H, 2.0), what="rfft2")
+        sp16 = K.sfmix_fwd(x16, dy16, alpha, False)
+        close(sp16, K.sfmix_fwd(x32, dy32, alpha, False), what="sfmix_fwd")
+        b16, b32 = K.sfmix_bwd(x16, dy16, alpha, x16, False), K.sfmix_bwd(x32, dy32, alpha, x32, False)
+        close(b16[0], b32[0], what="sfmix_bwd dspat")
+        close(b16[2], b32[2], 1e-5, "sfmix_bwd dalpha")
+    close(K.axpby(x16, 0.5, dy16, 2.0), K.axpby(x32, 0.5, dy32, 2.0), what="axpby")
+
+
+@pytest.mark.parametrize("M,N,Kd", [(2048, 1632, 272), (8192, 160, 960), (131072, 192, 32), (300, 48, 24), (2048, 272, 1632)])
+def test_half_operand_gemms(M, N, Kd):
+    """ud_gemm with half_mask: the three products of a 1x1 conv on half-stored activations (forward: A half, C half + the
+    epilogue statistics; data gradient: A half, C half, plain and accumulating; weight gradient: A and B half, C fp32)
+    against float64 on the same fp16-representable operands (fp16 MFMA products are exact, fp32 accumulation)."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(M % 977 + N)
+    a = torch.randn(M, Kd, generator=g).half().to(dev)
+    w = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).half().float().to(dev)       # fp32 weights holding fp16-exact values
+    ref = a.double() @ w.double().t()
+    acc = K.zeros64(2 * N, a)
+    y, done = K.gemm_nt(a, w, stats=acc)
+    assert y.dtype == torch.float16 and done
+    assert _rel(y.double(), ref) < 1e-3                      # one fp16 rounding of the result
+    yd = y.double()
+    assert _rel(acc[:N], yd.sum(0)) < 1e-9 and _rel(acc[N:], (yd * yd).sum(0)) < 1e-9
+    # data gradient dY @ W, plain and accumulating onto an existing gradient
+    dy = torch.randn(M, N, generator=g).half().to(dev)
+    refd = dy.double() @ w.double()
+    dx = K.gemm_nn(dy, w)
+    assert dx.dtype == torch.float16 and _rel(dx.double(), refd) < 1e-3
+    base = torch.randn(M, Kd, generator=g).half().to(dev)
+    dx2 = K.gemm_nn(dy, w, out=base.clone(), accumulate=True)
+    assert _rel(dx2.double(), refd + base.double()) < 1e-3
+    # weight gradient dY^T @ A: fp32 result
+    dw = K.gemm_tn(dy, a)
+    assert dw.dtype == torch.float32 and _rel(dw.double(), dy.double().t() @ a.double()) < 2e-6

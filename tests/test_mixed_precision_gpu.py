@@ -17,7 +17,7 @@ from tests import oracle_util as ou
 pytestmark = pytest.mark.gpu
 
 
-def _step(dev, path, n=16):
+def _step(dev, path, n=16, half_storage=False):
     from unidefense_amd import lib
     from unidefense_amd.loss import LOSSES
     from unidefense_amd.model import load_model
@@ -26,6 +26,7 @@ def _step(dev, path, n=16):
         m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5)
         param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
         m = m.to(dev).train()
+        m.half_storage = half_storage
         x = param_fill.make_input(n, 256, 21).to(dev)
         tgt = param_fill.make_labels(n).to(dev)
         rng = ou.make_rng(n, 5, 0.5)
@@ -47,12 +48,17 @@ def _step(dev, path, n=16):
         lib.call("ud_gemm_set_path", 0)
 
 
-def test_fp16_operand_gemms_track_the_fp32_step():
+@pytest.mark.parametrize("storage", ["fp32", "half"])
+def test_fp16_operand_gemms_track_the_fp32_step(storage):
+    """storage = "half": additionally the MBConv trunk keeps its activations and activation gradients in fp16
+    (model.half_storage; every kernel of tape.mbconv_fused instantiated for _Float16, half-operand GEMM loaders) — the
+    full configs[4] mode.  Each stored tensor adds one rounding of 2^-11 relative, the same size as the operand rounding
+    the fp32-storage mode already makes at every GEMM input: same bars."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     dev = torch.device("cuda:0")
     o32, g32 = _step(dev, 0)
-    o16, g16 = _step(dev, 3)
+    o16, g16 = _step(dev, 3, half_storage=storage == "half")
     errs = {k: float((o16[k] - o32[k]).abs().max() / o32[k].abs().max().clamp_min(1e-30)) for k in o32}
     rms = {k: float((o16[k] - o32[k]).norm() / o32[k].norm().clamp_min(1e-30)) for k in o32}
     print("  max-abs deviation / max:", {k: f"{v:.2e}" for k, v in errs.items()})

@@ -7,7 +7,7 @@ mkdir -p $out
 export PYTHONDONTWRITEBYTECODE=1
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $out/bench.log 2>&1
 echo "rocprof exit $?"; tail -2 $out/bench.log | cut -c1-400
 f=$(find $out/prof -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && mv "$f" $out/kernel_trace.csv && gzip -f $out/kernel_trace.csv

@@ -19,12 +19,12 @@ struct DwGeom {
     int N, H, W, C4, Ho, Wo, stride, pad_t, pad_l;
 };
 
-template <int K>
-__global__ __launch_bounds__(NT) void dw_fwd(DwGeom q, const float* __restrict__ x, const float* __restrict__ wt,
-                                             float* __restrict__ y) {
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+template <typename T, int K>
+__global__ __launch_bounds__(NT) void dw_fwd(DwGeom q, const T* __restrict__ x, const float* __restrict__ wt,
+                                             T* __restrict__ y) {
+    const In4<T> x4{x};
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
-    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const Out4<T> y4{y};
     const long total = (long)q.N * q.Ho * q.Wo * q.C4;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
         int c4 = (int)(e % q.C4);
@@ -48,16 +48,16 @@ __global__ __launch_bounds__(NT) void dw_fwd(DwGeom q, const float* __restrict__
                 acc += a * w;
             }
         }
-        y4[e] = acc;
+        y4.st(e, acc);
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const float* __restrict__ dy, const float* __restrict__ wt,
-                                                  const float* __restrict__ add, float* __restrict__ dx) {
-    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+template <typename T, int K>
+__global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const T* __restrict__ dy, const float* __restrict__ wt,
+                                                  const T* __restrict__ add, T* __restrict__ dx) {
+    const In4<T> dy4{dy}, add4{add};
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
-    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    const Out4<T> dx4{dx};
     const long total = (long)q.N * q.H * q.W * q.C4;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
         int c4 = (int)(e % q.C4);
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const float* __restr
                 acc += g * ww;
             }
         }
-        if (add) acc += reinterpret_cast<const f32x4*>(add)[e];
-        dx4[e] = acc;
+        if (add) acc += add4[e];
+        dx4.st(e, acc);
     }
 }
 
@@ -95,13 +95,13 @@ __global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const float* __restr
 // kernels above issue K*K (9 / 25) 16-byte loads per output and sit at ~30 % of their HBM roofline (L1-bound).
 constexpr int TW = 8;
 
-template <int K, int S>
-__global__ __launch_bounds__(NT) void dw_fwd_strip(DwGeom q, const float* __restrict__ x, const float* __restrict__ wt,
-                                                   float* __restrict__ y) {
+template <typename T, int K, int S>
+__global__ __launch_bounds__(NT) void dw_fwd_strip(DwGeom q, const T* __restrict__ x, const float* __restrict__ wt,
+                                                   T* __restrict__ y) {
     constexpr int NCOL = (TW - 1) * S + K;
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const In4<T> x4{x};
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
-    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const Out4<T> y4{y};
     const int WoB = (q.Wo + TW - 1) / TW;
     const long total = (long)q.N * q.Ho * WoB * q.C4;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_strip(DwGeom q, const float* __rest
         for (int kh = 0; kh < K; ++kh) {
             const int ih = ih0 + kh;
             if (ih < 0 || ih >= q.H) continue;
-            const f32x4* row = x4 + (((long)n * q.H + ih) * q.W) * q.C4 + c4;
+            const In4<T> row = x4 + ((((long)n * q.H + ih) * q.W) * q.C4 + c4);
             f32x4 in[NCOL], w[K];
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) {
@@ -134,22 +134,22 @@ __global__ __launch_bounds__(NT) void dw_fwd_strip(DwGeom q, const float* __rest
 #pragma unroll
                 for (int kw = 0; kw < K; ++kw) acc[t] += in[t * S + kw] * w[kw];
         }
-        f32x4* out = y4 + (((long)n * q.Ho + ho) * q.Wo + wo0) * q.C4 + c4;
+        const Out4<T> out = y4 + ((((long)n * q.Ho + ho) * q.Wo + wo0) * q.C4 + c4);
 #pragma unroll
         for (int t = 0; t < TW; ++t)
-            if (wo0 + t < q.Wo) out[(long)t * q.C4] = acc[t];
+            if (wo0 + t < q.Wo) out.st((long)t * q.C4, acc[t]);
     }
 }
 
 // data gradient, stride 1: dx[h][w] = sum dy[h + pad_t - kh][w + pad_l - kw] * w[kh][kw]
-template <int K>
-__global__ __launch_bounds__(NT) void dw_bwd_data_strip(DwGeom q, const float* __restrict__ dy,
-                                                        const float* __restrict__ wt, const float* __restrict__ add,
-                                                        float* __restrict__ dx) {
+template <typename T, int K>
+__global__ __launch_bounds__(NT) void dw_bwd_data_strip(DwGeom q, const T* __restrict__ dy,
+                                                        const float* __restrict__ wt, const T* __restrict__ add,
+                                                        T* __restrict__ dx) {
     constexpr int NCOL = TW + K - 1;
-    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const In4<T> dy4{dy};
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
-    f32x4* dx4 = reinterpret_cast<f32x4*>(dx);
+    const Out4<T> dx4{dx};
     const int WB = (q.W + TW - 1) / TW;
     const long total = (long)q.N * q.H * WB * q.C4;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_data_strip(DwGeom q, const float* _
         for (int kh = 0; kh < K; ++kh) {
             const int ho = h + q.pad_t - kh;
             if (ho < 0 || ho >= q.Ho) continue;
-            const f32x4* row = dy4 + (((long)n * q.Ho + ho) * q.Wo) * q.C4 + c4;
+            const In4<T> row = dy4 + ((((long)n * q.Ho + ho) * q.Wo) * q.C4 + c4);
             f32x4 g[NCOL], w[K];
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) {
@@ -183,11 +183,11 @@ __global__ __launch_bounds__(NT) void dw_bwd_data_strip(DwGeom q, const float* _
                 for (int kw = 0; kw < K; ++kw) acc[t] += g[t - kw + K - 1] * w[kw];
         }
         const long o0 = (((long)n * q.H + h) * q.W + w0) * q.C4 + c4;
-        f32x4* out = dx4 + o0;
-        const f32x4* add4 = reinterpret_cast<const f32x4*>(add) + o0;
+        const Out4<T> out = dx4 + o0;
+        const In4<T> add4 = In4<T>{add} + o0;
 #pragma unroll
         for (int t = 0; t < TW; ++t)
-            if (w0 + t < q.W) out[(long)t * q.C4] = add ? acc[t] + add4[(long)t * q.C4] : acc[t];
+            if (w0 + t < q.W) out.st((long)t * q.C4, add ? acc[t] + add4[(long)t * q.C4] : acc[t]);
     }
 }
 
@@ -337,8 +337,8 @@ bool geom_ok(const DwGeom& q, int K) {
 
 extern "C" {
 
-int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W, int C, int Ho, int Wo, int K,
-                  int stride, int pad_t, int pad_l, ud_stream_t stream) {
+int ud_dwconv_fwd(const void* xv, const float* wt, void* yv, int N, int H, int W, int C, int Ho, int Wo, int K,
+                  int stride, int pad_t, int pad_l, int f16, ud_stream_t stream) {
     if (C % 4) return UD_EINVAL;
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!geom_ok(q, K)) return UD_EINVAL;
@@ -346,22 +346,25 @@ int ud_dwconv_fwd(const float* x, const float* wt, float* y, int N, int H, int W
     hipStream_t s = (hipStream_t)stream;
     if (plain) {
         long total = (long)N * Ho * Wo * q.C4;
-        if (K == 3) hipLaunchKernelGGL(dw_fwd<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, x, wt, y);
-        else hipLaunchKernelGGL(dw_fwd<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, x, wt, y);
+        dim3 g(ew_blocks(total));
+        UD_STORAGE_DISPATCH(f16, const T* x = (const T*)xv; T* y = (T*)yv;
+                            if (K == 3) hipLaunchKernelGGL((dw_fwd<T, 3>), g, dim3(NT), 0, s, q, x, wt, y);
+                            else hipLaunchKernelGGL((dw_fwd<T, 5>), g, dim3(NT), 0, s, q, x, wt, y));
     } else {
         long total = (long)N * Ho * ((Wo + TW - 1) / TW) * q.C4;
         dim3 g(ew_blocks(total));
-        if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_fwd_strip<3, 1>), g, dim3(NT), 0, s, q, x, wt, y);
-        else if (K == 3) hipLaunchKernelGGL((dw_fwd_strip<3, 2>), g, dim3(NT), 0, s, q, x, wt, y);
-        else if (stride == 1) hipLaunchKernelGGL((dw_fwd_strip<5, 1>), g, dim3(NT), 0, s, q, x, wt, y);
-        else hipLaunchKernelGGL((dw_fwd_strip<5, 2>), g, dim3(NT), 0, s, q, x, wt, y);
+        UD_STORAGE_DISPATCH(f16, const T* x = (const T*)xv; T* y = (T*)yv;
+                            if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_fwd_strip<T, 3, 1>), g, dim3(NT), 0, s, q, x, wt, y);
+                            else if (K == 3) hipLaunchKernelGGL((dw_fwd_strip<T, 3, 2>), g, dim3(NT), 0, s, q, x, wt, y);
+                            else if (stride == 1) hipLaunchKernelGGL((dw_fwd_strip<T, 5, 1>), g, dim3(NT), 0, s, q, x, wt, y);
+                            else hipLaunchKernelGGL((dw_fwd_strip<T, 5, 2>), g, dim3(NT), 0, s, q, x, wt, y));
     }
     UD_LAUNCH_CHECK();
     return 0;
 }
 
-int ud_dwconv_bwd_data(const float* dy, const float* wt, const float* add, float* dx, int N, int H, int W, int C, int Ho,
-                       int Wo, int K, int stride, int pad_t, int pad_l, ud_stream_t stream) {
+int ud_dwconv_bwd_data(const void* dyv, const float* wt, const void* addv, void* dxv, int N, int H, int W, int C, int Ho,
+                       int Wo, int K, int stride, int pad_t, int pad_l, int f16, ud_stream_t stream) {
     if (C % 4) return UD_EINVAL;
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!geom_ok(q, K)) return UD_EINVAL;
@@ -369,12 +372,16 @@ int ud_dwconv_bwd_data(const float* dy, const float* wt, const float* add, float
     hipStream_t s = (hipStream_t)stream;
     if (stride == 1 && !plain) {
         long total = (long)N * H * ((W + TW - 1) / TW) * q.C4;
-        if (K == 3) hipLaunchKernelGGL(dw_bwd_data_strip<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, add, dx);
-        else hipLaunchKernelGGL(dw_bwd_data_strip<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, add, dx);
+        dim3 g(ew_blocks(total));
+        UD_STORAGE_DISPATCH(f16, const T* dy = (const T*)dyv; const T* add = (const T*)addv; T* dx = (T*)dxv;
+                            if (K == 3) hipLaunchKernelGGL((dw_bwd_data_strip<T, 3>), g, dim3(NT), 0, s, q, dy, wt, add, dx);
+                            else hipLaunchKernelGGL((dw_bwd_data_strip<T, 5>), g, dim3(NT), 0, s, q, dy, wt, add, dx));
     } else {       // stride 2 (4 of the 32 blocks): one output per thread
         long total = (long)N * H * W * q.C4;
-        if (K == 3) hipLaunchKernelGGL(dw_bwd_data<3>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, add, dx);
-        else hipLaunchKernelGGL(dw_bwd_data<5>, dim3(ew_blocks(total)), dim3(NT), 0, s, q, dy, wt, add, dx);
+        dim3 g(ew_blocks(total));
+        UD_STORAGE_DISPATCH(f16, const T* dy = (const T*)dyv; const T* add = (const T*)addv; T* dx = (T*)dxv;
+                            if (K == 3) hipLaunchKernelGGL((dw_bwd_data<T, 3>), g, dim3(NT), 0, s, q, dy, wt, add, dx);
+                            else hipLaunchKernelGGL((dw_bwd_data<T, 5>), g, dim3(NT), 0, s, q, dy, wt, add, dx));
     }
     UD_LAUNCH_CHECK();
     return 0;

@@ -18,6 +18,8 @@
 // one read of the input and one write of the output.
 #include "ud_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int NT = 512;
@@ -177,10 +179,10 @@ struct Lds {
 // f(kx) = scale for kx in {0, S/2}, scale * w_int otherwise.
 // EX: the input is act(bn(x)) of a deferred BatchNorm (coefficients from the fp64 sums, one channel per thread),
 // optionally also written out (act_out), and the result carries the gate factor (include/unidefense_hip.h).
-template <int S, int CB, bool EX>
-__global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, float* __restrict__ Y, int C,
+template <typename T, int S, int CB, bool EX>
+__global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* __restrict__ Y, int C,
                                                    float scale, float w_int, ud_bn_ref bn, int has_bn,
-                                                   float* __restrict__ act_out, const float* __restrict__ gate_alpha,
+                                                   T* __restrict__ act_out, const float* __restrict__ gate_alpha,
                                                    int gate_mode, const double* __restrict__ gate_acc,
                                                    float* __restrict__ gate_grad) {
     using L = Lds<S, CB>;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, 
     float re[S], im[S];
     // ---- pass 1: rows   (S * CB may be < 512 for the 5*2^k sizes: q >= S idles)
     if (q < S) {
-        const float* src = x + (((long)n * S + q) * S) * C + ch;
+        const T* src = x + (((long)n * S + q) * S) * C + ch;
         float mu = 0.f, is = 1.f, ga = 1.f, be = 0.f;
         if (EX && has_bn && cok) {
             const double m = bn.sum[ch] * bn.inv_count;
@@ -219,13 +221,13 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, 
                 bn.running_var[ch] = (1.f - bn.momentum) * bn.running_var[ch] + bn.momentum * (float)(vv * bn.unbias);
             }
         }
-        float* aout = (EX && act_out) ? act_out + (((long)n * S + q) * S) * C + ch : nullptr;
+        T* aout = (EX && act_out) ? act_out + (((long)n * S + q) * S) * C + ch : nullptr;
 #pragma unroll
         for (int w = 0; w < S; ++w) {
-            float v = cok ? src[(long)w * C] : 0.f;
+            float v = cok ? (float)src[(long)w * C] : 0.f;
             if (EX && has_bn) {
-                v = ud_act(ga * ((v - mu) * is) + be, bn.act);
-                if (aout && cok) aout[(long)w * C] = v;
+                v = ud_rounded<T>(ud_act(ga * ((v - mu) * is) + be, bn.act));     // transform what the other branch reads
+                if (aout && cok) aout[(long)w * C] = (T)v;
             }
             re[brev<S>(w)] = v;
             im[brev<S>(w)] = 0.f;
@@ -251,11 +253,11 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, 
             const float a = ud_sigmoid(gate_alpha[0]);
             f *= (gate_mode == 1) ? a : 1.f - a;
         }
-        float* dst = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
+        T* dst = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
 #pragma unroll
         for (int ky = 0; ky < S; ++ky) {
-            dst[(long)ky * L::WH * 2 * C] = re[ky] * f;
-            dst[(long)ky * L::WH * 2 * C + C] = im[ky] * f;
+            dst[(long)ky * L::WH * 2 * C] = (T)(re[ky] * f);
+            dst[(long)ky * L::WH * 2 * C + C] = (T)(im[ky] * f);
         }
     }
 }
@@ -263,10 +265,10 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const float* __restrict__ x, 
 // x[n][h][w][c] = scale * C2R( f(kx) * Y[n][ky][kx][c] )   with the Hermitian extension along kx
 // MIX: freq_out = irfft2(Y) * scale;  x = (1 - a) spat + a freq_out, a = sigmoid(alpha[0]);  per-channel sums of x and
 // x^2 folded over the workgroup's rows through LDS and added (fp64 atomics) to sum / sumsq  (exp.py:60-65 + BN1 stats)
-template <int S, int CB, bool MIX>
-__global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y, float* __restrict__ x, int C,
-                                                    float scale, float w_int, const float* __restrict__ spat,
-                                                    const float* __restrict__ alpha, float* __restrict__ freq_out,
+template <typename T, int S, int CB, bool MIX>
+__global__ __launch_bounds__(NT) void irfft2_kernel(const T* __restrict__ Y, T* __restrict__ x, int C,
+                                                    float scale, float w_int, const T* __restrict__ spat,
+                                                    const float* __restrict__ alpha, T* __restrict__ freq_out,
                                                     double* __restrict__ sum, double* __restrict__ sumsq) {
     using L = Lds<S, CB>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -285,18 +287,18 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y,
     constexpr int NHELP = S - (S / 2 + 1);               // columns [0, NHELP) have a helper row
     if (q > S / 2 && q < S) {
         const int kx = q - (S / 2 + 1);
-        const float* src = Y + (((long)n * S) * L::WH + kx) * (2L * C) + ch + C;
+        const T* src = Y + (((long)n * S) * L::WH + kx) * (2L * C) + ch + C;
 #pragma unroll
-        for (int ky = 0; ky < S; ++ky) re[ky] = cok ? src[(long)ky * L::WH * 2 * C] : 0.f;
+        for (int ky = 0; ky < S; ++ky) re[ky] = cok ? (float)src[(long)ky * L::WH * 2 * C] : 0.f;
 #pragma unroll
         for (int ky = 0; ky < S; ++ky) Lim[kx * L::KSTRIDE + ky * CB + c] = re[ky];
     } else if (q <= S / 2) {
-        const float* src = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
+        const T* src = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
 #pragma unroll
-        for (int ky = 0; ky < S; ++ky) re[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C] : 0.f;
+        for (int ky = 0; ky < S; ++ky) re[brev<S>(ky)] = cok ? (float)src[(long)ky * L::WH * 2 * C] : 0.f;
         if (q >= NHELP) {
 #pragma unroll
-            for (int ky = 0; ky < S; ++ky) im[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C + C] : 0.f;
+            for (int ky = 0; ky < S; ++ky) im[brev<S>(ky)] = cok ? (float)src[(long)ky * L::WH * 2 * C + C] : 0.f;
         }
     }
     __syncthreads();
@@ -335,20 +337,20 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y,
         }
         fft_inreg<S, true>(re, im);
         const long o0 = (((long)n * S + q) * S) * C + ch;
-        float* dst = x + o0;
+        T* dst = x + o0;
         if (!MIX) {
 #pragma unroll
-            for (int w = 0; w < S; ++w) dst[(long)w * C] = re[w] * scale;
+            for (int w = 0; w < S; ++w) dst[(long)w * C] = (T)(re[w] * scale);
         } else {
             const float a = ud_sigmoid(alpha[0]);
-            const float* sp = spat + o0;
-            float* fo = freq_out + o0;
+            const T* sp = spat + o0;
+            T* fo = freq_out + o0;
 #pragma unroll
             for (int w = 0; w < S; ++w) {
                 const float fr = re[w] * scale;
-                const float y = sp[(long)w * C] * (1.f - a) + fr * a;
-                fo[(long)w * C] = fr;
-                dst[(long)w * C] = y;
+                const float y = ud_rounded<T>((float)sp[(long)w * C] * (1.f - a) + fr * a);
+                fo[(long)w * C] = (T)fr;
+                dst[(long)w * C] = (T)y;
                 tot1 += (double)y;
                 tot2 += (double)y * (double)y;
             }
@@ -378,131 +380,150 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const float* __restrict__ Y,
 
 struct RfftEx {
     const ud_bn_ref* bn;
-    float* act_out;
+    void* act_out;
     const float* gate_alpha;
     int gate_mode;
     const double* gate_acc;
     float* gate_grad;
 };
 
-template <int S, int CB, bool EX>
-int launch_rfft2_t(const float* x, float* Y, int N, int C, float scale, float w_int, const RfftEx& ex, hipStream_t s) {
+template <typename T, int S, int CB, bool EX>
+int launch_rfft2_t(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx& ex, hipStream_t s) {
     using L = Lds<S, CB>;
     static bool attr_set = false;
     if (L::BYTES > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfft2_kernel<S, CB, EX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfft2_kernel<T, S, CB, EX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
     ud_bn_ref none{};
-    hipLaunchKernelGGL((rfft2_kernel<S, CB, EX>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
-                       ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, ex.act_out, ex.gate_alpha, ex.gate_mode, ex.gate_acc,
+    hipLaunchKernelGGL((rfft2_kernel<T, S, CB, EX>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
+                       ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, (T*)ex.act_out, ex.gate_alpha, ex.gate_mode, ex.gate_acc,
                        ex.gate_grad);
     UD_LAUNCH_CHECK();
     return 0;
 }
 
-template <int S, int CB>
-int launch_rfft2(const float* x, float* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
-    if (ex) return launch_rfft2_t<S, CB, true>(x, Y, N, C, scale, w_int, *ex, s);
-    return launch_rfft2_t<S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr}, s);
+template <typename T, int S, int CB>
+int launch_rfft2(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
+    if (ex) return launch_rfft2_t<T, S, CB, true>(x, Y, N, C, scale, w_int, *ex, s);
+    return launch_rfft2_t<T, S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr}, s);
 }
 
 struct IrfftMix {
-    const float* spat;
+    const void* spat;
     const float* alpha;
-    float* freq_out;
+    void* freq_out;
     double* sum;
     double* sumsq;
 };
 
-template <int S, int CB, bool MIX>
-int launch_irfft2_t(const float* Y, float* x, int N, int C, float scale, float w_int, const IrfftMix& m, hipStream_t s) {
+template <typename T, int S, int CB, bool MIX>
+int launch_irfft2_t(const T* Y, T* x, int N, int C, float scale, float w_int, const IrfftMix& m, hipStream_t s) {
     using L = Lds<S, CB>;
     static_assert(!MIX || L::BYTES >= (size_t)S * CB * 2 * sizeof(double), "LDS planes hold the row totals");
     static bool attr_set = false;
     if (L::BYTES > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&irfft2_kernel<S, CB, MIX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&irfft2_kernel<T, S, CB, MIX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
-    hipLaunchKernelGGL((irfft2_kernel<S, CB, MIX>), grid, dim3(NT), L::BYTES, s, Y, x, C, scale, w_int, m.spat, m.alpha,
-                       m.freq_out, m.sum, m.sumsq);
+    hipLaunchKernelGGL((irfft2_kernel<T, S, CB, MIX>), grid, dim3(NT), L::BYTES, s, Y, x, C, scale, w_int,
+                       (const T*)m.spat, m.alpha, (T*)m.freq_out, m.sum, m.sumsq);
     UD_LAUNCH_CHECK();
     return 0;
 }
 
-template <int S, int CB>
-int launch_irfft2(const float* Y, float* x, int N, int C, float scale, float w_int, const IrfftMix* m, hipStream_t s) {
-    if (m) return launch_irfft2_t<S, CB, true>(Y, x, N, C, scale, w_int, *m, s);
-    return launch_irfft2_t<S, CB, false>(Y, x, N, C, scale, w_int, IrfftMix{nullptr, nullptr, nullptr, nullptr, nullptr}, s);
+template <typename T, int S, int CB>
+int launch_irfft2(const T* Y, T* x, int N, int C, float scale, float w_int, const IrfftMix* m, hipStream_t s) {
+    if (m) return launch_irfft2_t<T, S, CB, true>(Y, x, N, C, scale, w_int, *m, s);
+    return launch_irfft2_t<T, S, CB, false>(Y, x, N, C, scale, w_int, IrfftMix{nullptr, nullptr, nullptr, nullptr, nullptr}, s);
 }
 
-int rfft2_dispatch(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, const RfftEx* ex,
+// half storage: the power-of-two sizes of the EfficientNet trunk only (the ResNet models' 5*2^k maps stay fp32)
+template <typename T>
+int rfft2_dispatch(const T* x, T* Y, int N, int S, int C, float scale, float w_interior, const RfftEx* ex,
                    hipStream_t s) {
     switch (S) {
-        case 8: return launch_rfft2<8, 64>(x, Y, N, C, scale, w_interior, ex, s);
-        case 16: return launch_rfft2<16, 32>(x, Y, N, C, scale, w_interior, ex, s);
-        case 32: return launch_rfft2<32, 16>(x, Y, N, C, scale, w_interior, ex, s);
-        case 64: return launch_rfft2<64, 8>(x, Y, N, C, scale, w_interior, ex, s);
-        case 10: return launch_rfft2<10, 51>(x, Y, N, C, scale, w_interior, ex, s);
-        case 20: return launch_rfft2<20, 25>(x, Y, N, C, scale, w_interior, ex, s);
-        case 40: return launch_rfft2<40, 12>(x, Y, N, C, scale, w_interior, ex, s);
-        case 80: return launch_rfft2<80, 5>(x, Y, N, C, scale, w_interior, ex, s);
-        default: return UD_EINVAL;
+        case 8: return launch_rfft2<T, 8, 64>(x, Y, N, C, scale, w_interior, ex, s);
+        case 16: return launch_rfft2<T, 16, 32>(x, Y, N, C, scale, w_interior, ex, s);
+        case 32: return launch_rfft2<T, 32, 16>(x, Y, N, C, scale, w_interior, ex, s);
+        case 64: return launch_rfft2<T, 64, 8>(x, Y, N, C, scale, w_interior, ex, s);
+        default: break;
     }
+    if constexpr (std::is_same<T, float>::value) {
+        switch (S) {
+            case 10: return launch_rfft2<T, 10, 51>(x, Y, N, C, scale, w_interior, ex, s);
+            case 20: return launch_rfft2<T, 20, 25>(x, Y, N, C, scale, w_interior, ex, s);
+            case 40: return launch_rfft2<T, 40, 12>(x, Y, N, C, scale, w_interior, ex, s);
+            case 80: return launch_rfft2<T, 80, 5>(x, Y, N, C, scale, w_interior, ex, s);
+            default: break;
+        }
+    }
+    return UD_EINVAL;
 }
 
-int irfft2_dispatch(const float* Y, float* x, int N, int S, int C, float scale, float w_interior, const IrfftMix* m,
+template <typename T>
+int irfft2_dispatch(const T* Y, T* x, int N, int S, int C, float scale, float w_interior, const IrfftMix* m,
                     hipStream_t s) {
     switch (S) {
-        case 8: return launch_irfft2<8, 64>(Y, x, N, C, scale, w_interior, m, s);
-        case 16: return launch_irfft2<16, 32>(Y, x, N, C, scale, w_interior, m, s);
-        case 32: return launch_irfft2<32, 16>(Y, x, N, C, scale, w_interior, m, s);
-        case 64: return launch_irfft2<64, 8>(Y, x, N, C, scale, w_interior, m, s);
-        case 10: return launch_irfft2<10, 51>(Y, x, N, C, scale, w_interior, m, s);
-        case 20: return launch_irfft2<20, 25>(Y, x, N, C, scale, w_interior, m, s);
-        case 40: return launch_irfft2<40, 12>(Y, x, N, C, scale, w_interior, m, s);
-        case 80: return launch_irfft2<80, 5>(Y, x, N, C, scale, w_interior, m, s);
-        default: return UD_EINVAL;
+        case 8: return launch_irfft2<T, 8, 64>(Y, x, N, C, scale, w_interior, m, s);
+        case 16: return launch_irfft2<T, 16, 32>(Y, x, N, C, scale, w_interior, m, s);
+        case 32: return launch_irfft2<T, 32, 16>(Y, x, N, C, scale, w_interior, m, s);
+        case 64: return launch_irfft2<T, 64, 8>(Y, x, N, C, scale, w_interior, m, s);
+        default: break;
     }
+    if constexpr (std::is_same<T, float>::value) {
+        switch (S) {
+            case 10: return launch_irfft2<T, 10, 51>(Y, x, N, C, scale, w_interior, m, s);
+            case 20: return launch_irfft2<T, 20, 25>(Y, x, N, C, scale, w_interior, m, s);
+            case 40: return launch_irfft2<T, 40, 12>(Y, x, N, C, scale, w_interior, m, s);
+            case 80: return launch_irfft2<T, 80, 5>(Y, x, N, C, scale, w_interior, m, s);
+            default: break;
+        }
+    }
+    return UD_EINVAL;
 }
 
 }  // namespace
 
 extern "C" {
 
-int ud_rfft2(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, ud_stream_t stream) {
+int ud_rfft2(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, int f16, ud_stream_t stream) {
     if (N < 1 || C < 1) return UD_EINVAL;
-    return rfft2_dispatch(x, Y, N, S, C, scale, w_interior, nullptr, (hipStream_t)stream);
+    UD_STORAGE_DISPATCH(f16, return rfft2_dispatch<T>((const T*)x, (T*)Y, N, S, C, scale, w_interior, nullptr,
+                                                      (hipStream_t)stream));
 }
 
-int ud_irfft2(const float* Y, float* x, int N, int S, int C, float scale, float w_interior, ud_stream_t stream) {
+int ud_irfft2(const void* Y, void* x, int N, int S, int C, float scale, float w_interior, int f16, ud_stream_t stream) {
     if (N < 1 || C < 1) return UD_EINVAL;
-    return irfft2_dispatch(Y, x, N, S, C, scale, w_interior, nullptr, (hipStream_t)stream);
+    UD_STORAGE_DISPATCH(f16, return irfft2_dispatch<T>((const T*)Y, (T*)x, N, S, C, scale, w_interior, nullptr,
+                                                       (hipStream_t)stream));
 }
 
-int ud_rfft2_ex(const float* x, float* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
-                float* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
-                ud_stream_t stream) {
+int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
+                void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
+                int f16, ud_stream_t stream) {
     if (N < 1 || C < 1 || !x || !Y) return UD_EINVAL;
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
     if (bn && bn->G != 1) return UD_EINVAL;
     if (act_out && !bn) return UD_EINVAL;
     if (gate_grad && (!gate_acc || !gate_alpha)) return UD_EINVAL;
     RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad};
-    return rfft2_dispatch(x, Y, N, S, C, scale, w_interior, &ex, (hipStream_t)stream);
+    UD_STORAGE_DISPATCH(f16, return rfft2_dispatch<T>((const T*)x, (T*)Y, N, S, C, scale, w_interior, &ex,
+                                                      (hipStream_t)stream));
 }
 
-int ud_irfft2_mix(const float* Y, float* y, int N, int S, int C, float scale, float w_interior, const float* spat,
-                  const float* alpha, float* freq_out, double* sum, double* sumsq, ud_stream_t stream) {
+int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, float w_interior, const void* spat,
+                  const float* alpha, void* freq_out, double* sum, double* sumsq, int f16, ud_stream_t stream) {
     if (N < 1 || C < 1 || !Y || !y || !spat || !alpha || !freq_out || !sum || !sumsq) return UD_EINVAL;
     IrfftMix m{spat, alpha, freq_out, sum, sumsq};
-    return irfft2_dispatch(Y, y, N, S, C, scale, w_interior, &m, (hipStream_t)stream);
+    UD_STORAGE_DISPATCH(f16, return irfft2_dispatch<T>((const T*)Y, (T*)y, N, S, C, scale, w_interior, &m,
+                                                       (hipStream_t)stream));
 }
 
 }  // extern "C"

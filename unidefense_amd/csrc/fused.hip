@@ -15,6 +15,9 @@ namespace {
 
 constexpr int NT = UD_COL_NT;
 
+// rows in flight per thread: a half quad is an 8-byte access, so twice the rows keep the same bytes in flight
+template <typename T> constexpr int kRowUnroll = sizeof(T) == 2 ? 8 : 4;
+
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 struct Bn4 { f32x4 mu, is, ga, be; };
@@ -142,11 +145,12 @@ __global__ __launch_bounds__(NT) void partials_to_acc(int nq, int G, int C, int 
 // ---------------------------------------------------------------------------------------------------------
 // statistics and lazy reductions
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void colstats_kernel(RedGeom q, const float* __restrict__ x, double* __restrict__ sum,
+template <typename T>
+__global__ __launch_bounds__(NT) void colstats_kernel(RedGeom q, const T* __restrict__ x, double* __restrict__ sum,
                                                       double* __restrict__ sumsq, double* __restrict__ part) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const In4<T> x4{x};
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         Rows w = rows_of(q, ri, c4);
@@ -173,19 +177,18 @@ __global__ __launch_bounds__(NT) void colstats_kernel(RedGeom q, const float* __
 }
 
 // DOT = false: out[g][c] += sum_r act(bn(x));  DOT = true: out[g][c] += sum_r dy * act(bn(x))
-template <bool DOT>
-__global__ __launch_bounds__(NT) void colsum_bn_kernel(RedGeom q, const float* __restrict__ x,
-                                                       const float* __restrict__ dy, ud_bn_ref bn,
+template <typename T, bool DOT>
+__global__ __launch_bounds__(NT) void colsum_bn_kernel(RedGeom q, const T* __restrict__ x,
+                                                       const T* __restrict__ dy, ud_bn_ref bn,
                                                        double* __restrict__ out, double* __restrict__ part) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    const In4<T> x4{x}, d4{dy};
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, !DOT && is_updater(ri));
         Rows w = rows_of(q, ri, c4);
-#pragma unroll 4
+#pragma unroll kRowUnroll<T>
         for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
             f32x4 a = bn_apply(x4[w.idx], cb, bn.act);
             if (DOT) {
@@ -218,52 +221,54 @@ __global__ __launch_bounds__(NT) void fc_fwd_d_kernel(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------------
 // elementwise consumers
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void se_scale_bn_kernel(RedGeom q, const float* __restrict__ x, ud_bn_ref bn,
-                                                         const float* __restrict__ s, float* __restrict__ y) {
+template <typename T>
+__global__ __launch_bounds__(NT) void se_scale_bn_kernel(RedGeom q, const T* __restrict__ x, ud_bn_ref bn,
+                                                         const float* __restrict__ s, T* __restrict__ y) {
     int ri, c4;
     if (!thread_coords(q, ri, c4)) return;
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const In4<T> x4{x};
+    const Out4<T> y4{y};
     const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
     f32x4 gate = reinterpret_cast<const f32x4*>(s)[(long)blockIdx.z * q.C4 + c4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) gate[e] = ud_sigmoid_fast(gate[e]);
     Rows w = rows_of(q, ri, c4);
-#pragma unroll 4
-    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) y4[w.idx] = bn_apply(x4[w.idx], cb, bn.act) * gate;
+#pragma unroll kRowUnroll<T>
+    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) y4.st(w.idx, bn_apply(x4[w.idx], cb, bn.act) * gate);
 }
 
-__global__ __launch_bounds__(NT) void residual_bn_kernel(RedGeom q, const float* __restrict__ x, ud_bn_ref bn,
+template <typename T>
+__global__ __launch_bounds__(NT) void residual_bn_kernel(RedGeom q, const T* __restrict__ x, ud_bn_ref bn,
                                                          const float* __restrict__ keep, float inv_keep,
-                                                         const float* __restrict__ skip, float* __restrict__ out) {
+                                                         const T* __restrict__ skip, T* __restrict__ out) {
     int ri, c4;
     if (!thread_coords(q, ri, c4)) return;
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    const f32x4* k4 = reinterpret_cast<const f32x4*>(skip);
-    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    const In4<T> x4{x}, k4{skip};
+    const Out4<T> o4{out};
     const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, is_updater(ri));
     const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
     Rows w = rows_of(q, ri, c4);
-#pragma unroll 4
+#pragma unroll kRowUnroll<T>
     for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
         f32x4 v = bn_apply(x4[w.idx], cb, bn.act) * sc;
         if (skip) v += k4[w.idx];
-        o4[w.idx] = v;
+        o4.st(w.idx, v);
     }
 }
 
 // y = act(bn(x)): the materialised form, for consumers that re-read their input many times (plain depthwise convs
 // and their weight gradient: re-evaluating the swish per tap costs more than this pass)
-__global__ __launch_bounds__(NT) void bn_apply_kernel(RedGeom q, const float* __restrict__ x, ud_bn_ref bn,
-                                                      float* __restrict__ y) {
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(RedGeom q, const T* __restrict__ x, ud_bn_ref bn,
+                                                      T* __restrict__ y) {
     int ri, c4;
     if (!thread_coords(q, ri, c4)) return;
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const In4<T> x4{x};
+    const Out4<T> y4{y};
     const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, is_updater(ri));
     Rows w = rows_of(q, ri, c4);
-#pragma unroll 4
-    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) y4[w.idx] = bn_apply(x4[w.idx], cb, bn.act);
+#pragma unroll kRowUnroll<T>
+    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) y4.st(w.idx, bn_apply(x4[w.idx], cb, bn.act));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -283,21 +288,21 @@ __device__ __forceinline__ void dz_terms(const f32x4& a, const f32x4& d, const B
     }
 }
 
-__global__ __launch_bounds__(NT) void normbwd_sums_kernel(RedGeom q, const float* __restrict__ x,
-                                                          const float* __restrict__ dy, const float* __restrict__ keep,
+template <typename T>
+__global__ __launch_bounds__(NT) void normbwd_sums_kernel(RedGeom q, const T* __restrict__ x,
+                                                          const T* __restrict__ dy, const float* __restrict__ keep,
                                                           float inv_keep, ud_bn_ref bn, int dy_is_dz,
                                                           double* __restrict__ s1, double* __restrict__ s2,
                                                           double* __restrict__ part) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    const In4<T> x4{x}, d4{dy};
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
         const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
         Rows w = rows_of(q, ri, c4);
-#pragma unroll 4
+#pragma unroll kRowUnroll<T>
         for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
             f32x4 dz, xh;
             dz_terms(x4[w.idx], d4[w.idx], cb, bn.act, dy_is_dz != 0, sc, dz, xh);
@@ -312,22 +317,19 @@ __global__ __launch_bounds__(NT) void normbwd_sums_kernel(RedGeom q, const float
 }
 
 // MIX: also the SF-mix gradient: acc += dd * (freq - spat)
-template <bool MIX>
-__global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const float* __restrict__ x,
-                                                           const float* __restrict__ dy, const float* __restrict__ keep,
+template <typename T, bool MIX>
+__global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* __restrict__ x,
+                                                           const T* __restrict__ dy, const float* __restrict__ keep,
                                                            float inv_keep, ud_bn_ref bn, int dy_is_dz,
                                                            const double* __restrict__ s1, const double* __restrict__ s2,
                                                            const double* __restrict__ s1l, const double* __restrict__ s2l,
-                                                           const float* __restrict__ spat, const float* __restrict__ freq,
-                                                           float* __restrict__ dx, double* __restrict__ dalpha_acc,
+                                                           const T* __restrict__ spat, const T* __restrict__ freq,
+                                                           T* __restrict__ dx, double* __restrict__ dalpha_acc,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
-    const f32x4* sp4 = reinterpret_cast<const f32x4*>(spat);
-    const f32x4* fr4 = reinterpret_cast<const f32x4*>(freq);
-    f32x4* o4 = reinterpret_cast<f32x4*>(dx);
+    const In4<T> x4{x}, d4{dy}, sp4{spat}, fr4{freq};
+    const Out4<T> o4{dx};
     double acc = 0.0;
     if (active) {
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
@@ -346,17 +348,17 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const floa
             }
         }
         Rows w = rows_of(q, ri, c4);
-#pragma unroll 4
+#pragma unroll kRowUnroll<T>
         for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
             f32x4 dz, xh, o;
             dz_terms(x4[w.idx], d4[w.idx], cb, bn.act, dy_is_dz != 0, sc, dz, xh);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = cb.ga[e] * cb.is[e] * (dz[e] - t1[e] - xh[e] * t2[e]);
-            o4[w.idx] = o;
+            o4.st(w.idx, o);
             if (MIX) {
                 f32x4 s = sp4[w.idx], f = fr4[w.idx];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc += (double)o[e] * ((double)f[e] - (double)s[e]);
+                for (int e = 0; e < 4; ++e) acc += (double)ud_rounded<T>(o[e]) * ((double)f[e] - (double)s[e]);
             }
         }
     }
@@ -384,17 +386,17 @@ __global__ void gate_grad_from_acc_kernel(const double* __restrict__ acc, const 
 }
 
 // db = dc * sigmoid(s) + dpool * inv_hw;  dz = db * act'(bn(x));  sums
-__global__ __launch_bounds__(NT) void se_scale_bwd_bn_kernel(RedGeom q, const float* __restrict__ dc,
-                                                             const float* __restrict__ x, ud_bn_ref bn,
+template <typename T>
+__global__ __launch_bounds__(NT) void se_scale_bwd_bn_kernel(RedGeom q, const T* __restrict__ dc,
+                                                             const T* __restrict__ x, ud_bn_ref bn,
                                                              const float* __restrict__ s, const float* __restrict__ dpool,
-                                                             float inv_hw, float* __restrict__ dzo,
+                                                             float inv_hw, T* __restrict__ dzo,
                                                              double* __restrict__ s1, double* __restrict__ s2,
                                                              double* __restrict__ part) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dc);
-    f32x4* o4 = reinterpret_cast<f32x4*>(dzo);
+    const In4<T> x4{x}, d4{dc};
+    const Out4<T> o4{dzo};
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(NT) void se_scale_bwd_bn_kernel(RedGeom q, const fl
 #pragma unroll
         for (int e = 0; e < 4; ++e) gate[e] = ud_sigmoid_fast(gate[e]);
         Rows w = rows_of(q, ri, c4);
-#pragma unroll 4
+#pragma unroll kRowUnroll<T>
         for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
             f32x4 a = x4[w.idx], d = d4[w.idx], dz;
 #pragma unroll
@@ -411,11 +413,12 @@ __global__ __launch_bounds__(NT) void se_scale_bwd_bn_kernel(RedGeom q, const fl
                 const float xh = (a[e] - cb.mu[e]) * cb.is[e];
                 float g = d[e] * gate[e] + dp[e];
                 if (bn.act) g *= ud_act_grad_fast(cb.ga[e] * xh + cb.be[e], bn.act);
+                g = ud_rounded<T>(g);                  // the sums are those of the stored gradient
                 dz[e] = g;
                 v[e] += (double)g;
                 v[4 + e] += (double)g * (double)xh;
             }
-            o4[w.idx] = dz;
+            o4.st(w.idx, dz);
         }
     }
     red_out<8>(q, ri, active, c4, v, s1, s2, part, false);
@@ -536,22 +539,20 @@ constexpr int TW = 8;
 
 // Data gradient.  STRIP (stride 1): items = (n, h, strip of TW input columns); otherwise one input pixel per item.
 // BN: push the result through act'(bn(x)) of the conv's input and accumulate the BatchNorm backward sums.
-template <int K, bool STRIP, bool BN>
-__global__ __launch_bounds__(NT) void dw_bwd_data_ex_kernel(RedGeom q, DwGeom d, const float* __restrict__ dy,
+template <typename T, int K, bool STRIP, bool BN>
+__global__ __launch_bounds__(NT) void dw_bwd_data_ex_kernel(RedGeom q, DwGeom d, const T* __restrict__ dy,
                                                             const float* __restrict__ gate_alpha, int gate_mode,
-                                                            const float* __restrict__ wt, const float* __restrict__ add,
-                                                            const float* __restrict__ x, ud_bn_ref bn,
-                                                            float* __restrict__ out, double* __restrict__ s1,
+                                                            const float* __restrict__ wt, const T* __restrict__ add,
+                                                            const T* __restrict__ x, ud_bn_ref bn,
+                                                            T* __restrict__ out, double* __restrict__ s1,
                                                             double* __restrict__ s2, double* __restrict__ part) {
     constexpr int TWB = STRIP ? TW : 1;
     constexpr int NCOL = TWB + K - 1;
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
-    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const In4<T> dy4{dy}, add4{add}, x4{x};
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
-    const f32x4* add4 = reinterpret_cast<const f32x4*>(add);
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    const Out4<T> o4{out};
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         Bn4 cb;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_data_ex_kernel(RedGeom q, DwGeom d,
                 for (int kh = 0; kh < K; ++kh) {
                     const int ho = h + d.pad_t - kh;
                     if (ho < 0 || ho >= d.Ho) continue;
-                    const f32x4* row = dy4 + (((long)n * d.Ho + ho) * d.Wo) * q.C4 + c4;
+                    const In4<T> row = dy4 + ((((long)n * d.Ho + ho) * d.Wo) * q.C4 + c4);
                     f32x4 g[NCOL], w[K];
 #pragma unroll
                     for (int j = 0; j < NCOL; ++j) {
@@ -618,12 +619,13 @@ __global__ __launch_bounds__(NT) void dw_bwd_data_ex_kernel(RedGeom q, DwGeom d,
                         const float xh = (a[e] - cb.mu[e]) * cb.is[e];
                         float g = da[e];
                         if (bn.act) g *= ud_act_grad_fast(cb.ga[e] * xh + cb.be[e], bn.act);
+                        g = ud_rounded<T>(g);
                         da[e] = g;
                         v[e] += (double)g;
                         v[4 + e] += (double)g * (double)xh;
                     }
                 }
-                o4[o] = da;
+                o4.st(o, da);
             }
         }
     }
@@ -632,23 +634,30 @@ __global__ __launch_bounds__(NT) void dw_bwd_data_ex_kernel(RedGeom q, DwGeom d,
 
 // Weight gradient, sliding-window form (as dwconv.hip:dw_bwd_weight_rows; its finalize below applies the gate factor).
 // x is the MATERIALISED activated input: re-evaluating a deferred swish for every window load made this kernel 5x slower.
-template <int K, int S>
-__global__ void dw_bwd_weight_rows_ex(DwGeom q, int C, int rows_per_group, const float* __restrict__ x,
-                                      const float* __restrict__ dy, float* __restrict__ part) {
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+template <typename T, int K, int S>
+__global__ __launch_bounds__(NT) void dw_bwd_weight_rows_ex(DwGeom q, int C, int rows_per_group, const T* __restrict__ x,
+                                      const T* __restrict__ dy, float* __restrict__ part) {
+    // a lane owns CPL adjacent channels: 1 float or 2 halves — a 4-byte access either way (2-byte accesses ran this
+    // kernel at a third of its fp32 speed)
+    constexpr int CPL = sizeof(T) == 2 ? 2 : 1;
+    typedef T VT __attribute__((ext_vector_type(CPL == 2 ? 2 : 1)));
+    typedef float VF __attribute__((ext_vector_type(CPL == 2 ? 2 : 1)));
+    const int c = (blockIdx.y * blockDim.x + threadIdx.x) * CPL;
     if (c >= C) return;
     const int p = blockIdx.x;
     const int rows_total = q.N * q.Ho;
     const int row0 = p * rows_per_group;
     int row1 = row0 + rows_per_group;
     if (row1 > rows_total) row1 = rows_total;
-    float acc[K * K];
+    const VF zero = {};
+    auto ld = [](const T* ptr) { return __builtin_convertvector(*reinterpret_cast<const VT*>(ptr), VF); };
+    VF acc[K * K];
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int i = 0; i < K * K; ++i) acc[i] = zero;
     for (int row = row0; row < row1; ++row) {
         const int n = row / q.Ho, ho = row % q.Ho;
         const int ih0 = ho * S - q.pad_t;
-        const float* xr[K];
+        const T* xr[K];
         bool vh[K];
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
@@ -656,18 +665,18 @@ __global__ void dw_bwd_weight_rows_ex(DwGeom q, int C, int rows_per_group, const
             vh[kh] = (ih >= 0) && (ih < q.H);
             xr[kh] = x + (((long)n * q.H + (vh[kh] ? ih : 0)) * q.W) * C + c;
         }
-        float w[K][K];
+        VF w[K][K];
 #pragma unroll
         for (int kh = 0; kh < K; ++kh)
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
                 const int iw = kw - q.pad_l;
-                w[kh][kw] = (vh[kh] && iw >= 0 && iw < q.W) ? xr[kh][(long)iw * C] : 0.f;
+                w[kh][kw] = (vh[kh] && iw >= 0 && iw < q.W) ? ld(xr[kh] + (long)iw * C) : zero;
             }
-        const float* dyr = dy + ((long)row * q.Wo) * C + c;
+        const T* dyr = dy + ((long)row * q.Wo) * C + c;
 #pragma unroll 4
         for (int wo = 0; wo < q.Wo; ++wo) {
-            const float g = dyr[(long)wo * C];
+            const VF g = ld(dyr + (long)wo * C);
 #pragma unroll
             for (int kh = 0; kh < K; ++kh)
 #pragma unroll
@@ -679,14 +688,14 @@ __global__ void dw_bwd_weight_rows_ex(DwGeom q, int C, int rows_per_group, const
 #pragma unroll
                 for (int j = 0; j < S; ++j) {
                     const int iw = (wo + 1) * S - q.pad_l + (K - S) + j;
-                    w[kh][K - S + j] = (vh[kh] && iw >= 0 && iw < q.W) ? xr[kh][(long)iw * C] : 0.f;
+                    w[kh][K - S + j] = (vh[kh] && iw >= 0 && iw < q.W) ? ld(xr[kh] + (long)iw * C) : zero;
                 }
             }
         }
     }
     float* out = part + (long)p * (K * K) * C + c;
 #pragma unroll
-    for (int i = 0; i < K * K; ++i) out[(long)i * C] = acc[i];
+    for (int i = 0; i < K * K; ++i) *reinterpret_cast<VF*>(out + (long)i * C) = acc[i];
 }
 
 // 64 lanes per output (4 partials in flight per lane), fp64 accumulation; result in the parameter's layout
@@ -782,33 +791,35 @@ int ud_stat_slots_fold(const double* slot_sum, const double* slot_sumsq, int slo
     return 0;
 }
 
-int ud_colstats(const float* x, int G, int R, int C, double* sum, double* sumsq, double* ws, ud_stream_t stream) {
+int ud_colstats(const void* x, int G, int R, int C, double* sum, double* sumsq, double* ws, int f16,
+                ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !sum || !sumsq) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     RedPlan pl = plan_reduce(G, R, C, true, ws);
-    hipLaunchKernelGGL(colstats_kernel, red_grid(pl.q), dim3(NT), 0, s, pl.q, x, sum, sumsq, pl.use_part ? ws : nullptr);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(colstats_kernel<T>, red_grid(pl.q), dim3(NT), 0, s, pl.q, (const T*)x, sum,
+                                                sumsq, pl.use_part ? ws : nullptr));
     UD_LAUNCH_CHECK();
     return finish_reduce(pl, 2, true, C, ws, sum, sumsq, s);
 }
 
-int ud_colsum_bn(const float* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
+int ud_colsum_bn(const void* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws, int f16,
                  ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !bn || !out) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     RedPlan pl = plan_reduce(G, R, C, true, ws);
-    hipLaunchKernelGGL(colsum_bn_kernel<false>, red_grid(pl.q), dim3(NT), 0, s, pl.q, x, nullptr, *bn, out,
-                       pl.use_part ? ws : nullptr);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((colsum_bn_kernel<T, false>), red_grid(pl.q), dim3(NT), 0, s, pl.q,
+                                                (const T*)x, (const T*)nullptr, *bn, out, pl.use_part ? ws : nullptr));
     UD_LAUNCH_CHECK();
     return finish_reduce(pl, 1, true, C, ws, out, nullptr, s);
 }
 
-int ud_coldot_bn(const float* dy, const float* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
-                 ud_stream_t stream) {
+int ud_coldot_bn(const void* dy, const void* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws,
+                 int f16, ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !dy || !bn || !out) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     RedPlan pl = plan_reduce(G, R, C, true, ws);
-    hipLaunchKernelGGL(colsum_bn_kernel<true>, red_grid(pl.q), dim3(NT), 0, s, pl.q, x, dy, *bn, out,
-                       pl.use_part ? ws : nullptr);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((colsum_bn_kernel<T, true>), red_grid(pl.q), dim3(NT), 0, s, pl.q,
+                                                (const T*)x, (const T*)dy, *bn, out, pl.use_part ? ws : nullptr));
     UD_LAUNCH_CHECK();
     return finish_reduce(pl, 1, true, C, ws, out, nullptr, s);
 }
@@ -823,68 +834,75 @@ int ud_fc_fwd_d(const double* xsum, float xscale, const float* W, const float* b
     return 0;
 }
 
-int ud_bn_apply(const float* x, const ud_bn_ref* bn, float* y, int G, int R, int C, ud_stream_t stream) {
+int ud_bn_apply(const void* x, const ud_bn_ref* bn, void* y, int G, int R, int C, int f16, ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !bn || !y) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
-    hipLaunchKernelGGL(bn_apply_kernel, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, *bn, y);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(bn_apply_kernel<T>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
+                                                (const T*)x, *bn, (T*)y));
     UD_LAUNCH_CHECK();
     return 0;
 }
 
-int ud_se_scale_bn(const float* x, const ud_bn_ref* bn, const float* s, float* y, int G, int R, int C,
+int ud_se_scale_bn(const void* x, const ud_bn_ref* bn, const float* s, void* y, int G, int R, int C, int f16,
                    ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !bn || !s || !y) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
-    hipLaunchKernelGGL(se_scale_bn_kernel, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, *bn, s, y);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(se_scale_bn_kernel<T>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
+                                                (const T*)x, *bn, s, (T*)y));
     UD_LAUNCH_CHECK();
     return 0;
 }
 
-int ud_residual_bn(const float* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const float* skip,
-                   float* out, int G, int R, int C, ud_stream_t stream) {
+int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const void* skip,
+                   void* out, int G, int R, int C, int f16, ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !bn || !out) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
-    hipLaunchKernelGGL(residual_bn_kernel, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, *bn, keep, inv_keep,
-                       skip, out);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(residual_bn_kernel<T>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
+                                                (const T*)x, *bn, keep, inv_keep, (const T*)skip, (T*)out));
     UD_LAUNCH_CHECK();
     return 0;
 }
 
-int ud_normbwd_sums(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
-                    int dy_is_dz, int G, int R, int C, double* s1, double* s2, double* ws, ud_stream_t stream) {
+int ud_normbwd_sums(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                    int dy_is_dz, int G, int R, int C, double* s1, double* s2, double* ws, int f16,
+                    ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !dy || !bn || !s1 || !s2 || bn->G != 1) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     RedPlan pl = plan_reduce(G, R, C, false, ws);
-    hipLaunchKernelGGL(normbwd_sums_kernel, red_grid(pl.q), dim3(NT), 0, s, pl.q, x, dy, keep, inv_keep, *bn, dy_is_dz,
-                       s1, s2, pl.use_part ? ws : nullptr);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(normbwd_sums_kernel<T>, red_grid(pl.q), dim3(NT), 0, s, pl.q, (const T*)x,
+                                                (const T*)dy, keep, inv_keep, *bn, dy_is_dz, s1, s2,
+                                                pl.use_part ? ws : nullptr));
     UD_LAUNCH_CHECK();
     return finish_reduce(pl, 2, false, C, ws, s1, s2, s);
 }
 
-int ud_normbwd_apply(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+int ud_normbwd_apply(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
                      int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
-                     const double* s2_local, int G, int R, int C, float* dx, float* dgamma, float* dbeta,
+                     const double* s2_local, int G, int R, int C, void* dx, float* dgamma, float* dbeta, int f16,
                      ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !dy || !bn || !s1 || !s2 || !dx || bn->G != 1) return UD_EINVAL;
     if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
-    hipLaunchKernelGGL(normbwd_apply_kernel<false>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, dy, keep,
-                       inv_keep, *bn, dy_is_dz, s1, s2, s1_local, s2_local, nullptr, nullptr, dx, nullptr, dgamma,
-                       dbeta);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, false>), red_grid(q), dim3(NT), 0,
+                                                (hipStream_t)stream, q, (const T*)x, (const T*)dy, keep, inv_keep, *bn,
+                                                dy_is_dz, s1, s2, s1_local, s2_local, (const T*)nullptr,
+                                                (const T*)nullptr, (T*)dx, (double*)nullptr, dgamma, dbeta));
     UD_LAUNCH_CHECK();
     return 0;
 }
 
-int ud_normbwd_apply_mix(const float* x, const float* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
-                         const double* s1_local, const double* s2_local, const float* spat, const float* freq,
-                         int G, int R, int C, float* dd, double* dalpha_acc, float* dgamma, float* dbeta,
+int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
+                         const double* s1_local, const double* s2_local, const void* spat, const void* freq,
+                         int G, int R, int C, void* dd, double* dalpha_acc, float* dgamma, float* dbeta, int f16,
                          ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !dz || !bn || !s1 || !s2 || !dd || !spat || !freq || !dalpha_acc || bn->G != 1)
         return UD_EINVAL;
     if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
     RedGeom q = make_geom_ex(G, R, C, 512, 4096, 4);      // one fp64 atomic per workgroup onto dalpha_acc
-    hipLaunchKernelGGL(normbwd_apply_kernel<true>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, dz, nullptr,
-                       1.f, *bn, 1, s1, s2, s1_local, s2_local, spat, freq, dd, dalpha_acc, dgamma, dbeta);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, true>), red_grid(q), dim3(NT), 0,
+                                                (hipStream_t)stream, q, (const T*)x, (const T*)dz, (const float*)nullptr,
+                                                1.f, *bn, 1, s1, s2, s1_local, s2_local, (const T*)spat, (const T*)freq,
+                                                (T*)dd, dalpha_acc, dgamma, dbeta));
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -923,14 +941,15 @@ int ud_se_bwd_b(const double* ds1_acc, const float* s1, const float* Wr, const d
     return 0;
 }
 
-int ud_se_scale_bwd_bn(const float* dc, const float* x, const ud_bn_ref* bn, const float* s, const float* dpool,
-                       float inv_hw, float* dz, double* s1, double* s2, double* ws, int G, int R, int C,
+int ud_se_scale_bwd_bn(const void* dc, const void* x, const ud_bn_ref* bn, const float* s, const float* dpool,
+                       float inv_hw, void* dz, double* s1, double* s2, double* ws, int G, int R, int C, int f16,
                        ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !dc || !x || !bn || !s || !dpool || !dz || !s1 || !s2 || bn->G != 1) return UD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     RedPlan pl = plan_reduce(G, R, C, false, ws);
-    hipLaunchKernelGGL(se_scale_bwd_bn_kernel, red_grid(pl.q), dim3(NT), 0, st, pl.q, dc, x, *bn, s, dpool, inv_hw, dz,
-                       s1, s2, pl.use_part ? ws : nullptr);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(se_scale_bwd_bn_kernel<T>, red_grid(pl.q), dim3(NT), 0, st, pl.q,
+                                                (const T*)dc, (const T*)x, *bn, s, dpool, inv_hw, (T*)dz, s1, s2,
+                                                pl.use_part ? ws : nullptr));
     UD_LAUNCH_CHECK();
     return finish_reduce(pl, 2, false, C, ws, s1, s2, st);
 }
@@ -947,8 +966,11 @@ long ud_dwconv_bwd_data_bn_ws_doubles(int N, int H, int W, int C, int stride) {
     return pl.use_part ? 2L * pl.q.G * pl.q.P * C : 0;
 }
 
-static int dw_bwd_data_launch(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
-                              const float* x, const ud_bn_ref* bn, float* out, double* s1, double* s2, double* ws, int N,
+}  // extern "C"
+
+template <typename T>
+static int dw_bwd_data_launch(const T* dy, const float* gate_alpha, int gate_mode, const float* wt, const T* add,
+                              const T* x, const ud_bn_ref* bn, T* out, double* s1, double* s2, double* ws, int N,
                               int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, hipStream_t s) {
     if (C % 4 || !dy || !wt || !out) return UD_EINVAL;
     DwGeom d{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
@@ -965,7 +987,7 @@ static int dw_bwd_data_launch(const float* dy, const float* gate_alpha, int gate
     double* part = pl.use_part ? ws : nullptr;
     const ud_bn_ref& b = has_bn ? *bn : none;
 #define UD_DW_BWD(KK, ST, BB)                                                                                        \
-    hipLaunchKernelGGL((dw_bwd_data_ex_kernel<KK, ST, BB>), red_grid(q), dim3(NT), 0, s, q, d, dy, gate_alpha,       \
+    hipLaunchKernelGGL((dw_bwd_data_ex_kernel<T, KK, ST, BB>), red_grid(q), dim3(NT), 0, s, q, d, dy, gate_alpha,    \
                        gate_mode, wt, add, x, b, out, s1, s2, part)
     if (K == 3) {
         if (strip) { if (has_bn) UD_DW_BWD(3, true, true); else UD_DW_BWD(3, true, false); }
@@ -979,25 +1001,30 @@ static int dw_bwd_data_launch(const float* dy, const float* gate_alpha, int gate
     return has_bn ? finish_reduce(pl, 2, false, C, ws, s1, s2, s) : 0;
 }
 
-int ud_dwconv_bwd_data_bn(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
-                          const float* x, const ud_bn_ref* bn, float* dz, double* s1, double* s2, double* ws, int N,
-                          int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l,
+extern "C" {
+
+int ud_dwconv_bwd_data_bn(const void* dy, const float* gate_alpha, int gate_mode, const float* wt, const void* add,
+                          const void* x, const ud_bn_ref* bn, void* dz, double* s1, double* s2, double* ws, int N,
+                          int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, int f16,
                           ud_stream_t stream) {
     if (!bn) return UD_EINVAL;
-    return dw_bwd_data_launch(dy, gate_alpha, gate_mode, wt, add, x, bn, dz, s1, s2, ws, N, H, W, C, Ho, Wo, K, stride,
-                              pad_t, pad_l, (hipStream_t)stream);
+    UD_STORAGE_DISPATCH(f16, return dw_bwd_data_launch<T>((const T*)dy, gate_alpha, gate_mode, wt, (const T*)add,
+                                                          (const T*)x, bn, (T*)dz, s1, s2, ws, N, H, W, C, Ho, Wo, K,
+                                                          stride, pad_t, pad_l, (hipStream_t)stream));
 }
 
-int ud_dwconv_bwd_data_ex(const float* dy, const float* gate_alpha, int gate_mode, const float* wt, const float* add,
-                          float* dx, int N, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t,
-                          int pad_l, ud_stream_t stream) {
-    return dw_bwd_data_launch(dy, gate_alpha, gate_mode, wt, add, nullptr, nullptr, dx, nullptr, nullptr, nullptr, N, H, W,
-                              C, Ho, Wo, K, stride, pad_t, pad_l, (hipStream_t)stream);
+int ud_dwconv_bwd_data_ex(const void* dy, const float* gate_alpha, int gate_mode, const float* wt, const void* add,
+                          void* dx, int N, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t,
+                          int pad_l, int f16, ud_stream_t stream) {
+    UD_STORAGE_DISPATCH(f16, return dw_bwd_data_launch<T>((const T*)dy, gate_alpha, gate_mode, wt, (const T*)add,
+                                                          (const T*)nullptr, nullptr, (T*)dx, nullptr, nullptr, nullptr,
+                                                          N, H, W, C, Ho, Wo, K, stride, pad_t, pad_l,
+                                                          (hipStream_t)stream));
 }
 
-int ud_dwconv_bwd_weight_ex(const float* x, const float* dy, const float* gate_alpha, int gate_mode, float* dwt,
+int ud_dwconv_bwd_weight_ex(const void* x, const void* dy, const float* gate_alpha, int gate_mode, float* dwt,
                             float* part, int chunks, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
-                            int pad_t, int pad_l, ud_stream_t stream) {
+                            int pad_t, int pad_l, int f16, ud_stream_t stream) {
     if (C % 4 || chunks < 1 || !x || !dy || !dwt || !part) return UD_EINVAL;
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!dw_geom_ok(q, K)) return UD_EINVAL;
@@ -1005,9 +1032,12 @@ int ud_dwconv_bwd_weight_ex(const float* x, const float* dy, const float* gate_a
     const int rows_total = N * Ho;
     if (chunks > rows_total) return UD_EINVAL;
     const int rpg = (rows_total + chunks - 1) / chunks;
-    int bt = ((C < NT ? C : NT) + 63) / 64 * 64;
-    dim3 grid((unsigned)chunks, (unsigned)ud_cdiv(C, bt), 1);
-#define UD_DW_WG(KK, SS) hipLaunchKernelGGL((dw_bwd_weight_rows_ex<KK, SS>), grid, dim3(bt), 0, s, q, C, rpg, x, dy, part)
+    const int lanes = f16 ? C / 2 : C;          // half: two adjacent channels per lane (C % 4 == 0)
+    int bt = ((lanes < NT ? lanes : NT) + 63) / 64 * 64;
+    dim3 grid((unsigned)chunks, (unsigned)ud_cdiv(lanes, bt), 1);
+#define UD_DW_WG(KK, SS)                                                                                              \
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((dw_bwd_weight_rows_ex<T, KK, SS>), grid, dim3(bt), 0, s, q, C, rpg,         \
+                                                (const T*)x, (const T*)dy, part))
     if (K == 3 && stride == 1) UD_DW_WG(3, 1);
     else if (K == 3) UD_DW_WG(3, 2);
     else if (stride == 1) UD_DW_WG(5, 1);

@@ -456,6 +456,7 @@ static void vec_flags(const ud_gemm_desc& d, int& a_vec, int& b_vec) {
 // (K or N = 24..56) are HBM-bound either way and stream better through its 3-deep register prefetch (A/B on the bench:
 // minimum dimension 64 -> 16: 38.33 -> 37.85 ms/step; 1: no further change)
 static bool takes_x3(const ud_gemm_desc& d, int a_vec, int b_vec) {
+    if (d.half_mask) return ud_gemm_x3_eligible(d, a_vec != 0, b_vec != 0);     // ud_gemm rejects the others
     const int path = g_path.load();
     if (path == 1 || !ud_gemm_x3_eligible(d, a_vec != 0, b_vec != 0)) return false;
     static const int min_dim = getenv("UD_GEMM_X3_MINDIM") ? atoi(getenv("UD_GEMM_X3_MINDIM")) : 16;
@@ -468,7 +469,7 @@ extern "C" int ud_gemm_query_path(const ud_gemm_desc* dp) {
     if (!dp) return UD_EINVAL;
     int a_vec = 0, b_vec = 0;
     vec_flags(*dp, a_vec, b_vec);
-    return takes_x3(*dp, a_vec, b_vec) ? (g_path.load() == 3 ? 3 : 2) : 1;
+    return takes_x3(*dp, a_vec, b_vec) ? ((g_path.load() == 3 || dp->half_mask) ? 3 : 2) : 1;
 }
 
 // Epilogue statistics (ud_gemm_desc.stat_sum): only the split-bf16 kernel's plain-store epilogue sees whole column sums.
@@ -502,6 +503,13 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         if (d.b_mode == 2 && (rows != d.K || cols != d.N)) return UD_EINVAL;
     }
     if (d.stat_sum && (!d.stat_sumsq || !stats_ok(d, a_vec, b_vec))) return UD_EINVAL;
+    if (d.half_mask) {
+        // half-stored operands exist only on the fp16-MFMA kernel: plain modes, one batch, no atomics onto a half result
+        if ((d.half_mask & ~7) || d.batch != 1 || d.a_mode > 1 || d.b_mode > 1 || !takes_x3(d, a_vec, b_vec) ||
+            ((d.half_mask & 4) && d.out_mode == 2))
+            return UD_EINVAL;
+        return ud_gemm_x3_launch_half(d, s);
+    }
     if (takes_x3(d, a_vec, b_vec)) return ud_gemm_x3_launch(d, s, g_path.load() == 3);
 #ifdef UD_GEMM_DEBUG_NOLOAD      // tuning aid, debug builds only: issue no global loads (results are WRONG)
     static const bool noload = getenv("UD_GEMM_NOLOAD") != nullptr;

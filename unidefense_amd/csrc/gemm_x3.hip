@@ -86,8 +86,11 @@ __device__ __forceinline__ int phys_row(int row) { return row ^ ((row >> 3) & 1)
 //         operands, fp32 accumulation, one v_mfma_f32_32x32x16_f16 instead of six bf16 MFMAs.
 // PREC 0: experiments only (-DUD_X3_FAKE_A / -DUD_X3_FAKE_B): three identical bf16 pieces, i.e. the split's arithmetic
 //         removed, to measure what it costs (measured: 4-8 % for B alone, 10-12 % for both: not the limiter).
-template <int ROWS, int MODE, int PREC = 3>
+// H: the operand is stored as _Float16 (half storage of the activations, PREC 1 only): the same element-to-thread map
+// with 8-byte / 4-byte loads, and the store is a masked copy (K-contiguous) or a pair interleave (row-contiguous).
+template <int ROWS, int MODE, int PREC = 3, bool H = false>
 struct XLoader {
+    static_assert(!H || PREC == 1, "half operands feed the fp16 MFMA directly");
     static constexpr bool FAKE = PREC == 0;
     static constexpr int NPL = PREC == 1 ? 1 : 3;      // bf16 / fp16 planes per operand
     static constexpr int GS = ROWS * 16 + 32;          // bytes of one (plane, k-group) image
@@ -97,9 +100,12 @@ struct XLoader {
     static constexpr bool KC = MODE == 0 || MODE == 2;                  // K-contiguous source (MODE 2: inside a tap)
     static constexpr int NV = KC ? NV0 : 2;
     static constexpr int NWRITE = KC ? NPL * NV0 : NPL * VEC;           // ds_write instructions per stage
-    using V = typename std::conditional<(KC || VEC == 4), f32x4, f32x2>::type;
+    using E = typename std::conditional<H, _Float16, float>::type;
+    using VF = typename std::conditional<(KC || VEC == 4), f32x4, f32x2>::type;
+    using VH = typename std::conditional<(KC || VEC == 4), f16x4, f16x2>::type;
+    using V = typename std::conditional<H, VH, VF>::type;
 
-    const float* base;
+    const E* base;
     long ld;
     int k_last;           // last valid k of this workgroup's K range
     long off[NV0 > 2 ? NV0 : 2];   // MODE 0: element offset of (clamped row, kq*4); MODE 1: [0] = clamped row offset
@@ -116,7 +122,7 @@ struct XLoader {
 
     __device__ __forceinline__ void init(const float* p, long ld_, int dim, int row0, int k_end, int tid,
                                          const ud_conv_geom& geom, int k_begin) {
-        base = p; ld = ld_; k_last = k_end - 1;
+        base = reinterpret_cast<const E*>(p); ld = ld_; k_last = k_end - 1;
         if constexpr (MODE == 2) {
             g = geom;
             kloc = (tid & 3) * 4;
@@ -217,7 +223,10 @@ struct XLoader {
                 const bool ok = MODE == 2 ? ((vmask[S] >> i) & 1u) != 0 : rowok[i] && (k0 + kq * 4 <= k_last);
                 V v = regs[S][i];
                 char* p = L + (kq >> 1) * GS + phys_row(row) * 16 + (kq & 1) * 8;
-                if constexpr (PREC == 1) {
+                if constexpr (H) {
+                    const u32x2 raw = __builtin_bit_cast(u32x2, v);
+                    *reinterpret_cast<u32x2*>(p) = ok ? raw : u32x2{0u, 0u};
+                } else if constexpr (PREC == 1) {
                     *reinterpret_cast<u32x2*>(p) = u32x2{pack_f16(ok ? v[0] : 0.f, ok ? v[1] : 0.f),
                                                          pack_f16(ok ? v[2] : 0.f, ok ? v[3] : 0.f)};
                 } else {
@@ -242,7 +251,10 @@ struct XLoader {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 char* p = p0 + phys_row(q * VEC + e) * 16;
-                if constexpr (PREC == 1) {
+                if constexpr (H) {
+                    const f16x2 pr = {ok0 ? v0[e] : (_Float16)0, ok1 ? v1[e] : (_Float16)0};
+                    *reinterpret_cast<uint32_t*>(p) = __builtin_bit_cast(uint32_t, pr);
+                } else if constexpr (PREC == 1) {
                     *reinterpret_cast<uint32_t*>(p) = pack_f16(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f);
                 } else {
                     uint32_t a0, a1, a2;
@@ -257,7 +269,7 @@ struct XLoader {
     }
 };
 
-template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 3>
+template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 3, bool AH = false, bool BH = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc d, int tiles_m, int tiles_n) {
     static_assert(WGM * WGN == 4, "4 waves");
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -265,12 +277,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
 #ifdef UD_X3_FAKE_A
     using LA = XLoader<BM, AMODE, PREC == 3 ? 0 : PREC>;
 #else
-    using LA = XLoader<BM, AMODE, PREC>;
+    using LA = XLoader<BM, AMODE, PREC, AH>;
 #endif
 #ifdef UD_X3_FAKE_B
     using LB = XLoader<BN, BMODE, PREC == 3 ? 0 : PREC>;
 #else
-    using LB = XLoader<BN, BMODE, PREC>;
+    using LB = XLoader<BN, BMODE, PREC, BH>;
 #endif
     __shared__ __attribute__((aligned(16))) char As[2][LA::STAGE];
     __shared__ __attribute__((aligned(16))) char Bs[2][LB::STAGE];
@@ -385,6 +397,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (nkt == 0 && d.out_mode != 0) return;
+    const bool c_half = (d.half_mask & 4) != 0;
+    if (c_half) {          // statistics and consumers see the rounded values
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = ud_rounded<_Float16>(acc[i][j][r]);
+    }
     if (d.stat_sum) {
         // per-column sums of this wave's TM*32 rows (rows beyond M hold exact zeros: their A rows were zero-filled), the
         // two lane halves (different rows, same column) folded by one shuffle, one fp64 atomic per column and quantity;
@@ -419,22 +440,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < d.M && col < d.N) {
-                    float* p = Cp + (long)row * d.ldc + col;
                     float v = acc[i][j][r];
-                    if (d.out_mode == 0) *p = v;
-                    else if (d.out_mode == 1) *p += v;
-                    else atomicAdd(p, v);
+                    if (c_half) {          // out_mode 0 / 1 only (ud_gemm rejects atomics onto half)
+                        _Float16* p = reinterpret_cast<_Float16*>(Cp) + (long)row * d.ldc + col;
+                        *p = (_Float16)(d.out_mode == 0 ? v : v + (float)*p);
+                    } else {
+                        float* p = Cp + (long)row * d.ldc + col;
+                        if (d.out_mode == 0) *p = v;
+                        else if (d.out_mode == 1) *p += v;
+                        else atomicAdd(p, v);
+                    }
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, int PREC>
+template <int BM, int BN, int AMODE, int BMODE, int PREC, bool AH = false, bool BH = false>
 int launch_tile(const ud_gemm_desc& d, hipStream_t s) {
     int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, (unsigned)d.batch);
-    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, 2, 2, AMODE, BMODE, PREC>), grid, dim3(NTHREADS), 0, s, d, tiles_m,
+    hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, 2, 2, AMODE, BMODE, PREC, AH, BH>), grid, dim3(NTHREADS), 0, s, d, tiles_m,
                        tiles_n);
     UD_LAUNCH_CHECK();
     return 0;
@@ -445,7 +471,7 @@ struct XCfg { int bm, bn; double penalty; };
 // with UD_GEMM_X3_CFG=0/1/2: 4096^3 179 vs 150 TFLOP/s), so they only win where they fill the chip better.
 constexpr XCfg kX[3] = {{128, 128, 1.00}, {128, 64, 1.20}, {64, 128, 1.20}};
 
-template <int AMODE, int BMODE, int PREC>
+template <int AMODE, int BMODE, int PREC, bool AH = false, bool BH = false>
 int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
     static const int forced = [] {
         const char* e = getenv("UD_GEMM_X3_CFG");
@@ -463,9 +489,9 @@ int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
     }
     if (forced >= 0) best = forced;
     switch (best) {
-        case 1: return launch_tile<128, 64, AMODE, BMODE, PREC>(d, s);
-        case 2: return launch_tile<64, 128, AMODE, BMODE, PREC>(d, s);
-        default: return launch_tile<128, 128, AMODE, BMODE, PREC>(d, s);
+        case 1: return launch_tile<128, 64, AMODE, BMODE, PREC, AH, BH>(d, s);
+        case 2: return launch_tile<64, 128, AMODE, BMODE, PREC, AH, BH>(d, s);
+        default: return launch_tile<128, 128, AMODE, BMODE, PREC, AH, BH>(d, s);
     }
 }
 
@@ -503,6 +529,18 @@ int ud_gemm_x3_tile_rows(const ud_gemm_desc& d) {
     }();
     if (forced >= 0) best = forced;
     return kX[best].bm;
+}
+
+// Half-stored operands (ud_gemm_desc.half_mask): activations / activation gradients are _Float16 in memory, weights and
+// weight gradients fp32 — the three products of a 1x1 conv: forward (0,0) and data gradient (0,1) with A half, weight
+// gradient (1,1) with both half.  Always the fp16 MFMA.
+int ud_gemm_x3_launch_half(const ud_gemm_desc& d, hipStream_t s) {
+    const int ab = d.half_mask & 3;
+    if (d.a_mode == 0 && d.b_mode == 0 && ab == 1) return launch_modes<0, 0, 1, true, false>(d, s);
+    if (d.a_mode == 0 && d.b_mode == 1 && ab == 1) return launch_modes<0, 1, 1, true, false>(d, s);
+    if (d.a_mode == 1 && d.b_mode == 1 && ab == 3) return launch_modes<1, 1, 1, true, true>(d, s);
+    if (ab == 0) return ud_gemm_x3_launch(d, s, true);          // fp32 operands, half result
+    return UD_EINVAL;
 }
 
 // f16: one fp16 piece per operand (mixed precision) instead of the exact three-way bf16 split

@@ -162,7 +162,8 @@ __global__ void sigmoid_grad_mul(long n, const float* __restrict__ s, float* __r
 // SFConv mixing  y = (1 - a) * spat + a * P(freq),  a = sigmoid(alpha),  P = identity or 2x2 average pool
 // (model/efficientnet/exp.py:61-65; adaptive_avg_pool2d from an even size to half of it == 2x2 mean).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 pooled_freq(const f32x4* f4, int pool, long n, int ho, int wo, int Ho, int Wo, int C4,
+template <typename T>
+__device__ __forceinline__ f32x4 pooled_freq(const In4<T>& f4, int pool, long n, int ho, int wo, int Ho, int Wo, int C4,
                                              int c4) {
     if (!pool) return f4[((n * Ho + ho) * Wo + wo) * C4 + c4];
     const int H = Ho * 2, W = Wo * 2;
@@ -171,13 +172,13 @@ __device__ __forceinline__ f32x4 pooled_freq(const f32x4* f4, int pool, long n, 
     return v * 0.25f;
 }
 
+template <typename T>
 __global__ __launch_bounds__(NT) void sfmix_fwd(long total4, int Ho, int Wo, int C4, int pool,
-                                                const float* __restrict__ spat, const float* __restrict__ freq,
-                                                const float* __restrict__ alpha, float* __restrict__ y) {
+                                                const T* __restrict__ spat, const T* __restrict__ freq,
+                                                const float* __restrict__ alpha, T* __restrict__ y) {
     const float a = ud_sigmoid(alpha[0]);
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(spat);
-    const f32x4* f4 = reinterpret_cast<const f32x4*>(freq);
-    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const In4<T> s4{spat}, f4{freq};
+    const Out4<T> y4{y};
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total4; e += (long)gridDim.x * NT) {
         int c4 = (int)(e % C4);
         long pix = e / C4;
@@ -186,22 +187,20 @@ __global__ __launch_bounds__(NT) void sfmix_fwd(long total4, int Ho, int Wo, int
         int ho = (int)(t % Ho);
         long n = t / Ho;
         f32x4 fp = pooled_freq(f4, pool, n, ho, wo, Ho, Wo, C4, c4);
-        y4[e] = s4[e] * (1.f - a) + fp * a;
+        y4.st(e, s4[e] * (1.f - a) + fp * a);
     }
 }
 
 // dspat = (1-a) dy;  dfreq = a * U(dy) (/4 when pooled);  part[block] = sum dy * (P(freq) - spat)
+template <typename T>
 __global__ __launch_bounds__(NT) void sfmix_bwd(long total4, int Ho, int Wo, int C4, int pool,
-                                                const float* __restrict__ spat, const float* __restrict__ freq,
-                                                const float* __restrict__ alpha, const float* __restrict__ dy,
-                                                float* __restrict__ dspat, float* __restrict__ dfreq,
+                                                const T* __restrict__ spat, const T* __restrict__ freq,
+                                                const float* __restrict__ alpha, const T* __restrict__ dy,
+                                                T* __restrict__ dspat, T* __restrict__ dfreq,
                                                 double* __restrict__ part) {
     const float a = ud_sigmoid(alpha[0]);
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(spat);
-    const f32x4* f4 = reinterpret_cast<const f32x4*>(freq);
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
-    f32x4* ds4 = reinterpret_cast<f32x4*>(dspat);
-    f32x4* df4 = reinterpret_cast<f32x4*>(dfreq);
+    const In4<T> s4{spat}, f4{freq}, d4{dy};
+    const Out4<T> ds4{dspat}, df4{dfreq};
     double acc = 0.0;   // fp64: the sum cancels heavily (sf_coef gradient)
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total4; e += (long)gridDim.x * NT) {
         int c4 = (int)(e % C4);
@@ -212,14 +211,14 @@ __global__ __launch_bounds__(NT) void sfmix_bwd(long total4, int Ho, int Wo, int
         long n = t / Ho;
         f32x4 fp = pooled_freq(f4, pool, n, ho, wo, Ho, Wo, C4, c4);
         f32x4 d = d4[e], s = s4[e];
-        ds4[e] = d * (1.f - a);
+        ds4.st(e, d * (1.f - a));
         if (!pool) {
-            df4[e] = d * a;
+            df4.st(e, d * a);
         } else {
             const int H = Ho * 2, W = Wo * 2;
             const long b = ((n * H + 2 * ho) * W + 2 * wo) * C4 + c4;
             f32x4 g = d * (0.25f * a);
-            df4[b] = g; df4[b + C4] = g; df4[b + (long)W * C4] = g; df4[b + (long)W * C4 + C4] = g;
+            df4.st(b, g); df4.st(b + C4, g); df4.st(b + (long)W * C4, g); df4.st(b + (long)W * C4 + C4, g);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc += (double)d[k] * ((double)fp[k] - (double)s[k]);
@@ -275,12 +274,13 @@ __global__ __launch_bounds__(NT) void residual_fwd(long total4, long per_sample4
 }
 
 // out = a * alpha + b * beta   (b may be null)
-__global__ __launch_bounds__(NT) void axpby(long total, const float* __restrict__ a, float alpha,
-                                            const float* __restrict__ b, float beta, float* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(NT) void axpby(long total, const T* __restrict__ a, float alpha,
+                                            const T* __restrict__ b, float beta, T* __restrict__ out) {
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
-        float v = a[e] * alpha;
-        if (b) v += b[e] * beta;
-        out[e] = v;
+        float v = (float)a[e] * alpha;
+        if (b) v += (float)b[e] * beta;
+        out[e] = (T)v;
     }
 }
 
@@ -638,25 +638,27 @@ int ud_sigmoid_grad_mul(const float* s, float* v, long n, ud_stream_t stream) {
 
 int ud_sfmix_blocks(int N, int Ho, int Wo, int C) { return ew_blocks((long)N * Ho * Wo * (C / 4), 1024); }
 
-int ud_sfmix_fwd(const float* spat, const float* freq, const float* alpha, float* y, int N, int Ho, int Wo, int C,
-                 int pool, ud_stream_t stream) {
+int ud_sfmix_fwd(const void* spat, const void* freq, const float* alpha, void* y, int N, int Ho, int Wo, int C,
+                 int pool, int f16, ud_stream_t stream) {
     if (C % 4) return UD_EINVAL;
     long total4 = (long)N * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(sfmix_fwd, dim3(ew_blocks(total4)), dim3(NT), 0, (hipStream_t)stream, total4, Ho, Wo, C / 4,
-                       pool, spat, freq, alpha, y);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(sfmix_fwd<T>, dim3(ew_blocks(total4)), dim3(NT), 0, (hipStream_t)stream,
+                                                total4, Ho, Wo, C / 4, pool, (const T*)spat, (const T*)freq, alpha,
+                                                (T*)y));
     UD_LAUNCH_CHECK();
     return 0;
 }
 
 // part must hold ud_sfmix_blocks(...) floats; dalpha receives sigmoid'(alpha) * sum dy (P(freq) - spat)
-int ud_sfmix_bwd(const float* spat, const float* freq, const float* alpha, const float* dy, float* dspat, float* dfreq,
-                 double* part, float* dalpha, int N, int Ho, int Wo, int C, int pool, ud_stream_t stream) {
+int ud_sfmix_bwd(const void* spat, const void* freq, const float* alpha, const void* dy, void* dspat, void* dfreq,
+                 double* part, float* dalpha, int N, int Ho, int Wo, int C, int pool, int f16, ud_stream_t stream) {
     if (C % 4) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     long total4 = (long)N * Ho * Wo * (C / 4);
     int nb = ew_blocks(total4, 1024);
-    hipLaunchKernelGGL(sfmix_bwd, dim3(nb), dim3(NT), 0, s, total4, Ho, Wo, C / 4, pool, spat, freq, alpha, dy, dspat,
-                       dfreq, part);
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(sfmix_bwd<T>, dim3(nb), dim3(NT), 0, s, total4, Ho, Wo, C / 4, pool,
+                                                (const T*)spat, (const T*)freq, alpha, (const T*)dy, (T*)dspat,
+                                                (T*)dfreq, part));
     UD_LAUNCH_CHECK();
     hipLaunchKernelGGL(gate_grad_finalize, dim3(1), dim3(NT), 0, s, nb, part, alpha, dalpha);
     UD_LAUNCH_CHECK();
@@ -691,8 +693,9 @@ int ud_residual_fwd(const float* x, const float* skip, const float* keep, float 
     return 0;
 }
 
-int ud_axpby(const float* a, float alpha, const float* b, float beta, float* out, long total, ud_stream_t stream) {
-    hipLaunchKernelGGL(axpby, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, total, a, alpha, b, beta, out);
+int ud_axpby(const void* a, float alpha, const void* b, float beta, void* out, long total, int f16, ud_stream_t stream) {
+    UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(axpby<T>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, total,
+                                                (const T*)a, alpha, (const T*)b, beta, (T*)out));
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -14,6 +14,49 @@ static inline int ud_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Storage type of the trunk's activation tensors (BASELINE configs[4]): float, or _Float16 with every kernel computing
+// in fp32 registers — a channel quad is one 16-byte (float) or 8-byte (half) access, converted on load / rounded to
+// nearest even on store.  Kernels are templates over T; entry points take `f16` (0 / 1) and dispatch.
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p, long i) { return reinterpret_cast<const f32x4*>(p)[i]; }
+    static __device__ __forceinline__ void st(float* p, long i, const f32x4& v) { reinterpret_cast<f32x4*>(p)[i] = v; }
+};
+template <> struct Quad<_Float16> {
+    static __device__ __forceinline__ f32x4 ld(const _Float16* p, long i) {
+        return __builtin_convertvector(reinterpret_cast<const f16x4*>(p)[i], f32x4);
+    }
+    static __device__ __forceinline__ void st(_Float16* p, long i, const f32x4& v) {
+        reinterpret_cast<f16x4*>(p)[i] = __builtin_convertvector(v, f16x4);
+    }
+};
+// read-only / writable views indexed in channel quads
+template <typename T> struct In4 {
+    const T* p;
+    __device__ __forceinline__ f32x4 operator[](long i) const { return Quad<T>::ld(p, i); }
+    __device__ __forceinline__ In4 operator+(long i) const { return In4{p + 4 * i}; }
+    __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+};
+template <typename T> struct Out4 {
+    T* p;
+    __device__ __forceinline__ void st(long i, const f32x4& v) const { Quad<T>::st(p, i, v); }
+    __device__ __forceinline__ Out4 operator+(long i) const { return Out4{p + 4 * i}; }
+};
+// value actually stored for v (statistics are taken of what consumers will read back)
+template <typename T> __device__ __forceinline__ float ud_rounded(float v) { return (float)(T)v; }
+
+#define UD_STORAGE_DISPATCH(f16, ...)            \
+    do {                                         \
+        if (f16) {                               \
+            using T = _Float16;                  \
+            __VA_ARGS__;                         \
+        } else {                                 \
+            using T = float;                     \
+            __VA_ARGS__;                         \
+        }                                        \
+    } while (0)
 
 // accurate expf (not the __expf fast intrinsic): these kernels are bandwidth bound, the ALU work is free
 __device__ __forceinline__ float ud_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -12,9 +12,10 @@ The path shards over the batch only.  Exchanges per backward:
     incoming loss gradient is scaled by 1/world before the tape runs (everything downstream is linear in it,
     including the SyncBN sums).
   * SyncBatchNorm statistics, enabled by ``sync_bn=True``.  Fused MBConv path (tape.mbconv_fused): the fp64
-    accumulators (sum x, sum x^2) of a BatchNorm are all-reduced IN PLACE between the kernel that fills them and the
-    kernels that consume them (tape.DataParallelCtx.reduce), likewise (sum dz, sum dz*xhat) in the backward — one
-    all_reduce of 2C doubles each way, ranks need not hold equal row counts.  Operator path (tape.batchnorm_act:
+    accumulators (sum x, sum x^2) of a BatchNorm are summed over the ranks IN PLACE between the kernel that fills them
+    and the kernels that consume them (tape.DataParallelCtx.reduce), likewise (sum dz, sum dz*xhat) in the backward —
+    2C doubles each way, ranks need not hold equal row counts.  On one node the sum is BnExchange's single kernel over
+    peer-mapped mailboxes (csrc/xchg.hip; rank-ordered, bit-identical on all ranks); otherwise one dist.all_reduce.  Operator path (tape.batchnorm_act:
     attention / head / ResNet models): one all_gather of (mean, var) per BN forward and one all_reduce of the two sums
     per BN backward.
 No other collective exists on the data path.
@@ -78,6 +79,95 @@ class GradReducer:
         return out
 
 
+class BnExchange:
+    """One-shot SyncBatchNorm exchange (csrc/xchg.hip): the fp64 BatchNorm accumulators are summed over the ranks of ONE
+    node by a single small kernel writing into peer-mapped mailboxes, instead of one RCCL collective per BatchNorm
+    (~200 per step, each latency-bound).  Setup is collective over `group` (handles travel through all_gather_object);
+    a self-test exchanges known vectors and every rank must see the exact sum, otherwise ALL ranks fall back to
+    dist.all_reduce (`ok` False) — e.g. ranks on different nodes, where the IPC open fails.  `UD_SYNCBN_EXCHANGE=0`
+    disables it."""
+
+    MAX_DOUBLES = 8192          # 2 * 3264 channels is the largest accumulator of the EfficientNet-b4 trunk
+    SLOTS = 4
+    SPIN_LIMIT = 1 << 20        # polls (~1 us each) before a missing peer is reported: about a second
+
+    def __init__(self, group, device):
+        import ctypes as C
+        import os
+        from .. import lib
+        self.group, self.device = group, device
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.ok, self.base, self.opened = False, None, []
+        want = os.environ.get("UD_SYNCBN_EXCHANGE", "1") == "1" and device.type == "cuda"
+        status, handle = 0, b""
+        if want:
+            base, buf = C.c_void_p(), C.create_string_buffer(64)
+            status = lib.load().ud_xchg_create(self.world, self.MAX_DOUBLES, self.SLOTS, C.byref(base), buf)
+            if status == 0:
+                self.base, handle = base.value, buf.raw
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (status == 0 and want, handle), group=group)
+        good = all(h[0] for h in handles)
+        ptrs = []
+        if good:
+            for r, (_, h) in enumerate(handles):
+                if r == self.rank:
+                    ptrs.append(self.base)
+                    continue
+                p = C.c_void_p()
+                if lib.load().ud_xchg_open(h, C.byref(p)) != 0:
+                    good = False
+                    break
+                self.opened.append(p.value)
+                ptrs.append(p.value)
+        flag = torch.tensor([1 if good else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            return
+        self.peers = torch.tensor(ptrs, dtype=torch.int64, device=device)
+        self.seq = torch.zeros(1, dtype=torch.int64, device=device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        self.ok = True
+        self.ok = self._self_test()
+
+    def _self_test(self):
+        n = 1000
+        good = True
+        for it in range(2 * self.SLOTS + 1):            # every slot twice
+            v = (torch.arange(n, device=self.device, dtype=torch.float64) + 1.0) * (self.rank + 1) + it
+            self.allreduce(v)
+            want = (torch.arange(n, device=self.device, dtype=torch.float64) + 1.0) * (self.world * (self.world + 1) / 2) \
+                + it * self.world
+            good = good and bool(torch.equal(v, want)) and int(self.err.item()) == 0
+        flag = torch.tensor([1 if good else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
+
+    def allreduce(self, acc):
+        """acc (contiguous fp64, <= MAX_DOUBLES): summed over the ranks in place, in rank order."""
+        from .. import kernels as K
+        from .. import lib
+        assert acc.dtype == torch.float64 and acc.is_contiguous() and acc.numel() <= self.MAX_DOUBLES
+        lib.call("ud_xchg_allreduce", K._p(acc), acc.numel(), K._p(self.peers), self.rank, self.world, self.MAX_DOUBLES,
+                 self.SLOTS, K._p(self.seq), K._p(self.err), self.SPIN_LIMIT, K._stream())
+
+    def check(self):
+        """Host-side check after a step (synchronises): a rank that timed out waiting raises here."""
+        e = int(self.err.item())
+        if e:
+            raise RuntimeError(f"SyncBatchNorm exchange: rank {e - 1} did not arrive (rank {self.rank} timed out)")
+
+    def close(self):
+        from .. import lib
+        for p in self.opened:
+            lib.load().ud_xchg_close(p)
+        self.opened = []
+        if self.base:
+            lib.load().ud_xchg_destroy(self.base)
+            self.base = None
+        self.ok = False
+
+
 class HipDataParallel(nn.Module):
     """Minimal DDP replacement exposing ``.module`` like torch's wrapper."""
 
@@ -97,6 +187,10 @@ class HipDataParallel(nn.Module):
             module._grad_prescale = 1.0 / self.world
         if sync_bn and (self.world > 1 or self.force):
             module._sync_bn_group = process_group if process_group is not None else dist.group.WORLD
+            dev = next(module.parameters()).device
+            if dev.type == "cuda":
+                self.bn_exchange = BnExchange(module._sync_bn_group, dev)
+                module._bn_exchange = self.bn_exchange if self.bn_exchange.ok else None
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

@@ -39,8 +39,24 @@ def _chk(*ts):
                              f"contiguous={t.is_contiguous()} shape={tuple(t.shape)}")
 
 
-def empty(shape, like):
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+def _act(*ts):
+    """Activation tensors of the trunk: contiguous CUDA, all fp32 or all fp16 (half storage, BASELINE configs[4]).
+    Returns the `f16` flag of the C ABI."""
+    dt = None
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype in (torch.float32, torch.float16) and t.is_contiguous()):
+            raise ValueError(f"expected a contiguous fp32 / fp16 CUDA tensor, got {t.dtype} {t.device} "
+                             f"contiguous={t.is_contiguous()} shape={tuple(t.shape)}")
+        if dt is not None and t.dtype != dt:
+            raise ValueError(f"mixed storage types in one call: {dt} and {t.dtype}")
+        dt = t.dtype
+    return 1 if dt == torch.float16 else 0
+
+
+def empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
 
 
 # Zero-initialised outputs of the split-K launches (atomic accumulation): ~180 per step, each a 5 us fill launch of
@@ -103,9 +119,10 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     """stats: fp64 accumulator [sum | sumsq] (2N doubles) the epilogue should add the result's column sums into; returns
     (Cout, True) when the kernel did (ud_gemm_stats_slots), (Cout, False) when the caller still has to run colstats."""
     d = GemmDesc()
-    d.A = A.data_ptr() + 4 * a_off
-    d.B = B.data_ptr() + 4 * b_off
+    d.A = A.data_ptr() + A.element_size() * a_off
+    d.B = B.data_ptr() + B.element_size() * b_off
     d.C = Cout.data_ptr()
+    d.half_mask = (A.dtype == torch.float16) | ((B.dtype == torch.float16) << 1) | ((Cout.dtype == torch.float16) << 2)
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
     d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
@@ -173,10 +190,16 @@ def gemm_nt(a, w, out=None, accumulate=False, stats=None):
     """out[M,N] (+)= a[M,K] @ w[N,K]^T     (1x1 conv / linear forward).
     stats (2N zeroed doubles): BatchNorm statistics of the result; returns (out, done) — done = the GEMM epilogue
     accumulated them (plain launches only: a split-K or tail-split plan leaves them to ud_colstats)."""
-    _chk(a, w)
+    half = _act(a)
+    _chk(w)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
+    if half:
+        # half storage: one plain launch (no atomics onto a half result); the fp16 MFMA leaves these memory-bound
+        if out is None:
+            out = empty((M, N), a, a.dtype)
+        return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 1 if accumulate else 0, stats=stats)
     if stats is not None:
         assert out is None and not accumulate
         if _tail_plan(M, N, K) is None and _fwd_split(M, N, K) <= 1:
@@ -202,10 +225,16 @@ def gemm_nt(a, w, out=None, accumulate=False, stats=None):
 
 def gemm_nn(a, w, out=None, accumulate=False):
     """out[M,N] (+)= a[M,K] @ w[K,N]       (data gradient of a 1x1 conv: dY @ W)"""
-    _chk(a, w)
+    half = _act(a, out)
+    _chk(w)
     M, K = a.shape
     N = w.shape[1]
     assert w.shape[0] == K
+    if half:
+        acc = out is not None and accumulate
+        if out is None:
+            out = empty((M, N), a, a.dtype)
+        return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if acc else 0)
     if out is None or accumulate:
         # accumulate: `out` already holds a term of the same gradient (the skip branch's): the plain part adds into
         # it (out_mode 1), the split-K parts add atomically onto it — no zero fill, no separate axpby pass
@@ -284,7 +313,7 @@ def _tiles(M, N, K=None):
 
 def gemm_tn(a, b):
     """out[M,N] = a[K,M]^T @ b[K,N]        (weight gradient: dY^T @ X, reduction over pixels)"""
-    _chk(a, b)
+    _act(a, b)          # both fp32, or both half (activation gradient x activation); the weight gradient is fp32
     K, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == K
@@ -499,10 +528,11 @@ def bcast_rows(g, HW, scale):
 # depthwise conv
 # ---------------------------------------------------------------------------------------------
 def dwconv_fwd(x, wt, K, stride, pad_t, pad_l, Ho, Wo):
-    _chk(x, wt)
+    h = _act(x)
+    _chk(wt)
     N, H, W, Cc = x.shape
-    y = empty((N, Ho, Wo, Cc), x)
-    _call("ud_dwconv_fwd", _p(x), _p(wt), _p(y), N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+    y = empty((N, Ho, Wo, Cc), x, x.dtype)
+    _call("ud_dwconv_fwd", _p(x), _p(wt), _p(y), N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, h, _stream())
     return y
 
 
@@ -533,11 +563,13 @@ def dw_weights_tapmajor(weights):
 
 def dwconv_bwd_data(dy, wt, K, stride, pad_t, pad_l, H, W, add=None):
     """add: another contribution to the same input gradient, summed in the store (saves an axpby pass)."""
-    _chk(dy, wt, add)
+    h = _act(dy, add)
+    _chk(wt)
     N, Ho, Wo, Cc = dy.shape
-    dx = empty((N, H, W, Cc), dy)
+    dx = empty((N, H, W, Cc), dy, dy.dtype)
     assert add is None or add.shape == dx.shape
-    _call("ud_dwconv_bwd_data", _p(dy), _p(wt), _p(add), _p(dx), N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+    _call("ud_dwconv_bwd_data", _p(dy), _p(wt), _p(add), _p(dx), N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, h,
+          _stream())
     return dx
 
 
@@ -563,21 +595,21 @@ def dwconv_bwd_weight(x, dy, K, stride, pad_t, pad_l):
 # ---------------------------------------------------------------------------------------------
 def rfft2(x, scale, w_interior=1.0):
     """x[N,S,S,C] -> Y[N,S,S/2+1,2C] (Re | Im channel halves)."""
-    _chk(x)
+    h = _act(x)
     N, S, S2, Cc = x.shape
     assert S == S2
-    Y = empty((N, S, S // 2 + 1, 2 * Cc), x)
-    _call("ud_rfft2", _p(x), _p(Y), N, S, Cc, scale, w_interior, _stream())
+    Y = empty((N, S, S // 2 + 1, 2 * Cc), x, x.dtype)
+    _call("ud_rfft2", _p(x), _p(Y), N, S, Cc, scale, w_interior, h, _stream())
     return Y
 
 
 def irfft2(Y, scale, w_interior=1.0):
     """Y[N,S,S/2+1,2C] -> x[N,S,S,C]."""
-    _chk(Y)
+    h = _act(Y)
     N, S, Wh, C2 = Y.shape
     assert Wh == S // 2 + 1 and C2 % 2 == 0
-    x = empty((N, S, S, C2 // 2), Y)
-    _call("ud_irfft2", _p(Y), _p(x), N, S, C2 // 2, scale, w_interior, _stream())
+    x = empty((N, S, S, C2 // 2), Y, Y.dtype)
+    _call("ud_irfft2", _p(Y), _p(x), N, S, C2 // 2, scale, w_interior, h, _stream())
     return x
 
 
@@ -627,15 +659,17 @@ def sigmoid_grad_mul_(s, v):
 
 
 def sfmix_fwd(spat, freq, alpha, pool):
-    _chk(spat, freq, alpha)
+    h = _act(spat, freq)
+    _chk(alpha)
     N, Ho, Wo, Cc = spat.shape
     y = torch.empty_like(spat)
-    _call("ud_sfmix_fwd", _p(spat), _p(freq), _p(alpha), _p(y), N, Ho, Wo, Cc, int(pool), _stream())
+    _call("ud_sfmix_fwd", _p(spat), _p(freq), _p(alpha), _p(y), N, Ho, Wo, Cc, int(pool), h, _stream())
     return y
 
 
 def sfmix_bwd(spat, freq, alpha, dy, pool):
-    _chk(spat, freq, alpha, dy)
+    h = _act(spat, freq, dy)
+    _chk(alpha)
     N, Ho, Wo, Cc = spat.shape
     nb = _call("ud_sfmix_blocks", N, Ho, Wo, Cc)
     part = torch.empty((nb,), dtype=torch.float64, device=spat.device)
@@ -643,7 +677,7 @@ def sfmix_bwd(spat, freq, alpha, dy, pool):
     dfreq = torch.empty_like(freq)
     dalpha = empty((), spat)
     _call("ud_sfmix_bwd", _p(spat), _p(freq), _p(alpha), _p(dy), _p(dspat), _p(dfreq), _p(part), _p(dalpha), N, Ho,
-          Wo, Cc, int(pool), _stream())
+          Wo, Cc, int(pool), h, _stream())
     return dspat, dfreq, dalpha
 
 
@@ -676,10 +710,10 @@ def residual(x, skip, keep=None, inv_keep=1.0):
 
 
 def axpby(a, alpha, b=None, beta=1.0, out=None):
-    _chk(a, b)
+    h = _act(a, b, out)
     if out is None:
         out = torch.empty_like(a)
-    _call("ud_axpby", _p(a), alpha, _p(b), beta, _p(out), a.numel(), _stream())
+    _call("ud_axpby", _p(a), alpha, _p(b), beta, _p(out), a.numel(), h, _stream())
     return out
 
 
@@ -1082,22 +1116,23 @@ def _ws64(ref, need):
 
 def colstats(x2, acc, G=1, R=None):
     """acc[0:G*C] += column sums of x2 [G*R, C], acc[G*C:2*G*C] += column sums of squares."""
-    _chk(x2)
+    h = _act(x2)
     Cc = x2.shape[-1]
     R = x2.numel() // (G * Cc) if R is None else R
-    _call("ud_colstats", _p(x2), G, R, Cc, _pd(acc), _pd(acc, G * Cc), _fused_ws(x2, G, R, Cc, True), _stream())
+    _call("ud_colstats", _p(x2), G, R, Cc, _pd(acc), _pd(acc, G * Cc), _fused_ws(x2, G, R, Cc, True), h, _stream())
 
 
 def colsum_bn(x, bn, G, R, out, update=False):
-    _chk(x)
+    h = _act(x)
     Cc = x.shape[-1]
-    _call("ud_colsum_bn", _p(x), C.byref(bn.ref(update)), G, R, Cc, _pd(out), _fused_ws(x, G, R, Cc, True), _stream())
+    _call("ud_colsum_bn", _p(x), C.byref(bn.ref(update)), G, R, Cc, _pd(out), _fused_ws(x, G, R, Cc, True), h, _stream())
 
 
 def coldot_bn(dy, x, bn, G, R, out):
-    _chk(dy, x)
+    h = _act(dy, x)
     Cc = x.shape[-1]
-    _call("ud_coldot_bn", _p(dy), _p(x), C.byref(bn.ref()), G, R, Cc, _pd(out), _fused_ws(x, G, R, Cc, True), _stream())
+    _call("ud_coldot_bn", _p(dy), _p(x), C.byref(bn.ref()), G, R, Cc, _pd(out), _fused_ws(x, G, R, Cc, True), h,
+          _stream())
 
 
 def fc_fwd_d(xsum, xscale, W, b, N):
@@ -1110,57 +1145,61 @@ def fc_fwd_d(xsum, xscale, W, b, N):
 
 def bn_apply(x, bn, G, R, update=False):
     """y = act(bn(x)), materialised."""
-    _chk(x)
+    h = _act(x)
     y = torch.empty_like(x)
-    _call("ud_bn_apply", _p(x), C.byref(bn.ref(update)), _p(y), G, R, x.shape[-1], _stream())
+    _call("ud_bn_apply", _p(x), C.byref(bn.ref(update)), _p(y), G, R, x.shape[-1], h, _stream())
     return y
 
 
 def se_scale_bn(x, bn, s, G, R):
-    _chk(x, s)
+    h = _act(x)
+    _chk(s)
     y = torch.empty_like(x)
-    _call("ud_se_scale_bn", _p(x), C.byref(bn.ref()), _p(s), _p(y), G, R, x.shape[-1], _stream())
+    _call("ud_se_scale_bn", _p(x), C.byref(bn.ref()), _p(s), _p(y), G, R, x.shape[-1], h, _stream())
     return y
 
 
 def residual_bn(x, bn, keep, inv_keep, skip, G, R, update=False):
-    _chk(x, keep, skip)
+    h = _act(x, skip)
+    _chk(keep)
     out = torch.empty_like(x)
     _call("ud_residual_bn", _p(x), C.byref(bn.ref(update)), _p(keep), float(inv_keep), _p(skip), _p(out), G, R,
-          x.shape[-1], _stream())
+          x.shape[-1], h, _stream())
     return out
 
 
 def normbwd_sums(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc):
     """sacc[0:C] += sum dz, sacc[C:2C] += sum dz * xhat."""
-    _chk(x, dy, keep)
+    h = _act(x, dy)
+    _chk(keep)
     Cc = x.shape[-1]
     _call("ud_normbwd_sums", _p(x), _p(dy), _p(keep), float(inv_keep), C.byref(bn.ref()), int(dy_is_dz), G, R, Cc,
-          _pd(sacc), _pd(sacc, Cc), _fused_ws(x, G, R, Cc, False), _stream())
+          _pd(sacc), _pd(sacc, Cc), _fused_ws(x, G, R, Cc, False), h, _stream())
 
 
 def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=None, want_dbeta=True):
     """Returns (dx, dgamma, dbeta).  sacc: sums over all ranks; sacc_local: this rank's (default: the same)."""
-    _chk(x, dy, keep)
+    h = _act(x, dy)
+    _chk(keep)
     Cc = x.shape[-1]
     loc = sacc if sacc_local is None else sacc_local
     dx = torch.empty_like(x)
     dg = empty((Cc,), x)
     db = empty((Cc,), x) if want_dbeta else None
     _call("ud_normbwd_apply", _p(x), _p(dy), _p(keep), float(inv_keep), C.byref(bn.ref()), int(dy_is_dz), _pd(sacc),
-          _pd(sacc, Cc), _pd(loc), _pd(loc, Cc), G, R, Cc, _p(dx), _p(dg), _p(db), _stream())
+          _pd(sacc, Cc), _pd(loc), _pd(loc, Cc), G, R, Cc, _p(dx), _p(dg), _p(db), h, _stream())
     return dx, dg, db
 
 
 def normbwd_apply_mix(x, dz, bn, G, R, sacc, spat, freq, dalpha_acc, sacc_local=None):
-    _chk(x, dz, spat, freq)
+    h = _act(x, dz, spat, freq)
     Cc = x.shape[-1]
     loc = sacc if sacc_local is None else sacc_local
     dd = torch.empty_like(x)
     dg = empty((Cc,), x)
     db = empty((Cc,), x)
     _call("ud_normbwd_apply_mix", _p(x), _p(dz), C.byref(bn.ref()), _pd(sacc), _pd(sacc, Cc), _pd(loc), _pd(loc, Cc),
-          _p(spat), _p(freq), G, R, Cc, _p(dd), _pd(dalpha_acc), _p(dg), _p(db), _stream())
+          _p(spat), _p(freq), G, R, Cc, _p(dd), _pd(dalpha_acc), _p(dg), _p(db), h, _stream())
     return dd, dg, db
 
 
@@ -1189,44 +1228,48 @@ def se_bwd(dgate, s2, s1, We, Wr, pool, pool_scale):
 
 
 def se_scale_bwd_bn(dc, x, bn, s, dpool, inv_hw, G, R, sacc):
-    _chk(dc, x, s, dpool)
+    h = _act(dc, x)
+    _chk(s, dpool)
     Cc = x.shape[-1]
     dz = torch.empty_like(x)
     _call("ud_se_scale_bwd_bn", _p(dc), _p(x), C.byref(bn.ref()), _p(s), _p(dpool), float(inv_hw), _p(dz), _pd(sacc),
-          _pd(sacc, Cc), _fused_ws(x, G, R, Cc, False), G, R, Cc, _stream())
+          _pd(sacc, Cc), _fused_ws(x, G, R, Cc, False), G, R, Cc, h, _stream())
     return dz
 
 
 def dwconv_bwd_data_bn(dy, gate_alpha, gate_mode, wt, add, x, bn, K, stride, pad_t, pad_l, sacc):
     """dz = (gate * dwconv_bwd_data(dy) + add) * act'(bn(x)); sacc += BatchNorm backward sums.  x: the conv's input."""
-    _chk(dy, wt, add, x)
+    h = _act(dy, add, x)
+    _chk(wt)
     N, H, W, Cc = x.shape
     _, Ho, Wo, _ = dy.shape
     dz = torch.empty_like(x)
     ws = _ws64(x, _call("ud_dwconv_bwd_data_bn_ws_doubles", N, H, W, Cc, stride))
     _call("ud_dwconv_bwd_data_bn", _p(dy), _p(gate_alpha), int(gate_mode), _p(wt), _p(add), _p(x), C.byref(bn.ref()),
-          _p(dz), _pd(sacc), _pd(sacc, Cc), ws, N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+          _p(dz), _pd(sacc), _pd(sacc, Cc), ws, N, H, W, Cc, Ho, Wo, K, stride, pad_t, pad_l, h, _stream())
     return dz
 
 
 def dwconv_bwd_data_ex(dy, gate_alpha, gate_mode, wt, add, K, stride, pad_t, pad_l, H, W):
-    _chk(dy, wt, add)
+    h = _act(dy, add)
+    _chk(wt)
     N, Ho, Wo, Cc = dy.shape
-    dx = empty((N, H, W, Cc), dy)
+    dx = empty((N, H, W, Cc), dy, dy.dtype)
     _call("ud_dwconv_bwd_data_ex", _p(dy), _p(gate_alpha), int(gate_mode), _p(wt), _p(add), _p(dx), N, H, W, Cc, Ho, Wo,
-          K, stride, pad_t, pad_l, _stream())
+          K, stride, pad_t, pad_l, h, _stream())
     return dx
 
 
 def dwconv_bwd_weight_ex(x, dy, gate_alpha, gate_mode, K, stride, pad_t, pad_l):
-    _chk(x, dy)
+    h = _act(x, dy)
     N, H, W, Cc = x.shape
     _, Ho, Wo, _ = dy.shape
-    chunks = max(1, min(N * Ho, -(-_DW_WGRAD_THREADS // Cc)))
+    lanes = Cc // 2 if h else Cc          # half: a lane owns two adjacent channels
+    chunks = max(1, min(N * Ho, -(-_DW_WGRAD_THREADS // lanes)))
     part = empty((chunks, K * K, Cc), x)
     dwt = empty((Cc, K * K), x)
     _call("ud_dwconv_bwd_weight_ex", _p(x), _p(dy), _p(gate_alpha), int(gate_mode), _p(dwt), _p(part), chunks, N, H, W,
-          Cc, Ho, Wo, K, stride, pad_t, pad_l, _stream())
+          Cc, Ho, Wo, K, stride, pad_t, pad_l, h, _stream())
     return dwt
 
 
@@ -1234,26 +1277,27 @@ def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None,
              gate_acc=None):
     """rfft2 of act(bn(x)) (bn optional) [* gate].  Returns (Y, activated input or None[, gate gradient when gate_acc:
     sigmoid'(alpha) * sum of the 64 accumulator slots])."""
-    _chk(x)
+    h = _act(x)
     N, S, S2, Cc = x.shape
     assert S == S2
-    Y = empty((N, S, S // 2 + 1, 2 * Cc), x)
+    Y = empty((N, S, S // 2 + 1, 2 * Cc), x, x.dtype)
     act = torch.empty_like(x) if (want_act and bn is not None) else None
     ggrad = empty((), x) if gate_acc is not None else None
     _call("ud_rfft2_ex", _p(x), _p(Y), N, S, Cc, float(scale), float(w_interior),
           C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode),
-          _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), _stream())
+          _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), h, _stream())
     return (Y, act, ggrad) if gate_acc is not None else (Y, act)
 
 
 def irfft2_mix(Y, scale, spat, alpha, acc):
     """(y, freq) = SF mix of spat with irfft2(Y); acc += [sum y | sum y^2]."""
-    _chk(Y, spat, alpha)
+    h = _act(Y, spat)
+    _chk(alpha)
     N, S, Wh, C2 = Y.shape
     Cc = C2 // 2
     assert spat.shape == (N, S, S, Cc)
     y = torch.empty_like(spat)
     fr = torch.empty_like(spat)
     _call("ud_irfft2_mix", _p(Y), _p(y), N, S, Cc, float(scale), 1.0, _p(spat), _p(alpha), _p(fr), _pd(acc),
-          _pd(acc, Cc), _stream())
+          _pd(acc, Cc), h, _stream())
     return y, fr

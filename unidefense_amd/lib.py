@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_long), ("ldb", C.c_long), ("ldc", C.c_long),
                 ("a_mode", C.c_int), ("b_mode", C.c_int), ("out_mode", C.c_int), ("split_k", C.c_int),
                 ("batch", C.c_int), ("strideA", C.c_long), ("strideB", C.c_long), ("strideC", C.c_long),
-                ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p)]
+                ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("half_mask", C.c_int)]
 
 
 class BnRef(C.Structure):
@@ -53,26 +53,26 @@ _SIGNATURES = {
     "ud_norm_bwd_apply": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P],
     "ud_group_colsum": [_P, _I, _I, _I, _F, _P, _P, _P],
     "ud_group_coldot": [_P, _P, _I, _I, _I, _F, _P, _P, _P],
-    "ud_dwconv_fwd": [_P, _P, _P] + [_I] * 10 + [_P],
-    "ud_dwconv_bwd_data": [_P, _P, _P, _P] + [_I] * 10 + [_P],
+    "ud_dwconv_fwd": [_P, _P, _P] + [_I] * 10 + [_I, _P],
+    "ud_dwconv_bwd_data": [_P, _P, _P, _P] + [_I] * 10 + [_I, _P],
     "ud_dw_weights_tapmajor": [_P, _I, _L, _P, _P],
     "ud_dwconv_bwd_weight_parts": [_I, _I],
     "ud_dwconv_bwd_weight": [_P, _P, _P, _P, _I] + [_I] * 10 + [_P],
-    "ud_rfft2": [_P, _P, _I, _I, _I, _F, _F, _P],
-    "ud_irfft2": [_P, _P, _I, _I, _I, _F, _F, _P],
+    "ud_rfft2": [_P, _P, _I, _I, _I, _F, _F, _I, _P],
+    "ud_irfft2": [_P, _P, _I, _I, _I, _F, _F, _I, _P],
     "ud_fc_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ud_fc_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ud_se_scale_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "ud_se_scale_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "ud_sigmoid_grad_mul": [_P, _P, _L, _P],
     "ud_sfmix_blocks": [_I, _I, _I, _I],
-    "ud_sfmix_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "ud_sfmix_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ud_sfmix_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ud_sfmix_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ud_gate_mix_blocks": [_L],
     "ud_gate_mix_fwd": [_P, _P, _P, _P, _L, _P],
     "ud_gate_mix_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "ud_residual_fwd": [_P, _P, _P, _F, _P, _L, _L, _P],
-    "ud_axpby": [_P, _F, _P, _F, _P, _L, _P],
+    "ud_axpby": [_P, _F, _P, _F, _P, _L, _I, _P],
     "ud_mask_scale": [_P, _P, _F, _P, _L, _P],
     "ud_absdiff": [_P, _P, _P, _L, _P],
     "ud_bcast_rows": [_P, _F, _P, _I, _I, _I, _P],
@@ -107,38 +107,44 @@ _SIGNATURES = {
     "ud_affine3": [_P, _P, _P, _I, _I, _P],
     # fused MBConv path (csrc/fused.hip, csrc/fft.hip)
     "ud_fused_reduce_ws_doubles": [_I, _I, _I, _I, _I],
-    "ud_colstats": [_P, _I, _I, _I, _P, _P, _P, _P],
-    "ud_colsum_bn": [_P, _BN, _I, _I, _I, _P, _P, _P],
-    "ud_coldot_bn": [_P, _P, _BN, _I, _I, _I, _P, _P, _P],
+    "ud_colstats": [_P, _I, _I, _I, _P, _P, _P, _I, _P],
+    "ud_colsum_bn": [_P, _BN, _I, _I, _I, _P, _P, _I, _P],
+    "ud_coldot_bn": [_P, _P, _BN, _I, _I, _I, _P, _P, _I, _P],
     "ud_fc_fwd_d": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
-    "ud_se_scale_bn": [_P, _BN, _P, _P, _I, _I, _I, _P],
-    "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _P],
-    "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _P],
-    "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
-    "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "ud_se_scale_bn": [_P, _BN, _P, _P, _I, _I, _I, _I, _P],
+    "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P],
+    "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
+    "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "ud_gate_grad_from_acc": [_P, _P, _P, _P],
     "ud_se_bwd_a": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "ud_se_bwd_b": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P],
-    "ud_se_scale_bwd_bn": [_P, _P, _BN, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
-    "ud_bn_apply": [_P, _BN, _P, _I, _I, _I, _P],
-    "ud_dwconv_bwd_data_bn": [_P, _P, _I, _P, _P, _P, _BN, _P, _P, _P, _P] + [_I] * 10 + [_P],
+    "ud_se_scale_bwd_bn": [_P, _P, _BN, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ud_bn_apply": [_P, _BN, _P, _I, _I, _I, _I, _P],
+    "ud_dwconv_bwd_data_bn": [_P, _P, _I, _P, _P, _P, _BN, _P, _P, _P, _P] + [_I] * 10 + [_I, _P],
     "ud_dwconv_bwd_data_bn_ws_doubles": [_I, _I, _I, _I, _I],
-    "ud_dwconv_bwd_data_ex": [_P, _P, _I, _P, _P, _P] + [_I] * 10 + [_P],
-    "ud_dwconv_bwd_weight_ex": [_P, _P, _P, _I, _P, _P, _I] + [_I] * 10 + [_P],
-    "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _P],
-    "ud_irfft2_mix": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P],
+    "ud_dwconv_bwd_data_ex": [_P, _P, _I, _P, _P, _P] + [_I] * 10 + [_I, _P],
+    "ud_dwconv_bwd_weight_ex": [_P, _P, _P, _I, _P, _P, _I] + [_I] * 10 + [_I, _P],
+    "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P],
+    "ud_irfft2_mix": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "ud_rfft2_planes_ws_floats": [_L, _I],
     "ud_rfft2_planes": [_P, _P, _P, _L, _I, _F, _P],
     "ud_rfft2_planes_adjoint": [_P, _P, _P, _L, _I, _F, _P],
     "ud_adamw_chunk_elems": [],
     "ud_adamw_multi": [_P, _P, _I, _P, _P, _I, C.c_double, C.c_double, C.c_double, _I, _I, _P, _P, _P, _P, _P],
+    "ud_xchg_bytes": [_I, _I, _I],
+    "ud_xchg_create": [_I, _I, _I, _P, _P],
+    "ud_xchg_open": [_P, _P],
+    "ud_xchg_close": [_P],
+    "ud_xchg_destroy": [_P],
+    "ud_xchg_allreduce": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _L, _P],
 }
 
 # helpers that return a count rather than a status code
 _COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
-                "ud_conv_small_wgrad_ws_floats"}
-_LONG_FUNCS = {"ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
+                "ud_conv_small_wgrad_ws_floats", "ud_xchg_bytes"}
+_LONG_FUNCS = {"ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
                "ud_dwconv_bwd_data_bn_ws_doubles"}        # return a C long
 
 EXPORTED = tuple(_SIGNATURES)

@@ -105,6 +105,11 @@ _OUT_KEYS = ("cls_out", "rec", "factorization", "triplet0", "triplet1", "triplet
 _FUSED_MBCONV = os.environ.get("UD_FUSED_MBCONV", "1") == "1"
 
 
+def _half_storage(model):
+    """fp16 activation storage in the MBConv trunk: `model.half_storage = True` (or env UD_HALF_STORAGE=1)."""
+    return bool(getattr(model, "half_storage", os.environ.get("UD_HALF_STORAGE", "0") == "1"))
+
+
 class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, noise_x, rng, *params):
@@ -426,12 +431,18 @@ class UniDefenseModelEb4(nn.Module):
         T.DW_WT = {id(w): (w, w._version, wts[id(w)]) for w in ws}       # looked up by the unfused tape.dwconv
 
         x_pix = K.planes_to_pix(x if noise_x is None else noise_x)       # [N,H,W,3]
+        # Half storage (BASELINE configs[4]): the MBConv trunk keeps its activations and their gradients in fp16 (fp32
+        # registers, fp64 BatchNorm sums, fp32 weights / weight gradients, fp16 MFMA); stem conv, decoder, attention,
+        # head and losses stay fp32 — T.cast at the boundaries.  Fused training path only.
+        st16 = self.training and _FUSED_MBCONV and _half_storage(self)
+        f32 = torch.float32
         if self.training and _FUSED_MBCONV:
-            dp = T.DataParallelCtx(self._sync_group(bb._bn0))
+            dp = T.DataParallelCtx(self._sync_group(bb._bn0), getattr(self, "_bn_exchange", None))
             rng["_fused"] = {"wt": wts, "dp": dp}
             if bb._bn0.num_batches_tracked is not None:
                 self.__dict__.setdefault("_nbt_pending", []).append(bb._bn0.num_batches_tracked)
-            h, lazy = T.stem_fused(tape, x_pix, bb._conv_stem.weight, bb._bn0, 2, pt, pl, Ho, Wo, dp)
+            h, lazy = T.stem_fused(tape, x_pix, bb._conv_stem.weight, bb._bn0, 2, pt, pl, Ho, Wo, dp,
+                                   torch.float16 if st16 else f32)
             x_b0 = self._blocks(tape, h, 0, rng, lazy)
         else:
             h = T.conv_dense(tape, x_pix, bb._conv_stem.weight, 2, pt, pl, Ho, Wo, need_dx=False)
@@ -440,7 +451,8 @@ class UniDefenseModelEb4(nn.Module):
         x_b1 = self._blocks(tape, x_b0, 1, rng)
         x_b2 = self._blocks(tape, x_b1, 2, rng)
         x_b3 = self._blocks(tape, x_b2, 3, rng)
-        x_b4 = self._blocks(tape, x_b3, 4, rng)
+        x_b4h = self._blocks(tape, x_b3, 4, rng)
+        x_b4 = T.cast(tape, x_b4h, f32)
 
         d_in = x_b4
         # F.dropout(x_b4, 0.2), unidefense.py:213 (hard-coded rate; `_dec_dropout = False` lets a test switch the
@@ -452,9 +464,9 @@ class UniDefenseModelEb4(nn.Module):
         dec3_pix = self._decoder(tape, dec2, self.dec_block3, True)
         dec3 = T.tanh_to_planes(tape, dec3_pix)                          # [N,3,128,128]
 
-        x_b5 = self._blocks(tape, x_b4, 5, rng)
+        x_b5 = T.cast(tape, self._blocks(tape, x_b4h, 5, rng), f32)
         att, freq_mask, spat_mask = self._attention(tape, dec3, x, x_b5, rng)
-        x_b6 = self._blocks(tape, att, 6, rng)
+        x_b6 = T.cast(tape, self._blocks(tape, T.cast(tape, att, torch.float16) if st16 else att, 6, rng), f32)
 
         h = T.conv1x1(tape, x_b6, bb._conv_head.weight)
         h = self._bn(tape, h, bb._bn1, 1)

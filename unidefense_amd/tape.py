@@ -706,8 +706,9 @@ class DataParallelCtx:
     """SyncBatchNorm context of the fused path: the fp64 accumulators are summed over the ranks in place (one
     all_reduce between the producing and the consuming kernels), counts are multiplied by the world size."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, exchange=None):
         self.group, self.world, self.synced = group, 1, False
+        self.exchange = exchange            # engine.parallel.BnExchange (one kernel per sum) or None (dist.all_reduce)
         if group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(group)
@@ -717,9 +718,12 @@ class DataParallelCtx:
         """Sum `acc` over the ranks in place; returns this rank's own sums (a copy) when keep_local, else None."""
         if not self.synced:
             return None
-        import torch.distributed as dist
         loc = acc.clone() if keep_local else None
-        dist.all_reduce(acc, group=self.group)
+        if self.exchange is not None and acc.numel() <= self.exchange.MAX_DOUBLES:
+            self.exchange.allreduce(acc)
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(acc, group=self.group)
         return loc
 
 
@@ -736,9 +740,26 @@ def _bn_of(mod, acc, count, act):
                         mod.momentum if mod.momentum is not None else 0.1, mod.running_mean, mod.running_var)
 
 
-def stem_fused(tape, x_pix, w, bn_mod, stride, pad_t, pad_l, Ho, Wo, dp):
-    """Stem conv (model/efficientnet/model.py:185-186) whose BatchNorm + swish is left to block 0's depthwise conv."""
-    h = conv_dense(tape, x_pix, w, stride, pad_t, pad_l, Ho, Wo, need_dx=False)
+def cast(tape, x, dtype):
+    """Storage-type boundary of the half-storage trunk (fp16 activations between the fp32 stem / decoder / attention /
+    head): y = x.to(dtype), the gradient converted back."""
+    if x.dtype == dtype:
+        return x
+    y = x.to(dtype)
+    if _needs(tape):
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is not None:
+                tape.add_grad(x, g.reshape(x.shape).to(x.dtype))
+        tape.record(bwd)
+    return y
+
+
+def stem_fused(tape, x_pix, w, bn_mod, stride, pad_t, pad_l, Ho, Wo, dp, storage=torch.float32):
+    """Stem conv (model/efficientnet/model.py:185-186) whose BatchNorm + swish is left to block 0's depthwise conv.
+    storage: dtype the trunk keeps its activations in (torch.float16: the raw conv output is handed on rounded)."""
+    h32 = conv_dense(tape, x_pix, w, stride, pad_t, pad_l, Ho, Wo, need_dx=False)
+    h = h32 if storage == torch.float32 else h32.to(storage)
     Cc = h.shape[-1]
     M = h.numel() // Cc
     acc = K.zeros64(2 * Cc, h)
@@ -751,7 +772,7 @@ def stem_fused(tape, x_pix, w, bn_mod, stride, pad_t, pad_l, Ho, Wo, dp):
         dh, dg, db = K.normbwd_apply(h, dz, None, 1.0, bn, is_dz, 1, M, sacc, loc)
         tape.add_param_grad(bn_mod.weight, dg)
         tape.add_param_grad(bn_mod.bias, db)
-        tape.add_grad(h, dh)
+        tape.add_grad(h32, dh if dh.dtype == h32.dtype else dh.to(h32.dtype))
     return h, LazyInput(bn, backward)
 
 
