@@ -274,6 +274,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    bn_exchange = getattr(model, "bn_exchange", None)
+    if bn_exchange is not None and bn_exchange.ok:
+        bn_exchange.check()          # a rank that timed out waiting for a peer's SyncBN sums: fail loudly, no line
     n_ranks_seen = 1
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -334,6 +337,9 @@ def main():
                        f"{args.model} {args.size}x{args.size} fwd + pass-1 loss + bwd, bs={bs}/GPU, dtype {args.dtype} (informational)",
                        "global_batch": world * bs, "parallelism": f"dp{world}", "exec": exec_mode,
                        "n_ranks_seen": n_ranks_seen,
+                       # SyncBN sums of the fused path: "peer-exchange" (csrc/xchg.hip mailboxes over xGMI) or "all_reduce" (RCCL)
+                       "syncbn": ("peer-exchange" if (bn_exchange is not None and bn_exchange.ok) else "all_reduce")
+                       if (world > 1 or force) else "local",
                        "final_loss": float(loss.detach()),
                        # checksum of the step's result (tests: the data-parallel path at world size 1 must give
                        # the plain step's gradients)

@@ -432,10 +432,11 @@ int ud_rfft2_planes_adjoint(const float* dY, float* dx, float* ws, long P, int S
 /* ---- one-shot SyncBatchNorm exchange (csrc/xchg.hip) ---------------------------------------------------------------
  * Replaces the per-BatchNorm library collectives of nn.SyncBatchNorm (engine/forgery_engine.py:142) on one node: every
  * rank owns a mailbox in fine-grained device memory mapped into its peers through HIP IPC; ud_xchg_allreduce is ONE
- * single-workgroup kernel that writes the rank's doubles into every mailbox (peer writes over xGMI), raises a flag,
- * waits for all ranks' flags and sums the rows in rank order (bit-identical on all ranks).  The sequence number is a
- * device word advanced by the kernel (hipGraph replays keep counting); a peer that does not arrive within spin_limit
- * polls sets *err (1 + its rank) instead of hanging.  Setup: ud_xchg_create on every rank, handles exchanged by the
+ * small kernel (a thread per double) that writes the rank's doubles, tagged with the exchange's sequence number, into
+ * every mailbox (peer writes over xGMI), polls the own mailbox until all ranks' words carry the tag and sums the rows
+ * in rank order (bit-identical on all ranks) — no fences, no separate flags.  seq_counter: two zero-initialised device
+ * words advanced by the kernel (hipGraph replays keep counting); a peer that does not arrive within spin_limit polls
+ * sets *err (1 + its rank) instead of hanging.  world <= 16.  Setup: ud_xchg_create on every rank, handles exchanged by the
  * host (64 bytes each), ud_xchg_open on every peer's handle, the `world` pointers (own base at [rank]) copied to a
  * device array.  max_doubles bounds n; slots >= 2 (a rank is never more than one exchange ahead of the slowest). */
 long ud_xchg_bytes(int world, int max_doubles, int slots);

@@ -3,16 +3,17 @@
 //
 // The fused MBConv path sums 2C fp64 accumulators over the ranks ~200 times per step (tape.DataParallelCtx.reduce);
 // each is at most 52 KB, so a library collective is pure latency (launch + protocol, ~15-25 us at 8 ranks).  Here every
-// rank owns a MAILBOX in fine-grained device memory, mapped into all peers through HIP IPC.  One kernel per exchange,
-// one workgroup:
-//   1. write this rank's n doubles into slot (seq % slots), row `rank` of EVERY rank's mailbox (peer writes over xGMI),
-//      fence at system scope, then release-store the sequence number into the matching flag of every mailbox;
-//   2. wait until all `world` flags of the own mailbox show this sequence number;
-//   3. sum the `world` rows in rank order (the same order on every rank: bit-identical results) into acc.
+// rank owns a MAILBOX in fine-grained device memory, mapped into all peers through HIP IPC, and an exchange is ONE
+// small kernel (one thread per double) speaking a flag-in-data protocol (no fences, no cache flushes, no separate flag round trip):
+//   * a double travels as two 8-byte words {low half | seq, high half | seq}, each an atomic system-scope store into
+//     slot (seq % slots), row `rank` of EVERY rank's mailbox (peer writes over xGMI);
+//   * the reader polls the words of all `world` rows of its OWN mailbox until they carry this exchange's sequence tag,
+//     and adds the rows in rank order (the same order on every rank: bit-identical results) into acc.
 // The sequence number lives in device memory and is advanced by the kernel, so a hipGraph replay of the step keeps
 // counting.  Slots: a rank can be at most one exchange ahead of the slowest (exchange k+1 cannot complete before
 // everyone has entered it, i.e. left exchange k), so two slots suffice; four are used.  The wait is bounded: a peer
-// that never arrives raises *err instead of hanging the GPU.
+// that never arrives raises *err instead of hanging the GPU.  (A first version with plain stores + system-scope
+// release / acquire fences cost 9.5 us per exchange on one device: the fences write back and invalidate the L2.)
 #include <string.h>
 
 #include "ud_common.h"
@@ -21,62 +22,75 @@ namespace {
 
 constexpr int NT = 256;
 
-struct Mailbox {
-    double* data;                  // [slots][world][max_doubles]
-    unsigned long long* flags;     // [slots][world]
-};
-__host__ __device__ inline Mailbox mailbox_of(void* base, int world, int max_doubles, int slots) {
-    Mailbox m;
-    m.data = reinterpret_cast<double*>(base);
-    m.flags = reinterpret_cast<unsigned long long*>(m.data + (long)slots * world * max_doubles);
-    return m;
-}
-inline size_t mailbox_bytes(int world, int max_doubles, int slots) {
-    return ((size_t)slots * world * max_doubles + (size_t)slots * world) * 8;
-}
+typedef unsigned long long u64;
 
+// words[slots][world][max_doubles][2]
+__host__ __device__ inline u64* mailbox_row(void* base, int world, int max_doubles, int slot, int r) {
+    return reinterpret_cast<u64*>(base) + ((long)slot * world + r) * max_doubles * 2;
+}
+inline size_t mailbox_bytes(int world, int max_doubles, int slots) { return (size_t)slots * world * max_doubles * 16; }
+
+constexpr int MAXW = 16;          // ranks of one node
+
+// grid: ceil(n / NT) workgroups, one element per thread — a single poll round trip whatever n is.  The workgroups are
+// independent (the protocol needs no cross-workgroup step); counters[0] = exchanges completed, counters[1] = workgroups
+// of the running exchange that have read counters[0]: the last of them advances the sequence number.
 __global__ __launch_bounds__(NT) void xchg_allreduce_kernel(double* __restrict__ acc, int n, void* const* __restrict__ peers,
                                                             int rank, int world, int max_doubles, int slots,
-                                                            unsigned long long* __restrict__ seq_counter,
-                                                            int* __restrict__ err, long spin_limit) {
-    const int tid = threadIdx.x;
-    const unsigned long long seq = *seq_counter + 1;
-    const int slot = (int)(seq % (unsigned long long)slots);
-    // 1. publish
-    for (int r = 0; r < world; ++r) {
-        double* dst = mailbox_of(peers[r], world, max_doubles, slots).data + ((long)slot * world + rank) * max_doubles;
-        for (int i = tid; i < n; i += NT) __hip_atomic_store(dst + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (tid < world) {
-        unsigned long long* f = mailbox_of(peers[tid], world, max_doubles, slots).flags + (long)slot * world + rank;
-        __hip_atomic_store(f, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // 2. wait for every rank's row of the own mailbox
-    const Mailbox mine = mailbox_of(peers[rank], world, max_doubles, slots);
-    if (tid < world) {
-        const unsigned long long* f = mine.flags + (long)slot * world + tid;
-        long spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > spin_limit) {
-                atomicExch(err, 1 + tid);          // rank `tid` never arrived: results below are garbage, the host checks
-                break;
-            }
+                                                            u64* __restrict__ counters, int* __restrict__ err,
+                                                            long spin_limit) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const u64 seq = __hip_atomic_load(counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __syncthreads();                                            // every wave of this workgroup has read it
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const u64 arrived = atomicAdd(counters + 1, 1ull) + 1;
+        if (arrived == gridDim.x) {                             // all workgroups have read counters[0]
+            __hip_atomic_store(counters + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(counters, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    // 3. sum in rank order
-    const double* rows = mine.data + (long)slot * world * max_doubles;
-    for (int i = tid; i < n; i += NT) {
-        double s = 0.0;
-        for (int r = 0; r < world; ++r)
-            s += __hip_atomic_load(rows + (long)r * max_doubles + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        acc[i] = s;
+    if (i >= n) return;
+    const int slot = (int)(seq % (u64)slots);
+    u64 tag = seq & 0xffffffffull;
+    if (tag == 0) tag = 0x80000000ull;                         // 0 is what a fresh mailbox holds
+    tag <<= 32;
+    // 1. publish
+    const u64 bits = (u64)__double_as_longlong(acc[i]);
+    const u64 w0 = (bits & 0xffffffffull) | tag, w1 = (bits >> 32) | tag;
+    for (int r = 0; r < world; ++r) {
+        u64* dst = mailbox_row(peers[r], world, max_doubles, slot, rank) + 2 * i;
+        __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (tid == 0) *seq_counter = seq;
+    // 2. collect: poll the words of every row of the own mailbox until they carry this exchange's tag; rank-ordered sum
+    void* mine = peers[rank];
+    u64 lo[MAXW], hi[MAXW];
+    unsigned pending = (1u << world) - 1u;
+    long spins = 0;
+    while (pending) {
+#pragma unroll
+        for (int r = 0; r < MAXW; ++r) {
+            if (r < world && ((pending >> r) & 1u)) {
+                const u64* src = mailbox_row(mine, world, max_doubles, slot, r) + 2 * i;
+                lo[r] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                hi[r] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MAXW; ++r)
+            if (r < world && (lo[r] & 0xffffffff00000000ull) == tag && (hi[r] & 0xffffffff00000000ull) == tag)
+                pending &= ~(1u << r);
+        if (pending && ++spins > spin_limit) {
+            atomicExch(err, __ffs(pending));                    // 1 + the lowest rank that never arrived
+            break;
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXW; ++r)
+        if (r < world) s += __longlong_as_double((long long)((lo[r] & 0xffffffffull) | (hi[r] << 32)));
+    acc[i] = s;
 }
 
 }  // namespace
@@ -91,7 +105,7 @@ long ud_xchg_bytes(int world, int max_doubles, int slots) {
 // Allocates this rank's mailbox (fine-grained device memory, zeroed) and exports it: handle receives the 64 bytes of a
 // hipIpcMemHandle_t for the peers' ud_xchg_open.
 int ud_xchg_create(int world, int max_doubles, int slots, void** base, char* handle) {
-    if (world < 1 || max_doubles < 1 || slots < 2 || !base || !handle) return UD_EINVAL;
+    if (world < 1 || world > MAXW || max_doubles < 1 || slots < 2 || !base || !handle) return UD_EINVAL;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
     void* p = nullptr;
     const size_t bytes = mailbox_bytes(world, max_doubles, slots);
@@ -131,15 +145,16 @@ int ud_xchg_destroy(void* base) {
 }
 
 // acc[0..n) <- sum over the ranks, in place.  peers: DEVICE array of `world` mailbox pointers in rank order (the own
-// one at [rank]); seq_counter / err: device words owned by the caller (zero-initialised).  spin_limit: polls (each
+// one at [rank]); seq_counter: TWO device words (exchanges completed, workgroups arrived) and err: one, owned by the
+// caller, zero-initialised.  spin_limit: polls (each
 // ~64 cycles apart) before a missing peer is reported through *err.
 int ud_xchg_allreduce(double* acc, int n, void* const* peers, int rank, int world, int max_doubles, int slots,
                       unsigned long long* seq_counter, int* err, long spin_limit, ud_stream_t stream) {
-    if (!acc || n < 1 || n > max_doubles || !peers || rank < 0 || rank >= world || world > NT || slots < 2 ||
+    if (!acc || n < 1 || n > max_doubles || !peers || rank < 0 || rank >= world || world > MAXW || slots < 2 ||
         !seq_counter || !err || spin_limit < 1)
         return UD_EINVAL;
-    hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, acc, n, peers, rank, world,
-                       max_doubles, slots, seq_counter, err, spin_limit);
+    hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(ud_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, acc, n, peers,
+                       rank, world, max_doubles, slots, seq_counter, err, spin_limit);
     UD_LAUNCH_CHECK();
     return 0;
 }

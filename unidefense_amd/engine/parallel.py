@@ -125,7 +125,7 @@ class BnExchange:
         if int(flag.item()) != 1:
             return
         self.peers = torch.tensor(ptrs, dtype=torch.int64, device=device)
-        self.seq = torch.zeros(1, dtype=torch.int64, device=device)
+        self.seq = torch.zeros(2, dtype=torch.int64, device=device)     # exchanges completed, workgroups arrived
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
         self.ok = True
         self.ok = self._self_test()

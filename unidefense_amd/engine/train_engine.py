@@ -126,6 +126,9 @@ class TrainEngine(AbstractEngine):
                 correct += (out["cls_out"].argmax(1) == in_tgt).sum()
                 seen += in_tgt.numel()
                 if cur_step % self.log_steps == 0 or cur_step == self.num_steps:
+                    exchange = getattr(self.model, "bn_exchange", None)
+                    if exchange is not None and exchange.ok:
+                        exchange.check()         # SyncBN peer exchange: a missing rank surfaces here, not as a silent NaN
                     keys = sorted(sums)
                     vals = self._mean_over_ranks([sums[k] / count for k in keys] + [correct / seen])
                     last = dict(zip(keys, vals[:-1]))
