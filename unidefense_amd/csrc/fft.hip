@@ -18,6 +18,8 @@
 // one read of the input and one write of the output.
 #include "ud_common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace {
@@ -167,6 +169,25 @@ __device__ __forceinline__ void fft_inreg(float (&re)[S], float (&im)[S]) {
     }
 }
 
+// XCD-aware work order.  Workgroups are dealt round-robin to the 8 XCDs by linear id, so with the plain (channel group,
+// sample) = blockIdx map the channel groups that share a 128-byte line of a pixel (CB = 8 / 16 channels: 32 / 64-byte
+// runs) land on different XCDs and every one of them pulls the whole line into its own L2.  Here XCD j works through a
+// CONTIGUOUS range of the (sample, channel group) items: neighbouring channel groups of a sample meet in one L2.
+// (UD_FFT_XCD=0 restores the plain order — A/B switch read on the host and passed as xcd_remap.)
+__device__ __forceinline__ void work_item(int xcd_remap, int& cgroup, int& n) {
+    const int ngroups = gridDim.x;
+    if (!xcd_remap) {
+        cgroup = blockIdx.x;
+        n = blockIdx.y;
+        return;
+    }
+    const int W = gridDim.x * gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = W >> 3, r = W & 7, xcd = L & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);      // bijective for any W
+    cgroup = w % ngroups;
+    n = w / ngroups;
+}
+
 template <int S, int CB>
 struct Lds {
     static constexpr int WH = S / 2 + 1;
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
                                                    float scale, float w_int, ud_bn_ref bn, int has_bn,
                                                    T* __restrict__ act_out, const float* __restrict__ gate_alpha,
                                                    int gate_mode, const double* __restrict__ gate_acc,
-                                                   float* __restrict__ gate_grad) {
+                                                   float* __restrict__ gate_grad, int xcd_remap) {
     using L = Lds<S, CB>;
     // EX, backward of the SF mix: the 64 slots a preceding kernel (ud_normbwd_apply_mix) filled with
     // sum dd * (freq - spat) become the gate's gradient here, by one wave, instead of a launch of their own
@@ -200,8 +221,9 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
     float* Lim = lds + L::PLANE;
     const int t = threadIdx.x;
     const int c = t % CB, q = t / CB;          // q = h in pass 1, kx in pass 2   (q in [0, S))
-    const int n = blockIdx.y;
-    const int ch = blockIdx.x * CB + c;
+    int cgroup, n;
+    work_item(xcd_remap, cgroup, n);
+    const int ch = cgroup * CB + c;
     const bool cok = ch < C;
     float re[S], im[S];
     // ---- pass 1: rows   (S * CB may be < 512 for the 5*2^k sizes: q >= S idles)
@@ -269,15 +291,16 @@ template <typename T, int S, int CB, bool MIX>
 __global__ __launch_bounds__(NT) void irfft2_kernel(const T* __restrict__ Y, T* __restrict__ x, int C,
                                                     float scale, float w_int, const T* __restrict__ spat,
                                                     const float* __restrict__ alpha, T* __restrict__ freq_out,
-                                                    double* __restrict__ sum, double* __restrict__ sumsq) {
+                                                    double* __restrict__ sum, double* __restrict__ sumsq, int xcd_remap) {
     using L = Lds<S, CB>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Lre = lds;
     float* Lim = lds + L::PLANE;
     const int t = threadIdx.x;
     const int c = t % CB, q = t / CB;          // q = kx in pass 1, h in pass 2
-    const int n = blockIdx.y;
-    const int ch = blockIdx.x * CB + c;
+    int cgroup, n;
+    work_item(xcd_remap, cgroup, n);
+    const int ch = cgroup * CB + c;
     const bool cok = ch < C;
     float re[S], im[S];
     // ---- pass 1: inverse transform along ky for each kept column kx.  Only S/2+1 of the S thread-rows own a column;
@@ -378,6 +401,12 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const T* __restrict__ Y, T* 
     }
 }
 
+// remap only where a workgroup's run of channels is shorter than a 128-byte line
+inline int xcd_remap_on(int run_bytes) {
+    static const bool on = !getenv("UD_FFT_XCD") || atoi(getenv("UD_FFT_XCD")) != 0;
+    return on && run_bytes < 128;
+}
+
 struct RfftEx {
     const ud_bn_ref* bn;
     void* act_out;
@@ -401,7 +430,7 @@ int launch_rfft2_t(const T* x, T* Y, int N, int C, float scale, float w_int, con
     ud_bn_ref none{};
     hipLaunchKernelGGL((rfft2_kernel<T, S, CB, EX>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
                        ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, (T*)ex.act_out, ex.gate_alpha, ex.gate_mode, ex.gate_acc,
-                       ex.gate_grad);
+                       ex.gate_grad, xcd_remap_on(CB * (int)sizeof(T)));
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -433,7 +462,7 @@ int launch_irfft2_t(const T* Y, T* x, int N, int C, float scale, float w_int, co
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
     hipLaunchKernelGGL((irfft2_kernel<T, S, CB, MIX>), grid, dim3(NT), L::BYTES, s, Y, x, C, scale, w_int,
-                       (const T*)m.spat, m.alpha, (T*)m.freq_out, m.sum, m.sumsq);
+                       (const T*)m.spat, m.alpha, (T*)m.freq_out, m.sum, m.sumsq, xcd_remap_on(CB * (int)sizeof(T)));
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -698,32 +698,41 @@ __global__ __launch_bounds__(NT) void dw_bwd_weight_rows_ex(DwGeom q, int C, int
     for (int i = 0; i < K * K; ++i) *reinterpret_cast<VF*>(out + (long)i * C) = acc[i];
 }
 
-// 64 lanes per output (4 partials in flight per lane), fp64 accumulation; result in the parameter's layout
-// dw[C][K*K], scaled by the gate
+// 16 lanes x 4 consecutive outputs (one 16-byte load per partial) x 16 part-slices per block, 4 partials in flight per
+// thread, fp64 accumulation; result in the parameter's layout dw[C][K*K], scaled by the gate.  KKC % 4 == 0 (C % 4 == 0).
 __global__ __launch_bounds__(NT) void dw_bwd_weight_finalize_ex(int nparts, int KK, int C, const float* __restrict__ part,
                                                                 const float* __restrict__ gate_alpha, int gate_mode,
                                                                 float* __restrict__ dw) {
     const int KKC = KK * C;
-    // a wave owns 64 consecutive outputs for a slice of the parts; 4 waves = 4 slices, folded through LDS
-    __shared__ double sm[NT];
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    double a = 0.0;
+    __shared__ double sm[16][16][4];
+    const int lane = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = (blockIdx.x * 16 + lane) * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
     if (i < KKC) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(part + i);
+        const long step = (long)KKC / 4;          // f32x4 stride between partials
         int p = sl;
-        for (; p + 12 < nparts; p += 16) {
-            const float a0 = part[(long)p * KKC + i], a1 = part[(long)(p + 4) * KKC + i];
-            const float a2 = part[(long)(p + 8) * KKC + i], a3 = part[(long)(p + 12) * KKC + i];
-            a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        for (; p + 48 < nparts; p += 64) {
+            const f32x4 v0 = p4[(long)p * step], v1 = p4[(long)(p + 16) * step];
+            const f32x4 v2 = p4[(long)(p + 32) * step], v3 = p4[(long)(p + 48) * step];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += ((double)v0[e] + (double)v1[e]) + ((double)v2[e] + (double)v3[e]);
         }
-        for (; p < nparts; p += 4) a += (double)part[(long)p * KKC + i];
+        for (; p < nparts; p += 16) {
+            const f32x4 v = p4[(long)p * step];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += (double)v[e];
+        }
     }
-    sm[threadIdx.x] = a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[sl][lane][e] = a[e];
     __syncthreads();
-    if (sl == 0 && i < KKC) {
-        a += sm[64 + lane] + sm[128 + lane] + sm[192 + lane];
-        const int tap = i / C, c = i % C;
-        dw[(long)c * KK + tap] = (float)(a * (double)gate_factor(gate_alpha, gate_mode));
+    if (sl < 4 && i < KKC) {                     // thread (lane, e = sl) folds the 16 slices of output i + e
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][lane][sl];
+        const int o = i + sl, tap = o / C, c = o % C;
+        dw[(long)c * KK + tap] = (float)(t * (double)gate_factor(gate_alpha, gate_mode));
     }
 }
 
