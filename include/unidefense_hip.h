@@ -373,10 +373,11 @@ int ud_se_scale_bwd_bn(const void* dc, const void* x, const ud_bn_ref* bn, const
     float inv_hw, void* dz, double* s1, double* s2, double* ws, int G, int R, int C, int f16, ud_stream_t
     stream);
 /* ud_normbwd_apply (dy_is_dz) fused with the gradient of the SF mix y = (1-a) spat + a freq (exp.py:61-65):
- * writes dd = dL/dy and accumulates sum dd * (freq - spat) into the 64 slots dalpha_acc[0..64) (zeroed by the caller) */
+ * writes dd = dL/dy and accumulates sum dd * diff, diff = freq - spat as stored by ud_irfft2_mix, into the 64 slots
+ * dalpha_acc[0..64) (zeroed by the caller) */
 int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
-    const double* s1_local, const double* s2_local, const void* spat, const void* freq, int G, int R, int C,
-    void* dd, double* dalpha_acc, float* dgamma, float* dbeta, int f16, ud_stream_t stream);
+    const double* s1_local, const double* s2_local, const void* diff, int G, int R, int C, void* dd,
+    double* dalpha_acc, float* dgamma, float* dbeta, int f16, ud_stream_t stream);
 /* out[0] = sigmoid'(alpha[0]) * sum(acc[0..64))      (sf_coef gradient from the accumulator above) */
 int ud_gate_grad_from_acc(const double* acc, const float* alpha, float* out, ud_stream_t stream);
 /* y = act(bn(x)): the materialised form for consumers that re-read their input per tap (a plain depthwise conv and its
@@ -403,10 +404,11 @@ int ud_dwconv_bwd_weight_ex(const void* x, const void* dy, const float* gate_alp
 int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
     void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad, int f16,
     ud_stream_t stream);
-/* irfft2 + SF mix + BN1 statistics (exp.py:60-65, stride 1):  freq_out = irfft2(Y) * scale;
- * y = (1 - a) spat + a freq_out, a = sigmoid(alpha[0]);  sum[c] += sum y, sumsq[c] += sum y^2 */
+/* irfft2 + SF mix + BN1 statistics (exp.py:60-65, stride 1):  freq = irfft2(Y) * scale;
+ * y = (1 - a) spat + a freq, a = sigmoid(alpha[0]);  diff_out = freq - spat (what the backward needs of the two
+ * branches: neither has to be kept);  sum[c] += sum y, sumsq[c] += sum y^2 */
 int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, float w_interior, const void* spat,
-    const float* alpha, void* freq_out, double* sum, double* sumsq, int f16, ud_stream_t stream);
+    const float* alpha, void* diff_out, double* sum, double* sumsq, int f16, ud_stream_t stream);
 
 /* ---- multi-tensor AdamW (csrc/optim.hip) ------------------------------------------------------------------------
  * torch.optim.AdamW(amsgrad) over timm's weight-decay groups (engine/forgery_engine.py:149-156) with GradScaler's

@@ -285,7 +285,8 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
 }
 
 // x[n][h][w][c] = scale * C2R( f(kx) * Y[n][ky][kx][c] )   with the Hermitian extension along kx
-// MIX: freq_out = irfft2(Y) * scale;  x = (1 - a) spat + a freq_out, a = sigmoid(alpha[0]);  per-channel sums of x and
+// MIX: freq = irfft2(Y) * scale;  x = (1 - a) spat + a freq, a = sigmoid(alpha[0]);  freq_out = freq - spat (all the
+// backward needs of the two branches: the gate's gradient is sum dx * (freq - spat));  per-channel sums of x and
 // x^2 folded over the workgroup's rows through LDS and added (fp64 atomics) to sum / sumsq  (exp.py:60-65 + BN1 stats)
 template <typename T, int S, int CB, bool MIX>
 __global__ __launch_bounds__(NT) void irfft2_kernel(const T* __restrict__ Y, T* __restrict__ x, int C,
@@ -370,9 +371,9 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const T* __restrict__ Y, T* 
             T* fo = freq_out + o0;
 #pragma unroll
             for (int w = 0; w < S; ++w) {
-                const float fr = re[w] * scale;
-                const float y = ud_rounded<T>((float)sp[(long)w * C] * (1.f - a) + fr * a);
-                fo[(long)w * C] = (T)fr;
+                const float fr = re[w] * scale, spv = (float)sp[(long)w * C];
+                const float y = ud_rounded<T>(spv * (1.f - a) + fr * a);
+                fo[(long)w * C] = (T)(fr - spv);
                 dst[(long)w * C] = (T)y;
                 tot1 += (double)y;
                 tot2 += (double)y * (double)y;

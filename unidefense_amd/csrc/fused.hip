@@ -316,19 +316,19 @@ __global__ __launch_bounds__(NT) void normbwd_sums_kernel(RedGeom q, const T* __
     red_out<8>(q, ri, active, c4, v, s1, s2, part, false);      // batch-norm sums: one set for all groups
 }
 
-// MIX: also the SF-mix gradient: acc += dd * (freq - spat)
+// MIX: also the SF-mix gradient: acc += dd * diff, diff = freq - spat as written by ud_irfft2_mix
 template <typename T, bool MIX>
 __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* __restrict__ x,
                                                            const T* __restrict__ dy, const float* __restrict__ keep,
                                                            float inv_keep, ud_bn_ref bn, int dy_is_dz,
                                                            const double* __restrict__ s1, const double* __restrict__ s2,
                                                            const double* __restrict__ s1l, const double* __restrict__ s2l,
-                                                           const T* __restrict__ spat, const T* __restrict__ freq,
+                                                           const T* __restrict__ freq,
                                                            T* __restrict__ dx, double* __restrict__ dalpha_acc,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
-    const In4<T> x4{x}, d4{dy}, sp4{spat}, fr4{freq};
+    const In4<T> x4{x}, d4{dy}, fr4{freq};
     const Out4<T> o4{dx};
     double acc = 0.0;
     if (active) {
@@ -356,9 +356,9 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
             for (int e = 0; e < 4; ++e) o[e] = cb.ga[e] * cb.is[e] * (dz[e] - t1[e] - xh[e] * t2[e]);
             o4.st(w.idx, o);
             if (MIX) {
-                f32x4 s = sp4[w.idx], f = fr4[w.idx];
+                f32x4 f = fr4[w.idx];                    // freq - spat (ud_irfft2_mix)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc += (double)ud_rounded<T>(o[e]) * ((double)f[e] - (double)s[e]);
+                for (int e = 0; e < 4; ++e) acc += (double)ud_rounded<T>(o[e]) * (double)f[e];
             }
         }
     }
@@ -753,12 +753,14 @@ struct RedPlan {
 };
 inline RedPlan plan_reduce(int G, int R, int C, bool per_group, const double* ws, int min_rows = 8,
                            int row_elems = 1) {
-    RedGeom qa = make_geom_ex(G, R, C, 1024, 64, min_rows);
+    static const int lim = getenv("UD_ATOMIC_CONTRIB") ? atoi(getenv("UD_ATOMIC_CONTRIB")) : 64;
+    static const long big_elems = getenv("UD_ATOMIC_BIG") ? atol(getenv("UD_ATOMIC_BIG")) : (1L << 20);
+    RedGeom qa = make_geom_ex(G, R, C, 1024, lim, min_rows);
     const long contrib = per_group ? qa.P : (long)qa.G * qa.P;
     // >= 16 MB (row_elems pixels per row item): the pass is bandwidth-bound and wants ~2000 workgroups; its finalize
     // launch is noise
-    const bool big = (long)G * R * row_elems * (C / 4) >= (1L << 20);
-    if ((contrib <= 64 && !big) || !ws) return RedPlan{qa, false};
+    const bool big = (long)G * R * row_elems * (C / 4) >= big_elems;
+    if ((contrib <= lim && !big) || !ws) return RedPlan{qa, false};
     return RedPlan{make_geom_ex(G, R, C, 2048, 512, min_rows), true};
 }
 inline int finish_reduce(const RedPlan& pl, int nq, bool per_group, int C, const double* ws, double* a1, double* a2,
@@ -894,24 +896,23 @@ int ud_normbwd_apply(const void* x, const void* dy, const float* keep, float inv
     RedGeom q = geom_ew(G, R, C);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, false>), red_grid(q), dim3(NT), 0,
                                                 (hipStream_t)stream, q, (const T*)x, (const T*)dy, keep, inv_keep, *bn,
-                                                dy_is_dz, s1, s2, s1_local, s2_local, (const T*)nullptr,
-                                                (const T*)nullptr, (T*)dx, (double*)nullptr, dgamma, dbeta));
+                                                dy_is_dz, s1, s2, s1_local, s2_local, (const T*)nullptr, (T*)dx,
+                                                (double*)nullptr, dgamma, dbeta));
     UD_LAUNCH_CHECK();
     return 0;
 }
 
 int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
-                         const double* s1_local, const double* s2_local, const void* spat, const void* freq,
-                         int G, int R, int C, void* dd, double* dalpha_acc, float* dgamma, float* dbeta, int f16,
-                         ud_stream_t stream) {
-    if (!shape_ok(G, R, C) || !x || !dz || !bn || !s1 || !s2 || !dd || !spat || !freq || !dalpha_acc || bn->G != 1)
+                         const double* s1_local, const double* s2_local, const void* diff, int G, int R, int C,
+                         void* dd, double* dalpha_acc, float* dgamma, float* dbeta, int f16, ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !dz || !bn || !s1 || !s2 || !dd || !diff || !dalpha_acc || bn->G != 1)
         return UD_EINVAL;
     if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
     RedGeom q = make_geom_ex(G, R, C, 512, 4096, 4);      // one fp64 atomic per workgroup onto dalpha_acc
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, true>), red_grid(q), dim3(NT), 0,
                                                 (hipStream_t)stream, q, (const T*)x, (const T*)dz, (const float*)nullptr,
-                                                1.f, *bn, 1, s1, s2, s1_local, s2_local, (const T*)spat, (const T*)freq,
-                                                (T*)dd, dalpha_acc, dgamma, dbeta));
+                                                1.f, *bn, 1, s1, s2, s1_local, s2_local, (const T*)diff, (T*)dd,
+                                                dalpha_acc, dgamma, dbeta));
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -1191,15 +1191,16 @@ def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=No
     return dx, dg, db
 
 
-def normbwd_apply_mix(x, dz, bn, G, R, sacc, spat, freq, dalpha_acc, sacc_local=None):
-    h = _act(x, dz, spat, freq)
+def normbwd_apply_mix(x, dz, bn, G, R, sacc, diff, dalpha_acc, sacc_local=None):
+    """diff = freq - spat (irfft2_mix)."""
+    h = _act(x, dz, diff)
     Cc = x.shape[-1]
     loc = sacc if sacc_local is None else sacc_local
     dd = torch.empty_like(x)
     dg = empty((Cc,), x)
     db = empty((Cc,), x)
     _call("ud_normbwd_apply_mix", _p(x), _p(dz), C.byref(bn.ref()), _pd(sacc), _pd(sacc, Cc), _pd(loc), _pd(loc, Cc),
-          _p(spat), _p(freq), G, R, Cc, _p(dd), _pd(dalpha_acc), _p(dg), _p(db), h, _stream())
+          _p(diff), G, R, Cc, _p(dd), _pd(dalpha_acc), _p(dg), _p(db), h, _stream())
     return dd, dg, db
 
 
@@ -1290,7 +1291,7 @@ def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None,
 
 
 def irfft2_mix(Y, scale, spat, alpha, acc):
-    """(y, freq) = SF mix of spat with irfft2(Y); acc += [sum y | sum y^2]."""
+    """(y, diff) = SF mix of spat with freq = irfft2(Y), and freq - spat; acc += [sum y | sum y^2]."""
     h = _act(Y, spat)
     _chk(alpha)
     N, S, Wh, C2 = Y.shape

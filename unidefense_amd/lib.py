@@ -115,7 +115,7 @@ _SIGNATURES = {
     "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P],
     "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
-    "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "ud_gate_grad_from_acc": [_P, _P, _P, _P],
     "ud_se_bwd_a": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "ud_se_bwd_b": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P],

@@ -830,7 +830,8 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
         yf = K.gemm_nt(xf.view(-1, 2 * Ce), Wf).view(xf.shape)
         if stride == 1:
-            d, fr = K.irfft2_mix(yf, s_i, spat, alpha, acc1)
+            d, fr = K.irfft2_mix(yf, s_i, spat, alpha, acc1)          # fr: freq - spat (neither branch is kept)
+            spat = None
         else:
             fr = K.irfft2(yf, s_i, 1.0)
             d = K.sfmix_fwd(spat, fr, alpha, True)
@@ -900,7 +901,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         if sf:
             if stride == 1:
                 dacc = K.zeros64(64, x)
-                dd, dg1, db1 = K.normbwd_apply_mix(d, dz1, bn1, N, HWo, sb1, spat, fr, dacc, loc1)
+                dd, dg1, db1 = K.normbwd_apply_mix(d, dz1, bn1, N, HWo, sb1, fr, dacc, loc1)
                 # adjoint of irfft2, x sigmoid(a); the same launch turns the accumulator slots into the gate's gradient
                 dyf, _, dalpha = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc)
                 tape.add_param_grad(alpha, dalpha)
