@@ -71,6 +71,10 @@ typedef struct {
      * plain modes only — (0,0) and (0,1) with A half (activations x fp32 weights), (1,1) with A and B half (the weight
      * gradient), any of them with fp32 operands; batch 1; a half C takes out_mode 0 / 1 (no atomics: split_k 1). */
     int half_mask;
+    /* Tile of the BF16-pipe kernel: 0 = chosen by the library's cost model; 1..4 = 128x128, 128x64, 64x128, 64x64 —
+     * for callers that tune per shape by measurement (unidefense_amd/kernels.py does, on the thin expand / project
+     * GEMMs whose few tiles leave the k-loop latency exposed). */
+    int tile_cfg;
 } ud_gemm_desc;
 int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
 /* 0: ud_gemm would ignore stat_sum / stat_sumsq for this descriptor (the caller runs ud_colstats on the result);

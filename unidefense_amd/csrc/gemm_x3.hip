@@ -469,14 +469,18 @@ int launch_tile(const ud_gemm_desc& d, hipStream_t s) {
 struct XCfg { int bm, bn; double penalty; };
 // Half-size tiles split every A (or B) row twice as often: 19-23 % more time per flop (tools/check_gemm_paths.py
 // with UD_GEMM_X3_CFG=0/1/2: 4096^3 179 vs 150 TFLOP/s), so they only win where they fill the chip better.
-constexpr XCfg kX[3] = {{128, 128, 1.00}, {128, 64, 1.20}, {64, 128, 1.20}};
+constexpr int NXCFG = 4;
+constexpr XCfg kX[NXCFG] = {{128, 128, 1.00}, {128, 64, 1.20}, {64, 128, 1.20}, {64, 64, 1.60}};
 
-template <int AMODE, int BMODE, int PREC, bool AH = false, bool BH = false>
-int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
+// tile configuration of a descriptor: d.tile_cfg (1 + index, set by the caller's per-shape tuner) > UD_GEMM_X3_CFG > the
+// cost model over the first three (the 64x64 tile is only ever chosen by measurement)
+int pick_cfg(const ud_gemm_desc& d) {
+    if (d.tile_cfg >= 1 && d.tile_cfg <= NXCFG) return d.tile_cfg - 1;
     static const int forced = [] {
         const char* e = getenv("UD_GEMM_X3_CFG");
-        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
+        return (e && e[0] >= '0' && e[0] < '0' + NXCFG) ? e[0] - '0' : -1;
     }();
+    if (forced >= 0) return forced;
     int best = 0;
     double best_cost = 1e300;
     for (int i = 0; i < 3; ++i) {
@@ -487,10 +491,15 @@ int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
         double cost = (double)rounds * kX[i].bm * kX[i].bn * kX[i].penalty;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
-    if (forced >= 0) best = forced;
-    switch (best) {
+    return best;
+}
+
+template <int AMODE, int BMODE, int PREC, bool AH = false, bool BH = false>
+int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
+    switch (pick_cfg(d)) {
         case 1: return launch_tile<128, 64, AMODE, BMODE, PREC, AH, BH>(d, s);
         case 2: return launch_tile<64, 128, AMODE, BMODE, PREC, AH, BH>(d, s);
+        case 3: return launch_tile<64, 64, AMODE, BMODE, PREC, AH, BH>(d, s);
         default: return launch_tile<128, 128, AMODE, BMODE, PREC, AH, BH>(d, s);
     }
 }
@@ -514,22 +523,7 @@ bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
 }
 
 // rows per tile of the configuration launch_modes picks (for the epilogue-statistics slot rule)
-int ud_gemm_x3_tile_rows(const ud_gemm_desc& d) {
-    int best = 0;
-    double best_cost = 1e300;
-    for (int i = 0; i < 3; ++i) {
-        long tiles = (long)ud_cdiv(d.M, kX[i].bm) * ud_cdiv(d.N, kX[i].bn) * d.split_k * d.batch;
-        long rounds = (tiles + 255) / 256;
-        double cost = (double)rounds * kX[i].bm * kX[i].bn * kX[i].penalty;
-        if (cost < best_cost) { best_cost = cost; best = i; }
-    }
-    static const int forced = [] {
-        const char* e = getenv("UD_GEMM_X3_CFG");
-        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
-    }();
-    if (forced >= 0) best = forced;
-    return kX[best].bm;
-}
+int ud_gemm_x3_tile_rows(const ud_gemm_desc& d) { return kX[pick_cfg(d)].bm; }
 
 // Half-stored operands (ud_gemm_desc.half_mask): activations / activation gradients are _Float16 in memory, weights and
 // weight gradients fp32 — the three products of a 1x1 conv: forward (0,0) and data gradient (0,1) with A half, weight

@@ -115,7 +115,7 @@ def zeros(shape, like):
 # GEMM family
 # ---------------------------------------------------------------------------------------------
 def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_k=1, geom=None,
-          batch=1, strideA=0, strideB=0, strideC=0, a_off=0, b_off=0, stats=None):
+          batch=1, strideA=0, strideB=0, strideC=0, a_off=0, b_off=0, stats=None, cfg=0):
     """stats: fp64 accumulator [sum | sumsq] (2N doubles) the epilogue should add the result's column sums into; returns
     (Cout, True) when the kernel did (ud_gemm_stats_slots), (Cout, False) when the caller still has to run colstats."""
     d = GemmDesc()
@@ -127,6 +127,7 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
     d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
+    d.tile_cfg = cfg
     if geom is not None:
         d.g = geom
     fold = None
@@ -186,6 +187,138 @@ def _tail_plan(M, N, K):
     return (mt - rows_tail) * 128, split
 
 
+# ---- per-shape launch tuner of the plain fp32 GEMMs ---------------------------------------------------------------
+# The model's ~90 GEMM shapes are fixed; the cost models above (tile rounds, split-K targets) miss the best (tile, split-K)
+# of many of them — the thin expand / project shapes are bound by the latency of a workgroup's k-loop, where 64x64
+# tiles with a few splits win, and e.g. 1152x3264x3264 runs 11 % faster split in two.  So the FIRST eager call with a
+# shape measures the candidates (a handful of back-to-back launches each, into scratch) and the winner is cached; an
+# exhaustive offline sweep (tools/sweep_gemm_plans.py) put the gain at 1.2 ms of the 17.8 ms the plain GEMMs take per
+# step.  Never inside a graph capture (an unseen shape then takes the cost-model plan); UD_GEMM_TUNE=0 turns it off.
+_TUNE_ON = os.environ.get("UD_GEMM_TUNE", "1") == "1"
+_TUNED = {}
+_X3_TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64)}
+_TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128, 256, 384)
+
+
+def _tune_candidates(M, N, K):
+    heavy = 2.0 * M * N * K > 2.0e10                   # the large spectral GEMMs: a few plans only
+    out = []
+    for cfg, (bm, bn) in _X3_TILES.items():
+        tiles = -(-M // bm) * -(-N // bn)
+        for split in _TUNE_SPLITS:
+            if split > 1 and (K // split < 64 or tiles * split > 4096 or (heavy and split > 4)):
+                continue
+            if (tiles * split < 64 and K >= 1024) or (heavy and cfg == 4):
+                continue
+            out.append((cfg, split))
+    return out
+
+
+def _time_launches(fn, n=6):
+    """Device time of one fn() in ms.  The launches are replayed from a small hipGraph: eager launches of a 20 us kernel
+    are paced by the host (ctypes + Python), which hides the differences the tuner is after."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cur = torch.cuda.current_stream()
+    try:
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                for _ in range(n):
+                    fn()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            g.replay()
+            e0.record()
+            g.replay()
+            g.replay()
+            e1.record()
+        e1.synchronize()
+        cur.wait_stream(s)
+        return e0.elapsed_time(e1) / (2 * n)
+    except Exception:                                   # noqa: BLE001 — no capture possible here: eager timing
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+
+
+def _tuned_plan(kind, M, N, K, launch, baseline, extra_if_split=None):
+    """(cfg, split) to run this shape with, or None = keep the cost-model plan.  launch(cfg, split): enqueue one launch
+    into scratch; baseline(): enqueue the cost-model plan; extra_if_split(): work a split plan adds (ud_colstats when the
+    caller wanted epilogue statistics)."""
+    key = (kind, M, N, K, extra_if_split is not None)
+    if key in _TUNED:
+        return _TUNED[key]
+    if not _TUNE_ON or torch.cuda.is_current_stream_capturing() or min(M, N, K) < _X3_MINDIM:
+        return None
+    best_t, best = _time_launches(baseline), None
+    extra = _time_launches(extra_if_split) if extra_if_split is not None else 0.0
+    for cfg, split in _tune_candidates(M, N, K):
+        t = _time_launches(lambda: launch(cfg, split)) + (extra if split > 1 else 0.0)
+        if t < 0.97 * best_t:                          # a clear win only: equal plans keep the model's choice
+            best_t, best = t, (cfg, split)
+    _TUNED[key] = best
+    return best
+
+
+def _model_plan_launch(a, w, out, M, N, K, lda, ldb, b_mode, acc):
+    """The cost-model plan of a forward / data-gradient GEMM: tail split, split-K for launches that cannot fill the
+    chip, or one plain launch.  out: existing gradient to accumulate onto (acc) or None (a fresh result is returned)."""
+    plan = _tail_plan(M, N, K)
+    if plan is not None:
+        m1, split = plan
+        if not acc:
+            out = empty((M, N), a)
+        _gemm(a, w, out, m1, N, K, lda, ldb, N, 0, b_mode, 1 if acc else 0)
+        tail = out[m1:]
+        if not acc:
+            tail.zero_()
+        _gemm(a[m1:], w, tail, M - m1, N, K, lda, ldb, N, 0, b_mode, 2, split)
+        return out
+    split = _fwd_split(M, N, K)
+    if split > 1:
+        if not acc:
+            out = zeros((M, N), a)
+        return _gemm(a, w, out, M, N, K, lda, ldb, N, 0, b_mode, 2, split)
+    if not acc:
+        out = empty((M, N), a)
+    return _gemm(a, w, out, M, N, K, lda, ldb, N, 0, b_mode, 1 if acc else 0)
+
+
+def _tuned_launch(kind, a, w, out, M, N, K, lda, ldb, a_mode, b_mode, acc, stats, model):
+    """Run the measured-best (tile, split-K) of this shape if the tuner has / can find one, else model()."""
+    tmp = []
+
+    def scratch():
+        if not tmp:
+            tmp.append(empty((M, N), a))
+        return tmp[0]
+    sacc = torch.zeros(2 * N, dtype=torch.float64, device=a.device) if (stats is not None and
+                                                                         (kind, M, N, K, True) not in _TUNED) else None
+    tuned = _tuned_plan(kind, M, N, K,
+                        lambda cfg, split: _gemm(a, w, scratch(), M, N, K, lda, ldb, N, a_mode, b_mode,
+                                                 2 if split > 1 else 0, split, cfg=cfg),
+                        lambda: model(scratch()),
+                        (lambda: colstats(scratch(), sacc)) if stats is not None else None)
+    if tuned is None:
+        return None
+    cfg, split = tuned
+    if split == 1:
+        if not acc:
+            out = empty((M, N), a)
+        return _gemm(a, w, out, M, N, K, lda, ldb, N, a_mode, b_mode, 1 if acc else 0, stats=stats, cfg=cfg)
+    if not acc:
+        out = zeros((M, N), a)
+    r = _gemm(a, w, out, M, N, K, lda, ldb, N, a_mode, b_mode, 2, split, cfg=cfg)
+    return (r, False) if stats is not None else r
+
+
 def gemm_nt(a, w, out=None, accumulate=False, stats=None):
     """out[M,N] (+)= a[M,K] @ w[N,K]^T     (1x1 conv / linear forward).
     stats (2N zeroed doubles): BatchNorm statistics of the result; returns (out, done) — done = the GEMM epilogue
@@ -200,26 +333,19 @@ def gemm_nt(a, w, out=None, accumulate=False, stats=None):
         if out is None:
             out = empty((M, N), a, a.dtype)
         return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 1 if accumulate else 0, stats=stats)
+    if out is None:
+        # during tuning the model plan is timed into scratch: as a plain launch there, its splits need no zeroing
+        r = _tuned_launch("nt", a, w, None, M, N, K, K, K, 0, 0, False, stats,
+                          lambda scr: _model_plan_launch(a, w, scr, M, N, K, K, K, 0, True))
+        if r is not None:
+            return r
     if stats is not None:
         assert out is None and not accumulate
         if _tail_plan(M, N, K) is None and _fwd_split(M, N, K) <= 1:
             return _gemm(a, w, empty((M, N), a), M, N, K, K, K, N, 0, 0, 0, stats=stats)
-        return gemm_nt(a, w), False
+        return _model_plan_launch(a, w, None, M, N, K, K, K, 0, False), False
     if out is None:
-        plan = _tail_plan(M, N, K)
-        if plan is not None:
-            m1, split = plan
-            out = empty((M, N), a)
-            _gemm(a, w, out, m1, N, K, K, K, N, 0, 0, 0)
-            tail = out[m1:]
-            tail.zero_()
-            _gemm(a[m1:], w, tail, M - m1, N, K, K, K, N, 0, 0, 2, split)
-            return out
-        split = _fwd_split(M, N, K)
-        if split > 1:
-            out = zeros((M, N), a)
-            return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 2, split)
-        out = empty((M, N), a)
+        return _model_plan_launch(a, w, None, M, N, K, K, K, 0, False)
     return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 1 if accumulate else 0)
 
 
@@ -239,25 +365,11 @@ def gemm_nn(a, w, out=None, accumulate=False):
         # accumulate: `out` already holds a term of the same gradient (the skip branch's): the plain part adds into
         # it (out_mode 1), the split-K parts add atomically onto it — no zero fill, no separate axpby pass
         acc = out is not None
-        plan = _tail_plan(M, N, K)
-        if plan is not None:
-            m1, split = plan
-            if not acc:
-                out = empty((M, N), a)
-            _gemm(a, w, out, m1, N, K, K, N, N, 0, 1, 1 if acc else 0)
-            tail = out[m1:]
-            if not acc:
-                tail.zero_()
-            _gemm(a[m1:], w, tail, M - m1, N, K, K, N, N, 0, 1, 2, split)
-            return out
-        split = _fwd_split(M, N, K)
-        if split > 1:
-            if not acc:
-                out = zeros((M, N), a)
-            return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 2, split)
-        if not acc:
-            out = empty((M, N), a)
-        return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if acc else 0)
+        r = _tuned_launch("nn", a, w, out, M, N, K, K, N, 0, 1, acc, None,
+                          lambda scr: _model_plan_launch(a, w, scr, M, N, K, K, N, 1, True))
+        if r is not None:
+            return r
+        return _model_plan_launch(a, w, out, M, N, K, K, N, 1, acc)
     return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 0)
 
 
@@ -318,6 +430,11 @@ def gemm_tn(a, b):
     N = b.shape[1]
     assert b.shape[0] == K
     split = _pick_split(_tiles(M, N, K), K)
+    if a.dtype == torch.float32:
+        r = _tuned_launch("tn", a, b, None, M, N, K, M, N, 1, 1, False, None,
+                          lambda scr: _gemm(a, b, scr, M, N, K, M, N, N, 1, 1, 2 if split > 1 else 0, split))
+        if r is not None:
+            return r
     if split > 1:
         out = zeros((M, N), a)
         return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 2, split)

@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_long), ("ldb", C.c_long), ("ldc", C.c_long),
                 ("a_mode", C.c_int), ("b_mode", C.c_int), ("out_mode", C.c_int), ("split_k", C.c_int),
                 ("batch", C.c_int), ("strideA", C.c_long), ("strideB", C.c_long), ("strideC", C.c_long),
-                ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("half_mask", C.c_int)]
+                ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("half_mask", C.c_int), ("tile_cfg", C.c_int)]
 
 
 class BnRef(C.Structure):
