@@ -188,7 +188,11 @@ def test_udr50_320_bs16_sample_independence_and_linearity():
     # the two runs repeat the forward; split-K float atomics order differently from run to run (1e-7 on activations), a
     # handful of the 1e8 ReLU units sits within that of zero and flips, which moves single weight gradients by ~1e-3:
     # observed worst 1.3e-3 (a ReLU-free UDEB4 shows 1e-6 in the same test above).  A non-linear kernel would be O(1).
-    assert len(lin) == 214 and max(lin)[0] <= 5e-3
+    # With the per-shape GEMM tuner many more of the ResNet's thin 1x1 convs run split-K (atomics), so more layers differ in
+    # the last bit between the two runs and more ReLU units flip: worst 1.2e-2 on one conv weight, typical 1e-3 (the
+    # median below), still two orders of magnitude under what a non-linear kernel would show.
+    import statistics
+    assert len(lin) == 214 and max(lin)[0] <= 4e-2 and statistics.median(v for v, _ in lin) <= 4e-3
 
 
 def test_deferred_bn_sums_combine_like_syncbn():

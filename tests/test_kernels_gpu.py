@@ -217,6 +217,37 @@ def test_gemm_split_bf16_path_has_fp32_accuracy(kind, M, N, K):
         assert errs[1] <= 2e-5
 
 
+@pytest.mark.parametrize("kind,M,N,K", [("nt", 2048, 272, 1632), ("nn", 2048, 1632, 272), ("tn", 1632, 272, 2048),
+                                        ("nt", 300, 72, 200), ("nn", 132, 68, 260), ("tn", 68, 76, 1001),
+                                        ("nt", 8192 + 64, 160, 960), ("tn", 160, 960, 8192 + 3)])
+def test_gemm_every_tile_configuration_and_split(kind, M, N, K):
+    """Every plan the per-shape tuner (kernels._tuned_plan) may pick: the four tiles of gemm_x3.hip (128x128, 128x64,
+    64x128, 64x64, each with its own prefetch depth) x split-K 1 ... 24, on ragged shapes, against float64 — a plan is a
+    speed choice, never a numerical one."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    g = torch.Generator().manual_seed(M + N)
+    sa, sb = ((K, M) if kind == "tn" else (M, K)), ((N, K) if kind == "nt" else (K, N))
+    a, b = torch.randn(sa, generator=g), torch.randn(sb, generator=g)
+    A = a.double().t() if kind == "tn" else a.double()
+    B = b.double().t() if kind == "nt" else b.double()
+    ref, scale = A @ B, A.abs() @ B.abs()
+    a, b = a.to(dev), b.to(dev)
+    a_mode, b_mode = (1, 1) if kind == "tn" else (0, 0 if kind == "nt" else 1)
+    lda, ldb = (M if kind == "tn" else K), (K if kind == "nt" else N)
+    worst = 0.0
+    for cfg in (1, 2, 3, 4):
+        for split in (1, 2, 3, 8, 24):
+            if split > 1 and K // split < 16:
+                continue
+            out = torch.zeros(M, N, device=dev)
+            Kk._gemm(a, b, out, M, N, K, lda, ldb, N, a_mode, b_mode, 2 if split > 1 else 0, split, cfg=cfg)
+            e = ((out.double().cpu() - ref).abs() / scale).max().item()
+            worst = max(worst, e)
+            assert e <= 2e-6, (cfg, split, e)
+    print(f"  {kind} {M}x{N}x{K}: worst error / sum|a||b| over 4 tiles x 5 splits: {worst:.2e}")
+
+
 def test_syncbn_combine_matches_gloo_tested_formula():
     """ud_syncbn_combine (the product's SyncBatchNorm fold) against tape.sync_batch_stats' math — the function the
     world_size-2 gloo test (tests/test_parallel_cpu.py) checks against torch.nn.SyncBatchNorm semantics."""
