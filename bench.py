@@ -297,7 +297,7 @@ def main():
 
     if rank == 0 and args.gemm_table:
         agg = {}
-        for e0, e1, f, key, path in prof:
+        for e0, e1, f, key, path, _nb in prof:
             a = agg.setdefault(key + (path,), [0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
@@ -321,7 +321,8 @@ def main():
         achieved = x3_flops / (x3_ms * 1e-3) / 1e12 if x3_ms > 0 else 0.0           # algorithmic fp32 TFLOP/s, x3 launches
         achieved_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # operand + result bytes of each x3 launch (fp32, every matrix touched once), to set beside the PMC traffic
-        alg_bytes = sum(4.0 * max(k[6], 1) * (k[0] * k[2] + k[2] * k[1] + k[0] * k[1]) for _, _, _, k, _ in x3) / max(len(x3), 1)
+        alg_bytes = sum(p[5] for p in x3) / max(len(x3), 1)
+        hbm_gbs = sum(p[5] for p in x3) / (x3_ms * 1e-3) / 1e9 if x3_ms > 0 else 0.0
         traffic, traffic_src = _pmc_traffic(args, bs)
         line = {
             "metric": ("images/sec fwd+bwd (256x256, EffNet-b4)" if (args.model, args.size) == ("UDEB4", 256)
@@ -344,7 +345,7 @@ def main():
                        # checksum of the step's result (tests: the data-parallel path at world size 1 must give
                        # the plain step's gradients)
                        "grad_l1": float(sum(p.grad.double().abs().sum() for p in params if p.grad is not None))},
-            "roofline": {"bound": "mfma",
+            "roofline": {"bound": "hbm" if args.dtype == "f16" else "mfma",
                          "kernel": "gemm_x3_kernel (csrc/gemm_x3.hip): fp32 GEMM on the BF16 matrix pipe — every fp32 operand "
                                    "split exactly into 3 bf16 pieces, SIX v_mfma_f32_32x32x16_bf16 per fp32 product tile, "
                                    "fp32-GEMM accuracy.  achieved = algorithmic fp32 FLOPs (2MNK) of its launches / their "
@@ -357,6 +358,10 @@ def main():
                          "frac_of_pipe": achieved * mfma_per_product / BF16_PEAK_TFLOPS,
                          # the same launches priced as fp32 work against the fp32 matrix peak (bounded by 2.67, not 1)
                          "frac_fp32_equiv": achieved / MFMA_F32_PEAK_TFLOPS,
+                         # HBM side of the same launches: algorithmic operand + result bytes (storage types as launched) /
+                         # their HIP-event time, against 8 TB/s — the bound that matters in the f16 mode, where one fp16
+                         # MFMA per product tile leaves the GEMMs memory-bound
+                         "hbm": {"achieved": hbm_gbs, "peak": 8000.0, "unit": "GB/s", "frac": hbm_gbs / 8000.0},
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (mean over the gemm_x3_kernel launches of a step)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
@@ -376,6 +381,11 @@ def main():
                                      "graph-replayed steps of this same command (tools/gpu_round.sh), and "
                                      "tools/roofline_from_rocprof.py recomputes these numbers from it"},
         }
+        if args.dtype == "f16":
+            # informational f16 line: the HBM side is the roofline (bound "hbm"); the matrix-pipe numbers move to "mfma"
+            r = line["roofline"]
+            r["mfma"] = {k: r[k] for k in ("achieved", "peak", "unit", "frac")}
+            r.update(achieved=hbm_gbs, peak=8000.0, unit="GB/s", frac=hbm_gbs / 8000.0)
         if (args.model, args.size) == ("UDEB4", 256):
             # whole-step fractions from the algorithmic work per image (fwd+bwd, fp32):
             # 68.9 GFLOP and 1044 MB at bs 32 — per GPU, against the fp32 matrix peak and 8 TB/s

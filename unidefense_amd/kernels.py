@@ -148,7 +148,9 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
         _call("ud_gemm", C.byref(d), _stream())
         e1.record()
         GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, a_mode, b_mode, split_k, batch),
-                             _call("ud_gemm_query_path", C.byref(d))))
+                             _call("ud_gemm_query_path", C.byref(d)),
+                             # operand + result bytes, every matrix touched once, in their storage types
+                             float(batch) * (A.element_size() * M * K + B.element_size() * K * N + Cout.element_size() * M * N)))
     else:
         _call("ud_gemm", C.byref(d), _stream())
     if fold is not None:
