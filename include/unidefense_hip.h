@@ -92,6 +92,7 @@ int ud_stat_slots_fold(const double* slot_sum, const double* slot_sumsq, int slo
  *   3 mixed precision (BASELINE configs[4]): wherever the split-bf16 kernel would run, the operands are rounded to fp16
  *     and multiplied by ONE v_mfma_f32_32x32x16_f16 per product tile with fp32 accumulation (fp32 storage stays). */
 int ud_gemm_set_path(int path);
+int ud_gemm_get_path(void);
 /* 2 if ud_gemm would run this descriptor on the BF16 matrix pipe (split-bf16 kernel), 3 for its fp16 mixed-precision
  * mode (path 3), 1 for the fp32 pipe */
 int ud_gemm_query_path(const ud_gemm_desc* d);

@@ -12,6 +12,7 @@ if [ "$2" != "nopytest" ]; then
   timeout 2700 python -m pytest tests -m gpu -q -rA --timeout 1200 > $out/pytest_gpu.log 2>&1
   echo "pytest exit $?"; grep -E "passed|failed|error" $out/pytest_gpu.log | tail -3
 fi
+export UD_GEMM_TUNE_CACHE=$PWD/$out/gemm_plans.json      # the profiled runs below repeat the benchmarked plans
 echo "== bench (default flags)"
 timeout 1200 python bench.py --gemm-table $out/gemm_table.txt > $out/bench.json 2> $out/bench.err
 echo "bench exit $?"; tail -1 $out/bench.json | cut -c1-400

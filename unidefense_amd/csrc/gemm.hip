@@ -442,6 +442,8 @@ extern "C" int ud_gemm_set_path(int path) {
     return 0;
 }
 
+extern "C" int ud_gemm_get_path(void) { return g_path.load(); }
+
 // vector-load eligibility of the two operands
 static void vec_flags(const ud_gemm_desc& d, int& a_vec, int& b_vec) {
     if (d.a_mode == 0) a_vec = aligned16(d.A) && d.lda % 4 == 0 && d.strideA % 4 == 0;

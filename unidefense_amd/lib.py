@@ -132,6 +132,7 @@ _SIGNATURES = {
     "ud_rfft2_planes_adjoint": [_P, _P, _P, _L, _I, _F, _P],
     "ud_adamw_chunk_elems": [],
     "ud_adamw_multi": [_P, _P, _I, _P, _P, _I, C.c_double, C.c_double, C.c_double, _I, _I, _P, _P, _P, _P, _P],
+    "ud_gemm_get_path": [],
     "ud_xchg_bytes": [_I, _I, _I],
     "ud_xchg_create": [_I, _I, _I, _P, _P],
     "ud_xchg_open": [_P, _P],
@@ -141,7 +142,7 @@ _SIGNATURES = {
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
                 "ud_conv_small_wgrad_ws_floats", "ud_xchg_bytes"}
 _LONG_FUNCS = {"ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
