@@ -36,3 +36,43 @@ def test_downscale_index_matches_the_oracle_rule():
     from unidefense_amd.model import perturb as P
     for s in (64, 128, 256, 320):
         assert np.array_equal(P.downscale_index(s), OP.downscale_index(s))
+
+
+def test_gemm_tuner_candidates_and_plan_cache(tmp_path):
+    """The per-shape GEMM tuner's host logic: candidate (tile, split-K) grids respect the kernel's limits (reduction rows per
+    split, workgroup count), the heavy spectral shapes get the short list, and the plan cache file round-trips."""
+    import importlib
+    import json
+    import os
+    from unidefense_amd import kernels as K
+    for M, N, Kd in ((2048, 272, 1632), (131072, 32, 192), (1152, 3264, 3264), (160, 960, 8192), (32, 144, 131072)):
+        cands = K._tune_candidates(M, N, Kd)
+        assert cands and len(set(cands)) == len(cands)
+        heavy = 2.0 * M * N * Kd > 2.0e10
+        for cfg, split in cands:
+            bm, bn = K._X3_TILES[cfg]
+            tiles = -(-M // bm) * -(-N // bn)
+            assert 1 <= cfg <= 4 and split >= 1
+            if split > 1:
+                assert Kd // split >= 64 and tiles * split <= 4096
+            if heavy:
+                assert split <= 4 and cfg != 4
+        assert any(s == 1 for _, s in cands) or Kd >= 1024
+    # cache file: written on every new plan, read back at import
+    path = str(tmp_path / "plans.json")
+    old_env = os.environ.get("UD_GEMM_TUNE_CACHE")
+    os.environ["UD_GEMM_TUNE_CACHE"] = path
+    try:
+        K2 = importlib.reload(K)
+        K2._TUNED[("nt", 2048, 272, 1632, False, 0)] = (4, 3)
+        K2._TUNED[("tn", 160, 960, 8192, False, 0)] = None
+        K2._tune_cache_save()
+        assert json.load(open(path))
+        K3 = importlib.reload(K2)
+        assert K3._TUNED[("nt", 2048, 272, 1632, False, 0)] == (4, 3) and K3._TUNED[("tn", 160, 960, 8192, False, 0)] is None
+    finally:
+        if old_env is None:
+            os.environ.pop("UD_GEMM_TUNE_CACHE", None)
+        else:
+            os.environ["UD_GEMM_TUNE_CACHE"] = old_env
+        importlib.reload(K)
