@@ -31,7 +31,7 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) / (5 * n) * 1e3          # us per launch
 
 
-for kind, M, N, Kd in SHAPES:
+for kind, M, N, Kd in (SHAPES if __name__ == "__main__" else []):
     if kind == "nt":
         a, b = torch.randn(M, Kd, device=dev), torch.randn(N, Kd, device=dev)
         args = lambda out, split: (a, b, out, M, N, Kd, Kd, Kd, N, 0, 0, 2 if split > 1 else 0, split)
