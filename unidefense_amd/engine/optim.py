@@ -66,14 +66,36 @@ class HipAdamW(torch.optim.Optimizer):
         self._flat, self._chunk = flat, chunk
         self._steps = torch.zeros(2, dtype=torch.int32, device=dev)
 
+    def _plan_stale(self, active):
+        """The cached parameter / state pointers no longer describe the tensors (load_state_dict replaced the state,
+        the parameters were moved): checked on the first and last tensor, every step."""
+        st = self._plan["static"]
+        for i in (0, len(active) - 1):
+            p = active[i][0]
+            if st[i][0] != p.data_ptr() or st[i][1] != self.state[p]["exp_avg"].data_ptr():
+                return True
+        return False
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plan = None
+
     def _make_plan(self, active, dev):
         """Static per set of updated tensors: chunk map and pointer table on the device."""
         rows = []
         for ti, (p, gi) in enumerate(active):
             rows.extend((ti, c) for c in range(-(-p.numel() // self._chunk)))
         chunk_map = torch.tensor(rows, dtype=torch.int32).contiguous().to(dev)
-        return {"key": tuple(id(p) for p, _ in active), "chunk_map": chunk_map, "n_chunks": len(rows),
-                "table": torch.zeros((len(active), 8), dtype=torch.int64, device=dev), "ptrs": None}
+        ams = self.param_groups[0]["amsgrad"]
+        static = []                                    # everything of a table row but the gradient pointer
+        for p, gi in active:
+            st = self.state[p]
+            static.append((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                           st["max_exp_avg_sq"].data_ptr() if ams else 0, p.numel(), gi))
+        # tables: one device pointer table per distinct SET of gradient buffers (the engine's two captured passes hand
+        # over two fixed sets, an eager backward a new one every time) — a steady-state step uploads nothing
+        return {"key": tuple(id(p) for p, _ in active), "chunk_map": chunk_map, "n_chunks": len(rows), "static": static,
+                "tables": {}}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -89,21 +111,23 @@ class HipAdamW(torch.optim.Optimizer):
         dev = active[0][0].device
         if self._steps is None:
             self._alloc_state(dev)
-        if self._plan is None or self._plan["key"] != tuple(id(p) for p, _ in active):
+        if self._plan is None or self._plan["key"] != tuple(id(p) for p, _ in active) or self._plan_stale(active):
             self._plan = self._make_plan(active, dev)
         plan = self._plan
         ams = self.param_groups[0]["amsgrad"]
-        ptrs = []
+        gptrs = []
         for p, gi in active:
             g = p.grad
             if g.dtype != torch.float32 or not g.is_contiguous():
                 g = p.grad = g.contiguous().to(torch.float32)
-            st = self.state[p]
-            ptrs.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                         st["max_exp_avg_sq"].data_ptr() if ams else 0, p.numel(), gi, 0))
-        if ptrs != plan["ptrs"]:                      # gradient buffers moved (eager backward): re-upload 64 B per tensor
-            plan["table"].copy_(torch.tensor(ptrs, dtype=torch.int64))      # synchronous staging copy, 32 KB
-            plan["ptrs"] = ptrs
+            gptrs.append(g.data_ptr())
+        gkey = tuple(gptrs)
+        table = plan["tables"].get(gkey)
+        if table is None:                             # new set of gradient buffers: upload 64 B per tensor (32 KB)
+            rows = [(st[0], gp, st[1], st[2], st[3], st[4], st[5], 0) for st, gp in zip(plan["static"], gptrs)]
+            if len(plan["tables"]) >= 8:               # eager backwards allocate new buffers every step: keep it bounded
+                plan["tables"].clear()
+            table = plan["tables"][gkey] = torch.tensor(rows, dtype=torch.int64).to(dev)
         ng = len(self.param_groups)
         lr = (C.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
         wd = (C.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
@@ -118,7 +142,7 @@ class HipAdamW(torch.optim.Optimizer):
             grad_scale = grad_scale.float()
         s_in = C.c_void_p(self._steps.data_ptr() + 4 * self._cur)
         s_out = C.c_void_p(self._steps.data_ptr() + 4 * (1 - self._cur))
-        lib.call("ud_adamw_multi", dp(plan["table"]), dp(plan["chunk_map"]), plan["n_chunks"], lr, wd, ng,
+        lib.call("ud_adamw_multi", dp(table), dp(plan["chunk_map"]), plan["n_chunks"], lr, wd, ng,
                  float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), int(bool(ams)), int(bool(g0["maximize"])),
                  dp(grad_scale), dp(found_inf), s_in, s_out, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         self._cur = 1 - self._cur
