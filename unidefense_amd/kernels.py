@@ -267,10 +267,10 @@ def _time_launches(fn, n=6):
         return e0.elapsed_time(e1) / n
 
 
-def _tuned_plan(kind, M, N, K, launch, baseline, extra_if_split=None):
+def _tuned_plan(kind, M, N, K, launch, baseline, extra_if_split=None, no_split=False):
     """(cfg, split) to run this shape with, or None = keep the cost-model plan.  launch(cfg, split): enqueue one launch
     into scratch; baseline(): enqueue the cost-model plan; extra_if_split(): work a split plan adds (ud_colstats when the
-    caller wanted epilogue statistics)."""
+    caller wanted epilogue statistics); no_split: a half result takes no atomics — tiles only."""
     key = (kind, M, N, K, extra_if_split is not None, _call("ud_gemm_get_path"))
     if key in _TUNED:
         return _TUNED[key]
@@ -279,6 +279,8 @@ def _tuned_plan(kind, M, N, K, launch, baseline, extra_if_split=None):
     best_t, best = _time_launches(baseline), None
     extra = _time_launches(extra_if_split) if extra_if_split is not None else 0.0
     for cfg, split in _tune_candidates(M, N, K):
+        if no_split and split > 1:
+            continue
         t = _time_launches(lambda: launch(cfg, split)) + (extra if split > 1 else 0.0)
         if t < 0.97 * best_t:                          # a clear win only: equal plans keep the model's choice
             best_t, best = t, (cfg, split)
@@ -311,13 +313,15 @@ def _model_plan_launch(a, w, out, M, N, K, lda, ldb, b_mode, acc):
     return _gemm(a, w, out, M, N, K, lda, ldb, N, 0, b_mode, 1 if acc else 0)
 
 
-def _tuned_launch(kind, a, w, out, M, N, K, lda, ldb, a_mode, b_mode, acc, stats, model):
-    """Run the measured-best (tile, split-K) of this shape if the tuner has / can find one, else model()."""
+def _tuned_launch(kind, a, w, out, M, N, K, lda, ldb, a_mode, b_mode, acc, stats, model, out_dtype=torch.float32):
+    """Run the measured-best (tile, split-K) of this shape if the tuner has / can find one, else model().
+    out_dtype: torch.float16 for the half-storage forward / data-gradient products (plain launches only)."""
     tmp = []
+    kind = kind if out_dtype == torch.float32 and a.dtype == torch.float32 else kind + "/h"
 
     def scratch():
         if not tmp:
-            tmp.append(empty((M, N), a))
+            tmp.append(empty((M, N), a, out_dtype))
         return tmp[0]
     sacc = []
 
@@ -329,13 +333,13 @@ def _tuned_launch(kind, a, w, out, M, N, K, lda, ldb, a_mode, b_mode, acc, stats
                         lambda cfg, split: _gemm(a, w, scratch(), M, N, K, lda, ldb, N, a_mode, b_mode,
                                                  2 if split > 1 else 0, split, cfg=cfg),
                         lambda: model(scratch()),
-                        stats_pass if stats is not None else None)
+                        stats_pass if stats is not None else None, no_split=out_dtype != torch.float32)
     if tuned is None:
         return None
     cfg, split = tuned
     if split == 1:
         if not acc:
-            out = empty((M, N), a)
+            out = empty((M, N), a, out_dtype)
         return _gemm(a, w, out, M, N, K, lda, ldb, N, a_mode, b_mode, 1 if acc else 0, stats=stats, cfg=cfg)
     if not acc:
         out = zeros((M, N), a)
@@ -353,8 +357,12 @@ def gemm_nt(a, w, out=None, accumulate=False, stats=None):
     N = w.shape[0]
     assert w.shape[1] == K
     if half:
-        # half storage: one plain launch (no atomics onto a half result); the fp16 MFMA leaves these memory-bound
+        # half storage: one plain launch (no atomics onto a half result), its tile tuned like the fp32 shapes'
         if out is None:
+            r = _tuned_launch("nt", a, w, None, M, N, K, K, K, 0, 0, False, stats,
+                              lambda scr: _gemm(a, w, scr, M, N, K, K, K, N, 0, 0, 0), out_dtype=a.dtype)
+            if r is not None:
+                return r
             out = empty((M, N), a, a.dtype)
         return _gemm(a, w, out, M, N, K, K, K, N, 0, 0, 1 if accumulate else 0, stats=stats)
     if out is None:
@@ -382,6 +390,11 @@ def gemm_nn(a, w, out=None, accumulate=False):
     assert w.shape[0] == K
     if half:
         acc = out is not None and accumulate
+        if out is None or acc:
+            r = _tuned_launch("nn", a, w, out, M, N, K, K, N, 0, 1, acc, None,
+                              lambda scr: _gemm(a, w, scr, M, N, K, K, N, N, 0, 1, 0), out_dtype=a.dtype)
+            if r is not None:
+                return r
         if out is None:
             out = empty((M, N), a, a.dtype)
         return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 1 if acc else 0)
@@ -454,11 +467,10 @@ def gemm_tn(a, b):
     N = b.shape[1]
     assert b.shape[0] == K
     split = _pick_split(_tiles(M, N, K), K)
-    if a.dtype == torch.float32:
-        r = _tuned_launch("tn", a, b, None, M, N, K, M, N, 1, 1, False, None,
-                          lambda scr: _gemm(a, b, scr, M, N, K, M, N, N, 1, 1, 2 if split > 1 else 0, split))
-        if r is not None:
-            return r
+    r = _tuned_launch("tn", a, b, None, M, N, K, M, N, 1, 1, False, None,          # fp32 or half operands, fp32 result
+                      lambda scr: _gemm(a, b, scr, M, N, K, M, N, N, 1, 1, 2 if split > 1 else 0, split))
+    if r is not None:
+        return r
     if split > 1:
         out = zeros((M, N), a)
         return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 2, split)
