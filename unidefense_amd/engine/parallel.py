@@ -139,6 +139,27 @@ class BnExchange:
             want = (torch.arange(n, device=self.device, dtype=torch.float64) + 1.0) * (self.world * (self.world + 1) / 2) \
                 + it * self.world
             good = good and bool(torch.equal(v, want)) and int(self.err.item()) == 0
+        # ... and from a replayed hipGraph, the way the captured train step issues them (device-side sequence counter)
+        if good and not torch.cuda.is_current_stream_capturing():
+            try:
+                a = torch.zeros(512, dtype=torch.float64, device=self.device)
+                src = torch.full((512,), float(self.rank + 1), dtype=torch.float64, device=self.device)
+                torch.cuda.synchronize()
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                        a.copy_(src)
+                        self.allreduce(a)
+                        a.mul_(0.5)
+                        self.allreduce(a)
+                    for _ in range(3):
+                        g.replay()
+                torch.cuda.synchronize()
+                tri = self.world * (self.world + 1) / 2.0                      # sum of (rank + 1)
+                good = bool((a == 0.5 * tri * self.world).all()) and int(self.err.item()) == 0
+            except Exception:                                                  # noqa: BLE001 — any failure: fall back
+                good = False
         flag = torch.tensor([1 if good else 0], device=self.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag.item()) == 1
