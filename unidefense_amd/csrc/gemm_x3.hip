@@ -78,6 +78,9 @@ __device__ __forceinline__ int phys_row(int row) { return row ^ ((row >> 3) & 1)
 
 // ---------------------------------------------------------------------------------------------------------
 // Operand tile: ROWS x 16.  MODE 0: source [row][k], K-contiguous.  MODE 1: source [k][row], row-contiguous.
+// MODE 2: conv gather with rows = output pixels, k = (tap, ci) (K-contiguous inside a tap).  MODE 3: conv gather with
+// k = output pixels and rows = (tap, ci) — the B operand of a conv's weight gradient: row-contiguous like MODE 1, the
+// thread's (tap, ci) fixed for the whole kernel, the pixel of its two k's walked incrementally.
 // Loads are branch-free (addresses clamped into the operand, validity re-derived at store time): a load under a
 // branch made hipcc wait for it on the spot, which serialised the whole prefetch ring.
 // ---------------------------------------------------------------------------------------------------------
@@ -115,8 +118,10 @@ struct XLoader {
     // MODE 2 (implicit-GEMM conv gather, rows = output pixels, k = (tap, ci); Cin % 4 == 0 so a float4 never straddles
     // taps): the (tap, ci) of the thread's NEXT load, advanced incrementally (no division in the loop), the rows'
     // pixel origins, and one validity bit per (ring slot, row) for the store
+    // MODE 3: g_kh / g_kw / g_ci = the thread's fixed tap and first channel, (g_img, g_oh, g_ow) = output pixel of g_k
     ud_conv_geom g;
     int g_k, g_ci, g_kh, g_kw;
+    int g_img, g_oh, g_ow;
     int g_nbase[NV0 > 2 ? NV0 : 2], g_ih0[NV0 > 2 ? NV0 : 2], g_iw0[NV0 > 2 ? NV0 : 2];
     unsigned vmask[PD];
 
@@ -152,6 +157,22 @@ struct XLoader {
                 off[i] = (long)(rowok[i] ? r : 0) * ld;
             }
             kloc = (tid & 3) * 4;          // (tid + i*256) & 3 == tid & 3
+        } else if constexpr (MODE == 3) {
+            g = geom;
+            const int q = (tid >> 5) * 4 + (tid & 3);
+            const int r = row0 + q * VEC;              // first of the thread's VEC columns (tap, ci .. ci + VEC - 1)
+            rowok[0] = r < dim;
+            const int rr = rowok[0] ? r : 0;
+            const int tap = rr / g.Cin;
+            g_ci = rr - tap * g.Cin;
+            g_kh = tap / g.KW;
+            g_kw = tap - g_kh * g.KW;
+            kloc = 2 * ((tid >> 2) & 7);
+            g_k = k_begin + kloc;
+            g_ow = g_k % g.Wout;
+            const int t = g_k / g.Wout;
+            g_oh = t % g.Hout;
+            g_img = t / g.Hout;
         } else {
             const int q = (tid >> 5) * 4 + (tid & 3);
             int r = row0 + q * VEC;
@@ -204,6 +225,39 @@ struct XLoader {
                 // one is redirected to the last inside one (k_last - 3) and zeroed at store time
                 regs[S][i] = *reinterpret_cast<const V*>(base + off[i] + min(k0 + kloc, k_last - 3));
             }
+        } else if constexpr (MODE == 3) {
+            // walk the pixel to this tile's k (non-decreasing; surplus prefetches past the end repeat the last tile)
+            const int delta = k0 + kloc - g_k;
+            g_k += delta;
+            g_ow += delta;
+            while (g_ow >= g.Wout) {
+                g_ow -= g.Wout;
+                if (++g_oh == g.Hout) { g_oh = 0; ++g_img; }
+            }
+            unsigned mask = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int ow = g_ow + i, oh = g_oh, img = g_img;
+                if (ow >= g.Wout) { ow -= g.Wout; if (++oh == g.Hout) { oh = 0; ++img; } }
+                int ih, iw;
+                bool ok;
+                if (!g.transposed) {
+                    ih = oh * g.stride - g.pad_t + g_kh;
+                    iw = ow * g.stride - g.pad_l + g_kw;
+                    ok = (ih >= 0) && (ih < g.Hin) && (iw >= 0) && (iw < g.Win);
+                } else {
+                    const int th = oh + g.pad_t - g_kh, tw = ow + g.pad_l - g_kw;
+                    ok = (th >= 0) && (tw >= 0) && (th % g.stride == 0) && (tw % g.stride == 0);
+                    ih = th / g.stride;
+                    iw = tw / g.stride;
+                    ok = ok && (ih < g.Hin) && (iw < g.Win);
+                }
+                ok = ok && rowok[0] && (g_k + i <= k_last);
+                const long o = ok ? (((long)img * g.Hin + ih) * g.Win + iw) * (long)g.Cin + g_ci : 0;     // branch-free
+                regs[S][i] = *reinterpret_cast<const V*>(base + o);
+                mask |= (ok ? 1u : 0u) << i;
+            }
+            vmask[S] = mask;
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -245,7 +299,8 @@ struct XLoader {
             }
         } else {
             const int q = (tid >> 5) * 4 + (tid & 3), kb = (tid >> 2) & 7;
-            const bool ok0 = rowok[0] && (k0 + kloc <= k_last), ok1 = rowok[0] && (k0 + kloc + 1 <= k_last);
+            const bool ok0 = MODE == 3 ? (vmask[S] & 1u) != 0 : rowok[0] && (k0 + kloc <= k_last);
+            const bool ok1 = MODE == 3 ? (vmask[S] & 2u) != 0 : rowok[0] && (k0 + kloc + 1 <= k_last);
             char* p0 = L + (kb >> 2) * GS + (kb & 3) * 4;
             V v0 = regs[S][0], v1 = regs[S][1];
 #pragma unroll
@@ -512,6 +567,11 @@ bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
         static const bool on = !getenv("UD_X3_GATHER") || atoi(getenv("UD_X3_GATHER")) != 0;
         return on && a_vec && b_vec && d.K % 4 == 0 && d.batch == 1;
     }
+    if (d.a_mode == 1 && d.b_mode == 2) {
+        // weight gradient of a conv: dY^T (row-contiguous A) x gathered input (B rows = (tap, ci)); Cin % 4 == 0 (b_vec)
+        static const bool on = !getenv("UD_X3_WGRAD_GATHER") || atoi(getenv("UD_X3_WGRAD_GATHER")) != 0;
+        return on && a_vec && b_vec && d.M % 4 == 0 && d.batch == 1;
+    }
     if (d.a_mode > 1 || d.b_mode > 1) return false;
     if (!(d.a_mode == 0 && d.b_mode == 0) && !(d.a_mode == 0 && d.b_mode == 1) && !(d.a_mode == 1 && d.b_mode == 1))
         return false;
@@ -540,6 +600,7 @@ int ud_gemm_x3_launch_half(const ud_gemm_desc& d, hipStream_t s) {
 // f16: one fp16 piece per operand (mixed precision) instead of the exact three-way bf16 split
 int ud_gemm_x3_launch(const ud_gemm_desc& d, hipStream_t s, bool f16) {
     if (d.a_mode == 2 && d.b_mode == 0) return f16 ? launch_modes<2, 0, 1>(d, s) : launch_modes<2, 0, 3>(d, s);
+    if (d.a_mode == 1 && d.b_mode == 2) return f16 ? launch_modes<1, 3, 1>(d, s) : launch_modes<1, 3, 3>(d, s);
     if (f16) {
         if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0, 1>(d, s);
         if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1, 1>(d, s);

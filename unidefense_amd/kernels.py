@@ -271,6 +271,7 @@ def _tuned_plan(kind, M, N, K, launch, baseline, extra_if_split=None, no_split=F
     """(cfg, split) to run this shape with, or None = keep the cost-model plan.  launch(cfg, split): enqueue one launch
     into scratch; baseline(): enqueue the cost-model plan; extra_if_split(): work a split plan adds (ud_colstats when the
     caller wanted epilogue statistics); no_split: a half result takes no atomics — tiles only."""
+    kind = kind if isinstance(kind, str) else "/".join(str(v) for v in kind)
     key = (kind, M, N, K, extra_if_split is not None, _call("ud_gemm_get_path"))
     if key in _TUNED:
         return _TUNED[key]
@@ -527,6 +528,22 @@ def conv_gather_nt(x, wmat, g):
     # split-K for the under-filled launches (e.g. the 3x3 filter conv at 8x8: M = 2048, K = 2448 -> 80 tiles);
     # an A/B inside one gpurun call decides (UD_CONV_SPLITK=0 disables)
     split = _fwd_split(M, Co, K) if _CONV_SPLITK else 1
+    if g.Cin % 4 == 0:                                  # the shapes the BF16-pipe gather takes: tuned like the plain GEMMs
+        gk = (g.Hin, g.Win, g.Cin, g.KH, g.KW, g.stride, g.transposed)
+        tmp = []
+
+        def scratch():
+            if not tmp:
+                tmp.append(empty((M, Co), x))
+            return tmp[0]
+        tuned = _tuned_plan(("conv",) + gk, M, Co, K,
+                            lambda cfg, sp: _gemm(x, wmat, scratch(), M, Co, K, 0, K, Co, 2, 0, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg),
+                            lambda: _gemm(x, wmat, scratch(), M, Co, K, 0, K, Co, 2, 0, 2 if split > 1 else 0, split, geom=g))
+        if tuned is not None:
+            cfg, sp = tuned
+            out = (zeros if sp > 1 else empty)((g.N, g.Hout, g.Wout, Co), x)
+            _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg)
+            return out
     if split > 1:
         out = zeros((g.N, g.Hout, g.Wout, Co), x)
         _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, 2, split, geom=g)
@@ -553,6 +570,21 @@ def conv_gather_wgrad(a, x, g):
         _call("ud_conv_small_wgrad", C.byref(g), _p(a), _p(x), _p(ws), _p(out), Ma, _stream())
         return out
     split = _pick_split(_tiles(Ma, Ncols), Kdim)
+    if g.Cin % 4 == 0 and Ma % 4 == 0:
+        gk = (g.Hin, g.Win, g.Cin, g.KH, g.KW, g.stride, g.transposed)
+        tmp = []
+
+        def scratch():
+            if not tmp:
+                tmp.append(empty((Ma, Ncols), a))
+            return tmp[0]
+        tuned = _tuned_plan(("convw",) + gk, Ma, Ncols, Kdim,
+                            lambda cfg, sp: _gemm(a, x, scratch(), Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg),
+                            lambda: _gemm(a, x, scratch(), Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if split > 1 else 0, split, geom=g))
+        if tuned is not None:
+            cfg, sp = tuned
+            out = (zeros if sp > 1 else empty)((Ma, Ncols), a)
+            return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg)
     if split > 1:
         out = zeros((Ma, Ncols), a)
         return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2, split, geom=g)
