@@ -8,8 +8,8 @@
 // 32x32x16) replace eight fp32 MFMAs (8 x 64 cycles): 2.67x the fp32 matrix rate.
 //
 // Used by ud_gemm for the plain GEMMs (a_mode, b_mode in {0,1}) and for the implicit-GEMM conv gather on the A side
-// (a_mode 2: forward / data gradient of the 3x3 and transposed convs); the weight-gradient gather (b_mode 2) and the
-// tiny / skinny shapes stay on gemm.hip's v_mfma_f32_32x32x2_f32 kernel.
+// (a_mode 2: forward / data gradient of the 3x3 and transposed convs) and on the B side (b_mode 2: their weight gradient);
+// tiny / skinny / unaligned shapes stay on gemm.hip's v_mfma_f32_32x32x2_f32 kernel.
 //
 // Structure: 256 threads = 4 wave64, block tile BM x BN x 16, wave tile (TM x TN) x 32x32.  Operand tiles go
 // global -> registers (3 K-tiles in flight) -> split -> LDS as three bf16 planes per operand, each plane

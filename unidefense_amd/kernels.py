@@ -233,9 +233,13 @@ def _tune_candidates(M, N, K):
     return out
 
 
-def _time_launches(fn, n=6):
+_TUNE_N = int(os.environ.get("UD_GEMM_TUNE_N", "6"))          # launches per timing graph
+
+
+def _time_launches(fn, n=None):
     """Device time of one fn() in ms.  The launches are replayed from a small hipGraph: eager launches of a 20 us kernel
     are paced by the host (ctypes + Python), which hides the differences the tuner is after."""
+    n = _TUNE_N if n is None else n
     fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     cur = torch.cuda.current_stream()
