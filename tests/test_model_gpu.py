@@ -36,11 +36,12 @@ STRUCT_ZERO_GRADS = {f"backbone._blocks.{i}._bn2.bias" for i in list(range(16)) 
 # ... and the same biases in the stage whose output x_b4 also reaches the decoder / the triplet feature: still almost
 # entirely cancelled (reference norm 1e-4 against 1e-2 .. 1e+1 elsewhere)
 NEAR_ZERO_GRADS = {f"backbone._blocks.{i}._bn2.bias" for i in range(16, 22)}
-# ... and the affine parameters of the InstanceNorm in front of dec_block2's last activation: gradient norm 1e-4 .. 4e-4
-# (the other decoder tensors: 4e-3 .. 2e-2) as sums over 65k pixels that cancel to 1 % — an absolute error of 5e-7, the
-# accumulation-order noise of those sums (it depends on which GEMM plan the tuner picked for the surrounding convs), is
-# 1.3e-3 of what is left.  Both still have to meet the 2e-5 floor and the < 1e-3 reference-norm condition below.
-NEAR_ZERO_GRADS |= {"dec_block2.7.weight", "dec_block2.7.bias"}
+# ... and the affine parameters of the decoder's InstanceNorms (dec_block1 / dec_block2, layers 1 / 4 / 7): in the smooth
+# loss variant their gradients have norms 7e-5 .. 1e-3 (the decoder convs: 4e-3 .. 2e-2) as sums over up to 65k pixels that
+# cancel to ~1 % — an absolute error of 5e-7, the accumulation-order noise of those sums (it depends on which GEMM plan
+# the tuner picked for the surrounding convs), exceeds 1e-3 of what is left.  They still have to meet the 2e-5 floor and
+# the < 1e-3 reference-norm condition below.
+NEAR_ZERO_GRADS |= {f"dec_block{b}.{l}.{w}" for b in (1, 2) for l in (1, 4, 7) for w in ("weight", "bias")}
 
 
 def _dev():
