@@ -201,10 +201,22 @@ _TUNED = {}
 # UD_GEMM_TUNE_CACHE=<file>: plans are read from / added to this JSON file, so that a profiled run (rocprofv3, PMC passes)
 # repeats the plans of the benchmarked one without the tuner's measurement launches in its kernel statistics
 _TUNE_CACHE = os.environ.get("UD_GEMM_TUNE_CACHE")
+# Shipped defaults: the plans measured on an MI355X for the shapes of the BASELINE configs (bs 32 / 64 UDEB4, UDR18, UDR50,
+# the engine's train step) — those shapes start with a plan instead of a measurement; anything else is tuned on first use.
+# UD_GEMM_TUNE_DEFAULTS=0 ignores the file (every shape is measured on this machine).
+_TUNE_DEFAULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_plans_gfx950.json")
+
+
+def _load_plans(path):
+    import json
+    with open(path) as fh:
+        return {tuple(json.loads(k)): (tuple(v) if v is not None else None) for k, v in json.load(fh).items()}
+
+
+if os.environ.get("UD_GEMM_TUNE_DEFAULTS", "1") == "1" and os.path.exists(_TUNE_DEFAULTS):
+    _TUNED.update(_load_plans(_TUNE_DEFAULTS))
 if _TUNE_CACHE and os.path.exists(_TUNE_CACHE):
-    import json as _json
-    with open(_TUNE_CACHE) as _fh:
-        _TUNED = {tuple(_json.loads(k)): (tuple(v) if v is not None else None) for k, v in _json.load(_fh).items()}
+    _TUNED.update(_load_plans(_TUNE_CACHE))
 
 
 def _tune_cache_save():
