@@ -202,7 +202,8 @@ _TUNED = {}
 # repeats the plans of the benchmarked one without the tuner's measurement launches in its kernel statistics
 _TUNE_CACHE = os.environ.get("UD_GEMM_TUNE_CACHE")
 # Shipped defaults: the plans measured on an MI355X for the shapes of the BASELINE configs (bs 32 / 64 UDEB4, UDR18, UDR50,
-# the engine's train step) — those shapes start with a plan instead of a measurement; anything else is tuned on first use.
+# the engine's train step) and of the parity tests — those shapes start with a plan instead of a measurement (the same
+# plan in every run: repeatable rounding); anything else is tuned on first use.
 # UD_GEMM_TUNE_DEFAULTS=0 ignores the file (every shape is measured on this machine).
 _TUNE_DEFAULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_plans_gfx950.json")
 
