@@ -178,23 +178,29 @@ def test_udr50_320_bs16_sample_independence_and_linearity():
         (loss * scale).backward()
         return loss.detach().clone(), [p.grad.detach().clone() for p in params]
 
-    l1, g1 = run(1.0)
-    l2, g2 = run(2.0)
-    # the two runs repeat the forward: its split-K launches order their float atomics differently, and a ReLU unit within
-    # 1e-7 of zero may flip — the loss moves in the 6th digit (2.5e-6 observed), not beyond
-    assert abs(l1.item() - l2.item()) <= 2e-5 * abs(l1.item())
+    # Linearity is a statement about the backward kernels on ONE forward.  The two runs below repeat the forward, so it
+    # has to come out the same both times: with split-K launches in it (float atomics in varying order, 1e-7 on
+    # activations) a handful of the 1e8 ReLU units within that of zero flips between the runs and single gradients move
+    # by up to 5 % (measured with the tuner's plans: worst 1.2e-2 ... 4.8e-2 on a conv weight / an sf_coef, median 1e-3)
+    # — the network landing on a neighbouring linear piece, not a kernel property.  So forward and data-gradient GEMMs
+    # run as single plain launches here (every (tile, split-K) plan is checked against float64 in test_kernels_gpu.py);
+    # the weight gradients keep their split-K launches (1e-6 effects).
+    from unidefense_amd import kernels as K
+    saved = (K._TUNE_ON, K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK, dict(K._TUNED))
+    K._TUNE_ON, K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK = False, False, 0, False
+    K._TUNED.clear()
+    try:
+        l1, g1 = run(1.0)
+        l2, g2 = run(2.0)
+    finally:
+        K._TUNE_ON, K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK = saved[:4]
+        K._TUNED.update(saved[4])
+    assert abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
     gmax = max(g.abs().max().item() for g in g1)
     lin = [((a2 - 2.0 * a_).abs().max().item() / (2 * (a_.abs().max().item() + 3e-3 * gmax)), name)
            for (name, _), a_, a2 in zip(named, g1, g2)]
     print(f"  {len(lin)} tensors: 2x loss vs 2x gradients worst {max(lin)[0]:.2e} ({max(lin)[1]})")
-    # the two runs repeat the forward; split-K float atomics order differently from run to run (1e-7 on activations), a
-    # handful of the 1e8 ReLU units sits within that of zero and flips, which moves single weight gradients by ~1e-3:
-    # observed worst 1.3e-3 (a ReLU-free UDEB4 shows 1e-6 in the same test above).  A non-linear kernel would be O(1).
-    # With the per-shape GEMM tuner many more of the ResNet's thin 1x1 convs run split-K (atomics), so more layers differ in
-    # the last bit between the two runs and more ReLU units flip: worst 1.2e-2 on one conv weight, typical 1e-3 (the
-    # median below), still two orders of magnitude under what a non-linear kernel would show.
-    import statistics
-    assert len(lin) == 214 and max(lin)[0] <= 4e-2 and statistics.median(v for v, _ in lin) <= 4e-3
+    assert len(lin) == 214 and max(lin)[0] <= 1e-4          # observed 1e-6, like the ReLU-free UDEB4 in the test above
 
 
 def test_deferred_bn_sums_combine_like_syncbn():
