@@ -102,3 +102,33 @@ def test_engine_with_prefetched_host_batches():
     cfg["data"]["iterator"] = pf
     log = get_engine("UE")(cfg, "Train").train()
     assert log["step"] == 3 and all(torch.isfinite(torch.tensor(v)) for v in log.values())
+
+
+@pytest.mark.gpu
+def test_engine_fp16_precision_mode():
+    """config.precision = "fp16" (BASELINE configs[4]): fp16-MFMA GEMMs + half storage of the MBConv trunk, under the
+    engine's GradScaler, with the passes graph-captured from the second step on: finite losses, parameters move, and the
+    process-wide GEMM path goes back to fp32 for the next fp32 engine."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import copy
+    from unidefense_amd import lib
+    from unidefense_amd.engine import get_engine
+    torch.manual_seed(0)
+    cfg = copy.deepcopy(CONFIG)
+    cfg["config"]["precision"] = "fp16"
+    try:
+        eng = get_engine("FE")(cfg, "Train")
+        assert lib.call("ud_gemm_get_path") == 3 and eng.model_without_ddp.half_storage is True
+        before = {k: v.detach().clone() for k, v in eng.model.named_parameters()}
+        log = eng.train()
+        assert log["step"] == 4 and all(torch.isfinite(torch.tensor(v)) for v in log.values()), log
+        moved = sum(int(not torch.equal(before[k], v.detach())) for k, v in eng.model.named_parameters())
+        assert moved >= 500, moved
+        bad = copy.deepcopy(CONFIG)
+        bad["config"]["precision"] = "bf16"
+        with pytest.raises(ValueError):
+            get_engine("FE")(bad, "Train")
+    finally:
+        get_engine("FE")(copy.deepcopy(CONFIG), "Train")              # an fp32 engine resets the path
+        assert lib.call("ud_gemm_get_path") == 0

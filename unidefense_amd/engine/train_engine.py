@@ -66,6 +66,17 @@ class TrainEngine(AbstractEngine):
 
         self.best_step, self.best_auc, self.best_acc = 1, 0., 0.                    # forgery_engine.py:159-161
         self.model = load_model(self.model_name)(**model_cfg).to(self.device)
+        # config.precision: "fp32" (default: fp32-accurate GEMMs, the reference's arithmetic) or "fp16" — BASELINE
+        # configs[4]: fp16 MFMA operands with fp32 accumulation in every GEMM (ud_gemm path 3, process-wide) and, on the
+        # EfficientNet model, fp16 storage of the MBConv trunk's activations; the GradScaler below is what keeps the half
+        # gradients in range.  The reference has no such mode (autocast(enabled=False), abstract_engine.py:208).
+        self.precision = str(cfg.get("precision", "fp32")).lower()
+        if self.precision not in ("fp32", "fp16"):
+            raise ValueError(f"config.precision must be 'fp32' or 'fp16', got {self.precision!r}")
+        from .. import lib as _lib
+        _lib.call("ud_gemm_set_path", 3 if self.precision == "fp16" else 0)
+        if self.precision == "fp16":
+            self.model.half_storage = True
         self.model_without_ddp = self.model
         if dist.is_available() and dist.is_initialized():
             self.model = wrap_data_parallel(self.model, self.local_rank)           # SyncBN + gradient exchange
