@@ -48,7 +48,9 @@ typedef struct {
  *        1: B[k][n] at B + k*ldb + n          (weights for the data gradient, X for the weight gradient)
  *        2: conv gather with k = (n,oh,ow) and n = (kh*KW+kw)*Cin + ci        (weight gradient of a conv)
  * supported (a_mode, b_mode): (0,0) (0,1) (1,1) (2,0) (1,2).
- * out_mode 0: store, 1: C += result, 2: atomicAdd (required when split_k > 1; C must be pre-zeroed)
+ * out_mode 0: store, 1: C += result, 2: atomicAdd (split_k > 1; C pre-zeroed or holding a term to add to),
+ *          3: split s STORES its partial product into its own slice C + s * slice_stride (split_k >= 1; fp32, batch 1):
+ *             the deterministic form of split-K — ud_sum_slices then adds the slices in ascending order
  * Serves: F.conv2d 1x1 in model/efficientnet/model.py:108,125 and exp.py:57 (freq_conv),
  *         nn.Conv2d 3x3 / nn.ConvTranspose2d in model/unidefense.py:59-102, model/modules.py:82,111,
  *         the stem conv model/efficientnet/model.py:185, torch.fft.rfft2 at 256x256 (as DFT-matrix
@@ -75,8 +77,12 @@ typedef struct {
      * for callers that tune per shape by measurement (unidefense_amd/kernels.py does, on the thin expand / project
      * GEMMs whose few tiles leave the k-loop latency exposed). */
     int tile_cfg;
+    long slice_stride;       /* out_mode 3: elements between the splits' slices (>= M * ldc) */
 } ud_gemm_desc;
 int ud_gemm(const ud_gemm_desc* d, ud_stream_t stream);
+/* out[i] (+)= sum_s ws[s * slice_stride + i], s = 0 .. slices-1 in this order (total, slice_stride multiples of 4) */
+int ud_sum_slices(const float* ws, float* out, int slices, long total, long slice_stride, int accumulate,
+                  ud_stream_t stream);
 /* 0: ud_gemm would ignore stat_sum / stat_sumsq for this descriptor (the caller runs ud_colstats on the result);
  * 1: the epilogue adds straight into [N] accumulators; 64: it adds into 64 slots of [64][N] (see ud_gemm_desc). */
 int ud_gemm_stats_slots(const ud_gemm_desc* d);

@@ -221,3 +221,61 @@ def test_deferred_bn_sums_combine_like_syncbn():
     assert _rel(full[:192] / x.shape[0], xd.mean(0)) <= 1e-12
     var = full[192:] / x.shape[0] - (full[:192] / x.shape[0]) ** 2
     assert _rel(var, xd.var(0, unbiased=False)) <= 1e-10
+
+
+_DET_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import param_fill
+from tests import oracle_util as ou
+from unidefense_amd import kernels as K
+from unidefense_amd.loss import LOSSES
+from unidefense_amd.model import load_model
+assert K.DETERMINISTIC
+dev = torch.device("cuda:0")
+res = []
+for name, ctor, n, size in (("UDEB4", dict(extractor="efficientnet-b4"), 8, 256), ("UDR18", {}, 8, 128)):
+    m = load_model(name)(num_classes=2, drop_rate=0.0, **ctor)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev).train()
+    m._dec_dropout = False
+    if hasattr(m, "arch"):
+        m.arch["drop_connect_rate"] = 0.0
+    x = param_fill.make_input(n, size, seed=5).to(dev)
+    tgt = param_fill.make_labels(n).to(dev)
+    runs = []
+    for _ in range(3):
+        for p in m.parameters():
+            p.grad = None
+        out = m(x)
+        ld = out["loss_dict"]
+        LOSSES["aw_triplet"].n_real = None
+        loss = LOSSES["cross_entropy"](out["cls_out"], tgt) + 0.1 * (ld["freq_mask"].mean() + ld["spat_mask"].mean()) \
+            + 0.1 * sum(LOSSES["aw_triplet"](f, tgt) for f in ld["triplet"]) + 0.1 * ld["spatial"][: n // 2].mean() \
+            + ld["freq"][: n // 2].mean()
+        loss.backward()
+        runs.append((loss.detach().clone(), out["rec"].detach().clone(),
+                     [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]))
+    same = all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) and len(r[2]) == len(runs[0][2])
+               and all(torch.equal(a, b) for a, b in zip(runs[0][2], r[2])) for r in runs[1:])
+    res.append((name, same, len(runs[0][2]), float(runs[0][0])))
+print("DET", res)
+assert all(r[1] for r in res), res
+"""
+
+
+def test_deterministic_mode_is_bitwise_repeatable():
+    """UD_DETERMINISTIC=1 (a process-wide switch read at import, hence the child process): split-K GEMMs through ordered
+    slices (ud_gemm out_mode 3 + ud_sum_slices), the operator path's fixed-order reductions instead of the fused node's fp64
+    atomics — three runs of the same train step (UDEB4 256x256 and UDR18 128x128, bs 8) give bit-identical losses, outputs
+    and parameter gradients."""
+    _dev()
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UD_DETERMINISTIC="1", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", _DET_SCRIPT % root], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "DET" in r.stdout

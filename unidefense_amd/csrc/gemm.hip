@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
 
     const float* Ap = d.A + (long)bz * d.strideA;
     const float* Bp = d.B + (long)bz * d.strideB;
-    float* Cp = d.C + (long)bz * d.strideC;
+    float* Cp = d.C + (long)bz * d.strideC + (d.out_mode == 3 ? (long)split * d.slice_stride : 0L);   // mode 3: own slice
 
     LA la; LB lb;
     la.init(Ap, d.lda, d.M, d.K, (a_vec & 1) != 0, d.g, m0, tid);
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (nkt == 0 && d.out_mode != 0) return;
+    if (nkt == 0 && (d.out_mode == 1 || d.out_mode == 2)) return;          // (modes 0 / 3 store the zeros)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
                 if (row < d.M && col < d.N) {
                     float* p = Cp + (long)row * d.ldc + col;
                     float v = acc[i][j][r];
-                    if (d.out_mode == 0) *p = v;
+                    if (d.out_mode == 0 || d.out_mode == 3) *p = v;
                     else if (d.out_mode == 1) *p += v;
                     else atomicAdd(p, v);
                 }
@@ -491,7 +491,9 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
     if (!dp) return UD_EINVAL;
     ud_gemm_desc d = *dp;
     if (d.M <= 0 || d.N <= 0 || d.K < 0 || d.split_k < 1 || d.batch < 1) return UD_EINVAL;
-    if (d.split_k > 1 && d.out_mode != 2) return UD_EINVAL;
+    if (d.out_mode < 0 || d.out_mode > 3) return UD_EINVAL;
+    if (d.split_k > 1 && d.out_mode != 2 && d.out_mode != 3) return UD_EINVAL;
+    if (d.out_mode == 3 && (d.batch != 1 || d.slice_stride < (long)d.M * d.ldc || (d.half_mask & 4))) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     int a_vec = 0, b_vec = 0;
     vec_flags(d, a_vec, b_vec);

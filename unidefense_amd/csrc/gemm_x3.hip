@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     int k_end = k_begin + kt_per * BK;
     if (k_end > d.K) k_end = d.K;
     const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
-    float* Cp = d.C + (long)bz * d.strideC;
+    float* Cp = d.C + (long)bz * d.strideC + (d.out_mode == 3 ? (long)split * d.slice_stride : 0L);   // mode 3: own slice
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (nkt == 0 && d.out_mode != 0) return;
+    if (nkt == 0 && (d.out_mode == 1 || d.out_mode == 2)) return;          // (modes 0 / 3 store the zeros)
     const bool c_half = (d.half_mask & 4) != 0;
     if (c_half) {          // statistics and consumers see the rounded values
 #pragma unroll
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
                         *p = (_Float16)(d.out_mode == 0 ? v : v + (float)*p);
                     } else {
                         float* p = Cp + (long)row * d.ldc + col;
-                        if (d.out_mode == 0) *p = v;
+                        if (d.out_mode == 0 || d.out_mode == 3) *p = v;
                         else if (d.out_mode == 1) *p += v;
                         else atomicAdd(p, v);
                     }

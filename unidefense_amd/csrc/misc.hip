@@ -284,6 +284,18 @@ __global__ __launch_bounds__(NT) void axpby(long total, const T* __restrict__ a,
     }
 }
 
+// out[i] (+)= sum_s ws[s][i], s ascending: the fixed-order end of a deterministic split-K GEMM (ud_gemm out_mode 3)
+__global__ __launch_bounds__(NT) void sum_slices(long total4, int slices, long stride4, const float* __restrict__ ws,
+                                                 float* __restrict__ out, int accumulate) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(ws);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total4; e += (long)gridDim.x * NT) {
+        f32x4 v = accumulate ? o4[e] : f32x4{0, 0, 0, 0};
+        for (int s = 0; s < slices; ++s) v += w4[(long)s * stride4 + e];
+        o4[e] = v;
+    }
+}
+
 // out = x * mask * scale        (dropout with an explicit keep-mask)
 __global__ __launch_bounds__(NT) void mask_scale(long total, const float* __restrict__ x, const float* __restrict__ m,
                                                  float scale, float* __restrict__ out) {
@@ -696,6 +708,15 @@ int ud_residual_fwd(const float* x, const float* skip, const float* keep, float 
 int ud_axpby(const void* a, float alpha, const void* b, float beta, void* out, long total, int f16, ud_stream_t stream) {
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(axpby<T>, dim3(ew_blocks(total)), dim3(NT), 0, (hipStream_t)stream, total,
                                                 (const T*)a, alpha, (const T*)b, beta, (T*)out));
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_sum_slices(const float* ws, float* out, int slices, long total, long slice_stride, int accumulate,
+                  ud_stream_t stream) {
+    if (!ws || !out || slices < 1 || total < 4 || total % 4 || slice_stride % 4 || slice_stride < total) return UD_EINVAL;
+    hipLaunchKernelGGL(sum_slices, dim3(ew_blocks(total / 4)), dim3(NT), 0, (hipStream_t)stream, total / 4, slices,
+                       slice_stride / 4, ws, out, accumulate);
     UD_LAUNCH_CHECK();
     return 0;
 }

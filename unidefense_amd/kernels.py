@@ -114,6 +114,21 @@ def zeros(shape, like):
 # ---------------------------------------------------------------------------------------------
 # GEMM family
 # ---------------------------------------------------------------------------------------------
+# UD_DETERMINISTIC=1: bit-reproducible steps.  Split-K GEMMs store their partial products into slices of a scratch buffer
+# and add them in ascending order (ud_gemm out_mode 3 + ud_sum_slices) instead of float atomics, and the model runs the
+# operator path whose reductions are fixed-order partials (model/unidefense.py) instead of the fused MBConv node with its
+# fp64 atomics.  Costs ~10 % of the step; the default mode's run-to-run variation is in the last bits.
+DETERMINISTIC = os.environ.get("UD_DETERMINISTIC", "0") == "1"
+_SLICE_WS = {}
+
+
+def _slice_ws(ref, n):
+    ws = _SLICE_WS.get(ref.device.index)
+    if ws is None or ws.numel() < n:
+        ws = _SLICE_WS[ref.device.index] = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=ref.device)
+    return ws
+
+
 def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_k=1, geom=None,
           batch=1, strideA=0, strideB=0, strideC=0, a_off=0, b_off=0, stats=None, cfg=0):
     """stats: fp64 accumulator [sum | sumsq] (2N doubles) the epilogue should add the result's column sums into; returns
@@ -128,6 +143,17 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
     d.tile_cfg = cfg
+    slices = None
+    if DETERMINISTIC and out_mode == 2:
+        # Cout holds zeros or a term to add to: result = Cout + the splits' partials in ascending order
+        total = M * ldc
+        if batch == 1 and total % 4 == 0 and Cout.dtype == torch.float32:
+            stride = total
+            ws = _slice_ws(Cout, split_k * stride)
+            d.C, d.out_mode, d.slice_stride = ws.data_ptr(), 3, stride
+            slices = (ws, stride, total)
+        else:                                   # no slice form for this output: one plain accumulating launch
+            d.out_mode, d.split_k = 1, 1
     if geom is not None:
         d.g = geom
     fold = None
@@ -153,6 +179,9 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
                              float(batch) * (A.element_size() * M * K + B.element_size() * K * N + Cout.element_size() * M * N)))
     else:
         _call("ud_gemm", C.byref(d), _stream())
+    if slices is not None:
+        ws, stride, total = slices
+        _call("ud_sum_slices", _p(ws), _p(Cout), split_k, total, stride, 1, _stream())
     if fold is not None:
         tgt, slots = fold
         _call("ud_stat_slots_fold", _pd64(tgt), _pd64(tgt, slots * N), slots, N, _pd64(stats), _pd64(stats, N), _stream())

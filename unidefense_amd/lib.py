@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("lda", C.c_long), ("ldb", C.c_long), ("ldc", C.c_long),
                 ("a_mode", C.c_int), ("b_mode", C.c_int), ("out_mode", C.c_int), ("split_k", C.c_int),
                 ("batch", C.c_int), ("strideA", C.c_long), ("strideB", C.c_long), ("strideC", C.c_long),
-                ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("half_mask", C.c_int), ("tile_cfg", C.c_int)]
+                ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("half_mask", C.c_int), ("tile_cfg", C.c_int), ("slice_stride", C.c_long)]
 
 
 class BnRef(C.Structure):
@@ -133,6 +133,7 @@ _SIGNATURES = {
     "ud_adamw_chunk_elems": [],
     "ud_adamw_multi": [_P, _P, _I, _P, _P, _I, C.c_double, C.c_double, C.c_double, _I, _I, _P, _P, _P, _P, _P],
     "ud_gemm_get_path": [],
+    "ud_sum_slices": [_P, _P, _I, _L, _L, _I, _P],
     "ud_xchg_bytes": [_I, _I, _I],
     "ud_xchg_create": [_I, _I, _I, _P, _P],
     "ud_xchg_open": [_P, _P],

@@ -102,7 +102,7 @@ _OUT_KEYS = ("cls_out", "rec", "factorization", "triplet0", "triplet1", "triplet
 
 # training mode: MBConv blocks as fused tape nodes with deferred BatchNorms (tape.mbconv_fused); UD_FUSED_MBCONV=0
 # runs the operator-by-operator path (same results: tests/test_fused_gpu.py compares the two)
-_FUSED_MBCONV = os.environ.get("UD_FUSED_MBCONV", "1") == "1"
+_FUSED_MBCONV = os.environ.get("UD_FUSED_MBCONV", "1") == "1" and not K.DETERMINISTIC      # (fp64 atomics: kernels.DETERMINISTIC)
 
 
 def _half_storage(model):
