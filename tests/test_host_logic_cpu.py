@@ -76,3 +76,23 @@ def test_gemm_tuner_candidates_and_plan_cache(tmp_path):
         else:
             os.environ["UD_GEMM_TUNE_CACHE"] = old_env
         importlib.reload(K)
+
+
+def test_tape_cast_converts_values_and_gradients():
+    """tape.cast — the storage-type boundary of the half-storage trunk: y = x.to(dtype), the gradient comes back in x's type
+    and accumulates with the other consumers' gradients of x."""
+    import torch
+    from unidefense_amd import tape as T
+    tape = T.Tape()
+    x = torch.randn(2, 3, 3, 4)
+    y = T.cast(tape, x, torch.float16)
+    assert y.dtype == torch.float16 and torch.equal(y, x.half())
+    assert T.cast(tape, x, torch.float32) is x                       # same type: identity, no tape node
+    n_nodes = len(tape.nodes)
+    assert n_nodes == 1
+    gy = torch.randn(2, 3, 3, 4).half()
+    tape.add_grad(y, gy)
+    for fn in reversed(tape.nodes):
+        fn()
+    gx = tape.pop_grad(x)
+    assert gx.dtype == torch.float32 and torch.equal(gx, gy.float())
