@@ -62,6 +62,29 @@ def _worker(rank, world, port, q):
         ok_stream = set(out2) == {id(p) for p in params} and tp.param_seen == tp.param_uses and all(
             torch.allclose(out2[id(p)], torch.full_like(p, (i + 1) * (1 + world) / 2.0)) for i, p in enumerate(params))
         ok_avg = ok_avg and ok_stream and dp.module._grad_prescale == 1.0 / world
+        # 5. the fused path's SyncBN context (tape.DataParallelCtx): fp64 accumulators summed in place, the local copy kept
+        #    for the affine gradients; sums that fit the mailbox go through the exchange object, larger ones through
+        #    dist.all_reduce (here a stand-in exchange that counts its calls and reduces over gloo)
+        dpc = T.DataParallelCtx(dist.group.WORLD)
+        acc = torch.full((6,), float(rank + 1), dtype=torch.float64)
+        loc = dpc.reduce(acc, keep_local=True)
+        tri = world * (world + 1) / 2.0
+        ok_ctx = dpc.world == world and dpc.synced and torch.equal(acc, torch.full((6,), tri, dtype=torch.float64)) \
+            and torch.equal(loc, torch.full((6,), float(rank + 1), dtype=torch.float64))
+
+        class _Exchange:
+            MAX_DOUBLES, calls = 4, 0
+
+            def allreduce(self, a):
+                self.calls += 1
+                dist.all_reduce(a)
+        ex = _Exchange()
+        dpx = T.DataParallelCtx(dist.group.WORLD, ex)
+        small, big = torch.ones(4, dtype=torch.float64), torch.ones(6, dtype=torch.float64)
+        dpx.reduce(small)
+        dpx.reduce(big)
+        ok_ctx = ok_ctx and ex.calls == 1 and bool((small == world).all()) and bool((big == world).all())
+        ok_bn = ok_bn and ok_ctx
         q.put((rank, ok_bcast, ok_avg, ok_bn, hasattr(net, "_sync_bn_group")))
     except Exception as e:          # surface the failure instead of letting the parent time out
         q.put((rank, False, False, False, repr(e)))
