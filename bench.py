@@ -7,8 +7,10 @@ engine/abstract_engine.py:210-281 in the reference) at 256x256, bs=32 per GPU, f
 
 Prints ONE JSON line on rank 0 (metric/unit from BASELINE.json; value = whole-job images/s with inputs
 resident in HBM; weak scaling: bs=32 per GPU).  Extra objects:
-  roofline     — dominant kernel = the fp32 MFMA GEMM (ud_gemm): algorithmic FLOPs of all its launches in
-                 the timed region / their HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak.
+  roofline     — dominant kernel = gemm_x3_kernel (fp32 GEMM on the BF16 matrix pipe, six bf16 MFMAs per fp32 product
+                 tile): algorithmic FLOPs (2MNK) of its launches / their HIP-event durations (3 eager instrumented steps
+                 after the timed region), against the pipe's dense BF16 peak / 6 (= 416.7 TFLOP/s); `hbm`: the same
+                 launches' algorithmic bytes against 8 TB/s; `traffic`: PMC-measured HBM bytes per launch (profiles/).
   cpu_baseline — the oracle (CPU restatement, "port") timed on the host cores (CPU quota of the job) on a bounded
                  sample (bs 8, ~10 s), in a child process after the timed region.
 """
@@ -176,7 +178,8 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    force = os.environ.get("UD_FORCE_COLLECTIVES", "0") == "1"     # 1-GPU exercise of the RCCL path (tape.py)
+    from unidefense_amd.config import cfg
+    force = cfg.force_collectives     # UD_FORCE_COLLECTIVES=1: 1-GPU exercise of the RCCL path (tape.py)
     if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -344,7 +347,8 @@ def main():
                        "final_loss": float(loss.detach()),
                        # checksum of the step's result (tests: the data-parallel path at world size 1 must give
                        # the plain step's gradients)
-                       "grad_l1": float(sum(p.grad.double().abs().sum() for p in params if p.grad is not None))},
+                       "grad_l1": float(sum(p.grad.double().abs().sum() for p in params if p.grad is not None)),
+                       "deterministic": cfg.deterministic},
             "roofline": {"bound": "hbm" if args.dtype == "f16" else "mfma",
                          "kernel": "gemm_x3_kernel (csrc/gemm_x3.hip): fp32 GEMM on the BF16 matrix pipe — every fp32 operand "
                                    "split exactly into 3 bf16 pieces, SIX v_mfma_f32_32x32x16_bf16 per fp32 product tile, "

@@ -141,7 +141,7 @@ def main():
     # the dynamic filters is 1.2e-3 for this batch (oracle.eb4 "_max_gap"), so the arg-max — whose
     # gradient is discontinuous — cannot flip under fp32 rounding differences.
     # Two loss variants: "full" = the reference's pass-1 loss; "smooth" = the same with
-    # lambda_recons = lambda_freq = 0 (the two L1 terms have sign() gradients, see tests/test_model_gpu.py).
+    # lambda_recons = lambda_freq = 0 (the two L1 terms have sign() gradients, see tests/test_c_model_gpu.py).
     n, in_seed, mask_seed = 4, 38, 138
     param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
     x = param_fill.make_input(n, 256, seed=in_seed)

@@ -143,7 +143,7 @@ def main():
             out[f"{tag}_{k}"] = v
         print(tag, {k: float(v) for k, v in st.items() if k.startswith("loss_")})
         # the same step in float64: |fp32 - fp64| of the reference itself is the conditioning yardstick the
-        # parity test scales its tolerances with (the first Adam steps are sign-like, see tests/test_engine_gpu.py)
+        # parity test scales its tolerances with (the first Adam steps are sign-like, see tests/test_d_engine_gpu.py)
         st64 = run(step, torch.float64)
         for k, v in st64.items():
             if k.startswith(("loss_", "out_", "delta_")):

@@ -10,7 +10,7 @@
 Every random draw is pinned: Bernoulli masks injected at the F.dropout / drop_connect sites, torch.rand(1) (branch),
 torch.randint (choice), torch.randperm (the engine's permutation lists) and the transfer's lmda = torch.rand((B,1,1[,1]))
 replaced by seeded stand-ins — oracle/pins.py holds the SAME stand-ins for the GPU test, which patches them around the
-HIP engine (its perturbation code draws in the reference's order, tests/test_perturb.py).
+HIP engine (its perturbation code draws in the reference's order, tests/test_c_perturb.py).
 Stored: the returned loss scalars + pass-1 cls_out, per-parameter update norms and heads, each also from a float64 run.
 
 Run:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_step2

@@ -3,7 +3,7 @@ of the reference's train step.  Only tests/, __graft_e
 cpu_baseline leg may import this package; the product path (unidefense_amd/) never does.
 
 Pinned against tests/golden/perturb_n4.npz (oracle/make_golden_perturb.py: the reference's own functions run in
-this container) by tests/test_perturb.py.  Random draws (lmda, the noise field, the branch choices) are INPUTS
+this container) by tests/test_c_perturb.py.  Random draws (lmda, the noise field, the branch choices) are INPUTS
 here; the reference takes them from torch's global CPU generator.
 
   downscale                 model/modules.py:19-21       F.interpolate(nearest) x0.75 then back to (H, W)

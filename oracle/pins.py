@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE — seeded stand-ins for the global-RNG draws of the pass-2 perturbation
 (model/unidefense.py:177-198 and engine/abstract_engine.py:287-289 of the reference), shared by the golden generator
-(oracle/make_golden_step2.py, run against the reference) and the GPU test (tests/test_engine_gpu.py, run around the HIP
+(oracle/make_golden_step2.py, run against the reference) and the GPU test (tests/test_d_engine_gpu.py, run around the HIP
 engine): both sides then take the same branch with the same permutation lists and mixing coefficients.
 
   torch.rand(1)            -> 0.75 for the style branch ('freq' / 'efdm'), 0.0 for the PERT_FUNCS branch ('downscale')

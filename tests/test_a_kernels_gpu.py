@@ -37,9 +37,10 @@ def rel_err(a, b):
 
 
 def check(name, got, ref, tol=RTOL):
+    from tests.margins import within
     e = rel_err(got, ref)
     print(f"  {name}: rel err {e:.3e}")
-    assert e <= tol, f"{name}: rel err {e:.3e} > {tol}"
+    assert within(name, e, tol), f"{name}: rel err {e:.3e} > {tol}"
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -220,12 +221,21 @@ def test_gemm_split_bf16_path_has_fp32_accuracy(kind, M, N, K):
 @pytest.mark.parametrize("kind,M,N,K", [("nt", 2048, 272, 1632), ("nn", 2048, 1632, 272), ("tn", 1632, 272, 2048),
                                         ("nt", 300, 72, 200), ("nn", 132, 68, 260), ("tn", 68, 76, 1001),
                                         ("nt", 8192 + 64, 160, 960), ("tn", 160, 960, 8192 + 3)])
-def test_gemm_every_tile_configuration_and_split(kind, M, N, K):
+@pytest.mark.parametrize("mode", ["ordered-slices", "atomics"])
+def test_gemm_every_tile_configuration_and_split(kind, M, N, K, mode):
     """Every plan the per-shape tuner (kernels._tuned_plan) may pick: the four tiles of gemm_x3.hip (128x128, 128x64,
     64x128, 64x64, each with its own prefetch depth) x split-K 1 ... 24, on ragged shapes, against float64 — a plan is a
-    speed choice, never a numerical one."""
+    speed choice, never a numerical one.  Both forms of split-K: partial products into ordered slices + ud_sum_slices
+    (cfg.deterministic, the default: also required to be BITWISE repeatable) and fp32 atomics."""
     dev = _dev()
     from unidefense_amd import kernels as Kk
+    from unidefense_amd.config import override
+    with override(deterministic=mode == "ordered-slices"):
+        _every_tile_and_split(dev, Kk, kind, M, N, K, mode)
+
+
+def _every_tile_and_split(dev, Kk, kind, M, N, K, mode):
+    from tests.margins import within
     g = torch.Generator().manual_seed(M + N)
     sa, sb = ((K, M) if kind == "tn" else (M, K)), ((N, K) if kind == "nt" else (K, N))
     a, b = torch.randn(sa, generator=g), torch.randn(sb, generator=g)
@@ -245,7 +255,15 @@ def test_gemm_every_tile_configuration_and_split(kind, M, N, K):
             e = ((out.double().cpu() - ref).abs() / scale).max().item()
             worst = max(worst, e)
             assert e <= 2e-6, (cfg, split, e)
-    print(f"  {kind} {M}x{N}x{K}: worst error / sum|a||b| over 4 tiles x 5 splits: {worst:.2e}")
+            if split > 1 and mode == "ordered-slices":
+                # a fresh (uninitialised) result buffer takes the write form of the slice sum; twice the same bits
+                o1, o2 = Kk.split_out((M, N), a), Kk.split_out((M, N), a)
+                o1.fill_(float("nan"))
+                Kk._gemm(a, b, o1, M, N, K, lda, ldb, N, a_mode, b_mode, 2, split, cfg=cfg)
+                Kk._gemm(a, b, o2, M, N, K, lda, ldb, N, a_mode, b_mode, 2, split, cfg=cfg)
+                assert torch.equal(o1, out) and torch.equal(o2, out), (cfg, split)
+    within(f"{kind} {M}x{N}x{K} [{mode}]: worst error / sum|a||b| over 4 tiles x 5 splits", worst, 2e-6)
+    print(f"  {kind} {M}x{N}x{K} [{mode}]: worst error / sum|a||b| over 4 tiles x 5 splits: {worst:.2e}")
 
 
 def test_syncbn_combine_matches_gloo_tested_formula():

@@ -29,7 +29,8 @@ def _style(g, x):
 
 def _close(got, ref, tol, what):
     err = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)).max() / max(np.abs(ref).max(), 1e-30)
-    assert err <= tol, (what, err)
+    from tests.margins import within
+    assert within(what, err, tol), (what, err)
     return err
 
 

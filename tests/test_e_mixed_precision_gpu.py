@@ -67,7 +67,9 @@ def test_fp16_operand_gemms_track_the_fp32_step(storage):
         # behind BatchNorm1d / InstanceNorm statistics over a batch of 4, single entries of `fac` and single pixels of `rec`
         # move by several percent of the range while each tensor as a whole stays within 2 % in L2
         # (half storage adds the roundings of the stored activations: single pixels of `rec` move by up to 12 % of the range)
-        assert rms[k] <= 2e-2 and errs[k] <= (1.5e-1 if storage == "half" else 1e-1), (k, errs[k], rms[k])
+        from tests.margins import within
+        ok = [within(f"{k}: relative L2 vs fp32 step", rms[k], 2e-2), within(f"{k}: max-abs / max", errs[k], 1.5e-1 if storage == "half" else 1e-1)]
+        assert all(ok), (k, errs[k], rms[k])
     assert all(torch.isfinite(g).all() for g in g16.values())
     rel, cos, n_sig = [], [], 0
     for k, a in g32.items():
@@ -96,6 +98,7 @@ def test_fp16_operand_gemms_track_the_fp32_step(storage):
     # gradient at the head (batch-16 statistics amplify a forward perturbation ~4x), not through lost gradient bits — it
     # is the same for loss scales 2^10 ... 2^16 and no common rescale removes it (tools/probe_loss_scale.py).
     med_bar = 1e-1 if storage == "half" else 5e-2
-    assert np.percentile(r, 50) <= med_bar and np.percentile(r, 90) <= 1.5e-1 and r.max() <= 0.6
-    assert c.min() >= 0.85 and np.percentile(c, 1) >= 0.95
+    ok = [within("gradient relative L2: median", np.percentile(r, 50), med_bar), within("... 90 %", np.percentile(r, 90), 1.5e-1),
+          within("... max", r.max(), 0.6), within("1 - min cosine", 1 - c.min(), 0.15), within("1 - 1 % cosine", 1 - np.percentile(c, 1), 0.05)]
+    assert all(ok)
     assert n_sig >= 450

@@ -14,7 +14,7 @@ def test_reference_style_syncbn_plus_ddp_wrapping_runs():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import param_fill
-    from tests.test_dp2_gpu import _build, _loss
+    from tests.test_f_dp2_gpu import _build, _loss
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -44,7 +44,8 @@ def test_reference_style_syncbn_plus_ddp_wrapping_runs():
                 assert p.grad is not None, k
                 worst = max(worst, (p.grad - ref[k]).abs().max().item() / (ref[k].abs().max().item() + 3e-3 * gmax))
         print(f"  DDP + SyncBN (1 rank) vs plain: worst gradient difference {worst:.2e}")
-        assert worst <= 2e-3
+        from tests.margins import within
+        assert within("SyncBN + DDP wrap vs plain step: worst gradient deviation", worst, 2e-3)
     finally:
         if created:
             dist.destroy_process_group()

@@ -59,10 +59,11 @@ def test_forced_collectives_match_plain_step(flags):
     print("  plain :", plain["config"]["exec"], plain["config"]["final_loss"], "%.1f ms" % plain["ms_per_step"])
     print("  forced:", forced["config"]["exec"], forced["config"]["final_loss"], "%.1f ms" % forced["ms_per_step"])
     a, b = plain["config"]["final_loss"], forced["config"]["final_loss"]
-    assert abs(a - b) <= 1e-4 * abs(a), (a, b)
+    from tests.margins import within
+    assert within("forced collectives vs plain: final loss", abs(a - b) / abs(a), 1e-4), (a, b)
     # gradients: streamed buckets (views of the reduced flat buffers) must be the plain step's gradients
     ga, gb = plain["config"]["grad_l1"], forced["config"]["grad_l1"]
     print("  grad L1:", ga, gb)
-    assert ga > 0 and abs(ga - gb) <= 1e-4 * ga, (ga, gb)
+    assert ga > 0 and within("forced collectives vs plain: gradient L1", abs(ga - gb) / ga, 1e-4), (ga, gb)
     if not flags:      # the RCCL calls must survive hipGraph capture, else the 8-GPU bench would run eagerly
         assert forced["config"]["exec"] == "hipgraph", err[-2000:]

@@ -70,7 +70,9 @@ def _worker(rank, port, q, exchange=True):
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         dist.init_process_group("gloo", rank=rank, world_size=2)
+        from unidefense_amd.config import cfg
         from unidefense_amd.engine.parallel import HipDataParallel
+        cfg.syncbn_exchange = bool(exchange)
         m = _build(dev)
         dp = HipDataParallel(m, bucket_bytes=32 << 20)
         x, idx = _shards()
@@ -128,20 +130,23 @@ def test_two_ranks_equal_one_process_full_batch(exchange):
         e1 = abs(cls - out["cls_out"].detach().cpu().numpy()[ids]).max() / out["cls_out"].abs().max().item()
         e2 = abs(rec - out["rec"].detach().cpu().numpy()[ids]).max() / out["rec"].abs().max().item()
         print(f"  rank {rank}: cls_out {e1:.2e}  rec {e2:.2e}")
-        assert e1 <= 1e-4 and e2 <= 1e-3, (rank, e1, e2)
+        from tests.margins import within
+        assert within(f"rank {rank} cls_out vs full batch", e1, 1e-4) and within(f"rank {rank} rec vs full batch", e2, 1e-3), (rank, e1, e2)
     # both ranks hold the same averaged gradients, equal to the full-batch gradients
     g0, g1 = got[0][2][0], got[1][2][0]
     assert set(g0) == set(ref_g) == set(g1)
     gmax = max(v[2] for v in ref_g.values())
     worst, worst_norm, worst_rr = (0.0, ""), (0.0, ""), 0.0
     for k, (head, norm, mx) in ref_g.items():
-        scale = mx + 3e-3 * gmax                     # zero-true-gradient tensors hold rounding noise (test_fullsize_gpu.py)
+        scale = mx + 3e-3 * gmax                     # zero-true-gradient tensors hold rounding noise (test_y_fullsize_gpu.py)
         worst = max(worst, (float(abs(g0[k][0] - head).max()) / scale, k))
         worst_norm = max(worst_norm, (abs(g0[k][1] - norm) / (norm + 3e-3 * gmax * head.size ** 0.5), k))
         worst_rr = max(worst_rr, float(abs(g0[k][0] - g1[k][0]).max()) / scale)
     print(f"  {len(ref_g)} gradients: 2 ranks vs full batch: worst entry {worst[0]:.2e} ({worst[1]}), worst norm "
           f"{worst_norm[0]:.2e} ({worst_norm[1]}); rank 0 vs rank 1 {worst_rr:.2e}")
-    assert worst_rr <= 1e-6 and worst[0] <= 2e-3 and worst_norm[0] <= 2e-3
+    ok = [within("rank 0 vs rank 1 gradients", worst_rr, 1e-6), within("averaged gradient heads vs full batch", worst[0], 2e-3),
+          within("averaged gradient norms vs full batch", worst_norm[0], 2e-3)]
+    assert all(ok)
 
 
 def _xchg_worker(rank, port, q):

@@ -60,8 +60,9 @@ def test_gemm_tuner_candidates_and_plan_cache(tmp_path):
         assert any(s == 1 for _, s in cands) or Kd >= 1024
     # cache file: written on every new plan, read back at import
     path = str(tmp_path / "plans.json")
-    old_env = os.environ.get("UD_GEMM_TUNE_CACHE")
-    os.environ["UD_GEMM_TUNE_CACHE"] = path
+    from unidefense_amd.config import cfg
+    old = cfg.gemm_tune_cache
+    cfg.gemm_tune_cache = path
     try:
         K2 = importlib.reload(K)
         K2._TUNED[("nt", 2048, 272, 1632, False, 0)] = (4, 3)
@@ -71,10 +72,7 @@ def test_gemm_tuner_candidates_and_plan_cache(tmp_path):
         K3 = importlib.reload(K2)
         assert K3._TUNED[("nt", 2048, 272, 1632, False, 0)] == (4, 3) and K3._TUNED[("tn", 160, 960, 8192, False, 0)] is None
     finally:
-        if old_env is None:
-            os.environ.pop("UD_GEMM_TUNE_CACHE", None)
-        else:
-            os.environ["UD_GEMM_TUNE_CACHE"] = old_env
+        cfg.gemm_tune_cache = old
         importlib.reload(K)
 
 

@@ -78,6 +78,11 @@ def check_updates(g, tag, delta, slack=0.02):
         elem_tot += head.size
     print(f"  update norms within 2e-3: {norm_ok}/{len(names)} (reference fp32-vs-fp64: {own_norm:.3f});  "
           f"leading elements within 1e-3: {elem_ok}/{elem_tot} (reference fp32-vs-fp64: {own_elem:.3f})")
+    from tests.margins import record
+    record(f"{tag}: share of update norms NOT within 2e-3 (bar: the reference's own fp32-vs-fp64 share + slack)",
+           1.0 - norm_ok / len(names), 1.0 - (own_norm - slack))
+    record(f"{tag}: share of leading update elements NOT within 1e-3 (bar likewise)", 1.0 - elem_ok / elem_tot,
+           1.0 - (own_elem - slack))
     assert norm_ok >= (own_norm - slack) * len(names), (norm_ok, len(names), own_norm)
     assert elem_ok >= (own_elem - slack) * elem_tot, (elem_ok, elem_tot, own_elem)
 

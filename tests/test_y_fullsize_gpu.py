@@ -42,7 +42,7 @@ def _rel(a, b):
 
 def _loss(out, tgt):
     from unidefense_amd.loss import LOSSES
-    from tests.test_model_gpu import _pass1_loss
+    from tests.test_c_model_gpu import _pass1_loss
     LOSSES["aw_triplet"].n_real = None
     return _pass1_loss(out, tgt, dict(ou.LAMBDAS))["total_loss"]
 
@@ -57,11 +57,11 @@ def test_samples_are_independent_in_eval_mode():
     for k in ("cls_out", "rec"):
         e = _rel(full[k], torch.cat([a[k], b[k]], 0))
         print(f"  {k}: {e:.2e}")
-        assert e <= 3e-4, (k, e)        # different batch -> different split-K / tile plans -> different rounding; a leak is O(1)
+        assert within("bs 32 vs two bs 16: " + k, e, 3e-4), (k, e)        # different batch -> different split-K / tile plans -> different rounding; a leak is O(1)
     for k in ("spatial", "freq", "freq_mask", "spat_mask", "factorization"):
         e = _rel(full["loss_dict"][k], torch.cat([a["loss_dict"][k], b["loss_dict"][k]], 0))
         print(f"  {k}: {e:.2e}")
-        assert e <= 3e-4, (k, e)        # different batch -> different split-K / tile plans -> different rounding; a leak is O(1)
+        assert within("bs 32 vs two bs 16: " + k, e, 3e-4), (k, e)        # a leak is O(1)
 
 
 def test_backward_is_linear_and_replay_is_deterministic():
@@ -94,7 +94,9 @@ def test_backward_is_linear_and_replay_is_deterministic():
         lin.append(((a2 - 2.0 * a).abs().max().item() / (2 * scale), name))
     print(f"  {len(det)} tensors: replay worst {max(det)[0]:.2e} ({max(det)[1]}), "
           f"2x loss vs 2x gradients worst {max(lin)[0]:.2e} ({max(lin)[1]})")
-    assert max(det)[0] <= 1e-3 and max(lin)[0] <= 1e-3      # typical 1e-6
+    ok = [within("replay: worst gradient deviation / scale", max(det)[0], 1e-3),
+          within("2x loss vs 2x gradients: worst deviation / scale", max(lin)[0], 1e-3)]
+    assert all(ok)      # typical 1e-6
 
 
 @pytest.mark.parametrize("S,C", [(64, 192), (32, 336), (16, 960), (8, 1632)])
@@ -113,7 +115,8 @@ def test_rfft2_irfft2_round_trip_full_batch(S, C):
     energy = ((re.double() ** 2 + im.double() ** 2) * w.view(1, 1, -1, 1).double()).sum()
     p = abs(energy.item() / (x.double() ** 2).sum().item() - 1.0)
     print(f"  S={S} C={C}: round trip {e:.2e}, Parseval {p:.2e}")
-    assert e <= 2e-6 and p <= 1e-6
+    ok = [within("rfft2 -> irfft2 round trip", e, 2e-6), within("Parseval", p, 1e-6)]
+    assert all(ok)
 
 
 def test_full_batch_bn_equals_syncbn_combination_of_halves():
@@ -155,11 +158,11 @@ def test_udr50_320_bs16_sample_independence_and_linearity():
     for k in ("cls_out", "rec"):
         e = _rel(full[k], torch.cat([a[k], b[k]], 0))
         print(f"  {k}: {e:.2e}")
-        assert e <= 3e-4, (k, e)
+        assert within("UDR50 bs 16 vs two bs 8: " + k, e, 3e-4), (k, e)
     for k in ("spatial", "freq", "freq_mask", "spat_mask", "factorization"):
         e = _rel(full["loss_dict"][k], torch.cat([a["loss_dict"][k], b["loss_dict"][k]], 0))
         print(f"  {k}: {e:.2e}")
-        assert e <= 3e-4, (k, e)
+        assert within("UDR50 bs 16 vs two bs 8: " + k, e, 3e-4), (k, e)
     m.train()
     tgt = param_fill.make_labels(n).to(dev)
     named = [(k, p) for k, p in m.named_parameters() if p.requires_grad]
@@ -183,24 +186,26 @@ def test_udr50_320_bs16_sample_independence_and_linearity():
     # activations) a handful of the 1e8 ReLU units within that of zero flips between the runs and single gradients move
     # by up to 5 % (measured with the tuner's plans: worst 1.2e-2 ... 4.8e-2 on a conv weight / an sf_coef, median 1e-3)
     # — the network landing on a neighbouring linear piece, not a kernel property.  So forward and data-gradient GEMMs
-    # run as single plain launches here (every (tile, split-K) plan is checked against float64 in test_kernels_gpu.py);
+    # run as single plain launches here (every (tile, split-K) plan is checked against float64 in test_a_kernels_gpu.py);
     # the weight gradients keep their split-K launches (1e-6 effects).
     from unidefense_amd import kernels as K
-    saved = (K._TUNE_ON, K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK, dict(K._TUNED))
-    K._TUNE_ON, K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK = False, False, 0, False
+    from unidefense_amd.config import override
+    saved = (K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK, dict(K._TUNED))
+    K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK = False, 0, False
     K._TUNED.clear()
     try:
-        l1, g1 = run(1.0)
-        l2, g2 = run(2.0)
+        with override(gemm_tune=False):
+            l1, g1 = run(1.0)
+            l2, g2 = run(2.0)
     finally:
-        K._TUNE_ON, K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK = saved[:4]
-        K._TUNED.update(saved[4])
+        K._TAIL_SPLIT, K._FWD_SPLIT_T, K._CONV_SPLITK = saved[:3]
+        K._TUNED.update(saved[3])
     assert abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
     gmax = max(g.abs().max().item() for g in g1)
     lin = [((a2 - 2.0 * a_).abs().max().item() / (2 * (a_.abs().max().item() + 3e-3 * gmax)), name)
            for (name, _), a_, a2 in zip(named, g1, g2)]
     print(f"  {len(lin)} tensors: 2x loss vs 2x gradients worst {max(lin)[0]:.2e} ({max(lin)[1]})")
-    assert len(lin) == 214 and max(lin)[0] <= 1e-4          # observed 1e-6, like the ReLU-free UDEB4 in the test above
+    assert len(lin) == 214 and within("UDR50 2x loss vs 2x gradients: worst deviation / scale", max(lin)[0], 1e-4)      # observed 1e-6
 
 
 def test_deferred_bn_sums_combine_like_syncbn():
@@ -223,18 +228,9 @@ def test_deferred_bn_sums_combine_like_syncbn():
     assert _rel(var, xd.var(0, unbiased=False)) <= 1e-10
 
 
-_DET_SCRIPT = r"""
-import sys, torch
-sys.path.insert(0, %r)
-from oracle import param_fill
-from tests import oracle_util as ou
-from unidefense_amd import kernels as K
-from unidefense_amd.loss import LOSSES
-from unidefense_amd.model import load_model
-assert K.DETERMINISTIC
-dev = torch.device("cuda:0")
-res = []
-for name, ctor, n, size in (("UDEB4", dict(extractor="efficientnet-b4"), 8, 256), ("UDR18", {}, 8, 128)):
+def _det_runs(dev, name, ctor, n, size, reps=3):
+    from unidefense_amd.loss import LOSSES
+    from unidefense_amd.model import load_model
     m = load_model(name)(num_classes=2, drop_rate=0.0, **ctor)
     param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
     m = m.to(dev).train()
@@ -244,7 +240,7 @@ for name, ctor, n, size in (("UDEB4", dict(extractor="efficientnet-b4"), 8, 256)
     x = param_fill.make_input(n, size, seed=5).to(dev)
     tgt = param_fill.make_labels(n).to(dev)
     runs = []
-    for _ in range(3):
+    for _ in range(reps):
         for p in m.parameters():
             p.grad = None
         out = m(x)
@@ -256,26 +252,33 @@ for name, ctor, n, size in (("UDEB4", dict(extractor="efficientnet-b4"), 8, 256)
         loss.backward()
         runs.append((loss.detach().clone(), out["rec"].detach().clone(),
                      [p.grad.detach().clone() for p in m.parameters() if p.grad is not None]))
-    same = all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) and len(r[2]) == len(runs[0][2])
-               and all(torch.equal(a, b) for a, b in zip(runs[0][2], r[2])) for r in runs[1:])
-    res.append((name, same, len(runs[0][2]), float(runs[0][0])))
-print("DET", res)
-assert all(r[1] for r in res), res
-"""
+    return runs
 
 
-def test_deterministic_mode_is_bitwise_repeatable():
-    """UD_DETERMINISTIC=1 (a process-wide switch read at import, hence the child process): split-K GEMMs through ordered
-    slices (ud_gemm out_mode 3 + ud_sum_slices), the operator path's fixed-order reductions instead of the fused node's fp64
-    atomics — three runs of the same train step (UDEB4 256x256 and UDR18 128x128, bs 8) give bit-identical losses, outputs
-    and parameter gradients."""
-    _dev()
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, UD_DETERMINISTIC="1", PYTHONDONTWRITEBYTECODE="1")
-    r = subprocess.run([sys.executable, "-c", _DET_SCRIPT % root], env=env, capture_output=True, text=True, timeout=900)
-    print(r.stdout[-2000:])
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert "DET" in r.stdout
+def _worst_rel(runs):
+    worst = 0.0
+    for r in runs[1:]:
+        assert len(r[2]) == len(runs[0][2])
+        for a, b in zip([runs[0][0], runs[0][1]] + runs[0][2], [r[0], r[1]] + r[2]):
+            worst = max(worst, float((a.double() - b.double()).abs().max() / a.double().abs().max().clamp_min(1e-30)))
+    return worst
+
+
+@pytest.mark.parametrize("name,ctor,n,size", [("UDEB4", dict(extractor="efficientnet-b4"), 8, 256), ("UDR18", {}, 8, 128)])
+def test_default_mode_is_repeatable(name, ctor, n, size):
+    """The package default (cfg.deterministic: split-K GEMMs through ordered slices, ud_gemm out_mode 3 + ud_sum_slices):
+    three runs of the same train step give the same loss, output and parameter gradients.  On the operator path (every
+    reduction in a fixed order) that is BITWISE; on the fused MBConv path the fp64 accumulators are filled by atomics, whose
+    order can move a sum by 1e-16 — held to 1e-9 of each tensor's scale here (observed: bitwise as well)."""
+    from tests.margins import within
+    from unidefense_amd.config import cfg, override
+    dev = _dev()
+    assert cfg.deterministic
+    with override(fused_mbconv=False):
+        runs = _det_runs(dev, name, ctor, n, size)
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1])
+               and all(torch.equal(a, b) for a, b in zip(runs[0][2], r[2])) for r in runs[1:]), "operator path not bitwise"
+    runs = _det_runs(dev, name, ctor, n, size)
+    w = _worst_rel(runs)
+    print(f"  {name}: fused path, worst run-to-run deviation {w:.1e} over {len(runs[0][2])} gradients")
+    assert within(f"{name} fused path run-to-run", w, 1e-9)

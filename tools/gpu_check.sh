@@ -5,11 +5,11 @@ export PYTHONDONTWRITEBYTECODE=1
 echo "== rocminfo" > gpurun_out/env.log
 (rocminfo | grep -E "gfx|Compute Unit|Marketing" | head -8; nproc; free -g | head -2) >> gpurun_out/env.log 2>&1
 echo "== kernels"
-timeout 1500 python -m pytest tests/test_kernels_gpu.py -m gpu -n 3 -rA -q --timeout 600 > gpurun_out/kernels.log 2>&1
+timeout 1500 python -m pytest tests/test_a_kernels_gpu.py -m gpu -n 3 -rA -q --timeout 600 > gpurun_out/kernels.log 2>&1
 echo "kernels exit $?"
 grep -E "passed|failed|error" gpurun_out/kernels.log | tail -3
 echo "== model"
-timeout 1500 python -m pytest tests/test_model_gpu.py -m gpu -rA -q --timeout 900 > gpurun_out/model.log 2>&1
+timeout 1500 python -m pytest tests/test_c_model_gpu.py -m gpu -rA -q --timeout 900 > gpurun_out/model.log 2>&1
 echo "model exit $?"
 grep -E "passed|failed|error" gpurun_out/model.log | tail -3
 if [ "$1" == "bench" ]; then

@@ -2,7 +2,7 @@
 scale factor (the bottleneck BatchNorm1d over few samples rescales all upstream gradients uniformly)."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from tests.test_mixed_precision_gpu import _step
+from tests.test_e_mixed_precision_gpu import _step
 dev = torch.device("cuda:0")
 o32, g32 = _step(dev, 0)
 for name, kw in (("fp32 storage", {}), ("half storage", {"half_storage": True})):

@@ -1,0 +1,80 @@
+"""The ONE place the package reads its environment: every run-time switch of unidefense_amd is a field of `cfg`,
+filled once at import from the `UD_*` variables listed here and changeable afterwards from Python
+(`from unidefense_amd.config import cfg; cfg.deterministic = True`) — the modules look the field up when they act,
+not when they are imported.  Anything not listed here is a compile-time constant of the kernels.
+
+| field | env | default | meaning |
+|---|---|---|---|
+| deterministic | UD_DETERMINISTIC | 1 | split-K GEMMs add their partial products in a FIXED order (slices + ud_sum_slices) instead of fp32 atomics: the same inputs give the same step on every run and every box (0: atomics, last-bit run-to-run noise) |
+| fused_mbconv | UD_FUSED_MBCONV | 1 | training-mode MBConv blocks as one tape node with deferred BatchNorm (0: operator by operator) |
+| half_storage | UD_HALF_STORAGE | 0 | fp16 activation storage in the MBConv trunk (BASELINE configs[4]); `model.half_storage` overrides |
+| gemm_tune | UD_GEMM_TUNE | 1 | measure (tile, split-K) candidates on the first eager call of an unseen GEMM shape |
+| gemm_tune_defaults | UD_GEMM_TUNE_DEFAULTS | 1 | start from the shipped plans (gemm_plans_gfx950.json) |
+| gemm_tune_cache | UD_GEMM_TUNE_CACHE | unset | JSON file the measured plans are read from / added to |
+| engine_graph | UD_ENGINE_GRAPH | 1 | the engine's two passes replayed from hipGraphs |
+| syncbn_exchange | UD_SYNCBN_EXCHANGE | 1 | SyncBN sums through the peer-mapped mailbox kernel (0: dist.all_reduce) |
+| force_collectives | UD_FORCE_COLLECTIVES | 0 | issue the data-parallel collectives even in a world of one rank (single-GPU test of the RCCL path) |
+| hip_adamw | UD_HIP_ADAMW | 1 | build_optimizer returns the multi-tensor HIP AdamW for 'adamw' on the GPU |
+| wgrad_stream | UD_WGRAD_STREAM | 0 | weight-gradient kernels on a second stream (measured slower; kept for A/B) |
+| lib_path | UD_LIB_PATH | unset | load another build of libunidefense_hip.so (A/B of kernel builds) |
+"""
+import os
+from dataclasses import dataclass, fields
+from typing import Optional
+
+
+def _flag(name, default):
+    return os.environ.get(name, "1" if default else "0") == "1"
+
+
+@dataclass
+class Config:
+    deterministic: bool = True
+    fused_mbconv: bool = True
+    half_storage: bool = False
+    gemm_tune: bool = True
+    gemm_tune_defaults: bool = True
+    gemm_tune_cache: Optional[str] = None
+    engine_graph: bool = True
+    syncbn_exchange: bool = True
+    force_collectives: bool = False
+    hip_adamw: bool = True
+    wgrad_stream: bool = False
+    lib_path: Optional[str] = None
+
+    @classmethod
+    def from_env(cls):
+        c = cls()
+        for f in fields(cls):
+            env = "UD_" + f.name.upper()
+            if f.type is bool:
+                setattr(c, f.name, _flag(env, f.default))
+            else:
+                setattr(c, f.name, os.environ.get(env) or None)
+        return c
+
+    def describe(self):
+        return {f.name: getattr(self, f.name) for f in fields(self)}
+
+
+cfg = Config.from_env()
+
+
+class override:
+    """`with override(deterministic=False): ...` — tests and A/B tools."""
+
+    def __init__(self, **kw):
+        self.kw, self.saved = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            if not hasattr(cfg, k):
+                raise AttributeError(k)
+            self.saved[k] = getattr(cfg, k)
+            setattr(cfg, k, v)
+        return cfg
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            setattr(cfg, k, v)
+        return False

@@ -4,7 +4,7 @@
 //   a0b0 + (a0b1 + a1b0) + (a1b1 + a0b2 + a2b0);
 // the dropped terms (a1b2, a2b1, a2b2) are below 2^-26 |ab|, i.e. under the rounding of an fp32 FMA chain.  Each
 // piece product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result has fp32 GEMM
-// accuracy (tests/test_kernels_gpu.py compares both kernels with float64) while six bf16 MFMAs (6 x 32 cycles per
+// accuracy (tests/test_a_kernels_gpu.py compares both kernels with float64) while six bf16 MFMAs (6 x 32 cycles per
 // 32x32x16) replace eight fp32 MFMAs (8 x 64 cycles): 2.67x the fp32 matrix rate.
 //
 // Used by ud_gemm for the plain GEMMs (a_mode, b_mode in {0,1}) and for the implicit-GEMM conv gather on the A side

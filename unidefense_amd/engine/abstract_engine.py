@@ -13,6 +13,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from ..config import cfg
+
 
 def _zero(device):
     return torch.tensor(0.0, device=device)
@@ -30,9 +32,9 @@ class AbstractEngine(object):
         self.config = config or {}
         self.model = self.optimizer = self.scheduler = self.loss_criterion = None
         self.num_steps, self.warmup_step, self.device = 1, 0, None
-        # hipGraph replay of the two passes (90 ms instead of 448 ms per train step at bs 32); UD_ENGINE_GRAPH=0 or
+        # hipGraph replay of the two passes (90 ms instead of 448 ms per train step at bs 32); cfg.engine_graph = False or
         # engine.use_graphs = False runs every launch eagerly
-        self.use_graphs = os.environ.get("UD_ENGINE_GRAPH", "1") == "1"
+        self.use_graphs = cfg.engine_graph
         self._graphs = {}
         self.max_graph_sets = 4          # distinct (shape, split, kl) sets kept captured at a time
 

@@ -2,9 +2,9 @@
 groups as timm's ``param_groups_weight_decay`` builds them, AdamW(amsgrad) and StepLR from the YAML keys.
 AdamW on the GPU is the multi-tensor HIP kernel of csrc/optim.hip; other optimizers and CPU
 parameters use torch's."""
-import os
-
 import torch
+
+from ..config import cfg as _cfg
 
 
 def param_groups_weight_decay(model, weight_decay=1e-5, no_weight_decay_list=()):
@@ -170,9 +170,9 @@ def build_optimizer(model, opt_cfg):
     groups = param_groups_weight_decay(model, wd)
     on_gpu = all(p.is_cuda for g in groups for p in g["params"])
     # AdamW on the GPU = the multi-tensor HIP kernel (one launch for the 504 tensors, GradScaler's
-    # unscale / found_inf folded in); UD_HIP_ADAMW=0 or explicit fused / foreach keys keep torch's implementation
+    # unscale / found_inf folded in); cfg.hip_adamw = False or explicit fused / foreach keys keep torch's implementation
     if name.lower() == "adamw" and on_gpu and "fused" not in cfg and "foreach" not in cfg \
-            and os.environ.get("UD_HIP_ADAMW", "1") == "1":
+            and _cfg.hip_adamw:
         return HipAdamW(groups, **cfg)
     if name.lower() in ("adamw", "adam") and "fused" not in cfg and "foreach" not in cfg and on_gpu:
         cfg["fused"] = True

@@ -25,6 +25,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .. import tape as T
+from ..config import cfg
 
 
 class GradReducer:
@@ -93,12 +94,11 @@ class BnExchange:
 
     def __init__(self, group, device):
         import ctypes as C
-        import os
         from .. import lib
         self.group, self.device = group, device
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.ok, self.base, self.opened = False, None, []
-        want = os.environ.get("UD_SYNCBN_EXCHANGE", "1") == "1" and device.type == "cuda"
+        want = cfg.syncbn_exchange and device.type == "cuda"
         status, handle = 0, b""
         if want:
             base, buf = C.c_void_p(), C.create_string_buffer(64)
@@ -202,7 +202,7 @@ class HipDataParallel(nn.Module):
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=process_group)
-        self.force = T.FORCE_COLLECTIVES           # single-GPU exercise of the RCCL calls (tape.py)
+        self.force = cfg.force_collectives           # single-GPU exercise of the RCCL calls (tape.py)
         if self.world > 1 or self.force:
             module._grad_reducer = GradReducer(process_group, bucket_bytes)
             module._grad_prescale = 1.0 / self.world

@@ -12,6 +12,7 @@ import os
 import torch
 
 from . import lib as _lib
+from .config import cfg as CFG
 from .lib import ConvGeom, GemmDesc
 
 _call = _lib.call
@@ -63,8 +64,8 @@ def empty(shape, like, dtype=torch.float32):
 # its own.  They are carved instead from a few large zero blocks (one fill per 32 MB); a block is never reused, so
 # every carve is still zero.  reset_zero_pool() at the start of a forward / backward makes a step captured into a
 # hipGraph contain the fills of every block it carves from.
-_ZERO_POOL_ON = os.environ.get("UD_ZERO_POOL", "1") == "1"
-_ZERO_BLOCK = int(os.environ.get("UD_ZERO_BLOCK", str(8 << 20)))            # floats per block (32 MB)
+_ZERO_POOL_ON = True
+_ZERO_BLOCK = 8 << 20            # floats per block (32 MB)
 _ZERO_OWN = 2 << 20              # tensors of at least this many floats get their own torch.zeros
 _ZERO_POOL = {}
 
@@ -76,7 +77,7 @@ def reset_zero_pool():
 
 # fp64 accumulators of the fused path (BatchNorm sums, SE pooling sums, gate gradients): carved from zero blocks the
 # same way — one fill per block instead of one per accumulator (~10 accumulators per MBConv block and pass).
-_ZERO64_BLOCK = int(os.environ.get("UD_ZERO64_BLOCK", str(1 << 20)))        # doubles per block (8 MB)
+_ZERO64_BLOCK = 1 << 20        # doubles per block (8 MB)
 _ZERO64_POOL = {}
 
 
@@ -111,14 +112,23 @@ def zeros(shape, like):
     return out
 
 
+def split_out(shape, like):
+    """Result buffer of a split-K launch: zeros for the atomics, an uninitialised buffer marked fresh for the ordered
+    slice sum (which then writes instead of adding: no fill, no read of zeros)."""
+    if not CFG.deterministic:
+        return zeros(shape, like)
+    out = torch.empty(shape, dtype=torch.float32, device=like.device)
+    out._ud_fresh = True
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # GEMM family
 # ---------------------------------------------------------------------------------------------
-# UD_DETERMINISTIC=1: bit-reproducible steps.  Split-K GEMMs store their partial products into slices of a scratch buffer
-# and add them in ascending order (ud_gemm out_mode 3 + ud_sum_slices) instead of float atomics, and the model runs the
-# operator path whose reductions are fixed-order partials (model/unidefense.py) instead of the fused MBConv node with its
-# fp64 atomics.  Costs ~10 % of the step; the default mode's run-to-run variation is in the last bits.
-DETERMINISTIC = os.environ.get("UD_DETERMINISTIC", "0") == "1"
+# CFG.deterministic (UD_DETERMINISTIC, default on): split-K GEMMs store their partial products into slices of a scratch
+# buffer and add them in ascending order (ud_gemm out_mode 3 + ud_sum_slices) instead of fp32 atomics, so the same inputs
+# give the same result on every run and box (the fp64 accumulators of the fused MBConv path are order-dependent at 1e-16
+# only).  CFG.deterministic = False: fp32 atomics — one launch less per split GEMM, last-bit run-to-run variation.
 _SLICE_WS = {}
 
 
@@ -144,16 +154,22 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
     d.tile_cfg = cfg
     slices = None
-    if DETERMINISTIC and out_mode == 2:
-        # Cout holds zeros or a term to add to: result = Cout + the splits' partials in ascending order
+    if CFG.deterministic and out_mode == 2:
+        # Cout holds a term to add to (or is a fresh buffer of split_out): result = [Cout +] the splits' partials in
+        # ascending order
         total = M * ldc
+        fresh = getattr(Cout, "_ud_fresh", False)
         if batch == 1 and total % 4 == 0 and Cout.dtype == torch.float32:
             stride = total
             ws = _slice_ws(Cout, split_k * stride)
             d.C, d.out_mode, d.slice_stride = ws.data_ptr(), 3, stride
-            slices = (ws, stride, total)
+            slices = (ws, stride, total, 0 if fresh else 1)
         else:                                   # no slice form for this output: one plain accumulating launch
+            if fresh:
+                Cout.zero_()
             d.out_mode, d.split_k = 1, 1
+        if fresh:
+            Cout._ud_fresh = False
     if geom is not None:
         d.g = geom
     fold = None
@@ -180,16 +196,16 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     else:
         _call("ud_gemm", C.byref(d), _stream())
     if slices is not None:
-        ws, stride, total = slices
-        _call("ud_sum_slices", _p(ws), _p(Cout), split_k, total, stride, 1, _stream())
+        ws, stride, total, accumulate = slices
+        _call("ud_sum_slices", _p(ws), _p(Cout), split_k, total, stride, accumulate, _stream())
     if fold is not None:
         tgt, slots = fold
         _call("ud_stat_slots_fold", _pd64(tgt), _pd64(tgt, slots * N), slots, N, _pd64(stats), _pd64(stats, N), _stream())
     return (Cout, stats_done) if stats is not None else Cout
 
 
-_TAIL_SPLIT = os.environ.get("UD_GEMM_TAIL_SPLIT", "1") == "1"
-_GEMM_EPILOGUE_STATS = os.environ.get("UD_GEMM_EPILOGUE_STATS", "1") == "1"      # A/B switch
+_TAIL_SPLIT = True
+_GEMM_EPILOGUE_STATS = True
 
 
 def _pd64(t, off_doubles=0):
@@ -225,11 +241,9 @@ def _tail_plan(M, N, K):
 # shape measures the candidates (a handful of back-to-back launches each, into scratch) and the winner is cached; an
 # exhaustive offline sweep (tools/sweep_gemm_plans.py) put the gain at 1.2 ms of the 17.8 ms the plain GEMMs take per
 # step.  Never inside a graph capture (an unseen shape then takes the cost-model plan); UD_GEMM_TUNE=0 turns it off.
-_TUNE_ON = os.environ.get("UD_GEMM_TUNE", "1") == "1"
 _TUNED = {}
 # UD_GEMM_TUNE_CACHE=<file>: plans are read from / added to this JSON file, so that a profiled run (rocprofv3, PMC passes)
 # repeats the plans of the benchmarked one without the tuner's measurement launches in its kernel statistics
-_TUNE_CACHE = os.environ.get("UD_GEMM_TUNE_CACHE")
 # Shipped defaults: the plans measured on an MI355X for the shapes of the BASELINE configs (bs 32 / 64 UDEB4, UDR18, UDR50,
 # the engine's train step) and of the parity tests — those shapes start with a plan instead of a measurement (the same
 # plan in every run: repeatable rounding); anything else is tuned on first use.
@@ -243,20 +257,21 @@ def _load_plans(path):
         return {tuple(json.loads(k)): (tuple(v) if v is not None else None) for k, v in json.load(fh).items()}
 
 
-if os.environ.get("UD_GEMM_TUNE_DEFAULTS", "1") == "1" and os.path.exists(_TUNE_DEFAULTS):
+if CFG.gemm_tune_defaults and os.path.exists(_TUNE_DEFAULTS):
     _TUNED.update(_load_plans(_TUNE_DEFAULTS))
-if _TUNE_CACHE and os.path.exists(_TUNE_CACHE):
-    _TUNED.update(_load_plans(_TUNE_CACHE))
+if CFG.gemm_tune_cache and os.path.exists(CFG.gemm_tune_cache):
+    _TUNED.update(_load_plans(CFG.gemm_tune_cache))
 
 
 def _tune_cache_save():
-    if not _TUNE_CACHE:
+    path = CFG.gemm_tune_cache
+    if not path:
         return
     import json
-    tmp = _TUNE_CACHE + ".tmp%d" % os.getpid()
+    tmp = path + ".tmp%d" % os.getpid()
     with open(tmp, "w") as fh:
         json.dump({json.dumps(list(k)): (list(v) if v is not None else None) for k, v in _TUNED.items()}, fh)
-    os.replace(tmp, _TUNE_CACHE)
+    os.replace(tmp, path)
 _X3_TILES = {1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64)}
 _TUNE_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128, 256, 384)
 
@@ -275,7 +290,7 @@ def _tune_candidates(M, N, K):
     return out
 
 
-_TUNE_N = int(os.environ.get("UD_GEMM_TUNE_N", "6"))          # launches per timing graph
+_TUNE_N = 6          # launches per timing graph
 
 
 def _time_launches(fn, n=None):
@@ -321,7 +336,7 @@ def _tuned_plan(kind, M, N, K, launch, baseline, extra_if_split=None, no_split=F
     key = (kind, M, N, K, extra_if_split is not None, _call("ud_gemm_get_path"))
     if key in _TUNED:
         return _TUNED[key]
-    if not _TUNE_ON or torch.cuda.is_current_stream_capturing() or min(M, N, K) < _X3_MINDIM:
+    if not CFG.gemm_tune or torch.cuda.is_current_stream_capturing() or min(M, N, K) < _X3_MINDIM:
         return None
     best_t, best = _time_launches(baseline), None
     extra = _time_launches(extra_if_split) if extra_if_split is not None else 0.0
@@ -353,7 +368,7 @@ def _model_plan_launch(a, w, out, M, N, K, lda, ldb, b_mode, acc):
     split = _fwd_split(M, N, K)
     if split > 1:
         if not acc:
-            out = zeros((M, N), a)
+            out = split_out((M, N), a)
         return _gemm(a, w, out, M, N, K, lda, ldb, N, 0, b_mode, 2, split)
     if not acc:
         out = empty((M, N), a)
@@ -389,7 +404,7 @@ def _tuned_launch(kind, a, w, out, M, N, K, lda, ldb, a_mode, b_mode, acc, stats
             out = empty((M, N), a, out_dtype)
         return _gemm(a, w, out, M, N, K, lda, ldb, N, a_mode, b_mode, 1 if acc else 0, stats=stats, cfg=cfg)
     if not acc:
-        out = zeros((M, N), a)
+        out = split_out((M, N), a)
     r = _gemm(a, w, out, M, N, K, lda, ldb, N, a_mode, b_mode, 2, split, cfg=cfg)
     return (r, False) if stats is not None else r
 
@@ -457,9 +472,9 @@ def gemm_nn(a, w, out=None, accumulate=False):
     return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 0)
 
 
-_WG_SPLIT_MAXT = int(os.environ.get("UD_WG_SPLIT_MAXT", "512"))
-_WG_SPLIT_TARGET = int(os.environ.get("UD_WG_SPLIT_TARGET", "768"))
-_WG_SPLIT_ROWS = int(os.environ.get("UD_WG_SPLIT_ROWS", "256"))
+_WG_SPLIT_MAXT = 512
+_WG_SPLIT_TARGET = 768
+_WG_SPLIT_ROWS = 256
 
 
 def _pick_split(tiles, K):
@@ -472,13 +487,13 @@ def _pick_split(tiles, K):
 
 
 _TILE_CFGS = ((128, 128, 1.00), (128, 64, 0.93), (256, 32, 1.10), (32, 256, 1.10), (64, 128, 0.93))
-_X3_TILE_MODEL = os.environ.get("UD_X3_TILE_MODEL", "0") == "1"      # A/B: the fp32-kernel tile model (more split-K) is 0.4 % faster
+_X3_TILE_MODEL = False      # A/B: the fp32-kernel tile model (more split-K) is 0.4 % faster
 
 
-_FWD_SPLIT_T = int(os.environ.get("UD_FWD_SPLIT_T", "224"))      # A/B on the bench: 128/1024 -> 224/512 = -0.6 % step time
-_FWD_SPLIT_K = int(os.environ.get("UD_FWD_SPLIT_K", "512"))
-_FWD_SPLIT_MINK = int(os.environ.get("UD_FWD_SPLIT_MINK", "256"))     # reduction length per split, at least
-_FWD_SPLIT_WGS = int(os.environ.get("UD_FWD_SPLIT_WGS", "320"))       # workgroups the split aims at
+_FWD_SPLIT_T = 224      # A/B on the bench: 128/1024 -> 224/512 = -0.6 % step time
+_FWD_SPLIT_K = 512
+_FWD_SPLIT_MINK = 256     # reduction length per split, at least
+_FWD_SPLIT_WGS = 320       # workgroups the split aims at
 
 
 def _fwd_split(M, N, K):
@@ -491,7 +506,7 @@ def _fwd_split(M, N, K):
 
 
 _X3_CFGS = ((128, 128, 1.00), (128, 64, 1.20), (64, 128, 1.20))          # gemm_x3.hip kX
-_X3_MINDIM = int(os.environ.get("UD_GEMM_X3_MINDIM", "16"))                 # gemm.hip's auto rule
+_X3_MINDIM = 16                 # gemm.hip's auto rule
 
 
 def _tiles(M, N, K=None):
@@ -519,7 +534,7 @@ def gemm_tn(a, b):
     if r is not None:
         return r
     if split > 1:
-        out = zeros((M, N), a)
+        out = split_out((M, N), a)
         return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 2, split)
     out = empty((M, N), a)
     return _gemm(a, b, out, M, N, K, M, N, N, 1, 1, 0, 1)
@@ -532,10 +547,10 @@ def conv_geom(N, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad_t, pad_l, transp
     return g
 
 
-_CONV_SPLITK = os.environ.get("UD_CONV_SPLITK", "1") == "1"
+_CONV_SPLITK = True
 
 
-_CONV_SMALL = os.environ.get("UD_CONV_SMALL", "1") == "1"
+_CONV_SMALL = True
 _CONV_SMALL_MIN_M = 262144          # one thread per output pixel: below ~1 wave per SIMD x 4 the GEMM path wins
 _CONV_SMALL_OK = {}
 
@@ -587,11 +602,11 @@ def conv_gather_nt(x, wmat, g):
                             lambda: _gemm(x, wmat, scratch(), M, Co, K, 0, K, Co, 2, 0, 2 if split > 1 else 0, split, geom=g))
         if tuned is not None:
             cfg, sp = tuned
-            out = (zeros if sp > 1 else empty)((g.N, g.Hout, g.Wout, Co), x)
+            out = (split_out if sp > 1 else empty)((g.N, g.Hout, g.Wout, Co), x)
             _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg)
             return out
     if split > 1:
-        out = zeros((g.N, g.Hout, g.Wout, Co), x)
+        out = split_out((g.N, g.Hout, g.Wout, Co), x)
         _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, 2, split, geom=g)
         return out
     out = empty((g.N, g.Hout, g.Wout, Co), x)
@@ -629,10 +644,10 @@ def conv_gather_wgrad(a, x, g):
                             lambda: _gemm(a, x, scratch(), Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if split > 1 else 0, split, geom=g))
         if tuned is not None:
             cfg, sp = tuned
-            out = (zeros if sp > 1 else empty)((Ma, Ncols), a)
+            out = (split_out if sp > 1 else empty)((Ma, Ncols), a)
             return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg)
     if split > 1:
-        out = zeros((Ma, Ncols), a)
+        out = split_out((Ma, Ncols), a)
         return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2, split, geom=g)
     out = empty((Ma, Ncols), a)
     return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 0, 1, geom=g)
@@ -804,7 +819,7 @@ def dwconv_bwd_data(dy, wt, K, stride, pad_t, pad_l, H, W, add=None):
     return dx
 
 
-_DW_WGRAD_THREADS = int(os.environ.get("UD_DW_WGRAD_THREADS", "131072"))      # tuning aid
+_DW_WGRAD_THREADS = 131072
 
 
 def dwconv_bwd_weight(x, dy, K, stride, pad_t, pad_l):
@@ -1094,7 +1109,7 @@ def dft_rfft2_planes(d, ortho=True):
     of csrc/fft_large.hip; other sizes: three batched GEMMs against DFT matrices."""
     _chk(d)
     P, S, _ = d.shape
-    if S in _FFT_PLANES_SIZES and os.environ.get("UD_FFT_PLANES_GEMM", "0") != "1":
+    if S in _FFT_PLANES_SIZES:
         Y = empty((P, 2 * S, -(-(S // 2 + 1) // 4) * 4), d)
         _call("ud_rfft2_planes", _p(d), _p(Y), _p(_fft_planes_ws(d, P, S)), P, S, (1.0 / S) if ortho else 1.0, _stream())
         return Y
@@ -1116,7 +1131,7 @@ def dft_rfft2_planes_adjoint(dY, S, ortho=True):
     """Adjoint of dft_rfft2_planes: dY [P, 2S, Whp] -> dd [P, S, S]."""
     _chk(dY)
     P = dY.shape[0]
-    if S in _FFT_PLANES_SIZES and os.environ.get("UD_FFT_PLANES_GEMM", "0") != "1":
+    if S in _FFT_PLANES_SIZES:
         dd = empty((P, S, S), dY)
         _call("ud_rfft2_planes_adjoint", _p(dY), _p(dd), _p(_fft_planes_ws(dY, P, S)), P, S, (1.0 / S) if ortho else 1.0,
               _stream())

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("UD_LIB_PATH") or os.path.join(_HERE, "libunidefense_hip.so")   # env: A/B of kernel builds
+from .config import cfg as _cfg  # noqa: E402
+
+LIB_PATH = _cfg.lib_path or os.path.join(_HERE, "libunidefense_hip.so")   # cfg.lib_path: A/B of kernel builds
 
 
 class UDLibraryError(RuntimeError):

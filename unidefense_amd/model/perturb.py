@@ -1,7 +1,7 @@
 """Input perturbations of the second (consistency) pass of the train step — no-grad preprocessing of the
 input batch, chosen with the torch global (CPU) RNG exactly like the reference (model/unidefense.py:177-198):
 same draws, same order, so a seeded run takes the reference's branches with the reference's lmda values
-(tests/test_perturb.py replays the recorded seeds of tests/golden/perturb_n4.npz).
+(tests/test_c_perturb.py replays the recorded seeds of tests/golden/perturb_n4.npz).
 
 SURVEY.md §8(f) rank 1.  The arithmetic runs in HIP kernels (csrc/perturb.hip + the DFT-matrix GEMMs of ud_gemm)
 through the C-ABI; there is no torch-op fallback.  What stays torch: the RNG draws (they DEFINE parity with the

@@ -6,13 +6,13 @@ CONTAINERS (they give the reference's key names, shapes and default initialisers
 never called — all compute goes through ``unidefense_amd.tape`` operators, i.e. the hand-written HIP kernels.
 Internally every activation is pixel-major [N,H,W,C]; the public tensors keep the reference's NCHW shapes.
 """
-import os
 from typing import List, Optional
 
 import torch
 import torch.nn as nn
 
 from .. import kernels as K
+from ..config import cfg
 from .. import tape as T
 from .arch import DELIMITER_DICT, build_arch
 
@@ -100,14 +100,15 @@ _OUT_KEYS = ("cls_out", "rec", "factorization", "triplet0", "triplet1", "triplet
              "spatial", "freq")
 
 
-# training mode: MBConv blocks as fused tape nodes with deferred BatchNorms (tape.mbconv_fused); UD_FUSED_MBCONV=0
-# runs the operator-by-operator path (same results: tests/test_fused_gpu.py compares the two)
-_FUSED_MBCONV = os.environ.get("UD_FUSED_MBCONV", "1") == "1" and not K.DETERMINISTIC      # (fp64 atomics: kernels.DETERMINISTIC)
+# training mode: MBConv blocks as fused tape nodes with deferred BatchNorms (tape.mbconv_fused); cfg.fused_mbconv = False
+# runs the operator-by-operator path (same results: tests/test_z_fused_selfcheck_gpu.py compares the two)
+def _fused_mbconv():
+    return cfg.fused_mbconv
 
 
 def _half_storage(model):
-    """fp16 activation storage in the MBConv trunk: `model.half_storage = True` (or env UD_HALF_STORAGE=1)."""
-    return bool(getattr(model, "half_storage", os.environ.get("UD_HALF_STORAGE", "0") == "1"))
+    """fp16 activation storage in the MBConv trunk: `model.half_storage = True` (or cfg.half_storage)."""
+    return bool(getattr(model, "half_storage", cfg.half_storage))
 
 
 class _NetFunction(torch.autograd.Function):
@@ -144,7 +145,7 @@ class _NetFunction(torch.autograd.Function):
         uses = getattr(model, "_param_uses", None)
         if reducer is not None:
             reducer.begin()
-            if uses is not None and not T.WGRAD_SIDE_STREAM:
+            if uses is not None and not cfg.wgrad_stream:
                 tape.param_uses, tape.param_ready = uses, reducer.ready
         for k, g in zip(ctx.keys, gouts):
             if g is not None:
@@ -434,9 +435,10 @@ class UniDefenseModelEb4(nn.Module):
         # Half storage (BASELINE configs[4]): the MBConv trunk keeps its activations and their gradients in fp16 (fp32
         # registers, fp64 BatchNorm sums, fp32 weights / weight gradients, fp16 MFMA); stem conv, decoder, attention,
         # head and losses stay fp32 — T.cast at the boundaries.  Fused training path only.
-        st16 = self.training and _FUSED_MBCONV and _half_storage(self)
+        fused = self.training and _fused_mbconv()
+        st16 = fused and _half_storage(self)
         f32 = torch.float32
-        if self.training and _FUSED_MBCONV:
+        if fused:
             dp = T.DataParallelCtx(self._sync_group(bb._bn0), getattr(self, "_bn_exchange", None))
             rng["_fused"] = {"wt": wts, "dp": dp}
             if bb._bn0.num_batches_tracked is not None:

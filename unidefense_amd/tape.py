@@ -10,17 +10,15 @@ Every operator takes pixel-major fp32 CUDA tensors (see kernels.py) and cites th
 import math
 from typing import Optional
 
-import os
-
 import torch
 
 from . import kernels as K
+from .config import cfg
 
 
-# Off by default: measured on MI355X (bs 32, whole step replayed as a hipGraph) the forked weight-gradient branch
-# made the step SLOWER (46.3 vs 43.6 ms) — the large GEMMs already fill the chip and the extra graph edges cost
-# more than the overlap with the bandwidth-bound kernels returns.  UD_WGRAD_STREAM=1 enables it (tests pass).
-WGRAD_SIDE_STREAM = os.environ.get("UD_WGRAD_STREAM", "0") == "1"
+# cfg.wgrad_stream, off by default: measured on MI355X (bs 32, whole step replayed as a hipGraph) the forked
+# weight-gradient branch made the step SLOWER (46.3 vs 43.6 ms) — the large GEMMs already fill the chip and the extra
+# graph edges cost more than the overlap with the bandwidth-bound kernels returns.
 _SIDE_STREAMS = {}
 
 
@@ -42,6 +40,8 @@ class Tape:
         self.watch = None        # debug: {id(tensor): name} -> gradients captured into self.captured
         self.captured = {}
         self.kinks = None        # parity tests: {site: ReLU output} (site = id(norm weight) or an explicit name)
+        self.gate_cond = {}      # parity tests (watch set): {id(sf_coef): sigmoid'(a) * sum |dy| |freq - spat|}, the
+        #                          conditioning of that scalar gradient (a global sum that cancels heavily)
         self._side = None        # second stream carrying the weight-gradient kernels of this backward
         self._side_keep = []
         # data parallel (engine/parallel.py): param_ready(id(p), g) is called the moment p's gradient is final, i.e.
@@ -86,7 +86,7 @@ class Tape:
         these launches (a third of the GEMM time) overlap the data-gradient chain — the bandwidth-bound norm /
         depthwise / SE kernels leave the matrix cores idle.  `inputs` are kept alive until the streams re-join
         in backward() (their memory must not be recycled by the main stream meanwhile)."""
-        if not WGRAD_SIDE_STREAM:
+        if not cfg.wgrad_stream:
             self.add_param_grad(p, fn())
             return
         main = torch.cuda.current_stream()
@@ -207,7 +207,7 @@ def linear(tape, x, w, b):
 # ---------------------------------------------------------------------------------------------
 # depthwise conv, FFT, SFConv
 # ---------------------------------------------------------------------------------------------
-_DW_FUSED_ADD = os.environ.get("UD_DW_FUSED_ADD", "1") == "1"
+_DW_FUSED_ADD = True
 DW_WT = {}            # {id(w): (w, w._version, tap-major wt)} for the forward in flight (kernels.dw_weights_tapmajor)
 
 
@@ -291,6 +291,14 @@ def sfmix(tape, spat, freq, alpha):
             if dy is None:
                 return
             ds, df, da = K.sfmix_bwd(spat, freq, alpha, dy, pool)
+            if tape.watch is not None:
+                with torch.no_grad():
+                    f = freq.float()
+                    if pool:
+                        n_, h_, w_, c_ = spat.shape
+                        f = f.view(n_, h_, 2, w_, 2, c_).mean((2, 4))
+                    sg = torch.sigmoid(alpha.double())
+                    tape.gate_cond[id(alpha)] = float(sg * (1 - sg) * (dy.double().abs() * (f.double() - spat.double()).abs()).sum())
             tape.add_grad(spat, ds)
             tape.add_grad(freq, df)
             tape.add_param_grad(alpha, da)
@@ -310,9 +318,8 @@ def sfconv_dw(tape, x, w, w_freq, alpha, stride, pad, norm):
 # ---------------------------------------------------------------------------------------------
 # normalisation + activation
 # ---------------------------------------------------------------------------------------------
-# UD_FORCE_COLLECTIVES=1: issue the data-parallel collectives (SyncBN statistics, gradient all-reduce) even in a
+# cfg.force_collectives: issue the data-parallel collectives (SyncBN statistics, gradient all-reduce) even in a
 # world of one process, so that a single-GPU box exercises the RCCL calls and their hipGraph capture
-FORCE_COLLECTIVES = os.environ.get("UD_FORCE_COLLECTIVES", "0") == "1"
 
 
 def sync_batch_stats(mean_l, var_l, eps, group):
@@ -343,7 +350,7 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
     if training and sync_group is not None:
         import torch.distributed as dist
         world = dist.get_world_size(sync_group)
-        synced = world > 1 or FORCE_COLLECTIVES
+        synced = world > 1 or cfg.force_collectives
     if synced:
         # 3 launches + 1 collective: local (mean, var) written straight into the all_gather payload, then one
         # kernel folds the world's statistics (same formula as sync_batch_stats above) and updates the running ones
@@ -499,6 +506,10 @@ def gate_mix(tape, p, q, alpha):
             if dy is None:
                 return
             dp, dq, da = K.gate_mix_bwd(p, q, alpha, dy)
+            if tape.watch is not None:
+                with torch.no_grad():
+                    sg = torch.sigmoid(alpha.double())
+                    tape.gate_cond[id(alpha)] = float(sg * (1 - sg) * (dy.double().abs() * (q.double() - p.double()).abs()).sum())
             tape.add_grad(p, dp)
             tape.add_grad(q, dq)
             tape.add_param_grad(alpha, da)
@@ -712,7 +723,7 @@ class DataParallelCtx:
         if group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(group)
-            self.synced = self.world > 1 or FORCE_COLLECTIVES
+            self.synced = self.world > 1 or cfg.force_collectives
 
     def reduce(self, acc, keep_local=False):
         """Sum `acc` over the ranks in place; returns this rank's own sums (a copy) when keep_local, else None."""
