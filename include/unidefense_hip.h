@@ -448,8 +448,8 @@ int ud_rfft2_planes_adjoint(const float* dY, float* dx, float* ws, long P, int S
  * small kernel (a thread per double) that writes the rank's doubles, tagged with the exchange's sequence number, into
  * every mailbox (peer writes over xGMI), polls the own mailbox until all ranks' words carry the tag and sums the rows
  * in rank order (bit-identical on all ranks) — no fences, no separate flags.  seq_counter: two zero-initialised device
- * words advanced by the kernel (hipGraph replays keep counting); a peer that does not arrive within spin_limit polls
- * sets *err (1 + its rank) instead of hanging.  world <= 16.  Setup: ud_xchg_create on every rank, handles exchanged by the
+ * words advanced by the kernel (hipGraph replays keep counting); a peer that does not arrive within timeout_ms of
+ * wall-clock time sets *err (1 + its rank) and turns the affected sums into NaN (never a partial sum) instead of hanging.  world <= 16.  Setup: ud_xchg_create on every rank, handles exchanged by the
  * host (64 bytes each), ud_xchg_open on every peer's handle, the `world` pointers (own base at [rank]) copied to a
  * device array.  max_doubles bounds n; slots >= 2 (a rank is never more than one exchange ahead of the slowest). */
 long ud_xchg_bytes(int world, int max_doubles, int slots);
@@ -458,7 +458,7 @@ int ud_xchg_open(const char* handle, void** ptr);
 int ud_xchg_close(void* ptr);
 int ud_xchg_destroy(void* base);
 int ud_xchg_allreduce(double* acc, int n, void* const* peers, int rank, int world, int max_doubles, int slots,
-                      unsigned long long* seq_counter, int* err, long spin_limit, ud_stream_t stream);
+                      unsigned long long* seq_counter, int* err, long timeout_ms, ud_stream_t stream);
 
 #ifdef __cplusplus
 }

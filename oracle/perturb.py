@@ -11,8 +11,16 @@ here; the reference takes them from torch's global CPU generator.
   spatial_style_transfer    model/modules.py:58-76       exact feature-distribution matching (sort / rank gather)
   coral                     utils/operation.py:7-45      colour transfer; _mat_sqrt multiplies by svd's V (":15-17")
   random_noise              model/modules.py:7-12        clip(x + noise, -1, 1), noise handed in
-  gaussian_blur5            torchvision 0.13.1 gaussian_blur(k=5) restated from its documented rule (reflect pad,
-                            sigma = 0.3*((k-1)*0.5-1)+0.8); torchvision is absent from this image: parity UNPINNED
+  gaussian_blur5            model/modules.py:15-16 random_blur = torchvision.transforms.functional.gaussian_blur(t, (5, 5)).
+                            THIRD-PARTY SOURCE ABSENT: torchvision (README.md:66 pins 0.13.1) is not vendored in the
+                            reference and not installed here, so its published algorithm is restated — sigma defaults to
+                            0.3*((k-1)*0.5-1)+0.8 = 0.15 k + 0.35 (= 1.1), kernel1d = exp(-0.5 (x/sigma)^2) on
+                            linspace(-(k-1)/2, (k-1)/2, k) normalised to sum 1, kernel2d = outer product, reflect padding
+                            by k//2, one depthwise conv2d.  gaussian_blur5 evaluates it separably in float64;
+                            gaussian_blur5_tv follows torchvision's own operation order in torch (2-D kernel built in the
+                            image dtype, F.pad(reflect) + F.conv2d(groups=C)).  tests/test_c_perturb.py pins the two to
+                            each other and to scipy.ndimage (an independent implementation of the same truncated Gaussian
+                            with mirror boundaries); the reference's call site passes no sigma, so nothing else is open.
 """
 import numpy as np
 
@@ -99,6 +107,24 @@ def gaussian_blur5(x):
     h, w = x.shape[-2:]
     rows = sum(k1[i] * xp[:, :, i:i + h, :] for i in range(k))
     return sum(k1[j] * rows[:, :, :, j:j + w] for j in range(k))
+
+
+def gaussian_blur5_tv(x, kernel_size=(5, 5)):
+    """torchvision 0.13.1 functional_tensor.gaussian_blur in its own operation order (torch tensor in, torch tensor out)."""
+    import torch
+    import torch.nn.functional as F
+    sigma = [k * 0.15 + 0.35 for k in kernel_size]
+
+    def k1d(k, sg):
+        half = (k - 1) * 0.5
+        xs = torch.linspace(-half, half, steps=k)
+        pdf = torch.exp(-0.5 * (xs / sg).pow(2))
+        return pdf / pdf.sum()
+    kx, ky = k1d(kernel_size[0], sigma[0]).to(x.dtype), k1d(kernel_size[1], sigma[1]).to(x.dtype)
+    k2 = torch.mm(ky[:, None], kx[None, :])
+    c = x.shape[-3]
+    pad = [kernel_size[0] // 2, kernel_size[0] // 2, kernel_size[1] // 2, kernel_size[1] // 2]
+    return F.conv2d(F.pad(x, pad, mode="reflect"), k2.expand(c, 1, *k2.shape), groups=c)
 
 
 def style_batch(x, pert_real, pert_fake):

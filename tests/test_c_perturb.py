@@ -147,3 +147,36 @@ def test_spatial_transfer_with_ties():
     xv = x.reshape(4, 3, -1)
     order = torch.sort(xv, dim=-1, stable=True).indices
     assert (matched.gather(-1, order).diff(dim=-1) >= -1e-5).all()
+
+
+def test_blur_oracle_forms_agree_and_match_scipy():
+    """random_blur's third-party arithmetic (torchvision gaussian_blur, absent here): the float64 separable restatement,
+    the restatement in torchvision's own operation order and scipy.ndimage's truncated Gaussian with mirror boundaries are
+    the same operator."""
+    import scipy.ndimage as ndi
+    x = param_fill.make_input(2, 40, seed=3)
+    a = OP.gaussian_blur5(x.numpy().astype(np.float64))
+    b = OP.gaussian_blur5_tv(x.double()).numpy()
+    c32 = OP.gaussian_blur5_tv(x).numpy()
+    assert np.abs(a - b).max() <= 1e-7 and np.abs(a - c32).max() <= 2e-6      # b: fp32 linspace / exp in the kernel
+    k1 = np.exp(-0.5 * (np.arange(-2, 3) / 1.1) ** 2)
+    k1 /= k1.sum()
+    s_ = ndi.correlate1d(ndi.correlate1d(x.numpy().astype(np.float64), k1, axis=-1, mode="mirror"), k1, axis=-2, mode="mirror")
+    assert np.abs(a - s_).max() <= 1e-12
+    # constants are kept; the reflect border does not include the edge pixel twice
+    assert np.abs(OP.gaussian_blur5(np.full((1, 1, 9, 9), 0.7)) - 0.7).max() <= 1e-15
+    ramp = np.tile(np.arange(9.0), (9, 1))[None, None]
+    assert abs(OP.gaussian_blur5(ramp)[0, 0, 4, 0] - 2 * (k1[3] * 1 + k1[4] * 2)) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,size", [(32, 256), (6, 128), (4, 320), (2, 37)])
+def test_product_blur_vs_oracle(n, size):
+    """perturb.random_blur (csrc/perturb.hip blur5_reflect) against the oracle at the BASELINE sizes and a ragged one."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidefense_amd.model import perturb
+    x = param_fill.make_input(n, size, seed=78)
+    got = perturb.random_blur(x.cuda()).cpu().numpy()
+    _close(got, OP.gaussian_blur5(x.numpy().astype(np.float64)), 1e-6, f"blur {size}")
+    _close(got, OP.gaussian_blur5_tv(x).numpy(), 2e-6, f"blur {size} vs torchvision operation order (fp32)")

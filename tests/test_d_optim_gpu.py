@@ -83,3 +83,57 @@ def test_grad_scaler_drives_hip_adamw():
     scaler.step(opt)
     scaler.update()
     assert torch.equal(p, before) and opt.step_count() == 1 and scaler.get_scale() == 2 ** 9
+
+
+@pytest.mark.parametrize("amsgrad", [True, False])
+def test_state_dict_round_trip_and_interchange_with_torch_adamw(amsgrad):
+    """Checkpoint / resume: 3 steps, state_dict() -> a freshly built HipAdamW on copies of the parameters ->
+    load_state_dict() -> 3 more steps must equal 6 uninterrupted steps of torch.optim.AdamW (moments kept, bias corrections
+    continued from step 3); and the two optimizers read each other's state dicts (same keys incl. the per-parameter `step`)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidefense_amd.engine.optim import HipAdamW
+    dev = torch.device("cuda:0")
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=amsgrad)
+    pa, pb = _params(dev, 2), _params(dev, 2)
+    ref = torch.optim.AdamW(pa, foreach=True, **kw)
+    hip = HipAdamW(pb, **kw)
+    gen = torch.Generator().manual_seed(9)
+    grads = [[torch.randn(p.shape, generator=gen).to(dev) for p in pa] for _ in range(6)]
+
+    def run(opt, ps, its):
+        for it in its:
+            for p, g in zip(ps, grads[it]):
+                p.grad = g.clone()
+            opt.step()
+    run(ref, pa, range(6))
+    run(hip, pb, range(3))
+    sd = hip.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    keys = {"step", "exp_avg", "exp_avg_sq"} | ({"max_exp_avg_sq"} if amsgrad else set())
+    assert all(set(st) == keys for st in sd["state"].values())
+    pc = [p.detach().clone().requires_grad_(True) for p in pb]
+    hip2 = HipAdamW(pc, **kw)
+    hip2.load_state_dict(sd)
+    run(hip2, pc, range(3, 6))
+    assert hip2.step_count() == 6
+    for i, (a, c) in enumerate(zip(pa, pc)):
+        assert _rel(c, a) <= 2e-6, ("param", SHAPES[i], _rel(c, a))
+        for k in keys - {"step"}:
+            assert _rel(hip2.state[c][k], ref.state[a][k]) <= 2e-6, (k, SHAPES[i])
+    # torch's optimizer resumes from HipAdamW's state, and HipAdamW from torch's
+    pd = [p.detach().clone().requires_grad_(True) for p in pb]
+    ref2 = torch.optim.AdamW(pd, foreach=True, **kw)
+    ref2.load_state_dict(sd)
+    run(ref2, pd, range(3, 6))
+    pe = [p.detach().clone().requires_grad_(True) for p in pa]          # parameters after 6 torch steps ...
+    hip3 = HipAdamW(pe, **kw)
+    hip3.load_state_dict(ref.state_dict())                               # ... and torch's state after 6 steps
+    assert all(_rel(d, a) <= 2e-6 for d, a in zip(pd, pa))
+    for p, g in zip(pa, grads[0]):
+        p.grad = g.clone()
+    for p, g in zip(pe, grads[0]):
+        p.grad = g.clone()
+    ref.step()
+    hip3.step()
+    assert hip3.step_count() == 7 and all(_rel(e, a) <= 2e-6 for e, a in zip(pe, pa))

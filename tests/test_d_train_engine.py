@@ -107,8 +107,9 @@ def test_engine_with_prefetched_host_batches():
 @pytest.mark.gpu
 def test_engine_fp16_precision_mode():
     """config.precision = "fp16" (BASELINE configs[4]): fp16-MFMA GEMMs + half storage of the MBConv trunk, under the
-    engine's GradScaler, with the passes graph-captured from the second step on: finite losses, parameters move, and the
-    process-wide GEMM path goes back to fp32 for the next fp32 engine."""
+    engine's GradScaler, with the passes graph-captured from the second step on: finite losses, parameters move.  The GEMM
+    path is process-wide: only an fp16 engine sets it, an fp32 engine built afterwards leaves it alone (it must not switch
+    the arithmetic under an engine that still lives)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import copy
@@ -129,6 +130,8 @@ def test_engine_fp16_precision_mode():
         bad["config"]["precision"] = "bf16"
         with pytest.raises(ValueError):
             get_engine("FE")(bad, "Train")
+        get_engine("FE")(copy.deepcopy(CONFIG), "Train")              # an fp32 engine does not touch the path
+        assert lib.call("ud_gemm_get_path") == 3
     finally:
-        get_engine("FE")(copy.deepcopy(CONFIG), "Train")              # an fp32 engine resets the path
+        lib.call("ud_gemm_set_path", 0)
         assert lib.call("ud_gemm_get_path") == 0

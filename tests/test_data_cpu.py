@@ -74,3 +74,25 @@ def test_worker_loader_decodes_off_the_main_process_and_reshuffles(workers):
     pf = RealFakePrefetcher(src_r, src_f)
     xr, yr, xf, yf = pf(1, 4, 6, "cpu")
     assert xr.shape == (4, 3, 6, 6) and yr.eq(0).all() and yf.eq(1).all()
+
+
+@pytest.mark.parametrize("n,world,bs,drop_last", [(127, 2, 32, False), (127, 2, 32, True), (13, 4, 2, False), (3, 4, 2, False),
+                                                  (64, 8, 4, True)])
+def test_every_rank_gets_the_same_number_of_equal_batches(n, world, bs, drop_last):
+    """The reference shards with DistributedSampler (engine/forgery_engine.py:67-86), which pads the epoch to a multiple of
+    the world size: all ranks step the same number of times with the same batch sizes (unequal counts would deadlock the
+    gradient all-reduce / the SyncBN exchange, unequal rows would break the fused SyncBN's M * world count)."""
+    from unidefense_amd.engine.data import DecodedBatches
+    ds = _ToyFaces(n, 0)
+    per_rank = []
+    for rank in range(world):
+        db = DecodedBatches(ds, bs, crop=2, seed=7, rank=rank, world=world, drop_last=drop_last)
+        per_rank.append([db[i][0][:, 0, 0, 0].int().tolist() for i in range(len(db))])
+    counts = {len(b) for b in per_rank}
+    assert len(counts) == 1, [len(b) for b in per_rank]
+    for i in range(len(per_rank[0])):
+        assert len({len(b[i]) for b in per_rank}) == 1
+    seen = [v for b in per_rank for batch in b for v in batch]
+    if not drop_last:
+        assert set(seen) == set(range(n))                   # padding only ever repeats samples, never drops one
+        assert len(seen) == -(-n // world) * world

@@ -28,10 +28,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(dev):
+MODELS = {"UDEB4": (256, dict(extractor="efficientnet-b4", drop_connect_rate=0.0)),
+          # BASELINE configs[3]: UDR50 at 320 x 320 — every BatchNorm on the operator path (engine/ocim_engine.py:130-133)
+          "UDR50": (320, dict(extractor="resnet50"))}
+
+
+def _build(dev, name="UDEB4"):
     from oracle import param_fill
     from unidefense_amd.model import load_model
-    m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.0, drop_connect_rate=0.0)
+    m = load_model(name)(num_classes=2, drop_rate=0.0, **MODELS[name][1])
     param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
     m = m.to(dev).train()
     m._dec_dropout = False
@@ -55,16 +60,16 @@ def _digest(g):
     return g.reshape(-1)[:4096].cpu().numpy(), g.double().norm().item(), g.abs().max().item()     # numpy: pickled by value
 
 
-def _shards():
+def _shards(name="UDEB4"):
     """Two [real, real, fake, fake] shards and the equivalent full batch [4 real; 4 fake]."""
     from oracle import param_fill
-    x = param_fill.make_input(2 * N_RANK, SIZE, seed=123)                 # rows 0-3 real, 4-7 fake
+    x = param_fill.make_input(2 * N_RANK, MODELS[name][0], seed=123)                 # rows 0-3 real, 4-7 fake
     h = N_RANK // 2
     idx = [list(range(r * h, (r + 1) * h)) + list(range(N_RANK + r * h, N_RANK + (r + 1) * h)) for r in range(2)]
     return x, idx
 
 
-def _worker(rank, port, q, exchange=True):
+def _worker(rank, port, q, exchange=True, name="UDEB4"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UD_SYNCBN_EXCHANGE="1" if exchange else "0")
     try:
         dev = torch.device("cuda:0")
@@ -73,9 +78,9 @@ def _worker(rank, port, q, exchange=True):
         from unidefense_amd.config import cfg
         from unidefense_amd.engine.parallel import HipDataParallel
         cfg.syncbn_exchange = bool(exchange)
-        m = _build(dev)
+        m = _build(dev, name)
         dp = HipDataParallel(m, bucket_bytes=32 << 20)
-        x, idx = _shards()
+        x, idx = _shards(name)
         xs = x[idx[rank]].contiguous().to(dev)
         tgt = torch.tensor([0] * (N_RANK // 2) + [1] * (N_RANK // 2), device=dev)
         res = None
@@ -98,16 +103,20 @@ def _worker(rank, port, q, exchange=True):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", [True, False], ids=["peer-exchange", "all_reduce"])
-def test_two_ranks_equal_one_process_full_batch(exchange):
-    """exchange: the SyncBN sums of the fused path travel through BnExchange's peer-mapped mailboxes (csrc/xchg.hip: HIP IPC
-    between the two processes, one kernel per sum) — it must have passed its self-test and been used; False: dist.all_reduce."""
+@pytest.mark.parametrize("name,exchange", [("UDEB4", True), ("UDEB4", False), ("UDR50", True)],
+                         ids=["UDEB4-peer-exchange", "UDEB4-all_reduce", "UDR50-320-peer-exchange"])
+def test_two_ranks_equal_one_process_full_batch(name, exchange):
+    """exchange: the SyncBN sums travel through BnExchange's peer-mapped mailboxes (csrc/xchg.hip: HIP IPC between the two
+    processes, one kernel per sum) — it must have passed its self-test and been used; False: dist.all_reduce.
+    UDEB4: the fused MBConv path + the operator-path BatchNorms of attention / head; UDR50 at 320 x 320 (BASELINE configs[3]):
+    every BatchNorm on the operator path (tape._syncbn_act), mailbox rows sized for its 2048-channel norms."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    from tests.margins import within
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, q, exchange)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, exchange, name)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=900) for _ in range(2)]
@@ -119,8 +128,8 @@ def test_two_ranks_equal_one_process_full_batch(exchange):
     assert [g[2][3] for g in got] == [exchange, exchange], "BnExchange state"
     # single process, whole batch, plain BatchNorm
     dev = torch.device("cuda:0")
-    m = _build(dev)
-    x, idx = _shards()
+    m = _build(dev, name)
+    x, idx = _shards(name)
     tgt = torch.tensor([0] * N_RANK + [1] * N_RANK, device=dev)
     out = m(x.to(dev))
     _loss(out, tgt).backward()
@@ -130,22 +139,30 @@ def test_two_ranks_equal_one_process_full_batch(exchange):
         e1 = abs(cls - out["cls_out"].detach().cpu().numpy()[ids]).max() / out["cls_out"].abs().max().item()
         e2 = abs(rec - out["rec"].detach().cpu().numpy()[ids]).max() / out["rec"].abs().max().item()
         print(f"  rank {rank}: cls_out {e1:.2e}  rec {e2:.2e}")
-        from tests.margins import within
         assert within(f"rank {rank} cls_out vs full batch", e1, 1e-4) and within(f"rank {rank} rec vs full batch", e2, 1e-3), (rank, e1, e2)
     # both ranks hold the same averaged gradients, equal to the full-batch gradients
     g0, g1 = got[0][2][0], got[1][2][0]
     assert set(g0) == set(ref_g) == set(g1)
     gmax = max(v[2] for v in ref_g.values())
-    worst, worst_norm, worst_rr = (0.0, ""), (0.0, ""), 0.0
+    worst, worst_norm, worst_rr, worst_l2 = (0.0, ""), (0.0, ""), 0.0, (0.0, "")
+    import numpy as np
     for k, (head, norm, mx) in ref_g.items():
         scale = mx + 3e-3 * gmax                     # zero-true-gradient tensors hold rounding noise (test_y_fullsize_gpu.py)
         worst = max(worst, (float(abs(g0[k][0] - head).max()) / scale, k))
         worst_norm = max(worst_norm, (abs(g0[k][1] - norm) / (norm + 3e-3 * gmax * head.size ** 0.5), k))
+        worst_l2 = max(worst_l2, (float(np.linalg.norm(g0[k][0] - head)) / (float(np.linalg.norm(head)) + 3e-3 * gmax * head.size ** 0.5), k))
         worst_rr = max(worst_rr, float(abs(g0[k][0] - g1[k][0]).max()) / scale)
     print(f"  {len(ref_g)} gradients: 2 ranks vs full batch: worst entry {worst[0]:.2e} ({worst[1]}), worst norm "
-          f"{worst_norm[0]:.2e} ({worst_norm[1]}); rank 0 vs rank 1 {worst_rr:.2e}")
-    ok = [within("rank 0 vs rank 1 gradients", worst_rr, 1e-6), within("averaged gradient heads vs full batch", worst[0], 2e-3),
-          within("averaged gradient norms vs full batch", worst_norm[0], 2e-3)]
+          f"{worst_norm[0]:.2e} ({worst_norm[1]}), worst relative L2 of the leading 4096 entries {worst_l2[0]:.2e} "
+          f"({worst_l2[1]}); rank 0 vs rank 1 {worst_rr:.2e}")
+    ok = [within("rank 0 vs rank 1 gradients", worst_rr, 1e-6), within("averaged gradient norms vs full batch", worst_norm[0], 2e-3)]
+    if name == "UDEB4":
+        ok.append(within("averaged gradient heads vs full batch", worst[0], 2e-3))
+    else:
+        # A ReLU network: the two shards run other GEMM plans than the full batch (other M), i.e. other rounding, and a
+        # handful of the 1e8 ReLU units within that of zero land on the other side — single weight-gradient ENTRIES move by
+        # percents (tests/test_y_fullsize_gpu.py), each tensor as a whole does not: relative L2 instead of the worst entry.
+        ok.append(within("averaged gradient heads vs full batch, relative L2 per tensor", worst_l2[0], 1e-2))
     assert all(ok)
 
 

@@ -16,6 +16,7 @@ import torch
 
 from oracle import param_fill
 from tests import oracle_util as ou
+from tests.margins import within
 
 pytestmark = pytest.mark.gpu
 N, SIZE = 32, 256
@@ -265,12 +266,11 @@ def _worst_rel(runs):
 
 
 @pytest.mark.parametrize("name,ctor,n,size", [("UDEB4", dict(extractor="efficientnet-b4"), 8, 256), ("UDR18", {}, 8, 128)])
-def test_default_mode_is_repeatable(name, ctor, n, size):
-    """The package default (cfg.deterministic: split-K GEMMs through ordered slices, ud_gemm out_mode 3 + ud_sum_slices):
+def test_deterministic_mode_is_repeatable(name, ctor, n, size):
+    """cfg.deterministic (the mode this suite runs in: split-K GEMMs through ordered slices, ud_gemm out_mode 3 + ud_sum_slices):
     three runs of the same train step give the same loss, output and parameter gradients.  On the operator path (every
     reduction in a fixed order) that is BITWISE; on the fused MBConv path the fp64 accumulators are filled by atomics, whose
     order can move a sum by 1e-16 — held to 1e-9 of each tensor's scale here (observed: bitwise as well)."""
-    from tests.margins import within
     from unidefense_amd.config import cfg, override
     dev = _dev()
     assert cfg.deterministic

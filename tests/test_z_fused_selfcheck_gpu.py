@@ -9,7 +9,7 @@ Both paths run the same parameters, inputs and dropout / drop-connect masks.  Ba
     is a sum that cancels to rounding noise: the next block's BatchNorm removes any per-channel shift of its input);
   * SCALAR gate gradients (24 sf_coef, fuse_coef): each is ONE global sum  sigmoid'(a) * sum dy * (freq - spat)  over up to
     3e6 terms of both signs, so its error is measured against the sum of the terms' MAGNITUDES (captured by the operator
-    path in debug mode: tape.gate_cond), not against what is left of the sum after cancellation: 1e-4 of it.
+    path in debug mode: tape.gate_cond), not against what is left of the sum after cancellation: 1e-5 of it (observed: 2e-7).
 """
 import pytest
 import torch
@@ -19,7 +19,7 @@ from tests import oracle_util as ou
 from tests.margins import within
 
 pytestmark = pytest.mark.gpu
-GATE_COND_RTOL = 1e-4
+GATE_COND_RTOL = 1e-5
 
 
 def _dev():
@@ -84,7 +84,7 @@ def _grad_bars(g0, g1, cond, label):
         if not d <= tol:
             bad.append(("grad " + k, d, ref, tol))
     ok_t = within(label + ": worst tensor-gradient deviation / bar", worst_t, 1.0)
-    ok_s = within(label + ": worst gate-gradient deviation / (1e-4 x sum|terms|)", worst_s, 1.0)
+    ok_s = within(label + ": worst gate-gradient deviation / (1e-5 x sum|terms|)", worst_s, 1.0)
     print(f"  {label}: worst deviation / bar: tensors {worst_t:.3f}, scalar gates {worst_s:.3f} ({len(g0)} gradients)")
     assert (ok_t and ok_s) == (not bad)
     return bad

@@ -92,7 +92,6 @@ struct Loader {
     int dim;        // number of valid rows (M or N)
     int K;
     bool vec;       // 16-byte loads allowed
-    bool skip;      // tuning aid (UD_GEMM_NOLOAD): issue no global loads, feed zeros
     ud_conv_geom g;
     // per-thread cached gather state
     int c_nbase[NV], c_ih0[NV], c_iw0[NV];
@@ -102,7 +101,7 @@ struct Loader {
 
     __device__ __forceinline__ void init(const float* p, long ld_, int dim_, int K_, bool vec_,
                                          const ud_conv_geom& g_, int row0, int tid) {
-        base = p; ld = ld_; dim = dim_; K = K_; vec = vec_; g = g_; skip = false;
+        base = p; ld = ld_; dim = dim_; K = K_; vec = vec_; g = g_;
         if constexpr (MODE == 2 && !IS_B) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -134,7 +133,6 @@ struct Loader {
         for (int i = 0; i < NV; ++i) {
             int f = tid + i * NTHREADS;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (skip) { regs[i] = v; continue; }
             if constexpr (MODE == 0) {
                 int row = f / KQ, kq = f % KQ;
                 int r = row0 + row, k = k0 + kq * 4;
@@ -275,9 +273,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const ud_gemm_desc d, in
 
     LA la; LB lb;
     la.init(Ap, d.lda, d.M, d.K, (a_vec & 1) != 0, d.g, m0, tid);
-    la.skip = (a_vec & 2) != 0;
     lb.init(Bp, d.ldb, d.N, d.K, (b_vec & 1) != 0, d.g, n0, tid);
-    lb.skip = (a_vec & 2) != 0;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -515,10 +511,6 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         return ud_gemm_x3_launch_half(d, s);
     }
     if (takes_x3(d, a_vec, b_vec)) return ud_gemm_x3_launch(d, s, g_path.load() == 3);
-#ifdef UD_GEMM_DEBUG_NOLOAD      // tuning aid, debug builds only: issue no global loads (results are WRONG)
-    static const bool noload = getenv("UD_GEMM_NOLOAD") != nullptr;
-    if (noload) a_vec |= 2;
-#endif
     if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0>(d, a_vec, b_vec, s);
     if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1>(d, a_vec, b_vec, s);
     if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1>(d, a_vec, b_vec, s);

@@ -87,14 +87,13 @@ __device__ __forceinline__ int phys_row(int row) { return row ^ ((row >> 3) & 1)
 // PREC 3: the exact three-way bf16 split (fp32 GEMM accuracy).
 // PREC 1: ONE fp16 piece per operand (round to nearest even): the mixed-precision mode of BASELINE configs[4] — fp16 MFMA
 //         operands, fp32 accumulation, one v_mfma_f32_32x32x16_f16 instead of six bf16 MFMAs.
-// PREC 0: experiments only (-DUD_X3_FAKE_A / -DUD_X3_FAKE_B): three identical bf16 pieces, i.e. the split's arithmetic
-//         removed, to measure what it costs (measured: 4-8 % for B alone, 10-12 % for both: not the limiter).
+// (Measured in round 2 with the split's arithmetic compiled out: it costs 4-8 % for B alone, 10-12 % for both operands —
+//  not the limiter.)
 // H: the operand is stored as _Float16 (half storage of the activations, PREC 1 only): the same element-to-thread map
 // with 8-byte / 4-byte loads, and the store is a masked copy (K-contiguous) or a pair interleave (row-contiguous).
 template <int ROWS, int MODE, int PREC = 3, bool H = false>
 struct XLoader {
     static_assert(!H || PREC == 1, "half operands feed the fp16 MFMA directly");
-    static constexpr bool FAKE = PREC == 0;
     static constexpr int NPL = PREC == 1 ? 1 : 3;      // bf16 / fp16 planes per operand
     static constexpr int GS = ROWS * 16 + 32;          // bytes of one (plane, k-group) image
     static constexpr int STAGE = 2 * NPL * GS;         // planes x 2 k-groups
@@ -285,13 +284,8 @@ struct XLoader {
                                                          pack_f16(ok ? v[2] : 0.f, ok ? v[3] : 0.f)};
                 } else {
                     uint32_t a0, a1, a2, b0, b1, b2;
-                    if (FAKE) {
-                        a0 = a1 = a2 = pack_bf16(ok ? v[0] : 0.f, ok ? v[1] : 0.f);
-                        b0 = b1 = b2 = pack_bf16(ok ? v[2] : 0.f, ok ? v[3] : 0.f);
-                    } else {
-                        split2(ok ? v[0] : 0.f, ok ? v[1] : 0.f, a0, a1, a2);
-                        split2(ok ? v[2] : 0.f, ok ? v[3] : 0.f, b0, b1, b2);
-                    }
+                    split2(ok ? v[0] : 0.f, ok ? v[1] : 0.f, a0, a1, a2);
+                    split2(ok ? v[2] : 0.f, ok ? v[3] : 0.f, b0, b1, b2);
                     *reinterpret_cast<u32x2*>(p) = u32x2{a0, b0};
                     *reinterpret_cast<u32x2*>(p + 2 * GS) = u32x2{a1, b1};
                     *reinterpret_cast<u32x2*>(p + 4 * GS) = u32x2{a2, b2};
@@ -313,8 +307,7 @@ struct XLoader {
                     *reinterpret_cast<uint32_t*>(p) = pack_f16(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f);
                 } else {
                     uint32_t a0, a1, a2;
-                    if (FAKE) a0 = a1 = a2 = pack_bf16(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f);
-                    else split2(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f, a0, a1, a2);
+                    split2(ok0 ? v0[e] : 0.f, ok1 ? v1[e] : 0.f, a0, a1, a2);
                     *reinterpret_cast<uint32_t*>(p) = a0;
                     *reinterpret_cast<uint32_t*>(p + 2 * GS) = a1;
                     *reinterpret_cast<uint32_t*>(p + 4 * GS) = a2;
@@ -329,16 +322,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     static_assert(WGM * WGN == 4, "4 waves");
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int NPL = PREC == 1 ? 1 : 3;
-#ifdef UD_X3_FAKE_A
-    using LA = XLoader<BM, AMODE, PREC == 3 ? 0 : PREC>;
-#else
     using LA = XLoader<BM, AMODE, PREC, AH>;
-#endif
-#ifdef UD_X3_FAKE_B
-    using LB = XLoader<BN, BMODE, PREC == 3 ? 0 : PREC>;
-#else
     using LB = XLoader<BN, BMODE, PREC, BH>;
-#endif
     __shared__ __attribute__((aligned(16))) char As[2][LA::STAGE];
     __shared__ __attribute__((aligned(16))) char Bs[2][LB::STAGE];
 

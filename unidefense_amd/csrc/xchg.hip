@@ -11,8 +11,10 @@
 //     and adds the rows in rank order (the same order on every rank: bit-identical results) into acc.
 // The sequence number lives in device memory and is advanced by the kernel, so a hipGraph replay of the step keeps
 // counting.  Slots: a rank can be at most one exchange ahead of the slowest (exchange k+1 cannot complete before
-// everyone has entered it, i.e. left exchange k), so two slots suffice; four are used.  The wait is bounded: a peer
-// that never arrives raises *err instead of hanging the GPU.  (A first version with plain stores + system-scope
+// everyone has entered it, i.e. left exchange k), so two slots suffice; four are used.  The wait is bounded by WALL-CLOCK
+// time (wall_clock64, minutes by default — ranks legitimately drift apart by seconds: a data-loader stall, rank 0 writing a
+// checkpoint, first-step GEMM tuning): a peer that never arrives raises *err instead of hanging the GPU, and the sums of
+// that exchange are POISONED with NaN, never left as the partial sum of the rows that did arrive.  (A first version with plain stores + system-scope
 // release / acquire fences cost 9.5 us per exchange on one device: the fences write back and invalidate the L2.)
 #include <string.h>
 
@@ -38,7 +40,7 @@ constexpr int MAXW = 16;          // ranks of one node
 __global__ __launch_bounds__(NT) void xchg_allreduce_kernel(double* __restrict__ acc, int n, void* const* __restrict__ peers,
                                                             int rank, int world, int max_doubles, int slots,
                                                             u64* __restrict__ counters, int* __restrict__ err,
-                                                            long spin_limit) {
+                                                            long long timeout_ticks) {
     const int i = blockIdx.x * NT + threadIdx.x;
     const u64 seq = __hip_atomic_load(counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     __syncthreads();                                            // every wave of this workgroup has read it
@@ -68,6 +70,8 @@ __global__ __launch_bounds__(NT) void xchg_allreduce_kernel(double* __restrict__
     u64 lo[MAXW], hi[MAXW];
     unsigned pending = (1u << world) - 1u;
     long spins = 0;
+    const long long t0 = wall_clock64();
+    bool timed_out = false;
     while (pending) {
 #pragma unroll
         for (int r = 0; r < MAXW; ++r) {
@@ -81,10 +85,15 @@ __global__ __launch_bounds__(NT) void xchg_allreduce_kernel(double* __restrict__
         for (int r = 0; r < MAXW; ++r)
             if (r < world && (lo[r] & 0xffffffff00000000ull) == tag && (hi[r] & 0xffffffff00000000ull) == tag)
                 pending &= ~(1u << r);
-        if (pending && ++spins > spin_limit) {
+        if (pending && (++spins & 1023) == 0 && wall_clock64() - t0 > timeout_ticks) {
             atomicExch(err, __ffs(pending));                    // 1 + the lowest rank that never arrived
+            timed_out = true;
             break;
         }
+    }
+    if (timed_out) {                                            // never a partial sum: the step's statistics are void
+        acc[i] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
     }
     double s = 0.0;
 #pragma unroll
@@ -146,15 +155,22 @@ int ud_xchg_destroy(void* base) {
 
 // acc[0..n) <- sum over the ranks, in place.  peers: DEVICE array of `world` mailbox pointers in rank order (the own
 // one at [rank]); seq_counter: TWO device words (exchanges completed, workgroups arrived) and err: one, owned by the
-// caller, zero-initialised.  spin_limit: polls (each
-// ~64 cycles apart) before a missing peer is reported through *err.
+// caller, zero-initialised.  timeout_ms: wall-clock wait for the slowest peer before it is reported missing through *err
+// (and the affected sums set to NaN).
 int ud_xchg_allreduce(double* acc, int n, void* const* peers, int rank, int world, int max_doubles, int slots,
-                      unsigned long long* seq_counter, int* err, long spin_limit, ud_stream_t stream) {
+                      unsigned long long* seq_counter, int* err, long timeout_ms, ud_stream_t stream) {
     if (!acc || n < 1 || n > max_doubles || !peers || rank < 0 || rank >= world || world > MAXW || slots < 2 ||
-        !seq_counter || !err || spin_limit < 1)
+        !seq_counter || !err || timeout_ms < 1)
         return UD_EINVAL;
+    static const long long khz = [] {                           // wall_clock64() ticks per millisecond
+        int dev = 0, rate = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate <= 0)
+            rate = 100000;                                      // 100 MHz: the constant counter of gfx9
+        return (long long)rate;
+    }();
     hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(ud_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, acc, n, peers,
-                       rank, world, max_doubles, slots, seq_counter, err, spin_limit);
+                       rank, world, max_doubles, slots, seq_counter, err, khz * (long long)timeout_ms);
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -81,7 +81,10 @@ class DecodedBatches(torch.utils.data.Dataset):
     (dataset/abstract_dataset.py:101-160, called at engine/forgery_engine.py:251-266).  This wrapper indexes BATCHES:
     item i = `load_item` of the i-th batch of a (seeded, per-epoch reshuffled) index order, run inside a worker process,
     so that `workers` batches decode in parallel while the GPU steps.  `rank` / `world` shard the order like the
-    reference's DistributedSampler (forgery_engine.py:67-86): every rank sees its own 1/world of each epoch."""
+    reference's DistributedSampler (forgery_engine.py:67-86): the epoch's order is padded by wrapping around to a multiple
+    of `world` (torch's DistributedSampler with drop_last=False), so EVERY rank sees the same number of samples, hence the
+    same number of equally sized batches — unequal step counts would leave the gradient all-reduces and the SyncBN
+    exchange of the longer ranks waiting for peers that have finished."""
 
     def __init__(self, dataset, batch_size, crop=None, shuffle=True, seed=0, rank=0, world=1, drop_last=True):
         self.dataset, self.batch_size, self.crop = dataset, int(batch_size), crop
@@ -98,10 +101,16 @@ class DecodedBatches(torch.utils.data.Dataset):
             idx = torch.randperm(n, generator=g).tolist()
         else:
             idx = list(range(n))
-        return idx[self.rank::self.world]
+        total = self._per_rank() * self.world
+        while len(idx) < total:                                      # pad by wrapping (n < world: more than once)
+            idx += idx[:total - len(idx)]
+        return idx[self.rank:total:self.world]
+
+    def _per_rank(self):
+        return -(-len(self.dataset) // self.world)
 
     def __len__(self):
-        n = len(range(self.rank, len(self.dataset), self.world))
+        n = self._per_rank()
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def __getitem__(self, i):

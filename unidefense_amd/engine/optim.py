@@ -28,7 +28,9 @@ class HipAdamW(torch.optim.Optimizer):
     decay, bias corrections from a device-side step counter, GradScaler's 1/scale and found_inf skip read on the device
     (`_step_supports_amp_scaling`: GradScaler.step hands both over instead of unscaling in a pass of its own).
     Reference: engine/forgery_engine.py:149-156,228; engine/abstract_engine.py:281-283,374-378.
-    State layout: exp_avg / exp_avg_sq / max_exp_avg_sq are views of three flat buffers (16-byte aligned per tensor)."""
+    State layout: exp_avg / exp_avg_sq / max_exp_avg_sq are views of three flat buffers (16-byte aligned per tensor);
+    state_dict() / load_state_dict() speak torch.optim.AdamW's format (incl. the per-parameter `step`), so a checkpointed
+    optimizer resumes with its moments and bias corrections, and either optimizer can load the other's state."""
 
     _step_supports_amp_scaling = True
 
@@ -59,12 +61,21 @@ class HipAdamW(torch.optim.Optimizer):
                 total += (p.numel() + 3) // 4 * 4
         names = ["exp_avg", "exp_avg_sq"] + (["max_exp_avg_sq"] if ams else [])
         flat = {k: torch.zeros(total, dtype=torch.float32, device=dev) for k in names}
+        loaded_step = 0
         for p, off in offs.items():
             st = self.state[p]
             for k in names:
-                st[k] = flat[k][off:off + p.numel()].view_as(p)
+                view = flat[k][off:off + p.numel()].view_as(p)
+                old = st.get(k)
+                if old is not None:                    # restored by load_state_dict (ours or torch.optim.AdamW's): keep it
+                    view.copy_(old.to(device=dev, dtype=torch.float32).view_as(p))
+                st[k] = view
+            if "step" in st:
+                loaded_step = max(loaded_step, int(float(st["step"])))
         self._flat, self._chunk = flat, chunk
-        self._steps = torch.zeros(2, dtype=torch.int32, device=dev)
+        # applied steps so far (bias corrections continue where the restored run stopped)
+        self._steps = torch.full((2,), loaded_step, dtype=torch.int32, device=dev)
+        self._cur = 0
 
     def _plan_stale(self, active):
         """The cached parameter / state pointers no longer describe the tensors (load_state_dict replaced the state,
@@ -76,9 +87,20 @@ class HipAdamW(torch.optim.Optimizer):
                 return True
         return False
 
+    def state_dict(self):
+        """torch.optim.AdamW's layout: per parameter `step` (applied steps, one device read here), exp_avg, exp_avg_sq
+        [, max_exp_avg_sq] — interchangeable with torch's optimizer in both directions."""
+        if self._steps is not None:
+            n = float(self.step_count())
+            for st in self.state.values():
+                st["step"] = torch.tensor(n)
+        return super().state_dict()
+
     def load_state_dict(self, state_dict):
+        """The restored moments are copied into the flat buffers (and the step counter set) by the next step()."""
         super().load_state_dict(state_dict)
         self._plan = None
+        self._steps = None
 
     def _make_plan(self, active, dev):
         """Static per set of updated tensors: chunk map and pointer table on the device."""

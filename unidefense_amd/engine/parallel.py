@@ -14,10 +14,12 @@ The path shards over the batch only.  Exchanges per backward:
   * SyncBatchNorm statistics, enabled by ``sync_bn=True``.  Fused MBConv path (tape.mbconv_fused): the fp64
     accumulators (sum x, sum x^2) of a BatchNorm are summed over the ranks IN PLACE between the kernel that fills them
     and the kernels that consume them (tape.DataParallelCtx.reduce), likewise (sum dz, sum dz*xhat) in the backward —
-    2C doubles each way, ranks need not hold equal row counts.  On one node the sum is BnExchange's single kernel over
-    peer-mapped mailboxes (csrc/xchg.hip; rank-ordered, bit-identical on all ranks); otherwise one dist.all_reduce.  Operator path (tape.batchnorm_act:
-    attention / head / ResNet models): one all_gather of (mean, var) per BN forward and one all_reduce of the two sums
-    per BN backward.
+    2C doubles each way.  Every rank must hold the SAME number of rows (the count is rows * world; engine/data.py pads the
+    shards like DistributedSampler so that they do).  On one node the sum is BnExchange's single kernel over peer-mapped
+    mailboxes (csrc/xchg.hip; rank-ordered, bit-identical on all ranks; sized for the model's widest BatchNorm);
+    otherwise one dist.all_reduce.  Operator path (tape.batchnorm_act: attention / head / the ResNet models, e.g. BASELINE
+    configs[3], UDR50 on 4 GPUs, engine/ocim_engine.py:130-133): the same fp64 sums through the same exchange
+    (tape._syncbn_act on the deferred-BatchNorm kernels).
 No other collective exists on the data path.
 """
 import torch
@@ -88,16 +90,21 @@ class BnExchange:
     dist.all_reduce (`ok` False) — e.g. ranks on different nodes, where the IPC open fails.  `UD_SYNCBN_EXCHANGE=0`
     disables it."""
 
-    MAX_DOUBLES = 8192          # 2 * 3264 channels is the largest accumulator of the EfficientNet-b4 trunk
+    MAX_DOUBLES = 8192          # default mailbox row: 2 * 3264 channels, the largest accumulator of the EfficientNet-b4 trunk
     SLOTS = 4
-    SPIN_LIMIT = 1 << 20        # polls (~1 us each) before a missing peer is reported: about a second
+    # Wall-clock wait for the slowest peer before it is reported missing.  Ranks of a healthy job drift apart by seconds
+    # (a data-loader stall, rank 0 writing a checkpoint, first-step GEMM tuning), so this is minutes — RCCL itself would
+    # wait for ever; a timed-out exchange poisons its sums with NaN and check() raises.
+    TIMEOUT_S = 600.0
 
-    def __init__(self, group, device):
+    def __init__(self, group, device, max_doubles=None):
         import ctypes as C
         from .. import lib
         self.group, self.device = group, device
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.ok, self.base, self.opened = False, None, []
+        if max_doubles is not None:
+            self.MAX_DOUBLES = max(int(max_doubles), 64)          # sized from the model (HipDataParallel)
         want = cfg.syncbn_exchange and device.type == "cuda"
         status, handle = 0, b""
         if want:
@@ -170,13 +177,18 @@ class BnExchange:
         from .. import lib
         assert acc.dtype == torch.float64 and acc.is_contiguous() and acc.numel() <= self.MAX_DOUBLES
         lib.call("ud_xchg_allreduce", K._p(acc), acc.numel(), K._p(self.peers), self.rank, self.world, self.MAX_DOUBLES,
-                 self.SLOTS, K._p(self.seq), K._p(self.err), self.SPIN_LIMIT, K._stream())
+                 self.SLOTS, K._p(self.seq), K._p(self.err), int(self.TIMEOUT_S * 1000), K._stream())
 
     def check(self):
-        """Host-side check after a step (synchronises): a rank that timed out waiting raises here."""
+        """Host-side check (synchronises): a rank that timed out waiting for a peer raises here.  The engine calls it at
+        every log step and BEFORE every checkpoint save / validation (the affected statistics are NaN, so nothing computed
+        from them can pass for a result either)."""
+        if not self.ok:
+            return
         e = int(self.err.item())
         if e:
-            raise RuntimeError(f"SyncBatchNorm exchange: rank {e - 1} did not arrive (rank {self.rank} timed out)")
+            raise RuntimeError(f"SyncBatchNorm exchange: rank {e - 1} did not arrive within {self.TIMEOUT_S:.0f} s "
+                               f"(rank {self.rank} timed out); the step's BatchNorm sums were set to NaN")
 
     def close(self):
         from .. import lib
@@ -210,7 +222,9 @@ class HipDataParallel(nn.Module):
             module._sync_bn_group = process_group if process_group is not None else dist.group.WORLD
             dev = next(module.parameters()).device
             if dev.type == "cuda":
-                self.bn_exchange = BnExchange(module._sync_bn_group, dev)
+                # mailbox rows sized for the widest BatchNorm of THIS model (sum | sum of squares: 2C doubles)
+                widest = max([m.num_features for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)] + [1])
+                self.bn_exchange = BnExchange(module._sync_bn_group, dev, max(BnExchange.MAX_DOUBLES, 2 * widest))
                 module._bn_exchange = self.bn_exchange if self.bn_exchange.ok else None
 
     def forward(self, *args, **kwargs):

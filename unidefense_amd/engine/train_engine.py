@@ -73,9 +73,11 @@ class TrainEngine(AbstractEngine):
         self.precision = str(cfg.get("precision", "fp32")).lower()
         if self.precision not in ("fp32", "fp16"):
             raise ValueError(f"config.precision must be 'fp32' or 'fp16', got {self.precision!r}")
-        from .. import lib as _lib
-        _lib.call("ud_gemm_set_path", 3 if self.precision == "fp16" else 0)
         if self.precision == "fp16":
+            # process-wide: the fp16-MFMA kernel for every plain GEMM from here on.  An fp32 engine leaves the path alone
+            # (it may have been chosen by UD_GEMM_PATH, or by an fp16 engine that still lives in this process).
+            from .. import lib as _lib
+            _lib.call("ud_gemm_set_path", 3)
             self.model.half_storage = True
         self.model_without_ddp = self.model
         if dist.is_available() and dist.is_initialized():
@@ -101,10 +103,20 @@ class TrainEngine(AbstractEngine):
     def _ckpt_path(self, best=False):
         return os.path.join(self.config["config"].get("dir", "."), "best_model.bin" if best else "latest_model.bin")
 
+    def _check_exchange(self):
+        """A SyncBN peer exchange that timed out has poisoned this step's statistics (NaN): raise before anything is
+        logged, validated or saved from them."""
+        exchange = getattr(self.model, "bn_exchange", None)
+        if exchange is not None:
+            exchange.check()
+
     def _save_ckpt(self, step, best=False):
+        self._check_exchange()
         if self.local_rank == 0:
             save_checkpoint(self.model_without_ddp, self._ckpt_path(best), step, self.best_step, self.best_auc,
                             self.best_acc)
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()              # the other ranks start the next step together with the writer (forgery_engine.py:219)
 
     def _load_ckpt(self, best=False, train=False):
         return load_checkpoint(self.model_without_ddp, self._ckpt_path(best))
@@ -137,9 +149,7 @@ class TrainEngine(AbstractEngine):
                 correct += (out["cls_out"].argmax(1) == in_tgt).sum()
                 seen += in_tgt.numel()
                 if cur_step % self.log_steps == 0 or cur_step == self.num_steps:
-                    exchange = getattr(self.model, "bn_exchange", None)
-                    if exchange is not None and exchange.ok:
-                        exchange.check()         # SyncBN peer exchange: a missing rank surfaces here, not as a silent NaN
+                    self._check_exchange()       # SyncBN peer exchange: a missing rank surfaces here, not as a silent NaN
                     keys = sorted(sums)
                     vals = self._mean_over_ranks([sums[k] / count for k in keys] + [correct / seen])
                     last = dict(zip(keys, vals[:-1]))
@@ -149,11 +159,13 @@ class TrainEngine(AbstractEngine):
                             cur_step, self.num_steps, last.get("total_loss", 0.0), last.get("triplet_loss", 0.0),
                             last.get("real_rec_loss", 0.0), last.get("real_freq_loss", 0.0), last["acc"], last["lr"]))
             if self.config["config"].get("dir"):
-                # the train loop has no validation pass (evaluation metrics are out of scope), so the best-so-far
-                # record is the train accuracy of the last log window; best_model.bin is what the reference's test
-                # stage reads (forgery_engine.py:202-207)
-                if last.get("acc", 0.0) >= self.best_acc:
-                    self.best_step, self.best_acc = self.num_steps, float(last.get("acc", 0.0))
+                # best_model.bin (what the reference's test stage reads, forgery_engine.py:202-207) is validate()'s to
+                # choose, by validation AUC + ACC.  Only a run that never validated — no best file, no best record — gets
+                # its final weights there, with the TRAIN accuracy of the last log window kept apart from the validation
+                # record (best_auc / best_acc are validation numbers).
+                self.last_train_acc = float(last.get("acc", 0.0))
+                if self.best_auc == 0.0 and self.best_acc == 0.0 and not os.path.exists(self._ckpt_path(best=True)):
+                    self.best_step = self.num_steps
                     self._save_ckpt(self.num_steps, best=True)
                 self._save_ckpt(self.num_steps)
             return last
@@ -193,6 +205,7 @@ class TrainEngine(AbstractEngine):
     def validate(self, step, batches=4):
         """The reference's validate (forgery_engine.py:320-421) without the figure / wandb plumbing: metrics over all
         ranks, best-so-far record (AUC + ACC), best_model.bin / latest_model.bin on rank 0."""
+        self._check_exchange()
         ret = self.test(batches)
         if "AUC" in ret and ret["AUC"] + ret["ACC"] > self.best_auc + self.best_acc:
             self.best_auc, self.best_acc, self.best_step = float(ret["AUC"]), float(ret["ACC"]), int(step)

@@ -125,10 +125,11 @@ def split_out(shape, like):
 # ---------------------------------------------------------------------------------------------
 # GEMM family
 # ---------------------------------------------------------------------------------------------
-# CFG.deterministic (UD_DETERMINISTIC, default on): split-K GEMMs store their partial products into slices of a scratch
+# CFG.deterministic (UD_DETERMINISTIC=1): split-K GEMMs store their partial products into slices of a scratch
 # buffer and add them in ascending order (ud_gemm out_mode 3 + ud_sum_slices) instead of fp32 atomics, so the same inputs
 # give the same result on every run and box (the fp64 accumulators of the fused MBConv path are order-dependent at 1e-16
-# only).  CFG.deterministic = False: fp32 atomics — one launch less per split GEMM, last-bit run-to-run variation.
+# only).  Default (False): fp32 atomics — one launch less per split GEMM (2.3 ms of the 35.8 ms deterministic bs-32 step),
+# last-bit run-to-run variation.
 _SLICE_WS = {}
 
 

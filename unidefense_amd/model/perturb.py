@@ -32,9 +32,10 @@ def random_noise(t, mean=0.0, std=1e-4):
 
 
 def random_blur(t, kernel_size=5):
-    """torchvision.transforms.functional.gaussian_blur(t, (5,5)) — torchvision is absent from this image, so
-    this follows its documented rule: sigma = 0.3*((k-1)*0.5 - 1) + 0.8, reflect padding, separable kernel.
-    (Parity for this one perturbation is UNPINNED)"""
+    """torchvision.transforms.functional.gaussian_blur(t, (5,5)) (model/modules.py:15-16).  torchvision is a third-party
+    dependency absent from the reference tree and from this image; its published algorithm — sigma = 0.3*((k-1)*0.5 - 1)
+    + 0.8, normalised exp(-x^2 / 2 sigma^2) taps, reflect padding, one depthwise 5x5 conv = two separable passes — is what
+    oracle/perturb.py restates (three independent forms, tests/test_c_perturb.py) and what this kernel is held to."""
     assert kernel_size == 5
     sigma = 0.3 * ((kernel_size - 1) * 0.5 - 1) + 0.8
     xs = np.linspace(-2.0, 2.0, 5)

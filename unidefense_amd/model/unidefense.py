@@ -286,7 +286,8 @@ class UniDefenseModelEb4(nn.Module):
         # converted by torch.nn.SyncBatchNorm.convert_sync_batchnorm (engine/forgery_engine.py:142)
         group = self._sync_group(bn)
         return T.batchnorm_act(tape, x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                               bn.momentum if bn.momentum is not None else 0.1, training, act, group)
+                               bn.momentum if bn.momentum is not None else 0.1, training, act, group,
+                               getattr(self, "_bn_exchange", None))
 
     def _mbconv(self, tape, x, blk, keep, keep_prob):
         """MBConvBlock.forward (model/efficientnet/model.py:94-135)."""

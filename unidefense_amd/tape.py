@@ -339,28 +339,35 @@ def sync_batch_stats(mean_l, var_l, eps, group):
     return mean.view(1, Cc).contiguous(), var.view(1, Cc), torch.rsqrt(var + eps).view(1, Cc).contiguous()
 
 
-def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentum, training, act, sync_group=None):
+def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentum, training, act, sync_group=None,
+                  exchange=None):
     """nn.BatchNorm2d/1d (+ MemoryEfficientSwish when act=1) on pixel-major x[..., C]
     (model/efficientnet/model.py:109-114,126; utils.py:66-82).  With sync_group: SyncBatchNorm semantics
-    (statistics over the batches of all ranks; engine/forgery_engine.py:142)."""
+    (statistics over the batches of all ranks; engine/forgery_engine.py:142, ocim_engine.py:130-133) — the fp64 sums
+    (sum x, sum x^2; sum dz, sum dz xhat in the backward) travel through `exchange` (engine.parallel.BnExchange: one
+    small kernel over peer-mapped mailboxes) when given, else through one dist.all_reduce each way."""
     Cc = x.shape[-1]
     x2 = x.view(-1, Cc)
     R = x2.shape[0]
-    world, synced = 1, False
+    synced = False
     if training and sync_group is not None:
         import torch.distributed as dist
-        world = dist.get_world_size(sync_group)
-        synced = world > 1 or cfg.force_collectives
+        synced = dist.get_world_size(sync_group) > 1 or cfg.force_collectives
+    if synced and Cc % 4 == 0:
+        return _syncbn_act(tape, x, x2, R, Cc, weight, bias, running_mean, running_var, eps, momentum, act, sync_group,
+                           exchange)
     if synced:
-        # 3 launches + 1 collective: local (mean, var) written straight into the all_gather payload, then one
-        # kernel folds the world's statistics (same formula as sync_batch_stats above) and updates the running ones
+        # channel counts the column kernels do not take (never in the reference's models): (mean, var) all_gather form
+        world = dist.get_world_size(sync_group)
         mv = K.norm_stats_local(x2, 1, R, eps)                               # [2, 1, C]
         gathered = torch.empty((world, 2, Cc), dtype=mv.dtype, device=mv.device)
         dist.all_gather_into_tensor(gathered.view(-1), mv.view(-1), group=sync_group)
         mean, invstd = K.syncbn_combine(gathered, world, Cc, R, eps, momentum, running_mean, running_var)
     elif training:
+        world = 1
         mean, invstd = K.norm_stats(x2, 1, R, eps, momentum, running_mean, running_var)
     else:
+        world = 1
         mean = running_mean.view(1, Cc)
         invstd = torch.rsqrt(running_var + eps).view(1, Cc)
     y = K.norm_apply(x2, 1, R, mean, invstd, weight, bias, act).view(x.shape)
@@ -382,6 +389,39 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
                                       1.0 / float(R * world), act)
             else:
                 dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
+            tape.add_grad(x, dx.view(x.shape))
+            tape.add_param_grad(weight, dg)
+            if bias.requires_grad:
+                tape.add_param_grad(bias, db)
+        tape.record(bwd)
+    return y
+
+
+def _syncbn_act(tape, x, x2, R, Cc, weight, bias, running_mean, running_var, eps, momentum, act, sync_group, exchange):
+    """SyncBatchNorm of the operator path (attention, head, the ResNet models) on the deferred-BatchNorm kernels of the
+    fused path: fp64 column sums -> summed over the ranks in place (DataParallelCtx.reduce: BnExchange's mailbox kernel or
+    one all_reduce) -> one apply pass that also moves the running statistics; the backward sums the same way.  Every rank
+    must hold the same number of rows (the count is R * world; engine/data.py pads the shards like DistributedSampler)."""
+    dp = DataParallelCtx(sync_group, exchange)
+    acc = K.zeros64(2 * Cc, x)
+    K.colstats(x2, acc)
+    dp.reduce(acc)
+    bn = K.DeferredBN(acc, Cc, R * dp.world, weight, bias, eps, act, momentum, running_mean, running_var)
+    y = K.bn_apply(x2, bn, 1, R, update=True).view(x.shape)
+    if act == 2 and tape is not None and tape.kinks is not None:
+        tape.kinks[id(weight)] = y
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dy2 = dy.reshape(-1, Cc)
+            if not dy2.is_contiguous():
+                dy2 = dy2.contiguous()
+            sb = K.zeros64(2 * Cc, x)
+            K.normbwd_sums(x2, dy2, None, 1.0, bn, False, 1, R, sb)
+            loc = dp.reduce(sb, keep_local=True)
+            dx, dg, db = K.normbwd_apply(x2, dy2, None, 1.0, bn, False, 1, R, sb, loc, want_dbeta=bias.requires_grad)
             tape.add_grad(x, dx.view(x.shape))
             tape.add_param_grad(weight, dg)
             if bias.requires_grad:
