@@ -432,6 +432,27 @@ int ud_adamw_multi(const void* table, const void* chunk_map, int n_chunks, const
                    double beta1, double beta2, double eps, int amsgrad, int maximize, const float* grad_scale,
                    const float* found_inf, const int* step_in, int* step_out, ud_stream_t stream);
 
+/* ---- LDS-tiled depthwise conv, stride 1 (csrc/dwtile.hip) -----------------------------------------------------------
+ * The depthwise k x k conv of MBConvBlock.forward (model/efficientnet/model.py:112-115; SFConv's spatial branch
+ * exp.py:49-51) with a halo tile of 32 channels staged in LDS once per workgroup, act(bn_in(src)) applied while staging
+ * (the activated tensor never exists in HBM).  out(oh, ow) = sum_{i,j} src'(oh + i - P_t, ow + j - P_l) * w[tap(i, j)],
+ * src' = act(bn_in(src)) (bn_in NULL: src), zero outside the image; flip = 0: tap = i*K + j (forward, P = the conv's
+ * pads); flip = 1: tap = K*K-1 - (i*K + j) with P = K-1 - pad: the data gradient over dy.  wt: tap-major [K*K][C].
+ * epi 0: store.  epi 1: also s1 += sum out, s2 += sum out^2 per channel (BN1 statistics of a plain depthwise block).
+ * epi 2: out = gate(gate_alpha, gate_mode) * conv [+ add]; with bn_out: out *= act'(bn_out(xbn)) and s1 += sum out,
+ * s2 += sum out * xhat (the BatchNorm backward sums).  ws: ud_dwtile_ws_doubles doubles when sums are taken. */
+long ud_dwtile_ws_doubles(int N, int Ho, int Wo, int C);
+int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* out, int N, int Hs, int Ws, int C, int Ho,
+              int Wo, int K, int P_t, int P_l, int flip, const float* gate_alpha, int gate_mode, const void* add,
+              const void* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2, double* ws, int f16,
+              ud_stream_t stream);
+/* weight gradient dwt[C][K*K] = gate * sum_pixels act(bn_in(src))(oh + i - P_t, ow + j - P_l) * dy(oh, ow);
+ * part: ud_dwtile_wgrad_part_rows(N, Ho, Wo) rows of K*K*C floats */
+long ud_dwtile_wgrad_part_rows(int N, int Ho, int Wo);
+int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, const float* gate_alpha, int gate_mode,
+                    float* dwt, float* part, long part_rows, int N, int Hs, int Ws, int C, int Ho, int Wo, int K, int P_t,
+                    int P_l, int f16, ud_stream_t stream);
+
 /* ---- large real 2-D FFT of image planes (csrc/fft_large.hip), S in {128, 256, 320} ------------------------------------
  * torch.fft.rfft2 on [N,3,S,S] images: the frequency reconstruction loss (model/unidefense.py:246-253; ResNet variants
  * :421-431, :615-625) and FrequencyStyleTransfer (model/modules.py:35-55), with their autograd adjoint.

@@ -397,3 +397,70 @@ def test_half_operand_gemms(M, N, Kd):
     # weight gradient dY^T @ A: fp32 result
     dw = K.gemm_tn(dy, a)
     assert dw.dtype == torch.float32 and _rel(dw.double(), dy.double().t() @ a.double()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ LDS-tiled depthwise
+@pytest.mark.parametrize("N,H,W,Cc,k", [(2, 8, 8, 40, 5), (3, 8, 8, 24, 3), (2, 16, 16, 48, 5), (2, 16, 16, 36, 3),
+                                        (1, 32, 32, 24, 5), (2, 64, 64, 8, 3), (2, 19, 23, 12, 5), (1, 9, 40, 68, 3),
+                                        (1, 130, 17, 4, 3)])
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
+def test_tiled_depthwise_kernels(N, H, W, Cc, k, half):
+    """csrc/dwtile.hip (stride 1, 'same' pads): forward with a deferred BatchNorm + swish on its input and the BN1
+    statistics of its output; data gradient with gate, added gradient, act'(bn(x)) and the BatchNorm backward sums; weight
+    gradient with the deferred BatchNorm on the staged input — against autograd in float64 at whole-image, multi-tile and
+    ragged maps, both storage types (half: inputs are fp16-representable, results within one rounding)."""
+    import torch.nn.functional as F
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N * 1000 + H + Cc + k)
+    pad = (k - 1) // 2
+    st = torch.float16 if half else torch.float32
+    tol = 2e-3 if half else 2e-5
+
+    def rnd(*s, scale=1.0):
+        v = torch.randn(*s, generator=g) * scale
+        return v.half().float() if half else v
+    x = rnd(N, H, W, Cc)
+    w = torch.randn(Cc, 1, k, k, generator=g) * 0.3
+    gamma, beta = 1.0 + 0.2 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    dy = rnd(N, H, W, Cc)
+    add = rnd(N, H, W, Cc)
+    alpha = torch.tensor(0.4)
+    # ---- reference (float64)
+    xd = x.double()
+    mean, var = xd.mean((0, 1, 2)), xd.var((0, 1, 2), unbiased=False)
+    xh = (xd - mean) / torch.sqrt(var + 1e-3)
+    z = xh * gamma.double() + beta.double()
+    a = (z * torch.sigmoid(z)).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_ref = F.conv2d(a.permute(0, 3, 1, 2), wd, padding=pad, groups=Cc).permute(0, 2, 3, 1)
+    (y_ref * dy.double()).sum().backward()
+    gate = float(1 - torch.sigmoid(alpha))
+    da_ref = gate * a.grad + add.double()
+    sg = torch.sigmoid(z)
+    dz_ref = da_ref * (sg * (1 + z * (1 - sg)))
+    # ---- device
+    xg, dyg, addg = x.to(dev, st), dy.to(dev, st), add.to(dev, st)
+    wt = w.view(Cc, k * k).t().contiguous().to(dev)
+    acc = K.zeros64(2 * Cc, xg)
+    K.colstats(xg.view(-1, Cc), acc)
+    bn = K.DeferredBN(acc, Cc, N * H * W, gamma.to(dev), beta.to(dev), 1e-3, 1)
+    stats = K.zeros64(2 * Cc, xg)
+    y = K.dwtile_fwd(xg, wt, k, pad, pad, H, W, bn=bn, stats=stats)
+    assert y.dtype == st and _rel(y, y_ref) < tol
+    yd = y.double().cpu()
+    assert _rel(stats[:Cc], yd.sum((0, 1, 2))) < 1e-9 and _rel(stats[Cc:], (yd * yd).sum((0, 1, 2))) < 1e-9
+    y_plain = K.dwtile_fwd(xg, wt, k, pad, pad, H, W)
+    assert _rel(y_plain, F.conv2d(xd.permute(0, 3, 1, 2), wd.detach(), padding=pad, groups=Cc).permute(0, 2, 3, 1)) < tol
+    sacc = K.zeros64(2 * Cc, xg)
+    dz = K.dwtile_bwd_data(dyg, wt, k, pad, pad, H, W, alpha.to(dev), 2, addg, xg, bn, sacc)
+    assert _rel(dz, dz_ref) < tol
+    dzd = dz.double().cpu()
+    stol = 3e-3 if half else 2e-5
+    assert _rel(sacc[:Cc], dz_ref.sum((0, 1, 2))) < stol and _rel(sacc[Cc:], (dz_ref * xh).sum((0, 1, 2))) < stol
+    assert _rel(sacc[:Cc], dzd.sum((0, 1, 2))) < 1e-6            # the sums are those of the stored values
+    da = K.dwtile_bwd_data(dyg, wt, k, pad, pad, H, W, alpha.to(dev), 2, addg)
+    assert _rel(da, da_ref) < tol
+    dw = K.dwtile_bwd_weight(xg, dyg, k, pad, pad, bn=bn, gate_alpha=alpha.to(dev), gate_mode=2)
+    assert _rel(dw.view(Cc, k, k), gate * wd.grad.view(Cc, k, k)) < (1e-3 if half else 2e-5)

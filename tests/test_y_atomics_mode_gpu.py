@@ -25,7 +25,7 @@ def test_atomics_mode_equals_default_mode_within_conditioning():
     with override(deterministic=False):
         l_a1, o_a1, f_a1, g_a1, _, _, _ = _run(dev, True, 0.0, 4, 11, False)
         l_a2, o_a2, f_a2, g_a2, _, _, _ = _run(dev, True, 0.0, 4, 11, False)
-    assert within("loss: atomics vs ordered", _rel(l_a1, l_det), 1e-6)
+    assert within("loss: atomics vs ordered", _rel(l_a1, l_det), 1e-5)       # observed 4e-7 .. 1.1e-6, run to run
     for k in ("cls_out", "rec"):
         assert within(f"{k}: atomics vs ordered", _rel(o_a1[k], o_det[k]), 1e-4)      # 1/10 of the 1e-3 parity bar
     worst_f = max(_rel(f_a1[k], f_det[k]) for k in f_det)

@@ -1,0 +1,454 @@
+// LDS-tiled depthwise k x k convolution, stride 1 (k = 3, 5), on pixel-major [N][H][W][C] activations: forward, data
+// gradient and weight gradient of the spatial branch of SFConv2dStaticSamePadding.forward (model/efficientnet/exp.py:49-51)
+// and of the plain depthwise Conv2dStaticSamePadding (model/efficientnet/utils.py:277-280) inside MBConvBlock.forward
+// (model/efficientnet/model.py:112-115).
+//
+// Why tiles: the strip kernels of dwconv.hip / fused.hip keep one (pixel strip, channel quad) per thread and re-read the
+// k x k window through L1 / L2 — every input element is fetched k * (strip + k - 1) / strip times, the 25 taps of a 5 x 5
+// window are re-loaded per strip row, and a deferred BatchNorm + swish on the input would be re-evaluated per tap (which
+// is why the unfused path MATERIALISES swish(bn0(e)) for the plain blocks).  Here a workgroup stages a (TH + k - 1) x
+// (TW + k - 1) halo tile of 32 channels in LDS ONCE — applying act(bn(x)) while staging, so the activated tensor never
+// exists in HBM — and every thread (channel quad, strip of SW output columns) slides its window over LDS:
+//   * forward      out = conv(act(bn(src)))                      [+ per-channel sum / sum of squares of out: BN1 statistics]
+//   * data grad    da  = gate * conv_flipped(dy) [+ add];  dz = da * act'(bn(x))   [+ BatchNorm backward sums of dz]
+//   * weight grad  dw[tap][c] = sum_pixels act(bn(src))[.. + tap] * dy           (fp32 partials per workgroup -> finalize)
+// Layout: 256 threads = 8 channel quads (32 channels = 128 contiguous bytes per pixel) x 32 pixel-threads; LDS holds fp32
+// whatever the storage type; the padded row pitch (odd number of pixels) keeps the 16 lanes of a ds_read_b128 phase — two
+// neighbouring rows x 8 quads — on distinct banks.  HBM-bound for k = 3; k = 5 (25 FMAs per element) is VALU / LDS-bound at
+// ~60 % of the HBM roofline.
+#include "bnref.h"
+
+namespace {
+
+constexpr int CQ = 8;                      // channel quads per workgroup
+constexpr int PTH = NT / CQ;               // pixel-threads per workgroup (32)
+
+struct TileGeom {
+    int N, Hs, Ws, C4, Ho, Wo;             // source / output extents (stride 1)
+    int P_t, P_l;                          // out(oh, ow) reads src(oh + i - P_t, ow + j - P_l), i, j in [0, K)
+    int flip;                              // 1: tap of (i, j) is (K-1-i, K-1-j) (data gradient)
+    int tiles_h, tiles_w;
+};
+
+// tile shape from the strip width: SW = 8 -> 16 x 16, SW = 4 -> 16 x 8, SW = 2 -> 8 x 8 outputs (32 strips each)
+template <int SW> struct TileShape {
+    static constexpr int TW_ = SW == 8 ? 16 : 8;
+    static constexpr int TH_ = PTH * SW / TW_;
+    static constexpr int SPR = TW_ / SW;               // strips per tile row
+};
+
+template <int K, int SW> struct Lds {
+    using S = TileShape<SW>;
+    static constexpr int ROWS = S::TH_ + K - 1;
+    static constexpr int COLS = S::TW_ + K - 1;
+    static constexpr int PITCH = (COLS | 1);           // pixels per LDS row, odd: rows r and r + 1 differ by 128 B mod 256 B
+    static constexpr int TILE_Q = ROWS * PITCH * CQ;   // f32x4 slots of the halo tile
+    static constexpr int W_Q = K * K * CQ;             // f32x4 slots of the tap table
+};
+
+// stage act(bn(src)) of the halo tile (zero outside the image) and the workgroup's taps
+template <typename T, int K, int SW>
+__device__ __forceinline__ void stage_tile(const TileGeom& g, const T* __restrict__ src, const ud_bn_ref& bn, bool has_bn,
+                                           const Bn4& cb, int n, int oh0, int ow0, int cq0, f32x4* tile) {
+    using L = Lds<K, SW>;
+    const In4<T> s4{src};
+    const int cq = threadIdx.x % CQ;
+    const bool cok = cq0 + cq < g.C4;
+    for (int p = threadIdx.x / CQ; p < L::ROWS * L::COLS; p += PTH) {
+        const int r = p / L::COLS, c = p % L::COLS;
+        const int ih = oh0 + r - g.P_t, iw = ow0 + c - g.P_l;
+        f32x4 v = {0, 0, 0, 0};
+        if (cok && ih >= 0 && ih < g.Hs && iw >= 0 && iw < g.Ws) {
+            v = s4[(((long)n * g.Hs + ih) * g.Ws + iw) * g.C4 + cq0 + cq];
+            if (has_bn) v = bn_apply(v, cb, bn.act);
+        }
+        tile[(r * L::PITCH + c) * CQ + cq] = v;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void stage_taps(const float* __restrict__ wt, int C4, int cq0, int flip, f32x4* taps) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
+    for (int i = threadIdx.x; i < K * K * CQ; i += NT) {
+        const int tap = i / CQ, cq = i % CQ;
+        const int src_tap = flip ? (K * K - 1 - tap) : tap;          // (K-1-i) * K + (K-1-j) = K*K - 1 - (i * K + j)
+        taps[i] = (cq0 + cq < C4) ? w4[(long)src_tap * C4 + cq0 + cq] : f32x4{0, 0, 0, 0};
+    }
+}
+
+// EPI 0: plain store.  EPI 1: + sum / sum of squares of the stored result (forward statistics).
+// EPI 2: data gradient: da = gate * acc [+ add]; with a BatchNorm behind it (has_bn_out): dz = da * act'(bn(x)), sums of dz
+//        and dz * xhat.
+template <typename T, int K, int SW, int EPI>
+__global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in, int has_bn_in,
+                                                     const float* __restrict__ wt, T* __restrict__ out,
+                                                     const float* __restrict__ gate_alpha, int gate_mode,
+                                                     const T* __restrict__ add, const T* __restrict__ xbn,
+                                                     ud_bn_ref bn_out, int has_bn_out, double* __restrict__ part) {
+    using L = Lds<K, SW>;
+    using S = TileShape<SW>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* tile = reinterpret_cast<f32x4*>(smem);
+    f32x4* taps = tile + L::TILE_Q;
+    const int cq = threadIdx.x % CQ, p = threadIdx.x / CQ;
+    const int cq0 = blockIdx.y * CQ;
+    const int c4 = cq0 + cq;
+    const bool cok = c4 < g.C4;
+    int t = blockIdx.x;
+    const int tw_i = t % g.tiles_w;
+    t /= g.tiles_w;
+    const int th_i = t % g.tiles_h, n = t / g.tiles_h;
+    const int oh0 = th_i * S::TH_, ow0 = tw_i * S::TW_;
+    Bn4 cbi;
+    if (has_bn_in && cok) cbi = bn_load(bn_in, 0, g.C4, c4, blockIdx.x == 0 && p == 0);
+    stage_tile<T, K, SW>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
+    stage_taps<K>(wt, g.C4, cq0, g.flip, taps);
+    __syncthreads();
+
+    // strip of this thread: row p % TH, columns (p / TH) * SW ..   (lanes 0-7 / 8-15 of a read phase: rows r, r + 1)
+    const int row = p % S::TH_, col0 = (p / S::TH_) * SW;
+    f32x4 acc[SW];
+#pragma unroll
+    for (int i = 0; i < SW; ++i) acc[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const f32x4* rowp = tile + ((row + i) * L::PITCH + col0) * CQ + cq;
+        f32x4 in[SW + K - 1], w[K];
+#pragma unroll
+        for (int j = 0; j < SW + K - 1; ++j) in[j] = rowp[j * CQ];
+#pragma unroll
+        for (int j = 0; j < K; ++j) w[j] = taps[(i * K + j) * CQ + cq];
+#pragma unroll
+        for (int o = 0; o < SW; ++o)
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[o] += in[o + j] * w[j];
+    }
+
+    const int oh = oh0 + row;
+    const Out4<T> o4{out};
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cok && oh < g.Ho) {
+        const In4<T> add4{add}, x4{xbn};
+        Bn4 cbo;
+        float gs = 1.f;
+        if (EPI == 2) {
+            gs = gate_factor(gate_alpha, gate_mode);
+            if (has_bn_out) cbo = bn_load(bn_out, 0, g.C4, c4, false);
+        }
+#pragma unroll
+        for (int o = 0; o < SW; ++o) {
+            const int ow = ow0 + col0 + o;
+            if (ow >= g.Wo) continue;
+            const long idx = (((long)n * g.Ho + oh) * g.Wo + ow) * g.C4 + c4;
+            f32x4 r = acc[o];
+            if (EPI == 2) {
+                r = r * gs;
+                if (add) r += add4[idx];
+                if (has_bn_out) {
+                    const f32x4 a = x4[idx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (a[e] - cbo.mu[e]) * cbo.is[e];
+                        float d = r[e];
+                        if (bn_out.act) d *= ud_act_grad_fast(cbo.ga[e] * xh + cbo.be[e], bn_out.act);
+                        d = ud_rounded<T>(d);
+                        r[e] = d;
+                        v[e] += (double)d;
+                        v[4 + e] += (double)d * (double)xh;
+                    }
+                }
+            } else if (EPI == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double d = (double)ud_rounded<T>(r[e]);
+                    v[e] += d;
+                    v[4 + e] += d * d;
+                }
+            }
+            o4.st(idx, r);
+        }
+    }
+    if (EPI == 1 || (EPI == 2 && has_bn_out)) {
+        // fold the 32 pixel-threads of every channel quad: LDS (the tile is dead), then one fp64 partial per (tile, channel)
+        __syncthreads();
+        double* sm = reinterpret_cast<double*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm[(e * PTH + p) * CQ + cq] = v[e];
+        __syncthreads();
+        if (threadIdx.x < 8 * CQ) {
+            const int e = threadIdx.x / CQ, q = threadIdx.x % CQ;
+            double s = 0.0;
+            for (int k = 0; k < PTH; ++k) s += sm[(e * PTH + k) * CQ + q];
+            sm[(8 * PTH) * CQ + threadIdx.x] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 * CQ) {
+            // part[q][tile][C]: quantity (0: first sum, 1: second), tile = blockIdx.x, channel
+            const int e = threadIdx.x / CQ, q = threadIdx.x % CQ;
+            if (cq0 + q < g.C4) {
+                const long C = (long)g.C4 * 4, P = gridDim.x;
+                const int quantity = e / 4, lane_e = e % 4;
+                part[((long)quantity * P + blockIdx.x) * C + (cq0 + q) * 4 + lane_e] = sm[(8 * PTH) * CQ + threadIdx.x];
+            }
+        }
+    }
+}
+
+// Weight gradient: acc[tap] += src_tile[.. + tap] * dy over the workgroup's tiles (images n0, n0 + nstep, ...), folded over
+// its 32 pixel-threads, one fp32 partial row [K*K][C] per workgroup for dw_tile_wgrad_finalize.
+template <typename T, int K, int SW>
+__global__ __launch_bounds__(NT) void dw_tile_wgrad_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in,
+                                                           int has_bn_in, const T* __restrict__ dy, int n_step,
+                                                           float* __restrict__ part) {
+    using L = Lds<K, SW>;
+    using S = TileShape<SW>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* tile = reinterpret_cast<f32x4*>(smem);
+    const int cq = threadIdx.x % CQ, p = threadIdx.x / CQ;
+    const int cq0 = blockIdx.y * CQ;
+    const int c4 = cq0 + cq;
+    const bool cok = c4 < g.C4;
+    const int tiles = g.tiles_h * g.tiles_w;
+    const int tsp = blockIdx.x % tiles, nb = blockIdx.x / tiles;        // spatial tile, first image
+    const int oh0 = (tsp / g.tiles_w) * S::TH_, ow0 = (tsp % g.tiles_w) * S::TW_;
+    const int row = p % S::TH_, col0 = (p / S::TH_) * SW;
+    const In4<T> dy4{dy};
+    Bn4 cbi;
+    if (has_bn_in && cok) cbi = bn_load(bn_in, 0, g.C4, c4, false);
+    f32x4 acc[K][K];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int n = nb; n < g.N; n += n_step) {
+        __syncthreads();                                       // previous tile fully consumed
+        stage_tile<T, K, SW>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
+        f32x4 gy[SW];
+        const int oh = oh0 + row;
+#pragma unroll
+        for (int o = 0; o < SW; ++o) {
+            const int ow = ow0 + col0 + o;
+            gy[o] = (cok && oh < g.Ho && ow < g.Wo) ? dy4[(((long)n * g.Ho + oh) * g.Wo + ow) * g.C4 + c4] : f32x4{0, 0, 0, 0};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const f32x4* rowp = tile + ((row + i) * L::PITCH + col0) * CQ + cq;
+            f32x4 in[SW + K - 1];
+#pragma unroll
+            for (int j = 0; j < SW + K - 1; ++j) in[j] = rowp[j * CQ];
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int o = 0; o < SW; ++o) acc[i][j] += in[o + j] * gy[o];
+        }
+    }
+    // fold the 8 pixel-threads of a wave (lane bits 3..5), then the 4 waves through LDS
+    __syncthreads();
+    float* sm = reinterpret_cast<float*>(smem);                 // [4 waves][K*K][CQ][4]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            f32x4 a = acc[i][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = a[e];
+                x += __shfl_xor(x, 8, 64);
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                a[e] = x;
+            }
+            if (lane < CQ) reinterpret_cast<f32x4*>(sm)[(wave * K * K + i * K + j) * CQ + lane] = a;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K * CQ * 4; i += NT) {
+        const int e = i % 4, q = (i / 4) % CQ, tap = i / (4 * CQ);
+        if (cq0 + q >= g.C4) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) s += sm[((w * K * K + tap) * CQ + q) * 4 + e];
+        part[((long)blockIdx.x * K * K + tap) * ((long)g.C4 * 4) + (cq0 + q) * 4 + e] = s;
+    }
+}
+
+// dw[c][tap] = gate * sum_p part[p][tap][c]   (fp64 accumulation; the parameter's own layout [C][K*K])
+__global__ __launch_bounds__(NT) void dw_tile_wgrad_finalize(int nparts, int KK, int C, const float* __restrict__ part,
+                                                             const float* __restrict__ gate_alpha, int gate_mode,
+                                                             float* __restrict__ dw) {
+    __shared__ double sm[16][16][4];
+    const int KKC = KK * C;
+    const int lane = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = (blockIdx.x * 16 + lane) * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (i < KKC) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(part + i);
+        const long step = (long)KKC / 4;
+        for (int p = sl; p < nparts; p += 16) {
+            const f32x4 v = p4[(long)p * step];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += (double)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[sl][lane][e] = a[e];
+    __syncthreads();
+    if (sl < 4 && i < KKC) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][lane][sl];
+        const int o = i + sl, tap = o / C, c = o % C;
+        dw[(long)c * KK + tap] = (float)(t * (double)gate_factor(gate_alpha, gate_mode));
+    }
+}
+
+inline bool tile_args_ok(int N, int Hs, int Ws, int C, int Ho, int Wo, int K) {
+    return N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0 && C >= 4 && C % 4 == 0 && (K == 3 || K == 5);
+}
+
+// strip width: the widest whose tile is not mostly padding on this map
+inline int pick_sw(int Ho, int Wo) {
+    if (Wo > 8 && Ho > 8) return 8;        // 16 x 16 tiles
+    if (Ho > 8) return 4;                  // 16 x 8
+    return 2;                              // 8 x 8
+}
+
+template <int SW> inline void tile_counts(int Ho, int Wo, int& th, int& tw) {
+    th = ud_cdiv(Ho, TileShape<SW>::TH_);
+    tw = ud_cdiv(Wo, TileShape<SW>::TW_);
+}
+
+template <typename T, int K, int SW>
+int launch_tile(TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* wt, T* out, const float* gate_alpha,
+                int gate_mode, const T* add, const T* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2,
+                double* ws, hipStream_t s) {
+    using L = Lds<K, SW>;
+    tile_counts<SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
+    const long nt = (long)g.N * g.tiles_h * g.tiles_w;
+    if (nt > 0x7fffffffL) return UD_EINVAL;
+    dim3 grid((unsigned)nt, (unsigned)ud_cdiv(g.C4, CQ));
+    size_t lds = (size_t)(L::TILE_Q + L::W_Q) * 16;
+    const size_t fold = (size_t)(8 * PTH * CQ + 8 * CQ) * 8;
+    if (lds < fold) lds = fold;
+    ud_bn_ref none{};
+    const ud_bn_ref& bi = bn_in ? *bn_in : none;
+    const ud_bn_ref& bo = bn_out ? *bn_out : none;
+    const bool sums = epi == 1 || (epi == 2 && bn_out);
+#define UD_TILE(E)                                                                                                    \
+    hipLaunchKernelGGL((dw_tile_kernel<T, K, SW, E>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, wt, out,     \
+                       gate_alpha, gate_mode, add, xbn, bo, bn_out ? 1 : 0, sums ? ws : nullptr)
+    if (epi == 0) UD_TILE(0);
+    else if (epi == 1) UD_TILE(1);
+    else UD_TILE(2);
+#undef UD_TILE
+    UD_LAUNCH_CHECK();
+    if (sums) {
+        const int C = g.C4 * 4;
+        hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv(C, 8)), dim3(NT), 0, s, 2, 1, C, (int)nt, ws, s1, s2);
+        UD_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+template <typename T>
+int dispatch_tile(int K, TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* wt, T* out, const float* gate_alpha,
+                  int gate_mode, const T* add, const T* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2,
+                  double* ws, hipStream_t s) {
+    const int sw = pick_sw(g.Ho, g.Wo);
+#define UD_GO(KK, SS) return launch_tile<T, KK, SS>(g, src, bn_in, wt, out, gate_alpha, gate_mode, add, xbn, bn_out, epi, s1, s2, ws, s)
+    if (K == 3) { if (sw == 8) UD_GO(3, 8); if (sw == 4) UD_GO(3, 4); UD_GO(3, 2); }
+    if (sw == 8) UD_GO(5, 8);
+    if (sw == 4) UD_GO(5, 4);
+    UD_GO(5, 2);
+#undef UD_GO
+}
+
+template <typename T, int K, int SW>
+int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, const float* gate_alpha, int gate_mode,
+                 float* part, long part_rows, float* dw, hipStream_t s) {
+    using L = Lds<K, SW>;
+    tile_counts<SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
+    const int tiles = g.tiles_h * g.tiles_w;
+    const int cblocks = ud_cdiv(g.C4, CQ);
+    // enough workgroups to fill the chip ~4 times over; every workgroup folds N / n_step images before it writes a partial
+    int n_step = (int)((1024 + (long)tiles * cblocks - 1) / ((long)tiles * cblocks));
+    if (n_step < 1) n_step = 1;
+    if (n_step > g.N) n_step = g.N;
+    const long nparts = (long)tiles * n_step;
+    if (nparts > part_rows) return UD_EINVAL;
+    size_t lds = (size_t)L::TILE_Q * 16;
+    const size_t fold = (size_t)(NT / 64) * K * K * CQ * 16;
+    if (lds < fold) lds = fold;
+    ud_bn_ref none{};
+    const ud_bn_ref& bi = bn_in ? *bn_in : none;
+    dim3 grid((unsigned)nparts, (unsigned)cblocks);
+    hipLaunchKernelGGL((dw_tile_wgrad_kernel<T, K, SW>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, dy, n_step, part);
+    UD_LAUNCH_CHECK();
+    const int KKC = K * K * g.C4 * 4;
+    hipLaunchKernelGGL(dw_tile_wgrad_finalize, dim3(ud_cdiv(KKC, 64)), dim3(NT), 0, s, (int)nparts, K * K, g.C4 * 4, part,
+                       gate_alpha, gate_mode, dw);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// doubles of scratch for the statistics partials of ud_dwtile (epi 1 / 2): 2 * tiles * C
+long ud_dwtile_ws_doubles(int N, int Ho, int Wo, int C) {
+    if (N < 1 || Ho < 1 || Wo < 1 || C < 4 || C % 4) return UD_EINVAL;
+    const int sw = pick_sw(Ho, Wo);
+    int th, tw;
+    if (sw == 8) tile_counts<8>(Ho, Wo, th, tw);
+    else if (sw == 4) tile_counts<4>(Ho, Wo, th, tw);
+    else tile_counts<2>(Ho, Wo, th, tw);
+    return 2L * N * th * tw * C;
+}
+
+// rows of K*K*C floats the weight-gradient partials may need (upper bound: one per (tile, image))
+long ud_dwtile_wgrad_part_rows(int N, int Ho, int Wo) {
+    if (N < 1 || Ho < 1 || Wo < 1) return UD_EINVAL;
+    const int sw = pick_sw(Ho, Wo);
+    int th, tw;
+    if (sw == 8) tile_counts<8>(Ho, Wo, th, tw);
+    else if (sw == 4) tile_counts<4>(Ho, Wo, th, tw);
+    else tile_counts<2>(Ho, Wo, th, tw);
+    return (long)N * th * tw;
+}
+
+int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* out, int N, int Hs, int Ws, int C, int Ho,
+              int Wo, int K, int P_t, int P_l, int flip, const float* gate_alpha, int gate_mode, const void* add,
+              const void* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2, double* ws, int f16,
+              ud_stream_t stream) {
+    if (!tile_args_ok(N, Hs, Ws, C, Ho, Wo, K) || !src || !wt || !out || epi < 0 || epi > 2) return UD_EINVAL;
+    if (bn_in && bn_in->G != 1) return UD_EINVAL;
+    if (epi != 2 && (add || xbn || bn_out || gate_mode)) return UD_EINVAL;
+    if (bn_out && (!xbn || bn_out->G != 1)) return UD_EINVAL;
+    if ((epi == 1 || bn_out) && (!s1 || !s2 || !ws)) return UD_EINVAL;
+    TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, flip ? 1 : 0, 0, 0};
+    UD_STORAGE_DISPATCH(f16, return dispatch_tile<T>(K, g, (const T*)src, bn_in, wt, (T*)out, gate_alpha, gate_mode,
+                                                      (const T*)add, (const T*)xbn, bn_out, epi, s1, s2, ws,
+                                                      (hipStream_t)stream));
+}
+
+int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, const float* gate_alpha, int gate_mode,
+                    float* dwt, float* part, long part_rows, int N, int Hs, int Ws, int C, int Ho, int Wo, int K, int P_t,
+                    int P_l, int f16, ud_stream_t stream) {
+    if (!tile_args_ok(N, Hs, Ws, C, Ho, Wo, K) || !src || !dy || !dwt || !part || part_rows < 1) return UD_EINVAL;
+    if (bn_in && bn_in->G != 1) return UD_EINVAL;
+    TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, 0, 0, 0};
+    const int sw = pick_sw(Ho, Wo);
+    hipStream_t s = (hipStream_t)stream;
+#define UD_WG(KK, SS)                                                                                                 \
+    UD_STORAGE_DISPATCH(f16, return launch_wgrad<T, KK, SS>(g, (const T*)src, bn_in, (const T*)dy, gate_alpha, gate_mode, \
+                                                            part, part_rows, dwt, s))
+    if (K == 3) { if (sw == 8) UD_WG(3, 8); if (sw == 4) UD_WG(3, 4); UD_WG(3, 2); }
+    if (sw == 8) UD_WG(5, 8);
+    if (sw == 4) UD_WG(5, 4);
+    UD_WG(5, 2);
+#undef UD_WG
+}
+
+}  // extern "C"

@@ -331,7 +331,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8), each with its own 4 MiB L2.  With
+    // tile_cfg bit 8 every XCD gets one CONTIGUOUS range of the (column-major) tile order instead of every eighth tile, so
+    // that the A / B panels its workgroups share are fetched into ONE L2 (a bijection for any tile count: no padding).
+    int bt = blockIdx.x;
+    if (d.tile_cfg & 0x100) {
+        const int T = tiles_m * tiles_n, q = T >> 3, r = T & 7, x = bt & 7;
+        bt = x * q + (x < r ? x : r) + (bt >> 3);
+    }
+    const int tile_m = bt % tiles_m, tile_n = bt / tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.y, bz = blockIdx.z;
 
@@ -515,7 +523,8 @@ constexpr XCfg kX[NXCFG] = {{128, 128, 1.00}, {128, 64, 1.20}, {64, 128, 1.20}, 
 // tile configuration of a descriptor: d.tile_cfg (1 + index, set by the caller's per-shape tuner) > UD_GEMM_X3_CFG > the
 // cost model over the first three (the 64x64 tile is only ever chosen by measurement)
 int pick_cfg(const ud_gemm_desc& d) {
-    if (d.tile_cfg >= 1 && d.tile_cfg <= NXCFG) return d.tile_cfg - 1;
+    const int want = d.tile_cfg & 0xff;          // bit 8: XCD-contiguous tile order (gemm_x3_kernel)
+    if (want >= 1 && want <= NXCFG) return want - 1;
     static const int forced = [] {
         const char* e = getenv("UD_GEMM_X3_CFG");
         return (e && e[0] >= '0' && e[0] < '0' + NXCFG) ? e[0] - '0' : -1;

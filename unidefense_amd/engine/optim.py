@@ -46,6 +46,7 @@ class HipAdamW(torch.optim.Optimizer):
         self._plan = None
         self._steps = None          # device int32 [2]: ping-pong step counter (a skipped step does not advance it)
         self._cur = 0
+        self._loaded_step = 0       # applied steps of a restored state (load_state_dict)
 
     def _alloc_state(self, dev):
         import ctypes as C
@@ -61,7 +62,6 @@ class HipAdamW(torch.optim.Optimizer):
                 total += (p.numel() + 3) // 4 * 4
         names = ["exp_avg", "exp_avg_sq"] + (["max_exp_avg_sq"] if ams else [])
         flat = {k: torch.zeros(total, dtype=torch.float32, device=dev) for k in names}
-        loaded_step = 0
         for p, off in offs.items():
             st = self.state[p]
             for k in names:
@@ -70,11 +70,9 @@ class HipAdamW(torch.optim.Optimizer):
                 if old is not None:                    # restored by load_state_dict (ours or torch.optim.AdamW's): keep it
                     view.copy_(old.to(device=dev, dtype=torch.float32).view_as(p))
                 st[k] = view
-            if "step" in st:
-                loaded_step = max(loaded_step, int(float(st["step"])))
         self._flat, self._chunk = flat, chunk
-        # applied steps so far (bias corrections continue where the restored run stopped)
-        self._steps = torch.full((2,), loaded_step, dtype=torch.int32, device=dev)
+        # applied steps so far (bias corrections continue where a restored run stopped: load_state_dict)
+        self._steps = torch.full((2,), int(self._loaded_step), dtype=torch.int32, device=dev)
         self._cur = 0
 
     def _plan_stale(self, active):
@@ -97,10 +95,16 @@ class HipAdamW(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
-        """The restored moments are copied into the flat buffers (and the step counter set) by the next step()."""
+        """The restored moments are copied into this optimizer's flat buffers and the step counter is set HERE, not at the
+        next step(): torch hands state tensors over by reference when dtype and device already match, and a source
+        optimizer that is still alive would go on updating them."""
         super().load_state_dict(state_dict)
         self._plan = None
         self._steps = None
+        self._loaded_step = max([int(float(st["step"])) for st in self.state.values() if "step" in st] + [0])
+        params = [p for g in self.param_groups for p in g["params"]]
+        if params and all(p.is_cuda for p in params):
+            self._alloc_state(params[0].device)
 
     def _make_plan(self, active, dev):
         """Static per set of updated tensors: chunk map and pointer table on the device."""

@@ -153,7 +153,7 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
     d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
-    d.tile_cfg = cfg
+    d.tile_cfg = cfg | (0x100 if _XCD_CONTIGUOUS else 0)
     slices = None
     if CFG.deterministic and out_mode == 2:
         # Cout holds a term to add to (or is a fresh buffer of split_out): result = [Cout +] the splits' partials in
@@ -206,6 +206,7 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
 
 
 _TAIL_SPLIT = True
+_XCD_CONTIGUOUS = False          # ud_gemm_desc.tile_cfg bit 8: each XCD takes a contiguous range of the tile order
 _GEMM_EPILOGUE_STATS = True
 
 
@@ -1549,3 +1550,59 @@ def irfft2_mix(Y, scale, spat, alpha, acc):
     _call("ud_irfft2_mix", _p(Y), _p(y), N, S, Cc, float(scale), 1.0, _p(spat), _p(alpha), _p(fr), _pd(acc),
           _pd(acc, Cc), h, _stream())
     return y, fr
+
+
+# ---------------------------------------------------------------------------------------------
+# LDS-tiled depthwise conv, stride 1 (csrc/dwtile.hip): deferred BatchNorm applied while the halo tile is staged
+# ---------------------------------------------------------------------------------------------
+def _bnp(bn, update=False):
+    return C.byref(bn.ref(update)) if bn is not None else None
+
+
+def dwtile_fwd(x, wt, K, pad_t, pad_l, Ho, Wo, bn=None, stats=None, update=False):
+    """y = dwconv(act(bn(x))) (bn: DeferredBN or None), stride 1; stats: 2C zeroed doubles that receive sum y | sum y^2."""
+    h = _act(x)
+    _chk(wt)
+    N, H, W, Cc = x.shape
+    y = empty((N, Ho, Wo, Cc), x, x.dtype)
+    ws = None
+    if stats is not None:
+        ws = _ws64(x, _call("ud_dwtile_ws_doubles", N, Ho, Wo, Cc))
+    _call("ud_dwtile", _p(x), _bnp(bn, update), _p(wt), _p(y), N, H, W, Cc, Ho, Wo, K, pad_t, pad_l, 0, None, 0, None, None,
+          None, 1 if stats is not None else 0, _pd(stats) if stats is not None else None,
+          _pd(stats, Cc) if stats is not None else None, ws, h, _stream())
+    return y
+
+
+def dwtile_bwd_data(dy, wt, K, pad_t, pad_l, H, W, gate_alpha=None, gate_mode=0, add=None, x=None, bn=None, sacc=None):
+    """da = gate * dwconv_bwd_data(dy) [+ add]; with (x, bn, sacc): dz = da * act'(bn(x)), sacc += BatchNorm backward sums."""
+    h = _act(dy, add, x)
+    _chk(wt)
+    N, Ho, Wo, Cc = dy.shape
+    out = empty((N, H, W, Cc), dy, dy.dtype)
+    ws = None
+    if bn is not None:
+        ws = _ws64(dy, _call("ud_dwtile_ws_doubles", N, H, W, Cc))
+    _call("ud_dwtile", _p(dy), None, _p(wt), _p(out), N, Ho, Wo, Cc, H, W, K, K - 1 - pad_t, K - 1 - pad_l, 1,
+          _p(gate_alpha), int(gate_mode), _p(add), _p(x) if bn is not None else None, _bnp(bn), 2,
+          _pd(sacc) if bn is not None else None, _pd(sacc, Cc) if bn is not None else None, ws, h, _stream())
+    return out
+
+
+_DWTILE_PART = {}
+
+
+def dwtile_bwd_weight(x, dy, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0):
+    """dw[C, K*K] = gate * sum act(bn(x))(window) * dy, stride 1; x: the conv's RAW input when bn is given."""
+    h = _act(x, dy)
+    N, H, W, Cc = x.shape
+    _, Ho, Wo, _ = dy.shape
+    rows = _call("ud_dwtile_wgrad_part_rows", N, Ho, Wo)
+    need = rows * K * K * Cc
+    part = _DWTILE_PART.get(x.device.index)
+    if part is None or part.numel() < need:
+        part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
+    dwt = empty((Cc, K * K), x)
+    _call("ud_dwtile_wgrad", _p(x), _bnp(bn), _p(dy), _p(gate_alpha), int(gate_mode), _p(dwt), _p(part), rows, N, H, W, Cc,
+          Ho, Wo, K, pad_t, pad_l, h, _stream())
+    return dwt
