@@ -4,20 +4,22 @@ stay fp32) against the fp32-accurate path on the same seeded step.
 
 The reference itself never runs this mode (autocast(enabled=False), engine/abstract_engine.py:208,286), so the oracle is the
 fp32 path with a stated tolerance.  fp16 operands carry 11 significant bits (5e-4 per product, averaging over K); through
-32 MBConv blocks at batch 16 (batch statistics over 4 samples make the bottleneck BatchNorm1d ill-conditioned: a uniform 11 % gradient rescale) the observed deviations are ~1e-2 in L2 on outputs.  Bars: outputs 2e-2 in
-relative L2 (1e-1 of the largest entry for single elements); every parameter gradient with a non-negligible norm within 10 % in L2 and cosine
->= 0.99; the gradient of the loss scale 2^10 the engine's GradScaler uses (forgery_engine.py:228) is applied so that fp16
-gradient operands do not underflow."""
+32 MBConv blocks with batch statistics the step amplifies ANY perturbation of that size to ~1e-2 in L2 on the outputs and
+~5 % on the parameter gradients — measured here by the yardstick of the test below (one rounding of the parameters, exact
+arithmetic), which is what the mode is held to.  The loss scale 2^10 the engine's GradScaler uses (forgery_engine.py:228) is
+applied so that fp16 gradient operands do not underflow."""
+import numpy as np
 import pytest
 import torch
 
 from oracle import param_fill
 from tests import oracle_util as ou
+from tests.margins import within
 
 pytestmark = pytest.mark.gpu
 
 
-def _step(dev, path, n=16, half_storage=False, loss_scale=1024.0):
+def _step(dev, path, n=16, half_storage=False, loss_scale=1024.0, round_params=False):
     from unidefense_amd import lib
     from unidefense_amd.loss import LOSSES
     from unidefense_amd.model import load_model
@@ -28,6 +30,12 @@ def _step(dev, path, n=16, half_storage=False, loss_scale=1024.0):
         m = m.to(dev).train()
         m.half_storage = half_storage
         x = param_fill.make_input(n, 256, 21).to(dev)
+        if round_params:
+            # the yardstick: the exact (fp32) step on parameters and inputs perturbed by ONE fp16 rounding each
+            with torch.no_grad():
+                for p_ in m.parameters():
+                    p_.copy_(p_.half().float())
+                x = x.half().float()
         tgt = param_fill.make_labels(n).to(dev)
         rng = ou.make_rng(n, 5, 0.5)
         rng = {k: ({i: v.to(dev) for i, v in val.items()} if isinstance(val, dict) else val.to(dev)) for k, val in rng.items()}
@@ -48,57 +56,75 @@ def _step(dev, path, n=16, half_storage=False, loss_scale=1024.0):
         lib.call("ud_gemm_set_path", 0)
 
 
-@pytest.mark.parametrize("storage", ["fp32", "half"])
-def test_fp16_operand_gemms_track_the_fp32_step(storage):
-    """storage = "half": additionally the MBConv trunk keeps its activations and activation gradients in fp16
-    (model.half_storage; every kernel of tape.mbconv_fused instantiated for _Float16, half-operand GEMM loaders) — the
-    full configs[4] mode.  Each stored tensor adds one rounding of 2^-11 relative, the same size as the operand rounding
-    the fp32-storage mode already makes at every GEMM input: same bars."""
+def _deviation(o, g, o32, g32):
+    """Relative L2 deviation of outputs and of every well-defined parameter gradient from the fp32 step's."""
+    outs = {k: float((o[k] - o32[k]).norm() / o32[k].norm().clamp_min(1e-30)) for k in o32 if k != "loss"}
+    rel = []
+    for k, a in g32.items():
+        na = float(a.norm())
+        # BN2's bias inside a backbone stage has a structurally zero gradient (the next block's BatchNorm removes any per-channel
+        # shift of its input), the scalar gates are single global sums with heavy cancellation (tests/test_z_fused_selfcheck_gpu.py):
+        # what any two evaluations hold there differs by rounding noise amplified without bound
+        if na < 1e-6 or k.endswith("._bn2.bias") or k.endswith("_coef"):
+            continue
+        rel.append(float((g[k] - a).norm()) / na)
+    r = np.array(rel)
+    return outs, {"median": float(np.percentile(r, 50)), "90 %": float(np.percentile(r, 90)), "99 %": float(np.percentile(r, 99)),
+                  "max": float(r.max())}, len(rel)
+
+
+@pytest.fixture(scope="module")
+def fp32_and_yardstick():
+    """The fp32 step at the config's own batch (64) and the YARDSTICK: the same exact step with every parameter and the input
+    rounded to fp16 once — how far one rounding of its data moves this step through the network's own conditioning (batch
+    statistics, 32 blocks of swish / SE gates): outputs 0.9-1.3e-2 in relative L2, parameter gradients 4.7 % at the median."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     dev = torch.device("cuda:0")
-    o32, g32 = _step(dev, 0)
-    o16, g16 = _step(dev, 3, half_storage=storage == "half")
-    errs = {k: float((o16[k] - o32[k]).abs().max() / o32[k].abs().max().clamp_min(1e-30)) for k in o32}
-    rms = {k: float((o16[k] - o32[k]).norm() / o32[k].norm().clamp_min(1e-30)) for k in o32}
-    print("  max-abs deviation / max:", {k: f"{v:.2e}" for k, v in errs.items()})
-    print("  relative L2 deviation  :", {k: f"{v:.2e}" for k, v in rms.items()})
-    for k in o32:
-        # behind BatchNorm1d / InstanceNorm statistics over a batch of 4, single entries of `fac` and single pixels of `rec`
-        # move by several percent of the range while each tensor as a whole stays within 2 % in L2
-        # (half storage adds the roundings of the stored activations: single pixels of `rec` move by up to 12 % of the range)
-        from tests.margins import within
-        ok = [within(f"{k}: relative L2 vs fp32 step", rms[k], 2e-2), within(f"{k}: max-abs / max", errs[k], 1.5e-1 if storage == "half" else 1e-1)]
-        assert all(ok), (k, errs[k], rms[k])
+    o32, g32 = _step(dev, 0, n=64)
+    oy, gy = _step(dev, 0, n=64, round_params=True)
+    return dev, o32, g32, _deviation(oy, gy, o32, g32)
+
+
+@pytest.mark.parametrize("storage", ["fp32", "half"])
+def test_fp16_mode_deviates_like_one_rounding_of_the_parameters(storage, fp32_and_yardstick):
+    """BASELINE configs[4] at its own batch (64 per GPU).  storage = "fp32": fp16 MFMA operands, fp32 accumulation, fp32
+    activations; "half": additionally the MBConv trunk keeps activations and activation gradients in fp16 (every kernel of
+    tape.mbconv_fused instantiated for _Float16, half-operand GEMM loaders) — the full mode.
+    The reference has no such mode, so the bar is the step's own conditioning: each deviation from the fp32 step (outputs in
+    relative L2; median / 90 % / 99 % / max of the per-tensor relative L2 of the ~480 well-defined parameter gradients) must
+    stay within 4 x what ONE fp16 rounding of the parameters and inputs does to the exact step (observed: 0.8 x with fp32
+    storage, 1.1 - 1.5 x with half storage — the fp16 machinery loses nothing beyond the rounding of its data)."""
+    dev, o32, g32, (y_out, y_grad, n_y) = fp32_and_yardstick
+    o16, g16 = _step(dev, 3, n=64, half_storage=storage == "half")
     assert all(torch.isfinite(g).all() for g in g16.values())
-    rel, cos, n_sig = [], [], 0
-    for k, a in g32.items():
-        na = float(a.norm())
-        # BN2's bias inside a backbone stage has a structurally zero gradient (the next block's BatchNorm removes any
-        # per-channel shift of its input): what both paths hold there is rounding noise
-        if na < 1e-6 or k.endswith("._bn2.bias"):
-            continue
-        n_sig += 1
-        b = g16[k]
-        rel.append((float((b - a).norm()) / na, k))
-        cos.append((float((a * b).sum() / (na * float(b.norm()) + 1e-30)), k))
-    rel.sort(reverse=True)
-    cos.sort()
-    print("  worst relative L2:", rel[:5])
-    print("  worst cosine:", cos[:5])
-    import numpy as np
-    r = np.array([x[0] for x in rel if not x[1].endswith("_coef")])
-    c = np.array([x[0] for x in cos if not x[1].endswith("_coef")])
-    print("  relative L2 percentiles 50/90/99/max: %.3g %.3g %.3g %.3g ; cosine min/1%%: %.4f %.4f ; tensors %d" % (
-        np.percentile(r, 50), np.percentile(r, 90), np.percentile(r, 99), r.max(), c.min(), np.percentile(c, 1), n_sig))
-    # Bars (fp16 has 11 significant bits; observed: median 2 %, the dynamic filters' arg-max over channels and the
-    # scalar gates — single global sums with heavy cancellation, excluded above — are the ill-conditioned ends):
-    # Half storage: the outputs move 1.6x as much as with fp32 storage (1.8e-2 vs 1.1e-2 in L2) and so does every gradient,
-    # uniformly (median 7.1 % vs 4.4 %, 90th percentile within 10 % of the median): the deviation enters through the loss
-    # gradient at the head (batch-16 statistics amplify a forward perturbation ~4x), not through lost gradient bits — it
-    # is the same for loss scales 2^10 ... 2^16 and no common rescale removes it (tools/probe_loss_scale.py).
-    med_bar = 1e-1 if storage == "half" else 5e-2
-    ok = [within("gradient relative L2: median", np.percentile(r, 50), med_bar), within("... 90 %", np.percentile(r, 90), 1.5e-1),
-          within("... max", r.max(), 0.6), within("1 - min cosine", 1 - c.min(), 0.15), within("1 - 1 % cosine", 1 - np.percentile(c, 1), 0.05)]
-    assert all(ok)
-    assert n_sig >= 450
+    d_out, d_grad, n_sig = _deviation(o16, g16, o32, g32)
+    print("  outputs   (mode / yardstick):", {k: f"{d_out[k]:.2e} / {y_out[k]:.2e}" for k in d_out})
+    print("  gradients (mode / yardstick):", {k: f"{d_grad[k]:.3g} / {y_grad[k]:.3g}" for k in d_grad}, f"over {n_sig} tensors")
+    ok = [within(f"{k}: deviation / (4 x yardstick)", d_out[k] / (4.0 * y_out[k]), 1.0) for k in d_out]
+    ok += [within(f"gradient relative L2 {k}: deviation / (4 x yardstick)", d_grad[k] / (4.0 * y_grad[k]), 1.0) for k in d_grad]
+    assert all(ok) and n_sig >= 440 and n_sig == n_y
+    assert abs(float(o16["loss"] - o32["loss"])) <= 1e-2 * abs(float(o32["loss"]))
+
+
+def test_half_step_backward_is_linear_in_the_loss_scale():
+    """The half-storage backward is linear in the incoming gradient: the loss scaled by 2^10 (where forgery_engine.py:228
+    starts its GradScaler) and by 2^12 gives the same gradients after unscaling, up to what the fp16 SUBNORMAL range costs
+    the smallest stored activation gradients at 2^10 (values under 6e-5 keep fewer than 11 bits): 2e-3 at the median, no
+    well-defined tensor beyond a few percent, and no overflow at 2^12.  (BN2 biases with a structurally zero gradient and the
+    cancelling scalar gates are noise amplifiers, excluded as in the test above.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    _, ga = _step(dev, 3, n=16, half_storage=True, loss_scale=1024.0)
+    _, gb = _step(dev, 3, n=16, half_storage=True, loss_scale=4096.0)
+    assert all(torch.isfinite(v).all() for v in gb.values())
+    gmax = max(float(v.norm()) for v in ga.values())
+    rows = sorted(((float((gb[k] - ga[k]).norm()) / (float(ga[k].norm()) + 1e-3 * gmax), k, float(ga[k].norm())) for k in ga
+                   if not (k.endswith("._bn2.bias") or k.endswith("_coef"))), reverse=True)
+    print("  worst:", ", ".join(f"{e:.2e} {k} (norm {nn:.1e})" for e, k, nn in rows[:6]))
+    vals = sorted(r[0] for r in rows)
+    med = vals[len(vals) // 2]
+    ok = [within("gradients at loss scale 2^12 vs 2^10, median relative L2", med, 8e-3),
+          within("gradients at loss scale 2^12 vs 2^10, worst relative L2", rows[0][0], 5e-2)]
+    assert all(ok), rows[:4]

@@ -130,3 +130,62 @@ def test_skip_gradient_accumulated_in_place_equals_separate_add():
     _, _, _, g2, _, _, _ = _run(dev, True, 0.0, 4, 3, False, debug=False)
     bad = _grad_bars(g1, g2, cond, "in-place skip gradient vs separate add")
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
+def test_tiled_depthwise_policy_equals_strip_kernels(half):
+    """tape._dw_tile_policy routes some depthwise convs of the fused node to the LDS-tiled kernels (csrc/dwtile.hip); with
+    the policy off every one of them runs on the strip kernels.  Same step either way: fp32 storage to fp32 rounding; half
+    storage to a few fp16 roundings (the tiled forward reads swish(bn0(e)) unrounded, the strip kernel reads the fp16 copy
+    rfft2_ex / bn_apply stored)."""
+    from unidefense_amd import tape as T
+    from unidefense_amd.loss import LOSSES
+    from unidefense_amd.model import load_model
+    dev = _dev()
+    n = 8
+
+    def run(tiled):
+        saved = T._DW_TILED
+        T._DW_TILED = tiled
+        try:
+            m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5)
+            param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+            m = m.to(dev).train()
+            m.half_storage = half
+            x = param_fill.make_input(n, 256, 31).to(dev)
+            tgt = param_fill.make_labels(n).to(dev)
+            rng = ou.make_rng(n, 7, 0.5)
+            rng = {k: ({i: v.to(dev) for i, v in val.items()} if isinstance(val, dict) else val.to(dev)) for k, val in rng.items()}
+            LOSSES["aw_triplet"].n_real = n // 2
+            out = m(x, rng=rng)
+            ld = out["loss_dict"]
+            loss = LOSSES["cross_entropy"](out["cls_out"], tgt) + 0.1 * (ld["freq_mask"].mean() + ld["spat_mask"].mean()) \
+                + 0.1 * sum(LOSSES["aw_triplet"](f, tgt) for f in ld["triplet"]) + out["rec"].square().mean()
+            (loss * 64.0).backward()
+            torch.cuda.synchronize()
+            return ({k: out[k].detach().double() for k in ("cls_out", "rec")},
+                    {k: p.grad.detach().double() / 64.0 for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            T._DW_TILED = saved
+            LOSSES["aw_triplet"].n_real = None
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    otol, gtol = (2e-2, 5e-2) if half else (1e-4, 1e-3)
+    for k in o0:
+        e = float((o1[k] - o0[k]).norm() / o0[k].norm())
+        assert within(f"{k}: tiled vs strip, relative L2", e, otol), (k, e)
+    gscale = 1e-3 * max(float(v.norm()) for v in g0.values())
+    rows = sorted(((float((g1[k] - g0[k]).norm() / (g0[k].norm() + gscale)), k) for k in g0), reverse=True)
+    print("  worst gradients, tiled vs strip:", ", ".join(f"{e:.2e} {k}" for e, k in rows[:6]))
+    if not half:
+        assert within("parameter gradients: tiled vs strip, worst relative L2", rows[0][0], gtol), rows[:6]
+    else:
+        # a changed fp16 rounding early in the trunk is amplified like any perturbation of that size (tests/
+        # test_e_mixed_precision_gpu.py measures the step's conditioning: one rounding of the parameters moves the gradients by
+        # 5 % at the median, the cancelling scalar gates and the arg-max of the dynamic filters by tens of percent): distribution
+        vals = sorted(e for e, k in rows if not k.endswith("_coef"))
+        med, p90 = vals[len(vals) // 2], vals[int(0.9 * len(vals))]
+        print(f"  half storage: median {med:.3g}, 90 % {p90:.3g}, worst {rows[0][0]:.3g}")
+        ok = [within("parameter gradients: tiled vs strip, median relative L2 (4 x the one-rounding yardstick)", med, 0.19),
+              within("parameter gradients: tiled vs strip, 90 % relative L2 (4 x the one-rounding yardstick)", p90, 0.21)]
+        assert all(ok)

@@ -12,16 +12,16 @@
 //   * forward      out = conv(act(bn(src)))                      [+ per-channel sum / sum of squares of out: BN1 statistics]
 //   * data grad    da  = gate * conv_flipped(dy) [+ add];  dz = da * act'(bn(x))   [+ BatchNorm backward sums of dz]
 //   * weight grad  dw[tap][c] = sum_pixels act(bn(src))[.. + tap] * dy           (fp32 partials per workgroup -> finalize)
-// Layout: 256 threads = 8 channel quads (32 channels = 128 contiguous bytes per pixel) x 32 pixel-threads; LDS holds fp32
-// whatever the storage type; the padded row pitch (odd number of pixels) keeps the 16 lanes of a ds_read_b128 phase — two
-// neighbouring rows x 8 quads — on distinct banks.  HBM-bound for k = 3; k = 5 (25 FMAs per element) is VALU / LDS-bound at
+// Layout: 256 threads = CQ channel quads x 256 / CQ pixel-threads — (8, 32): 16 x 16 output tiles of 32 channels (128
+// contiguous bytes per pixel) for the maps of 16 x 16 and more, (16, 16): the whole 8 x 8 map of 64 channels; LDS holds fp32
+// whatever the storage type; the padded row pitch (odd number of pixels) keeps the 16 lanes of a ds_read_b128 phase on
+// distinct banks.  All global loads of the staging phase are issued before the first one is used (address-clamped, no
+// branch around a load), and the epilogue's operands (added gradient, the BatchNorm's input) are fetched before the
+// window loop, so that their latency hides behind the LDS traffic.  HBM-bound for k = 3; k = 5 (25 FMAs per element) is VALU / LDS-bound at
 // ~60 % of the HBM roofline.
 #include "bnref.h"
 
 namespace {
-
-constexpr int CQ = 8;                      // channel quads per workgroup
-constexpr int PTH = NT / CQ;               // pixel-threads per workgroup (32)
 
 struct TileGeom {
     int N, Hs, Ws, C4, Ho, Wo;             // source / output extents (stride 1)
@@ -30,43 +30,62 @@ struct TileGeom {
     int tiles_h, tiles_w;
 };
 
-// tile shape from the strip width: SW = 8 -> 16 x 16, SW = 4 -> 16 x 8, SW = 2 -> 8 x 8 outputs (32 strips each)
-template <int SW> struct TileShape {
+// A workgroup = CQ channel quads x PTH = 256 / CQ pixel-threads; every pixel-thread owns a strip of SW output columns of
+// one tile row: (CQ, SW) = (8, 8): 16 x 16 outputs, (16, 4): 8 x 8 outputs.
+template <int CQ, int SW> struct TileShape {
+    static constexpr int PTH = NT / CQ;
     static constexpr int TW_ = SW == 8 ? 16 : 8;
     static constexpr int TH_ = PTH * SW / TW_;
-    static constexpr int SPR = TW_ / SW;               // strips per tile row
 };
 
-template <int K, int SW> struct Lds {
-    using S = TileShape<SW>;
+template <int K, int CQ, int SW> struct Lds {
+    using S = TileShape<CQ, SW>;
     static constexpr int ROWS = S::TH_ + K - 1;
     static constexpr int COLS = S::TW_ + K - 1;
-    static constexpr int PITCH = (COLS | 1);           // pixels per LDS row, odd: rows r and r + 1 differ by 128 B mod 256 B
+    static constexpr int PITCH = (COLS | 1);           // pixels per LDS row, odd: rows r and r + 1 differ by half a bank sweep
     static constexpr int TILE_Q = ROWS * PITCH * CQ;   // f32x4 slots of the halo tile
     static constexpr int W_Q = K * K * CQ;             // f32x4 slots of the tap table
+    static constexpr int NPIX = ROWS * COLS;
+    static constexpr int NL = (NPIX + S::PTH - 1) / S::PTH;      // staged pixels per thread
 };
 
-// stage act(bn(src)) of the halo tile (zero outside the image) and the workgroup's taps
-template <typename T, int K, int SW>
+// Stage act(bn(src)) of the halo tile (zero outside the image).  Two phases: every load first (branch-free: an invalid
+// element re-reads a valid address and is zeroed afterwards), then transform + LDS store.
+template <typename T, int K, int CQ, int SW>
 __device__ __forceinline__ void stage_tile(const TileGeom& g, const T* __restrict__ src, const ud_bn_ref& bn, bool has_bn,
                                            const Bn4& cb, int n, int oh0, int ow0, int cq0, f32x4* tile) {
-    using L = Lds<K, SW>;
+    using L = Lds<K, CQ, SW>;
+    constexpr int PTH = L::S::PTH;
     const In4<T> s4{src};
-    const int cq = threadIdx.x % CQ;
+    const int cq = threadIdx.x % CQ, p0 = threadIdx.x / CQ;
     const bool cok = cq0 + cq < g.C4;
-    for (int p = threadIdx.x / CQ; p < L::ROWS * L::COLS; p += PTH) {
+    const int c4 = cok ? cq0 + cq : 0;
+    const long img = (long)n * g.Hs * g.Ws;
+    f32x4 v[L::NL];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int l = 0; l < L::NL; ++l) {
+        const int p = p0 + l * PTH;
         const int r = p / L::COLS, c = p % L::COLS;
         const int ih = oh0 + r - g.P_t, iw = ow0 + c - g.P_l;
-        f32x4 v = {0, 0, 0, 0};
-        if (cok && ih >= 0 && ih < g.Hs && iw >= 0 && iw < g.Ws) {
-            v = s4[(((long)n * g.Hs + ih) * g.Ws + iw) * g.C4 + cq0 + cq];
-            if (has_bn) v = bn_apply(v, cb, bn.act);
+        const bool ok = cok && p < L::NPIX && ih >= 0 && ih < g.Hs && iw >= 0 && iw < g.Ws;
+        const long pix = ok ? img + (long)ih * g.Ws + iw : img;
+        v[l] = s4[pix * g.C4 + c4];
+        okmask |= (ok ? 1u : 0u) << l;
+    }
+#pragma unroll
+    for (int l = 0; l < L::NL; ++l) {
+        const int p = p0 + l * PTH;
+        if (p < L::NPIX) {
+            f32x4 a = v[l];
+            if (has_bn) a = bn_apply(a, cb, bn.act);
+            if (!((okmask >> l) & 1u)) a = f32x4{0, 0, 0, 0};
+            tile[((p / L::COLS) * L::PITCH + p % L::COLS) * CQ + cq] = a;
         }
-        tile[(r * L::PITCH + c) * CQ + cq] = v;
     }
 }
 
-template <int K>
+template <int K, int CQ>
 __device__ __forceinline__ void stage_taps(const float* __restrict__ wt, int C4, int cq0, int flip, f32x4* taps) {
     const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
     for (int i = threadIdx.x; i < K * K * CQ; i += NT) {
@@ -79,14 +98,15 @@ __device__ __forceinline__ void stage_taps(const float* __restrict__ wt, int C4,
 // EPI 0: plain store.  EPI 1: + sum / sum of squares of the stored result (forward statistics).
 // EPI 2: data gradient: da = gate * acc [+ add]; with a BatchNorm behind it (has_bn_out): dz = da * act'(bn(x)), sums of dz
 //        and dz * xhat.
-template <typename T, int K, int SW, int EPI>
+template <typename T, int K, int CQ, int SW, int EPI>
 __global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in, int has_bn_in,
                                                      const float* __restrict__ wt, T* __restrict__ out,
                                                      const float* __restrict__ gate_alpha, int gate_mode,
                                                      const T* __restrict__ add, const T* __restrict__ xbn,
                                                      ud_bn_ref bn_out, int has_bn_out, double* __restrict__ part) {
-    using L = Lds<K, SW>;
-    using S = TileShape<SW>;
+    using L = Lds<K, CQ, SW>;
+    using S = TileShape<CQ, SW>;
+    constexpr int PTH = S::PTH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* tile = reinterpret_cast<f32x4*>(smem);
     f32x4* taps = tile + L::TILE_Q;
@@ -99,14 +119,28 @@ __global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __rest
     t /= g.tiles_w;
     const int th_i = t % g.tiles_h, n = t / g.tiles_h;
     const int oh0 = th_i * S::TH_, ow0 = tw_i * S::TW_;
+    // strip of this thread: row p % TH, columns (p / TH) * SW ..
+    const int row = p % S::TH_, col0 = (p / S::TH_) * SW;
+    const int oh = oh0 + row;
+    const long obase = (((long)n * g.Ho + (oh < g.Ho ? oh : 0)) * g.Wo) * g.C4 + (cok ? c4 : 0);
+    // epilogue operands first: their latency hides behind the staging and the window loop
+    const In4<T> add4{add}, x4{xbn};
+    f32x4 pre_add[EPI == 2 ? SW : 1], pre_x[EPI == 2 ? SW : 1];
+    if (EPI == 2) {
+#pragma unroll
+        for (int o = 0; o < SW; ++o) {
+            int ow = ow0 + col0 + o;
+            if (ow >= g.Wo) ow = g.Wo - 1;                      // clamped: stored only when in range
+            if (add) pre_add[o] = add4[obase + (long)ow * g.C4];
+            if (has_bn_out) pre_x[o] = x4[obase + (long)ow * g.C4];
+        }
+    }
     Bn4 cbi;
     if (has_bn_in && cok) cbi = bn_load(bn_in, 0, g.C4, c4, blockIdx.x == 0 && p == 0);
-    stage_tile<T, K, SW>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
-    stage_taps<K>(wt, g.C4, cq0, g.flip, taps);
+    stage_tile<T, K, CQ, SW>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
+    stage_taps<K, CQ>(wt, g.C4, cq0, g.flip, taps);
     __syncthreads();
 
-    // strip of this thread: row p % TH, columns (p / TH) * SW ..   (lanes 0-7 / 8-15 of a read phase: rows r, r + 1)
-    const int row = p % S::TH_, col0 = (p / S::TH_) * SW;
     f32x4 acc[SW];
 #pragma unroll
     for (int i = 0; i < SW; ++i) acc[i] = f32x4{0, 0, 0, 0};
@@ -124,11 +158,9 @@ __global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __rest
             for (int j = 0; j < K; ++j) acc[o] += in[o + j] * w[j];
     }
 
-    const int oh = oh0 + row;
     const Out4<T> o4{out};
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (cok && oh < g.Ho) {
-        const In4<T> add4{add}, x4{xbn};
         Bn4 cbo;
         float gs = 1.f;
         if (EPI == 2) {
@@ -139,13 +171,13 @@ __global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __rest
         for (int o = 0; o < SW; ++o) {
             const int ow = ow0 + col0 + o;
             if (ow >= g.Wo) continue;
-            const long idx = (((long)n * g.Ho + oh) * g.Wo + ow) * g.C4 + c4;
+            const long idx = obase + (long)ow * g.C4;
             f32x4 r = acc[o];
             if (EPI == 2) {
                 r = r * gs;
-                if (add) r += add4[idx];
+                if (add) r += pre_add[o];
                 if (has_bn_out) {
-                    const f32x4 a = x4[idx];
+                    const f32x4 a = pre_x[o];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float xh = (a[e] - cbo.mu[e]) * cbo.is[e];
@@ -169,7 +201,7 @@ __global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __rest
         }
     }
     if (EPI == 1 || (EPI == 2 && has_bn_out)) {
-        // fold the 32 pixel-threads of every channel quad: LDS (the tile is dead), then one fp64 partial per (tile, channel)
+        // fold the pixel-threads of every channel quad: LDS (the tile is dead), then one fp64 partial per (tile, channel)
         __syncthreads();
         double* sm = reinterpret_cast<double*>(smem);
 #pragma unroll
@@ -179,29 +211,23 @@ __global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __rest
             const int e = threadIdx.x / CQ, q = threadIdx.x % CQ;
             double s = 0.0;
             for (int k = 0; k < PTH; ++k) s += sm[(e * PTH + k) * CQ + q];
-            sm[(8 * PTH) * CQ + threadIdx.x] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < 8 * CQ) {
-            // part[q][tile][C]: quantity (0: first sum, 1: second), tile = blockIdx.x, channel
-            const int e = threadIdx.x / CQ, q = threadIdx.x % CQ;
             if (cq0 + q < g.C4) {
+                // part[quantity][tile][C]: quantity 0 = first sum, 1 = second; tile = blockIdx.x
                 const long C = (long)g.C4 * 4, P = gridDim.x;
-                const int quantity = e / 4, lane_e = e % 4;
-                part[((long)quantity * P + blockIdx.x) * C + (cq0 + q) * 4 + lane_e] = sm[(8 * PTH) * CQ + threadIdx.x];
+                part[((long)(e / 4) * P + blockIdx.x) * C + (cq0 + q) * 4 + e % 4] = s;
             }
         }
     }
 }
 
 // Weight gradient: acc[tap] += src_tile[.. + tap] * dy over the workgroup's tiles (images n0, n0 + nstep, ...), folded over
-// its 32 pixel-threads, one fp32 partial row [K*K][C] per workgroup for dw_tile_wgrad_finalize.
-template <typename T, int K, int SW>
+// its pixel-threads, one fp32 partial row [K*K][C] per workgroup for dw_tile_wgrad_finalize.
+template <typename T, int K, int CQ, int SW>
 __global__ __launch_bounds__(NT) void dw_tile_wgrad_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in,
                                                            int has_bn_in, const T* __restrict__ dy, int n_step,
                                                            float* __restrict__ part) {
-    using L = Lds<K, SW>;
-    using S = TileShape<SW>;
+    using L = Lds<K, CQ, SW>;
+    using S = TileShape<CQ, SW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* tile = reinterpret_cast<f32x4*>(smem);
     const int cq = threadIdx.x % CQ, p = threadIdx.x / CQ;
@@ -212,6 +238,7 @@ __global__ __launch_bounds__(NT) void dw_tile_wgrad_kernel(TileGeom g, const T* 
     const int tsp = blockIdx.x % tiles, nb = blockIdx.x / tiles;        // spatial tile, first image
     const int oh0 = (tsp / g.tiles_w) * S::TH_, ow0 = (tsp % g.tiles_w) * S::TW_;
     const int row = p % S::TH_, col0 = (p / S::TH_) * SW;
+    const int oh = oh0 + row;
     const In4<T> dy4{dy};
     Bn4 cbi;
     if (has_bn_in && cok) cbi = bn_load(bn_in, 0, g.C4, c4, false);
@@ -221,15 +248,19 @@ __global__ __launch_bounds__(NT) void dw_tile_wgrad_kernel(TileGeom g, const T* 
 #pragma unroll
         for (int j = 0; j < K; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     for (int n = nb; n < g.N; n += n_step) {
-        __syncthreads();                                       // previous tile fully consumed
-        stage_tile<T, K, SW>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
+        // this thread's dy strip (branch-free, zeroed when out of range), then the tile
         f32x4 gy[SW];
-        const int oh = oh0 + row;
+        const long gbase = (((long)n * g.Ho + (oh < g.Ho ? oh : 0)) * g.Wo) * g.C4 + (cok ? c4 : 0);
 #pragma unroll
         for (int o = 0; o < SW; ++o) {
             const int ow = ow0 + col0 + o;
-            gy[o] = (cok && oh < g.Ho && ow < g.Wo) ? dy4[(((long)n * g.Ho + oh) * g.Wo + ow) * g.C4 + c4] : f32x4{0, 0, 0, 0};
+            gy[o] = dy4[gbase + (long)(ow < g.Wo ? ow : g.Wo - 1) * g.C4];
         }
+        __syncthreads();                                       // previous tile fully consumed
+        stage_tile<T, K, CQ, SW>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
+#pragma unroll
+        for (int o = 0; o < SW; ++o)
+            if (!(cok && oh < g.Ho && ow0 + col0 + o < g.Wo)) gy[o] = f32x4{0, 0, 0, 0};
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -243,7 +274,7 @@ __global__ __launch_bounds__(NT) void dw_tile_wgrad_kernel(TileGeom g, const T* 
                 for (int o = 0; o < SW; ++o) acc[i][j] += in[o + j] * gy[o];
         }
     }
-    // fold the 8 pixel-threads of a wave (lane bits 3..5), then the 4 waves through LDS
+    // fold the pixel-threads of a wave (the lane bits above the channel quad), then the 4 waves through LDS
     __syncthreads();
     float* sm = reinterpret_cast<float*>(smem);                 // [4 waves][K*K][CQ][4]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -255,9 +286,8 @@ __global__ __launch_bounds__(NT) void dw_tile_wgrad_kernel(TileGeom g, const T* 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = a[e];
-                x += __shfl_xor(x, 8, 64);
-                x += __shfl_xor(x, 16, 64);
-                x += __shfl_xor(x, 32, 64);
+#pragma unroll
+                for (int m = CQ; m < 64; m <<= 1) x += __shfl_xor(x, m, 64);
                 a[e] = x;
             }
             if (lane < CQ) reinterpret_cast<f32x4*>(sm)[(wave * K * K + i * K + j) * CQ + lane] = a;
@@ -307,36 +337,33 @@ inline bool tile_args_ok(int N, int Hs, int Ws, int C, int Ho, int Wo, int K) {
     return N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0 && C >= 4 && C % 4 == 0 && (K == 3 || K == 5);
 }
 
-// strip width: the widest whose tile is not mostly padding on this map
-inline int pick_sw(int Ho, int Wo) {
-    if (Wo > 8 && Ho > 8) return 8;        // 16 x 16 tiles
-    if (Ho > 8) return 4;                  // 16 x 8
-    return 2;                              // 8 x 8
+// maps up to 8 x 8 with at least 64 channels: one 8 x 8 tile of 64 channels; everything else: 16 x 16 tiles of 32 channels
+inline bool small_map(int Ho, int Wo, int C) { return Ho <= 8 && Wo <= 8 && C >= 64; }
+
+inline void tile_counts(int Ho, int Wo, int C, int& th, int& tw, int& cq) {
+    if (small_map(Ho, Wo, C)) { th = ud_cdiv(Ho, 8); tw = ud_cdiv(Wo, 8); cq = 16; }
+    else { th = ud_cdiv(Ho, 16); tw = ud_cdiv(Wo, 16); cq = 8; }
 }
 
-template <int SW> inline void tile_counts(int Ho, int Wo, int& th, int& tw) {
-    th = ud_cdiv(Ho, TileShape<SW>::TH_);
-    tw = ud_cdiv(Wo, TileShape<SW>::TW_);
-}
-
-template <typename T, int K, int SW>
+template <typename T, int K, int CQ, int SW>
 int launch_tile(TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* wt, T* out, const float* gate_alpha,
                 int gate_mode, const T* add, const T* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2,
                 double* ws, hipStream_t s) {
-    using L = Lds<K, SW>;
-    tile_counts<SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
+    using L = Lds<K, CQ, SW>;
+    int cq;
+    tile_counts(g.Ho, g.Wo, g.C4 * 4, g.tiles_h, g.tiles_w, cq);
     const long nt = (long)g.N * g.tiles_h * g.tiles_w;
     if (nt > 0x7fffffffL) return UD_EINVAL;
     dim3 grid((unsigned)nt, (unsigned)ud_cdiv(g.C4, CQ));
     size_t lds = (size_t)(L::TILE_Q + L::W_Q) * 16;
-    const size_t fold = (size_t)(8 * PTH * CQ + 8 * CQ) * 8;
+    const size_t fold = (size_t)(8 * NT) * 8;
     if (lds < fold) lds = fold;
     ud_bn_ref none{};
     const ud_bn_ref& bi = bn_in ? *bn_in : none;
     const ud_bn_ref& bo = bn_out ? *bn_out : none;
     const bool sums = epi == 1 || (epi == 2 && bn_out);
 #define UD_TILE(E)                                                                                                    \
-    hipLaunchKernelGGL((dw_tile_kernel<T, K, SW, E>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, wt, out,     \
+    hipLaunchKernelGGL((dw_tile_kernel<T, K, CQ, SW, E>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, wt, out, \
                        gate_alpha, gate_mode, add, xbn, bo, bn_out ? 1 : 0, sums ? ws : nullptr)
     if (epi == 0) UD_TILE(0);
     else if (epi == 1) UD_TILE(1);
@@ -351,24 +378,12 @@ int launch_tile(TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* w
     return 0;
 }
 
-template <typename T>
-int dispatch_tile(int K, TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* wt, T* out, const float* gate_alpha,
-                  int gate_mode, const T* add, const T* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2,
-                  double* ws, hipStream_t s) {
-    const int sw = pick_sw(g.Ho, g.Wo);
-#define UD_GO(KK, SS) return launch_tile<T, KK, SS>(g, src, bn_in, wt, out, gate_alpha, gate_mode, add, xbn, bn_out, epi, s1, s2, ws, s)
-    if (K == 3) { if (sw == 8) UD_GO(3, 8); if (sw == 4) UD_GO(3, 4); UD_GO(3, 2); }
-    if (sw == 8) UD_GO(5, 8);
-    if (sw == 4) UD_GO(5, 4);
-    UD_GO(5, 2);
-#undef UD_GO
-}
-
-template <typename T, int K, int SW>
+template <typename T, int K, int CQ, int SW>
 int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, const float* gate_alpha, int gate_mode,
                  float* part, long part_rows, float* dw, hipStream_t s) {
-    using L = Lds<K, SW>;
-    tile_counts<SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
+    using L = Lds<K, CQ, SW>;
+    int cq;
+    tile_counts(g.Ho, g.Wo, g.C4 * 4, g.tiles_h, g.tiles_w, cq);
     const int tiles = g.tiles_h * g.tiles_w;
     const int cblocks = ud_cdiv(g.C4, CQ);
     // enough workgroups to fill the chip ~4 times over; every workgroup folds N / n_step images before it writes a partial
@@ -383,7 +398,8 @@ int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, 
     ud_bn_ref none{};
     const ud_bn_ref& bi = bn_in ? *bn_in : none;
     dim3 grid((unsigned)nparts, (unsigned)cblocks);
-    hipLaunchKernelGGL((dw_tile_wgrad_kernel<T, K, SW>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, dy, n_step, part);
+    hipLaunchKernelGGL((dw_tile_wgrad_kernel<T, K, CQ, SW>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, dy, n_step,
+                       part);
     UD_LAUNCH_CHECK();
     const int KKC = K * K * g.C4 * 4;
     hipLaunchKernelGGL(dw_tile_wgrad_finalize, dim3(ud_cdiv(KKC, 64)), dim3(NT), 0, s, (int)nparts, K * K, g.C4 * 4, part,
@@ -399,23 +415,15 @@ extern "C" {
 // doubles of scratch for the statistics partials of ud_dwtile (epi 1 / 2): 2 * tiles * C
 long ud_dwtile_ws_doubles(int N, int Ho, int Wo, int C) {
     if (N < 1 || Ho < 1 || Wo < 1 || C < 4 || C % 4) return UD_EINVAL;
-    const int sw = pick_sw(Ho, Wo);
-    int th, tw;
-    if (sw == 8) tile_counts<8>(Ho, Wo, th, tw);
-    else if (sw == 4) tile_counts<4>(Ho, Wo, th, tw);
-    else tile_counts<2>(Ho, Wo, th, tw);
+    int th, tw, cq;
+    tile_counts(Ho, Wo, C, th, tw, cq);
     return 2L * N * th * tw * C;
 }
 
 // rows of K*K*C floats the weight-gradient partials may need (upper bound: one per (tile, image))
 long ud_dwtile_wgrad_part_rows(int N, int Ho, int Wo) {
     if (N < 1 || Ho < 1 || Wo < 1) return UD_EINVAL;
-    const int sw = pick_sw(Ho, Wo);
-    int th, tw;
-    if (sw == 8) tile_counts<8>(Ho, Wo, th, tw);
-    else if (sw == 4) tile_counts<4>(Ho, Wo, th, tw);
-    else tile_counts<2>(Ho, Wo, th, tw);
-    return (long)N * th * tw;
+    return (long)N * ud_cdiv(Ho, 8) * ud_cdiv(Wo, 8);
 }
 
 int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* out, int N, int Hs, int Ws, int C, int Ho,
@@ -428,9 +436,16 @@ int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* ou
     if (bn_out && (!xbn || bn_out->G != 1)) return UD_EINVAL;
     if ((epi == 1 || bn_out) && (!s1 || !s2 || !ws)) return UD_EINVAL;
     TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, flip ? 1 : 0, 0, 0};
-    UD_STORAGE_DISPATCH(f16, return dispatch_tile<T>(K, g, (const T*)src, bn_in, wt, (T*)out, gate_alpha, gate_mode,
-                                                      (const T*)add, (const T*)xbn, bn_out, epi, s1, s2, ws,
-                                                      (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    const bool sm = small_map(Ho, Wo, C);
+#define UD_GO(KK, QQ, SS)                                                                                             \
+    UD_STORAGE_DISPATCH(f16, return (launch_tile<T, KK, QQ, SS>(g, (const T*)src, bn_in, wt, (T*)out, gate_alpha,     \
+                                                                gate_mode, (const T*)add, (const T*)xbn, bn_out, epi, \
+                                                                s1, s2, ws, s)))
+    if (K == 3) { if (sm) UD_GO(3, 16, 4); UD_GO(3, 8, 8); }
+    if (sm) UD_GO(5, 16, 4);
+    UD_GO(5, 8, 8);
+#undef UD_GO
 }
 
 int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, const float* gate_alpha, int gate_mode,
@@ -439,15 +454,14 @@ int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, con
     if (!tile_args_ok(N, Hs, Ws, C, Ho, Wo, K) || !src || !dy || !dwt || !part || part_rows < 1) return UD_EINVAL;
     if (bn_in && bn_in->G != 1) return UD_EINVAL;
     TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, 0, 0, 0};
-    const int sw = pick_sw(Ho, Wo);
     hipStream_t s = (hipStream_t)stream;
-#define UD_WG(KK, SS)                                                                                                 \
-    UD_STORAGE_DISPATCH(f16, return launch_wgrad<T, KK, SS>(g, (const T*)src, bn_in, (const T*)dy, gate_alpha, gate_mode, \
-                                                            part, part_rows, dwt, s))
-    if (K == 3) { if (sw == 8) UD_WG(3, 8); if (sw == 4) UD_WG(3, 4); UD_WG(3, 2); }
-    if (sw == 8) UD_WG(5, 8);
-    if (sw == 4) UD_WG(5, 4);
-    UD_WG(5, 2);
+    const bool sm = small_map(Ho, Wo, C);
+#define UD_WG(KK, QQ, SS)                                                                                             \
+    UD_STORAGE_DISPATCH(f16, return (launch_wgrad<T, KK, QQ, SS>(g, (const T*)src, bn_in, (const T*)dy, gate_alpha,   \
+                                                                 gate_mode, part, part_rows, dwt, s)))
+    if (K == 3) { if (sm) UD_WG(3, 16, 4); UD_WG(3, 8, 8); }
+    if (sm) UD_WG(5, 16, 4);
+    UD_WG(5, 8, 8);
 #undef UD_WG
 }
 

@@ -208,6 +208,29 @@ def linear(tape, x, w, b):
 # depthwise conv, FFT, SFConv
 # ---------------------------------------------------------------------------------------------
 _DW_FUSED_ADD = True
+# Stride-1 depthwise convs of the fused MBConv node on the LDS-tiled kernels of csrc/dwtile.hip (the deferred BatchNorm is
+# applied while the halo tile is staged: swish(bn0(e)) is never materialised) WHERE THEY WIN — measured per shape against
+# the strip kernels with tools/bench_dwtile.py on an MI355X (profiles/r03/dwtile_*.txt):
+#   forward       : every plain block (one launch replaces bn_apply + conv + colstats: 118 -> 82, 64 -> 47, 122 -> 61,
+#                   37 -> 23 us at 128^2 x 48, 128^2 x 24, 64^2 x 192, 8^2 x 2688); the SF blocks get swish(bn0(e)) from
+#                   rfft2_ex as a by-product, so only their 3x3 / 16x16 maps gain (half storage);
+#   weight grad   : plain blocks (fp32: 64 -> 55, 65 -> 56 us), every block in half storage (283 -> 107, 287 -> 73, 199 -> 94,
+#                   162 -> 108 us ...: the strip kernel's 2-byte window loads);
+#   data gradient : only the 5x5 / 32x32 maps in half storage (260 -> 181 us); the strip kernel wins everywhere else
+#                   (the tile kernel's epilogue operands + window push it to 256 VGPRs).
+_DW_TILED = True
+
+
+def _dw_tile_policy(sf, k, stride, H, half):
+    """(forward, weight gradient, data gradient) on the tiled kernels?"""
+    if not _DW_TILED or stride != 1:
+        return False, False, False
+    if not sf:
+        return True, True, False
+    if half:
+        fwd = k == 3 and H == 16
+        return fwd, True, (k == 5 and H == 32)
+    return False, False, False
 DW_WT = {}            # {id(w): (w, w._version, tap-major wt)} for the forward in flight (kernels.dw_weights_tapmajor)
 
 
@@ -873,11 +896,16 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         S = H
         s_f, s_i = _fft_scales(S, sp.sf_norm)
         alpha = dwm.sf_coef
+        t_fwd, t_wg, t_bwd = _dw_tile_policy(True, k, stride, H, x.dtype == torch.float16)
         if src_bn is not None:
-            xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=True, update=True)   # also writes a = swish(bn0(e))
+            # a strip kernel needs a = swish(bn0(e)) materialised (rfft2_ex writes it); the tiled ones apply it on load
+            xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=not (t_fwd and t_wg), update=True)
         else:
             xf, a = K.rfft2(src, s_f, 1.0), src
-        spat = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
+        if t_fwd:
+            spat = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn)
+        else:
+            spat = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
         Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
         yf = K.gemm_nt(xf.view(-1, 2 * Ce), Wf).view(xf.shape)
         if stride == 1:
@@ -890,10 +918,16 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         del yf
     else:
         alpha = None
-        # a plain depthwise conv (and its weight gradient) re-reads its input per tap: materialise the activation
-        a = K.bn_apply(src, src_bn, 1, M, update=True) if src_bn is not None else src
-        d = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
-        K.colstats(d.view(Mo, Ce), acc1)
+        t_fwd, t_wg, t_bwd = _dw_tile_policy(False, k, stride, H, x.dtype == torch.float16)
+        if t_fwd:
+            # halo tile staged in LDS with swish(bn0(e)) applied on the way in; BN1 statistics out of the epilogue
+            a = None
+            d = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn, stats=acc1, update=True)
+        else:
+            # the strip kernel (and its weight gradient) re-reads its input per tap: materialise the activation
+            a = K.bn_apply(src, src_bn, 1, M, update=True) if src_bn is not None else src
+            d = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
+            K.colstats(d.view(Mo, Ce), acc1)
     dp.reduce(acc1)
     bn1 = _bn_of(blk._bn1, acc1, Mo * dp.world, 1)
 
@@ -971,11 +1005,18 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
             g_sp = dd
         tape.add_param_grad(blk._bn1.weight, dg1)
         tape.add_param_grad(blk._bn1.bias, db1)
-        tape.add_param_grad(dwm.weight, K.dwconv_bwd_weight_ex(a, g_sp, g_alpha, g_mode, k, stride, pt, pl))
+        if t_wg:
+            tape.add_param_grad(dwm.weight, K.dwtile_bwd_weight(src, g_sp, k, pt, pl, bn=src_bn, gate_alpha=g_alpha,
+                                                                gate_mode=g_mode))
+        else:
+            tape.add_param_grad(dwm.weight, K.dwconv_bwd_weight_ex(a, g_sp, g_alpha, g_mode, k, stride, pt, pl))
         # ---- depthwise data gradient (+ spectral branch), through swish(bn0(.)) when the input is deferred
         if src_bn is not None:
             sb0 = K.zeros64(2 * src.shape[-1], x)
-            if stride == 1:
+            if t_bwd:
+                dz0 = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, da_f, src, src_bn, sb0)
+                is_dz = True
+            elif stride == 1:
                 dz0 = K.dwconv_bwd_data_bn(g_sp, g_alpha, g_mode, wt, da_f, src, src_bn, k, stride, pt, pl, sb0)
                 is_dz = True
             else:       # stride 2 (4 of 32 blocks): gather kernel, then the sums as a pass of their own
@@ -1003,7 +1044,10 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 add, skip_done = dout, True
             else:
                 skip_done = not sp.skip
-            dx = K.dwconv_bwd_data_ex(g_sp, g_alpha, g_mode, wt, add, k, stride, pt, pl, H, W)
+            if t_bwd:
+                dx = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, add)
+            else:
+                dx = K.dwconv_bwd_data_ex(g_sp, g_alpha, g_mode, wt, add, k, stride, pt, pl, H, W)
             if not skip_done:
                 dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
         dx._ud_owned = True
