@@ -98,8 +98,13 @@ __device__ __forceinline__ void stage_taps(const float* __restrict__ wt, int C4,
 // EPI 0: plain store.  EPI 1: + sum / sum of squares of the stored result (forward statistics).
 // EPI 2: data gradient: da = gate * acc [+ add]; with a BatchNorm behind it (has_bn_out): dz = da * act'(bn(x)), sums of dz
 //        and dz * xhat.
+// waves per SIMD the register allocation has to leave room for: what the LDS tile allows (57 KB at K = 5 / 16 x 16: two
+// workgroups per CU; 33 - 44 KB otherwise: three or four) — without the bound hipcc hoists every LDS read of the unrolled
+// window loop and takes all 256 VGPRs
+template <int K, int SW> constexpr int kMinWaves = (K == 5 && SW == 8) ? 2 : (SW == 4 ? 4 : 3);
+
 template <typename T, int K, int CQ, int SW, int EPI>
-__global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in, int has_bn_in,
+__global__ __launch_bounds__(NT, (kMinWaves<K, SW>)) void dw_tile_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in, int has_bn_in,
                                                      const float* __restrict__ wt, T* __restrict__ out,
                                                      const float* __restrict__ gate_alpha, int gate_mode,
                                                      const T* __restrict__ add, const T* __restrict__ xbn,
@@ -156,6 +161,10 @@ __global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __rest
         for (int o = 0; o < SW; ++o)
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[o] += in[o + j] * w[j];
+        // one window row at a time: pin the running sums here, or hipcc sinks every multiply-add below the LDS reads of
+        // all K rows (K * (SW + K - 1) quads live at once) and spills
+#pragma unroll
+        for (int o = 0; o < SW; ++o) asm volatile("" : "+v"(acc[o]));
     }
 
     const Out4<T> o4{out};
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(NT) void dw_tile_kernel(TileGeom g, const T* __rest
 // Weight gradient: acc[tap] += src_tile[.. + tap] * dy over the workgroup's tiles (images n0, n0 + nstep, ...), folded over
 // its pixel-threads, one fp32 partial row [K*K][C] per workgroup for dw_tile_wgrad_finalize.
 template <typename T, int K, int CQ, int SW>
-__global__ __launch_bounds__(NT) void dw_tile_wgrad_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in,
+__global__ __launch_bounds__(NT, 2) void dw_tile_wgrad_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in,
                                                            int has_bn_in, const T* __restrict__ dy, int n_step,
                                                            float* __restrict__ part) {
     using L = Lds<K, CQ, SW>;
@@ -272,6 +281,8 @@ __global__ __launch_bounds__(NT) void dw_tile_wgrad_kernel(TileGeom g, const T* 
             for (int j = 0; j < K; ++j)
 #pragma unroll
                 for (int o = 0; o < SW; ++o) acc[i][j] += in[o + j] * gy[o];
+#pragma unroll
+            for (int j = 0; j < K; ++j) asm volatile("" : "+v"(acc[i][j]));      // one window row at a time (see dw_tile_kernel)
         }
     }
     // fold the pixel-threads of a wave (the lane bits above the channel quad), then the 4 waves through LDS
@@ -340,9 +351,9 @@ inline bool tile_args_ok(int N, int Hs, int Ws, int C, int Ho, int Wo, int K) {
 // maps up to 8 x 8 with at least 64 channels: one 8 x 8 tile of 64 channels; everything else: 16 x 16 tiles of 32 channels
 inline bool small_map(int Ho, int Wo, int C) { return Ho <= 8 && Wo <= 8 && C >= 64; }
 
-inline void tile_counts(int Ho, int Wo, int C, int& th, int& tw, int& cq) {
-    if (small_map(Ho, Wo, C)) { th = ud_cdiv(Ho, 8); tw = ud_cdiv(Wo, 8); cq = 16; }
-    else { th = ud_cdiv(Ho, 16); tw = ud_cdiv(Wo, 16); cq = 8; }
+template <int CQ, int SW> inline void tile_counts(int Ho, int Wo, int& th, int& tw) {
+    th = ud_cdiv(Ho, TileShape<CQ, SW>::TH_);
+    tw = ud_cdiv(Wo, TileShape<CQ, SW>::TW_);
 }
 
 template <typename T, int K, int CQ, int SW>
@@ -350,8 +361,7 @@ int launch_tile(TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* w
                 int gate_mode, const T* add, const T* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2,
                 double* ws, hipStream_t s) {
     using L = Lds<K, CQ, SW>;
-    int cq;
-    tile_counts(g.Ho, g.Wo, g.C4 * 4, g.tiles_h, g.tiles_w, cq);
+    tile_counts<CQ, SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
     const long nt = (long)g.N * g.tiles_h * g.tiles_w;
     if (nt > 0x7fffffffL) return UD_EINVAL;
     dim3 grid((unsigned)nt, (unsigned)ud_cdiv(g.C4, CQ));
@@ -382,8 +392,7 @@ template <typename T, int K, int CQ, int SW>
 int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, const float* gate_alpha, int gate_mode,
                  float* part, long part_rows, float* dw, hipStream_t s) {
     using L = Lds<K, CQ, SW>;
-    int cq;
-    tile_counts(g.Ho, g.Wo, g.C4 * 4, g.tiles_h, g.tiles_w, cq);
+    tile_counts<CQ, SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
     const int tiles = g.tiles_h * g.tiles_w;
     const int cblocks = ud_cdiv(g.C4, CQ);
     // enough workgroups to fill the chip ~4 times over; every workgroup folds N / n_step images before it writes a partial
@@ -412,12 +421,10 @@ int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, 
 
 extern "C" {
 
-// doubles of scratch for the statistics partials of ud_dwtile (epi 1 / 2): 2 * tiles * C
+// doubles of scratch for the statistics partials of ud_dwtile (epi 1 / 2): 2 * tiles * C (bound: the smallest tile, 8 x 8)
 long ud_dwtile_ws_doubles(int N, int Ho, int Wo, int C) {
     if (N < 1 || Ho < 1 || Wo < 1 || C < 4 || C % 4) return UD_EINVAL;
-    int th, tw, cq;
-    tile_counts(Ho, Wo, C, th, tw, cq);
-    return 2L * N * th * tw * C;
+    return 2L * N * ud_cdiv(Ho, 8) * ud_cdiv(Wo, 8) * C;
 }
 
 // rows of K*K*C floats the weight-gradient partials may need (upper bound: one per (tile, image))
@@ -442,8 +449,10 @@ int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* ou
     UD_STORAGE_DISPATCH(f16, return (launch_tile<T, KK, QQ, SS>(g, (const T*)src, bn_in, wt, (T*)out, gate_alpha,     \
                                                                 gate_mode, (const T*)add, (const T*)xbn, bn_out, epi, \
                                                                 s1, s2, ws, s)))
-    if (K == 3) { if (sm) UD_GO(3, 16, 4); UD_GO(3, 8, 8); }
+    // the data gradient (epi 2) keeps its epilogue operands in registers next to the window: strips of 4 (16 x 8 tiles)
+    if (K == 3) { if (sm) UD_GO(3, 16, 4); if (epi == 2) UD_GO(3, 8, 4); UD_GO(3, 8, 8); }
     if (sm) UD_GO(5, 16, 4);
+    if (epi == 2) UD_GO(5, 8, 4);
     UD_GO(5, 8, 8);
 #undef UD_GO
 }
@@ -459,9 +468,10 @@ int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, con
 #define UD_WG(KK, QQ, SS)                                                                                             \
     UD_STORAGE_DISPATCH(f16, return (launch_wgrad<T, KK, QQ, SS>(g, (const T*)src, bn_in, (const T*)dy, gate_alpha,   \
                                                                  gate_mode, part, part_rows, dwt, s)))
+    // 5 x 5: 25 accumulator quads per thread — strips of 4 (16 x 8 tiles) keep the kernel clear of spills
     if (K == 3) { if (sm) UD_WG(3, 16, 4); UD_WG(3, 8, 8); }
     if (sm) UD_WG(5, 16, 4);
-    UD_WG(5, 8, 8);
+    UD_WG(5, 8, 4);
 #undef UD_WG
 }
 

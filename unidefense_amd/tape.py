@@ -210,14 +210,15 @@ def linear(tape, x, w, b):
 _DW_FUSED_ADD = True
 # Stride-1 depthwise convs of the fused MBConv node on the LDS-tiled kernels of csrc/dwtile.hip (the deferred BatchNorm is
 # applied while the halo tile is staged: swish(bn0(e)) is never materialised) WHERE THEY WIN — measured per shape against
-# the strip kernels with tools/bench_dwtile.py on an MI355X (profiles/r03/dwtile_*.txt):
-#   forward       : every plain block (one launch replaces bn_apply + conv + colstats: 118 -> 82, 64 -> 47, 122 -> 61,
-#                   37 -> 23 us at 128^2 x 48, 128^2 x 24, 64^2 x 192, 8^2 x 2688); the SF blocks get swish(bn0(e)) from
-#                   rfft2_ex as a by-product, so only their 3x3 / 16x16 maps gain (half storage);
-#   weight grad   : plain blocks (fp32: 64 -> 55, 65 -> 56 us), every block in half storage (283 -> 107, 287 -> 73, 199 -> 94,
-#                   162 -> 108 us ...: the strip kernel's 2-byte window loads);
-#   data gradient : only the 5x5 / 32x32 maps in half storage (260 -> 181 us); the strip kernel wins everywhere else
-#                   (the tile kernel's epilogue operands + window push it to 256 VGPRs).
+# the strip kernels with tools/bench_dwtile.py on an MI355X (profiles/r03/dwtile_f32_bs32.txt, dwtile_f16_bs64.txt):
+#   half storage  : everywhere, by 1.3 - 3x (forward 109 -> 53, data gradient 260 -> 86, weight gradient 284 -> 106 us ...:
+#                   the strip kernels' per-tap 8-byte window loads and conversions);
+#   fp32 forward  : every block (one launch replaces bn_apply + conv + colstats of the plain blocks: 118 -> 74, 63 -> 43,
+#                   121 -> 52, 37 -> 23 us; SF blocks 43 -> 33, 31 -> 23 us) but the 5x5 / 8x8 maps (16 vs 14 us);
+#   fp32 data grad: 5x5 at 16x16 and 32x32 (70 -> 49, 45 -> 36 us) and 3x3 at 32x32 ... 64x64 (101 -> 94 us); the strip kernel
+#                   keeps the 8x8 and 128x128 maps;
+#   fp32 weight grad: the plain blocks (63 -> 54, 66 -> 55 us at 128^2 / 64^2; they have no materialised activation any
+#                   more); the SF blocks keep the strip kernel (36 vs 45, 23 vs 29 us) on the activation rfft2_ex writes.
 _DW_TILED = True
 
 
@@ -225,13 +226,11 @@ def _dw_tile_policy(sf, k, stride, H, half):
     """(forward, weight gradient, data gradient) on the tiled kernels?"""
     if not _DW_TILED or stride != 1:
         return False, False, False
-    if not sf:
-        return True, True, False
     if half:
-        fwd = k == 3 and H == 16
-        return fwd, True, (k == 5 and H == 32)
-    return False, False, False
-DW_WT = {}            # {id(w): (w, w._version, tap-major wt)} for the forward in flight (kernels.dw_weights_tapmajor)
+        return True, True, True
+    fwd = not (k == 5 and H <= 8)
+    bwd = (k == 5 and H >= 16) or (k == 3 and 32 <= H <= 64)
+    return (fwd or not sf), not sf, bwd
 
 
 def dwconv(tape, x, w, stride, pad):
