@@ -233,6 +233,9 @@ def _dw_tile_policy(sf, k, stride, H, half):
     return (fwd or not sf), not sf, bwd
 
 
+DW_WT = {}            # {id(w): (w, w._version, tap-major wt)} for the forward in flight (kernels.dw_weights_tapmajor)
+
+
 def dwconv(tape, x, w, stride, pad):
     """Depthwise Conv2dStaticSamePadding (model/efficientnet/utils.py:277-280; exp.py:49-51).
     pad = (left, right, top, bottom) as in nn.ZeroPad2d."""
