@@ -108,7 +108,8 @@ __global__ __launch_bounds__(NT, (kMinWaves<K, SW>)) void dw_tile_kernel(TileGeo
                                                      const float* __restrict__ wt, T* __restrict__ out,
                                                      const float* __restrict__ gate_alpha, int gate_mode,
                                                      const T* __restrict__ add, const T* __restrict__ xbn,
-                                                     ud_bn_ref bn_out, int has_bn_out, double* __restrict__ part) {
+                                                     ud_bn_ref bn_out, int has_bn_out, double* __restrict__ part,
+                                                     double* __restrict__ s1, double* __restrict__ s2) {
     using L = Lds<K, CQ, SW>;
     using S = TileShape<CQ, SW>;
     constexpr int PTH = S::PTH;
@@ -221,9 +222,14 @@ __global__ __launch_bounds__(NT, (kMinWaves<K, SW>)) void dw_tile_kernel(TileGeo
             double s = 0.0;
             for (int k = 0; k < PTH; ++k) s += sm[(e * PTH + k) * CQ + q];
             if (cq0 + q < g.C4) {
-                // part[quantity][tile][C]: quantity 0 = first sum, 1 = second; tile = blockIdx.x
                 const long C = (long)g.C4 * 4, P = gridDim.x;
-                part[((long)(e / 4) * P + blockIdx.x) * C + (cq0 + q) * 4 + e % 4] = s;
+                if (part) {
+                    // part[quantity][tile][C]: quantity 0 = first sum, 1 = second; tile = blockIdx.x
+                    part[((long)(e / 4) * P + blockIdx.x) * C + (cq0 + q) * 4 + e % 4] = s;
+                } else {
+                    // few tiles per channel (the 8 x 8 / 16 x 16 maps): straight into the accumulator, no finalize launch
+                    atomic_add_f64((e < 4 ? s1 : s2) + (cq0 + q) * 4 + e % 4, s);
+                }
             }
         }
     }
@@ -372,15 +378,18 @@ int launch_tile(TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* w
     const ud_bn_ref& bi = bn_in ? *bn_in : none;
     const ud_bn_ref& bo = bn_out ? *bn_out : none;
     const bool sums = epi == 1 || (epi == 2 && bn_out);
+    // at most 64 tiles add to one address: fp64 atomics (12 ns each, serialised per address) instead of partials + a
+    // finalize launch — the rule of fused.hip's plan_reduce
+    const bool use_part = sums && nt > 64;
 #define UD_TILE(E)                                                                                                    \
     hipLaunchKernelGGL((dw_tile_kernel<T, K, CQ, SW, E>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, wt, out, \
-                       gate_alpha, gate_mode, add, xbn, bo, bn_out ? 1 : 0, sums ? ws : nullptr)
+                       gate_alpha, gate_mode, add, xbn, bo, bn_out ? 1 : 0, use_part ? ws : nullptr, s1, s2)
     if (epi == 0) UD_TILE(0);
     else if (epi == 1) UD_TILE(1);
     else UD_TILE(2);
 #undef UD_TILE
     UD_LAUNCH_CHECK();
-    if (sums) {
+    if (use_part) {
         const int C = g.C4 * 4;
         hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv(C, 8)), dim3(NT), 0, s, 2, 1, C, (int)nt, ws, s1, s2);
         UD_LAUNCH_CHECK();
