@@ -440,18 +440,21 @@ int ud_adamw_multi(const void* table, const void* chunk_map, int n_chunks, const
  * pads); flip = 1: tap = K*K-1 - (i*K + j) with P = K-1 - pad: the data gradient over dy.  wt: tap-major [K*K][C].
  * epi 0: store.  epi 1: also s1 += sum out, s2 += sum out^2 per channel (BN1 statistics of a plain depthwise block).
  * epi 2: out = gate(gate_alpha, gate_mode) * conv [+ add]; with bn_out: out *= act'(bn_out(xbn)) and s1 += sum out,
- * s2 += sum out * xhat (the BatchNorm backward sums).  ws: ud_dwtile_ws_doubles doubles when sums are taken. */
+ * s2 += sum out * xhat (the BatchNorm backward sums).  ws: ud_dwtile_ws_doubles doubles when sums are taken.
+ * stride 2 (the four down-sampling blocks): flip = 0 — the forward reads src(2 oh + i - P_t, ..) (epi 0 / 1); flip = 1 with
+ * epi 2 — the data gradient: src = dy of the strided conv is read through a zero-stuffed grid (position v holds dy(v / 2)
+ * for even v), P = K-1 - pad as for stride 1. */
 long ud_dwtile_ws_doubles(int N, int Ho, int Wo, int C);
 int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* out, int N, int Hs, int Ws, int C, int Ho,
               int Wo, int K, int P_t, int P_l, int flip, const float* gate_alpha, int gate_mode, const void* add,
-              const void* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2, double* ws, int f16,
-              ud_stream_t stream);
+              const void* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2, double* ws, int stride,
+              int f16, ud_stream_t stream);
 /* weight gradient dwt[C][K*K] = gate * sum_pixels act(bn_in(src))(oh + i - P_t, ow + j - P_l) * dy(oh, ow);
  * part: ud_dwtile_wgrad_part_rows(N, Ho, Wo) rows of K*K*C floats */
 long ud_dwtile_wgrad_part_rows(int N, int Ho, int Wo);
 int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, const float* gate_alpha, int gate_mode,
                     float* dwt, float* part, long part_rows, int N, int Hs, int Ws, int C, int Ho, int Wo, int K, int P_t,
-                    int P_l, int f16, ud_stream_t stream);
+                    int P_l, int stride, int f16, ud_stream_t stream);
 
 /* ---- large real 2-D FFT of image planes (csrc/fft_large.hip), S in {128, 256, 320} ------------------------------------
  * torch.fft.rfft2 on [N,3,S,S] images: the frequency reconstruction loss (model/unidefense.py:246-253; ResNet variants

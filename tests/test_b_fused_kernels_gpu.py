@@ -464,3 +464,60 @@ def test_tiled_depthwise_kernels(N, H, W, Cc, k, half):
     assert _rel(da, da_ref) < tol
     dw = K.dwtile_bwd_weight(xg, dyg, k, pad, pad, bn=bn, gate_alpha=alpha.to(dev), gate_mode=2)
     assert _rel(dw.view(Cc, k, k), gate * wd.grad.view(Cc, k, k)) < (1e-3 if half else 2e-5)
+
+
+@pytest.mark.parametrize("N,H,Cc,k,pad", [(2, 32, 24, 3, (0, 1, 0, 1)), (2, 16, 40, 5, (2, 2, 2, 2)), (1, 64, 8, 3, (0, 1, 0, 1)),
+                                          (3, 16, 36, 5, (1, 2, 1, 2)), (2, 18, 12, 5, (1, 2, 1, 2)), (1, 21, 8, 3, (1, 1, 1, 1))])
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
+def test_tiled_depthwise_kernels_stride2(N, H, Cc, k, pad, half):
+    """csrc/dwtile.hip at stride 2 with the static asymmetric pads of the four down-sampling MBConv blocks (pad = left, right,
+    top, bottom: model/efficientnet/utils.py:264-275): forward (window stepped by 2) with the deferred BatchNorm and the output
+    statistics, data gradient through the zero-stuffed tile with act'(bn(x)) and the BatchNorm sums, weight gradient — against
+    autograd in float64."""
+    import torch.nn.functional as F
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N * 100 + H + Cc + k)
+    pl, pr, pt, pb = pad
+    st = torch.float16 if half else torch.float32
+    tol = 2e-3 if half else 2e-5
+    Ho, Wo = (H + pt + pb - k) // 2 + 1, (H + pl + pr - k) // 2 + 1
+
+    def rnd(*s):
+        v = torch.randn(*s, generator=g)
+        return v.half().float() if half else v
+    x, dy, add = rnd(N, H, H, Cc), rnd(N, Ho, Wo, Cc), rnd(N, H, H, Cc)
+    w = torch.randn(Cc, 1, k, k, generator=g) * 0.3
+    gamma, beta = 1.0 + 0.2 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    xd = x.double()
+    mean, var = xd.mean((0, 1, 2)), xd.var((0, 1, 2), unbiased=False)
+    xh = (xd - mean) / torch.sqrt(var + 1e-3)
+    z = xh * gamma.double() + beta.double()
+    a = (z * torch.sigmoid(z)).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_ref = F.conv2d(F.pad(a.permute(0, 3, 1, 2), (pl, pr, pt, pb)), wd, stride=2, groups=Cc).permute(0, 2, 3, 1)
+    assert y_ref.shape == (N, Ho, Wo, Cc)
+    (y_ref * dy.double()).sum().backward()
+    da_ref = a.grad + add.double()
+    sg = torch.sigmoid(z)
+    dz_ref = da_ref * (sg * (1 + z * (1 - sg)))
+    xg, dyg, addg = x.to(dev, st), dy.to(dev, st), add.to(dev, st)
+    wt = w.view(Cc, k * k).t().contiguous().to(dev)
+    acc = K.zeros64(2 * Cc, xg)
+    K.colstats(xg.view(-1, Cc), acc)
+    bn = K.DeferredBN(acc, Cc, N * H * H, gamma.to(dev), beta.to(dev), 1e-3, 1)
+    stats = K.zeros64(2 * Cc, xg)
+    y = K.dwtile_fwd(xg, wt, k, pt, pl, Ho, Wo, bn=bn, stats=stats, stride=2)
+    assert y.dtype == st and _rel(y, y_ref) < tol
+    yd = y.double().cpu()
+    assert _rel(stats[:Cc], yd.sum((0, 1, 2))) < 1e-9 and _rel(stats[Cc:], (yd * yd).sum((0, 1, 2))) < 1e-9
+    sacc = K.zeros64(2 * Cc, xg)
+    dz = K.dwtile_bwd_data(dyg, wt, k, pt, pl, H, H, None, 0, addg, xg, bn, sacc, stride=2)
+    assert _rel(dz, dz_ref) < tol
+    stol = 3e-3 if half else 2e-5
+    assert _rel(sacc[:Cc], dz_ref.sum((0, 1, 2))) < stol and _rel(sacc[Cc:], (dz_ref * xh).sum((0, 1, 2))) < stol
+    da = K.dwtile_bwd_data(dyg, wt, k, pt, pl, H, H, None, 0, addg, stride=2)
+    assert _rel(da, da_ref) < tol
+    dw = K.dwtile_bwd_weight(xg, dyg, k, pt, pl, bn=bn, stride=2)
+    assert _rel(dw.view(Cc, k, k), wd.grad.view(Cc, k, k)) < (1e-3 if half else 2e-5)

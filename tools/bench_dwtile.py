@@ -38,7 +38,55 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / (5 * reps) * 1e3
 
 
+S2 = [("b2", 128, 144, 3, (0, 1, 0, 1), True), ("b6", 64, 192, 5, (2, 2, 2, 2), False), ("b10", 32, 336, 3, (0, 1, 0, 1), False),
+      ("b22", 16, 960, 5, (1, 2, 1, 2), False)]
+
+
+def stride2():
+    print("stride 2: %-6s %4s %5s %2s | fwd old / new | bwd-data (+ sums pass) old / new | wgrad old / new  (us)" % ("block", "H", "C", "k"))
+    for name, H, Cc, k, (pl, pr, pt, pb), plain in S2:
+        Ho = (H + pt + pb - k) // 2 + 1
+        x = torch.randn(N, H, H, Cc, device=dev).to(st)
+        dy = torch.randn(N, Ho, Ho, Cc, device=dev).to(st)
+        add = torch.randn(N, H, H, Cc, device=dev).to(st)
+        wt = torch.randn(k * k, Cc, device=dev) * 0.2
+        gamma, beta = torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.1
+        M = N * H * H
+        acc = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+        K.colstats(x.view(M, Cc), acc)
+        bn = K.DeferredBN(acc, Cc, M, gamma, beta, 1e-3, 1)
+        a = K.bn_apply(x, bn, 1, M)
+
+        def fwd_old():
+            a_ = K.bn_apply(x, bn, 1, M) if plain else a
+            d = K.dwconv_fwd(a_, wt, k, 2, pt, pl, Ho, Ho)
+            if plain:
+                K.colstats(d.view(-1, Cc), K.zeros64(2 * Cc, x))
+
+        def fwd_new():
+            K.dwtile_fwd(x, wt, k, pt, pl, Ho, Ho, bn=bn, stats=K.zeros64(2 * Cc, x) if plain else None, stride=2)
+
+        def bwd_old():
+            dz = K.dwconv_bwd_data(dy, wt, k, 2, pt, pl, H, H, add=add)
+            K.normbwd_sums(x, dz, None, 1.0, bn, False, 1, M, K.zeros64(2 * Cc, x))
+
+        def bwd_new():
+            K.dwtile_bwd_data(dy, wt, k, pt, pl, H, H, None, 0, add, x, bn, K.zeros64(2 * Cc, x), stride=2)
+
+        def wg_old():
+            K.dwconv_bwd_weight_ex(a, dy, None, 0, k, 2, pt, pl)
+
+        def wg_new():
+            K.dwtile_bwd_weight(x, dy, k, pt, pl, bn=bn, stride=2)
+        r = [timed(f) for f in (fwd_old, fwd_new, bwd_old, bwd_new, wg_old, wg_new)]
+        print("          %-6s %4d %5d %2d | %7.1f / %7.1f | %9.1f / %9.1f | %8.1f / %8.1f   (%.0f MB input)" % (
+            name, H, Cc, k, r[0], r[1], r[2], r[3], r[4], r[5], x.numel() * x.element_size() / 1e6))
+
+
 print("storage", st, "batch", N)
+if "--stride2" in sys.argv:
+    stride2()
+    sys.exit(0)
 print("%-8s %4s %5s %2s | %-26s | %-26s | %-20s" % ("blocks", "H", "C", "k", "fwd old / new (us)", "bwd-data+bn old / new", "wgrad old / new"))
 for name, H, Cc, k, plain in SHAPES:
     x = torch.randn(N, H, H, Cc, device=dev).to(st)

@@ -19,6 +19,10 @@
 // branch around a load), and the epilogue's operands (added gradient, the BatchNorm's input) are fetched before the
 // window loop, so that their latency hides behind the LDS traffic.  HBM-bound for k = 3; k = 5 (25 FMAs per element) is VALU / LDS-bound at
 // ~60 % of the HBM roofline.
+// Stride 2 (the four down-sampling blocks): forward and weight gradient step their window by 2 over an 8 x 8 output tile
+// (halo 19 x 19 at k = 5); the data gradient runs the stride-1 kernel over a ZERO-STUFFED tile of dy (source pixel v of the
+// up-sampled grid holds dy(v / 2) when v is even, else 0), which also folds the BatchNorm backward sums the strided path used
+// to take in a pass of its own.
 #include "bnref.h"
 
 namespace {
@@ -28,6 +32,7 @@ struct TileGeom {
     int P_t, P_l;                          // out(oh, ow) reads src(oh + i - P_t, ow + j - P_l), i, j in [0, K)
     int flip;                              // 1: tap of (i, j) is (K-1-i, K-1-j) (data gradient)
     int tiles_h, tiles_w;
+    int up;                                // 1: the source is dy of a stride-2 conv read through a zero-stuffed grid
 };
 
 // A workgroup = CQ channel quads x PTH = 256 / CQ pixel-threads; every pixel-thread owns a strip of SW output columns of
@@ -38,10 +43,10 @@ template <int CQ, int SW> struct TileShape {
     static constexpr int TH_ = PTH * SW / TW_;
 };
 
-template <int K, int CQ, int SW> struct Lds {
+template <int K, int CQ, int SW, int ST = 1> struct Lds {
     using S = TileShape<CQ, SW>;
-    static constexpr int ROWS = S::TH_ + K - 1;
-    static constexpr int COLS = S::TW_ + K - 1;
+    static constexpr int ROWS = (S::TH_ - 1) * ST + K;
+    static constexpr int COLS = (S::TW_ - 1) * ST + K;
     static constexpr int PITCH = (COLS | 1);           // pixels per LDS row, odd: rows r and r + 1 differ by half a bank sweep
     static constexpr int TILE_Q = ROWS * PITCH * CQ;   // f32x4 slots of the halo tile
     static constexpr int W_Q = K * K * CQ;             // f32x4 slots of the tap table
@@ -51,10 +56,10 @@ template <int K, int CQ, int SW> struct Lds {
 
 // Stage act(bn(src)) of the halo tile (zero outside the image).  Two phases: every load first (branch-free: an invalid
 // element re-reads a valid address and is zeroed afterwards), then transform + LDS store.
-template <typename T, int K, int CQ, int SW>
+template <typename T, int K, int CQ, int SW, int ST>
 __device__ __forceinline__ void stage_tile(const TileGeom& g, const T* __restrict__ src, const ud_bn_ref& bn, bool has_bn,
                                            const Bn4& cb, int n, int oh0, int ow0, int cq0, f32x4* tile) {
-    using L = Lds<K, CQ, SW>;
+    using L = Lds<K, CQ, SW, ST>;
     constexpr int PTH = L::S::PTH;
     const In4<T> s4{src};
     const int cq = threadIdx.x % CQ, p0 = threadIdx.x / CQ;
@@ -67,8 +72,14 @@ __device__ __forceinline__ void stage_tile(const TileGeom& g, const T* __restric
     for (int l = 0; l < L::NL; ++l) {
         const int p = p0 + l * PTH;
         const int r = p / L::COLS, c = p % L::COLS;
-        const int ih = oh0 + r - g.P_t, iw = ow0 + c - g.P_l;
-        const bool ok = cok && p < L::NPIX && ih >= 0 && ih < g.Hs && iw >= 0 && iw < g.Ws;
+        int ih = oh0 * ST + r - g.P_t, iw = ow0 * ST + c - g.P_l;
+        bool par = true;
+        if (g.up) {                                             // zero-stuffed grid: only even positions hold a sample
+            par = ((ih | iw) & 1) == 0;
+            ih >>= 1;
+            iw >>= 1;
+        }
+        const bool ok = cok && par && p < L::NPIX && ih >= 0 && ih < g.Hs && iw >= 0 && iw < g.Ws;
         const long pix = ok ? img + (long)ih * g.Ws + iw : img;
         v[l] = s4[pix * g.C4 + c4];
         okmask |= (ok ? 1u : 0u) << l;
@@ -103,16 +114,17 @@ __device__ __forceinline__ void stage_taps(const float* __restrict__ wt, int C4,
 // window loop and takes all 256 VGPRs
 template <int K, int SW> constexpr int kMinWaves = (K == 5 && SW == 8) ? 2 : (SW == 4 ? 4 : 3);
 
-template <typename T, int K, int CQ, int SW, int EPI>
+template <typename T, int K, int CQ, int SW, int EPI, int ST = 1>
 __global__ __launch_bounds__(NT, (kMinWaves<K, SW>)) void dw_tile_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in, int has_bn_in,
                                                      const float* __restrict__ wt, T* __restrict__ out,
                                                      const float* __restrict__ gate_alpha, int gate_mode,
                                                      const T* __restrict__ add, const T* __restrict__ xbn,
                                                      ud_bn_ref bn_out, int has_bn_out, double* __restrict__ part,
                                                      double* __restrict__ s1, double* __restrict__ s2) {
-    using L = Lds<K, CQ, SW>;
+    using L = Lds<K, CQ, SW, ST>;
     using S = TileShape<CQ, SW>;
     constexpr int PTH = S::PTH;
+    static_assert(ST == 1 || EPI != 2, "the strided data gradient runs the stride-1 kernel over a zero-stuffed tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* tile = reinterpret_cast<f32x4*>(smem);
     f32x4* taps = tile + L::TILE_Q;
@@ -143,25 +155,26 @@ __global__ __launch_bounds__(NT, (kMinWaves<K, SW>)) void dw_tile_kernel(TileGeo
     }
     Bn4 cbi;
     if (has_bn_in && cok) cbi = bn_load(bn_in, 0, g.C4, c4, blockIdx.x == 0 && p == 0);
-    stage_tile<T, K, CQ, SW>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
+    stage_tile<T, K, CQ, SW, ST>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
     stage_taps<K, CQ>(wt, g.C4, cq0, g.flip, taps);
     __syncthreads();
 
+    constexpr int NIN = (SW - 1) * ST + K;
     f32x4 acc[SW];
 #pragma unroll
     for (int i = 0; i < SW; ++i) acc[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        const f32x4* rowp = tile + ((row + i) * L::PITCH + col0) * CQ + cq;
-        f32x4 in[SW + K - 1], w[K];
+        const f32x4* rowp = tile + ((row * ST + i) * L::PITCH + col0 * ST) * CQ + cq;
+        f32x4 in[NIN], w[K];
 #pragma unroll
-        for (int j = 0; j < SW + K - 1; ++j) in[j] = rowp[j * CQ];
+        for (int j = 0; j < NIN; ++j) in[j] = rowp[j * CQ];
 #pragma unroll
         for (int j = 0; j < K; ++j) w[j] = taps[(i * K + j) * CQ + cq];
 #pragma unroll
         for (int o = 0; o < SW; ++o)
 #pragma unroll
-            for (int j = 0; j < K; ++j) acc[o] += in[o + j] * w[j];
+            for (int j = 0; j < K; ++j) acc[o] += in[o * ST + j] * w[j];
         // one window row at a time: pin the running sums here, or hipcc sinks every multiply-add below the LDS reads of
         // all K rows (K * (SW + K - 1) quads live at once) and spills
 #pragma unroll
@@ -237,12 +250,13 @@ __global__ __launch_bounds__(NT, (kMinWaves<K, SW>)) void dw_tile_kernel(TileGeo
 
 // Weight gradient: acc[tap] += src_tile[.. + tap] * dy over the workgroup's tiles (images n0, n0 + nstep, ...), folded over
 // its pixel-threads, one fp32 partial row [K*K][C] per workgroup for dw_tile_wgrad_finalize.
-template <typename T, int K, int CQ, int SW>
+template <typename T, int K, int CQ, int SW, int ST = 1>
 __global__ __launch_bounds__(NT, 2) void dw_tile_wgrad_kernel(TileGeom g, const T* __restrict__ src, ud_bn_ref bn_in,
                                                            int has_bn_in, const T* __restrict__ dy, int n_step,
                                                            float* __restrict__ part) {
-    using L = Lds<K, CQ, SW>;
+    using L = Lds<K, CQ, SW, ST>;
     using S = TileShape<CQ, SW>;
+    constexpr int NIN = (SW - 1) * ST + K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* tile = reinterpret_cast<f32x4*>(smem);
     const int cq = threadIdx.x % CQ, p = threadIdx.x / CQ;
@@ -272,21 +286,21 @@ __global__ __launch_bounds__(NT, 2) void dw_tile_wgrad_kernel(TileGeom g, const 
             gy[o] = dy4[gbase + (long)(ow < g.Wo ? ow : g.Wo - 1) * g.C4];
         }
         __syncthreads();                                       // previous tile fully consumed
-        stage_tile<T, K, CQ, SW>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
+        stage_tile<T, K, CQ, SW, ST>(g, src, bn_in, has_bn_in != 0, cbi, n, oh0, ow0, cq0, tile);
 #pragma unroll
         for (int o = 0; o < SW; ++o)
             if (!(cok && oh < g.Ho && ow0 + col0 + o < g.Wo)) gy[o] = f32x4{0, 0, 0, 0};
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            const f32x4* rowp = tile + ((row + i) * L::PITCH + col0) * CQ + cq;
-            f32x4 in[SW + K - 1];
+            const f32x4* rowp = tile + ((row * ST + i) * L::PITCH + col0 * ST) * CQ + cq;
+            f32x4 in[NIN];
 #pragma unroll
-            for (int j = 0; j < SW + K - 1; ++j) in[j] = rowp[j * CQ];
+            for (int j = 0; j < NIN; ++j) in[j] = rowp[j * CQ];
 #pragma unroll
             for (int j = 0; j < K; ++j)
 #pragma unroll
-                for (int o = 0; o < SW; ++o) acc[i][j] += in[o + j] * gy[o];
+                for (int o = 0; o < SW; ++o) acc[i][j] += in[o * ST + j] * gy[o];
 #pragma unroll
             for (int j = 0; j < K; ++j) asm volatile("" : "+v"(acc[i][j]));      // one window row at a time (see dw_tile_kernel)
         }
@@ -362,11 +376,11 @@ template <int CQ, int SW> inline void tile_counts(int Ho, int Wo, int& th, int& 
     tw = ud_cdiv(Wo, TileShape<CQ, SW>::TW_);
 }
 
-template <typename T, int K, int CQ, int SW>
+template <typename T, int K, int CQ, int SW, int ST = 1>
 int launch_tile(TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* wt, T* out, const float* gate_alpha,
                 int gate_mode, const T* add, const T* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2,
                 double* ws, hipStream_t s) {
-    using L = Lds<K, CQ, SW>;
+    using L = Lds<K, CQ, SW, ST>;
     tile_counts<CQ, SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
     const long nt = (long)g.N * g.tiles_h * g.tiles_w;
     if (nt > 0x7fffffffL) return UD_EINVAL;
@@ -382,11 +396,12 @@ int launch_tile(TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* w
     // finalize launch — the rule of fused.hip's plan_reduce
     const bool use_part = sums && nt > 64;
 #define UD_TILE(E)                                                                                                    \
-    hipLaunchKernelGGL((dw_tile_kernel<T, K, CQ, SW, E>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, wt, out, \
-                       gate_alpha, gate_mode, add, xbn, bo, bn_out ? 1 : 0, use_part ? ws : nullptr, s1, s2)
+    hipLaunchKernelGGL((dw_tile_kernel<T, K, CQ, SW, E, ST>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, wt,   \
+                       out, gate_alpha, gate_mode, add, xbn, bo, bn_out ? 1 : 0, use_part ? ws : nullptr, s1, s2)
     if (epi == 0) UD_TILE(0);
     else if (epi == 1) UD_TILE(1);
-    else UD_TILE(2);
+    else if constexpr (ST == 1) UD_TILE(2);
+    else return UD_EINVAL;
 #undef UD_TILE
     UD_LAUNCH_CHECK();
     if (use_part) {
@@ -397,10 +412,10 @@ int launch_tile(TileGeom g, const T* src, const ud_bn_ref* bn_in, const float* w
     return 0;
 }
 
-template <typename T, int K, int CQ, int SW>
+template <typename T, int K, int CQ, int SW, int ST = 1>
 int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, const float* gate_alpha, int gate_mode,
                  float* part, long part_rows, float* dw, hipStream_t s) {
-    using L = Lds<K, CQ, SW>;
+    using L = Lds<K, CQ, SW, ST>;
     tile_counts<CQ, SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
     const int tiles = g.tiles_h * g.tiles_w;
     const int cblocks = ud_cdiv(g.C4, CQ);
@@ -416,8 +431,8 @@ int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, 
     ud_bn_ref none{};
     const ud_bn_ref& bi = bn_in ? *bn_in : none;
     dim3 grid((unsigned)nparts, (unsigned)cblocks);
-    hipLaunchKernelGGL((dw_tile_wgrad_kernel<T, K, CQ, SW>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, dy, n_step,
-                       part);
+    hipLaunchKernelGGL((dw_tile_wgrad_kernel<T, K, CQ, SW, ST>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, dy,
+                       n_step, part);
     UD_LAUNCH_CHECK();
     const int KKC = K * K * g.C4 * 4;
     hipLaunchKernelGGL(dw_tile_wgrad_finalize, dim3(ud_cdiv(KKC, 64)), dim3(NT), 0, s, (int)nparts, K * K, g.C4 * 4, part,
@@ -444,20 +459,27 @@ long ud_dwtile_wgrad_part_rows(int N, int Ho, int Wo) {
 
 int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* out, int N, int Hs, int Ws, int C, int Ho,
               int Wo, int K, int P_t, int P_l, int flip, const float* gate_alpha, int gate_mode, const void* add,
-              const void* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2, double* ws, int f16,
-              ud_stream_t stream) {
+              const void* xbn, const ud_bn_ref* bn_out, int epi, double* s1, double* s2, double* ws, int stride,
+              int f16, ud_stream_t stream) {
     if (!tile_args_ok(N, Hs, Ws, C, Ho, Wo, K) || !src || !wt || !out || epi < 0 || epi > 2) return UD_EINVAL;
+    if (stride != 1 && stride != 2) return UD_EINVAL;
+    if (stride == 2 && ((flip != 0) != (epi == 2))) return UD_EINVAL;      // strided: forward (epi 0 / 1) or data gradient
     if (bn_in && bn_in->G != 1) return UD_EINVAL;
     if (epi != 2 && (add || xbn || bn_out || gate_mode)) return UD_EINVAL;
     if (bn_out && (!xbn || bn_out->G != 1)) return UD_EINVAL;
     if ((epi == 1 || bn_out) && (!s1 || !s2 || !ws)) return UD_EINVAL;
-    TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, flip ? 1 : 0, 0, 0};
+    // stride 2: the forward steps its window by 2 (8 x 8 output tiles); the data gradient reads dy through a zero-stuffed grid
+    TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, flip ? 1 : 0, 0, 0, (stride == 2 && flip) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     const bool sm = small_map(Ho, Wo, C);
-#define UD_GO(KK, QQ, SS)                                                                                             \
-    UD_STORAGE_DISPATCH(f16, return (launch_tile<T, KK, QQ, SS>(g, (const T*)src, bn_in, wt, (T*)out, gate_alpha,     \
-                                                                gate_mode, (const T*)add, (const T*)xbn, bn_out, epi, \
-                                                                s1, s2, ws, s)))
+#define UD_GO(KK, QQ, SS, ...)                                                                                        \
+    UD_STORAGE_DISPATCH(f16, return (launch_tile<T, KK, QQ, SS, ##__VA_ARGS__>(g, (const T*)src, bn_in, wt, (T*)out,  \
+                                                                gate_alpha, gate_mode, (const T*)add, (const T*)xbn,  \
+                                                                bn_out, epi, s1, s2, ws, s)))
+    if (stride == 2 && !flip) {
+        if (K == 3) UD_GO(3, 8, 2, 2);
+        UD_GO(5, 8, 2, 2);
+    }
     // the data gradient (epi 2) keeps its epilogue operands in registers next to the window: strips of 4 (16 x 8 tiles)
     if (K == 3) { if (sm) UD_GO(3, 16, 4); if (epi == 2) UD_GO(3, 8, 4); UD_GO(3, 8, 8); }
     if (sm) UD_GO(5, 16, 4);
@@ -468,15 +490,20 @@ int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* ou
 
 int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, const float* gate_alpha, int gate_mode,
                     float* dwt, float* part, long part_rows, int N, int Hs, int Ws, int C, int Ho, int Wo, int K, int P_t,
-                    int P_l, int f16, ud_stream_t stream) {
+                    int P_l, int stride, int f16, ud_stream_t stream) {
     if (!tile_args_ok(N, Hs, Ws, C, Ho, Wo, K) || !src || !dy || !dwt || !part || part_rows < 1) return UD_EINVAL;
     if (bn_in && bn_in->G != 1) return UD_EINVAL;
-    TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, 0, 0, 0};
+    if (stride != 1 && stride != 2) return UD_EINVAL;
+    TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, 0, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     const bool sm = small_map(Ho, Wo, C);
-#define UD_WG(KK, QQ, SS)                                                                                             \
-    UD_STORAGE_DISPATCH(f16, return (launch_wgrad<T, KK, QQ, SS>(g, (const T*)src, bn_in, (const T*)dy, gate_alpha,   \
-                                                                 gate_mode, part, part_rows, dwt, s)))
+#define UD_WG(KK, QQ, SS, ...)                                                                                        \
+    UD_STORAGE_DISPATCH(f16, return (launch_wgrad<T, KK, QQ, SS, ##__VA_ARGS__>(g, (const T*)src, bn_in, (const T*)dy, \
+                                                                 gate_alpha, gate_mode, part, part_rows, dwt, s)))
+    if (stride == 2) {
+        if (K == 3) UD_WG(3, 8, 2, 2);
+        UD_WG(5, 8, 2, 2);
+    }
     // 5 x 5: 25 accumulator quads per thread — strips of 4 (16 x 8 tiles) keep the kernel clear of spills
     if (K == 3) { if (sm) UD_WG(3, 16, 4); UD_WG(3, 8, 8); }
     if (sm) UD_WG(5, 16, 4);

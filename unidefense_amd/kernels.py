@@ -1559,8 +1559,8 @@ def _bnp(bn, update=False):
     return C.byref(bn.ref(update)) if bn is not None else None
 
 
-def dwtile_fwd(x, wt, K, pad_t, pad_l, Ho, Wo, bn=None, stats=None, update=False):
-    """y = dwconv(act(bn(x))) (bn: DeferredBN or None), stride 1; stats: 2C zeroed doubles that receive sum y | sum y^2."""
+def dwtile_fwd(x, wt, K, pad_t, pad_l, Ho, Wo, bn=None, stats=None, update=False, stride=1):
+    """y = dwconv(act(bn(x))) (bn: DeferredBN or None), stride 1 / 2; stats: 2C zeroed doubles that receive sum y | sum y^2."""
     h = _act(x)
     _chk(wt)
     N, H, W, Cc = x.shape
@@ -1570,11 +1570,12 @@ def dwtile_fwd(x, wt, K, pad_t, pad_l, Ho, Wo, bn=None, stats=None, update=False
         ws = _ws64(x, _call("ud_dwtile_ws_doubles", N, Ho, Wo, Cc))
     _call("ud_dwtile", _p(x), _bnp(bn, update), _p(wt), _p(y), N, H, W, Cc, Ho, Wo, K, pad_t, pad_l, 0, None, 0, None, None,
           None, 1 if stats is not None else 0, _pd(stats) if stats is not None else None,
-          _pd(stats, Cc) if stats is not None else None, ws, h, _stream())
+          _pd(stats, Cc) if stats is not None else None, ws, int(stride), h, _stream())
     return y
 
 
-def dwtile_bwd_data(dy, wt, K, pad_t, pad_l, H, W, gate_alpha=None, gate_mode=0, add=None, x=None, bn=None, sacc=None):
+def dwtile_bwd_data(dy, wt, K, pad_t, pad_l, H, W, gate_alpha=None, gate_mode=0, add=None, x=None, bn=None, sacc=None,
+                    stride=1):
     """da = gate * dwconv_bwd_data(dy) [+ add]; with (x, bn, sacc): dz = da * act'(bn(x)), sacc += BatchNorm backward sums."""
     h = _act(dy, add, x)
     _chk(wt)
@@ -1585,14 +1586,14 @@ def dwtile_bwd_data(dy, wt, K, pad_t, pad_l, H, W, gate_alpha=None, gate_mode=0,
         ws = _ws64(dy, _call("ud_dwtile_ws_doubles", N, H, W, Cc))
     _call("ud_dwtile", _p(dy), None, _p(wt), _p(out), N, Ho, Wo, Cc, H, W, K, K - 1 - pad_t, K - 1 - pad_l, 1,
           _p(gate_alpha), int(gate_mode), _p(add), _p(x) if bn is not None else None, _bnp(bn), 2,
-          _pd(sacc) if bn is not None else None, _pd(sacc, Cc) if bn is not None else None, ws, h, _stream())
+          _pd(sacc) if bn is not None else None, _pd(sacc, Cc) if bn is not None else None, ws, int(stride), h, _stream())
     return out
 
 
 _DWTILE_PART = {}
 
 
-def dwtile_bwd_weight(x, dy, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0):
+def dwtile_bwd_weight(x, dy, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0, stride=1):
     """dw[C, K*K] = gate * sum act(bn(x))(window) * dy, stride 1; x: the conv's RAW input when bn is given."""
     h = _act(x, dy)
     N, H, W, Cc = x.shape
@@ -1604,5 +1605,5 @@ def dwtile_bwd_weight(x, dy, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mod
         part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
     dwt = empty((Cc, K * K), x)
     _call("ud_dwtile_wgrad", _p(x), _bnp(bn), _p(dy), _p(gate_alpha), int(gate_mode), _p(dwt), _p(part), rows, N, H, W, Cc,
-          Ho, Wo, K, pad_t, pad_l, h, _stream())
+          Ho, Wo, K, pad_t, pad_l, int(stride), h, _stream())
     return dwt

@@ -224,8 +224,17 @@ _DW_TILED = True
 
 def _dw_tile_policy(sf, k, stride, H, half):
     """(forward, weight gradient, data gradient) on the tiled kernels?"""
-    if not _DW_TILED or stride != 1:
+    if not _DW_TILED:
         return False, False, False
+    if stride == 2:
+        # the four down-sampling blocks (profiles/r03/dwtile_stride2.txt).  Data gradient through the zero-stuffed tile, with
+        # the BatchNorm sums in its epilogue instead of a pass of their own: 189 -> 88, 59 -> 40, 57 -> 32 us (fp32), but not
+        # on the 128 x 128 map in half storage (630 -> 699); forward 271 -> 130 us on the plain 128 x 128 block (incl. the
+        # BatchNorm apply + statistics passes it absorbs), otherwise only on the large maps; weight gradient: half storage
+        # (515 -> 177, 208 -> 100 us) and the plain block, the strip kernel elsewhere (49 vs 63 us)
+        if half:
+            return True, True, H < 128
+        return (not sf) or H >= 64, not sf, True
     if half:
         return True, True, True
     fwd = not (k == 5 and H <= 8)
@@ -905,7 +914,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         else:
             xf, a = K.rfft2(src, s_f, 1.0), src
         if t_fwd:
-            spat = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn)
+            spat = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn, stride=stride)
         else:
             spat = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
         Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
@@ -924,7 +933,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         if t_fwd:
             # halo tile staged in LDS with swish(bn0(e)) applied on the way in; BN1 statistics out of the epilogue
             a = None
-            d = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn, stats=acc1, update=True)
+            d = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn, stats=acc1, update=True, stride=stride)
         else:
             # the strip kernel (and its weight gradient) re-reads its input per tap: materialise the activation
             a = K.bn_apply(src, src_bn, 1, M, update=True) if src_bn is not None else src
@@ -1009,14 +1018,14 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         tape.add_param_grad(blk._bn1.bias, db1)
         if t_wg:
             tape.add_param_grad(dwm.weight, K.dwtile_bwd_weight(src, g_sp, k, pt, pl, bn=src_bn, gate_alpha=g_alpha,
-                                                                gate_mode=g_mode))
+                                                                gate_mode=g_mode, stride=stride))
         else:
             tape.add_param_grad(dwm.weight, K.dwconv_bwd_weight_ex(a, g_sp, g_alpha, g_mode, k, stride, pt, pl))
         # ---- depthwise data gradient (+ spectral branch), through swish(bn0(.)) when the input is deferred
         if src_bn is not None:
             sb0 = K.zeros64(2 * src.shape[-1], x)
             if t_bwd:
-                dz0 = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, da_f, src, src_bn, sb0)
+                dz0 = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, da_f, src, src_bn, sb0, stride=stride)
                 is_dz = True
             elif stride == 1:
                 dz0 = K.dwconv_bwd_data_bn(g_sp, g_alpha, g_mode, wt, da_f, src, src_bn, k, stride, pt, pl, sb0)
@@ -1047,7 +1056,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
             else:
                 skip_done = not sp.skip
             if t_bwd:
-                dx = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, add)
+                dx = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, add, stride=stride)
             else:
                 dx = K.dwconv_bwd_data_ex(g_sp, g_alpha, g_mode, wt, add, k, stride, pt, pl, H, W)
             if not skip_done:
