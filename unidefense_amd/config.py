@@ -17,6 +17,10 @@ not when they are imported.  Anything not listed here is a compile-time constant
 | hip_adamw | UD_HIP_ADAMW | 1 | build_optimizer returns the multi-tensor HIP AdamW for 'adamw' on the GPU |
 | wgrad_stream | UD_WGRAD_STREAM | 0 | weight-gradient kernels on a second stream (measured slower; kept for A/B) |
 | lib_path | UD_LIB_PATH | unset | load another build of libunidefense_hip.so (A/B of kernel builds) |
+
+The shared library itself reads three variables when it is loaded, for hosts that do not go through Python:
+UD_GEMM_PATH (the initial `ud_gemm_set_path` value: 0 auto, 1 fp32 pipe, 2 split-bf16 everywhere, 3 fp16 MFMA) and the
+kernel-bench overrides UD_GEMM_CFG / UD_GEMM_X3_CFG (force one tile configuration; tools/bench_gemm.py).
 """
 import os
 from dataclasses import dataclass, fields

@@ -52,9 +52,9 @@ inline RedGeom make_geom_ex(int G, int R, int C, long target_blocks, long max_p,
     RedGeom q;
     q.G = G; q.R = R; q.C4 = C / 4;
     // float4 columns per workgroup: 16 (256-byte row segments, 16 rows per iteration) measured best on the bench
-    // (8: +0.4 %, 32: +0.4 %, 64: +0.5 %, 128: +1.1 % step time); UD_RED_CW overrides.  The columns are spread
+    // (8: +0.4 %, 32: +0.4 %, 64: +0.5 %, 128: +1.1 % step time).  The columns are spread
     // evenly over the groups (C4 = 36 -> 3 groups of 12, not 16 + 16 + 4 with a quarter-filled last workgroup).
-    static const int cw_max = getenv("UD_RED_CW") ? atoi(getenv("UD_RED_CW")) : 16;
+    constexpr int cw_max = 16;
     const int ngroups = (q.C4 + cw_max - 1) / cw_max;
     q.CW = (q.C4 + ngroups - 1) / ngroups;
     q.rpi = UD_COL_NT / q.CW;

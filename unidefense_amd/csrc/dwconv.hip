@@ -20,39 +20,6 @@ struct DwGeom {
 };
 
 template <typename T, int K>
-__global__ __launch_bounds__(NT) void dw_fwd(DwGeom q, const T* __restrict__ x, const float* __restrict__ wt,
-                                             T* __restrict__ y) {
-    const In4<T> x4{x};
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(wt);
-    const Out4<T> y4{y};
-    const long total = (long)q.N * q.Ho * q.Wo * q.C4;
-    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
-        int c4 = (int)(e % q.C4);
-        long pix = e / q.C4;
-        int wo = (int)(pix % q.Wo);
-        long t = pix / q.Wo;
-        int ho = (int)(t % q.Ho);
-        int n = (int)(t / q.Ho);
-        const int ih0 = ho * q.stride - q.pad_t, iw0 = wo * q.stride - q.pad_l;
-        f32x4 acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
-            int ih = ih0 + kh;
-            if (ih < 0 || ih >= q.H) continue;
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                int iw = iw0 + kw;
-                if (iw < 0 || iw >= q.W) continue;
-                f32x4 a = x4[(((long)n * q.H + ih) * q.W + iw) * q.C4 + c4];
-                f32x4 w = w4[(kh * K + kw) * q.C4 + c4];
-                acc += a * w;
-            }
-        }
-        y4.st(e, acc);
-    }
-}
-
-template <typename T, int K>
 __global__ __launch_bounds__(NT) void dw_bwd_data(DwGeom q, const T* __restrict__ dy, const float* __restrict__ wt,
                                                   const T* __restrict__ add, T* __restrict__ dx) {
     const In4<T> dy4{dy}, add4{add};
@@ -342,15 +309,8 @@ int ud_dwconv_fwd(const void* xv, const float* wt, void* yv, int N, int H, int W
     if (C % 4) return UD_EINVAL;
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!geom_ok(q, K)) return UD_EINVAL;
-    static const bool plain = getenv("UD_DW_PLAIN") != nullptr;       // tuning aid: the one-output-per-thread kernels
     hipStream_t s = (hipStream_t)stream;
-    if (plain) {
-        long total = (long)N * Ho * Wo * q.C4;
-        dim3 g(ew_blocks(total));
-        UD_STORAGE_DISPATCH(f16, const T* x = (const T*)xv; T* y = (T*)yv;
-                            if (K == 3) hipLaunchKernelGGL((dw_fwd<T, 3>), g, dim3(NT), 0, s, q, x, wt, y);
-                            else hipLaunchKernelGGL((dw_fwd<T, 5>), g, dim3(NT), 0, s, q, x, wt, y));
-    } else {
+    {
         long total = (long)N * Ho * ((Wo + TW - 1) / TW) * q.C4;
         dim3 g(ew_blocks(total));
         UD_STORAGE_DISPATCH(f16, const T* x = (const T*)xv; T* y = (T*)yv;
@@ -368,9 +328,8 @@ int ud_dwconv_bwd_data(const void* dyv, const float* wt, const void* addv, void*
     if (C % 4) return UD_EINVAL;
     DwGeom q{N, H, W, C / 4, Ho, Wo, stride, pad_t, pad_l};
     if (!geom_ok(q, K)) return UD_EINVAL;
-    static const bool plain = getenv("UD_DW_PLAIN") != nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (stride == 1 && !plain) {
+    if (stride == 1) {
         long total = (long)N * H * ((W + TW - 1) / TW) * q.C4;
         dim3 g(ew_blocks(total));
         UD_STORAGE_DISPATCH(f16, const T* dy = (const T*)dyv; const T* add = (const T*)addv; T* dx = (T*)dxv;

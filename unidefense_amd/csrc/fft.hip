@@ -173,7 +173,7 @@ __device__ __forceinline__ void fft_inreg(float (&re)[S], float (&im)[S]) {
 // sample) = blockIdx map the channel groups that share a 128-byte line of a pixel (CB = 8 / 16 channels: 32 / 64-byte
 // runs) land on different XCDs and every one of them pulls the whole line into its own L2.  Here XCD j works through a
 // CONTIGUOUS range of the (sample, channel group) items: neighbouring channel groups of a sample meet in one L2.
-// (UD_FFT_XCD=0 restores the plain order — A/B switch read on the host and passed as xcd_remap.)
+// (applied only where a workgroup's run of channels is shorter than a 128-byte line; passed as xcd_remap.)
 __device__ __forceinline__ void work_item(int xcd_remap, int& cgroup, int& n) {
     const int ngroups = gridDim.x;
     if (!xcd_remap) {
@@ -404,8 +404,7 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const T* __restrict__ Y, T* 
 
 // remap only where a workgroup's run of channels is shorter than a 128-byte line
 inline int xcd_remap_on(int run_bytes) {
-    static const bool on = !getenv("UD_FFT_XCD") || atoi(getenv("UD_FFT_XCD")) != 0;
-    return on && run_bytes < 128;
+    return run_bytes < 128;
 }
 
 struct RfftEx {

@@ -670,8 +670,8 @@ struct RedPlan {
 };
 inline RedPlan plan_reduce(int G, int R, int C, bool per_group, const double* ws, int min_rows = 8,
                            int row_elems = 1) {
-    static const int lim = getenv("UD_ATOMIC_CONTRIB") ? atoi(getenv("UD_ATOMIC_CONTRIB")) : 64;
-    static const long big_elems = getenv("UD_ATOMIC_BIG") ? atol(getenv("UD_ATOMIC_BIG")) : (1L << 20);
+    constexpr int lim = 64;                 // most contributions per column that still go through fp64 atomics
+    constexpr long big_elems = 1L << 20;
     RedGeom qa = make_geom_ex(G, R, C, 1024, lim, min_rows);
     const long contrib = per_group ? qa.P : (long)qa.G * qa.P;
     // >= 16 MB (row_elems pixels per row item): the pass is bandwidth-bound and wants ~2000 workgroups; its finalize

@@ -370,8 +370,7 @@ int launch_cfg(const ud_gemm_desc& d, int a_vec, int b_vec, hipStream_t s) {
     // measured (tools/bench_gemm.py) 1280x3264x3264 = 510 tiles pads to 768 workgroups and drops from 94 to
     // 72 TFLOP/s when patched, while 4096^3 (1024 tiles, no padding) gains ~3 %
     unsigned gx = (unsigned)(tiles_m * tiles_n);
-    static const bool nopatch = getenv("UD_GEMM_NOPATCH") != nullptr;     // tuning aid
-    if (tiles_m * tiles_n >= 1024 && !nopatch) {
+    if (tiles_m * tiles_n >= 1024) {
         int patches = ud_cdiv(tiles_m, PATCH_M) * ud_cdiv(tiles_n, PATCH_N);
         unsigned padded = (unsigned)(ud_cdiv(patches, 8) * 8 * PATCH_M * PATCH_N);
         if (padded != gx && padded <= gx + gx / 16) gx = padded;   // (equal sizes read as 'plain order': fine too)
@@ -457,7 +456,7 @@ static bool takes_x3(const ud_gemm_desc& d, int a_vec, int b_vec) {
     if (d.half_mask) return ud_gemm_x3_eligible(d, a_vec != 0, b_vec != 0);     // ud_gemm rejects the others
     const int path = g_path.load();
     if (path == 1 || !ud_gemm_x3_eligible(d, a_vec != 0, b_vec != 0)) return false;
-    static const int min_dim = getenv("UD_GEMM_X3_MINDIM") ? atoi(getenv("UD_GEMM_X3_MINDIM")) : 16;
+    constexpr int min_dim = 16;
     return path == 2 || path == 3 || (d.M >= min_dim && d.N >= min_dim && d.K >= min_dim);
 }
 

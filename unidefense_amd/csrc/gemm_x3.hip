@@ -558,13 +558,11 @@ int launch_modes(const ud_gemm_desc& d, hipStream_t s) {
 bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
     if (d.a_mode == 2 && d.b_mode == 0) {
         // implicit-GEMM conv (forward and data gradient of the 3x3 / transposed convs): Cin % 4 == 0 (a_vec), batch 1
-        static const bool on = !getenv("UD_X3_GATHER") || atoi(getenv("UD_X3_GATHER")) != 0;
-        return on && a_vec && b_vec && d.K % 4 == 0 && d.batch == 1;
+        return a_vec && b_vec && d.K % 4 == 0 && d.batch == 1;
     }
     if (d.a_mode == 1 && d.b_mode == 2) {
         // weight gradient of a conv: dY^T (row-contiguous A) x gathered input (B rows = (tap, ci)); Cin % 4 == 0 (b_vec)
-        static const bool on = !getenv("UD_X3_WGRAD_GATHER") || atoi(getenv("UD_X3_WGRAD_GATHER")) != 0;
-        return on && a_vec && b_vec && d.M % 4 == 0 && d.batch == 1;
+        return a_vec && b_vec && d.M % 4 == 0 && d.batch == 1;
     }
     if (d.a_mode > 1 || d.b_mode > 1) return false;
     if (!(d.a_mode == 0 && d.b_mode == 0) && !(d.a_mode == 0 && d.b_mode == 1) && !(d.a_mode == 1 && d.b_mode == 1))
