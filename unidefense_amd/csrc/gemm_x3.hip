@@ -331,23 +331,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
+    // tile_cfg bit 9: STREAM-K.  The launch is gridDim.x persistent workgroups (two per CU) and the (tile, K-tile)
+    // iteration space, tile-major, is cut into gridDim.x equal runs: a workgroup works through its run segment by
+    // segment (a segment = the part of the run inside one tile) and adds each partial tile atomically (out_mode 2), so
+    // the chip finishes together whatever the tile count — 260 tiles split three ways are 780 workgroups for 512
+    // slots, 3.05 per CU with some CUs holding 4: a quarter of the launch is tail.
+    const bool streamk = (d.tile_cfg & 0x200) != 0;
+    const int kt_total = (d.K + BK - 1) / BK;
+    long it = 0, it_end = 0;
+    if (streamk) {
+        const long total = (long)tiles_m * tiles_n * kt_total;
+        it = (long)blockIdx.x * total / gridDim.x;
+        it_end = (long)(blockIdx.x + 1) * total / gridDim.x;
+        if (it >= it_end) return;
+    }
+  for (;;) {
     // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8), each with its own 4 MiB L2.  With
     // tile_cfg bit 8 every XCD gets one CONTIGUOUS range of the (column-major) tile order instead of every eighth tile, so
     // that the A / B panels its workgroups share are fetched into ONE L2 (a bijection for any tile count: no padding).
-    int bt = blockIdx.x;
-    if (d.tile_cfg & 0x100) {
-        const int T = tiles_m * tiles_n, q = T >> 3, r = T & 7, x = bt & 7;
-        bt = x * q + (x < r ? x : r) + (bt >> 3);
+    int bt = blockIdx.x, split = blockIdx.y, k_begin, k_end;
+    const int bz = blockIdx.z;
+    if (streamk) {
+        bt = (int)(it / kt_total);
+        const int kt0 = (int)(it - (long)bt * kt_total);
+        const long left = it_end - it;
+        const int n = left < (long)(kt_total - kt0) ? (int)left : kt_total - kt0;
+        k_begin = kt0 * BK;
+        k_end = (kt0 + n) * BK;
+        it += n;
+        split = 0;
+    } else {
+        if (d.tile_cfg & 0x100) {
+            const int T = tiles_m * tiles_n, q = T >> 3, r = T & 7, x = bt & 7;
+            bt = x * q + (x < r ? x : r) + (bt >> 3);
+        }
+        const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
+        k_begin = split * kt_per * BK;
+        k_end = k_begin + kt_per * BK;
     }
+    if (k_end > d.K) k_end = d.K;
     const int tile_m = bt % tiles_m, tile_n = bt / tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y, bz = blockIdx.z;
-
-    const int kt_total = (d.K + BK - 1) / BK;
-    const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
-    const int k_begin = split * kt_per * BK;
-    int k_end = k_begin + kt_per * BK;
-    if (k_end > d.K) k_end = d.K;
     const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
     float* Cp = d.C + (long)bz * d.strideC + (d.out_mode == 3 ? (long)split * d.slice_stride : 0L);   // mode 3: own slice
 
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (nkt == 0 && (d.out_mode == 1 || d.out_mode == 2)) return;          // (modes 0 / 3 store the zeros)
+    if (nkt == 0 && (d.out_mode == 1 || d.out_mode == 2)) return;          // (modes 0 / 3 store the zeros; never stream-K)
     const bool c_half = (d.half_mask & 4) != 0;
     if (c_half) {          // statistics and consumers see the rounded values
 #pragma unroll
@@ -502,12 +526,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
             }
         }
     }
+    if (!streamk || it >= it_end) break;
+  }
 }
 
 template <int BM, int BN, int AMODE, int BMODE, int PREC, bool AH = false, bool BH = false>
 int launch_tile(const ud_gemm_desc& d, hipStream_t s) {
     int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, (unsigned)d.batch);
+    if (d.tile_cfg & 0x200) {          // stream-K (ud_gemm checked: out_mode 2, split_k 1, batch 1, no statistics)
+        const long total = (long)tiles_m * tiles_n * ud_cdiv(d.K, BK);
+        long wgs = (d.tile_cfg >> 16) & 0x7fff;
+        if (wgs == 0) wgs = 2L * ud_num_cus();
+        grid = dim3((unsigned)(wgs < total ? wgs : total), 1, 1);
+    }
     hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, 2, 2, AMODE, BMODE, PREC, AH, BH>), grid, dim3(NTHREADS), 0, s, d, tiles_m,
                        tiles_n);
     UD_LAUNCH_CHECK();
