@@ -46,12 +46,27 @@ __device__ __forceinline__ uint32_t pack_f16(float x, float y) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
-// exact three-way split of two floats; p[i] packs piece i of (x, y)
+__device__ __forceinline__ bf16x2 opaque_bf16x2(uint32_t bits) {
+    asm volatile("" : "+s"(bits));
+    return __builtin_bit_cast(bf16x2, bits);
+}
+
+// exact three-way split of two floats; p[i] packs piece i of (x, y).  A residual x - float(bf16(x)) is ONE
+// v_dot2c_f32_bf16: acc = x, acc += piece.lo * (-1) + piece.hi * 0 — the packed piece is used as it is (no shift / mask
+// to turn a half back into a float, no subtract): 7 vector instructions per pair instead of 11.  Exact: the product is
+// the piece itself and the difference is representable (it is the rounding error of the piece).
 __device__ __forceinline__ void split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    p0 = pack_bf16(x, y);
-    float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
-    p1 = pack_bf16(rx, ry);
-    float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xffff0000u);
+    // the selectors {-1, 0} / {0, -1} live in scalar registers: written as literals, hipcc encodes {-1, 0} as the inline
+    // constant -1.0, which this instruction reads as the fp32 pattern 0xbf800000 = {0, -1} (tools/native/check_dot2c.hip)
+    const bf16x2 sel_lo = opaque_bf16x2(0x0000bf80u), sel_hi = opaque_bf16x2(0xbf800000u);
+    const bf16x2 h = {(__bf16)x, (__bf16)y};
+    const float rx = __builtin_amdgcn_fdot2_f32_bf16(h, sel_lo, x, false);
+    const float ry = __builtin_amdgcn_fdot2_f32_bf16(h, sel_hi, y, false);
+    const bf16x2 m = {(__bf16)rx, (__bf16)ry};
+    const float sx = __builtin_amdgcn_fdot2_f32_bf16(m, sel_lo, rx, false);
+    const float sy = __builtin_amdgcn_fdot2_f32_bf16(m, sel_hi, ry, false);
+    p0 = __builtin_bit_cast(uint32_t, h);
+    p1 = __builtin_bit_cast(uint32_t, m);
     p2 = pack_bf16(sx, sy);
 }
 
@@ -123,6 +138,39 @@ struct XLoader {
     int g_img, g_oh, g_ow;
     int g_nbase[NV0 > 2 ? NV0 : 2], g_ih0[NV0 > 2 ? NV0 : 2], g_iw0[NV0 > 2 ? NV0 : 2];
     unsigned vmask[PD];
+    // FAST path (MODE 0 / 1, a workgroup whose rows are all inside the operand and whose K range is whole tiles): the
+    // address of a load is a UNIFORM pointer (operand base + this tile's k, in scalar registers) plus a per-thread 32-bit
+    // element offset fixed for the whole kernel — no per-load vector arithmetic (the general path pays a clamp, a 64-bit
+    // add and, for the row-contiguous operand, a quarter-rate 32-bit multiply per load) and no validity selects at store
+    // time (one v_cndmask per element there).
+    unsigned voff[NV];
+
+    // can this workgroup take the FAST path for this operand?  (uniform; voff is a BYTE offset below 2^31)
+    __device__ __forceinline__ static bool fast_ok(long ld_, int dim, int row0, int k_begin, int k_end) {
+        if constexpr (MODE > 1) return false;
+        return row0 + ROWS <= dim && (k_end - k_begin) % BK == 0 &&
+               (MODE == 0 ? (long)dim * ld_ : 16 * ld_ + dim) * (long)sizeof(E) < (1L << 31);
+    }
+
+    __device__ __forceinline__ void init_fast(int row0, int tid) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < NV0; ++i)
+                voff[i] = (unsigned)(((row0 + ((tid + i * NTHREADS) >> 2)) * ld + (tid & 3) * 4) * (long)sizeof(E));
+        } else if constexpr (MODE == 1) {
+            const int q = (tid >> 5) * 4 + (tid & 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                voff[i] = (unsigned)(((2 * ((tid >> 2) & 7) + i) * ld + row0 + q * VEC) * (long)sizeof(E));
+        }
+    }
+
+    template <int S>
+    __device__ __forceinline__ void load_fast(int k0) {
+        const char* ub = reinterpret_cast<const char*>(MODE == 0 ? base + k0 : base + (long)k0 * ld);     // uniform
+#pragma unroll
+        for (int i = 0; i < NV; ++i) regs[S][i] = *reinterpret_cast<const V*>(ub + voff[i]);
+    }
 
     __device__ __forceinline__ void init(const float* p, long ld_, int dim, int row0, int k_end, int tid,
                                          const ud_conv_geom& geom, int k_begin) {
@@ -266,14 +314,14 @@ struct XLoader {
         }
     }
 
-    template <int S>
+    template <int S, bool FAST = false>
     __device__ __forceinline__ void store(char* L, int tid, int k0) const {
         if constexpr (KC) {
 #pragma unroll
             for (int i = 0; i < NV0; ++i) {
                 int f = tid + i * NTHREADS;
                 int row = f >> 2, kq = f & 3;
-                const bool ok = MODE == 2 ? ((vmask[S] >> i) & 1u) != 0 : rowok[i] && (k0 + kq * 4 <= k_last);
+                const bool ok = FAST ? true : MODE == 2 ? ((vmask[S] >> i) & 1u) != 0 : rowok[i] && (k0 + kq * 4 <= k_last);
                 V v = regs[S][i];
                 char* p = L + (kq >> 1) * GS + phys_row(row) * 16 + (kq & 1) * 8;
                 if constexpr (H) {
@@ -293,8 +341,8 @@ struct XLoader {
             }
         } else {
             const int q = (tid >> 5) * 4 + (tid & 3), kb = (tid >> 2) & 7;
-            const bool ok0 = MODE == 3 ? (vmask[S] & 1u) != 0 : rowok[0] && (k0 + kloc <= k_last);
-            const bool ok1 = MODE == 3 ? (vmask[S] & 2u) != 0 : rowok[0] && (k0 + kloc + 1 <= k_last);
+            const bool ok0 = FAST ? true : MODE == 3 ? (vmask[S] & 1u) != 0 : rowok[0] && (k0 + kloc <= k_last);
+            const bool ok1 = FAST ? true : MODE == 3 ? (vmask[S] & 2u) != 0 : rowok[0] && (k0 + kloc + 1 <= k_last);
             char* p0 = L + (kb >> 2) * GS + (kb & 3) * 4;
             V v0 = regs[S][0], v1 = regs[S][1];
 #pragma unroll
@@ -383,20 +431,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nkt > 0) {
+    auto kloop = [&](auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
         LA la; LB lb;
         la.init(d.A + (long)bz * d.strideA, d.lda, d.M, m0, k_end, tid, d.g, k_begin);
         lb.init(d.B + (long)bz * d.strideB, d.ldb, d.N, n0, k_end, tid, d.g, k_begin);
+        if constexpr (FAST) { la.init_fast(m0, tid); lb.init_fast(n0, tid); }
         const int kt_max = nkt - 1;
         auto k0_of = [&](int kt) { return k_begin + min(kt, kt_max) * BK; };   // clamped: surplus prefetches re-read the last tile
+        auto ld_a = [&](auto slot_c, int k0) {
+            constexpr int S = decltype(slot_c)::value;
+            if constexpr (FAST) la.template load_fast<S>(k0); else la.template load<S>(k0);
+        };
+        auto ld_b = [&](auto slot_c, int k0) {
+            constexpr int S = decltype(slot_c)::value;
+            if constexpr (FAST) lb.template load_fast<S>(k0); else lb.template load<S>(k0);
+        };
+        using std::integral_constant;
+        using I0 = integral_constant<int, 0>; using I1 = integral_constant<int, 1>; using I2 = integral_constant<int, 2>;
 
         // prologue: K-tiles 0..PD-1 in flight, tile 0 into LDS stage 0, then tile PD into the freed slot
-        la.template load<0>(k0_of(0)); lb.template load<0>(k0_of(0));
-        la.template load<1>(k0_of(1)); lb.template load<1>(k0_of(1));
-        la.template load<2>(k0_of(2)); lb.template load<2>(k0_of(2));
-        la.template store<0>(As[0], tid, k0_of(0));
-        lb.template store<0>(Bs[0], tid, k0_of(0));
-        la.template load<0>(k0_of(PD)); lb.template load<0>(k0_of(PD));
+        ld_a(I0{}, k0_of(0)); ld_b(I0{}, k0_of(0));
+        ld_a(I1{}, k0_of(1)); ld_b(I1{}, k0_of(1));
+        ld_a(I2{}, k0_of(2)); ld_b(I2{}, k0_of(2));
+        la.template store<0, FAST>(As[0], tid, k0_of(0));
+        lb.template store<0, FAST>(Bs[0], tid, k0_of(0));
+        ld_a(I0{}, k0_of(PD)); ld_b(I0{}, k0_of(PD));
         __syncthreads();
 
         const int pr = phys_row(l31);
@@ -423,8 +483,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
                     fb[j][p] = *reinterpret_cast<const bf16x8*>(Bb + 2 * p * LB::GS + j * 512);
             }
             if constexpr (STAGE_NEXT) {
-                la.template store<S>(As[(kt + 1) & 1], tid, k0_of(kt + 1));
-                lb.template store<S>(Bs[(kt + 1) & 1], tid, k0_of(kt + 1));
+                la.template store<S, FAST>(As[(kt + 1) & 1], tid, k0_of(kt + 1));
+                lb.template store<S, FAST>(Bs[(kt + 1) & 1], tid, k0_of(kt + 1));
             }
             // smallest terms first into the running sum
 #pragma unroll
@@ -449,12 +509,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
                 // issue order: the split / LDS-write work rides in the issue slots between the MFMAs (an MFMA
                 // holds the vector issue port for 8 of its 32 cycles): 1 MFMA, 6 VALU, NW/NM LDS writes, repeat
                 SchedPipe<0, NM, NW>::run();
-                la.template load<S>(k0_of(kt + 1 + PD));
-                lb.template load<S>(k0_of(kt + 1 + PD));
+                ld_a(slot_c, k0_of(kt + 1 + PD));
+                ld_b(slot_c, k0_of(kt + 1 + PD));
             }
             __syncthreads();
         };
-        using std::integral_constant;
         int kt = 0;
         for (; kt + PD <= kt_max; kt += PD) {          // steady state: branch-free body, register slots static
             stage(integral_constant<int, 1>{}, integral_constant<bool, true>{}, kt);
@@ -465,6 +524,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
         if (kt < kt_max) { stage(integral_constant<int, 1>{}, integral_constant<bool, true>{}, kt); ++kt; }
         if (kt < kt_max) { stage(integral_constant<int, 2>{}, integral_constant<bool, true>{}, kt); ++kt; }
         stage(integral_constant<int, 0>{}, integral_constant<bool, false>{}, kt);
+    };
+    if (nkt > 0) {
+        // uniform: every row of both tiles inside the operands, whole K-tiles, 32-bit element offsets
+        const bool fast = AMODE <= 1 && BMODE <= 1 &&
+                          LA::fast_ok(d.lda, d.M, m0, k_begin, k_end) && LB::fast_ok(d.ldb, d.N, n0, k_begin, k_end);
+        if (fast) kloop(std::integral_constant<bool, true>{});
+        else kloop(std::integral_constant<bool, false>{});
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
