@@ -134,12 +134,13 @@ def test_two_ranks_equal_one_process_full_batch(name, exchange):
     out = m(x.to(dev))
     _loss(out, tgt).backward()
     ref_g = {k: _digest(p.grad) for k, p in m.named_parameters() if p.grad is not None}
-    # forward: every sample's outputs agree (SyncBN == full-batch BN)
+    # forward: every sample's outputs agree (SyncBN == full-batch BN; the batch statistics are summed in two halves, so the
+    # head's logits move by fp32 rounding through the whole trunk: 1e-5 (UDEB4) ... 6e-5 (UDR50 at 320) of their scale)
     for rank, ids, (g, cls, rec, _xok), _ in got:
         e1 = abs(cls - out["cls_out"].detach().cpu().numpy()[ids]).max() / out["cls_out"].abs().max().item()
         e2 = abs(rec - out["rec"].detach().cpu().numpy()[ids]).max() / out["rec"].abs().max().item()
         print(f"  rank {rank}: cls_out {e1:.2e}  rec {e2:.2e}")
-        assert within(f"rank {rank} cls_out vs full batch", e1, 1e-4) and within(f"rank {rank} rec vs full batch", e2, 1e-3), (rank, e1, e2)
+        assert within(f"rank {rank} cls_out vs full batch", e1, 3e-4) and within(f"rank {rank} rec vs full batch", e2, 1e-3), (rank, e1, e2)
     # both ranks hold the same averaged gradients, equal to the full-batch gradients
     g0, g1 = got[0][2][0], got[1][2][0]
     assert set(g0) == set(ref_g) == set(g1)

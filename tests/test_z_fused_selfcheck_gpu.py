@@ -170,7 +170,9 @@ def test_tiled_depthwise_policy_equals_strip_kernels(half):
             LOSSES["aw_triplet"].n_real = None
     o0, g0 = run(False)
     o1, g1 = run(True)
-    otol, gtol = (2e-2, 5e-2) if half else (1e-4, 1e-3)
+    # half storage: 4 x what ONE rounding of parameters and inputs to fp16 does to the outputs of this step (0.9 - 1.3e-2,
+    # tests/test_e_mixed_precision_gpu.py); observed 1.7 - 1.9e-2 (two valid roundings of the same half-storage step)
+    otol, gtol = (5e-2, 5e-2) if half else (1e-4, 1e-3)
     for k in o0:
         e = float((o1[k] - o0[k]).norm() / o0[k].norm())
         assert within(f"{k}: tiled vs strip, relative L2", e, otol), (k, e)
