@@ -180,7 +180,8 @@ def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant):
     assert not odd, odd
 
 
-@pytest.mark.parametrize("variant,n,seeds", [("smooth", 2, (38, 138)), ("smooth", 4, (38, 138)), ("full", 2, (38, 138))])
+# (a third case, ("smooth", 2), ran until round 3: it adds 80 - 100 s of CPU oracle time and nothing the two below do not cover)
+@pytest.mark.parametrize("variant,n,seeds", [("smooth", 4, (38, 138)), ("full", 2, (38, 138))])
 def test_train_grads_vs_oracle_elementwise(variant, n, seeds):
     """Every parameter gradient, element by element, against the oracle in FLOAT64 on the CPU (same seeded
     inputs, parameters and masks), with the oracle's own float32 run as the conditioning yardstick."""
