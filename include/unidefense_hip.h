@@ -76,10 +76,7 @@ typedef struct {
     /* Tile of the BF16-pipe kernel: 0 = chosen by the library's cost model; 1..4 = 128x128, 128x64, 64x128, 64x64 —
      * for callers that tune per shape by measurement (unidefense_amd/kernels.py does, on the thin expand / project
      * GEMMs whose few tiles leave the k-loop latency exposed).
-     * bit 8 (0x100): each XCD takes a contiguous range of the tile order (measured neutral; off in the shipped plans).
-     * bit 9 (0x200): STREAM-K on the BF16-pipe kernel — a fixed number of persistent workgroups (bits 16..30; 0 = two per
-     * compute unit) share the (tile, K-tile) iteration space evenly and add their partial tiles atomically: needs
-     * out_mode 2, split_k 1, batch 1 and no epilogue statistics (UD_EINVAL otherwise). */
+     * bit 8 (0x100): each XCD takes a contiguous range of the tile order (measured neutral; off in the shipped plans). */
     int tile_cfg;
     long slice_stride;       /* out_mode 3: elements between the splits' slices (>= M * ldc) */
 } ud_gemm_desc;

@@ -224,7 +224,7 @@ def test_gemm_split_bf16_path_has_fp32_accuracy(kind, M, N, K):
 @pytest.mark.parametrize("mode", ["ordered-slices", "atomics"])
 def test_gemm_every_tile_configuration_and_split(kind, M, N, K, mode):
     """Every plan the per-shape tuner (kernels._tuned_plan) may pick: the four tiles of gemm_x3.hip (128x128, 128x64,
-    64x128, 64x64, each with its own prefetch depth) x split-K 1 ... 24 and stream-K, on ragged shapes, against float64 — a plan is a
+    64x128, 64x64, each with its own prefetch depth) x split-K 1 ... 24, on ragged shapes, against float64 — a plan is a
     speed choice, never a numerical one.  Both forms of split-K: partial products into ordered slices + ud_sum_slices
     (cfg.deterministic, the default: also required to be BITWISE repeatable) and fp32 atomics."""
     dev = _dev()
@@ -247,11 +247,11 @@ def _every_tile_and_split(dev, Kk, kind, M, N, K, mode):
     lda, ldb = (M if kind == "tn" else K), (K if kind == "nt" else N)
     worst = 0.0
     for cfg in (1, 2, 3, 4):
-        for split in (1, 2, 3, 8, 24, 0, -1, -3):          # <= 0: stream-K, 2 / 1 / 3 persistent workgroups per CU
+        for split in (1, 2, 3, 8, 24):
             if split > 1 and K // split < 16:
                 continue
             out = torch.zeros(M, N, device=dev)
-            Kk._gemm(a, b, out, M, N, K, lda, ldb, N, a_mode, b_mode, 2 if split != 1 else 0, split, cfg=cfg)
+            Kk._gemm(a, b, out, M, N, K, lda, ldb, N, a_mode, b_mode, 2 if split > 1 else 0, split, cfg=cfg)
             e = ((out.double().cpu() - ref).abs() / scale).max().item()
             worst = max(worst, e)
             assert e <= 2e-6, (cfg, split, e)
@@ -262,7 +262,7 @@ def _every_tile_and_split(dev, Kk, kind, M, N, K, mode):
                 Kk._gemm(a, b, o1, M, N, K, lda, ldb, N, a_mode, b_mode, 2, split, cfg=cfg)
                 Kk._gemm(a, b, o2, M, N, K, lda, ldb, N, a_mode, b_mode, 2, split, cfg=cfg)
                 assert torch.equal(o1, out) and torch.equal(o2, out), (cfg, split)
-    within(f"{kind} {M}x{N}x{K} [{mode}]: worst error / sum|a||b| over 4 tiles x 8 split plans", worst, 2e-6)
+    within(f"{kind} {M}x{N}x{K} [{mode}]: worst error / sum|a||b| over 4 tiles x 5 splits", worst, 2e-6)
     print(f"  {kind} {M}x{N}x{K} [{mode}]: worst error / sum|a||b| over 4 tiles x 5 splits: {worst:.2e}")
 
 

@@ -489,9 +489,6 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
     if (d.out_mode < 0 || d.out_mode > 3) return UD_EINVAL;
     if (d.split_k > 1 && d.out_mode != 2 && d.out_mode != 3) return UD_EINVAL;
     if (d.out_mode == 3 && (d.batch != 1 || d.slice_stride < (long)d.M * d.ldc || (d.half_mask & 4))) return UD_EINVAL;
-    if (d.tile_cfg & 0x200) {          // stream-K: atomic partial tiles of one un-batched product, no epilogue statistics
-        if (d.out_mode != 2 || d.split_k != 1 || d.batch != 1 || d.stat_sum) return UD_EINVAL;
-    }
     hipStream_t s = (hipStream_t)stream;
     int a_vec = 0, b_vec = 0;
     vec_flags(d, a_vec, b_vec);
@@ -513,7 +510,6 @@ extern "C" int ud_gemm(const ud_gemm_desc* dp, ud_stream_t stream) {
         return ud_gemm_x3_launch_half(d, s);
     }
     if (takes_x3(d, a_vec, b_vec)) return ud_gemm_x3_launch(d, s, g_path.load() == 3);
-    d.tile_cfg &= ~0x200;          // the fp32-pipe kernels have no stream-K form: one plain atomic launch
     if (d.a_mode == 0 && d.b_mode == 0) return launch_modes<0, 0>(d, a_vec, b_vec, s);
     if (d.a_mode == 0 && d.b_mode == 1) return launch_modes<0, 1>(d, a_vec, b_vec, s);
     if (d.a_mode == 1 && d.b_mode == 1) return launch_modes<1, 1>(d, a_vec, b_vec, s);

@@ -46,27 +46,12 @@ __device__ __forceinline__ uint32_t pack_f16(float x, float y) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
-__device__ __forceinline__ bf16x2 opaque_bf16x2(uint32_t bits) {
-    asm volatile("" : "+s"(bits));
-    return __builtin_bit_cast(bf16x2, bits);
-}
-
-// exact three-way split of two floats; p[i] packs piece i of (x, y).  A residual x - float(bf16(x)) is ONE
-// v_dot2c_f32_bf16: acc = x, acc += piece.lo * (-1) + piece.hi * 0 — the packed piece is used as it is (no shift / mask
-// to turn a half back into a float, no subtract): 7 vector instructions per pair instead of 11.  Exact: the product is
-// the piece itself and the difference is representable (it is the rounding error of the piece).
+// exact three-way split of two floats; p[i] packs piece i of (x, y)
 __device__ __forceinline__ void split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    // the selectors {-1, 0} / {0, -1} live in scalar registers: written as literals, hipcc encodes {-1, 0} as the inline
-    // constant -1.0, which this instruction reads as the fp32 pattern 0xbf800000 = {0, -1} (tools/native/check_dot2c.hip)
-    const bf16x2 sel_lo = opaque_bf16x2(0x0000bf80u), sel_hi = opaque_bf16x2(0xbf800000u);
-    const bf16x2 h = {(__bf16)x, (__bf16)y};
-    const float rx = __builtin_amdgcn_fdot2_f32_bf16(h, sel_lo, x, false);
-    const float ry = __builtin_amdgcn_fdot2_f32_bf16(h, sel_hi, y, false);
-    const bf16x2 m = {(__bf16)rx, (__bf16)ry};
-    const float sx = __builtin_amdgcn_fdot2_f32_bf16(m, sel_lo, rx, false);
-    const float sy = __builtin_amdgcn_fdot2_f32_bf16(m, sel_hi, ry, false);
-    p0 = __builtin_bit_cast(uint32_t, h);
-    p1 = __builtin_bit_cast(uint32_t, m);
+    p0 = pack_bf16(x, y);
+    float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pack_bf16(rx, ry);
+    float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xffff0000u);
     p2 = pack_bf16(sx, sy);
 }
 
@@ -365,8 +350,15 @@ struct XLoader {
     }
 };
 
+// resident waves per SIMD the register budget must allow: the small tiles are chosen where a launch is latency-bound, and
+// live on occupancy (with the general and the fast k-loop in one kernel hipcc otherwise spends up to 205 VGPRs on the
+// 128x64 tile: two waves per SIMD instead of three, -6 % on the UDR18 step)
+template <int BM, int BN>
+constexpr int kWavesPerSimd = BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 64 ? 3 : 4;
+
 template <int BM, int BN, int WGM, int WGN, int AMODE, int BMODE, int PREC = 3, bool AH = false, bool BH = false>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc d, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(NTHREADS, (kWavesPerSimd<BM, BN>)) void gemm_x3_kernel(const ud_gemm_desc d, int tiles_m,
+                                                                                   int tiles_n) {
     static_assert(WGM * WGN == 4, "4 waves");
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
     constexpr int NPL = PREC == 1 ? 1 : 3;
@@ -379,44 +371,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    // tile_cfg bit 9: STREAM-K.  The launch is gridDim.x persistent workgroups (two per CU) and the (tile, K-tile)
-    // iteration space, tile-major, is cut into gridDim.x equal runs: a workgroup works through its run segment by
-    // segment (a segment = the part of the run inside one tile) and adds each partial tile atomically (out_mode 2), so
-    // the chip finishes together whatever the tile count — 260 tiles split three ways are 780 workgroups for 512
-    // slots, 3.05 per CU with some CUs holding 4: a quarter of the launch is tail.
-    const bool streamk = (d.tile_cfg & 0x200) != 0;
-    const int kt_total = (d.K + BK - 1) / BK;
-    long it = 0, it_end = 0;
-    if (streamk) {
-        const long total = (long)tiles_m * tiles_n * kt_total;
-        it = (long)blockIdx.x * total / gridDim.x;
-        it_end = (long)(blockIdx.x + 1) * total / gridDim.x;
-        if (it >= it_end) return;
-    }
-  for (;;) {
     // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8), each with its own 4 MiB L2.  With
     // tile_cfg bit 8 every XCD gets one CONTIGUOUS range of the (column-major) tile order instead of every eighth tile, so
     // that the A / B panels its workgroups share are fetched into ONE L2 (a bijection for any tile count: no padding).
-    int bt = blockIdx.x, split = blockIdx.y, k_begin, k_end;
-    const int bz = blockIdx.z;
-    if (streamk) {
-        bt = (int)(it / kt_total);
-        const int kt0 = (int)(it - (long)bt * kt_total);
-        const long left = it_end - it;
-        const int n = left < (long)(kt_total - kt0) ? (int)left : kt_total - kt0;
-        k_begin = kt0 * BK;
-        k_end = (kt0 + n) * BK;
-        it += n;
-        split = 0;
-    } else {
-        if (d.tile_cfg & 0x100) {
-            const int T = tiles_m * tiles_n, q = T >> 3, r = T & 7, x = bt & 7;
-            bt = x * q + (x < r ? x : r) + (bt >> 3);
-        }
-        const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
-        k_begin = split * kt_per * BK;
-        k_end = k_begin + kt_per * BK;
+    int bt = blockIdx.x;
+    if (d.tile_cfg & 0x100) {
+        const int T = tiles_m * tiles_n, q = T >> 3, r = T & 7, x = bt & 7;
+        bt = x * q + (x < r ? x : r) + (bt >> 3);
     }
+    const int split = blockIdx.y, bz = blockIdx.z;
+    const int kt_total = (d.K + BK - 1) / BK;
+    const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
+    const int k_begin = split * kt_per * BK;
+    int k_end = k_begin + kt_per * BK;
     if (k_end > d.K) k_end = d.K;
     const int tile_m = bt % tiles_m, tile_n = bt / tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -534,7 +501,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
     }
 
     // epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (nkt == 0 && (d.out_mode == 1 || d.out_mode == 2)) return;          // (modes 0 / 3 store the zeros; never stream-K)
+    if (nkt == 0 && (d.out_mode == 1 || d.out_mode == 2)) return;          // (modes 0 / 3 store the zeros)
     const bool c_half = (d.half_mask & 4) != 0;
     if (c_half) {          // statistics and consumers see the rounded values
 #pragma unroll
@@ -592,20 +559,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3_kernel(const ud_gemm_desc
             }
         }
     }
-    if (!streamk || it >= it_end) break;
-  }
 }
 
 template <int BM, int BN, int AMODE, int BMODE, int PREC, bool AH = false, bool BH = false>
 int launch_tile(const ud_gemm_desc& d, hipStream_t s) {
     int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, (unsigned)d.batch);
-    if (d.tile_cfg & 0x200) {          // stream-K (ud_gemm checked: out_mode 2, split_k 1, batch 1, no statistics)
-        const long total = (long)tiles_m * tiles_n * ud_cdiv(d.K, BK);
-        long wgs = (d.tile_cfg >> 16) & 0x7fff;
-        if (wgs == 0) wgs = 2L * ud_num_cus();
-        grid = dim3((unsigned)(wgs < total ? wgs : total), 1, 1);
-    }
     hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, 2, 2, AMODE, BMODE, PREC, AH, BH>), grid, dim3(NTHREADS), 0, s, d, tiles_m,
                        tiles_n);
     UD_LAUNCH_CHECK();

@@ -11,17 +11,6 @@
     } while (0)
 
 static inline int ud_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
-// compute units of the current device (256 on an MI355X; asked once)
-static inline int ud_num_cus() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-            v = 256;
-        return v;
-    }();
-    return n;
-}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -151,23 +151,16 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
     d.half_mask = (A.dtype == torch.float16) | ((B.dtype == torch.float16) << 1) | ((Cout.dtype == torch.float16) << 2)
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
-    plan_split = split_k
-    streamk = split_k < 1          # plan value 0 / -n: stream-K with 2 / n persistent workgroups per compute unit
-    if streamk:
-        assert out_mode == 2 and batch == 1 and stats is None
-        per_cu, split_k = (-split_k or 2), 1
     d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
     d.tile_cfg = cfg | (0x100 if _XCD_CONTIGUOUS else 0)
-    if streamk and not CFG.deterministic:
-        d.tile_cfg |= 0x200 | ((per_cu * _num_cus(Cout.device)) << 16)
     slices = None
     if CFG.deterministic and out_mode == 2:
         # Cout holds a term to add to (or is a fresh buffer of split_out): result = [Cout +] the splits' partials in
         # ascending order
         total = M * ldc
         fresh = getattr(Cout, "_ud_fresh", False)
-        if batch == 1 and total % 4 == 0 and Cout.dtype == torch.float32 and not streamk:
+        if batch == 1 and total % 4 == 0 and Cout.dtype == torch.float32:
             stride = total
             ws = _slice_ws(Cout, split_k * stride)
             d.C, d.out_mode, d.slice_stride = ws.data_ptr(), 3, stride
@@ -197,7 +190,7 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
         e0.record()
         _call("ud_gemm", C.byref(d), _stream())
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, a_mode, b_mode, plan_split, batch),
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch, (M, N, K, a_mode, b_mode, split_k, batch),
                              _call("ud_gemm_query_path", C.byref(d)),
                              # operand + result bytes, every matrix touched once, in their storage types
                              float(batch) * (A.element_size() * M * K + B.element_size() * K * N + Cout.element_size() * M * N)))
@@ -210,16 +203,6 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
         tgt, slots = fold
         _call("ud_stat_slots_fold", _pd64(tgt), _pd64(tgt, slots * N), slots, N, _pd64(stats), _pd64(stats, N), _stream())
     return (Cout, stats_done) if stats is not None else Cout
-
-
-_NUM_CUS = {}
-
-
-def _num_cus(device):
-    n = _NUM_CUS.get(device.index)
-    if n is None:
-        n = _NUM_CUS[device.index] = torch.cuda.get_device_properties(device).multi_processor_count
-    return n
 
 
 _TAIL_SPLIT = True
@@ -306,16 +289,9 @@ def _tune_candidates(M, N, K):
             if (tiles * split < 64 and K >= 1024) or (heavy and cfg == 4):
                 continue
             out.append((cfg, split))
-        # stream-K (split 0 / -n: 2 / n persistent workgroups per CU over the (tile, K-tile) space): where the tiles do not
-        # fill whole rounds of the chip and the k-loop is long enough to cut
-        if _STREAMK_CANDIDATES and K >= 512 and tiles >= 16 and cfg <= 2:
-            out.append((cfg, 0))
     return out
 
 
-# measured (profiles/r03/gemm_streamk_pmc.txt): the tuner picks stream-K for six of the large bs-32 shapes (+0.5 ... +8 % per
-# launch) and the step does not move — the plans stay split-K, the kernel form stays available (plan split 0 / -n)
-_STREAMK_CANDIDATES = False
 _TUNE_N = 6          # launches per timing graph
 
 
@@ -367,9 +343,9 @@ def _tuned_plan(kind, M, N, K, launch, baseline, extra_if_split=None, no_split=F
     best_t, best = _time_launches(baseline), None
     extra = _time_launches(extra_if_split) if extra_if_split is not None else 0.0
     for cfg, split in _tune_candidates(M, N, K):
-        if no_split and split != 1:
+        if no_split and split > 1:
             continue
-        t = _time_launches(lambda: launch(cfg, split)) + (extra if split != 1 else 0.0)
+        t = _time_launches(lambda: launch(cfg, split)) + (extra if split > 1 else 0.0)
         if t < 0.97 * best_t:                          # a clear win only: equal plans keep the model's choice
             best_t, best = t, (cfg, split)
     _TUNED[key] = best
@@ -419,7 +395,7 @@ def _tuned_launch(kind, a, w, out, M, N, K, lda, ldb, a_mode, b_mode, acc, stats
         colstats(scratch(), sacc[0])
     tuned = _tuned_plan(kind, M, N, K,
                         lambda cfg, split: _gemm(a, w, scratch(), M, N, K, lda, ldb, N, a_mode, b_mode,
-                                                 2 if split != 1 else 0, split, cfg=cfg),
+                                                 2 if split > 1 else 0, split, cfg=cfg),
                         lambda: model(scratch()),
                         stats_pass if stats is not None else None, no_split=out_dtype != torch.float32)
     if tuned is None:
@@ -624,12 +600,12 @@ def conv_gather_nt(x, wmat, g):
                 tmp.append(empty((M, Co), x))
             return tmp[0]
         tuned = _tuned_plan(("conv",) + gk, M, Co, K,
-                            lambda cfg, sp: _gemm(x, wmat, scratch(), M, Co, K, 0, K, Co, 2, 0, 2 if sp != 1 else 0, sp, geom=g, cfg=cfg),
+                            lambda cfg, sp: _gemm(x, wmat, scratch(), M, Co, K, 0, K, Co, 2, 0, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg),
                             lambda: _gemm(x, wmat, scratch(), M, Co, K, 0, K, Co, 2, 0, 2 if split > 1 else 0, split, geom=g))
         if tuned is not None:
             cfg, sp = tuned
-            out = (split_out if sp != 1 else empty)((g.N, g.Hout, g.Wout, Co), x)
-            _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, 2 if sp != 1 else 0, sp, geom=g, cfg=cfg)
+            out = (split_out if sp > 1 else empty)((g.N, g.Hout, g.Wout, Co), x)
+            _gemm(x, wmat, out, M, Co, K, 0, K, Co, 2, 0, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg)
             return out
     if split > 1:
         out = split_out((g.N, g.Hout, g.Wout, Co), x)
@@ -666,12 +642,12 @@ def conv_gather_wgrad(a, x, g):
                 tmp.append(empty((Ma, Ncols), a))
             return tmp[0]
         tuned = _tuned_plan(("convw",) + gk, Ma, Ncols, Kdim,
-                            lambda cfg, sp: _gemm(a, x, scratch(), Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if sp != 1 else 0, sp, geom=g, cfg=cfg),
+                            lambda cfg, sp: _gemm(a, x, scratch(), Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg),
                             lambda: _gemm(a, x, scratch(), Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if split > 1 else 0, split, geom=g))
         if tuned is not None:
             cfg, sp = tuned
-            out = (split_out if sp != 1 else empty)((Ma, Ncols), a)
-            return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if sp != 1 else 0, sp, geom=g, cfg=cfg)
+            out = (split_out if sp > 1 else empty)((Ma, Ncols), a)
+            return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2 if sp > 1 else 0, sp, geom=g, cfg=cfg)
     if split > 1:
         out = split_out((Ma, Ncols), a)
         return _gemm(a, x, out, Ma, Ncols, Kdim, Ma, 0, Ncols, 1, 2, 2, split, geom=g)
