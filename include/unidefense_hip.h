@@ -422,6 +422,19 @@ int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float 
 int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, float w_interior, const void* spat,
     const float* alpha, void* diff_out, double* sum, double* sumsq, int f16, ud_stream_t stream);
 
+/* Two-pass forms of the 32 x 32 / 64 x 64 transforms (torch.fft.rfft2 / irfft2 of exp.py:55,60 and their adjoints): a
+ * row kernel and a column kernel with the half-spectrum between them in ws (ud_fft2_two_pass_ws_floats floats, fp32,
+ * [N][S][S/2+1][Re 0..C | Im 0..C]); a wave owns 64 consecutive channels of one image row / one kx column, so every access
+ * is a run of whole lines where the one-kernel forms above read 16 ... 64-byte pieces.  Same results to the last bit or
+ * two.  bn / act_out / gate_*: as ud_rfft2_ex (all NULL / 0: plain
+ * ud_rfft2); spat / alpha / freq_out / sum / sumsq: as ud_irfft2_mix (spat NULL: plain ud_irfft2). */
+long ud_fft2_two_pass_ws_floats(int N, int S, int C);
+int ud_rfft2_two_pass(const void* x, void* Y, float* ws, int N, int S, int C, float scale, float w_interior,
+    const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc,
+    float* gate_grad, int f16, ud_stream_t stream);
+int ud_irfft2_two_pass(const void* Y, void* y, float* ws, int N, int S, int C, float scale, float w_interior,
+    const void* spat, const float* alpha, void* freq_out, double* sum, double* sumsq, int f16, ud_stream_t stream);
+
 /* ---- multi-tensor AdamW (csrc/optim.hip) ------------------------------------------------------------------------
  * torch.optim.AdamW(amsgrad) over timm's weight-decay groups (engine/forgery_engine.py:149-156) with GradScaler's
  * unscale and found_inf skip (engine/abstract_engine.py:281-283) folded in: ONE launch for all parameter tensors.

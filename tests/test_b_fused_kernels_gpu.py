@@ -4,6 +4,7 @@ channel counts that do not fill a column group, row counts that are not multiple
 both forms of every reduction (fp64 atomics / partials + finalize).  Reference semantics: model/efficientnet/model.py:94-135
 (MBConvBlock.forward), exp.py:46-65 (SFConv), utils.py:66-77 (swish)."""
 import pytest
+from tests.margins import within
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -236,6 +237,60 @@ def test_fft_fused_variants(S, Cc, N):
     y_ref = (1 - a) * spat.double().cpu() + a * fr_ref
     assert _rel(fr, fr_ref - spat.double().cpu()) < 2e-5 and _rel(y, y_ref) < 2e-5          # second output: freq - spat
     assert _rel(acc[:Cc], y_ref.sum((0, 1, 2))) < 2e-5 and _rel(acc[Cc:], (y_ref * y_ref).sum((0, 1, 2))) < 2e-5
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
+@pytest.mark.parametrize("S,Cc,N", [(64, 144, 3), (64, 200, 2), (32, 192, 3), (32, 40, 2)])
+def test_fft_two_pass_equals_one_kernel(S, Cc, N, half):
+    """The two-pass forms (row kernel + column kernel, half-spectrum in HBM: ud_rfft2_two_pass / ud_irfft2_two_pass) run the
+    same butterflies on the same values as the LDS-resident kernels: every tensor they write equals the one-kernel form's
+    to the LAST BIT OR TWO (hipcc contracts the scale factor into the first butterfly in one form and not in the other: 1 ulp,
+    observed on ~1e-6 of the elements), plain and with every fused prologue / epilogue (deferred BN + swish on load, activated
+    copy, running statistics, gate factor, gate gradient from the slots; SF mix + freq - spat + BN sums), channel counts that
+    are not a multiple of the 64 a wave owns, both storage types.  Against float64: test_fft_fused_variants (whichever form
+    the policy picks) and test_half_storage_kernels."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    dt = torch.float16 if half else torch.float32
+    g = torch.Generator().manual_seed(S + Cc)
+    x = torch.randn(N, S, S, Cc, generator=g).to(dev).to(dt)
+    gamma, beta = (1.0 + 0.2 * torch.randn(Cc, generator=g)).to(dev), (0.1 * torch.randn(Cc, generator=g)).to(dev)
+    alpha = torch.tensor(-0.3, device=dev)
+    Yin = torch.randn(N, S, S // 2 + 1, 2 * Cc, generator=g).to(dev).to(dt)
+    spat = torch.randn(N, S, S, Cc, generator=g).to(dev).to(dt)
+    slots = torch.randn(64, generator=g, dtype=torch.float64).to(dev)
+
+    def run(two_pass):
+        saved = K._FFT_TWO_PASS
+        K._FFT_TWO_PASS = two_pass
+        try:
+            out = {}
+            out["rfft"] = K.rfft2(x, 1.0 / S, 2.0)
+            out["irfft"] = K.irfft2(Yin, 1.0 / S, 0.5)
+            rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+            bn = _deferred(K, x.view(N, S * S, Cc), gamma, beta, 1e-3, 1, rm, rv, 0.01)
+            out["ex Y"], out["ex act"] = K.rfft2_ex(x, 1.0 / S, 1.0, bn=bn, want_act=True, update=True)
+            out["ex running_mean"], out["ex running_var"] = rm, rv
+            out["gate Y"], _, out["gate grad"] = K.rfft2_ex(x, 1.0 / S, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=slots)
+            out["gate2 Y"], _ = K.rfft2_ex(x, 1.0 / S, 1.0, gate_alpha=alpha, gate_mode=2)
+            acc = K.zeros64(2 * Cc, x)
+            out["mix y"], out["mix diff"] = K.irfft2_mix(Yin, 1.0 / S, spat, alpha, acc)
+            torch.cuda.synchronize()
+            return out, acc.clone()
+        finally:
+            K._FFT_TWO_PASS = saved
+    o1, a1 = run(False)
+    o2, a2 = run(True)
+    ulp = 2.0 ** -10 if half else 2.0 ** -23
+    worst = 0.0
+    for k in o1:
+        scale = float(o1[k].double().abs().max())
+        e = float((o1[k].double() - o2[k].double()).abs().max()) / (scale if scale > 0 else 1.0)
+        worst = max(worst, e / ulp)
+        assert e <= 2.0 * ulp, (k, e)
+    within(f"two-pass vs one-kernel, worst |difference| / max|value| in ulps of the storage type", worst, 2.0)
+    assert _rel(a2, a1) < (1e-3 if half else 1e-6)          # sums of y and y^2 whose last bits differ as above
 
 
 @pytest.mark.parametrize("M,N,Kd", [(2048, 1632, 272), (8192 + 40, 960, 160), (131072, 192, 32), (524288 // 4, 144, 24),

@@ -1,10 +1,5 @@
 #!/bin/bash
-export PYTHONDONTWRITEBYTECODE=1
-export UD_BENCH_ARGS=""
-bash tools/gpu_lib_ab.sh base
-export UD_BENCH_ARGS="--model UDR18 --size 128 --batch 8"
-bash tools/gpu_lib_ab.sh base
-export UD_BENCH_ARGS="--model UDR50 --size 320 --batch 16"
-bash tools/gpu_lib_ab.sh base
-export UD_BENCH_ARGS="--dtype f16 --batch 64"
-bash tools/gpu_lib_ab.sh base
+export PYTHONDONTWRITEBYTECODE=1 UD_MARGIN_RUN=t13
+python -m pytest tests/test_b_fused_kernels_gpu.py -q -m gpu -k "fft or half" 2>&1 | tail -2
+python tools/bench_fft2p.py 2>&1 | grep -v amdgpu.ids
+python tools/bench_fft2p.py --half 2>&1 | grep -v amdgpu.ids

@@ -473,6 +473,240 @@ int launch_irfft2(const T* Y, T* x, int N, int C, float scale, float w_int, cons
     return launch_irfft2_t<T, S, CB, false>(Y, x, N, C, scale, w_int, IrfftMix{nullptr, nullptr, nullptr, nullptr, nullptr}, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// TWO-PASS form for the large planes (S = 32, 64).  The LDS-resident kernels above hold S x (S/2+1) complex fp32 per
+// channel (16.9 KB at 64 x 64), so a workgroup takes 8 / 16 channels: 32 / 64-byte runs per pixel in fp32 storage,
+// 16 / 32 in half storage — every 128-byte line is pulled by 4 ... 8 workgroups and a wave-load touches 8 lines for 128
+// useful bytes.  Here the transform is a ROW kernel and a COLUMN kernel with the half-spectrum in between kept in HBM
+// (Z[n][h][kx][Re 0..C | Im 0..C], fp32): the channel is still the lane, but a wave owns 64 CONSECUTIVE channels of one
+// image row (or one kx column), so every access is a whole run of lines; no LDS, no barrier.  Same butterflies on the
+// same values in the same order as the one-kernel form: the results agree to the last bit or two (hipcc contracts the scale
+// factor into the first butterfly differently in the two forms).  Extra traffic: Z written and read once.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int NT2 = 256;          // 64 channels x 4 rows (or kx columns)
+constexpr int RPT = 4;            // image rows one thread of the inverse row kernel walks (fewer atomics per channel)
+
+template <typename T, int S, bool EX>
+__global__ __launch_bounds__(NT2) void rows_fwd_kernel(const T* __restrict__ x, float* __restrict__ Z, int C, ud_bn_ref bn,
+                                                       int has_bn, T* __restrict__ act_out,
+                                                       const float* __restrict__ gate_alpha,
+                                                       const double* __restrict__ gate_acc, float* __restrict__ gate_grad) {
+    constexpr int WH = S / 2 + 1;
+    if (EX && gate_grad && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
+        const double tot = ud_wave_sum_d(gate_acc[threadIdx.x]);
+        if (threadIdx.x == 0) {
+            const double a = 1.0 / (1.0 + exp(-(double)gate_alpha[0]));
+            gate_grad[0] = (float)(tot * a * (1.0 - a));
+        }
+    }
+    const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int h = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (ch >= C || h >= S) return;
+    float mu = 0.f, is = 1.f, ga = 1.f, be = 0.f;
+    if (EX && has_bn) {
+        const double m = bn.sum[ch] * bn.inv_count;
+        double vv = bn.sumsq[ch] * bn.inv_count - m * m;
+        if (vv < 0.0) vv = 0.0;
+        mu = (float)m;
+        is = (float)(1.0 / sqrt(vv + (double)bn.eps));
+        ga = bn.gamma[ch];
+        be = bn.beta[ch];
+        if (n == 0 && h == 0 && bn.running_mean) {          // one thread per channel
+            bn.running_mean[ch] = (1.f - bn.momentum) * bn.running_mean[ch] + bn.momentum * (float)m;
+            bn.running_var[ch] = (1.f - bn.momentum) * bn.running_var[ch] + bn.momentum * (float)(vv * bn.unbias);
+        }
+    }
+    const long o0 = (((long)n * S + h) * S) * C + ch;
+    const T* src = x + o0;
+    T* aout = (EX && act_out) ? act_out + o0 : nullptr;
+    float re[S], im[S];
+    // all S loads first (in flight together), then the transform of the values and the activated copy
+#pragma unroll
+    for (int w = 0; w < S; ++w) re[brev<S>(w)] = (float)src[(long)w * C];
+#pragma unroll
+    for (int w = 0; w < S; ++w) {
+        if (EX && has_bn) {
+            const float v = ud_rounded<T>(ud_act(ga * ((re[brev<S>(w)] - mu) * is) + be, bn.act));
+            if (aout) aout[(long)w * C] = (T)v;
+            re[brev<S>(w)] = v;
+        }
+        im[brev<S>(w)] = 0.f;
+    }
+    fft_inreg<S, false>(re, im);
+    float* dst = Z + (((long)n * S + h) * WH) * (2L * C) + ch;
+#pragma unroll
+    for (int kx = 0; kx <= S / 2; ++kx) {
+        dst[(long)kx * 2 * C] = re[kx];
+        dst[(long)kx * 2 * C + C] = im[kx];
+    }
+}
+
+template <typename T, int S, bool EX>
+__global__ __launch_bounds__(NT2) void cols_fwd_kernel(const float* __restrict__ Z, T* __restrict__ Y, int C, float scale,
+                                                       float w_int, const float* __restrict__ gate_alpha, int gate_mode) {
+    constexpr int WH = S / 2 + 1;
+    const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int kx = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (ch >= C || kx >= WH) return;
+    const float* src = Z + (((long)n * S) * WH + kx) * (2L * C) + ch;
+    float re[S], im[S];
+#pragma unroll
+    for (int h = 0; h < S; ++h) {
+        re[brev<S>(h)] = src[(long)h * WH * 2 * C];
+        im[brev<S>(h)] = src[(long)h * WH * 2 * C + C];
+    }
+    fft_inreg<S, false>(re, im);
+    float f = (kx == 0 || kx == S / 2) ? scale : scale * w_int;
+    if (EX && gate_mode != 0) {
+        const float a = ud_sigmoid(gate_alpha[0]);
+        f *= (gate_mode == 1) ? a : 1.f - a;
+    }
+    T* dst = Y + (((long)n * S) * WH + kx) * (2L * C) + ch;
+#pragma unroll
+    for (int ky = 0; ky < S; ++ky) {
+        dst[(long)ky * WH * 2 * C] = (T)(re[ky] * f);
+        dst[(long)ky * WH * 2 * C + C] = (T)(im[ky] * f);
+    }
+}
+
+template <typename T, int S>
+__global__ __launch_bounds__(NT2) void cols_inv_kernel(const T* __restrict__ Y, float* __restrict__ Z, int C, float w_int) {
+    constexpr int WH = S / 2 + 1;
+    const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int kx = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (ch >= C || kx >= WH) return;
+    const T* src = Y + (((long)n * S) * WH + kx) * (2L * C) + ch;
+    const float f = (kx == 0 || kx == S / 2) ? 1.f : w_int;
+    float re[S], im[S];
+#pragma unroll
+    for (int ky = 0; ky < S; ++ky) {
+        re[brev<S>(ky)] = (float)src[(long)ky * WH * 2 * C];
+        im[brev<S>(ky)] = (float)src[(long)ky * WH * 2 * C + C];
+    }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        re[k] *= f;
+        im[k] *= f;
+    }
+    fft_inreg<S, true>(re, im);
+    float* dst = Z + (((long)n * S) * WH + kx) * (2L * C) + ch;
+#pragma unroll
+    for (int h = 0; h < S; ++h) {
+        dst[(long)h * WH * 2 * C] = re[h];
+        dst[(long)h * WH * 2 * C + C] = im[h];
+    }
+}
+
+template <typename T, int S, bool MIX>
+__global__ __launch_bounds__(NT2) void rows_inv_kernel(const float* __restrict__ Z, T* __restrict__ x, int C, float scale,
+                                                       const T* __restrict__ spat, const float* __restrict__ alpha,
+                                                       T* __restrict__ freq_out, double* __restrict__ sum,
+                                                       double* __restrict__ sumsq) {
+    constexpr int WH = S / 2 + 1;
+    __shared__ double red[MIX ? 2 * NT2 : 1];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + lane;
+    const int n = blockIdx.z;
+    const bool cok = ch < C;
+    double tot1 = 0.0, tot2 = 0.0;
+    float a = 0.f;
+    if (MIX) a = ud_sigmoid(alpha[0]);
+    if (cok) {
+#pragma unroll 1
+        for (int r = 0; r < RPT; ++r) {
+            const int h = (blockIdx.y * 4 + rg) * RPT + r;
+            if (h >= S) break;
+            const float* src = Z + (((long)n * S + h) * WH) * (2L * C) + ch;
+            float re[S], im[S];
+#pragma unroll
+            for (int kx = 0; kx <= S / 2; ++kx) {
+                const float zr = src[(long)kx * 2 * C];
+                const float zi = src[(long)kx * 2 * C + C];
+                re[brev<S>(kx)] = zr;
+                im[brev<S>(kx)] = (kx == 0 || kx == S / 2) ? 0.f : zi;   // c2r ignores these imaginary parts
+                if (kx > 0 && kx < S / 2) {
+                    re[brev<S>(S - kx)] = zr;
+                    im[brev<S>(S - kx)] = -zi;
+                }
+            }
+            fft_inreg<S, true>(re, im);
+            const long o0 = (((long)n * S + h) * S) * C + ch;
+            T* dst = x + o0;
+            if (!MIX) {
+#pragma unroll
+                for (int w = 0; w < S; ++w) dst[(long)w * C] = (T)(re[w] * scale);
+            } else {
+                const T* sp = spat + o0;
+                T* fo = freq_out + o0;
+#pragma unroll
+                for (int w = 0; w < S; ++w) {
+                    const float fr = re[w] * scale, spv = (float)sp[(long)w * C];
+                    const float y = ud_rounded<T>(spv * (1.f - a) + fr * a);
+                    fo[(long)w * C] = (T)(fr - spv);
+                    dst[(long)w * C] = (T)y;
+                    tot1 += (double)y;
+                    tot2 += (double)y * (double)y;
+                }
+            }
+        }
+    }
+    if (MIX) {
+        red[threadIdx.x * 2] = tot1;
+        red[threadIdx.x * 2 + 1] = tot2;
+        __syncthreads();
+        if (rg == 0 && cok) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                t1 += red[(g * 64 + lane) * 2];
+                t2 += red[(g * 64 + lane) * 2 + 1];
+            }
+            unsafeAtomicAdd(sum + ch, t1);
+            unsafeAtomicAdd(sumsq + ch, t2);
+        }
+    }
+}
+
+template <typename T, int S>
+int rfft2_two_pass(const T* x, T* Y, float* Z, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
+    constexpr int WH = S / 2 + 1;
+    const dim3 gr((unsigned)ud_cdiv(C, 64), (unsigned)(S / 4), (unsigned)N);
+    const dim3 gc((unsigned)ud_cdiv(C, 64), (unsigned)ud_cdiv(WH, 4), (unsigned)N);
+    ud_bn_ref none{};
+    if (ex) {
+        hipLaunchKernelGGL((rows_fwd_kernel<T, S, true>), gr, dim3(NT2), 0, s, x, Z, C, ex->bn ? *ex->bn : none,
+                           ex->bn ? 1 : 0, (T*)ex->act_out, ex->gate_alpha, ex->gate_acc, ex->gate_grad);
+        hipLaunchKernelGGL((cols_fwd_kernel<T, S, true>), gc, dim3(NT2), 0, s, Z, Y, C, scale, w_int, ex->gate_alpha,
+                           ex->gate_mode);
+    } else {
+        hipLaunchKernelGGL((rows_fwd_kernel<T, S, false>), gr, dim3(NT2), 0, s, x, Z, C, none, 0, (T*)nullptr,
+                           (const float*)nullptr, (const double*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL((cols_fwd_kernel<T, S, false>), gc, dim3(NT2), 0, s, Z, Y, C, scale, w_int,
+                           (const float*)nullptr, 0);
+    }
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int S>
+int irfft2_two_pass(const T* Y, T* x, float* Z, int N, int C, float scale, float w_int, const IrfftMix* m, hipStream_t s) {
+    constexpr int WH = S / 2 + 1;
+    const dim3 gc((unsigned)ud_cdiv(C, 64), (unsigned)ud_cdiv(WH, 4), (unsigned)N);
+    const dim3 gr((unsigned)ud_cdiv(C, 64), (unsigned)ud_cdiv(S, 4 * RPT), (unsigned)N);
+    hipLaunchKernelGGL((cols_inv_kernel<T, S>), gc, dim3(NT2), 0, s, Y, Z, C, w_int);
+    if (m)
+        hipLaunchKernelGGL((rows_inv_kernel<T, S, true>), gr, dim3(NT2), 0, s, Z, x, C, scale, (const T*)m->spat, m->alpha,
+                           (T*)m->freq_out, m->sum, m->sumsq);
+    else
+        hipLaunchKernelGGL((rows_inv_kernel<T, S, false>), gr, dim3(NT2), 0, s, Z, x, C, scale, (const T*)nullptr,
+                           (const float*)nullptr, (T*)nullptr, (double*)nullptr, (double*)nullptr);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
 // half storage: the power-of-two sizes of the EfficientNet trunk only (the ResNet models' 5*2^k maps stay fp32)
 template <typename T>
 int rfft2_dispatch(const T* x, T* Y, int N, int S, int C, float scale, float w_interior, const RfftEx* ex,
@@ -553,6 +787,40 @@ int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, floa
     IrfftMix m{spat, alpha, freq_out, sum, sumsq};
     UD_STORAGE_DISPATCH(f16, return irfft2_dispatch<T>((const T*)Y, (T*)y, N, S, C, scale, w_interior, &m,
                                                        (hipStream_t)stream));
+}
+
+// floats of scratch the two-pass forms need (the half-spectrum between the row and the column kernel); 0: S has no
+// two-pass form
+long ud_fft2_two_pass_ws_floats(int N, int S, int C) {
+    if (N < 1 || C < 1 || (S != 32 && S != 64)) return 0;
+    return (long)N * S * (S / 2 + 1) * 2 * C;
+}
+
+int ud_rfft2_two_pass(const void* x, void* Y, float* ws, int N, int S, int C, float scale, float w_interior,
+                      const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc,
+                      float* gate_grad, int f16, ud_stream_t stream) {
+    if (N < 1 || C < 1 || !x || !Y || !ws || (S != 32 && S != 64)) return UD_EINVAL;
+    if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
+    if (bn && bn->G != 1) return UD_EINVAL;
+    if (act_out && !bn) return UD_EINVAL;
+    if (gate_grad && (!gate_acc || !gate_alpha)) return UD_EINVAL;
+    RfftEx exv{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad};
+    const RfftEx* ex = (bn || gate_mode != 0 || gate_grad) ? &exv : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    UD_STORAGE_DISPATCH(f16, if (S == 64) return rfft2_two_pass<T, 64>((const T*)x, (T*)Y, ws, N, C, scale, w_interior, ex, s);
+                        return rfft2_two_pass<T, 32>((const T*)x, (T*)Y, ws, N, C, scale, w_interior, ex, s));
+}
+
+int ud_irfft2_two_pass(const void* Y, void* y, float* ws, int N, int S, int C, float scale, float w_interior,
+                       const void* spat, const float* alpha, void* freq_out, double* sum, double* sumsq, int f16,
+                       ud_stream_t stream) {
+    if (N < 1 || C < 1 || !Y || !y || !ws || (S != 32 && S != 64)) return UD_EINVAL;
+    if (spat && (!alpha || !freq_out || !sum || !sumsq)) return UD_EINVAL;
+    IrfftMix mv{spat, alpha, freq_out, sum, sumsq};
+    const IrfftMix* m = spat ? &mv : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    UD_STORAGE_DISPATCH(f16, if (S == 64) return irfft2_two_pass<T, 64>((const T*)Y, (T*)y, ws, N, C, scale, w_interior, m, s);
+                        return irfft2_two_pass<T, 32>((const T*)Y, (T*)y, ws, N, C, scale, w_interior, m, s));
 }
 
 }  // extern "C"

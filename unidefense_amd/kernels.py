@@ -841,12 +841,39 @@ def dwconv_bwd_weight(x, dy, K, stride, pad_t, pad_l):
 # ---------------------------------------------------------------------------------------------
 # FFT
 # ---------------------------------------------------------------------------------------------
+# Two-pass form of the 32 x 32 / 64 x 64 transforms (csrc/fft.hip: a row kernel and a column kernel with the half-spectrum
+# between them in HBM, whole lines per access) where it beats the LDS-resident kernel — measured per (variant, size,
+# storage) with tools/bench_fft2p.py (profiles/r03/fft_two_pass.txt): half storage, where the one-kernel form reads 16 / 32
+# bytes per pixel, everything at 64 x 64 (1.3 - 3.7x) and the plain inverse at 32 x 32 (1.7 - 2x); fp32 storage the two fused
+# 64 x 64 variants (1.1 - 1.7x).  _FFT_TWO_PASS: None = this table, True / False = everywhere possible / nowhere (tests).
+_FFT_TWO_PASS = None
+_FFT2P_POLICY = {("rfft", 64, True), ("rfft_ex", 64, True), ("irfft", 64, True), ("irfft_mix", 64, True),
+                 ("irfft", 32, True),
+                 ("rfft_ex", 64, False), ("irfft_mix", 64, False)}
+
+
+def _fft_two_pass(kind, S, half):
+    if S not in (32, 64):
+        return False
+    if _FFT_TWO_PASS is not None:
+        return _FFT_TWO_PASS
+    return (kind, S, bool(half)) in _FFT2P_POLICY
+
+
+def _fft_ws(N, S, Cc, like):
+    return empty((N, S, S // 2 + 1, 2 * Cc), like, torch.float32)
+
+
 def rfft2(x, scale, w_interior=1.0):
     """x[N,S,S,C] -> Y[N,S,S/2+1,2C] (Re | Im channel halves)."""
     h = _act(x)
     N, S, S2, Cc = x.shape
     assert S == S2
     Y = empty((N, S, S // 2 + 1, 2 * Cc), x, x.dtype)
+    if _fft_two_pass("rfft", S, h):
+        _call("ud_rfft2_two_pass", _p(x), _p(Y), _p(_fft_ws(N, S, Cc, x)), N, S, Cc, scale, w_interior, None, None, None, 0,
+              None, None, h, _stream())
+        return Y
     _call("ud_rfft2", _p(x), _p(Y), N, S, Cc, scale, w_interior, h, _stream())
     return Y
 
@@ -857,6 +884,10 @@ def irfft2(Y, scale, w_interior=1.0):
     N, S, Wh, C2 = Y.shape
     assert Wh == S // 2 + 1 and C2 % 2 == 0
     x = empty((N, S, S, C2 // 2), Y, Y.dtype)
+    if _fft_two_pass("irfft", S, h):
+        _call("ud_irfft2_two_pass", _p(Y), _p(x), _p(_fft_ws(N, S, C2 // 2, Y)), N, S, C2 // 2, scale, w_interior, None, None,
+              None, None, None, h, _stream())
+        return x
     _call("ud_irfft2", _p(Y), _p(x), N, S, C2 // 2, scale, w_interior, h, _stream())
     return x
 
@@ -1532,9 +1563,12 @@ def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None,
     Y = empty((N, S, S // 2 + 1, 2 * Cc), x, x.dtype)
     act = torch.empty_like(x) if (want_act and bn is not None) else None
     ggrad = empty((), x) if gate_acc is not None else None
-    _call("ud_rfft2_ex", _p(x), _p(Y), N, S, Cc, float(scale), float(w_interior),
-          C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode),
-          _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), h, _stream())
+    tail = (C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode),
+            _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), h, _stream())
+    if _fft_two_pass("rfft_ex", S, h):
+        _call("ud_rfft2_two_pass", _p(x), _p(Y), _p(_fft_ws(N, S, Cc, x)), N, S, Cc, float(scale), float(w_interior), *tail)
+    else:
+        _call("ud_rfft2_ex", _p(x), _p(Y), N, S, Cc, float(scale), float(w_interior), *tail)
     return (Y, act, ggrad) if gate_acc is not None else (Y, act)
 
 
@@ -1547,8 +1581,12 @@ def irfft2_mix(Y, scale, spat, alpha, acc):
     assert spat.shape == (N, S, S, Cc)
     y = torch.empty_like(spat)
     fr = torch.empty_like(spat)
-    _call("ud_irfft2_mix", _p(Y), _p(y), N, S, Cc, float(scale), 1.0, _p(spat), _p(alpha), _p(fr), _pd(acc),
-          _pd(acc, Cc), h, _stream())
+    if _fft_two_pass("irfft_mix", S, h):
+        _call("ud_irfft2_two_pass", _p(Y), _p(y), _p(_fft_ws(N, S, Cc, Y)), N, S, Cc, float(scale), 1.0, _p(spat), _p(alpha),
+              _p(fr), _pd(acc), _pd(acc, Cc), h, _stream())
+    else:
+        _call("ud_irfft2_mix", _p(Y), _p(y), N, S, Cc, float(scale), 1.0, _p(spat), _p(alpha), _p(fr), _pd(acc),
+              _pd(acc, Cc), h, _stream())
     return y, fr
 
 

@@ -129,6 +129,9 @@ _SIGNATURES = {
     "ud_dwconv_bwd_weight_ex": [_P, _P, _P, _I, _P, _P, _I] + [_I] * 10 + [_I, _P],
     "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P],
     "ud_irfft2_mix": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
+    "ud_rfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P],
+    "ud_irfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
+    "ud_fft2_two_pass_ws_floats": [_I, _I, _I],
     "ud_dwtile_ws_doubles": [_I, _I, _I, _I],
     "ud_dwtile": [_P, _BN, _P, _P] + [_I] * 10 + [_P, _I, _P, _P, _BN, _I, _P, _P, _P, _I, _I, _P],
     "ud_dwtile_wgrad_part_rows": [_I, _I, _I],
@@ -149,10 +152,10 @@ _SIGNATURES = {
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
                 "ud_conv_small_wgrad_ws_floats", "ud_xchg_bytes"}
-_LONG_FUNCS = {"ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
+_LONG_FUNCS = {"ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
                "ud_dwconv_bwd_data_bn_ws_doubles"}        # return a C long
 
 EXPORTED = tuple(_SIGNATURES)
