@@ -271,14 +271,14 @@ def test_deterministic_mode_is_repeatable(name, ctor, n, size):
     three runs of the same train step give the same loss, output and parameter gradients.  On the operator path (every
     reduction in a fixed order) that is BITWISE; on the fused MBConv path the fp64 accumulators are filled by atomics, whose
     order can move a sum by 1e-16 — held to 1e-9 of each tensor's scale here (observed: bitwise as well)."""
-    from unidefense_amd.config import cfg, override
+    from unidefense_amd.config import override
     dev = _dev()
-    assert cfg.deterministic
-    with override(fused_mbconv=False):
+    with override(deterministic=True, fused_mbconv=False):
         runs = _det_runs(dev, name, ctor, n, size)
     assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1])
                and all(torch.equal(a, b) for a, b in zip(runs[0][2], r[2])) for r in runs[1:]), "operator path not bitwise"
-    runs = _det_runs(dev, name, ctor, n, size)
+    with override(deterministic=True):
+        runs = _det_runs(dev, name, ctor, n, size)
     w = _worst_rel(runs)
     print(f"  {name}: fused path, worst run-to-run deviation {w:.1e} over {len(runs[0][2])} gradients")
     assert within(f"{name} fused path run-to-run", w, 1e-9)
