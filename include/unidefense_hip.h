@@ -104,6 +104,36 @@ int ud_gemm_get_path(void);
  * mode (path 3), 1 for the fp32 pipe */
 int ud_gemm_query_path(const ud_gemm_desc* d);
 
+/* ---- ud_gemm_p3: the same fp32-accurate product from PRE-SPLIT operands (round 4) ----------------------------------
+ * Serves the spectral 1x1 conv of the SF blocks, F.conv2d(x_freq, freq_conv.weight) in model/efficientnet/exp.py:57 (and
+ * model/resnet/exp.py's copy), its data gradient and its weight gradient — the large GEMMs of the step.
+ * An operand is a matrix X[R][Cx] stored as three bf16 planes x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0),
+ * x2 = bf16(x - x0 - x1): the exact split ud_gemm performs inside its k-loop) in the "P32" panel layout:
+ *     piece p of X[r][c]   at   X + p * plane + (c / 32) * panel + r * 32 + (c % 32)        (bf16 elements)
+ * written by ud_split_planes (or by the kernel that produces X).  Each panel must be backed by rows up to the next
+ * multiple of 128 (panel >= 32 * roundup(R, 128); slack rows are read, their products discarded).
+ *   mode 0: GEMM row = row of X, k = column of X     (activations [pixels][C] as A; weights [Cout][Cin] as B)
+ *   mode 1: GEMM row = column of X, k = row of X     (dY / X of a weight gradient; weights of a data gradient)
+ * K % 32 == 0.  *_npanel: panels reachable from the pointer (mode 1 clamps its tile to them).  out_mode / split_k /
+ * slice_stride / stat_sum / stat_sumsq / tile_cfg bit 8 as in ud_gemm_desc (statistics: out_mode 0, split_k 1; one slot
+ * array [N] while M <= 64 * 128, else 64 slots). */
+typedef struct {
+    const uint16_t* A; const uint16_t* B; float* C;
+    int M, N, K;
+    long a_panel, a_plane, b_panel, b_plane;   /* bf16 elements between panels / between the three planes */
+    int a_npanel, b_npanel;
+    long ldc;
+    int a_mode, b_mode, out_mode, split_k;
+    double* stat_sum; double* stat_sumsq;
+    int tile_cfg;
+    long slice_stride;
+} ud_gemm_p3_desc;
+int ud_gemm_p3(const ud_gemm_p3_desc* d, ud_stream_t stream);
+/* x fp32 [R][C] (row stride ld; C, ld multiples of 4) -> three bf16 planes in the P32 layout above; columns C .. 32*ceil(C/32)-1
+ * are written as zeros, slack rows are left untouched. */
+int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,
+                    ud_stream_t stream);
+
 /* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------
  * Every reduction is a partial pass (fp64 per-workgroup totals stored into the scratch `ws`) plus a small
  * finalize launch; deterministic, no atomics.  ws: ud_reduce_ws_doubles(G, R, C) doubles of scratch, no

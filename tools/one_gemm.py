@@ -13,6 +13,12 @@ elif kind == "nn":
     a, b = torch.randn(M, Kd, device=dev), torch.randn(Kd, N, device=dev); fn = lambda: K.gemm_nn(a, b)
 else:
     a, b = torch.randn(Kd, M, device=dev), torch.randn(Kd, N, device=dev); fn = lambda: K.gemm_tn(a, b)
+if os.environ.get("UD_ONE_GEMM_P3"):
+    am, bm = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}[kind]
+    ap, bp = K.split_planes(a), K.split_planes(b)
+    out = torch.empty(M, N, device=dev)
+    cfg = int(os.environ.get("UD_ONE_GEMM_CFG", "0"), 0)
+    fn = lambda: K._gemm_p3(ap, bp, out, M, N, Kd, am, bm, cfg=cfg)
 for _ in range(it):
     fn()
 torch.cuda.synchronize()

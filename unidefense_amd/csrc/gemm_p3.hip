@@ -1,0 +1,469 @@
+// fp32-accurate GEMM on the gfx950 BF16 matrix pipe from PRE-SPLIT operands (round 4).
+//
+// gemm_x3.hip splits every fp32 operand tile into three bf16 pieces inside the k-loop: global -> VGPR -> ~160 vector
+// instructions -> ds_write, per K-tile and wave, against 24 MFMAs.  Here the operands ARRIVE split: a matrix X[R][C] is
+// stored by its producer (ud_split_planes, or the epilogue of the kernel that computes it) as three bf16 planes in the
+// "P32" panel layout
+//     plane p (0..2), panel c/32, row r, column c%32        at   p*plane + (c/32)*panel + r*32 + (c%32)   (bf16 elements)
+// so that BOTH uses of the matrix see contiguous 1-KiB pieces of whole cache lines:
+//     mode 0 (GEMM rows = rows of X, k = columns of X):  a 128 x 32 tile is ONE contiguous 8-KiB run of a panel;
+//     mode 1 (GEMM rows = columns of X, k = rows of X):   a 32 x 128 tile is four 2-KiB runs (one per panel).
+// The k-loop is LDS-DMA + ds_read + MFMA only: tiles go global -> LDS without passing VGPRs (global_load_lds_dwordx4,
+// 1 KiB per wave-instruction, three stages of 48 KiB in a ring, counted vmcnt + one raw s_barrier per K-tile), the
+// mode-0 image is XOR-swizzled on the SOURCE address (the DMA destination is lane-linear) so that the ds_read_b128
+// operand fetch is conflict-free, the mode-1 image is read with ds_read_b64_tr_b16 (hardware transpose).
+// Arithmetic identical to gemm_x3.hip: six piece products per 32x32x16 in the same order, fp32 accumulation, k ascending.
+//
+// Serves the spectral 1x1 convs of the SF blocks (model/efficientnet/exp.py:57 freq_conv: forward, data gradient, weight
+// gradient) — the 72 large launches per step.
+#include "gemm_internal.h"
+#include "ud_common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace {
+
+constexpr int NT = 512;                       // 4 MFMA waves (one per SIMD) + 4 loader waves
+constexpr int BK = 32;
+constexpr int BM = 128, BN = 128;
+constexpr int PLANE_IMG = 128 * 64;           // bytes of one plane of one operand tile (128 rows x 32 bf16)
+constexpr int OP_IMG = 3 * PLANE_IMG;         // one operand, three planes
+constexpr int STAGE = 2 * OP_IMG;             // A then B
+constexpr int NSTAGE = 3;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) char lds_char;
+
+// One LDS-DMA piece: 64 lanes x 16 B from gbase + voff (per lane) to LDS byte address lds_dst + 16 * lane.
+// Absent from hipcc's waitcnt bookkeeping: completion is counted by hand (vmcnt in issue order) — see the k-loop.
+__device__ __forceinline__ void dma_piece(unsigned voff, unsigned lds_dst, const char* gbase) {
+    // no "memory" clobber: the statement is ordered against the wait / barrier statements (all volatile), and no LDS read
+    // between two barriers touches the stage a DMA of that interval writes — hipcc may interleave it with the ds_reads.
+    // s_nop 1 + the three scalar instructions = the 5 wait states between a scalar write of %2 / %3 and the load reading them.
+    unsigned keep;
+    asm volatile(
+        "s_nop 1\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds_dst), "s"(gbase));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_dma_and_barrier() {
+    // all but the N youngest DMA pieces of this wave have landed, every LDS read of this wave has returned; then the
+    // workgroup barrier makes the other waves' pieces visible and their reads of the stage about to be refilled done
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void wait_lds_and_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Operand fragments of one 16-deep k-step: [row block 0/1][plane]
+struct Frags {
+    bf16x8 v[2][3];
+};
+
+// MODE 0 image of a plane: [row 128][64 B], 16-byte chunk c of row r stored at slot c ^ ((r >> 2) & 3).
+// MODE 1 image of a plane: [panel 4][k 32][64 B = 32 GEMM rows], linear.
+template <int MODE>
+struct Reader {
+    unsigned b0, b1;          // MODE 0: byte offsets of the lane's chunk for k-step 0 / 1 (row block 0, plane 0); MODE 1: b0 only
+
+    __device__ __forceinline__ void init(int lane, int wrow) {          // wrow: first of the wave's 64 rows inside the tile
+        if constexpr (MODE == 0) {
+            const int r = lane & 31, h = lane >> 5, x = (r >> 2) & 3;
+            b0 = (unsigned)((wrow + r) * 64 + ((h ^ x) << 4));
+            b1 = (unsigned)((wrow + r) * 64 + (((2 + h) ^ x) << 4));
+        } else {
+            const int g = lane >> 4, u = lane & 15, q = u >> 2, pp = u & 3;
+            b0 = (unsigned)((wrow >> 5) * 2048 + (8 * (g >> 1) + q) * 64 + (g & 1) * 32 + pp * 8);
+            b1 = 0;
+        }
+    }
+
+    // fragment (row block I, plane PL) of k-step S
+    template <int S, int I, int PL>
+    __device__ __forceinline__ void read_one(const lds_char* img, Frags& f) const {
+        if constexpr (MODE == 0) {
+            const lds_char* p = img + (S == 0 ? b0 : b1) + I * 2048 + PL * PLANE_IMG;
+            f.v[I][PL] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(p);
+        } else {
+            const lds_char* p = img + b0 + S * 1024 + I * 2048 + PL * PLANE_IMG;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 256));
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            f.v[I][PL] = __builtin_bit_cast(bf16x8, both);
+        }
+    }
+
+    template <int S>
+    __device__ __forceinline__ void read(const lds_char* img, Frags& f) const {
+        read_one<S, 0, 0>(img, f); read_one<S, 0, 1>(img, f); read_one<S, 0, 2>(img, f);
+        read_one<S, 1, 0>(img, f); read_one<S, 1, 1>(img, f); read_one<S, 1, 2>(img, f);
+    }
+};
+
+// per-lane source offset of a DMA piece (bytes from the piece's uniform base)
+template <int MODE>
+__device__ __forceinline__ unsigned dma_lane_offset(int lane) {
+    if constexpr (MODE == 0) return (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    else return (unsigned)(lane * 16);
+}
+
+// MFMA number Mi (0..23) of a k-step: product term Mi / 4 of accumulator (Mi % 4).  Every accumulator sees its six terms
+// in the order of gemm_x3.hip (smallest first: a2b0, a0b2, a1b1, a1b0, a0b1, a0b0); the accumulators are interleaved.
+template <int Mi>
+__device__ __forceinline__ void mma_one(f32x16 (&acc)[2][2], const Frags& a, const Frags& b) {
+    constexpr int term = Mi / 4, i = (Mi % 4) / 2, j = Mi % 2;
+    constexpr int pa = term == 0 ? 2 : (term == 1 || term >= 4) ? 0 : 1;
+    constexpr int pb = term == 0 ? 0 : term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[i][pa], b.v[j][pb], acc[i][j], 0, 0, 0);
+}
+
+// SK = false: grid (tiles, split_k); workgroup (tile, s) reduces K-tiles [s * kt_per, (s+1) * kt_per) — ud_gemm's launch forms
+//             (out_mode 0 / 1 / 2 / 3, epilogue statistics).
+// SK = true ("stream-K"): ONE workgroup per CU (the kernel owns 144 KiB of LDS, so a CU never holds two) and tile counts like 260
+//             or 540 on 256 CUs waste up to half a round.  The (tile, K-tile) units are dealt evenly instead: grid G (a multiple
+//             of 8, <= CUs), worker g takes units [g U / G, (g+1) U / G) of the tile-major order — the tail of one tile, whole tiles,
+//             the head of another.  A segment that covers its tile's whole K range stores (out_mode 0) or adds (1); a partial one
+//             adds atomically — C must be zero (out_mode 0) or hold the term to add to (1) before the launch.  Workers of one XCD
+//             (blockIdx % 8) take CONSECUTIVE ranges and the tile order walks 8-wide column bands row by row, so that the ~32
+//             tiles an XCD works on at any time form a patch sharing A and B panels in its L2.
+template <int AMODE, int BMODE, bool SK = false>
+__global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(1024))) char L[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int kt_total = d.K / BK;
+    const lds_char* Lp = (const lds_char*)L;          // generic -> LDS address space: the low 32 bits are the LDS byte address
+    const unsigned lds0 = (unsigned)(uintptr_t)Lp;
+    const int lw = wave & 3;                                        // loader wave lw moves tile rows 32 lw .. 32 lw + 31
+    const unsigned dst_w = lds0 + (unsigned)lw * 2048u;            // its pieces inside a plane image
+    const long a_plane = d.a_plane * 2, b_plane = d.b_plane * 2;
+    const unsigned a_voff = dma_lane_offset<AMODE>(lane), b_voff = dma_lane_offset<BMODE>(lane);
+    Reader<AMODE> ra;
+    Reader<BMODE> rb;
+    ra.init(lane, wm * 64);
+    rb.init(lane, wn * 64);
+    using std::integral_constant;
+    using H0 = integral_constant<int, 0>;
+    using H1 = integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    // K-tiles [kt0, kt0 + nkt) of tile (tile_m, tile_n); ep: 0 store, 1 add, 2 atomic add; stats only with ep 0
+    auto segment = [&](int tile_m, int tile_n, int kt0, int nkt, int ep, float* Cp, bool first) {
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        if (nkt > 0) {
+            // ---- DMA source of this wave: 32 tile rows (mode 0: rows 32w .. 32w+31 = pieces 2w, 2w+1; mode 1: panel w, both
+            // 16-deep halves of the K-tile); g(t, plane, jj) = g0 + t * step + plane * plane_bytes + jj * 1024
+            const char* a_g0;
+            const char* b_g0;
+            long a_step, b_step;
+            if constexpr (AMODE == 0) {
+                a_g0 = reinterpret_cast<const char*>(d.A) + (long)kt0 * d.a_panel * 2 + (long)(m0 + 32 * lw) * 64;
+                a_step = d.a_panel * 2;
+            } else {
+                a_g0 = reinterpret_cast<const char*>(d.A) + (long)min(m0 / 32 + lw, d.a_npanel - 1) * d.a_panel * 2 +
+                       (long)kt0 * BK * 64;
+                a_step = BK * 64;
+            }
+            if constexpr (BMODE == 0) {
+                b_g0 = reinterpret_cast<const char*>(d.B) + (long)kt0 * d.b_panel * 2 + (long)(n0 + 32 * lw) * 64;
+                b_step = d.b_panel * 2;
+            } else {
+                b_g0 = reinterpret_cast<const char*>(d.B) + (long)min(n0 / 32 + lw, d.b_npanel - 1) * d.b_panel * 2 +
+                       (long)kt0 * BK * 64;
+                b_step = BK * 64;
+            }
+
+            // piece PC (0..5: plane PC / 2, 16-row half PC % 2) of half WHICH (0: the wave's six A pieces, 1: its six B pieces)
+            auto issue_one = [&](auto which_c, auto pc_c, int t) {
+                constexpr int WHICH = decltype(which_c)::value, PC = decltype(pc_c)::value, pl = PC / 2, jj = PC % 2;
+                const unsigned dst = dst_w + (unsigned)(t % NSTAGE) * STAGE + (WHICH ? OP_IMG : 0) + pl * PLANE_IMG + jj * 1024;
+                const char* g = (WHICH ? b_g0 : a_g0) + (long)t * (WHICH ? b_step : a_step) +
+                                pl * (WHICH ? b_plane : a_plane) + jj * 1024;
+                dma_piece(WHICH ? b_voff : a_voff, dst, g);
+            };
+            auto issue = [&](auto which_c, int t) {
+                issue_one(which_c, integral_constant<int, 0>{}, t); issue_one(which_c, integral_constant<int, 1>{}, t);
+                issue_one(which_c, integral_constant<int, 2>{}, t); issue_one(which_c, integral_constant<int, 3>{}, t);
+                issue_one(which_c, integral_constant<int, 4>{}, t); issue_one(which_c, integral_constant<int, 5>{}, t);
+            };
+
+            // Roles: waves 0-3 compute (one per SIMD), waves 4-7 only move data: the ISSUE of an LDS-DMA piece costs the issuing
+            // wave 60-180 cycles while the texture-address path is busy (MI355X_MICROARCH.md), which in a computing wave is time
+            // the matrix pipe idles (measured: the k-loop ran 15-18 % faster with its DMA compiled out).  One workgroup barrier
+            // per K-tile is the whole protocol:
+            //   barrier(t):  loaders arrive after THEIR pieces of tile t+1 have landed (counted vmcnt; tile t+2 stays in flight),
+            //                MFMA waves after their last read of stage t%3 (tile t, k-step 1)  ->  after it tile t+1 is visible
+            //                and stage t%3 may be refilled with tile t+3 ... which the loaders issue right away.
+            if (wave >= 4) {
+                if (!first) wait_dma_and_barrier<0>();          // later stream-K segment: everyone is done with the stages
+                issue(H0{}, 0); issue(H1{}, 0);
+                if (nkt > 1) {
+                    issue(H0{}, 1); issue(H1{}, 1);
+                    if (nkt > 2) { issue(H0{}, 2); issue(H1{}, 2); wait_dma_and_barrier<24>(); }
+                    else wait_dma_and_barrier<12>();
+                } else {
+                    wait_dma_and_barrier<0>();
+                }
+                // barrier(t), t = 0 .. nkt-2
+                int t = 0;
+                for (; t + 3 < nkt; ++t) { wait_dma_and_barrier<12>(); issue(H0{}, t + 3); issue(H1{}, t + 3); }
+                if (t + 2 < nkt) { wait_dma_and_barrier<12>(); ++t; }
+                if (t + 1 < nkt) wait_dma_and_barrier<0>();
+                return;          // loaders hold no accumulators
+            }
+            if (!first) wait_lds_and_barrier();
+            wait_lds_and_barrier();          // tile 0 landed
+
+            Frags fa0, fb0, fa1, fb1;
+            ra.template read<0>(Lp, fa0);
+            rb.template read<0>(Lp + OP_IMG, fb0);
+
+            // One PHASE = the 24 MFMAs of a k-step, with the reads of the next k-step's fragments spread between them
+            // (pinned by sched_barrier: two reads, four MFMAs, six times), in the order the next phase first needs them.
+            auto phase = [&](auto rs_c, auto do_read_c, const Frags& ca, const Frags& cb, Frags& na, Frags& nb,
+                             const lds_char* img) {
+                constexpr int RS = decltype(rs_c)::value;
+                constexpr bool RD = decltype(do_read_c)::value;
+                auto slot = [&](auto k_c) {
+                    constexpr int k = decltype(k_c)::value;          // slot k: MFMAs 4k .. 4k+3
+                    constexpr int ai = k & 1, apl = k < 2 ? 2 : k < 4 ? 0 : 1;
+                    constexpr int bi = k & 1, bpl = k < 2 ? 0 : k < 4 ? 2 : 1;
+                    if constexpr (RD) {
+                        ra.template read_one<RS, ai, apl>(img, na);
+                        rb.template read_one<RS, bi, bpl>(img + OP_IMG, nb);
+                    }
+                    mma_one<4 * k>(acc, ca, cb);
+                    mma_one<4 * k + 1>(acc, ca, cb);
+                    mma_one<4 * k + 2>(acc, ca, cb);
+                    mma_one<4 * k + 3>(acc, ca, cb);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                slot(integral_constant<int, 0>{}); slot(integral_constant<int, 1>{}); slot(integral_constant<int, 2>{});
+                slot(integral_constant<int, 3>{}); slot(integral_constant<int, 4>{}); slot(integral_constant<int, 5>{});
+            };
+            // iteration t (fragments of (t, k-step 0) in fa0 / fb0):
+            //   phase A: MFMAs of k-step 0 | reads of (t, k-step 1);  barrier(t);  phase B: MFMAs of k-step 1 | reads of (t+1, k-step 0)
+            for (int t = 0; t + 1 < nkt; ++t) {
+                phase(H1{}, T{}, fa0, fb0, fa1, fb1, Lp + (t % NSTAGE) * STAGE);
+                wait_lds_and_barrier();
+                phase(H0{}, T{}, fa1, fb1, fa0, fb0, Lp + ((t + 1) % NSTAGE) * STAGE);
+            }
+            phase(H1{}, T{}, fa0, fb0, fa1, fb1, Lp + ((nkt - 1) % NSTAGE) * STAGE);
+            phase(H0{}, F{}, fa1, fb1, fa0, fb0, Lp);
+        } else if (wave >= 4) {
+            return;
+        }
+
+        // ---- epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (nkt <= 0 && ep != 0) return;
+        if (!SK && d.stat_sum) {
+            if (m0 + BM > d.M) {          // rows beyond M were fed from the allocation's slack: not part of the statistics
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (row >= d.M) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+                    }
+            }
+            const long slot = (tiles_m > 64) ? (long)(tile_m & 63) * d.N : 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const double v = (double)acc[i][j][r];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                const int col = n0 + wn * 64 + j * 32 + l31;
+                if (half == 0 && col < d.N) {
+                    unsafeAtomicAdd(d.stat_sum + slot + col, s1);
+                    unsafeAtomicAdd(d.stat_sumsq + slot + col, s2);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < d.M && col < d.N) {
+                        const float v = acc[i][j][r];
+                        float* p = Cp + (long)row * d.ldc + col;
+                        if (ep == 0) *p = v;
+                        else if (ep == 1) *p += v;
+                        else atomicAdd(p, v);
+                    }
+                }
+            }
+        }
+    };
+
+    if constexpr (!SK) {
+        int bt = blockIdx.x;
+        if (d.tile_cfg & 0x100) {          // each XCD takes a contiguous range of the tile order (see gemm_x3.hip)
+            const int Tn = tiles_m * tiles_n, q = Tn >> 3, r = Tn & 7, x = bt & 7;
+            bt = x * q + (x < r ? x : r) + (bt >> 3);
+        }
+        const int split = blockIdx.y;
+        const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
+        const int kt0 = split * kt_per;
+        const int nkt = min(kt_per, kt_total - kt0);
+        segment(bt % tiles_m, bt / tiles_m, kt0, nkt, d.out_mode == 3 ? 0 : d.out_mode,
+                d.C + (d.out_mode == 3 ? (long)split * d.slice_stride : 0L), true);
+    } else {
+        const int G = gridDim.x, b = blockIdx.x;
+        const int g = (b & 7) * (G >> 3) + (b >> 3);
+        const long U = (long)tiles_m * tiles_n * kt_total;
+        long u = g * U / G;
+        const long u1 = (g + 1) * U / G;
+        // tile order: column bands of 8 tiles, row by row inside a band (the last band may be narrower)
+        const int band_tiles = 8 * tiles_m;
+        bool first = true;
+        while (u < u1) {
+            const int tile = (int)(u / kt_total), kt_b = (int)(u - (long)tile * kt_total);
+            const int kt_e = (int)min((long)kt_total, kt_b + (u1 - u));
+            const int band = tile / band_tiles, in_band = tile - band * band_tiles;
+            const int bw = min(8, tiles_n - band * 8);
+            const int tile_m = in_band / bw, tile_n = band * 8 + in_band - tile_m * bw;
+            const bool whole = kt_b == 0 && kt_e == kt_total;
+            segment(tile_m, tile_n, kt_b, kt_e - kt_b, whole ? d.out_mode : 2, d.C, first);
+            first = false;
+            u += kt_e - kt_b;
+        }
+    }
+}
+
+int num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
+template <int AMODE, int BMODE>
+int launch(const ud_gemm_p3_desc& d, hipStream_t s) {
+    const int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
+    if (d.tile_cfg & 0x800) {
+        // stream-K: one worker per CU, at least 4 K-tiles of work each, a multiple of 8 (the XCD count)
+        const long U = (long)tiles_m * tiles_n * (d.K / BK);
+        long G = std::min<long>(num_cus(), U / 4);
+        G = std::max<long>(8, G / 8 * 8);
+        hipLaunchKernelGGL((gemm_p3_kernel<AMODE, BMODE, true>), dim3((unsigned)G), dim3(NT), 0, s, d, tiles_m, tiles_n);
+    } else {
+        dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, 1);
+        hipLaunchKernelGGL((gemm_p3_kernel<AMODE, BMODE>), grid, dim3(NT), 0, s, d, tiles_m, tiles_n);
+    }
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fp32 [R][C] (row stride ld) -> three bf16 planes in the P32 layout; one thread = 8 consecutive columns of one row
+__device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v = {(__bf16)x, (__bf16)y};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ void split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = pack_bf16(x, y);
+    const float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pack_bf16(rx, ry);
+    const float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16(sx, sy);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long R, int C, long ld,
+                                                           uint16_t* __restrict__ out, long panel, long plane) {
+    // workgroup: 64 rows x one panel; thread: row = tid >> 2, chunk (8 columns) = tid & 3
+    const int tid = threadIdx.x;
+    const long row = (long)blockIdx.x * 64 + (tid >> 2);
+    const int pan = blockIdx.y, c0 = pan * 32 + (tid & 3) * 8;
+    if (row >= R) return;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + 8 <= C) {
+        v0 = *reinterpret_cast<const f32x4*>(x + row * ld + c0);
+        v1 = *reinterpret_cast<const f32x4*>(x + row * ld + c0 + 4);
+    } else if (c0 + 4 <= C) {
+        v0 = *reinterpret_cast<const f32x4*>(x + row * ld + c0);
+    }
+    uint32_t a[4], b[4], c[4];
+    split2(v0[0], v0[1], a[0], b[0], c[0]);
+    split2(v0[2], v0[3], a[1], b[1], c[1]);
+    split2(v1[0], v1[1], a[2], b[2], c[2]);
+    split2(v1[2], v1[3], a[3], b[3], c[3]);
+    const u32x4 p0 = {a[0], a[1], a[2], a[3]}, p1 = {b[0], b[1], b[2], b[3]}, p2 = {c[0], c[1], c[2], c[3]};
+    uint16_t* o = out + (long)pan * panel + row * 32 + (tid & 3) * 8;
+    *reinterpret_cast<u32x4*>(o) = p0;
+    *reinterpret_cast<u32x4*>(o + plane) = p1;
+    *reinterpret_cast<u32x4*>(o + 2 * plane) = p2;
+}
+
+}  // namespace
+
+extern "C" int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride,
+                               long plane_stride, ud_stream_t stream) {
+    if (!x || !planes || R <= 0 || C <= 0 || C % 4 != 0 || ld % 4 != 0 || ld < C || panel_stride < R * 32 ||
+        panel_stride % 8 != 0 || plane_stride % 8 != 0 || plane_stride < (long)ud_cdiv(C, 32) * panel_stride)
+        return UD_EINVAL;
+    dim3 grid((unsigned)ud_cdiv(R, 64), (unsigned)ud_cdiv(C, 32));
+    hipLaunchKernelGGL(split_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, R, C, ld, planes, panel_stride,
+                       plane_stride);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ud_gemm_p3(const ud_gemm_p3_desc* dp, ud_stream_t stream) {
+    if (!dp) return UD_EINVAL;
+    const ud_gemm_p3_desc& d = *dp;
+    if (!d.A || !d.B || !d.C || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.K % BK != 0 || d.split_k < 1 ||
+        d.split_k > d.K / BK || d.out_mode < 0 || d.out_mode > 3 || d.a_mode < 0 || d.a_mode > 1 || d.b_mode < 0 ||
+        d.b_mode > 1 || d.a_panel % 8 != 0 || d.b_panel % 8 != 0 || d.a_plane % 8 != 0 || d.b_plane % 8 != 0 ||
+        d.a_npanel < 1 || d.b_npanel < 1)
+        return UD_EINVAL;
+    if (d.stat_sum && (d.out_mode != 0 || d.split_k != 1 || !d.stat_sumsq || (d.tile_cfg & 0x800))) return UD_EINVAL;
+    if ((d.tile_cfg & 0x800) && (d.out_mode > 1 || d.split_k != 1)) return UD_EINVAL;          // stream-K: store-onto-zeros or add
+    if (d.out_mode == 3 && d.slice_stride < (long)d.M * d.ldc) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (d.a_mode == 0 && d.b_mode == 0) return launch<0, 0>(d, s);
+    if (d.a_mode == 0 && d.b_mode == 1) return launch<0, 1>(d, s);
+    if (d.a_mode == 1 && d.b_mode == 1) return launch<1, 1>(d, s);
+    if (d.a_mode == 1 && d.b_mode == 0) return launch<1, 0>(d, s);
+    return UD_EINVAL;
+}

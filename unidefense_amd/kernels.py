@@ -13,7 +13,7 @@ import torch
 
 from . import lib as _lib
 from .config import cfg as CFG
-from .lib import ConvGeom, GemmDesc
+from .lib import ConvGeom, GemmDesc, GemmP3Desc
 
 _call = _lib.call
 
@@ -196,6 +196,89 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
                              float(batch) * (A.element_size() * M * K + B.element_size() * K * N + Cout.element_size() * M * N)))
     else:
         _call("ud_gemm", C.byref(d), _stream())
+    if slices is not None:
+        ws, stride, total, accumulate = slices
+        _call("ud_sum_slices", _p(ws), _p(Cout), split_k, total, stride, accumulate, _stream())
+    if fold is not None:
+        tgt, slots = fold
+        _call("ud_stat_slots_fold", _pd64(tgt), _pd64(tgt, slots * N), slots, N, _pd64(stats), _pd64(stats, N), _stream())
+    return (Cout, stats_done) if stats is not None else Cout
+
+
+class Planes:
+    """A matrix X[R][C] as three bf16 planes x = x0 + x1 + x2 in the P32 panel layout of ud_gemm_p3
+    (include/unidefense_hip.h): piece p of X[r][c] at p * plane + (c // 32) * panel + r * 32 + c % 32."""
+    __slots__ = ("buf", "R", "C", "panel", "plane", "npanel")
+
+    def __init__(self, R, Cc, like):
+        self.R, self.C = R, Cc
+        self.npanel = -(-Cc // 32)
+        self.panel = 32 * (-(-R // 128) * 128)          # every panel is backed by rows up to the next multiple of 128
+        self.plane = self.npanel * self.panel
+        self.buf = torch.empty(3 * self.plane, dtype=torch.int16, device=like.device)
+
+
+def split_planes(x2, out=None):
+    """fp32 [R, C] (row stride >= C) -> Planes (the exact three-way bf16 split of gemm_x3.hip, done once by the producer)."""
+    _chk(x2)
+    R, Cc = x2.shape
+    assert x2.stride(1) == 1 and Cc % 4 == 0 and x2.stride(0) % 4 == 0
+    pl = out if out is not None else Planes(R, Cc, x2)
+    assert pl.R == R and pl.C == Cc
+    _call("ud_split_planes", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _stream())
+    return pl
+
+
+def p3_ok(M, N, K):
+    """shapes ud_gemm_p3 takes and is worth taking: whole 32-deep K-tiles, the large spectral GEMMs"""
+    return K % 32 == 0 and min(M, N) >= 128 and K >= 128
+
+
+def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=None, a_row0=0, cfg=0):
+    """Cout[M][N] (+)= A . B from pre-split operands.  a_row0: first GEMM row of A used (a multiple of 128; mode 0: a row
+    offset inside every panel, mode 1: whole panels).  stats as in _gemm."""
+    d = GemmP3Desc()
+    if a_mode == 0:
+        d.A = A.buf.data_ptr() + 2 * (a_row0 * 32)
+        d.a_npanel = A.npanel
+    else:
+        d.A = A.buf.data_ptr() + 2 * ((a_row0 // 32) * A.panel)
+        d.a_npanel = A.npanel - a_row0 // 32
+    d.B = B.buf.data_ptr()
+    d.b_npanel = B.npanel
+    d.C = Cout.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.a_panel, d.a_plane, d.b_panel, d.b_plane = A.panel, A.plane, B.panel, B.plane
+    d.ldc = N
+    d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
+    d.tile_cfg = cfg | (0x100 if _XCD_CONTIGUOUS else 0)
+    slices = None
+    if CFG.deterministic and out_mode == 2:
+        total = M * N
+        fresh = getattr(Cout, "_ud_fresh", False)
+        ws = _slice_ws(Cout, split_k * total)
+        d.C, d.out_mode, d.slice_stride = ws.data_ptr(), 3, total
+        slices = (ws, total, total, 0 if fresh else 1)
+        if fresh:
+            Cout._ud_fresh = False
+    fold = None
+    stats_done = False
+    if stats is not None and _GEMM_EPILOGUE_STATS and out_mode == 0 and split_k == 1:
+        stats_done = True
+        slots = 64 if -(-M // 128) > 64 else 1
+        tgt = stats if slots == 1 else zeros64(2 * slots * N, Cout)
+        d.stat_sum, d.stat_sumsq = tgt.data_ptr(), tgt.data_ptr() + 8 * (slots * N if slots > 1 else N)
+        if slots > 1:
+            fold = (tgt, slots)
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _call("ud_gemm_p3", C.byref(d), _stream())
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, a_mode, b_mode, split_k, 1), 4,
+                             6.0 * (M * K + K * N) + 4.0 * M * N))
+    else:
+        _call("ud_gemm_p3", C.byref(d), _stream())
     if slices is not None:
         ws, stride, total, accumulate = slices
         _call("ud_sum_slices", _p(ws), _p(Cout), split_k, total, stride, accumulate, _stream())

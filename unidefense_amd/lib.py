@@ -30,6 +30,16 @@ class GemmDesc(C.Structure):
                 ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("half_mask", C.c_int), ("tile_cfg", C.c_int), ("slice_stride", C.c_long)]
 
 
+class GemmP3Desc(C.Structure):
+    """ud_gemm_p3_desc: GEMM on pre-split bf16 planes (P32 layout), include/unidefense_hip.h."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("a_panel", C.c_long), ("a_plane", C.c_long), ("b_panel", C.c_long), ("b_plane", C.c_long),
+                ("a_npanel", C.c_int), ("b_npanel", C.c_int), ("ldc", C.c_long),
+                ("a_mode", C.c_int), ("b_mode", C.c_int), ("out_mode", C.c_int), ("split_k", C.c_int),
+                ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("tile_cfg", C.c_int), ("slice_stride", C.c_long)]
+
+
 class BnRef(C.Structure):
     """ud_bn_ref: a deferred BatchNorm (fp64 sums + affine parameters) applied by the consuming kernel."""
     _fields_ = [("sum", C.c_void_p), ("sumsq", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
@@ -43,6 +53,8 @@ _BN = C.POINTER(BnRef)
 # name -> argtypes (the trailing stream argument included); every function returns int
 _SIGNATURES = {
     "ud_gemm": [C.POINTER(GemmDesc), _P],
+    "ud_gemm_p3": [C.POINTER(GemmP3Desc), _P],
+    "ud_split_planes": [_P, _L, _I, _L, _P, _L, _L, _P],
     "ud_gemm_set_path": [C.c_int],
     "ud_gemm_query_path": [C.POINTER(GemmDesc)],
     "ud_gemm_stats_slots": [C.POINTER(GemmDesc)],
