@@ -107,32 +107,46 @@ int ud_gemm_query_path(const ud_gemm_desc* d);
 /* ---- ud_gemm_p3: the same fp32-accurate product from PRE-SPLIT operands (round 4) ----------------------------------
  * Serves the spectral 1x1 conv of the SF blocks, F.conv2d(x_freq, freq_conv.weight) in model/efficientnet/exp.py:57 (and
  * model/resnet/exp.py's copy), its data gradient and its weight gradient — the large GEMMs of the step.
- * An operand is a matrix X[R][Cx] stored as three bf16 planes x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0),
- * x2 = bf16(x - x0 - x1): the exact split ud_gemm performs inside its k-loop) in the "P32" panel layout:
- *     piece p of X[r][c]   at   X + p * plane + (c / 32) * panel + r * 32 + (c % 32)        (bf16 elements)
- * written by ud_split_planes (or by the kernel that produces X).  Each panel must be backed by rows up to the next
- * multiple of 128 (panel >= 32 * roundup(R, 128); slack rows are read, their products discarded).
+ * An operand is a matrix X[R][Cx] stored as 16-bit planes in the "P32" panel layout:
+ *     piece p of X[r][c]   at   X + p * plane + (c / 32) * panel + r * 32 + (c % 32)        (16-bit elements)
+ * Each panel must be backed by rows up to the next multiple of 128 (panel >= 32 * roundup(R, 128); slack rows are read,
+ * their products discarded).
+ *   prec 3: three bf16 planes x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): the exact split
+ *           ud_gemm performs inside its k-loop), six piece products — bitwise ud_gemm's result.  Written by ud_split_planes.
+ *   prec 2: two fp16 planes s_r * x = h0 + h1 with one power-of-two scale s_r per GEMM row (the row maximum scaled into
+ *           [2^14, 2^15)), three piece products a1b0 + a0b1 + a0b0 on the fp16 matrix pipe, the result multiplied by
+ *           a_inv_scale[m] * b_inv_scale[n] (= 1 / s, fp32 vectors [M] / [N]).  22 significand bits per element down to 2^-18
+ *           of its row maximum, the dropped a1b1 < 2^-24 |ab|, fp32 accumulation: the accuracy of an fp32 GEMM at half the
+ *           matrix work.  Written by ud_split_planes_h2 (scale per row of X: mode 0 operands only).
  *   mode 0: GEMM row = row of X, k = column of X     (activations [pixels][C] as A; weights [Cout][Cin] as B)
  *   mode 1: GEMM row = column of X, k = row of X     (dY / X of a weight gradient; weights of a data gradient)
- * K % 32 == 0.  *_npanel: panels reachable from the pointer (mode 1 clamps its tile to them).  out_mode / split_k /
- * slice_stride / stat_sum / stat_sumsq / tile_cfg bit 8 as in ud_gemm_desc (statistics: out_mode 0, split_k 1; one slot
- * array [N] while M <= 64 * 128, else 64 slots). */
+ * (a_mode, b_mode): prec 3 any; prec 2 (0,0).  K % 32 == 0.  *_npanel: panels reachable from the pointer (mode 1 clamps
+ * its tile to them).  out_mode / split_k / slice_stride / stat_sum / stat_sumsq as in ud_gemm_desc (statistics: out_mode 0,
+ * split_k 1; one slot array [N] while M <= 64 * 128, else 64 slots).
+ * tile_cfg bit 8: each XCD takes a contiguous range of the tile order; bit 11 (0x800): stream-K — one workgroup per CU, the
+ * (tile, K-tile) units dealt evenly; out_mode 0 (C zeroed by the caller: whole-tile segments store, partial ones add
+ * atomically) or 1 (C holds a term to add to); split_k 1, no statistics. */
 typedef struct {
     const uint16_t* A; const uint16_t* B; float* C;
     int M, N, K;
-    long a_panel, a_plane, b_panel, b_plane;   /* bf16 elements between panels / between the three planes */
+    long a_panel, a_plane, b_panel, b_plane;   /* 16-bit elements between panels / between the planes */
     int a_npanel, b_npanel;
     long ldc;
     int a_mode, b_mode, out_mode, split_k;
     double* stat_sum; double* stat_sumsq;
     int tile_cfg;
     long slice_stride;
+    int prec;                                   /* 3 or 2 */
+    const float* a_inv_scale; const float* b_inv_scale;   /* prec 2 */
 } ud_gemm_p3_desc;
 int ud_gemm_p3(const ud_gemm_p3_desc* d, ud_stream_t stream);
 /* x fp32 [R][C] (row stride ld; C, ld multiples of 4) -> three bf16 planes in the P32 layout above; columns C .. 32*ceil(C/32)-1
  * are written as zeros, slack rows are left untouched. */
 int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,
                     ud_stream_t stream);
+/* the prec-2 form: two fp16 planes of s_r * x[r][:] and inv_scale[r] = 1 / s_r (C <= 4096) */
+int ud_split_planes_h2(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,
+                       float* inv_scale, ud_stream_t stream);
 
 /* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------
  * Every reduction is a partial pass (fp64 per-workgroup totals stored into the scratch `ws`) plus a small

@@ -90,6 +90,42 @@ torch.cuda.synchronize()
 e = (out.double() - a[384:].double() @ b.double().t()).abs().max().item()
 print("row offset:", e, "ok" if e < 1e-3 else "FAIL")
 bad += e >= 1e-3
+# ---- prec 2: two fp16 pieces of the row-scaled operands, three products (nt form; nn runs as nt on the transposed weights)
+print("\n# prec 2 (fp16 x 2, row scales) against float64, error relative to sum |a||b| per output; x3 for comparison")
+def dist(name, M, Kd):
+    g = torch.randn(M, Kd, device=dev)
+    if name == "randn": return g
+    if name == "same-sign": return g.abs()
+    if name == "lognormal3": return g * torch.exp(3 * torch.randn(M, Kd, device=dev))
+    if name == "rows-e8": return g * torch.exp(8 * torch.randn(M, 1, device=dev))
+    if name == "cols-e4": return g * torch.exp(4 * torch.randn(1, Kd, device=dev))
+    if name == "tiny": return g * 1e-30
+    if name == "huge": return g * 1e30
+    if name == "zero-rows":
+        g[::3] = 0
+        return g
+for name in ("randn", "same-sign", "lognormal3", "rows-e8", "cols-e4", "tiny", "huge", "zero-rows"):
+    for M, N, Kd in ((384, 200, 96), (1280, 3264, 3264)):
+        a, b = dist(name, M, Kd), dist("randn" if name in ("tiny", "huge") else name, N, Kd)
+        want = a.double() @ b.double().t()
+        scale = a.double().abs() @ b.double().abs().t() + 1e-300
+        ap, bp = K.split_planes(a, prec=2), K.split_planes(b, prec=2)
+        out = torch.full((M, N), float("nan"), device=dev)
+        K._gemm_p3(ap, bp, out, M, N, Kd, 0, 0)
+        outs = torch.zeros(M, N, device=dev)
+        K._gemm_p3(ap, bp, outs, M, N, Kd, 0, 0, 2, 2)
+        outk = torch.zeros(M, N, device=dev)
+        K._gemm_p3(ap, bp, outk, M, N, Kd, 0, 0, 0, 1, cfg=0x800)
+        ref = torch.empty(M, N, device=dev)
+        x3("nt", a, b, ref, M, N, Kd)
+        torch.cuda.synchronize()
+        e = ((out.double() - want).abs() / scale).max().item()
+        es = ((outs.double() - want).abs() / scale).max().item()
+        ek = ((outk.double() - want).abs() / scale).max().item()
+        e3 = ((ref.double() - want).abs() / scale).max().item()
+        ok = max(e, es, ek) < max(2e-6, 2 * e3) and torch.isfinite(out).all().item()
+        bad += not ok
+        print(f"{name:11s} {M}x{N}x{Kd}: p2 {e:.2e} split-2 {es:.2e} stream-K {ek:.2e} | x3 {e3:.2e}  {'ok' if ok else 'FAIL'}", flush=True)
 print("FAILURES:", bad, flush=True)
 
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
@@ -115,6 +151,19 @@ for kind, M, N, Kd, split in rows:
     ts_b = K._time_launches(lambda: K.split_planes(b, bp), n=8)
     best = min(tp.values())
     fl = 2.0 * M * N * Kd
+    t2 = ""
+    if kind != "tn" and Kd <= 4096:
+        a2 = a
+        b2 = b if kind == "nt" else b.t().contiguous()
+        ap2, bp2 = K.split_planes(a2, prec=2), K.split_planes(b2, prec=2)
+        tq = {sp: K._time_launches(lambda: K._gemm_p3(ap2, bp2, out, M, N, Kd, 0, 0, 2 if sp > 1 else 0, sp), n=8)
+              for sp in sorted({1, split}) if Kd // 32 >= sp}
+        tq["sk"] = K._time_launches(lambda: K._gemm_p3(ap2, bp2, outz, M, N, Kd, 0, 0, 1, 1, cfg=0x800), n=8)
+        th_a = K._time_launches(lambda: K.split_planes(a2, ap2), n=8)
+        th_b = K._time_launches(lambda: K.split_planes(b2, bp2), n=8)
+        bq = min(tq.values())
+        t2 = (" || p2 " + " ".join(f"{k} {t * 1e3:6.1f}" for k, t in tq.items()) +
+              f" best {fl / bq / 1e9:5.1f} TF x{t3 / bq:.2f} split A {th_a * 1e3:.1f} B {th_b * 1e3:.1f}")
     print(f"{kind} {M}x{N}x{Kd}: x3 {t3 * 1e3:7.1f} ({fl / t3 / 1e9:5.1f} TF)  p3 " +
           " ".join(f"s{sp} {t * 1e3:7.1f}" for sp, t in tp.items()) +
-          f"  best {fl / best / 1e9:5.1f} TF  x{t3 / best:.2f} | stream-K {tsk * 1e3:7.1f} ({fl / tsk / 1e9:5.1f} TF) x{t3 / tsk:.2f} | split A {ts_a * 1e3:.1f} B {ts_b * 1e3:.1f}", flush=True)
+          f"  best {fl / best / 1e9:5.1f} TF  x{t3 / best:.2f} | stream-K {tsk * 1e3:7.1f} ({fl / tsk / 1e9:5.1f} TF) x{t3 / tsk:.2f} | split A {ts_a * 1e3:.1f} B {ts_b * 1e3:.1f}" + t2, flush=True)

@@ -1,21 +1,33 @@
-// fp32-accurate GEMM on the gfx950 BF16 matrix pipe from PRE-SPLIT operands (round 4).
+// fp32-accurate GEMM on the gfx950 matrix pipe from PRE-SPLIT operands (round 4).
 //
 // gemm_x3.hip splits every fp32 operand tile into three bf16 pieces inside the k-loop: global -> VGPR -> ~160 vector
 // instructions -> ds_write, per K-tile and wave, against 24 MFMAs.  Here the operands ARRIVE split: a matrix X[R][C] is
-// stored by its producer (ud_split_planes, or the epilogue of the kernel that computes it) as three bf16 planes in the
-// "P32" panel layout
-//     plane p (0..2), panel c/32, row r, column c%32        at   p*plane + (c/32)*panel + r*32 + (c%32)   (bf16 elements)
+// stored by its producer (ud_split_planes*) as NPL 16-bit planes in the "P32" panel layout
+//     plane p, panel c/32, row r, column c%32        at   p*plane + (c/32)*panel + r*32 + (c%32)        (16-bit elements)
 // so that BOTH uses of the matrix see contiguous 1-KiB pieces of whole cache lines:
 //     mode 0 (GEMM rows = rows of X, k = columns of X):  a 128 x 32 tile is ONE contiguous 8-KiB run of a panel;
 //     mode 1 (GEMM rows = columns of X, k = rows of X):   a 32 x 128 tile is four 2-KiB runs (one per panel).
-// The k-loop is LDS-DMA + ds_read + MFMA only: tiles go global -> LDS without passing VGPRs (global_load_lds_dwordx4,
-// 1 KiB per wave-instruction, three stages of 48 KiB in a ring, counted vmcnt + one raw s_barrier per K-tile), the
-// mode-0 image is XOR-swizzled on the SOURCE address (the DMA destination is lane-linear) so that the ds_read_b128
-// operand fetch is conflict-free, the mode-1 image is read with ds_read_b64_tr_b16 (hardware transpose).
-// Arithmetic identical to gemm_x3.hip: six piece products per 32x32x16 in the same order, fp32 accumulation, k ascending.
+// Two precisions:
+//   PREC 3: x = x0 + x1 + x2 in bf16 (the exact split of gemm_x3.hip), six piece products per 32x32x16 in gemm_x3's order —
+//           bitwise the results of gemm_x3_kernel.
+//   PREC 2: s*x = h0 + 2^-11 h1 in fp16 with a power-of-two scale s PER GEMM ROW (row maximum -> [2^14, 2^15)); the second piece
+//           is stored scaled by 2^11, so that it is a NORMAL fp16 wherever the first is (the matrix pipe flushes fp16 subnormals:
+//           unscaled, every element more than 2^-18 below its row's maximum lost its second piece — measured 1.4e-5 on
+//           heavy-tailed rows).  Three products on v_mfma_f32_32x32x16_f16 into TWO fp32 accumulators per tile — a0b0, and
+//           a1b0 + a0b1 — combined as (hi + 2^-11 lo) / (sa sb) in the epilogue.  h0 + 2^-11 h1 carries 22 significand bits of every
+//           element within 2^-29 of its row's maximum, the dropped a1b1 is below 2^-24 |ab|: the error of a product is that of an
+//           fp32 multiply, the sum is accumulated in fp32 as before — HALF the matrix-pipe work and two thirds of the operand
+//           bytes of PREC 3, which is what counts on a part that holds its clock down under MFMA load (measured 1.5-1.6 GHz).
+//
+// The k-loop is LDS-DMA + ds_read + MFMA only.  Roles: waves 0-3 compute (one per SIMD), waves 4-7 only move data — the ISSUE of
+// an LDS-DMA piece (global_load_lds_dwordx4, 1 KiB per wave-instruction) costs the issuing wave 60-180 cycles while the CU's
+// texture-address path is busy, which in a computing wave is time the matrix pipe idles (measured: +15-18 % with the DMA
+// compiled out of a combined loop, +7 % from giving it to loader waves).  A ring of NSTAGE stages, counted vmcnt, ONE raw
+// s_barrier per K-tile.  The mode-0 image is XOR-swizzled on the SOURCE address (the DMA destination is lane-linear) so that the
+// ds_read_b128 operand fetch is conflict-free (SQ_LDS_BANK_CONFLICT = 0), the mode-1 image is read with ds_read_b64_tr_b16.
 //
 // Serves the spectral 1x1 convs of the SF blocks (model/efficientnet/exp.py:57 freq_conv: forward, data gradient, weight
-// gradient) — the 72 large launches per step.
+// gradient) — the large launches of the step.
 #include "gemm_internal.h"
 #include "ud_common.h"
 
@@ -27,22 +39,28 @@ namespace {
 constexpr int NT = 512;                       // 4 MFMA waves (one per SIMD) + 4 loader waves
 constexpr int BK = 32;
 constexpr int BM = 128, BN = 128;
-constexpr int PLANE_IMG = 128 * 64;           // bytes of one plane of one operand tile (128 rows x 32 bf16)
-constexpr int OP_IMG = 3 * PLANE_IMG;         // one operand, three planes
-constexpr int STAGE = 2 * OP_IMG;             // A then B
-constexpr int NSTAGE = 3;
+constexpr int PLANE_IMG = 128 * 64;           // bytes of one plane of one operand tile (128 rows x 32 16-bit elements)
+
+template <int PREC> struct Cfg {
+    static constexpr int NPL = PREC;                    // planes per operand
+    static constexpr int OP_IMG = NPL * PLANE_IMG;      // one operand, all planes
+    static constexpr int STAGE = 2 * OP_IMG;            // A then B
+    static constexpr int NSTAGE = PREC == 3 ? 3 : 4;    // 144 KiB / 128 KiB of LDS
+    static constexpr int PT = 4 * NPL;                  // DMA pieces per tile and loader wave
+    static constexpr int NTERM = PREC == 3 ? 6 : 3;     // piece products per 32x32x16
+};
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) char lds_char;
 
 // One LDS-DMA piece: 64 lanes x 16 B from gbase + voff (per lane) to LDS byte address lds_dst + 16 * lane.
-// Absent from hipcc's waitcnt bookkeeping: completion is counted by hand (vmcnt in issue order) — see the k-loop.
+// Absent from hipcc's waitcnt bookkeeping: completion is counted by hand (vmcnt in issue order) — see the loader.
+// No "memory" clobber: the statement is ordered against the wait / barrier statements (all volatile).
+// s_nop 1 + the three scalar instructions = the 5 wait states between a scalar write of %2 / %3 and the load reading them.
 __device__ __forceinline__ void dma_piece(unsigned voff, unsigned lds_dst, const char* gbase) {
-    // no "memory" clobber: the statement is ordered against the wait / barrier statements (all volatile), and no LDS read
-    // between two barriers touches the stage a DMA of that interval writes — hipcc may interleave it with the ds_reads.
-    // s_nop 1 + the three scalar instructions = the 5 wait states between a scalar write of %2 / %3 and the load reading them.
     unsigned keep;
     asm volatile(
         "s_nop 1\n\t"
@@ -55,20 +73,26 @@ __device__ __forceinline__ void dma_piece(unsigned voff, unsigned lds_dst, const
         : "v"(voff), "s"(lds_dst), "s"(gbase));
 }
 
+// all but the N youngest DMA pieces of this wave have landed (and its LDS reads returned), then the workgroup barrier
 template <int N>
 __device__ __forceinline__ void wait_dma_and_barrier() {
-    // all but the N youngest DMA pieces of this wave have landed, every LDS read of this wave has returned; then the
-    // workgroup barrier makes the other waves' pieces visible and their reads of the stage about to be refilled done
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
-
+// ... with N = tiles * PT chosen at run time (uniform)
+template <int PT>
+__device__ __forceinline__ void wait_tiles_and_barrier(int tiles) {
+    if (tiles <= 0) wait_dma_and_barrier<0>();
+    else if (tiles == 1) wait_dma_and_barrier<PT>();
+    else if (tiles == 2) wait_dma_and_barrier<2 * PT>();
+    else wait_dma_and_barrier<3 * PT>();
+}
 __device__ __forceinline__ void wait_lds_and_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // Operand fragments of one 16-deep k-step: [row block 0/1][plane]
-struct Frags {
-    bf16x8 v[2][3];
+template <int NPL> struct Frags {
+    s16x8 v[2][NPL];
 };
 
 // MODE 0 image of a plane: [row 128][64 B], 16-byte chunk c of row r stored at slot c ^ ((r >> 2) & 3).
@@ -90,24 +114,24 @@ struct Reader {
     }
 
     // fragment (row block I, plane PL) of k-step S
-    template <int S, int I, int PL>
-    __device__ __forceinline__ void read_one(const lds_char* img, Frags& f) const {
+    template <int S, int I, int PL, int NPL>
+    __device__ __forceinline__ void read_one(const lds_char* img, Frags<NPL>& f) const {
         if constexpr (MODE == 0) {
             const lds_char* p = img + (S == 0 ? b0 : b1) + I * 2048 + PL * PLANE_IMG;
-            f.v[I][PL] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(p);
+            f.v[I][PL] = *reinterpret_cast<const __attribute__((address_space(3))) s16x8*>(p);
         } else {
             const lds_char* p = img + b0 + S * 1024 + I * 2048 + PL * PLANE_IMG;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 256));
-            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            f.v[I][PL] = __builtin_bit_cast(bf16x8, both);
+            f.v[I][PL] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     }
 
-    template <int S>
-    __device__ __forceinline__ void read(const lds_char* img, Frags& f) const {
-        read_one<S, 0, 0>(img, f); read_one<S, 0, 1>(img, f); read_one<S, 0, 2>(img, f);
-        read_one<S, 1, 0>(img, f); read_one<S, 1, 1>(img, f); read_one<S, 1, 2>(img, f);
+    template <int S, int NPL>
+    __device__ __forceinline__ void read(const lds_char* img, Frags<NPL>& f) const {
+        read_one<S, 0, 0>(img, f); read_one<S, 1, 0>(img, f);
+        read_one<S, 0, 1>(img, f); read_one<S, 1, 1>(img, f);
+        if constexpr (NPL == 3) { read_one<S, 0, 2>(img, f); read_one<S, 1, 2>(img, f); }
     }
 };
 
@@ -118,32 +142,50 @@ __device__ __forceinline__ unsigned dma_lane_offset(int lane) {
     else return (unsigned)(lane * 16);
 }
 
-// MFMA number Mi (0..23) of a k-step: product term Mi / 4 of accumulator (Mi % 4).  Every accumulator sees its six terms
-// in the order of gemm_x3.hip (smallest first: a2b0, a0b2, a1b1, a1b0, a0b1, a0b0); the accumulators are interleaved.
-template <int Mi>
-__device__ __forceinline__ void mma_one(f32x16 (&acc)[2][2], const Frags& a, const Frags& b) {
+// planes of the TERM-th piece product, smallest first.  PREC 3 (gemm_x3.hip's order): a2b0, a0b2, a1b1, a1b0, a0b1, a0b0;
+// PREC 2: a1b0, a0b1, a0b0
+template <int PREC, int TERM> struct Term {
+    static constexpr int pa = PREC == 3 ? (TERM == 0 ? 2 : (TERM == 1 || TERM >= 4) ? 0 : 1) : (TERM == 0 ? 1 : 0);
+    static constexpr int pb = PREC == 3 ? (TERM == 0 ? 0 : TERM == 1 ? 2 : (TERM == 2 || TERM == 4) ? 1 : 0) : (TERM == 1 ? 1 : 0);
+};
+
+// MFMA number Mi of a k-step: product term Mi / 4 of accumulator Mi % 4 (the accumulators are interleaved, every one sees
+// its terms in order).  PREC 2: the cross terms (a1b0, a0b1: pieces scaled by 2^11) go to `lo`, a0b0 to `acc`.
+template <int PREC, int Mi>
+__device__ __forceinline__ void mma_one(f32x16 (&acc)[2][2], f32x16 (&lo)[2][2], const Frags<PREC>& a, const Frags<PREC>& b) {
     constexpr int term = Mi / 4, i = (Mi % 4) / 2, j = Mi % 2;
-    constexpr int pa = term == 0 ? 2 : (term == 1 || term >= 4) ? 0 : 1;
-    constexpr int pb = term == 0 ? 0 : term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[i][pa], b.v[j][pb], acc[i][j], 0, 0, 0);
+    using Tm = Term<PREC, term>;
+    if constexpr (PREC == 3) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v[i][Tm::pa]),
+                                                            __builtin_bit_cast(bf16x8, b.v[j][Tm::pb]), acc[i][j], 0, 0, 0);
+    } else if constexpr (term < 2) {
+        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v[i][Tm::pa]),
+                                                          __builtin_bit_cast(f16x8, b.v[j][Tm::pb]), lo[i][j], 0, 0, 0);
+    } else {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v[i][Tm::pa]),
+                                                           __builtin_bit_cast(f16x8, b.v[j][Tm::pb]), acc[i][j], 0, 0, 0);
+    }
 }
 
 // SK = false: grid (tiles, split_k); workgroup (tile, s) reduces K-tiles [s * kt_per, (s+1) * kt_per) — ud_gemm's launch forms
 //             (out_mode 0 / 1 / 2 / 3, epilogue statistics).
-// SK = true ("stream-K"): ONE workgroup per CU (the kernel owns 144 KiB of LDS, so a CU never holds two) and tile counts like 260
+// SK = true ("stream-K"): ONE workgroup per CU (the kernel owns most of the LDS, so a CU never holds two) and tile counts like 260
 //             or 540 on 256 CUs waste up to half a round.  The (tile, K-tile) units are dealt evenly instead: grid G (a multiple
 //             of 8, <= CUs), worker g takes units [g U / G, (g+1) U / G) of the tile-major order — the tail of one tile, whole tiles,
 //             the head of another.  A segment that covers its tile's whole K range stores (out_mode 0) or adds (1); a partial one
 //             adds atomically — C must be zero (out_mode 0) or hold the term to add to (1) before the launch.  Workers of one XCD
-//             (blockIdx % 8) take CONSECUTIVE ranges and the tile order walks 8-wide column bands row by row, so that the ~32
-//             tiles an XCD works on at any time form a patch sharing A and B panels in its L2.
-template <int AMODE, int BMODE, bool SK = false>
+//             (blockIdx % 8) take CONSECUTIVE ranges and the tile order walks 8-wide column bands row by row.  Measured: it pays
+//             only where the tile count sits just above a multiple of the CUs (260 tiles: 1.2x); elsewhere workers that share a
+//             panel no longer stream the same k at the same time and the L2 hit rate falls (540 tiles: 0.95x).
+template <int PREC, int AMODE, int BMODE, bool SK = false>
 __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d, int tiles_m, int tiles_n) {
+    using CF = Cfg<PREC>;
+    constexpr int NPL = CF::NPL, OP_IMG = CF::OP_IMG, STAGE = CF::STAGE, NSTAGE = CF::NSTAGE, PT = CF::PT;
     __shared__ __attribute__((aligned(1024))) char L[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
     const int kt_total = d.K / BK;
     const lds_char* Lp = (const lds_char*)L;          // generic -> LDS address space: the low 32 bits are the LDS byte address
@@ -165,104 +207,105 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
     // K-tiles [kt0, kt0 + nkt) of tile (tile_m, tile_n); ep: 0 store, 1 add, 2 atomic add; stats only with ep 0
     auto segment = [&](int tile_m, int tile_n, int kt0, int nkt, int ep, float* Cp, bool first) {
         const int m0 = tile_m * BM, n0 = tile_n * BN;
-        f32x16 acc[2][2];
+        f32x16 acc[2][2], lo[PREC == 2 ? 2 : 1][2];          // lo: PREC 2's cross terms
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    acc[i][j][r] = 0.f;
+                    if constexpr (PREC == 2) lo[i][j][r] = 0.f;
+                }
 
         if (nkt > 0) {
-            // ---- DMA source of this wave: 32 tile rows (mode 0: rows 32w .. 32w+31 = pieces 2w, 2w+1; mode 1: panel w, both
-            // 16-deep halves of the K-tile); g(t, plane, jj) = g0 + t * step + plane * plane_bytes + jj * 1024
-            const char* a_g0;
-            const char* b_g0;
-            long a_step, b_step;
-            if constexpr (AMODE == 0) {
-                a_g0 = reinterpret_cast<const char*>(d.A) + (long)kt0 * d.a_panel * 2 + (long)(m0 + 32 * lw) * 64;
-                a_step = d.a_panel * 2;
-            } else {
-                a_g0 = reinterpret_cast<const char*>(d.A) + (long)min(m0 / 32 + lw, d.a_npanel - 1) * d.a_panel * 2 +
-                       (long)kt0 * BK * 64;
-                a_step = BK * 64;
-            }
-            if constexpr (BMODE == 0) {
-                b_g0 = reinterpret_cast<const char*>(d.B) + (long)kt0 * d.b_panel * 2 + (long)(n0 + 32 * lw) * 64;
-                b_step = d.b_panel * 2;
-            } else {
-                b_g0 = reinterpret_cast<const char*>(d.B) + (long)min(n0 / 32 + lw, d.b_npanel - 1) * d.b_panel * 2 +
-                       (long)kt0 * BK * 64;
-                b_step = BK * 64;
-            }
-
-            // piece PC (0..5: plane PC / 2, 16-row half PC % 2) of half WHICH (0: the wave's six A pieces, 1: its six B pieces)
-            auto issue_one = [&](auto which_c, auto pc_c, int t) {
-                constexpr int WHICH = decltype(which_c)::value, PC = decltype(pc_c)::value, pl = PC / 2, jj = PC % 2;
-                const unsigned dst = dst_w + (unsigned)(t % NSTAGE) * STAGE + (WHICH ? OP_IMG : 0) + pl * PLANE_IMG + jj * 1024;
-                const char* g = (WHICH ? b_g0 : a_g0) + (long)t * (WHICH ? b_step : a_step) +
-                                pl * (WHICH ? b_plane : a_plane) + jj * 1024;
-                dma_piece(WHICH ? b_voff : a_voff, dst, g);
-            };
-            auto issue = [&](auto which_c, int t) {
-                issue_one(which_c, integral_constant<int, 0>{}, t); issue_one(which_c, integral_constant<int, 1>{}, t);
-                issue_one(which_c, integral_constant<int, 2>{}, t); issue_one(which_c, integral_constant<int, 3>{}, t);
-                issue_one(which_c, integral_constant<int, 4>{}, t); issue_one(which_c, integral_constant<int, 5>{}, t);
-            };
-
-            // Roles: waves 0-3 compute (one per SIMD), waves 4-7 only move data: the ISSUE of an LDS-DMA piece costs the issuing
-            // wave 60-180 cycles while the texture-address path is busy (MI355X_MICROARCH.md), which in a computing wave is time
-            // the matrix pipe idles (measured: the k-loop ran 15-18 % faster with its DMA compiled out).  One workgroup barrier
-            // per K-tile is the whole protocol:
-            //   barrier(t):  loaders arrive after THEIR pieces of tile t+1 have landed (counted vmcnt; tile t+2 stays in flight),
-            //                MFMA waves after their last read of stage t%3 (tile t, k-step 1)  ->  after it tile t+1 is visible
-            //                and stage t%3 may be refilled with tile t+3 ... which the loaders issue right away.
             if (wave >= 4) {
-                if (!first) wait_dma_and_barrier<0>();          // later stream-K segment: everyone is done with the stages
-                issue(H0{}, 0); issue(H1{}, 0);
-                if (nkt > 1) {
-                    issue(H0{}, 1); issue(H1{}, 1);
-                    if (nkt > 2) { issue(H0{}, 2); issue(H1{}, 2); wait_dma_and_barrier<24>(); }
-                    else wait_dma_and_barrier<12>();
+                // ---- loader.  Source of this wave: 32 tile rows (mode 0: rows 32 lw .. 32 lw + 31 = pieces 2 lw, 2 lw + 1; mode 1:
+                // panel lw, both 16-deep halves of the K-tile); g(t, plane, jj) = g0 + t * step + plane * plane_bytes + jj * 1024
+                const char* a_g0;
+                const char* b_g0;
+                long a_step, b_step;
+                if constexpr (AMODE == 0) {
+                    a_g0 = reinterpret_cast<const char*>(d.A) + (long)kt0 * d.a_panel * 2 + (long)(m0 + 32 * lw) * 64;
+                    a_step = d.a_panel * 2;
                 } else {
-                    wait_dma_and_barrier<0>();
+                    a_g0 = reinterpret_cast<const char*>(d.A) + (long)min(m0 / 32 + lw, d.a_npanel - 1) * d.a_panel * 2 +
+                           (long)kt0 * BK * 64;
+                    a_step = BK * 64;
                 }
-                // barrier(t), t = 0 .. nkt-2
-                int t = 0;
-                for (; t + 3 < nkt; ++t) { wait_dma_and_barrier<12>(); issue(H0{}, t + 3); issue(H1{}, t + 3); }
-                if (t + 2 < nkt) { wait_dma_and_barrier<12>(); ++t; }
-                if (t + 1 < nkt) wait_dma_and_barrier<0>();
+                if constexpr (BMODE == 0) {
+                    b_g0 = reinterpret_cast<const char*>(d.B) + (long)kt0 * d.b_panel * 2 + (long)(n0 + 32 * lw) * 64;
+                    b_step = d.b_panel * 2;
+                } else {
+                    b_g0 = reinterpret_cast<const char*>(d.B) + (long)min(n0 / 32 + lw, d.b_npanel - 1) * d.b_panel * 2 +
+                           (long)kt0 * BK * 64;
+                    b_step = BK * 64;
+                }
+                // tile t: the wave's 2 NPL pieces of A (plane, 16-row half), then those of B
+                auto issue = [&](int t) {
+                    const unsigned dst = dst_w + (unsigned)(t % NSTAGE) * STAGE;
+                    const char* ga = a_g0 + (long)t * a_step;
+                    const char* gb = b_g0 + (long)t * b_step;
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+                            dma_piece(a_voff, dst + pl * PLANE_IMG + jj * 1024, ga + pl * a_plane + jj * 1024);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+                            dma_piece(b_voff, dst + OP_IMG + pl * PLANE_IMG + jj * 1024, gb + pl * b_plane + jj * 1024);
+                };
+                // One workgroup barrier per K-tile is the whole protocol:
+                //   barrier(t):  loaders arrive after THEIR pieces of tile t+1 have landed (counted vmcnt; later tiles stay in
+                //                flight), MFMA waves after their last read of stage t % NSTAGE (tile t, k-step 1)  ->  after it tile
+                //                t+1 is visible and stage t % NSTAGE is refilled with tile t + NSTAGE.
+                if (!first) wait_dma_and_barrier<0>();          // later stream-K segment: everyone is done with the stages
+                const int pro = min(nkt, NSTAGE);
+                for (int t = 0; t < pro; ++t) issue(t);
+                wait_tiles_and_barrier<PT>(pro - 1);          // tile 0 landed
+                for (int t = 0; t + 1 < nkt; ++t) {
+                    wait_tiles_and_barrier<PT>(min(nkt, t + NSTAGE) - (t + 2));
+                    if (t + NSTAGE < nkt) issue(t + NSTAGE);
+                }
                 return;          // loaders hold no accumulators
             }
+            // ---- MFMA wave
             if (!first) wait_lds_and_barrier();
             wait_lds_and_barrier();          // tile 0 landed
 
-            Frags fa0, fb0, fa1, fb1;
+            f32x16 (&lo2)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&lo[0][0]);          // (PREC 3: never touched)
+            Frags<NPL> fa0, fb0, fa1, fb1;
             ra.template read<0>(Lp, fa0);
             rb.template read<0>(Lp + OP_IMG, fb0);
 
-            // One PHASE = the 24 MFMAs of a k-step, with the reads of the next k-step's fragments spread between them
-            // (pinned by sched_barrier: two reads, four MFMAs, six times), in the order the next phase first needs them.
-            auto phase = [&](auto rs_c, auto do_read_c, const Frags& ca, const Frags& cb, Frags& na, Frags& nb,
+            // One PHASE = the 4 NTERM MFMAs of a k-step, with the reads of the next k-step's fragments spread between them
+            // (pinned by sched_barrier: two reads and 4 / 3 MFMAs per slot), in the order the next phase first needs them.
+            auto phase = [&](auto rs_c, auto do_read_c, const Frags<NPL>& ca, const Frags<NPL>& cb, Frags<NPL>& na, Frags<NPL>& nb,
                              const lds_char* img) {
                 constexpr int RS = decltype(rs_c)::value;
                 constexpr bool RD = decltype(do_read_c)::value;
+                constexpr int NSLOT = 2 * NPL, PER = 4 * CF::NTERM / NSLOT;          // 6 slots of 4 MFMAs / 4 slots of 3
                 auto slot = [&](auto k_c) {
-                    constexpr int k = decltype(k_c)::value;          // slot k: MFMAs 4k .. 4k+3
-                    constexpr int ai = k & 1, apl = k < 2 ? 2 : k < 4 ? 0 : 1;
-                    constexpr int bi = k & 1, bpl = k < 2 ? 0 : k < 4 ? 2 : 1;
+                    constexpr int k = decltype(k_c)::value;
+                    // fragment pair k: row block k & 1; planes in the order of first use (PREC 3: A 2,0,1 / B 0,2,1; PREC 2: A 1,0 / B 0,1)
+                    constexpr int ai = k & 1, bi = k & 1;
+                    constexpr int apl = NPL == 3 ? (k < 2 ? 2 : k < 4 ? 0 : 1) : (k < 2 ? 1 : 0);
+                    constexpr int bpl = NPL == 3 ? (k < 2 ? 0 : k < 4 ? 2 : 1) : (k < 2 ? 0 : 1);
                     if constexpr (RD) {
                         ra.template read_one<RS, ai, apl>(img, na);
                         rb.template read_one<RS, bi, bpl>(img + OP_IMG, nb);
                     }
-                    mma_one<4 * k>(acc, ca, cb);
-                    mma_one<4 * k + 1>(acc, ca, cb);
-                    mma_one<4 * k + 2>(acc, ca, cb);
-                    mma_one<4 * k + 3>(acc, ca, cb);
+                    mma_one<PREC, PER * k>(acc, lo2, ca, cb);
+                    mma_one<PREC, PER * k + 1>(acc, lo2, ca, cb);
+                    mma_one<PREC, PER * k + 2>(acc, lo2, ca, cb);
+                    if constexpr (PER == 4) mma_one<PREC, PER * k + 3>(acc, lo2, ca, cb);
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 slot(integral_constant<int, 0>{}); slot(integral_constant<int, 1>{}); slot(integral_constant<int, 2>{});
-                slot(integral_constant<int, 3>{}); slot(integral_constant<int, 4>{}); slot(integral_constant<int, 5>{});
+                slot(integral_constant<int, 3>{});
+                if constexpr (NSLOT == 6) { slot(integral_constant<int, 4>{}); slot(integral_constant<int, 5>{}); }
             };
             // iteration t (fragments of (t, k-step 0) in fa0 / fb0):
             //   phase A: MFMAs of k-step 0 | reads of (t, k-step 1);  barrier(t);  phase B: MFMAs of k-step 1 | reads of (t+1, k-step 0)
@@ -279,8 +322,26 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
 
         // ---- epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
         if (nkt <= 0 && ep != 0) return;
+        if constexpr (PREC == 2) {
+            // undo the operands' per-row power-of-two scales (exact); rows / columns beyond the matrix were fed from slack: zero
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + l31;
+                const bool cok = col < d.N;
+                const float ib = cok ? d.b_inv_scale[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const bool ok = cok && row < d.M;
+                        const float ia = ok ? d.a_inv_scale[row] : 0.f;
+                        acc[i][j][r] = ok ? (acc[i][j][r] + 0x1p-11f * lo[i][j][r]) * (ia * ib) : 0.f;
+                    }
+            }
+        }
         if (!SK && d.stat_sum) {
-            if (m0 + BM > d.M) {          // rows beyond M were fed from the allocation's slack: not part of the statistics
+            if (PREC == 3 && m0 + BM > d.M) {          // rows beyond M were fed from the allocation's slack: not part of the statistics
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -376,7 +437,7 @@ int num_cus() {
     return n;
 }
 
-template <int AMODE, int BMODE>
+template <int PREC, int AMODE, int BMODE>
 int launch(const ud_gemm_p3_desc& d, hipStream_t s) {
     const int tiles_m = ud_cdiv(d.M, BM), tiles_n = ud_cdiv(d.N, BN);
     if (d.tile_cfg & 0x800) {
@@ -384,10 +445,10 @@ int launch(const ud_gemm_p3_desc& d, hipStream_t s) {
         const long U = (long)tiles_m * tiles_n * (d.K / BK);
         long G = std::min<long>(num_cus(), U / 4);
         G = std::max<long>(8, G / 8 * 8);
-        hipLaunchKernelGGL((gemm_p3_kernel<AMODE, BMODE, true>), dim3((unsigned)G), dim3(NT), 0, s, d, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_p3_kernel<PREC, AMODE, BMODE, true>), dim3((unsigned)G), dim3(NT), 0, s, d, tiles_m, tiles_n);
     } else {
         dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)d.split_k, 1);
-        hipLaunchKernelGGL((gemm_p3_kernel<AMODE, BMODE>), grid, dim3(NT), 0, s, d, tiles_m, tiles_n);
+        hipLaunchKernelGGL((gemm_p3_kernel<PREC, AMODE, BMODE>), grid, dim3(NT), 0, s, d, tiles_m, tiles_n);
     }
     UD_LAUNCH_CHECK();
     return 0;
@@ -408,6 +469,7 @@ __device__ __forceinline__ void split2(float x, float y, uint32_t& p0, uint32_t&
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long R, int C, long ld,
                                                            uint16_t* __restrict__ out, long panel, long plane) {
@@ -435,6 +497,57 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     *reinterpret_cast<u32x4*>(o + 2 * plane) = p2;
 }
 
+// ---- fp32 [R][C] -> two fp16 planes of s[r] * x[r][:], s[r] = the power of two that takes the row maximum into [2^14, 2^15),
+// and inv[r] = 1 / s[r].  One wave per row (the row lives in registers between the maximum and the split: C <= 256 * MAXQ),
+// four consecutive rows per workgroup, so that each panel receives 256 contiguous bytes.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(float x, float y, uint32_t& h0, uint32_t& h1) {
+    const f16x2 a = {(_Float16)x, (_Float16)y};
+    h0 = __builtin_bit_cast(uint32_t, a);
+    const f16x2 b = {(_Float16)((x - (float)a[0]) * 2048.f), (_Float16)((y - (float)a[1]) * 2048.f)};          // exact residual x 2^11
+    h1 = __builtin_bit_cast(uint32_t, b);
+}
+
+constexpr int H2_MAXQ = 16;          // float4 per lane: rows of up to 4096 columns
+
+__global__ __launch_bounds__(256) void split_h2_rows_kernel(const float* __restrict__ x, long R, int C, long ld,
+                                                            uint16_t* __restrict__ out, long panel, long plane,
+                                                            float* __restrict__ inv_scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int nq = C >> 2;                      // float4 of the row
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * ld);
+    f32x4 v[H2_MAXQ];
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < H2_MAXQ; ++i) {
+        const int q = lane + 64 * i;
+        v[i] = q < nq ? xr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3]))));
+    }
+    m = ud_wave_max(m);
+    // exponent field e of the maximum -> scale 2^(14 - (e - 127)) (field 268 - e), kept inside the normal range; an all-zero row: 1
+    const int e = (int)(__float_as_uint(m) >> 23) & 0xff;
+    int fs = m > 0.f ? 268 - e : 127;
+    fs = fs < 1 ? 1 : fs > 254 ? 254 : fs;
+    const float s = __uint_as_float((uint32_t)fs << 23), inv = __uint_as_float((uint32_t)(254 - fs) << 23);
+    if (lane == 0) inv_scale[row] = inv;
+    const int nq_pad = ((C + 31) >> 5) << 3;          // float4 up to the end of the last panel: zero columns
+#pragma unroll
+    for (int i = 0; i < H2_MAXQ; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq_pad) {
+            uint32_t a0, a1, b0, b1;
+            split2h(v[i][0] * s, v[i][1] * s, a0, a1);
+            split2h(v[i][2] * s, v[i][3] * s, b0, b1);
+            uint16_t* o = out + (long)(q >> 3) * panel + row * 32 + (q & 7) * 4;
+            *reinterpret_cast<u32x2*>(o) = u32x2{a0, b0};
+            *reinterpret_cast<u32x2*>(o + plane) = u32x2{a1, b1};
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride,
@@ -449,21 +562,39 @@ extern "C" int ud_split_planes(const float* x, long R, int C, long ld, uint16_t*
     return 0;
 }
 
+extern "C" int ud_split_planes_h2(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride,
+                                  long plane_stride, float* inv_scale, ud_stream_t stream) {
+    if (!x || !planes || !inv_scale || R <= 0 || C <= 0 || C % 4 != 0 || C > 256 * H2_MAXQ || ld % 4 != 0 || ld < C ||
+        panel_stride < R * 32 || panel_stride % 8 != 0 || plane_stride % 8 != 0 ||
+        plane_stride < (long)ud_cdiv(C, 32) * panel_stride)
+        return UD_EINVAL;
+    hipLaunchKernelGGL(split_h2_rows_kernel, dim3((unsigned)ud_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, R, C, ld,
+                       planes, panel_stride, plane_stride, inv_scale);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ud_gemm_p3(const ud_gemm_p3_desc* dp, ud_stream_t stream) {
     if (!dp) return UD_EINVAL;
     const ud_gemm_p3_desc& d = *dp;
     if (!d.A || !d.B || !d.C || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.K % BK != 0 || d.split_k < 1 ||
         d.split_k > d.K / BK || d.out_mode < 0 || d.out_mode > 3 || d.a_mode < 0 || d.a_mode > 1 || d.b_mode < 0 ||
         d.b_mode > 1 || d.a_panel % 8 != 0 || d.b_panel % 8 != 0 || d.a_plane % 8 != 0 || d.b_plane % 8 != 0 ||
-        d.a_npanel < 1 || d.b_npanel < 1)
+        d.a_npanel < 1 || d.b_npanel < 1 || (d.prec != 2 && d.prec != 3))
         return UD_EINVAL;
+    if (d.prec == 2 && (!d.a_inv_scale || !d.b_inv_scale)) return UD_EINVAL;
     if (d.stat_sum && (d.out_mode != 0 || d.split_k != 1 || !d.stat_sumsq || (d.tile_cfg & 0x800))) return UD_EINVAL;
     if ((d.tile_cfg & 0x800) && (d.out_mode > 1 || d.split_k != 1)) return UD_EINVAL;          // stream-K: store-onto-zeros or add
     if (d.out_mode == 3 && d.slice_stride < (long)d.M * d.ldc) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (d.a_mode == 0 && d.b_mode == 0) return launch<0, 0>(d, s);
-    if (d.a_mode == 0 && d.b_mode == 1) return launch<0, 1>(d, s);
-    if (d.a_mode == 1 && d.b_mode == 1) return launch<1, 1>(d, s);
-    if (d.a_mode == 1 && d.b_mode == 0) return launch<1, 0>(d, s);
+    if (d.prec == 2) {
+        if (d.a_mode == 0 && d.b_mode == 0) return launch<2, 0, 0>(d, s);
+        if (d.a_mode == 1 && d.b_mode == 1) return launch<2, 1, 1>(d, s);
+        return UD_EINVAL;
+    }
+    if (d.a_mode == 0 && d.b_mode == 0) return launch<3, 0, 0>(d, s);
+    if (d.a_mode == 0 && d.b_mode == 1) return launch<3, 0, 1>(d, s);
+    if (d.a_mode == 1 && d.b_mode == 1) return launch<3, 1, 1>(d, s);
+    if (d.a_mode == 1 && d.b_mode == 0) return launch<3, 1, 0>(d, s);
     return UD_EINVAL;
 }

@@ -206,26 +206,32 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
 
 
 class Planes:
-    """A matrix X[R][C] as three bf16 planes x = x0 + x1 + x2 in the P32 panel layout of ud_gemm_p3
-    (include/unidefense_hip.h): piece p of X[r][c] at p * plane + (c // 32) * panel + r * 32 + c % 32."""
-    __slots__ = ("buf", "R", "C", "panel", "plane", "npanel")
+    """A matrix X[R][C] as 16-bit planes in the P32 panel layout of ud_gemm_p3 (include/unidefense_hip.h): piece p of X[r][c]
+    at p * plane + (c // 32) * panel + r * 32 + c % 32.  prec 3: three bf16 planes (exact split); prec 2: two fp16 planes of
+    the row-scaled matrix + inv = 1 / scale per row."""
+    __slots__ = ("buf", "R", "C", "panel", "plane", "npanel", "prec", "inv")
 
-    def __init__(self, R, Cc, like):
-        self.R, self.C = R, Cc
+    def __init__(self, R, Cc, like, prec=3):
+        self.R, self.C, self.prec = R, Cc, prec
         self.npanel = -(-Cc // 32)
         self.panel = 32 * (-(-R // 128) * 128)          # every panel is backed by rows up to the next multiple of 128
         self.plane = self.npanel * self.panel
-        self.buf = torch.empty(3 * self.plane, dtype=torch.int16, device=like.device)
+        self.buf = torch.empty(prec * self.plane, dtype=torch.int16, device=like.device)
+        self.inv = torch.empty(R, dtype=torch.float32, device=like.device) if prec == 2 else None
 
 
-def split_planes(x2, out=None):
-    """fp32 [R, C] (row stride >= C) -> Planes (the exact three-way bf16 split of gemm_x3.hip, done once by the producer)."""
+def split_planes(x2, out=None, prec=3):
+    """fp32 [R, C] (row stride >= C) -> Planes: prec 3 the exact three-way bf16 split of gemm_x3.hip, prec 2 two fp16 pieces of
+    the matrix scaled per row — done once by the producer instead of by every workgroup that loads a tile."""
     _chk(x2)
     R, Cc = x2.shape
     assert x2.stride(1) == 1 and Cc % 4 == 0 and x2.stride(0) % 4 == 0
-    pl = out if out is not None else Planes(R, Cc, x2)
+    pl = out if out is not None else Planes(R, Cc, x2, prec)
     assert pl.R == R and pl.C == Cc
-    _call("ud_split_planes", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _stream())
+    if pl.prec == 3:
+        _call("ud_split_planes", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _stream())
+    else:
+        _call("ud_split_planes_h2", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _p(pl.inv), _stream())
     return pl
 
 
@@ -252,6 +258,12 @@ def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=N
     d.ldc = N
     d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
     d.tile_cfg = cfg | (0x100 if _XCD_CONTIGUOUS else 0)
+    assert A.prec == B.prec
+    d.prec = A.prec
+    if A.prec == 2:
+        assert a_mode == 0 and b_mode == 0
+        d.a_inv_scale = A.inv.data_ptr() + 4 * a_row0
+        d.b_inv_scale = B.inv.data_ptr()
     slices = None
     if CFG.deterministic and out_mode == 2:
         total = M * N
@@ -276,7 +288,7 @@ def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=N
         _call("ud_gemm_p3", C.byref(d), _stream())
         e1.record()
         GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, a_mode, b_mode, split_k, 1), 4,
-                             6.0 * (M * K + K * N) + 4.0 * M * N))
+                             2.0 * A.prec * (M * K + K * N) + 4.0 * M * N))
     else:
         _call("ud_gemm_p3", C.byref(d), _stream())
     if slices is not None:
