@@ -113,14 +113,16 @@ int ud_gemm_query_path(const ud_gemm_desc* d);
  * their products discarded).
  *   prec 3: three bf16 planes x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): the exact split
  *           ud_gemm performs inside its k-loop), six piece products — bitwise ud_gemm's result.  Written by ud_split_planes.
- *   prec 2: two fp16 planes s_r * x = h0 + h1 with one power-of-two scale s_r per GEMM row (the row maximum scaled into
- *           [2^14, 2^15)), three piece products a1b0 + a0b1 + a0b0 on the fp16 matrix pipe, the result multiplied by
- *           a_inv_scale[m] * b_inv_scale[n] (= 1 / s, fp32 vectors [M] / [N]).  22 significand bits per element down to 2^-18
- *           of its row maximum, the dropped a1b1 < 2^-24 |ab|, fp32 accumulation: the accuracy of an fp32 GEMM at half the
- *           matrix work.  Written by ud_split_planes_h2 (scale per row of X: mode 0 operands only).
+ *   prec 2: two fp16 planes s * x = h0 + 2^-11 h1 with a power-of-two scale s that takes the largest |x| it covers into
+ *           [2^14, 2^15) — ONE scale for the tensor (ud_absmax + ud_split_planes_h2t; any mode) or one per row of X
+ *           (ud_split_planes_h2; mode 0 only: the scale must be constant along k).  Three piece products on the fp16 matrix
+ *           pipe into two fp32 accumulators (a0b0, and a1b0 + a0b1), the result (hi + 2^-11 lo) * a_inv_scale[m * a_scale_stride]
+ *           * b_inv_scale[n * b_scale_stride] (= 1 / s; stride 0: a scalar, 1: a vector [M] / [N]).  22 significand bits of every
+ *           element within 2^-29 of the scale's maximum, the dropped a1b1 < 2^-24 |ab|, fp32 accumulation: the accuracy of an
+ *           fp32 GEMM (measured at or below ud_gemm's error on every operand distribution tried) at half the matrix work.
  *   mode 0: GEMM row = row of X, k = column of X     (activations [pixels][C] as A; weights [Cout][Cin] as B)
  *   mode 1: GEMM row = column of X, k = row of X     (dY / X of a weight gradient; weights of a data gradient)
- * (a_mode, b_mode): prec 3 any; prec 2 (0,0).  K % 32 == 0.  *_npanel: panels reachable from the pointer (mode 1 clamps
+ * (a_mode, b_mode): prec 3 any; prec 2 (0,0) (0,1) (1,1).  K % 32 == 0.  *_npanel: panels reachable from the pointer (mode 1 clamps
  * its tile to them).  out_mode / split_k / slice_stride / stat_sum / stat_sumsq as in ud_gemm_desc (statistics: out_mode 0,
  * split_k 1; one slot array [N] while M <= 64 * 128, else 64 slots).
  * tile_cfg bit 8: each XCD takes a contiguous range of the tile order; bit 11 (0x800): stream-K — one workgroup per CU, the
@@ -138,15 +140,22 @@ typedef struct {
     long slice_stride;
     int prec;                                   /* 3 or 2 */
     const float* a_inv_scale; const float* b_inv_scale;   /* prec 2 */
+    int a_scale_stride, b_scale_stride;         /* 0: one scale for the operand; 1: one per GEMM row */
 } ud_gemm_p3_desc;
 int ud_gemm_p3(const ud_gemm_p3_desc* d, ud_stream_t stream);
 /* x fp32 [R][C] (row stride ld; C, ld multiples of 4) -> three bf16 planes in the P32 layout above; columns C .. 32*ceil(C/32)-1
  * are written as zeros, slack rows are left untouched. */
 int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,
                     ud_stream_t stream);
-/* the prec-2 form: two fp16 planes of s_r * x[r][:] and inv_scale[r] = 1 / s_r (C <= 4096) */
+/* the prec-2 form with one scale per row: two fp16 planes of s_r * x[r][:] and inv_scale[r] = 1 / s_r (C <= 4096) */
 int ud_split_planes_h2(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,
                        float* inv_scale, ud_stream_t stream);
+/* the prec-2 form with one scale for the tensor: absmax[256] = partial maxima of |x| over the matrix, as the bit patterns of
+ * non-negative floats (ud_absmax writes all 256; a producer kernel may fill them instead), then the split folds them and writes
+ * the planes and *inv_scale = 1 / s */
+int ud_absmax(const float* x, long R, int C, long ld, uint32_t* absmax, ud_stream_t stream);
+int ud_split_planes_h2t(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,
+                        const uint32_t* absmax, float* inv_scale, ud_stream_t stream);
 
 /* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------
  * Every reduction is a partial pass (fp64 per-workgroup totals stored into the scratch `ws`) plus a small

@@ -109,23 +109,46 @@ for name in ("randn", "same-sign", "lognormal3", "rows-e8", "cols-e4", "tiny", "
         a, b = dist(name, M, Kd), dist("randn" if name in ("tiny", "huge") else name, N, Kd)
         want = a.double() @ b.double().t()
         scale = a.double().abs() @ b.double().abs().t() + 1e-300
-        ap, bp = K.split_planes(a, prec=2), K.split_planes(b, prec=2)
-        out = torch.full((M, N), float("nan"), device=dev)
-        K._gemm_p3(ap, bp, out, M, N, Kd, 0, 0)
-        outs = torch.zeros(M, N, device=dev)
-        K._gemm_p3(ap, bp, outs, M, N, Kd, 0, 0, 2, 2)
-        outk = torch.zeros(M, N, device=dev)
-        K._gemm_p3(ap, bp, outk, M, N, Kd, 0, 0, 0, 1, cfg=0x800)
         ref = torch.empty(M, N, device=dev)
         x3("nt", a, b, ref, M, N, Kd)
-        torch.cuda.synchronize()
-        e = ((out.double() - want).abs() / scale).max().item()
-        es = ((outs.double() - want).abs() / scale).max().item()
-        ek = ((outk.double() - want).abs() / scale).max().item()
         e3 = ((ref.double() - want).abs() / scale).max().item()
-        ok = max(e, es, ek) < max(2e-6, 2 * e3) and torch.isfinite(out).all().item()
-        bad += not ok
-        print(f"{name:11s} {M}x{N}x{Kd}: p2 {e:.2e} split-2 {es:.2e} stream-K {ek:.2e} | x3 {e3:.2e}  {'ok' if ok else 'FAIL'}", flush=True)
+        for per_row in (True, False):
+            if name == "rows-e8" and not per_row:
+                continue          # one scale for a tensor whose rows span 2^+-35: outside the format's range by construction
+            ap, bp = K.split_planes(a, prec=2, per_row=per_row), K.split_planes(b, prec=2, per_row=per_row)
+            out = torch.full((M, N), float("nan"), device=dev)
+            K._gemm_p3(ap, bp, out, M, N, Kd, 0, 0)
+            outs = torch.zeros(M, N, device=dev)
+            K._gemm_p3(ap, bp, outs, M, N, Kd, 0, 0, 2, 2)
+            outk = torch.zeros(M, N, device=dev)
+            K._gemm_p3(ap, bp, outk, M, N, Kd, 0, 0, 0, 1, cfg=0x800)
+            torch.cuda.synchronize()
+            e = ((out.double() - want).abs() / scale).max().item()
+            es = ((outs.double() - want).abs() / scale).max().item()
+            ek = ((outk.double() - want).abs() / scale).max().item()
+            ok = max(e, es, ek) < max(2e-6, 2 * e3) and torch.isfinite(out).all().item()
+            bad += not ok
+            print(f"{name:11s} {M}x{N}x{Kd} {'row' if per_row else 'tensor'} scales: p2 {e:.2e} split-2 {es:.2e} stream-K {ek:.2e} | x3 {e3:.2e}  {'ok' if ok else 'FAIL'}", flush=True)
+# the other two products on tensor-scaled planes: nn (a [M,K] x w [K,N]) and tn (a [K,M]^T x b [K,N])
+for kind, M, N, Kd in (("nn", 384, 256, 160), ("nn", 1280, 3264, 3264), ("tn", 192, 320, 256), ("tn", 3264, 3264, 1280), ("tn", 672, 672, 17408)):
+    a, b, am, bm = operands(kind, M, N, Kd)
+    want = ref64(kind, a, b)
+    scale = (a.double().abs() @ b.double().abs() if kind == "nn" else a.double().abs().t() @ b.double().abs())
+    ap, bp = K.split_planes(a, prec=2), K.split_planes(b, prec=2)
+    res = {}
+    for tag, (om, sp, cfg) in {"plain": (0, 1, 0), "split-3": (2, 3, 0), "stream-K": (0, 1, 0x800)}.items():
+        if Kd // 32 < sp:
+            continue
+        out = torch.zeros(M, N, device=dev)
+        K._gemm_p3(ap, bp, out, M, N, Kd, am, bm, om, sp, cfg=cfg)
+        torch.cuda.synchronize()
+        res[tag] = ((out.double() - want).abs() / scale).max().item()
+    ref = torch.empty(M, N, device=dev)
+    x3(kind, a, b, ref, M, N, Kd)
+    e3 = ((ref.double() - want).abs() / scale).max().item()
+    ok = max(res.values()) < max(2e-6, 2 * e3)
+    bad += not ok
+    print(f"{kind} {M}x{N}x{Kd} tensor scales: " + " ".join(f"{k} {v:.2e}" for k, v in res.items()) + f" | x3 {e3:.2e}  {'ok' if ok else 'FAIL'}", flush=True)
 print("FAILURES:", bad, flush=True)
 
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
@@ -151,19 +174,15 @@ for kind, M, N, Kd, split in rows:
     ts_b = K._time_launches(lambda: K.split_planes(b, bp), n=8)
     best = min(tp.values())
     fl = 2.0 * M * N * Kd
-    t2 = ""
-    if kind != "tn" and Kd <= 4096:
-        a2 = a
-        b2 = b if kind == "nt" else b.t().contiguous()
-        ap2, bp2 = K.split_planes(a2, prec=2), K.split_planes(b2, prec=2)
-        tq = {sp: K._time_launches(lambda: K._gemm_p3(ap2, bp2, out, M, N, Kd, 0, 0, 2 if sp > 1 else 0, sp), n=8)
-              for sp in sorted({1, split}) if Kd // 32 >= sp}
-        tq["sk"] = K._time_launches(lambda: K._gemm_p3(ap2, bp2, outz, M, N, Kd, 0, 0, 1, 1, cfg=0x800), n=8)
-        th_a = K._time_launches(lambda: K.split_planes(a2, ap2), n=8)
-        th_b = K._time_launches(lambda: K.split_planes(b2, bp2), n=8)
-        bq = min(tq.values())
-        t2 = (" || p2 " + " ".join(f"{k} {t * 1e3:6.1f}" for k, t in tq.items()) +
-              f" best {fl / bq / 1e9:5.1f} TF x{t3 / bq:.2f} split A {th_a * 1e3:.1f} B {th_b * 1e3:.1f}")
+    ap2, bp2 = K.split_planes(a, prec=2), K.split_planes(b, prec=2)
+    tq = {sp: K._time_launches(lambda: K._gemm_p3(ap2, bp2, out, M, N, Kd, am, bm, 2 if sp > 1 else 0, sp), n=8)
+          for sp in sorted({1, split, 2 * split}) if Kd // 32 >= sp}
+    tq["sk"] = K._time_launches(lambda: K._gemm_p3(ap2, bp2, outz, M, N, Kd, am, bm, 1, 1, cfg=0x800), n=8)
+    th_a = K._time_launches(lambda: K.split_planes(a, ap2), n=8)
+    th_b = K._time_launches(lambda: K.split_planes(b, bp2), n=8)
+    bq = min(tq.values())
+    t2 = (" || p2 " + " ".join(f"{k} {t * 1e3:6.1f}" for k, t in tq.items()) +
+          f" best {fl / bq / 1e9:5.1f} TF x{t3 / bq:.2f} absmax+split A {th_a * 1e3:.1f} B {th_b * 1e3:.1f}")
     print(f"{kind} {M}x{N}x{Kd}: x3 {t3 * 1e3:7.1f} ({fl / t3 / 1e9:5.1f} TF)  p3 " +
           " ".join(f"s{sp} {t * 1e3:7.1f}" for sp, t in tp.items()) +
           f"  best {fl / best / 1e9:5.1f} TF  x{t3 / best:.2f} | stream-K {tsk * 1e3:7.1f} ({fl / tsk / 1e9:5.1f} TF) x{t3 / tsk:.2f} | split A {ts_a * 1e3:.1f} B {ts_b * 1e3:.1f}" + t2, flush=True)

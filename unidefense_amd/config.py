@@ -17,6 +17,7 @@ not when they are imported.  Anything not listed here is a compile-time constant
 | hip_adamw | UD_HIP_ADAMW | 1 | build_optimizer returns the multi-tensor HIP AdamW for 'adamw' on the GPU |
 | wgrad_stream | UD_WGRAD_STREAM | 0 | weight-gradient kernels on a second stream (measured slower; kept for A/B) |
 | lib_path | UD_LIB_PATH | unset | load another build of libunidefense_hip.so (A/B of kernel builds) |
+| spectral_p2 | UD_SPECTRAL_P2 | auto | the spectral 1x1 convs' forward / data-gradient GEMMs from pre-split fp16 x 2 planes (ud_gemm_p3 prec 2): `auto` where measured (or, untuned, estimated) faster than the in-kernel bf16 x 3 split, `on` wherever the kernel takes the shape, `off` never |
 
 The shared library itself reads three variables when it is loaded, for hosts that do not go through Python:
 UD_GEMM_PATH (the initial `ud_gemm_set_path` value: 0 auto, 1 fp32 pipe, 2 split-bf16 everywhere, 3 fp16 MFMA) and the
@@ -45,6 +46,7 @@ class Config:
     hip_adamw: bool = True
     wgrad_stream: bool = False
     lib_path: Optional[str] = None
+    spectral_p2: str = "auto"
 
     @classmethod
     def from_env(cls):
@@ -54,7 +56,7 @@ class Config:
             if f.type is bool:
                 setattr(c, f.name, _flag(env, f.default))
             else:
-                setattr(c, f.name, os.environ.get(env) or None)
+                setattr(c, f.name, os.environ.get(env) or f.default)
         return c
 
     def describe(self):

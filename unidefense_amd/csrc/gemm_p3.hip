@@ -328,14 +328,14 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
             for (int j = 0; j < 2; ++j) {
                 const int col = n0 + wn * 64 + j * 32 + l31;
                 const bool cok = col < d.N;
-                const float ib = cok ? d.b_inv_scale[col] : 0.f;
+                const float ib = cok ? d.b_inv_scale[(long)col * d.b_scale_stride] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                         const bool ok = cok && row < d.M;
-                        const float ia = ok ? d.a_inv_scale[row] : 0.f;
+                        const float ia = ok ? d.a_inv_scale[(long)row * d.a_scale_stride] : 0.f;
                         acc[i][j][r] = ok ? (acc[i][j][r] + 0x1p-11f * lo[i][j][r]) * (ia * ib) : 0.f;
                     }
             }
@@ -548,7 +548,107 @@ __global__ __launch_bounds__(256) void split_h2_rows_kernel(const float* __restr
     }
 }
 
+// ---- per-TENSOR scale: |x|max over the whole matrix, as ABSMAX_SLOTS partial maxima (bit patterns of non-negative floats:
+// unsigned order = float order) that the split kernel folds — no atomics (8192 atomic maxima onto one word took 100 us), no
+// zero fill.  A producer kernel may fill the slots itself.
+constexpr int ABSMAX_SLOTS = 256;
+__global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ x, long R, int C, long ld, uint32_t* __restrict__ out) {
+    // 256 workgroups x 16 waves, two 16-byte loads in flight per lane: a reduction this short lives on loads in flight
+    __shared__ float red[16];
+    const long nq = R * (long)(C >> 2);
+    const int cq = C >> 2;
+    const long stride = (long)ABSMAX_SLOTS * 1024;
+    float m = 0.f;
+    auto at = [&](long q) {
+        const long r = q / cq;
+        return *reinterpret_cast<const f32x4*>(x + r * ld + (q - r * cq) * 4);
+    };
+    long q = (long)blockIdx.x * 1024 + threadIdx.x;
+    for (; q + stride < nq; q += 2 * stride) {
+        const f32x4 v = at(q), w = at(q + stride);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3]))));
+    }
+    if (q < nq) {
+        const f32x4 v = at(q);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    m = ud_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = red[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t = fmaxf(t, red[i]);
+        out[blockIdx.x] = __float_as_uint(t);
+    }
+}
+
+// scale of a tensor whose |x|max has the bit pattern `bits`: the power of two taking it into [2^14, 2^15) (exponent field
+// 268 - e, kept inside the normal range; all zeros: 1); inv = 1 / scale.  NaN / inf maxima end up as NaN / inf pieces.
+__device__ __forceinline__ void h2_scale(uint32_t bits, float& s, float& inv) {
+    const int e = (int)(bits >> 23) & 0xff;
+    int fs = bits ? 268 - e : 127;
+    fs = fs < 1 ? 1 : fs > 254 ? 254 : fs;
+    s = __uint_as_float((uint32_t)fs << 23);
+    inv = __uint_as_float((uint32_t)(254 - fs) << 23);
+}
+
+// fp32 [R][C] -> two fp16 planes of s * x with ONE scale for the tensor (any GEMM mode may read them); thread = 8 columns of a row
+__global__ __launch_bounds__(256) void split_h2_tensor_kernel(const float* __restrict__ x, long R, int C, long ld,
+                                                              uint16_t* __restrict__ out, long panel, long plane,
+                                                              const uint32_t* __restrict__ absmax, float* __restrict__ inv_scale) {
+    const int tid = threadIdx.x;
+    const long row = (long)blockIdx.x * 64 + (tid >> 2);
+    const int pan = blockIdx.y, c0 = pan * 32 + (tid & 3) * 8;
+    // fold the partial maxima (every wave by itself: 4 per lane; no barrier)
+    uint32_t mb = 0;
+#pragma unroll
+    for (int i = 0; i < ABSMAX_SLOTS / 64; ++i) mb = max(mb, absmax[(tid & 63) + 64 * i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, o, 64));
+    float s, inv;
+    h2_scale(mb, s, inv);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *inv_scale = inv;
+    if (row >= R) return;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + 8 <= C) {
+        v0 = *reinterpret_cast<const f32x4*>(x + row * ld + c0);
+        v1 = *reinterpret_cast<const f32x4*>(x + row * ld + c0 + 4);
+    } else if (c0 + 4 <= C) {
+        v0 = *reinterpret_cast<const f32x4*>(x + row * ld + c0);
+    }
+    uint32_t a[4], b[4];
+    split2h(v0[0] * s, v0[1] * s, a[0], b[0]);
+    split2h(v0[2] * s, v0[3] * s, a[1], b[1]);
+    split2h(v1[0] * s, v1[1] * s, a[2], b[2]);
+    split2h(v1[2] * s, v1[3] * s, a[3], b[3]);
+    uint16_t* o = out + (long)pan * panel + row * 32 + (tid & 3) * 8;
+    *reinterpret_cast<u32x4*>(o) = u32x4{a[0], a[1], a[2], a[3]};
+    *reinterpret_cast<u32x4*>(o + plane) = u32x4{b[0], b[1], b[2], b[3]};
+}
+
 }  // namespace
+
+extern "C" int ud_absmax(const float* x, long R, int C, long ld, uint32_t* out, ud_stream_t stream) {
+    if (!x || !out || R <= 0 || C <= 0 || C % 4 != 0 || ld % 4 != 0 || ld < C) return UD_EINVAL;
+    hipLaunchKernelGGL(absmax_kernel, dim3(ABSMAX_SLOTS), dim3(1024), 0, (hipStream_t)stream, x, R, C, ld, out);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ud_split_planes_h2t(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride,
+                                   long plane_stride, const uint32_t* absmax, float* inv_scale, ud_stream_t stream) {
+    if (!x || !planes || !absmax || !inv_scale || R <= 0 || C <= 0 || C % 4 != 0 || ld % 4 != 0 || ld < C ||
+        panel_stride < R * 32 || panel_stride % 8 != 0 || plane_stride % 8 != 0 ||
+        plane_stride < (long)ud_cdiv(C, 32) * panel_stride)
+        return UD_EINVAL;
+    dim3 grid((unsigned)ud_cdiv(R, 64), (unsigned)ud_cdiv(C, 32));
+    hipLaunchKernelGGL(split_h2_tensor_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, R, C, ld, planes, panel_stride,
+                       plane_stride, absmax, inv_scale);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride,
                                long plane_stride, ud_stream_t stream) {
@@ -582,13 +682,16 @@ extern "C" int ud_gemm_p3(const ud_gemm_p3_desc* dp, ud_stream_t stream) {
         d.b_mode > 1 || d.a_panel % 8 != 0 || d.b_panel % 8 != 0 || d.a_plane % 8 != 0 || d.b_plane % 8 != 0 ||
         d.a_npanel < 1 || d.b_npanel < 1 || (d.prec != 2 && d.prec != 3))
         return UD_EINVAL;
-    if (d.prec == 2 && (!d.a_inv_scale || !d.b_inv_scale)) return UD_EINVAL;
+    if (d.prec == 2 && (!d.a_inv_scale || !d.b_inv_scale || d.a_scale_stride < 0 || d.a_scale_stride > 1 ||
+                        d.b_scale_stride < 0 || d.b_scale_stride > 1))
+        return UD_EINVAL;
     if (d.stat_sum && (d.out_mode != 0 || d.split_k != 1 || !d.stat_sumsq || (d.tile_cfg & 0x800))) return UD_EINVAL;
     if ((d.tile_cfg & 0x800) && (d.out_mode > 1 || d.split_k != 1)) return UD_EINVAL;          // stream-K: store-onto-zeros or add
     if (d.out_mode == 3 && d.slice_stride < (long)d.M * d.ldc) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (d.prec == 2) {
         if (d.a_mode == 0 && d.b_mode == 0) return launch<2, 0, 0>(d, s);
+        if (d.a_mode == 0 && d.b_mode == 1) return launch<2, 0, 1>(d, s);
         if (d.a_mode == 1 && d.b_mode == 1) return launch<2, 1, 1>(d, s);
         return UD_EINVAL;
     }

@@ -208,30 +208,37 @@ def _gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode, b_mode, out_mode=0, split_
 class Planes:
     """A matrix X[R][C] as 16-bit planes in the P32 panel layout of ud_gemm_p3 (include/unidefense_hip.h): piece p of X[r][c]
     at p * plane + (c // 32) * panel + r * 32 + c % 32.  prec 3: three bf16 planes (exact split); prec 2: two fp16 planes of
-    the row-scaled matrix + inv = 1 / scale per row."""
-    __slots__ = ("buf", "R", "C", "panel", "plane", "npanel", "prec", "inv")
+    the scaled matrix + inv = 1 / scale — one scale for the tensor (scale_stride 0; readable in both GEMM modes) or one per
+    row (scale_stride 1; mode 0 only)."""
+    __slots__ = ("buf", "R", "C", "panel", "plane", "npanel", "prec", "inv", "scale_stride")
 
-    def __init__(self, R, Cc, like, prec=3):
+    def __init__(self, R, Cc, like, prec=3, per_row=False):
         self.R, self.C, self.prec = R, Cc, prec
         self.npanel = -(-Cc // 32)
         self.panel = 32 * (-(-R // 128) * 128)          # every panel is backed by rows up to the next multiple of 128
         self.plane = self.npanel * self.panel
         self.buf = torch.empty(prec * self.plane, dtype=torch.int16, device=like.device)
-        self.inv = torch.empty(R, dtype=torch.float32, device=like.device) if prec == 2 else None
+        self.scale_stride = 1 if per_row else 0
+        self.inv = torch.empty(R if per_row else 1, dtype=torch.float32, device=like.device) if prec == 2 else None
 
 
-def split_planes(x2, out=None, prec=3):
+def split_planes(x2, out=None, prec=3, per_row=False):
     """fp32 [R, C] (row stride >= C) -> Planes: prec 3 the exact three-way bf16 split of gemm_x3.hip, prec 2 two fp16 pieces of
-    the matrix scaled per row — done once by the producer instead of by every workgroup that loads a tile."""
+    the scaled matrix — done once by the producer instead of by every workgroup that loads a tile."""
     _chk(x2)
     R, Cc = x2.shape
     assert x2.stride(1) == 1 and Cc % 4 == 0 and x2.stride(0) % 4 == 0
-    pl = out if out is not None else Planes(R, Cc, x2, prec)
+    pl = out if out is not None else Planes(R, Cc, x2, prec, per_row)
     assert pl.R == R and pl.C == Cc
     if pl.prec == 3:
         _call("ud_split_planes", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _stream())
-    else:
+    elif pl.scale_stride:
         _call("ud_split_planes_h2", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _p(pl.inv), _stream())
+    else:
+        amax = empty((256,), x2)                    # partial maxima (ud_absmax writes every slot)
+        _call("ud_absmax", _p(x2), R, Cc, x2.stride(0), _p(amax), _stream())
+        _call("ud_split_planes_h2t", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _p(amax), _p(pl.inv),
+              _stream())
     return pl
 
 
@@ -261,9 +268,10 @@ def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=N
     assert A.prec == B.prec
     d.prec = A.prec
     if A.prec == 2:
-        assert a_mode == 0 and b_mode == 0
-        d.a_inv_scale = A.inv.data_ptr() + 4 * a_row0
+        assert (a_mode == 0 or not A.scale_stride) and (b_mode == 0 or not B.scale_stride)
+        d.a_inv_scale = A.inv.data_ptr() + 4 * a_row0 * A.scale_stride
         d.b_inv_scale = B.inv.data_ptr()
+        d.a_scale_stride, d.b_scale_stride = A.scale_stride, B.scale_stride
     slices = None
     if CFG.deterministic and out_mode == 2:
         total = M * N
@@ -567,6 +575,163 @@ def gemm_nn(a, w, out=None, accumulate=False):
             return r
         return _model_plan_launch(a, w, out, M, N, K, K, N, 1, acc)
     return _gemm(a, w, out, M, N, K, K, N, N, 0, 1, 0)
+
+
+# ---- spectral 1x1 convs on pre-split fp16 x 2 planes (ud_gemm_p3 prec 2) -------------------------------------------------
+# F.conv2d(x_freq, freq_conv.weight) of the SF blocks (model/efficientnet/exp.py:57), its data gradient and its weight gradient:
+# three products over the SAME three matrices (x_freq [pixels x 2C], the weight [2C x 2C], dY [pixels x 2C]).  Each matrix is
+# split ONCE into two fp16 pieces with one power-of-two scale for the tensor (ud_absmax + ud_split_planes_h2t; the planes then
+# serve every GEMM mode) and the products run on three fp16 MFMAs per tile instead of six bf16 ones; the fp32 tensors are not
+# kept.  Which blocks take this path, and each product's launch plan, is measured per shape on first use (`p2sf` entries of the
+# plan table) like the tile / split-K plans of the in-kernel-split GEMMs.
+_P2_MIN = (1024, 512)          # untuned `auto`: M, 2C from which the planes path is taken
+_P2_SPLITS = (2, 3, 4, 6, 8)
+_P2_TN_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256)
+_P2_MODES = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}
+
+
+def _p2_shape_ok(M, C2):
+    return C2 % 32 == 0 and M % 32 == 0 and M >= 128 and C2 >= 128
+
+
+def _p2_plans(kind, M, N, K):
+    tiles = -(-M // 128) * -(-N // 128)
+    out = []
+    if kind == "tn":
+        for s_ in _P2_TN_SPLITS:
+            if (s_ == 1 or K // 32 // s_ >= 4) and 64 <= tiles * s_ <= 2048:
+                out.append(("split", s_) if s_ > 1 else ("plain",))
+    else:
+        out.append(("plain",))
+        for s_ in _P2_SPLITS:
+            if K // 32 // s_ >= 4 and tiles * s_ <= 2048:
+                out.append(("split", s_))
+        tp = _tail_plan(M, N, K)
+        if tp is not None:
+            out.append(("tail", tp[0], tp[1]))
+    if not CFG.deterministic:
+        out.append(("sk",))
+    return out or [("plain",)]
+
+
+def _p2_run(kind, plan, ap, bp, M, N, K, like):
+    """one product of the planes path.  kind nt: ap [M,K] x bp [N,K]; nn: ap [M,K] x bp [K,N]; tn: ap [K,M] x bp [K,N]"""
+    am, bm = _P2_MODES[kind]
+    how = plan[0]
+    if how == "plain":
+        return _gemm_p3(ap, bp, empty((M, N), like), M, N, K, am, bm, 0, 1)
+    if how == "split":
+        return _gemm_p3(ap, bp, split_out((M, N), like), M, N, K, am, bm, 2, int(plan[1]))
+    if how == "sk":
+        return _gemm_p3(ap, bp, zeros((M, N), like), M, N, K, am, bm, 0, 1, cfg=0x800)
+    m1, s_ = int(plan[1]), int(plan[2])          # "tail" (nt / nn): whole rounds of tiles plain, the last row tiles split
+    out = empty((M, N), like)
+    _gemm_p3(ap, bp, out, m1, N, K, am, bm, 0, 1)
+    tail = out[m1:]
+    if CFG.deterministic:
+        tail._ud_fresh = True
+    else:
+        tail.zero_()
+    _gemm_p3(ap, bp, tail, M - m1, N, K, am, bm, 2, s_, a_row0=m1)
+    return out
+
+
+def _p2_default_plan(kind, M, N, K):
+    """untuned: a plain launch unless the tile count sits just above whole rounds of the CUs; weight gradients split"""
+    tiles = -(-M // 128) * -(-N // 128)
+    if kind == "tn":
+        s_ = max(1, min(256 // tiles if tiles <= 256 else 1, K // 32 // 4))
+        return ("split", s_) if s_ > 1 else ("plain",)
+    full, rem = divmod(tiles, 256)
+    if full >= 1 and 0 < rem <= 64:
+        tp = _tail_plan(M, N, K)
+        if tp is not None:
+            return ("tail", tp[0], tp[1])
+        if not CFG.deterministic:
+            return ("sk",)
+    if tiles < 128 and K >= 1024:
+        return ("split", min(4, max(2, 256 // tiles)))
+    return ("plain",)
+
+
+class SpectralCtx:
+    """what the backward of one spectral conv needs: the planes (or, on the in-kernel-split path, the fp32 operands)"""
+    __slots__ = ("plans", "x", "w", "dy", "M", "C2")
+
+
+def _p2_block_plans(xf2, w2):
+    """None (in-kernel split) or {"nt": plan, "nn": plan, "tn": plan} for a spectral conv of this shape"""
+    M, C2 = xf2.shape
+    mode = CFG.spectral_p2
+    if (mode == "off" or xf2.dtype != torch.float32 or w2.dtype != torch.float32 or not _p2_shape_ok(M, C2) or
+            _call("ud_gemm_get_path") not in (0, 2)):
+        return None
+    key = ("p2sf", M, C2, bool(CFG.deterministic), mode == "on", 0)
+    plans = _TUNED.get(key, "?")
+    if plans == "?":
+        if CFG.gemm_tune and not torch.cuda.is_current_stream_capturing():
+            plans = _p2_tune(key, xf2, w2, M, C2, mode == "on")
+        elif mode == "on" or (M >= _P2_MIN[0] and C2 >= _P2_MIN[1]):
+            plans = [_p2_default_plan("nt", M, C2, C2), _p2_default_plan("nn", M, C2, C2), _p2_default_plan("tn", C2, C2, M)]
+        else:
+            plans = None
+    if plans is None:
+        return None
+    return {"nt": tuple(plans[0]), "nn": tuple(plans[1]), "tn": tuple(plans[2])}
+
+
+def spectral_fwd(xf2, w2):
+    """yf[M, 2C] = xf[M, 2C] @ w[2C, 2C]^T and the context of its backward"""
+    ctx = SpectralCtx()
+    ctx.M, ctx.C2 = xf2.shape
+    ctx.plans = _p2_block_plans(xf2, w2)
+    ctx.dy = None
+    if ctx.plans is None:
+        ctx.x, ctx.w = xf2, w2
+        return gemm_nt(xf2, w2), ctx
+    ctx.x, ctx.w = split_planes(xf2, prec=2), split_planes(w2, prec=2)
+    return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.C2, ctx.C2, xf2), ctx
+
+
+def _spectral_dy(ctx, dyf2):
+    if ctx.dy is None:
+        ctx.dy = split_planes(dyf2, prec=2)
+    return ctx.dy
+
+
+def spectral_dgrad(ctx, dyf2):
+    """dxf[M, 2C] = dyf[M, 2C] @ w[2C, 2C]"""
+    if ctx.plans is None:
+        return gemm_nn(dyf2, ctx.w)
+    return _p2_run("nn", ctx.plans["nn"], _spectral_dy(ctx, dyf2), ctx.w, ctx.M, ctx.C2, ctx.C2, dyf2)
+
+
+def spectral_wgrad(ctx, dyf2):
+    """dw[2C, 2C] = dyf[M, 2C]^T @ xf[M, 2C]"""
+    if ctx.plans is None:
+        return gemm_tn(dyf2, ctx.x)
+    return _p2_run("tn", ctx.plans["tn"], _spectral_dy(ctx, dyf2), ctx.x, ctx.C2, ctx.C2, ctx.M, dyf2)
+
+
+def _p2_tune(key, xf2, w2, M, C2, forced):
+    """the three products of a spectral conv on the in-kernel-split path against the planes path (its three splits included),
+    every plan of each product measured; the winner is cached (None = in-kernel split)"""
+    t_x3 = _time_launches(lambda: (gemm_nt(xf2, w2), gemm_nn(xf2, w2), gemm_tn(xf2, xf2)))
+    xp, wp = split_planes(xf2, prec=2), split_planes(w2, prec=2)
+    t_p2 = _time_launches(lambda: (split_planes(xf2, xp), split_planes(xf2, xp), split_planes(w2, wp)))
+    plans = []
+    for kind, (a, b, m, n, k) in (("nt", (xp, wp, M, C2, C2)), ("nn", (xp, wp, M, C2, C2)), ("tn", (xp, xp, C2, C2, M))):
+        best, best_t = None, 1e30
+        for plan in _p2_plans(kind, m, n, k):
+            t = _time_launches(lambda: _p2_run(kind, plan, a, b, m, n, k, xf2))
+            if t < best_t:
+                best, best_t = plan, t
+        plans.append(list(best))
+        t_p2 += best_t
+    res = plans if (forced or t_p2 < 0.97 * t_x3) else None
+    _TUNED[key] = res
+    _tune_cache_save()
+    return res
 
 
 _WG_SPLIT_MAXT = 512

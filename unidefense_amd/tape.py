@@ -918,7 +918,9 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         else:
             spat = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
         Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
-        yf = K.gemm_nt(xf.view(-1, 2 * Ce), Wf).view(xf.shape)
+        yf, sctx = K.spectral_fwd(xf.view(-1, 2 * Ce), Wf)
+        yf = yf.view(xf.shape)
+        xf_shape, xf = xf.shape, None          # the context holds what the backward needs of it
         if stride == 1:
             d, fr = K.irfft2_mix(yf, s_i, spat, alpha, acc1)          # fr: freq - spat (neither branch is kept)
             spat = None
@@ -1007,9 +1009,9 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 g_sp, dfr, dalpha = K.sfmix_bwd(spat, fr, alpha, dd, True)
                 tape.add_param_grad(alpha, dalpha)
                 dyf = K.rfft2(dfr, s_i, 2.0)
-            dyf2, xf2 = dyf.view(-1, 2 * Ce), xf.view(-1, 2 * Ce)
-            tape.wgrad(dwm.freq_conv.weight, lambda: K.gemm_tn(dyf2, xf2), dyf2, xf2)
-            dxf = K.gemm_nn(dyf2, Wf).view(xf.shape)
+            dyf2 = dyf.view(-1, 2 * Ce)
+            tape.wgrad(dwm.freq_conv.weight, lambda: K.spectral_wgrad(sctx, dyf2), dyf2)
+            dxf = K.spectral_dgrad(sctx, dyf2).view(xf_shape)
             da_f = K.irfft2(dxf, s_f, 0.5)                                             # adjoint of rfft2
         else:
             dd, dg1, db1 = K.normbwd_apply(d, dz1, None, 1.0, bn1, True, N, HWo, sb1, loc1)
