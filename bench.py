@@ -105,6 +105,76 @@ def cpu_baseline(timeout_s=300):
                 "sample": f"not finished within {timeout_s} s"}
 
 
+def train_step_measure(bs):
+    """the engine's full two-pass train step (AbstractEngine.train_unidefense_model, abstract_engine.py:207-381: clean pass +
+    perturbed pass, two AdamW steps) on UDEB4 256x256 — informational, run in a child process of the default bench"""
+    from unidefense_amd.engine import AbstractEngine
+    from unidefense_amd.engine.optim import build_optimizer
+    from unidefense_amd.loss import LOSSES
+    from unidefense_amd.model import load_model
+    import contextlib
+    dev = torch.device("cuda:0")
+    with contextlib.redirect_stdout(sys.stderr):
+        m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5).to(dev).train()
+    eng = AbstractEngine({"config": dict(lambda_triplet=0.1, lambda_recons=0.1, lambda_freq=1.0, lambda_mask=0.1, lambda_fac=0.1)})
+    eng.model, eng.device, eng.num_steps, eng.warmup_step = m, dev, 1000, 0
+    eng.optimizer = build_optimizer(m, dict(name="adamw", lr=1e-4, betas=[0.9, 0.999], weight_decay=5e-6, amsgrad=True))
+    eng.scheduler = torch.optim.lr_scheduler.StepLR(eng.optimizer, step_size=22500, gamma=0.5)
+    eng.loss_criterion = {"softmax": LOSSES["cross_entropy"], "triplet": LOSSES["aw_triplet"], "kl_div": LOSSES["kl_div"],
+                          "fac": LOSSES["factorization"]}
+    x = (2 * torch.rand(bs, 3, 256, 256) - 1).to(dev)
+    tgt = torch.tensor([0] * (bs // 2) + [1] * (bs // 2), device=dev)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2 ** 10, enabled=False)
+
+    def step(i):
+        eng.optimizer.zero_grad()
+        return eng.train_unidefense_model(x, tgt, 200 + i, scaler, bs // 2, bs // 2)
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    t0, n = time.perf_counter(), 5
+    for i in range(n):
+        step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"what": f"engine two-pass train step (2 x fwd+bwd + 2 AdamW), UDEB4 256x256 bs {bs}", "ms_per_step": 1e3 * dt,
+            "value": bs / dt, "unit": "train images/sec (each image goes through 2 passes)", "steps": n}
+
+
+def extra_measurements(budget_s=75):
+    """Driver-visible numbers of the other BASELINE configs: bounded 5-step runs in CHILD processes after the timed region
+    (configs[4] f16 bs 64, configs[3] UDR50 320^2 bs 16, configs[0] UDR18 128^2 bs 8, the two-pass train step)."""
+    import subprocess
+    me = os.path.abspath(__file__)
+    common = ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extra"]
+    jobs = [("configs[4]: UDEB4 256x256 fp16 MFMA + half storage, bs 64", ["--dtype", "f16", "--batch", "64"] + common),
+            ("configs[3]: UDR50 320x320 bs 16", ["--model", "UDR50", "--size", "320", "--batch", "16"] + common),
+            ("configs[0]: UDR18 128x128 bs 8", ["--model", "UDR18", "--size", "128", "--batch", "8"] + common),
+            ("two-pass train step", ["--train-step"])]
+    out, t_start = [], time.perf_counter()
+    for name, argv in jobs:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 8:
+            out.append({"what": name, "value": None, "note": "skipped: the extras' time budget was spent"})
+            continue
+        try:
+            r = subprocess.run([sys.executable, me] + argv, capture_output=True, text=True, timeout=left, cwd=ROOT)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            d = json.loads(lines[-1]) if (r.returncode == 0 and lines) else None
+        except (subprocess.TimeoutExpired, ValueError):
+            d = None
+        if d is None:
+            out.append({"what": name, "value": None, "note": "failed or not finished in time"})
+        elif "metric" in d:
+            rf = d.get("roofline", {})
+            out.append({"what": name, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                        "dtype": d["dtype"], "exec": d["config"].get("exec"),
+                        "step_achieved_hbm_frac": rf.get("step_achieved_hbm_frac")})
+        else:
+            out.append(d)
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N` over
     this same command line as a CHILD process (never exec; nothing in this process has touched the GPU yet), relay its
@@ -126,7 +196,7 @@ def self_launch(n):
     return subprocess.run(cmd, env=env, cwd=ROOT).returncode
 
 
-def _pmc_traffic(args, bs):
+def _pmc_traffic(args, bs, family="gemm_x3_kernel"):
     """roofline.traffic: HBM bytes per GEMM launch from the committed PMC summary of this same workload
     (tools/gpu_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 half-count correction).  PMC passes
     cannot run inside the timed bench, so the number is read from profiles/; None when no summary matches."""
@@ -138,7 +208,9 @@ def _pmc_traffic(args, bs):
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            fam = d.get("families", {}).get("gemm_x3_kernel") or d["gemm_family"]       # the roofline's kernel
+            fam = d.get("families", {}).get(family) or d.get("families", {}).get(family.split("<")[0])       # the roofline's kernel
+            if fam is None:
+                continue
             return float(fam["hbm_bytes_per_launch"]), os.path.relpath(f, root)
         except (OSError, KeyError, ValueError):
             continue
@@ -163,9 +235,15 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a hipGraph")
     ap.add_argument("--gemm-table", default=None, help="write a per-shape GEMM timing table to this file")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the bounded secondary measurements (the other BASELINE configs, the engine's two-pass train step)")
+    ap.add_argument("--train-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_measure()), flush=True)
+        return
+    if args.train_step:
+        print(json.dumps(train_step_measure(args.batch)), flush=True)
         return
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -312,21 +390,40 @@ def main():
                 fh.write("%7d %5d %6d %d %d %3d %3d %d | %4d %8.3f %8.3f %7.1f %9.3f\n" %
                          (*key, cnt, ms, ms / prof_steps, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0, fl / 1e9 / prof_steps))
     if rank == 0:
-        # the dominant kernel is gemm_x3_kernel: launches ud_gemm routes to the BF16 matrix pipe (ud_gemm_query_path == 2)
+        # GEMM families on the matrix pipe: gemm_p3_kernel prec 2 (path 4: pre-split fp16 x 2 planes, THREE fp16 MFMAs per
+        # product tile), gemm_x3_kernel (path 2: in-kernel bf16 x 3 split, SIX bf16 MFMAs; path 3: its one-MFMA fp16 mode);
+        # everything else is gemm_kernel on the fp32 pipe.  The roofline's kernel is the family with the most time.
+        p2 = [p for p in prof if p[4] == 4]
         x3 = [p for p in prof if p[4] in (2, 3)]
-        f32 = [p for p in prof if p[4] not in (2, 3)]
-        mfma_per_product = 1 if args.dtype == "f16" else X3_MFMA_PER_PRODUCT
+        f32 = [p for p in prof if p[4] not in (2, 3, 4)]
+
+        def fam(ps, mfma_per_product):
+            ms = sum(p[0].elapsed_time(p[1]) for p in ps)
+            fl = sum(p[2] for p in ps)
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            by = sum(p[5] for p in ps)
+            return {"launches_per_step": len(ps) / prof_steps, "ms_per_step": ms / prof_steps, "gflop_per_step": fl / 1e9 / prof_steps,
+                    "achieved_tflops_fp32_equiv": ach, "mfma_per_product": mfma_per_product,
+                    "executed_mfma_tflops": ach * mfma_per_product, "frac_of_pipe": ach * mfma_per_product / BF16_PEAK_TFLOPS,
+                    "algorithmic_bytes_per_launch": by / max(len(ps), 1),
+                    "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+        fam_p2 = fam(p2, 3)
+        fam_x3 = fam(x3, 1 if args.dtype == "f16" else X3_MFMA_PER_PRODUCT)
+        dom_name, dom = (("gemm_p3_kernel<prec 2>", fam_p2) if fam_p2["ms_per_step"] > fam_x3["ms_per_step"]
+                         else ("gemm_x3_kernel", fam_x3))
+        mfma_per_product = dom["mfma_per_product"]
         x3_ms = sum(p[0].elapsed_time(p[1]) for p in x3)
         x3_flops = sum(p[2] for p in x3)
         f32_ms = sum(p[0].elapsed_time(p[1]) for p in f32)
         f32_flops = sum(p[2] for p in f32)
-        gemm_ms, gemm_flops = x3_ms + f32_ms, x3_flops + f32_flops
-        achieved = x3_flops / (x3_ms * 1e-3) / 1e12 if x3_ms > 0 else 0.0           # algorithmic fp32 TFLOP/s, x3 launches
+        gemm_ms = x3_ms + f32_ms + fam_p2["ms_per_step"] * prof_steps
+        gemm_flops = x3_flops + f32_flops + fam_p2["gflop_per_step"] * 1e9 * prof_steps
+        achieved = dom["achieved_tflops_fp32_equiv"]                                   # algorithmic fp32 TFLOP/s of the dominant family
         achieved_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        # operand + result bytes of each x3 launch (fp32, every matrix touched once), to set beside the PMC traffic
-        alg_bytes = sum(p[5] for p in x3) / max(len(x3), 1)
-        hbm_gbs = sum(p[5] for p in x3) / (x3_ms * 1e-3) / 1e9 if x3_ms > 0 else 0.0
-        traffic, traffic_src = _pmc_traffic(args, bs)
+        alg_bytes = dom["algorithmic_bytes_per_launch"]
+        hbm_gbs = dom["hbm_gbs"]
+        n_dom = dom["launches_per_step"]
+        traffic, traffic_src = _pmc_traffic(args, bs, dom_name)
         line = {
             "metric": ("images/sec fwd+bwd (256x256, EffNet-b4)" if (args.model, args.size) == ("UDEB4", 256)
                        else f"images/sec fwd+bwd ({args.size}x{args.size}, {args.model})")
@@ -350,11 +447,14 @@ def main():
                        "grad_l1": float(sum(p.grad.double().abs().sum() for p in params if p.grad is not None)),
                        "deterministic": cfg.deterministic},
             "roofline": {"bound": "hbm" if args.dtype == "f16" else "mfma",
-                         "kernel": "gemm_x3_kernel (csrc/gemm_x3.hip): fp32 GEMM on the BF16 matrix pipe — every fp32 operand "
-                                   "split exactly into 3 bf16 pieces, SIX v_mfma_f32_32x32x16_bf16 per fp32 product tile, "
-                                   "fp32-GEMM accuracy.  achieved = algorithmic fp32 FLOPs (2MNK) of its launches / their "
-                                   "HIP-event time; peak = the pipe's dense BF16 peak (2500 TFLOP/s) / 6 executed MFMAs per "
-                                   "algorithmic product, so frac = executed MFMA work / pipe peak",
+                         "kernel": dom_name + ": the GEMM family with the most time in the step.  gemm_p3_kernel<prec 2> "
+                                   "(csrc/gemm_p3.hip): fp32-accurate GEMM from operands pre-split into two fp16 pieces (one "
+                                   "power-of-two scale per tensor), LDS-DMA loader waves + MFMA waves, THREE "
+                                   "v_mfma_f32_32x32x16_f16 per fp32 product tile; gemm_x3_kernel (csrc/gemm_x3.hip): every fp32 "
+                                   "operand split in the k-loop into 3 bf16 pieces, SIX v_mfma_f32_32x32x16_bf16 per tile.  "
+                                   "achieved = algorithmic fp32 FLOPs (2MNK) of the family's launches / their HIP-event time; "
+                                   "peak = the pipe's dense 16-bit peak (2500 TFLOP/s) / executed MFMAs per algorithmic product, "
+                                   "so frac = executed MFMA work / pipe peak",
                          "achieved": achieved, "peak": BF16_PEAK_TFLOPS / mfma_per_product, "unit": "TFLOP/s",
                          "frac": achieved * mfma_per_product / BF16_PEAK_TFLOPS,
                          "executed_mfma_tflops": achieved * mfma_per_product, "pipe_peak": BF16_PEAK_TFLOPS,
@@ -367,9 +467,10 @@ def main():
                          # MFMA per product tile leaves the GEMMs memory-bound
                          "hbm": {"achieved": hbm_gbs, "peak": 8000.0, "unit": "GB/s", "frac": hbm_gbs / 8000.0},
                          "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (mean over the gemm_x3_kernel launches of a step)",
+                         "traffic_unit": "HBM bytes per launch (mean over the dominant family's launches of a step)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                         "launches_per_step": len(x3) / prof_steps,
+                         "launches_per_step": n_dom,
+                         "families": {"gemm_p3_kernel<prec 2>": fam_p2, "gemm_x3_kernel": fam_x3},
                          "x3_ms_per_step": x3_ms / prof_steps, "x3_gflop_per_step": x3_flops / 1e9 / prof_steps,
                          # the rest of the GEMM family: gather-mode 3x3 convs / tiny shapes on v_mfma_f32_32x32x2_f32
                          "fp32_pipe_kernel": {"launches_per_step": len(f32) / prof_steps, "ms_per_step": f32_ms / prof_steps,
@@ -381,7 +482,7 @@ def main():
                          "gemm_family_tflops_fp32_equiv": achieved_all,
                          "measured": f"{prof_steps} EAGER steps after the timed region, HIP events around every launch on its "
                                      "stream (events cannot be read inside the replayed graph the headline number comes "
-                                     "from); profiles/r03/ holds the rocprofv3 --kernel-trace --stats summary of the "
+                                     "from); profiles/r04/ holds the rocprofv3 --kernel-trace --stats summary of the "
                                      "graph-replayed steps of this same command (tools/gpu_round.sh), and "
                                      "tools/roofline_from_rocprof.py recomputes these numbers from it"},
         }
@@ -395,7 +496,15 @@ def main():
             # 68.9 GFLOP and 1044 MB at bs 32 — per GPU, against the fp32 matrix peak and 8 TB/s
             ips = bs * args.steps / elapsed
             line["roofline"]["step_achieved_mfma_frac"] = 68.9e9 * ips / (MFMA_F32_PEAK_TFLOPS * 1e12)
-            line["roofline"]["step_achieved_hbm_frac"] = 1044e6 * ips / 8e12
+            # B_alg per image: 996.3 MB of activations (fp32) + 3*4*P/bs of weights and weight gradients; half storage of the
+            # trunk halves the activation term (~0.52 GB/img at bs 64)
+            act_mb = 996.3 * (0.5 if (args.dtype == "f16" and args.storage == "f16") else 1.0)
+            b_alg = (act_mb + 3 * 4 * 128.31 / bs) * 1e6
+            line["roofline"]["step_algorithmic_bytes_per_image"] = b_alg
+            line["roofline"]["step_achieved_hbm_frac"] = b_alg * ips / 8e12
+        if world == 1 and not args.no_extra and (args.model, args.size, bs, args.dtype) == ("UDEB4", 256, 32, "f32"):
+            torch.cuda.empty_cache()
+            line["extra"] = extra_measurements()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     if dist.is_initialized():

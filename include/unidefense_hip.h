@@ -118,7 +118,9 @@ int ud_gemm_query_path(const ud_gemm_desc* d);
  *           (ud_split_planes_h2; mode 0 only: the scale must be constant along k).  Three piece products on the fp16 matrix
  *           pipe into two fp32 accumulators (a0b0, and a1b0 + a0b1), the result (hi + 2^-11 lo) * a_inv_scale[m * a_scale_stride]
  *           * b_inv_scale[n * b_scale_stride] (= 1 / s; stride 0: a scalar, 1: a vector [M] / [N]).  22 significand bits of every
- *           element within 2^-29 of the scale's maximum, the dropped a1b1 < 2^-24 |ab|, fp32 accumulation: the accuracy of an
+ *           element within 2^-18 of the scale's maximum (smaller elements: an absolute error of 2^-40 of that maximum — so with ONE
+ *           scale per tensor a GEMM row lying 2^-24 below the largest keeps ~16 bits; with a scale per row every row keeps 22), the
+ *           dropped a1b1 < 2^-24 |ab|, fp32 accumulation: the accuracy of an
  *           fp32 GEMM (measured at or below ud_gemm's error on every operand distribution tried) at half the matrix work.
  *   mode 0: GEMM row = row of X, k = column of X     (activations [pixels][C] as A; weights [Cout][Cin] as B)
  *   mode 1: GEMM row = column of X, k = row of X     (dY / X of a weight gradient; weights of a data gradient)

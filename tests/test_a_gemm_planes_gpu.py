@@ -1,0 +1,198 @@
+"""GPU parity tests of ud_gemm_p3 (csrc/gemm_p3.hip) and its producers, through the C ABI: the GEMM on pre-split operands that
+serves the spectral 1x1 convs (model/efficientnet/exp.py:57: F.conv2d(x_freq, freq_conv.weight), its data gradient and its
+weight gradient).
+
+* prec 3 (three bf16 planes): the arithmetic of ud_gemm's split-bf16 kernel with the split done by the producer — results must
+  be BITWISE those of ud_gemm (plain launches; split-K launches are compared with float64).
+* prec 2 (two fp16 planes, power-of-two scale per tensor or per row): against float64, error relative to sum |a||b| of every
+  output — the bar is ud_gemm's own error on the same operands (x 2) or 2e-6, on well- and badly-conditioned operands.
+* ud_split_planes* / ud_absmax: the planes re-assembled on the host must give back the input (prec 3: exactly; prec 2: to
+  2^-21 of the scale's maximum), the scale must put the maximum into [2^14, 2^15).
+* stream-K, split-K (atomics and ordered slices), tail plan, row offsets, epilogue statistics.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _operands(kind, M, N, Kd, dev, dist="randn"):
+    """(a, b, a_mode, b_mode) in the storage of the three products.  k-e4 / rows-e3: magnitudes e^(4 randn) along k, e^(3 randn)
+    across the GEMM rows (clamped to 2^+-8.7 around the median: inside the 2^18 full-precision window of ONE tensor scale); tiny / huge scale A only."""
+    def mk(r, c, k_dim, first):
+        g = torch.randn(r, c, device=dev)
+        if dist == "same-sign":
+            return g.abs()
+        if dist == "lognormal3":
+            return g * torch.exp(3 * torch.randn(r, c, device=dev))
+        if dist in ("k-e4", "rows-e3"):
+            along_k = dist == "k-e4"
+            sig = 4.0 if along_k else 3.0
+            shape = ((1, c) if k_dim == 1 else (r, 1)) if along_k else ((r, 1) if k_dim == 1 else (1, c))
+            return g * torch.exp((sig * torch.randn(shape, device=dev)).clamp(-2 * sig, 2 * sig))
+        if dist == "tiny" and first:
+            return g * 1e-30
+        if dist == "huge" and first:
+            return g * 1e30
+        if dist == "zero-rows":
+            g[::3] = 0
+        return g
+    if kind == "nt":
+        return mk(M, Kd, 1, True), mk(N, Kd, 1, False), 0, 0
+    if kind == "nn":
+        return mk(M, Kd, 1, True), mk(Kd, N, 0, False), 0, 1
+    return mk(Kd, M, 0, True), mk(Kd, N, 0, False), 1, 1
+
+
+def _ref64(kind, a, b):
+    a, b = a.double(), b.double()
+    return a @ b.t() if kind == "nt" else a @ b if kind == "nn" else a.t() @ b
+
+
+def _x3(K, kind, a, b, M, N, Kd):
+    am, bm = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}[kind]
+    out = torch.empty(M, N, device=a.device)
+    return K._gemm(a, b, out, M, N, Kd, a.shape[1], b.shape[1], N, am, bm, 0, 1, cfg=1)
+
+
+@pytest.mark.parametrize("kind,M,N,Kd", [("nt", 256, 256, 64), ("nt", 384, 200, 96), ("nn", 300, 264, 160),
+                                         ("tn", 192, 320, 256), ("nt", 1280, 3264, 3264 // 3), ("tn", 672, 672, 4352)])
+def test_prec3_is_bitwise_the_in_kernel_split(kind, M, N, Kd):
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(1)
+    a, b, am, bm = _operands(kind, M, N, Kd, dev)
+    ap, bp = K.split_planes(a), K.split_planes(b)
+    out = torch.full((M, N), float("nan"), device=dev)
+    K._gemm_p3(ap, bp, out, M, N, Kd, am, bm)
+    ref = _x3(K, kind, a, b, M, N, Kd)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    # split-K (ordered slices under cfg.deterministic, else atomics) and stream-K against float64
+    want = _ref64(kind, a, b)
+    scale = _ref64(kind, a.abs(), b.abs())
+    for out_mode, split, cfg in ((2, 3, 0), (0, 1, 0x800)):
+        if Kd // 32 < split:
+            continue
+        o = K.split_out((M, N), a) if out_mode == 2 else torch.zeros(M, N, device=dev)
+        K._gemm_p3(ap, bp, o, M, N, Kd, am, bm, out_mode, split, cfg=cfg)
+        torch.cuda.synchronize()
+        assert ((o.double() - want).abs() / scale).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("dist", ["randn", "same-sign", "lognormal3", "k-e4", "rows-e3", "tiny", "huge", "zero-rows"])
+@pytest.mark.parametrize("kind,M,N,Kd", [("nt", 384, 200, 96), ("nn", 640, 1344, 1344), ("tn", 672, 416, 2176)])
+def test_prec2_has_fp32_gemm_accuracy(dist, kind, M, N, Kd):
+    from unidefense_amd import kernels as K
+    from tests.margins import within
+    dev = _dev()
+    torch.manual_seed(2)
+    a, b, am, bm = _operands(kind, M, N, Kd, dev, dist)
+    want = _ref64(kind, a, b)
+    scale = _ref64(kind, a.abs(), b.abs()) + 1e-300
+    e3 = ((_x3(K, kind, a, b, M, N, Kd).double() - want).abs() / scale).max().item()
+    ap, bp = K.split_planes(a, prec=2), K.split_planes(b, prec=2)
+    worst = 0.0
+    for out_mode, split, cfg in ((0, 1, 0), (2, 2, 0), (0, 1, 0x800)):
+        o = K.split_out((M, N), a) if out_mode == 2 else torch.zeros(M, N, device=dev)
+        K._gemm_p3(ap, bp, o, M, N, Kd, am, bm, out_mode, split, cfg=cfg)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all()
+        worst = max(worst, ((o.double() - want).abs() / scale).max().item())
+    assert within(f"gemm_p3 prec 2 {kind} {dist} vs float64 (bar: the in-kernel-split GEMM's error x 2)", worst, max(2e-6, 2 * e3))
+
+
+def test_prec2_row_scales_cover_rows_of_any_magnitude():
+    """one scale per GEMM row (mode 0): rows 2^+-35 apart keep fp32-GEMM accuracy each (a single tensor scale could not)"""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(3)
+    M, N, Kd = 512, 384, 672
+    a = torch.randn(M, Kd, device=dev) * torch.exp(8 * torch.randn(M, 1, device=dev))
+    b = torch.randn(N, Kd, device=dev) * torch.exp(8 * torch.randn(N, 1, device=dev))
+    ap, bp = K.split_planes(a, prec=2, per_row=True), K.split_planes(b, prec=2, per_row=True)
+    out = torch.empty(M, N, device=dev)
+    K._gemm_p3(ap, bp, out, M, N, Kd, 0, 0)
+    torch.cuda.synchronize()
+    want = a.double() @ b.double().t()
+    scale = a.double().abs() @ b.double().abs().t()
+    assert ((out.double() - want).abs() / scale).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("R,C", [(300, 96), (1280, 3264), (64, 40)])
+def test_split_kernels_reassemble_to_the_input(R, C):
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(4)
+    x = torch.randn(R, C, device=dev) * torch.exp(2 * torch.randn(R, C, device=dev))
+
+    def unpack(pl, dtype):
+        npan, rows = pl.npanel, pl.panel // 32
+        planes = pl.buf.view(pl.prec, npan, rows, 32)[:, :, :R].view(dtype)          # [prec][panel][R][32]
+        return planes.permute(0, 2, 1, 3).reshape(pl.prec, R, npan * 32)[:, :, :C].double()
+    p3 = K.split_planes(x)
+    torch.cuda.synchronize()
+    assert torch.equal(unpack(p3, torch.bfloat16).sum(0), x.double())          # exact three-way split
+    for per_row in (False, True):
+        p2 = K.split_planes(x, prec=2, per_row=per_row)
+        torch.cuda.synchronize()
+        h = unpack(p2, torch.float16)
+        inv = p2.inv.double().view(-1, 1) if per_row else p2.inv.double()
+        back = (h[0] + h[1] / 2048.0) * inv
+        top = x.abs().amax(1, keepdim=True).double() if per_row else x.abs().max().double()
+        assert ((back - x.double()).abs() / top).max().item() < 2.0 ** -21
+        smax = (x.double().abs() / inv).amax(1) if per_row else (x.double().abs() / inv).max()
+        assert (smax >= 2.0 ** 14).all() and (smax < 2.0 ** 15).all()
+        if (C % 32) != 0:          # the last panel's padding columns are zeros (they are multiplied as K padding)
+            pad = p2.buf.view(2, p2.npanel, p2.panel // 32, 32)[:, -1, :R, C % 32:]
+            assert (pad == 0).all()
+
+
+def test_row_offsets_tail_plan_and_epilogue_statistics():
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(5)
+    M, N, Kd = 640, 256, 128
+    a, b = torch.randn(M, Kd, device=dev), torch.randn(N, Kd, device=dev)
+    for prec in (3, 2):
+        ap, bp = K.split_planes(a, prec=prec), K.split_planes(b, prec=prec)
+        out = torch.empty(256, N, device=dev)
+        K._gemm_p3(ap, bp, out, 256, N, Kd, 0, 0, a_row0=384)
+        acc = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+        full = torch.empty(M, N, device=dev)
+        _, done = K._gemm_p3(ap, bp, full, M, N, Kd, 0, 0, stats=acc)
+        torch.cuda.synchronize()
+        want = a.double() @ b.double().t()
+        assert (out.double() - want[384:]).abs().max().item() < 1e-4
+        assert done
+        assert ((acc[:N] - full.double().sum(0)).abs().max() / full.double().abs().sum(0).max()).item() < 1e-12
+        assert ((acc[N:] - (full.double() ** 2).sum(0)).abs().max() / (full.double() ** 2).sum(0).max()).item() < 1e-12
+    # the three-product context the tape uses, every plan kind, against the in-kernel-split functions
+    from unidefense_amd.config import override
+    M, C2 = 1152, 672
+    x, w, dy = torch.randn(M, C2, device=dev), torch.randn(C2, C2, device=dev) * 0.05, torch.randn(M, C2, device=dev)
+    with override(spectral_p2="off"):
+        y0, c0 = K.spectral_fwd(x, w)
+        dx0, dw0 = K.spectral_dgrad(c0, dy), K.spectral_wgrad(c0, dy)
+    with override(spectral_p2="on"):
+        y1, c1 = K.spectral_fwd(x, w)
+        assert c1.plans is not None
+        dx1, dw1 = K.spectral_dgrad(c1, dy), K.spectral_wgrad(c1, dy)
+    torch.cuda.synchronize()
+    for got, ref in ((y1, y0), (dx1, dx0), (dw1, dw0)):
+        assert ((got - ref).abs().max() / ref.abs().max()).item() < 5e-6
+    xp, wp = K.split_planes(x, prec=2), K.split_planes(w, prec=2)
+    for kind, (m, n, k, pa, pb, ref) in {"nt": (M, C2, C2, xp, wp, y0), "nn": (M, C2, C2, xp, wp, None),
+                                         "tn": (C2, C2, M, xp, xp, None)}.items():
+        if ref is None:
+            ref = (x.double() @ w.double()).float() if kind == "nn" else (x.double().t() @ x.double()).float()
+        for plan in K._p2_plans(kind, m, n, k) + [("tail", 1024, 2)] * (kind != "tn"):
+            got = K._p2_run(kind, plan, pa, pb, m, n, k, x)
+            torch.cuda.synchronize()
+            assert ((got - ref).abs().max() / ref.abs().max()).item() < 5e-6, (kind, plan)

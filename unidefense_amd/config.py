@@ -1,22 +1,24 @@
 """The ONE place the package reads its environment: every run-time switch of unidefense_amd is a field of `cfg`,
 filled once at import from the `UD_*` variables listed here and changeable afterwards from Python
 (`from unidefense_amd.config import cfg; cfg.deterministic = True`) — the modules look the field up when they act,
-not when they are imported.  Anything not listed here is a compile-time constant of the kernels.
+not when they are imported, EXCEPT the four marked (import): gemm_tune_defaults, the load side of gemm_tune_cache and
+lib_path are consumed when unidefense_amd.kernels / .lib are imported, engine_graph when an engine is built — set those
+through the environment (tools/run_with.py does).  Anything not listed here is a compile-time constant of the kernels.
 
 | field | env | default | meaning |
 |---|---|---|---|
-| deterministic | UD_DETERMINISTIC | 0 | split-K GEMMs add their partial products in a FIXED order (slices + ud_sum_slices) instead of fp32 atomics: the same inputs give the same step on every run and every box, on the fused MBConv path as on the operator path (measured: +2.3 ms on the 33.5 ms bs-32 step, which is why it is opt-in; the parity suite runs with it, tests/conftest.py) |
+| deterministic | UD_DETERMINISTIC | 0 | split-K GEMMs add their partial products in a FIXED order (slices + ud_sum_slices) instead of fp32 atomics: the step no longer depends on the ORDER in which fp32 atomics land (what remains order-dependent are the fp64 atomic sums of the fused MBConv path, at 1e-16: repeatable in every run observed, tests/test_y_fullsize_gpu.py, not guaranteed bitwise; the operator path, cfg.fused_mbconv = False, reduces in a fixed order throughout) (measured: +2.3 ms on the 33.5 ms bs-32 step, which is why it is opt-in; the parity suite runs with it, tests/conftest.py) |
 | fused_mbconv | UD_FUSED_MBCONV | 1 | training-mode MBConv blocks as one tape node with deferred BatchNorm (0: operator by operator) |
 | half_storage | UD_HALF_STORAGE | 0 | fp16 activation storage in the MBConv trunk (BASELINE configs[4]); `model.half_storage` overrides |
 | gemm_tune | UD_GEMM_TUNE | 1 | measure (tile, split-K) candidates on the first eager call of an unseen GEMM shape |
-| gemm_tune_defaults | UD_GEMM_TUNE_DEFAULTS | 1 | start from the shipped plans (gemm_plans_gfx950.json) |
-| gemm_tune_cache | UD_GEMM_TUNE_CACHE | unset | JSON file the measured plans are read from / added to |
-| engine_graph | UD_ENGINE_GRAPH | 1 | the engine's two passes replayed from hipGraphs |
+| gemm_tune_defaults (import) | UD_GEMM_TUNE_DEFAULTS | 1 | start from the shipped plans (gemm_plans_gfx950.json) |
+| gemm_tune_cache | UD_GEMM_TUNE_CACHE | unset | JSON file the measured plans are added to (and read from at import) |
+| engine_graph (engine init) | UD_ENGINE_GRAPH | 1 | the engine's two passes replayed from hipGraphs |
 | syncbn_exchange | UD_SYNCBN_EXCHANGE | 1 | SyncBN sums through the peer-mapped mailbox kernel (0: dist.all_reduce) |
 | force_collectives | UD_FORCE_COLLECTIVES | 0 | issue the data-parallel collectives even in a world of one rank (single-GPU test of the RCCL path) |
 | hip_adamw | UD_HIP_ADAMW | 1 | build_optimizer returns the multi-tensor HIP AdamW for 'adamw' on the GPU |
 | wgrad_stream | UD_WGRAD_STREAM | 0 | weight-gradient kernels on a second stream (measured slower; kept for A/B) |
-| lib_path | UD_LIB_PATH | unset | load another build of libunidefense_hip.so (A/B of kernel builds) |
+| lib_path (import) | UD_LIB_PATH | unset | load another build of libunidefense_hip.so (A/B of kernel builds) |
 | spectral_p2 | UD_SPECTRAL_P2 | auto | the spectral 1x1 convs' forward / data-gradient GEMMs from pre-split fp16 x 2 planes (ud_gemm_p3 prec 2): `auto` where measured (or, untuned, estimated) faster than the in-kernel bf16 x 3 split, `on` wherever the kernel takes the shape, `off` never |
 
 The shared library itself reads three variables when it is loaded, for hosts that do not go through Python:

@@ -15,7 +15,8 @@
 //           unscaled, every element more than 2^-18 below its row's maximum lost its second piece — measured 1.4e-5 on
 //           heavy-tailed rows).  Three products on v_mfma_f32_32x32x16_f16 into TWO fp32 accumulators per tile — a0b0, and
 //           a1b0 + a0b1 — combined as (hi + 2^-11 lo) / (sa sb) in the epilogue.  h0 + 2^-11 h1 carries 22 significand bits of every
-//           element within 2^-29 of its row's maximum, the dropped a1b1 is below 2^-24 |ab|: the error of a product is that of an
+//           element within 2^-18 of the scale's maximum (below that the error is ABSOLUTE: 2^-40 of the maximum — a residual
+//           under 2^-25 of the scaled value flushes), the dropped a1b1 is below 2^-24 |ab|: the error of a product is that of an
 //           fp32 multiply, the sum is accumulated in fp32 as before — HALF the matrix-pipe work and two thirds of the operand
 //           bytes of PREC 3, which is what counts on a part that holds its clock down under MFMA load (measured 1.5-1.6 GHz).
 //

@@ -30,7 +30,11 @@ class HipAdamW(torch.optim.Optimizer):
     Reference: engine/forgery_engine.py:149-156,228; engine/abstract_engine.py:281-283,374-378.
     State layout: exp_avg / exp_avg_sq / max_exp_avg_sq are views of three flat buffers (16-byte aligned per tensor);
     state_dict() / load_state_dict() speak torch.optim.AdamW's format (incl. the per-parameter `step`), so a checkpointed
-    optimizer resumes with its moments and bias corrections, and either optimizer can load the other's state."""
+    optimizer resumes with its moments and bias corrections, and either optimizer can load the other's state.
+    ONE step counter serves every parameter (the kernel derives the bias corrections from it): state_dict() stamps it on
+    every entry, load_state_dict() requires the loaded per-parameter steps to agree — which they do whenever every parameter
+    received a gradient in every step, as in the reference's engines; a state in which they differ (parameters frozen for part
+    of a torch.optim.AdamW run) is refused rather than silently averaged."""
 
     _step_supports_amp_scaling = True
 
@@ -101,7 +105,10 @@ class HipAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._plan = None
         self._steps = None
-        self._loaded_step = max([int(float(st["step"])) for st in self.state.values() if "step" in st] + [0])
+        steps = {int(float(st["step"])) for st in self.state.values() if "step" in st}
+        if len(steps) > 1:
+            raise ValueError(f"HipAdamW keeps one step counter for all parameters; the loaded state has {sorted(steps)}")
+        self._loaded_step = max(steps) if steps else 0
         params = [p for g in self.param_groups for p in g["params"]]
         if params and all(p.is_cuda for p in params):
             self._alloc_state(params[0].device)

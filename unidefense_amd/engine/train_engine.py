@@ -73,11 +73,13 @@ class TrainEngine(AbstractEngine):
         self.precision = str(cfg.get("precision", "fp32")).lower()
         if self.precision not in ("fp32", "fp16"):
             raise ValueError(f"config.precision must be 'fp32' or 'fp16', got {self.precision!r}")
+        # The GEMM path is process-wide state of the library: an fp16 engine selects the fp16-MFMA kernel (3), an fp32 engine
+        # the path the process started with (UD_GEMM_PATH, default 0) — and each re-asserts its own at the start of every
+        # train() / validate(), so an fp32 engine built after an fp16 one (an A/B run, a notebook) does not inherit path 3.
+        from .. import lib as _lib
+        self._gemm_path = 3 if self.precision == "fp16" else int(os.environ.get("UD_GEMM_PATH", "0") or 0)
+        _lib.call("ud_gemm_set_path", self._gemm_path)
         if self.precision == "fp16":
-            # process-wide: the fp16-MFMA kernel for every plain GEMM from here on.  An fp32 engine leaves the path alone
-            # (it may have been chosen by UD_GEMM_PATH, or by an fp16 engine that still lives in this process).
-            from .. import lib as _lib
-            _lib.call("ud_gemm_set_path", 3)
             self.model.half_storage = True
         self.model_without_ddp = self.model
         if dist.is_available() and dist.is_initialized():
@@ -103,12 +105,28 @@ class TrainEngine(AbstractEngine):
     def _ckpt_path(self, best=False):
         return os.path.join(self.config["config"].get("dir", "."), "best_model.bin" if best else "latest_model.bin")
 
+    def _any_rank(self, flag):
+        """True on every rank iff `flag` is true on at least one (a no-op without a process group): decisions that guard a
+        collective are taken from this, never from rank-local state such as the file system."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item())
+
     def _check_exchange(self):
         """A SyncBN peer exchange that timed out has poisoned this step's statistics (NaN): raise before anything is
-        logged, validated or saved from them."""
+        logged, validated or saved from them — on EVERY rank together, so that no rank is left waiting in the barrier /
+        all_reduce that follows while another has already raised."""
         exchange = getattr(self.model, "bn_exchange", None)
+        err = None
         if exchange is not None:
-            exchange.check()
+            try:
+                exchange.check()
+            except Exception as e:          # noqa: BLE001 — re-raised below, after the ranks have agreed
+                err = e
+        if self._any_rank(err is not None):
+            raise err if err is not None else RuntimeError("SyncBN peer exchange failed on another rank")
 
     def _save_ckpt(self, step, best=False):
         self._check_exchange()
@@ -129,8 +147,14 @@ class TrainEngine(AbstractEngine):
             t /= dist.get_world_size()
         return t.tolist()
 
+    def _assert_gemm_path(self):
+        from .. import lib as _lib
+        if _lib.call("ud_gemm_get_path") != self._gemm_path:
+            _lib.call("ud_gemm_set_path", self._gemm_path)
+
     def train(self):
         try:
+            self._assert_gemm_path()
             grad_scalar = torch.amp.GradScaler("cuda", init_scale=2 ** 10)        # forgery_engine.py:228
             sums, count, correct, seen, last = {}, 0, 0, 0, {}
             for cur_step in range(1, self.num_steps + 1):
@@ -164,7 +188,10 @@ class TrainEngine(AbstractEngine):
                 # its final weights there, with the TRAIN accuracy of the last log window kept apart from the validation
                 # record (best_auc / best_acc are validation numbers).
                 self.last_train_acc = float(last.get("acc", 0.0))
-                if self.best_auc == 0.0 and self.best_acc == 0.0 and not os.path.exists(self._ckpt_path(best=True)):
+                # (_save_ckpt ends in a barrier: the decision is rank 0's, broadcast — a rank that stats the directory a
+                # moment after rank 0 created the file must not skip a barrier the others run)
+                has_best = self._any_rank(self.local_rank == 0 and os.path.exists(self._ckpt_path(best=True)))
+                if self.best_auc == 0.0 and self.best_acc == 0.0 and not has_best:
                     self.best_step = self.num_steps
                     self._save_ckpt(self.num_steps, best=True)
                 self._save_ckpt(self.num_steps)
@@ -192,6 +219,7 @@ class TrainEngine(AbstractEngine):
         """The reference's test stage (forgery_engine.py:423-452): scores -> cal_metrics (EER, HTER = ACER, TPR@5 %, AUC,
         ACC, ...) over the frames of all ranks."""
         from .metrics import cal_metrics
+        self._assert_gemm_path()
         scores, labels = self._score(batches)
         sc, lb = scores.float().cpu().numpy(), labels.cpu().numpy()
         ret = {"scores": scores.cpu(), "labels": labels.cpu(), "acc": float(((sc < 0.5).astype(int) == lb).mean())}
