@@ -208,7 +208,7 @@ def _pmc_traffic(args, bs, family="gemm_x3_kernel"):
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            fam = d.get("families", {}).get(family) or d.get("families", {}).get(family.split("<")[0])       # the roofline's kernel
+            fam = d.get("families", {}).get(family) or d.get("gemm_family")       # the roofline's kernel family
             if fam is None:
                 continue
             return float(fam["hbm_bytes_per_launch"]), os.path.relpath(f, root)
@@ -383,8 +383,8 @@ def main():
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
         with open(args.gemm_table, "w") as fh:
-            fh.write("# per-shape ud_gemm timing, %d eager instrumented steps; pipe: 2 = gemm_x3_kernel (BF16 matrix pipe), "
-                     "1 = gemm_kernel (fp32 pipe)\n" % prof_steps)
+            fh.write("# per-shape GEMM timing, %d eager instrumented steps; pipe: 4 = gemm_p3_kernel<prec 2> (pre-split fp16 x 2 planes, "
+                     "3 MFMAs per product), 2 = gemm_x3_kernel (in-kernel bf16 x 3 split, 6 MFMAs), 1 = gemm_kernel (fp32 pipe)\n" % prof_steps)
             fh.write("M N K a_mode b_mode split batch pipe | calls ms_total ms_per_step TFLOP/s gflop_per_step\n")
             for key, (cnt, ms, fl) in rows:
                 fh.write("%7d %5d %6d %d %d %3d %3d %d | %4d %8.3f %8.3f %7.1f %9.3f\n" %
@@ -409,8 +409,19 @@ def main():
                     "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
         fam_p2 = fam(p2, 3)
         fam_x3 = fam(x3, 1 if args.dtype == "f16" else X3_MFMA_PER_PRODUCT)
-        dom_name, dom = (("gemm_p3_kernel<prec 2>", fam_p2) if fam_p2["ms_per_step"] > fam_x3["ms_per_step"]
-                         else ("gemm_x3_kernel", fam_x3))
+        # the roofline's kernel: BOTH matrix-pipe kernels as one family (they share the pipe, and which of the two has more time
+        # flips with the host pacing of the eager instrumented steps): achieved = their algorithmic fp32 FLOPs / their time,
+        # executed MFMA work = 3 x the planes kernel's + 6 x the in-kernel-split kernel's algorithmic FLOPs
+        dom_name = "matrix-pipe GEMM family: gemm_p3_kernel<prec 2> + gemm_x3_kernel"
+        pipe_ms = fam_p2["ms_per_step"] + fam_x3["ms_per_step"]
+        pipe_gf = fam_p2["gflop_per_step"] + fam_x3["gflop_per_step"]
+        exec_gf = fam_p2["gflop_per_step"] * fam_p2["mfma_per_product"] + fam_x3["gflop_per_step"] * fam_x3["mfma_per_product"]
+        n_pipe = max(len(p2) + len(x3), 1)
+        dom = {"achieved_tflops_fp32_equiv": pipe_gf / pipe_ms if pipe_ms > 0 else 0.0,
+               "mfma_per_product": exec_gf / pipe_gf if pipe_gf > 0 else 6.0,
+               "algorithmic_bytes_per_launch": (sum(p[5] for p in p2) + sum(p[5] for p in x3)) / n_pipe,
+               "hbm_gbs": (sum(p[5] for p in p2) + sum(p[5] for p in x3)) / prof_steps / (pipe_ms * 1e-3) / 1e9 if pipe_ms > 0 else 0.0,
+               "launches_per_step": n_pipe / prof_steps}
         mfma_per_product = dom["mfma_per_product"]
         x3_ms = sum(p[0].elapsed_time(p[1]) for p in x3)
         x3_flops = sum(p[2] for p in x3)
@@ -447,7 +458,7 @@ def main():
                        "grad_l1": float(sum(p.grad.double().abs().sum() for p in params if p.grad is not None)),
                        "deterministic": cfg.deterministic},
             "roofline": {"bound": "hbm" if args.dtype == "f16" else "mfma",
-                         "kernel": dom_name + ": the GEMM family with the most time in the step.  gemm_p3_kernel<prec 2> "
+                         "kernel": dom_name + ".  gemm_p3_kernel<prec 2> "
                                    "(csrc/gemm_p3.hip): fp32-accurate GEMM from operands pre-split into two fp16 pieces (one "
                                    "power-of-two scale per tensor), LDS-DMA loader waves + MFMA waves, THREE "
                                    "v_mfma_f32_32x32x16_f16 per fp32 product tile; gemm_x3_kernel (csrc/gemm_x3.hip): every fp32 "
@@ -460,6 +471,9 @@ def main():
                          "executed_mfma_tflops": achieved * mfma_per_product, "pipe_peak": BF16_PEAK_TFLOPS,
                          "mfma_per_product": mfma_per_product,
                          "frac_of_pipe": achieved * mfma_per_product / BF16_PEAK_TFLOPS,
+                         # for comparison with rounds 1-3, whose GEMMs all executed six MFMAs per product: the same algorithmic
+                         # throughput priced at six (what the round-3 kernel would have had to execute for it)
+                         "frac_six_product_equiv": achieved * X3_MFMA_PER_PRODUCT / BF16_PEAK_TFLOPS,
                          # the same launches priced as fp32 work against the fp32 matrix peak (bounded by 2.67, not 1)
                          "frac_fp32_equiv": achieved / MFMA_F32_PEAK_TFLOPS,
                          # HBM side of the same launches: algorithmic operand + result bytes (storage types as launched) /

@@ -12,16 +12,18 @@ import sys
 
 def main(stats_csv, table_txt, steps):
     steps = float(steps)
-    x3_ns = f32_ns = total_ns = 0.0
+    x3_ns = f32_ns = p3_ns = total_ns = 0.0
     with open(stats_csv) as fh:
         for row in csv.DictReader(fh):
             ns = float(row["TotalDurationNs"])
             total_ns += ns
-            if "gemm_x3_kernel" in row["Name"]:
+            if "gemm_p3_kernel" in row["Name"]:
+                p3_ns += ns
+            elif "gemm_x3_kernel" in row["Name"]:
                 x3_ns += ns
             elif "gemm_kernel" in row["Name"]:
                 f32_ns += ns
-    x3_gflop = f32_gflop = 0.0
+    x3_gflop = f32_gflop = p3_gflop = 0.0
     with open(table_txt) as fh:
         for ln in fh:
             if ln.startswith("#") or ln.startswith("M "):
@@ -29,7 +31,9 @@ def main(stats_csv, table_txt, steps):
             left, right = ln.split("|")
             pipe = int(left.split()[7])
             gflop = float(right.split()[4])
-            if pipe == 2:
+            if pipe == 4:
+                p3_gflop += gflop
+            elif pipe == 2:
                 x3_gflop += gflop
             else:
                 f32_gflop += gflop
@@ -42,7 +46,15 @@ def main(stats_csv, table_txt, steps):
     if f32_ms > 0:
         print(f"gemm_kernel (fp32 pipe): {f32_ms:8.3f} ms/step, {f32_gflop:8.1f} GFLOP/step -> {f32_gflop / f32_ms:6.1f} TFLOP/s "
               f"= {f32_gflop / f32_ms / 157.3:.3f} of the fp32 matrix peak")
-    print(f"non-GEMM kernels      : {(total_ns - x3_ns - f32_ns) / steps / 1e6:8.3f} ms/step")
+    if p3_ns > 0:
+        p3_ms = p3_ns / steps / 1e6
+        print(f"gemm_p3_kernel<prec 2>: {p3_ms:8.3f} ms/step, {p3_gflop:8.1f} GFLOP/step algorithmic -> {p3_gflop / p3_ms:6.1f} TFLOP/s "
+              f"fp32-equivalent; executed fp16 MFMA (x 3): {3 * p3_gflop / p3_ms:8.1f} TFLOP/s = {3 * p3_gflop / p3_ms / 2500:.3f} of the pipe")
+        fam_ms, fam_gf, fam_ex = p3_ms + x3_ms, p3_gflop + x3_gflop, 3 * p3_gflop + 6 * x3_gflop
+        print(f"matrix-pipe family    : {fam_ms:8.3f} ms/step, {fam_gf:8.1f} GFLOP/step -> {fam_gf / fam_ms:6.1f} TFLOP/s fp32-equivalent; "
+              f"executed MFMA {fam_ex / fam_ms:8.1f} TFLOP/s = {fam_ex / fam_ms / 2500:.3f} of the pipe (roofline.frac); priced at six "
+              f"MFMAs per product like rounds 1-3: {6 * fam_gf / fam_ms / 2500:.3f}")
+    print(f"non-GEMM kernels      : {(total_ns - x3_ns - f32_ns - p3_ns) / steps / 1e6:8.3f} ms/step")
 
 
 if __name__ == "__main__":

@@ -584,14 +584,15 @@ def gemm_nn(a, w, out=None, accumulate=False):
 # serve every GEMM mode) and the products run on three fp16 MFMAs per tile instead of six bf16 ones; the fp32 tensors are not
 # kept.  Which blocks take this path, and each product's launch plan, is measured per shape on first use (`p2sf` entries of the
 # plan table) like the tile / split-K plans of the in-kernel-split GEMMs.
-_P2_MIN = (1024, 512)          # untuned `auto`: M, 2C from which the planes path is taken
+_P2_MIN = (1024, 512)          # untuned `auto`: M and min(N, K) from which the planes path is taken
 _P2_SPLITS = (2, 3, 4, 6, 8)
 _P2_TN_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256)
 _P2_MODES = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}
 
 
-def _p2_shape_ok(M, C2):
-    return C2 % 32 == 0 and M % 32 == 0 and M >= 128 and C2 >= 128
+def _p2_shape_ok(M, N, K):
+    """a 1x1 conv y[M,N] = x[M,K] w[N,K]^T whose three products (nt: k = K, nn: k = N, tn: k = M) all have whole 32-deep K-tiles"""
+    return K % 32 == 0 and N % 32 == 0 and M % 32 == 0 and min(M, N, K) >= 128
 
 
 def _p2_plans(kind, M, N, K):
@@ -655,24 +656,25 @@ def _p2_default_plan(kind, M, N, K):
 
 
 class SpectralCtx:
-    """what the backward of one spectral conv needs: the planes (or, on the in-kernel-split path, the fp32 operands)"""
-    __slots__ = ("plans", "x", "w", "dy", "M", "C2")
+    """what the backward of one 1x1 conv needs: the planes (or, on the in-kernel-split path, the fp32 operands)"""
+    __slots__ = ("plans", "x", "w", "dy", "M", "N", "K")
 
 
-def _p2_block_plans(xf2, w2):
-    """None (in-kernel split) or {"nt": plan, "nn": plan, "tn": plan} for a spectral conv of this shape"""
-    M, C2 = xf2.shape
+def _p2_block_plans(x2, w2):
+    """None (in-kernel split) or {"nt": plan, "nn": plan, "tn": plan} for a 1x1 conv of this shape"""
+    M, Kd = x2.shape
+    N = w2.shape[0]
     mode = CFG.spectral_p2
-    if (mode == "off" or xf2.dtype != torch.float32 or w2.dtype != torch.float32 or not _p2_shape_ok(M, C2) or
+    if (mode == "off" or x2.dtype != torch.float32 or w2.dtype != torch.float32 or not _p2_shape_ok(M, N, Kd) or
             _call("ud_gemm_get_path") not in (0, 2)):
         return None
-    key = ("p2sf", M, C2, bool(CFG.deterministic), mode == "on", 0)
+    key = ("p2c", M, N, Kd, bool(CFG.deterministic), mode == "on", 0)
     plans = _TUNED.get(key, "?")
     if plans == "?":
         if CFG.gemm_tune and not torch.cuda.is_current_stream_capturing():
-            plans = _p2_tune(key, xf2, w2, M, C2, mode == "on")
-        elif mode == "on" or (M >= _P2_MIN[0] and C2 >= _P2_MIN[1]):
-            plans = [_p2_default_plan("nt", M, C2, C2), _p2_default_plan("nn", M, C2, C2), _p2_default_plan("tn", C2, C2, M)]
+            plans = _p2_tune(key, x2, w2, M, N, Kd, mode == "on")
+        elif mode == "on" or (M >= _P2_MIN[0] and min(N, Kd) >= _P2_MIN[1]):
+            plans = [_p2_default_plan("nt", M, N, Kd), _p2_default_plan("nn", M, Kd, N), _p2_default_plan("tn", N, Kd, M)]
         else:
             plans = None
     if plans is None:
@@ -680,50 +682,52 @@ def _p2_block_plans(xf2, w2):
     return {"nt": tuple(plans[0]), "nn": tuple(plans[1]), "tn": tuple(plans[2])}
 
 
-def spectral_fwd(xf2, w2):
-    """yf[M, 2C] = xf[M, 2C] @ w[2C, 2C]^T and the context of its backward"""
+def spectral_fwd(x2, w2):
+    """y[M, N] = x[M, K] @ w[N, K]^T (a 1x1 conv; the spectral convs are the square case) and the context of its backward"""
     ctx = SpectralCtx()
-    ctx.M, ctx.C2 = xf2.shape
-    ctx.plans = _p2_block_plans(xf2, w2)
+    ctx.M, ctx.K = x2.shape
+    ctx.N = w2.shape[0]
+    ctx.plans = _p2_block_plans(x2, w2)
     ctx.dy = None
     if ctx.plans is None:
-        ctx.x, ctx.w = xf2, w2
-        return gemm_nt(xf2, w2), ctx
-    ctx.x, ctx.w = split_planes(xf2, prec=2), split_planes(w2, prec=2)
-    return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.C2, ctx.C2, xf2), ctx
+        ctx.x, ctx.w = x2, w2
+        return gemm_nt(x2, w2), ctx
+    ctx.x, ctx.w = split_planes(x2, prec=2), split_planes(w2, prec=2)
+    return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, x2), ctx
 
 
-def _spectral_dy(ctx, dyf2):
+def _spectral_dy(ctx, dy2):
     if ctx.dy is None:
-        ctx.dy = split_planes(dyf2, prec=2)
+        ctx.dy = split_planes(dy2, prec=2)
     return ctx.dy
 
 
-def spectral_dgrad(ctx, dyf2):
-    """dxf[M, 2C] = dyf[M, 2C] @ w[2C, 2C]"""
+def spectral_dgrad(ctx, dy2):
+    """dx[M, K] = dy[M, N] @ w[N, K]"""
     if ctx.plans is None:
-        return gemm_nn(dyf2, ctx.w)
-    return _p2_run("nn", ctx.plans["nn"], _spectral_dy(ctx, dyf2), ctx.w, ctx.M, ctx.C2, ctx.C2, dyf2)
+        return gemm_nn(dy2, ctx.w)
+    return _p2_run("nn", ctx.plans["nn"], _spectral_dy(ctx, dy2), ctx.w, ctx.M, ctx.K, ctx.N, dy2)
 
 
-def spectral_wgrad(ctx, dyf2):
-    """dw[2C, 2C] = dyf[M, 2C]^T @ xf[M, 2C]"""
+def spectral_wgrad(ctx, dy2):
+    """dw[N, K] = dy[M, N]^T @ x[M, K]"""
     if ctx.plans is None:
-        return gemm_tn(dyf2, ctx.x)
-    return _p2_run("tn", ctx.plans["tn"], _spectral_dy(ctx, dyf2), ctx.x, ctx.C2, ctx.C2, ctx.M, dyf2)
+        return gemm_tn(dy2, ctx.x)
+    return _p2_run("tn", ctx.plans["tn"], _spectral_dy(ctx, dy2), ctx.x, ctx.N, ctx.K, ctx.M, dy2)
 
 
-def _p2_tune(key, xf2, w2, M, C2, forced):
-    """the three products of a spectral conv on the in-kernel-split path against the planes path (its three splits included),
+def _p2_tune(key, x2, w2, M, N, Kd, forced):
+    """the three products of a 1x1 conv on the in-kernel-split path against the planes path (its three splits included),
     every plan of each product measured; the winner is cached (None = in-kernel split)"""
-    t_x3 = _time_launches(lambda: (gemm_nt(xf2, w2), gemm_nn(xf2, w2), gemm_tn(xf2, xf2)))
-    xp, wp = split_planes(xf2, prec=2), split_planes(w2, prec=2)
-    t_p2 = _time_launches(lambda: (split_planes(xf2, xp), split_planes(xf2, xp), split_planes(w2, wp)))
+    dy2 = torch.randn(M, N, device=x2.device)
+    t_x3 = _time_launches(lambda: (gemm_nt(x2, w2), gemm_nn(dy2, w2), gemm_tn(dy2, x2)))
+    xp, wp, dp = split_planes(x2, prec=2), split_planes(w2, prec=2), split_planes(dy2, prec=2)
+    t_p2 = _time_launches(lambda: (split_planes(x2, xp), split_planes(dy2, dp), split_planes(w2, wp)))
     plans = []
-    for kind, (a, b, m, n, k) in (("nt", (xp, wp, M, C2, C2)), ("nn", (xp, wp, M, C2, C2)), ("tn", (xp, xp, C2, C2, M))):
+    for kind, (a, b, m, n, k) in (("nt", (xp, wp, M, N, Kd)), ("nn", (dp, wp, M, Kd, N)), ("tn", (dp, xp, N, Kd, M))):
         best, best_t = None, 1e30
         for plan in _p2_plans(kind, m, n, k):
-            t = _time_launches(lambda: _p2_run(kind, plan, a, b, m, n, k, xf2))
+            t = _time_launches(lambda: _p2_run(kind, plan, a, b, m, n, k, x2))
             if t < best_t:
                 best, best_t = plan, t
         plans.append(list(best))

@@ -125,17 +125,21 @@ def conv1x1(tape, x, w, need_dx=True):
     Co, Ci = w.shape[0], w.shape[1]
     w2 = w.view(Co, Ci)
     x2 = x.view(-1, Ci)
-    y = K.gemm_nt(x2, w2).view(*x.shape[:-1], Co)
-    if _needs(tape):
-        def bwd():
-            dy = tape.pop_grad(y)
-            if dy is None:
-                return
-            dy2 = dy.view(-1, Co)
-            tape.wgrad(w, lambda: K.gemm_tn(dy2, x2), dy2, x2)
-            if need_dx:
-                tape.add_grad(x, K.gemm_nn(dy2, w2).view(x.shape))
-        tape.record(bwd)
+    if not _needs(tape):
+        return K.gemm_nt(x2, w2).view(*x.shape[:-1], Co)
+    # the three products share their operands: large shapes split them once into fp16 x 2 planes (kernels.spectral_*)
+    y2, ctx = K.spectral_fwd(x2, w2)
+    y = y2.view(*x.shape[:-1], Co)
+
+    def bwd():
+        dy = tape.pop_grad(y)
+        if dy is None:
+            return
+        dy2 = dy.reshape(-1, Co)
+        tape.wgrad(w, lambda: K.spectral_wgrad(ctx, dy2), dy2)
+        if need_dx:
+            tape.add_grad(x, K.spectral_dgrad(ctx, dy2).view(x.shape))
+    tape.record(bwd)
     return y
 
 
