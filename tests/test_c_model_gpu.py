@@ -18,6 +18,7 @@ Tolerances (BASELINE.json north_star: "within 1e-3 rel fp32"):
       its spectrum (~4e5 each) within rounding of zero flips its sign under any change of summation order and
       moves the upstream gradient by ~2/sqrt(4e5) ~ 3e-3 of its norm.
 """
+import functools
 import os
 
 import numpy as np
@@ -127,7 +128,7 @@ def test_eval_intermediates_vs_oracle():
 
 
 @pytest.mark.parametrize("variant", ["smooth", "full"])
-def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant):
+def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant, run_mode):
     """Outputs, losses and all 504 parameter gradients (norm + first 8 elements) of the train-mode step vs the
     vectors recorded from the reference (fp32 CPU): EVERY tensor within 1e-3 of its norm (+ the 2e-5 floor), both loss
     variants (observed: 3.5e-4 smooth / 7.4e-4 full at worst).  The floor matters for exactly one family: BN2's bias in
@@ -181,8 +182,23 @@ def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant):
 
 
 # (a third case, ("smooth", 2), ran until round 3: it adds 80 - 100 s of CPU oracle time and nothing the two below do not cover)
+@functools.lru_cache(maxsize=None)
+def _oracle_grads(variant, n, seeds):
+    """the float64 and float32 CPU oracle runs of a case (80 s): shared by the run modes"""
+    lam = ou.SMOOTH_LAMBDAS if variant == "smooth" else ou.LAMBDAS
+    x = param_fill.make_input(n, 256, seeds[0])
+    tgt = param_fill.make_labels(n)
+    rng = ou.make_rng(n, seeds[1], 0.5)
+    sd = ou.oracle_state(0.0, 0.3, dtype=torch.float64, requires_grad=True)
+    o64, _ = ou.oracle_train_pass1(sd, x.double(), tgt, rng, 0.5, lam)
+    assert o64["_max_gap"].item() > 1e-3
+    sd32 = ou.oracle_state(0.0, 0.3, requires_grad=True)
+    ou.oracle_train_pass1(sd32, x, tgt, rng, 0.5, lam)
+    return sd, sd32
+
+
 @pytest.mark.parametrize("variant,n,seeds", [("smooth", 4, (38, 138)), ("full", 2, (38, 138))])
-def test_train_grads_vs_oracle_elementwise(variant, n, seeds):
+def test_train_grads_vs_oracle_elementwise(variant, n, seeds, run_mode):
     """Every parameter gradient, element by element, against the oracle in FLOAT64 on the CPU (same seeded
     inputs, parameters and masks), with the oracle's own float32 run as the conditioning yardstick."""
     dev = _dev()
@@ -193,11 +209,7 @@ def test_train_grads_vs_oracle_elementwise(variant, n, seeds):
     x = param_fill.make_input(n, 256, seeds[0])
     tgt = param_fill.make_labels(n)
     rng = ou.make_rng(n, seeds[1], 0.5)
-    sd = ou.oracle_state(0.0, 0.3, dtype=torch.float64, requires_grad=True)
-    o64, _ = ou.oracle_train_pass1(sd, x.double(), tgt, rng, 0.5, lam)
-    assert o64["_max_gap"].item() > 1e-3
-    sd32 = ou.oracle_state(0.0, 0.3, requires_grad=True)
-    ou.oracle_train_pass1(sd32, x, tgt, rng, 0.5, lam)
+    sd, sd32 = _oracle_grads(variant, n, seeds)
     m = _model(dev, 0.0, 0.3).train()
     out = m(x.to(dev), rng=rng)
     _pass1_loss(out, tgt.to(dev), lam)["total_loss"].backward()

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("tag,cur_step", [("early", 1), ("kl", 50)])
-def test_two_pass_step_vs_reference_golden(golden_dir, tag, cur_step):
+def test_two_pass_step_vs_reference_golden(golden_dir, tag, cur_step, run_mode):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     dev = torch.device("cuda:0")
@@ -169,7 +169,7 @@ def _check_step(g, tag, ret, m, before, loss_tol=1e-3, slack=0.02):
 
 
 @pytest.mark.parametrize("tag", ["freq", "efdm"])
-def test_two_pass_step_style_perturbation_vs_reference_golden(golden_dir, tag):
+def test_two_pass_step_style_perturbation_vs_reference_golden(golden_dir, tag, run_mode):
     """The reference ENGINE's step with pass 2 perturbed by the style branch (permuted batch -> CORAL -> frequency
     amplitude transfer / exact feature-distribution matching; model/unidefense.py:177-191, model/modules.py:35-76): the
     ten returned scalars + pass-1 logits within 1e-3, parameter updates as in test_two_pass_step_vs_reference_golden.
@@ -198,7 +198,7 @@ def test_two_pass_step_style_perturbation_vs_reference_golden(golden_dir, tag):
 
 
 @pytest.mark.parametrize("tag,cur_step", [("early", 1), ("kl", 50)])
-def test_udr18_two_pass_step_vs_reference_golden(golden_dir, tag, cur_step):
+def test_udr18_two_pass_step_vs_reference_golden(golden_dir, tag, cur_step, run_mode):
     """BASELINE configs[0] (ResNet18, 128x128, bs 8): the reference engine's two-pass step, pass 2 perturbed by `downscale`."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
