@@ -180,24 +180,32 @@ def test_two_ranks_equal_one_process_full_batch(name, exchange):
     assert all(ok)
 
 
-def _xchg_worker(rank, port, q):
+def _xchg_worker(rank, port, q, world=2, skew=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     try:
+        import time
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        dist.init_process_group("gloo", rank=rank, world_size=2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
         from unidefense_amd.engine.parallel import BnExchange
         ex = BnExchange(dist.group.WORLD, dev)
         assert ex.ok, "self-test failed"
         g = torch.Generator().manual_seed(7)
-        vecs = [torch.randn(2, n, generator=g, dtype=torch.float64) for n in (8, 96, 1632 * 2, 3264 * 2, 5, 8192)]
+        vecs = [torch.randn(world, n, generator=g, dtype=torch.float64) for n in (8, 96, 1632 * 2, 3264 * 2, 5, 8192)]
         worst = 0.0
         for rep in range(3):
-            for v in vecs:
+            for i, v in enumerate(vecs):
+                if skew and (i + rep + rank) % world == 0:
+                    # one rank (a different one each time) arrives late: the others spin in the kernel on its tagged row while
+                    # their own later exchanges must not overwrite a slot it has not read yet (SLOTS = 4 in flight)
+                    torch.cuda.synchronize()
+                    time.sleep(0.05)
                 a = (v[rank] * (rep + 1)).to(dev)
                 ex.allreduce(a)
-                want = (v[0] * (rep + 1) + v[1] * (rep + 1)).to(dev)          # rank order 0 + 1: exactly this fp64 sum
-                worst = max(worst, float((a - want).abs().max()))
+                want = v[0] * (rep + 1)
+                for r in range(1, world):                                     # rank order 0 + 1 + ...: exactly this fp64 sum
+                    want = want + v[r] * (rep + 1)
+                worst = max(worst, float((a - want.to(dev)).abs().max()))
         # a captured sequence replays with the device-side sequence counter still advancing
         a = torch.zeros(4096, dtype=torch.float64, device=dev)
         src = torch.full((4096,), float(rank + 1), dtype=torch.float64, device=dev)
@@ -213,7 +221,8 @@ def _xchg_worker(rank, port, q):
             gr.replay()
         torch.cuda.synchronize()
         ex.check()
-        replay_ok = bool((a == 3.0).all())              # (1 + 2) -> 1.5 on both -> 3.0
+        tot = world * (world + 1) / 2.0                 # world 2: (1 + 2) -> 1.5 on both -> 3.0
+        replay_ok = bool((a == tot * 0.5 * world).all())
         ex.close()
         q.put((rank, worst, replay_ok, None))
     except Exception:                      # noqa: BLE001
@@ -236,6 +245,25 @@ def test_bn_exchange_two_processes():
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+    for rank, worst, replay_ok, err in got:
+        assert err is None, f"rank {rank}:\n{err}"
+        assert worst == 0.0 and replay_ok, (rank, worst, replay_ok)
+
+
+def test_bn_exchange_four_processes_with_skewed_arrivals():
+    """Four mailboxes on the one GPU (what a 4-GPU node maps, BASELINE configs[3]), ranks arriving up to 50 ms apart in turn:
+    every sum exact in rank order, slots reused 18 times each without a reader losing its row, a captured pair replayed."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xchg_worker, args=(r, port, q, 4, True)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(4)]
     for p in procs:
         p.join(120)
     for rank, worst, replay_ok, err in got:
