@@ -189,6 +189,15 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
     const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
     const int kt_total = d.K / BK;
+    // the descriptor fields the epilogue needs, as values: read through the lambda's reference to the kernel argument hipcc
+    // re-loaded d.ldc from the argument segment (and waited for it) before EVERY one of a lane's 64 stores — 9 us per tile
+    const int dM = d.M, dN = d.N;
+    const long ldc = d.ldc;
+    double* const stat_sum = d.stat_sum;
+    double* const stat_sumsq = d.stat_sumsq;
+    const float* const a_inv = d.a_inv_scale;
+    const float* const b_inv = d.b_inv_scale;
+    const long ast = d.a_scale_stride, bst = d.b_scale_stride;
     const lds_char* Lp = (const lds_char*)L;          // generic -> LDS address space: the low 32 bits are the LDS byte address
     const unsigned lds0 = (unsigned)(uintptr_t)Lp;
     const int lw = wave & 3;                                        // loader wave lw moves tile rows 32 lw .. 32 lw + 31
@@ -324,34 +333,53 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
         // ---- epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
         if (nkt <= 0 && ep != 0) return;
         if constexpr (PREC == 2) {
-            // undo the operands' per-row power-of-two scales (exact); rows / columns beyond the matrix were fed from slack: zero
+            // undo the operands' power-of-two scales (exact); rows / columns beyond the matrix were fed from slack: zero.
+            // The scales are loaded UNCONDITIONALLY from clamped addresses, all of them before the first use: a load under a
+            // per-element select (`ok ? scale[row] : 0`) made hipcc branch around each one and wait for it on the spot —
+            // 64 dependent round trips, 13 us per tile with nothing else resident on the CU (a third of a 1920-deep tile).
+            const float* __restrict__ as = a_inv;
+            const float* __restrict__ bs = b_inv;
+            float ib[2], ia[2][16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ib[j] = bs[(long)min(n0 + wn * 64 + j * 32 + l31, dN - 1) * bst];
+            if (ast == 0) {
+                const float a0 = as[0];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ia[i][r] = a0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ia[i][r] = as[min(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dM - 1)];
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + l31;
-                const bool cok = col < d.N;
-                const float ib = cok ? d.b_inv_scale[(long)col * d.b_scale_stride] : 0.f;
+                const bool cok = n0 + wn * 64 + j * 32 + l31 < dN;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const bool ok = cok && row < d.M;
-                        const float ia = ok ? d.a_inv_scale[(long)row * d.a_scale_stride] : 0.f;
-                        acc[i][j][r] = ok ? (acc[i][j][r] + 0x1p-11f * lo[i][j][r]) * (ia * ib) : 0.f;
+                        float v = (acc[i][j][r] + 0x1p-11f * lo[i][j][r]) * (ia[i][r] * ib[j]);
+                        asm volatile("" : "+v"(v));          // computed, then selected: no branch around the arithmetic
+                        acc[i][j][r] = (cok && row < dM) ? v : 0.f;
                     }
             }
         }
-        if (!SK && d.stat_sum) {
-            if (PREC == 3 && m0 + BM > d.M) {          // rows beyond M were fed from the allocation's slack: not part of the statistics
+        if (!SK && stat_sum) {
+            if (PREC == 3 && m0 + BM > dM) {          // rows beyond M were fed from the allocation's slack: not part of the statistics
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (row >= d.M) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+                        if (row >= dM) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
                     }
             }
-            const long slot = (tiles_m > 64) ? (long)(tile_m & 63) * d.N : 0;
+            const long slot = (tiles_m > 64) ? (long)(tile_m & 63) * dN : 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 double s1 = 0.0, s2 = 0.0;
@@ -366,29 +394,44 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
                 const int col = n0 + wn * 64 + j * 32 + l31;
-                if (half == 0 && col < d.N) {
-                    unsafeAtomicAdd(d.stat_sum + slot + col, s1);
-                    unsafeAtomicAdd(d.stat_sumsq + slot + col, s2);
+                if (half == 0 && col < dN) {
+                    unsafeAtomicAdd(stat_sum + slot + col, s1);
+                    unsafeAtomicAdd(stat_sumsq + slot + col, s2);
                 }
             }
         }
+        auto store_all = [&](auto mode_c, auto inside_c) {
+            constexpr int MODE = decltype(mode_c)::value;          // the output form decided ONCE, not per element
+            constexpr bool INSIDE = decltype(inside_c)::value;     // the whole tile inside C: no per-element predicate
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + l31;
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + wn * 64 + j * 32 + l31;
+                    float* pc = Cp + (long)(m0 + wm * 64 + i * 32 + 4 * half) * ldc + col;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < d.M && col < d.N) {
-                        const float v = acc[i][j][r];
-                        float* p = Cp + (long)row * d.ldc + col;
-                        if (ep == 0) *p = v;
-                        else if (ep == 1) *p += v;
-                        else atomicAdd(p, v);
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        if (INSIDE || (m0 + wm * 64 + i * 32 + 4 * half + dr < dM && col < dN)) {
+                            const float v = acc[i][j][r];
+                            float* p = pc + (long)dr * ldc;
+                            if constexpr (MODE == 0) *p = v;
+                            else if constexpr (MODE == 1) *p += v;
+                            else atomicAdd(p, v);
+                        }
                     }
                 }
             }
+        };
+        const bool inside = m0 + BM <= dM && n0 + BN <= dN;
+        if (inside) {
+            if (ep == 0) store_all(integral_constant<int, 0>{}, T{});
+            else if (ep == 1) store_all(integral_constant<int, 1>{}, T{});
+            else store_all(integral_constant<int, 2>{}, T{});
+        } else {
+            if (ep == 0) store_all(integral_constant<int, 0>{}, F{});
+            else if (ep == 1) store_all(integral_constant<int, 1>{}, F{});
+            else store_all(integral_constant<int, 2>{}, F{});
         }
     };
 

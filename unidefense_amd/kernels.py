@@ -218,6 +218,9 @@ class Planes:
         self.panel = 32 * (-(-R // 128) * 128)          # every panel is backed by rows up to the next multiple of 128
         self.plane = self.npanel * self.panel
         self.buf = torch.empty(prec * self.plane, dtype=torch.int16, device=like.device)
+        if R % 32:
+            # read as k (mode 1) the matrix is walked in whole 32-row K-tiles: the rows that pad the last one must multiply as zeros
+            self.buf.view(prec, self.npanel, self.panel // 32, 32)[:, :, R:-(-R // 32) * 32].zero_()
         self.scale_stride = 1 if per_row else 0
         self.inv = torch.empty(R if per_row else 1, dtype=torch.float32, device=like.device) if prec == 2 else None
 
@@ -591,8 +594,9 @@ _P2_MODES = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}
 
 
 def _p2_shape_ok(M, N, K):
-    """a 1x1 conv y[M,N] = x[M,K] w[N,K]^T whose three products (nt: k = K, nn: k = N, tn: k = M) all have whole 32-deep K-tiles"""
-    return K % 32 == 0 and N % 32 == 0 and M % 32 == 0 and min(M, N, K) >= 128
+    """a 1x1 conv y[M,N] = x[M,K] w[N,K]^T on the planes kernel: its three products reduce over K, N and M in 32-deep K-tiles —
+    channel counts are padded with zero columns / zero weight rows by the split, pixel counts must be whole tiles"""
+    return M % 32 == 0 and K % 4 == 0 and N % 4 == 0 and min(N, K) >= 64 and M >= 128
 
 
 def _p2_plans(kind, M, N, K):
@@ -615,26 +619,34 @@ def _p2_plans(kind, M, N, K):
     return out or [("plain",)]
 
 
-def _p2_run(kind, plan, ap, bp, M, N, K, like):
-    """one product of the planes path.  kind nt: ap [M,K] x bp [N,K]; nn: ap [M,K] x bp [K,N]; tn: ap [K,M] x bp [K,N]"""
+def _p2_run(kind, plan, ap, bp, M, N, K, like, stats=None, out=None):
+    """one product of the planes path.  kind nt: ap [M,K] x bp [N,K]; nn: ap [M,K] x bp [K,N]; tn: ap [K,M] x bp [K,N].
+    out: an existing term the product is ADDED to (the skip branch's gradient), else a fresh result.  stats: see _gemm (only a
+    plain launch fills them: returns (out, done))."""
     am, bm = _P2_MODES[kind]
+    Kp = -(-K // 32) * 32                      # the operands' zero padding makes up the last K-tile
     how = plan[0]
+    acc = out is not None
+    assert not (acc and stats is not None)
     if how == "plain":
-        return _gemm_p3(ap, bp, empty((M, N), like), M, N, K, am, bm, 0, 1)
+        return _gemm_p3(ap, bp, out if acc else empty((M, N), like), M, N, Kp, am, bm, 1 if acc else 0, 1, stats=stats)
+    res = None
     if how == "split":
-        return _gemm_p3(ap, bp, split_out((M, N), like), M, N, K, am, bm, 2, int(plan[1]))
-    if how == "sk":
-        return _gemm_p3(ap, bp, zeros((M, N), like), M, N, K, am, bm, 0, 1, cfg=0x800)
-    m1, s_ = int(plan[1]), int(plan[2])          # "tail" (nt / nn): whole rounds of tiles plain, the last row tiles split
-    out = empty((M, N), like)
-    _gemm_p3(ap, bp, out, m1, N, K, am, bm, 0, 1)
-    tail = out[m1:]
-    if CFG.deterministic:
-        tail._ud_fresh = True
+        res = _gemm_p3(ap, bp, out if acc else split_out((M, N), like), M, N, Kp, am, bm, 2, int(plan[1]))
+    elif how == "sk":
+        res = _gemm_p3(ap, bp, out if acc else zeros((M, N), like), M, N, Kp, am, bm, 1 if acc else 0, 1, cfg=0x800)
     else:
-        tail.zero_()
-    _gemm_p3(ap, bp, tail, M - m1, N, K, am, bm, 2, s_, a_row0=m1)
-    return out
+        m1, s_ = int(plan[1]), int(plan[2])          # "tail" (nt / nn): whole rounds of tiles plain, the last row tiles split
+        res = out if acc else empty((M, N), like)
+        _gemm_p3(ap, bp, res, m1, N, Kp, am, bm, 1 if acc else 0, 1)
+        tail = res[m1:]
+        if not acc:
+            if CFG.deterministic:
+                tail._ud_fresh = True
+            else:
+                tail.zero_()
+        _gemm_p3(ap, bp, tail, M - m1, N, Kp, am, bm, 2, s_, a_row0=m1)
+    return (res, False) if stats is not None else res
 
 
 def _p2_default_plan(kind, M, N, K):
@@ -660,21 +672,23 @@ class SpectralCtx:
     __slots__ = ("plans", "x", "w", "dy", "M", "N", "K")
 
 
-def _p2_block_plans(x2, w2):
-    """None (in-kernel split) or {"nt": plan, "nn": plan, "tn": plan} for a 1x1 conv of this shape"""
+def _p2_block_plans(x2, w2, want_stats=False):
+    """None (in-kernel split) or {"nt": plan, "nn": plan, "tn": plan} for a 1x1 conv of this shape.  want_stats: the forward
+    launch is to fill BatchNorm statistics in its epilogue (a plain launch does; other plans are charged a ud_colstats pass)"""
     M, Kd = x2.shape
     N = w2.shape[0]
     mode = CFG.spectral_p2
     if (mode == "off" or x2.dtype != torch.float32 or w2.dtype != torch.float32 or not _p2_shape_ok(M, N, Kd) or
             _call("ud_gemm_get_path") not in (0, 2)):
         return None
-    key = ("p2c", M, N, Kd, bool(CFG.deterministic), mode == "on", 0)
+    key = ("p2c", M, N, Kd, bool(CFG.deterministic), mode == "on", bool(want_stats))
     plans = _TUNED.get(key, "?")
     if plans == "?":
         if CFG.gemm_tune and not torch.cuda.is_current_stream_capturing():
-            plans = _p2_tune(key, x2, w2, M, N, Kd, mode == "on")
+            plans = _p2_tune(key, x2, w2, M, N, Kd, mode == "on", want_stats)
         elif mode == "on" or (M >= _P2_MIN[0] and min(N, Kd) >= _P2_MIN[1]):
-            plans = [_p2_default_plan("nt", M, N, Kd), _p2_default_plan("nn", M, Kd, N), _p2_default_plan("tn", N, Kd, M)]
+            plans = [("plain",) if want_stats else _p2_default_plan("nt", M, N, Kd), _p2_default_plan("nn", M, Kd, N),
+                     _p2_default_plan("tn", N, Kd, M)]
         else:
             plans = None
     if plans is None:
@@ -682,18 +696,19 @@ def _p2_block_plans(x2, w2):
     return {"nt": tuple(plans[0]), "nn": tuple(plans[1]), "tn": tuple(plans[2])}
 
 
-def spectral_fwd(x2, w2):
-    """y[M, N] = x[M, K] @ w[N, K]^T (a 1x1 conv; the spectral convs are the square case) and the context of its backward"""
+def spectral_fwd(x2, w2, stats=None):
+    """y[M, N] = x[M, K] @ w[N, K]^T (a 1x1 conv; the spectral convs are the square case) and the context of its backward.
+    stats: BatchNorm accumulator of the result (gemm_nt's contract: returns ((y, done), ctx))"""
     ctx = SpectralCtx()
     ctx.M, ctx.K = x2.shape
     ctx.N = w2.shape[0]
-    ctx.plans = _p2_block_plans(x2, w2)
+    ctx.plans = _p2_block_plans(x2, w2, stats is not None)
     ctx.dy = None
     if ctx.plans is None:
         ctx.x, ctx.w = x2, w2
-        return gemm_nt(x2, w2), ctx
+        return gemm_nt(x2, w2, stats=stats), ctx
     ctx.x, ctx.w = split_planes(x2, prec=2), split_planes(w2, prec=2)
-    return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, x2), ctx
+    return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, x2, stats=stats), ctx
 
 
 def _spectral_dy(ctx, dy2):
@@ -702,11 +717,11 @@ def _spectral_dy(ctx, dy2):
     return ctx.dy
 
 
-def spectral_dgrad(ctx, dy2):
-    """dx[M, K] = dy[M, N] @ w[N, K]"""
+def spectral_dgrad(ctx, dy2, out=None):
+    """dx[M, K] = dy[M, N] @ w[N, K]   (out: a term of the same gradient to add onto, in place)"""
     if ctx.plans is None:
-        return gemm_nn(dy2, ctx.w)
-    return _p2_run("nn", ctx.plans["nn"], _spectral_dy(ctx, dy2), ctx.w, ctx.M, ctx.K, ctx.N, dy2)
+        return gemm_nn(dy2, ctx.w, out=out, accumulate=out is not None)
+    return _p2_run("nn", ctx.plans["nn"], _spectral_dy(ctx, dy2), ctx.w, ctx.M, ctx.K, ctx.N, dy2, out=out)
 
 
 def spectral_wgrad(ctx, dy2):
@@ -716,18 +731,28 @@ def spectral_wgrad(ctx, dy2):
     return _p2_run("tn", ctx.plans["tn"], _spectral_dy(ctx, dy2), ctx.x, ctx.N, ctx.K, ctx.M, dy2)
 
 
-def _p2_tune(key, x2, w2, M, N, Kd, forced):
+def _p2_tune(key, x2, w2, M, N, Kd, forced, want_stats=False):
     """the three products of a 1x1 conv on the in-kernel-split path against the planes path (its three splits included),
     every plan of each product measured; the winner is cached (None = in-kernel split)"""
     dy2 = torch.randn(M, N, device=x2.device)
-    t_x3 = _time_launches(lambda: (gemm_nt(x2, w2), gemm_nn(dy2, w2), gemm_tn(dy2, x2)))
+    acc = torch.zeros(2 * N, dtype=torch.float64, device=x2.device) if want_stats else None
+
+    def fwd_x3():
+        r = gemm_nt(x2, w2, stats=acc)
+        if want_stats and not r[1]:
+            colstats(r[0], acc)
+    t_x3 = _time_launches(lambda: (fwd_x3(), gemm_nn(dy2, w2), gemm_tn(dy2, x2)))
     xp, wp, dp = split_planes(x2, prec=2), split_planes(w2, prec=2), split_planes(dy2, prec=2)
     t_p2 = _time_launches(lambda: (split_planes(x2, xp), split_planes(dy2, dp), split_planes(w2, wp)))
+    t_stats = _time_launches(lambda: colstats(dy2, acc)) if want_stats else 0.0
     plans = []
     for kind, (a, b, m, n, k) in (("nt", (xp, wp, M, N, Kd)), ("nn", (dp, wp, M, Kd, N)), ("tn", (dp, xp, N, Kd, M))):
         best, best_t = None, 1e30
         for plan in _p2_plans(kind, m, n, k):
-            t = _time_launches(lambda: _p2_run(kind, plan, a, b, m, n, k, x2))
+            st = acc if (kind == "nt" and want_stats) else None
+            t = _time_launches(lambda: _p2_run(kind, plan, a, b, m, n, k, x2, stats=st))
+            if st is not None and plan[0] != "plain":
+                t += t_stats
             if t < best_t:
                 best, best_t = plan, t
         plans.append(list(best))

@@ -893,7 +893,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         We = blk._expand_conv.weight.view(Ce, Cin)
         x2 = x.view(M, Cin)
         acc0 = K.zeros64(2 * Ce, x)
-        e, done = K.gemm_nt(x2, We, stats=acc0)            # BN0 statistics in the GEMM epilogue where the launch is plain
+        (e, done), ectx = K.spectral_fwd(x2, We, stats=acc0)          # BN0 statistics in the GEMM epilogue where the launch is plain
         if not done:
             K.colstats(e, acc0)
         e = e.view(N, H, W, Ce)
@@ -961,7 +961,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
     Wp = blk._project_conv.weight.view(Co, Ce)
     c2 = c.view(Mo, Ce)
     acc2 = K.zeros64(2 * Co, x)
-    p, done = K.gemm_nt(c2, Wp, stats=acc2)
+    (p, done), pctx = K.spectral_fwd(c2, Wp, stats=acc2)
     if not done:
         K.colstats(p, acc2)
     dp.reduce(acc2)
@@ -985,8 +985,8 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         tape.add_param_grad(blk._bn2.weight, dg2)
         tape.add_param_grad(blk._bn2.bias, db2)
         dp2 = dp_.view(Mo, Co)
-        tape.wgrad(blk._project_conv.weight, lambda: K.gemm_tn(dp2, c2), dp2, c2)
-        dc = K.gemm_nn(dp2, Wp).view(N, Ho, Wo, Ce)
+        tape.wgrad(blk._project_conv.weight, lambda: K.spectral_wgrad(pctx, dp2), dp2)
+        dc = K.spectral_dgrad(pctx, dp2).view(N, Ho, Wo, Ce)
         # ---- squeeze-excite backward
         dgate = K.zeros64(N * Ce, x)
         K.coldot_bn(dc, d, bn1, N, HWo, dgate)
@@ -1048,11 +1048,11 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
             tape.add_param_grad(blk._bn0.weight, dg0)
             tape.add_param_grad(blk._bn0.bias, db0)
             de2 = de.view(M, Ce)
-            tape.wgrad(blk._expand_conv.weight, lambda: K.gemm_tn(de2, x2), de2, x2)
+            tape.wgrad(blk._expand_conv.weight, lambda: K.spectral_wgrad(ectx, de2), de2)
             if sp.skip and tape.watch is None and getattr(dout, "_ud_owned", False):
-                dx = K.gemm_nn(de2, We, out=dout.view(M, Cin), accumulate=True).view(x.shape)    # + skip gradient
+                dx = K.spectral_dgrad(ectx, de2, out=dout.view(M, Cin)).view(x.shape)    # + skip gradient
             else:
-                dx = K.gemm_nn(de2, We).view(x.shape)
+                dx = K.spectral_dgrad(ectx, de2).view(x.shape)
                 if sp.skip:
                     dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
         else:
