@@ -410,13 +410,15 @@ int ud_coldot_bn(const void* dy, const void* x, const ud_bn_ref* bn, int G, int 
 /* y[n][o] = sum_i (xsum[n][i] * xscale) W[o][i] + b[o]      (SE reduce conv on the pooled sums) */
 int ud_fc_fwd_d(const double* xsum, float xscale, const float* W, const float* b, float* y, int N, int I, int O,
                 ud_stream_t stream);
-/* y = act(bn(x)) * sigmoid(s[g][c])        (BN1 + swish + SE gate in one pass, model.py:114-122) */
+/* y = act(bn(x)) * sigmoid(s[g][c])        (BN1 + swish + SE gate in one pass, model.py:114-122)
+ * absmax (here and below; may be NULL): 256 caller-zeroed slots that receive |result|max as a side output — the scale of
+ * ud_split_planes_h2t without a pass of its own, for results that feed a 1x1 conv on ud_gemm_p3 */
 int ud_se_scale_bn(const void* x, const ud_bn_ref* bn, const float* s, void* y, int G, int R, int C, int f16,
-    ud_stream_t stream);
+    uint32_t* absmax, ud_stream_t stream);
 /* out = bn(x) * (keep[g] * inv_keep) + skip   (BN2 + drop_connect + residual, model.py:126-134; keep / skip may be
  * NULL; bn->running_* are updated here) */
 int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const void* skip,
-    void* out, int G, int R, int C, int f16, ud_stream_t stream);
+    void* out, int G, int R, int C, int f16, uint32_t* absmax, ud_stream_t stream);
 /* BatchNorm backward, reductions: dz = dy * (keep[g] * inv_keep) * act'(z)  (dy_is_dz: dz = dy);
  * s1[c] += sum dz, s2[c] += sum dz * xhat */
 int ud_normbwd_sums(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn, int
@@ -425,7 +427,7 @@ int ud_normbwd_sums(const void* x, const void* dy, const float* keep, float inv_
  * rank's sums -> dbeta / dgamma (NULL: not written) */
 int ud_normbwd_apply(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn, int
     dy_is_dz, const double* s1, const double* s2, const double* s1_local, const double* s2_local, int G, int R,
-    int C, void* dx, float* dgamma, float* dbeta, int f16, ud_stream_t stream);
+    int C, void* dx, float* dgamma, float* dbeta, int f16, uint32_t* absmax, ud_stream_t stream);
 /* SE backward, the two small FC layers (model.py:119-121) in two launches:
  *   a: dpre = dgate[n][c] * sigmoid'(s2);  ds1[n][i] = swish'(s1) sum_c dpre W_e[c][i];
  *      dW_e[c][i] = sum_n dpre swish(s1[n][i]);  db_e[c] = sum_n dpre
@@ -470,7 +472,7 @@ int ud_dwconv_bwd_weight_ex(const void* x, const void* dy, const float* gate_alp
  * gate_grad[0] = sigmoid'(alpha) * sum(gate_acc[0..64)), from the slots ud_normbwd_apply_mix filled just before. */
 int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
     void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad, int f16,
-    ud_stream_t stream);
+    uint32_t* absmax, ud_stream_t stream);
 /* irfft2 + SF mix + BN1 statistics (exp.py:60-65, stride 1):  freq = irfft2(Y) * scale;
  * y = (1 - a) spat + a freq, a = sigmoid(alpha[0]);  diff_out = freq - spat (what the backward needs of the two
  * branches: neither has to be kept);  sum[c] += sum y, sumsq[c] += sum y^2 */
@@ -486,7 +488,7 @@ int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, floa
 long ud_fft2_two_pass_ws_floats(int N, int S, int C);
 int ud_rfft2_two_pass(const void* x, void* Y, float* ws, int N, int S, int C, float scale, float w_interior,
     const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc,
-    float* gate_grad, int f16, ud_stream_t stream);
+    float* gate_grad, int f16, uint32_t* absmax, ud_stream_t stream);
 int ud_irfft2_two_pass(const void* Y, void* y, float* ws, int N, int S, int C, float scale, float w_interior,
     const void* spat, const float* alpha, void* freq_out, double* sum, double* sumsq, int f16, ud_stream_t stream);
 

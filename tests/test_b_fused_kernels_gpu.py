@@ -576,3 +576,66 @@ def test_tiled_depthwise_kernels_stride2(N, H, Cc, k, pad, half):
     assert _rel(da, da_ref) < tol
     dw = K.dwtile_bwd_weight(xg, dyg, k, pt, pl, bn=bn, stride=2)
     assert _rel(dw.view(Cc, k, k), wd.grad.view(Cc, k, k)) < (1e-3 if half else 2e-5)
+
+
+@pytest.mark.parametrize("two_pass", [False, True], ids=["one-kernel", "two-pass"])
+def test_producers_report_the_absmax_of_what_they_wrote(two_pass):
+    """The planes GEMM (ud_gemm_p3 prec 2) scales an operand by the power of two its largest magnitude asks for.  The kernels that
+    WRITE the operands (ud_se_scale_bn, ud_residual_bn, ud_normbwd_apply, ud_rfft2_ex / ud_rfft2_two_pass) leave that maximum in
+    256 slots as a side output, so ud_absmax need not read the tensor again: the slots' maximum must be max|out| to the bit, on
+    shapes whose last workgroups are partial, and split_planes given the slots must produce the planes it produces without."""
+    from unidefense_amd import kernels as K
+    from unidefense_amd.config import override
+    dev = _dev()
+    K.reset_zero_pool()
+
+    def check(out, what):
+        slots = out._ud_absmax
+        assert slots is not None and slots.numel() == 256, what
+        torch.cuda.synchronize()
+        assert slots.max().item() == out.abs().max().item(), what
+        o2 = out.reshape(-1, out.shape[-1])
+        if o2.shape[0] % 32 == 0:
+            a, b = K.split_planes(o2, prec=2, absmax=slots), K.split_planes(o2, prec=2)
+            torch.cuda.synchronize()
+            rows = lambda pl: pl.buf.view(2, pl.npanel, pl.panel // 32, 32)[:, :, :o2.shape[0]]     # (backing rows beyond R: unwritten)
+            assert torch.equal(rows(a), rows(b)) and torch.equal(a.inv, b.inv), what
+
+    with override(spectral_p2="on"):
+        for G, R, Cc in ((3, 1000, 40), (4, 256, 672), (2, 4096, 24)):
+            g, x, gamma, beta = _mk(G, R, Cc, 5 + Cc, dev)
+            x = x * 37.0
+            bn = _deferred(K, x, gamma, beta, 1e-3, 1)
+            s = torch.randn(G, Cc, generator=g).to(dev)
+            check(K.se_scale_bn(x, bn, s, G, R, want_absmax=True), "se_scale_bn")
+            assert getattr(K.se_scale_bn(x, bn, s, G, R), "_ud_absmax", None) is None
+            bn0 = _deferred(K, x, gamma, beta, 1e-3, 0)
+            keep = (torch.rand(G, generator=g) < 0.7).float().to(dev)
+            skip = torch.randn(G, R, Cc, generator=g).to(dev)
+            check(K.residual_bn(x, bn0, keep, 1.25, skip, G, R, want_absmax=True), "residual_bn + skip")
+            check(K.residual_bn(x, bn0, keep, 1.25, None, G, R, want_absmax=True), "residual_bn")
+            dy = torch.randn(G, R, Cc, generator=g).to(dev) * 1e-3
+            for act, b in ((1, bn), (0, bn0)):
+                sacc = K.zeros64(2 * Cc, x)
+                K.normbwd_sums(x, dy, keep, 1.25, b, False, G, R, sacc)
+                check(K.normbwd_apply(x, dy, keep, 1.25, b, False, G, R, sacc, want_absmax=True)[0], "normbwd_apply")
+        saved = K._FFT_TWO_PASS
+        K._FFT_TWO_PASS = two_pass
+        try:
+            for S, Cc, N in ((64, 144, 3), (32, 200, 2), (16, 40, 4), (8, 272, 5)):
+                g = torch.Generator().manual_seed(S + Cc)
+                x = torch.randn(N, S, S, Cc, generator=g).to(dev) * 11.0
+                gamma, beta = (1.0 + 0.2 * torch.randn(Cc, generator=g)).to(dev), (0.1 * torch.randn(Cc, generator=g)).to(dev)
+                alpha = torch.tensor(-0.3, device=dev)
+                bn = _deferred(K, x.view(N, S * S, Cc), gamma, beta, 1e-3, 1)
+                check(K.rfft2(x, 1.0 / S, 2.0, want_absmax=True), "rfft2")
+                check(K.rfft2_ex(x, 1.0 / S, 1.0, bn=bn, want_act=True, want_absmax=True)[0], "rfft2_ex bn")
+                slots = torch.randn(64, generator=g, dtype=torch.float64).to(dev)
+                check(K.rfft2_ex(x, 1.0 / S, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=slots, want_absmax=True)[0], "rfft2_ex gate")
+        finally:
+            K._FFT_TWO_PASS = saved
+    # half storage and the planes path switched off: no slots, the kernels run as before
+    with override(spectral_p2="off"):
+        g, x, gamma, beta = _mk(2, 256, 48, 7, dev)
+        bn = _deferred(K, x, gamma, beta, 1e-3, 1)
+        assert K.se_scale_bn(x, bn, torch.zeros(2, 48, device=dev), 2, 256, want_absmax=True)._ud_absmax is None

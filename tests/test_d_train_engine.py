@@ -108,8 +108,7 @@ def test_engine_with_prefetched_host_batches():
 def test_engine_fp16_precision_mode():
     """config.precision = "fp16" (BASELINE configs[4]): fp16-MFMA GEMMs + half storage of the MBConv trunk, under the
     engine's GradScaler, with the passes graph-captured from the second step on: finite losses, parameters move.  The GEMM
-    path is process-wide: only an fp16 engine sets it, an fp32 engine built afterwards leaves it alone (it must not switch
-    the arithmetic under an engine that still lives)."""
+    path is process-wide: building an engine leaves it alone, each engine selects its own on entry to train() / test()."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import copy
@@ -120,7 +119,7 @@ def test_engine_fp16_precision_mode():
     cfg["config"]["precision"] = "fp16"
     try:
         eng = get_engine("FE")(cfg, "Train")
-        assert lib.call("ud_gemm_get_path") == 3 and eng.model_without_ddp.half_storage is True
+        assert eng._gemm_path == 3 and eng.model_without_ddp.half_storage is True
         before = {k: v.detach().clone() for k, v in eng.model.named_parameters()}
         log = eng.train()
         assert log["step"] == 4 and all(torch.isfinite(torch.tensor(v)) for v in log.values()), log
@@ -130,7 +129,11 @@ def test_engine_fp16_precision_mode():
         bad["config"]["precision"] = "bf16"
         with pytest.raises(ValueError):
             get_engine("FE")(bad, "Train")
-        get_engine("FE")(copy.deepcopy(CONFIG), "Train")              # an fp32 engine does not touch the path
+        e32 = get_engine("FE")(copy.deepcopy(CONFIG), "Train")        # building an fp32 engine does not touch the path
+        assert lib.call("ud_gemm_get_path") == 3
+        e32.test(batches=1)
+        assert lib.call("ud_gemm_get_path") == 0                      # ... running it selects its own
+        eng.test(batches=1)
         assert lib.call("ud_gemm_get_path") == 3
     finally:
         lib.call("ud_gemm_set_path", 0)

@@ -42,11 +42,17 @@ def test_bench_line_contract():
     assert "workload" in line["config"] and line["config"]["exec"] == "hipgraph", err[-1500:]
     assert abs(line["value"] - 8 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]          # bs 8 in _bench
     r = line["roofline"]
-    # the split-bf16 kernel is priced against ITS pipe: peak = 2500 TFLOP/s dense BF16 / 6 MFMAs per fp32 product
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["peak"] - 2500.0 / 6) < 1e-9
+    # the matrix-pipe GEMM family is priced against ITS pipe: peak = 2500 TFLOP/s dense 16-bit / the MFMAs its launches execute
+    # per algorithmic fp32 product (3 on pre-split fp16 planes, 6 with the in-kernel bf16 split; the mix is the step's)
+    mpp = r["mfma_per_product"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 3.0 <= mpp <= 6.0 and abs(r["peak"] - 2500.0 / mpp) < 1e-9
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
-    assert abs(r["executed_mfma_tflops"] - 6 * r["achieved"]) < 1e-6 and r["pipe_peak"] == 2500.0
+    assert abs(r["executed_mfma_tflops"] - mpp * r["achieved"]) < 1e-6 and r["pipe_peak"] == 2500.0
     assert abs(r["frac_of_pipe"] - r["frac"]) < 1e-12 and abs(r["frac_fp32_equiv"] - r["achieved"] / 157.3) < 1e-9
+    assert abs(r["frac_six_product_equiv"] - 6 * r["achieved"] / 2500.0) < 1e-9
+    fams = r["families"]
+    assert set(fams) == {"gemm_p3_kernel<prec 2>", "gemm_x3_kernel"}
+    assert fams["gemm_p3_kernel<prec 2>"]["mfma_per_product"] == 3 and fams["gemm_x3_kernel"]["mfma_per_product"] == 6
     assert "traffic" in r and line["config"]["n_ranks_seen"] == 1
 
 

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
                                                    float scale, float w_int, ud_bn_ref bn, int has_bn,
                                                    T* __restrict__ act_out, const float* __restrict__ gate_alpha,
                                                    int gate_mode, const double* __restrict__ gate_acc,
-                                                   float* __restrict__ gate_grad, int xcd_remap) {
+                                                   float* __restrict__ gate_grad, int xcd_remap,
+                                                   uint32_t* __restrict__ amax) {
     using L = Lds<S, CB>;
     // EX, backward of the SF mix: the 64 slots a preceding kernel (ud_normbwd_apply_mix) filled with
     // sum dd * (freq - spat) become the gate's gradient here, by one wave, instead of a launch of their own
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
     }
     __syncthreads();
     // ---- pass 2: columns
+    float mabs = 0.f;
     if (q <= S / 2 && cok) {
 #pragma unroll
         for (int h = 0; h < S; ++h) {
@@ -280,8 +282,10 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
         for (int ky = 0; ky < S; ++ky) {
             dst[(long)ky * L::WH * 2 * C] = (T)(re[ky] * f);
             dst[(long)ky * L::WH * 2 * C + C] = (T)(im[ky] * f);
+            if (EX) mabs = fmaxf(mabs, fmaxf(fabsf(re[ky] * f), fabsf(im[ky] * f)));
         }
     }
+    if (EX) ud_absmax_commit(mabs, amax);
 }
 
 // x[n][h][w][c] = scale * C2R( f(kx) * Y[n][ky][kx][c] )   with the Hermitian extension along kx
@@ -414,6 +418,7 @@ struct RfftEx {
     int gate_mode;
     const double* gate_acc;
     float* gate_grad;
+    uint32_t* absmax;          // 256 slots: |Y|max as a side output (ud_absmax_commit), or NULL
 };
 
 template <typename T, int S, int CB, bool EX>
@@ -430,7 +435,7 @@ int launch_rfft2_t(const T* x, T* Y, int N, int C, float scale, float w_int, con
     ud_bn_ref none{};
     hipLaunchKernelGGL((rfft2_kernel<T, S, CB, EX>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
                        ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, (T*)ex.act_out, ex.gate_alpha, ex.gate_mode, ex.gate_acc,
-                       ex.gate_grad, xcd_remap_on(CB * (int)sizeof(T)));
+                       ex.gate_grad, xcd_remap_on(CB * (int)sizeof(T)), ex.absmax);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -438,7 +443,7 @@ int launch_rfft2_t(const T* x, T* Y, int N, int C, float scale, float w_int, con
 template <typename T, int S, int CB>
 int launch_rfft2(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
     if (ex) return launch_rfft2_t<T, S, CB, true>(x, Y, N, C, scale, w_int, *ex, s);
-    return launch_rfft2_t<T, S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr}, s);
+    return launch_rfft2_t<T, S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr}, s);
 }
 
 struct IrfftMix {
@@ -544,12 +549,17 @@ __global__ __launch_bounds__(NT2) void rows_fwd_kernel(const T* __restrict__ x, 
 
 template <typename T, int S, bool EX>
 __global__ __launch_bounds__(NT2) void cols_fwd_kernel(const float* __restrict__ Z, T* __restrict__ Y, int C, float scale,
-                                                       float w_int, const float* __restrict__ gate_alpha, int gate_mode) {
+                                                       float w_int, const float* __restrict__ gate_alpha, int gate_mode,
+                                                       uint32_t* __restrict__ amax) {
     constexpr int WH = S / 2 + 1;
     const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
     const int kx = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int n = blockIdx.z;
-    if (ch >= C || kx >= WH) return;
+    if (ch >= C || kx >= WH) {
+        ud_absmax_commit(0.f, amax);
+        return;
+    }
+    float mabs = 0.f;
     const float* src = Z + (((long)n * S) * WH + kx) * (2L * C) + ch;
     float re[S], im[S];
 #pragma unroll
@@ -568,7 +578,9 @@ __global__ __launch_bounds__(NT2) void cols_fwd_kernel(const float* __restrict__
     for (int ky = 0; ky < S; ++ky) {
         dst[(long)ky * WH * 2 * C] = (T)(re[ky] * f);
         dst[(long)ky * WH * 2 * C + C] = (T)(im[ky] * f);
+        mabs = fmaxf(mabs, fmaxf(fabsf(re[ky] * f), fabsf(im[ky] * f)));
     }
+    ud_absmax_commit(mabs, amax);
 }
 
 template <typename T, int S>
@@ -680,12 +692,12 @@ int rfft2_two_pass(const T* x, T* Y, float* Z, int N, int C, float scale, float 
         hipLaunchKernelGGL((rows_fwd_kernel<T, S, true>), gr, dim3(NT2), 0, s, x, Z, C, ex->bn ? *ex->bn : none,
                            ex->bn ? 1 : 0, (T*)ex->act_out, ex->gate_alpha, ex->gate_acc, ex->gate_grad);
         hipLaunchKernelGGL((cols_fwd_kernel<T, S, true>), gc, dim3(NT2), 0, s, Z, Y, C, scale, w_int, ex->gate_alpha,
-                           ex->gate_mode);
+                           ex->gate_mode, ex->absmax);
     } else {
         hipLaunchKernelGGL((rows_fwd_kernel<T, S, false>), gr, dim3(NT2), 0, s, x, Z, C, none, 0, (T*)nullptr,
                            (const float*)nullptr, (const double*)nullptr, (float*)nullptr);
         hipLaunchKernelGGL((cols_fwd_kernel<T, S, false>), gc, dim3(NT2), 0, s, Z, Y, C, scale, w_int,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, (uint32_t*)nullptr);
     }
     UD_LAUNCH_CHECK();
     return 0;
@@ -770,13 +782,13 @@ int ud_irfft2(const void* Y, void* x, int N, int S, int C, float scale, float w_
 
 int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
                 void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
-                int f16, ud_stream_t stream) {
+                int f16, uint32_t* absmax, ud_stream_t stream) {
     if (N < 1 || C < 1 || !x || !Y) return UD_EINVAL;
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
     if (bn && bn->G != 1) return UD_EINVAL;
     if (act_out && !bn) return UD_EINVAL;
     if (gate_grad && (!gate_acc || !gate_alpha)) return UD_EINVAL;
-    RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad};
+    RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad, absmax};
     UD_STORAGE_DISPATCH(f16, return rfft2_dispatch<T>((const T*)x, (T*)Y, N, S, C, scale, w_interior, &ex,
                                                       (hipStream_t)stream));
 }
@@ -798,14 +810,14 @@ long ud_fft2_two_pass_ws_floats(int N, int S, int C) {
 
 int ud_rfft2_two_pass(const void* x, void* Y, float* ws, int N, int S, int C, float scale, float w_interior,
                       const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc,
-                      float* gate_grad, int f16, ud_stream_t stream) {
+                      float* gate_grad, int f16, uint32_t* absmax, ud_stream_t stream) {
     if (N < 1 || C < 1 || !x || !Y || !ws || (S != 32 && S != 64)) return UD_EINVAL;
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
     if (bn && bn->G != 1) return UD_EINVAL;
     if (act_out && !bn) return UD_EINVAL;
     if (gate_grad && (!gate_acc || !gate_alpha)) return UD_EINVAL;
-    RfftEx exv{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad};
-    const RfftEx* ex = (bn || gate_mode != 0 || gate_grad) ? &exv : nullptr;
+    RfftEx exv{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad, absmax};
+    const RfftEx* ex = (bn || gate_mode != 0 || gate_grad || absmax) ? &exv : nullptr;
     hipStream_t s = (hipStream_t)stream;
     UD_STORAGE_DISPATCH(f16, if (S == 64) return rfft2_two_pass<T, 64>((const T*)x, (T*)Y, ws, N, C, scale, w_interior, ex, s);
                         return rfft2_two_pass<T, 32>((const T*)x, (T*)Y, ws, N, C, scale, w_interior, ex, s));

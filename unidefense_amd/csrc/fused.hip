@@ -140,37 +140,50 @@ __global__ __launch_bounds__(NT) void fc_fwd_d_kernel(const double* __restrict__
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void se_scale_bn_kernel(RedGeom q, const T* __restrict__ x, ud_bn_ref bn,
-                                                         const float* __restrict__ s, T* __restrict__ y) {
+                                                         const float* __restrict__ s, T* __restrict__ y,
+                                                         uint32_t* __restrict__ amax) {
     int ri, c4;
-    if (!thread_coords(q, ri, c4)) return;
-    const In4<T> x4{x};
-    const Out4<T> y4{y};
-    const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
-    f32x4 gate = reinterpret_cast<const f32x4*>(s)[(long)blockIdx.z * q.C4 + c4];
+    float m = 0.f;
+    if (thread_coords(q, ri, c4)) {
+        const In4<T> x4{x};
+        const Out4<T> y4{y};
+        const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
+        f32x4 gate = reinterpret_cast<const f32x4*>(s)[(long)blockIdx.z * q.C4 + c4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) gate[e] = ud_sigmoid_fast(gate[e]);
-    Rows w = rows_of(q, ri, c4);
+        for (int e = 0; e < 4; ++e) gate[e] = ud_sigmoid_fast(gate[e]);
+        Rows w = rows_of(q, ri, c4);
 #pragma unroll kRowUnroll<T>
-    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) y4.st(w.idx, bn_apply(x4[w.idx], cb, bn.act) * gate);
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+            const f32x4 v = bn_apply(x4[w.idx], cb, bn.act) * gate;
+            y4.st(w.idx, v);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+    ud_absmax_commit(m, amax);
 }
 
 template <typename T>
 __global__ __launch_bounds__(NT) void residual_bn_kernel(RedGeom q, const T* __restrict__ x, ud_bn_ref bn,
                                                          const float* __restrict__ keep, float inv_keep,
-                                                         const T* __restrict__ skip, T* __restrict__ out) {
+                                                         const T* __restrict__ skip, T* __restrict__ out,
+                                                         uint32_t* __restrict__ amax) {
     int ri, c4;
-    if (!thread_coords(q, ri, c4)) return;
-    const In4<T> x4{x}, k4{skip};
-    const Out4<T> o4{out};
-    const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, is_updater(ri));
-    const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
-    Rows w = rows_of(q, ri, c4);
+    float m = 0.f;
+    if (thread_coords(q, ri, c4)) {
+        const In4<T> x4{x}, k4{skip};
+        const Out4<T> o4{out};
+        const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, is_updater(ri));
+        const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
+        Rows w = rows_of(q, ri, c4);
 #pragma unroll kRowUnroll<T>
-    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
-        f32x4 v = bn_apply(x4[w.idx], cb, bn.act) * sc;
-        if (skip) v += k4[w.idx];
-        o4.st(w.idx, v);
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+            f32x4 v = bn_apply(x4[w.idx], cb, bn.act) * sc;
+            if (skip) v += k4[w.idx];
+            o4.st(w.idx, v);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
     }
+    ud_absmax_commit(m, amax);
 }
 
 // y = act(bn(x)): the materialised form, for consumers that re-read their input many times (plain depthwise convs
@@ -242,12 +255,14 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
                                                            const double* __restrict__ s1l, const double* __restrict__ s2l,
                                                            const T* __restrict__ freq,
                                                            T* __restrict__ dx, double* __restrict__ dalpha_acc,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           uint32_t* __restrict__ amax) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
     const In4<T> x4{x}, d4{dy}, fr4{freq};
     const Out4<T> o4{dx};
     double acc = 0.0;
+    float mo = 0.f;
     if (active) {
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
         const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
@@ -272,6 +287,7 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = cb.ga[e] * cb.is[e] * (dz[e] - t1[e] - xh[e] * t2[e]);
             o4.st(w.idx, o);
+            mo = fmaxf(mo, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
             if (MIX) {
                 f32x4 f = fr4[w.idx];                    // freq - spat (ud_irfft2_mix)
 #pragma unroll
@@ -291,6 +307,7 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
             atomic_add_f64(dalpha_acc + ((blockIdx.x + 7 * blockIdx.y + 13 * blockIdx.z) & 63), tot);
         }
     }
+    ud_absmax_commit(mo, amax);
 }
 
 __global__ void gate_grad_from_acc_kernel(const double* __restrict__ acc, const float* __restrict__ alpha,
@@ -772,21 +789,21 @@ int ud_bn_apply(const void* x, const ud_bn_ref* bn, void* y, int G, int R, int C
 }
 
 int ud_se_scale_bn(const void* x, const ud_bn_ref* bn, const float* s, void* y, int G, int R, int C, int f16,
-                   ud_stream_t stream) {
+                   uint32_t* absmax, ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !bn || !s || !y) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(se_scale_bn_kernel<T>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
-                                                (const T*)x, *bn, s, (T*)y));
+                                                (const T*)x, *bn, s, (T*)y, absmax));
     UD_LAUNCH_CHECK();
     return 0;
 }
 
 int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const void* skip,
-                   void* out, int G, int R, int C, int f16, ud_stream_t stream) {
+                   void* out, int G, int R, int C, int f16, uint32_t* absmax, ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !bn || !out) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(residual_bn_kernel<T>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
-                                                (const T*)x, *bn, keep, inv_keep, (const T*)skip, (T*)out));
+                                                (const T*)x, *bn, keep, inv_keep, (const T*)skip, (T*)out, absmax));
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -807,14 +824,14 @@ int ud_normbwd_sums(const void* x, const void* dy, const float* keep, float inv_
 int ud_normbwd_apply(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
                      int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
                      const double* s2_local, int G, int R, int C, void* dx, float* dgamma, float* dbeta, int f16,
-                     ud_stream_t stream) {
+                     uint32_t* absmax, ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !dy || !bn || !s1 || !s2 || !dx || bn->G != 1) return UD_EINVAL;
     if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, false>), red_grid(q), dim3(NT), 0,
                                                 (hipStream_t)stream, q, (const T*)x, (const T*)dy, keep, inv_keep, *bn,
                                                 dy_is_dz, s1, s2, s1_local, s2_local, (const T*)nullptr, (T*)dx,
-                                                (double*)nullptr, dgamma, dbeta));
+                                                (double*)nullptr, dgamma, dbeta, absmax));
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -829,7 +846,7 @@ int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, con
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, true>), red_grid(q), dim3(NT), 0,
                                                 (hipStream_t)stream, q, (const T*)x, (const T*)dz, (const float*)nullptr,
                                                 1.f, *bn, 1, s1, s2, s1_local, s2_local, (const T*)diff, (T*)dd,
-                                                dalpha_acc, dgamma, dbeta));
+                                                dalpha_acc, dgamma, dbeta, (uint32_t*)nullptr));
     UD_LAUNCH_CHECK();
     return 0;
 }

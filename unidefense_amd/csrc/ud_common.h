@@ -107,3 +107,21 @@ __device__ __forceinline__ float ud_wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Tensor |x|max as a SIDE OUTPUT of the kernel that produces the tensor (the scale of ud_split_planes_h2t): every thread of the
+// workgroup calls this once with the largest |value| it stored (0 if none; `slots` uniform, NULL = not wanted): wave maximum,
+// workgroup maximum through LDS, ONE atomic maximum per workgroup onto one of the 256 slots (bit patterns of non-negative
+// floats order like unsigned integers).  The caller zeroes the slots.
+__device__ __forceinline__ void ud_absmax_commit(float m, uint32_t* __restrict__ slots) {
+    if (!slots) return;
+    __shared__ unsigned ud_sm_absmax;
+    if (threadIdx.x == 0 && threadIdx.y == 0) ud_sm_absmax = 0u;
+    __syncthreads();
+    unsigned bits = __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));          // (inactive lanes read as 0 or own)
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(&ud_sm_absmax, bits);
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0 && ud_sm_absmax)
+        atomicMax(slots + ((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & 255u), ud_sm_absmax);
+}

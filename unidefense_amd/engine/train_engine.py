@@ -73,12 +73,11 @@ class TrainEngine(AbstractEngine):
         self.precision = str(cfg.get("precision", "fp32")).lower()
         if self.precision not in ("fp32", "fp16"):
             raise ValueError(f"config.precision must be 'fp32' or 'fp16', got {self.precision!r}")
-        # The GEMM path is process-wide state of the library: an fp16 engine selects the fp16-MFMA kernel (3), an fp32 engine
-        # the path the process started with (UD_GEMM_PATH, default 0) — and each re-asserts its own at the start of every
-        # train() / validate(), so an fp32 engine built after an fp16 one (an A/B run, a notebook) does not inherit path 3.
-        from .. import lib as _lib
+        # The GEMM path is process-wide state of the library: an fp16 engine wants the fp16-MFMA kernel (3), an fp32 engine the
+        # path the process started with (UD_GEMM_PATH, default 0).  Building an engine does not touch it (an engine that still
+        # lives keeps its arithmetic); each engine selects its own on entry to train() / test() / validate(), so two engines
+        # of different precision in one process (an A/B run, a notebook) each compute in theirs.
         self._gemm_path = 3 if self.precision == "fp16" else int(os.environ.get("UD_GEMM_PATH", "0") or 0)
-        _lib.call("ud_gemm_set_path", self._gemm_path)
         if self.precision == "fp16":
             self.model.half_storage = True
         self.model_without_ddp = self.model
@@ -147,14 +146,14 @@ class TrainEngine(AbstractEngine):
             t /= dist.get_world_size()
         return t.tolist()
 
-    def _assert_gemm_path(self):
+    def _select_gemm_path(self):
         from .. import lib as _lib
         if _lib.call("ud_gemm_get_path") != self._gemm_path:
             _lib.call("ud_gemm_set_path", self._gemm_path)
 
     def train(self):
         try:
-            self._assert_gemm_path()
+            self._select_gemm_path()
             grad_scalar = torch.amp.GradScaler("cuda", init_scale=2 ** 10)        # forgery_engine.py:228
             sums, count, correct, seen, last = {}, 0, 0, 0, {}
             for cur_step in range(1, self.num_steps + 1):
@@ -219,7 +218,7 @@ class TrainEngine(AbstractEngine):
         """The reference's test stage (forgery_engine.py:423-452): scores -> cal_metrics (EER, HTER = ACER, TPR@5 %, AUC,
         ACC, ...) over the frames of all ranks."""
         from .metrics import cal_metrics
-        self._assert_gemm_path()
+        self._select_gemm_path()
         scores, labels = self._score(batches)
         sc, lb = scores.float().cpu().numpy(), labels.cpu().numpy()
         ret = {"scores": scores.cpu(), "labels": labels.cpu(), "acc": float(((sc < 0.5).astype(int) == lb).mean())}

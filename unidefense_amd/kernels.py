@@ -225,7 +225,15 @@ class Planes:
         self.inv = torch.empty(R if per_row else 1, dtype=torch.float32, device=like.device) if prec == 2 else None
 
 
-def split_planes(x2, out=None, prec=3, per_row=False):
+def amax_slots(like, want=True):
+    """256 zeroed words for a producer kernel's |result|max side output (ud_absmax_commit; the scale of the tensor's planes
+    without a pass of its own), or None where the planes path cannot take the tensor"""
+    if not want or CFG.spectral_p2 == "off" or like.dtype != torch.float32:
+        return None
+    return zeros((256,), like)
+
+
+def split_planes(x2, out=None, prec=3, per_row=False, absmax=None):
     """fp32 [R, C] (row stride >= C) -> Planes: prec 3 the exact three-way bf16 split of gemm_x3.hip, prec 2 two fp16 pieces of
     the scaled matrix — done once by the producer instead of by every workgroup that loads a tile."""
     _chk(x2)
@@ -238,8 +246,10 @@ def split_planes(x2, out=None, prec=3, per_row=False):
     elif pl.scale_stride:
         _call("ud_split_planes_h2", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _p(pl.inv), _stream())
     else:
-        amax = empty((256,), x2)                    # partial maxima (ud_absmax writes every slot)
-        _call("ud_absmax", _p(x2), R, Cc, x2.stride(0), _p(amax), _stream())
+        amax = absmax                               # 256 partial maxima: the producer's side output, or a pass of our own
+        if amax is None:
+            amax = empty((256,), x2)
+            _call("ud_absmax", _p(x2), R, Cc, x2.stride(0), _p(amax), _stream())
         _call("ud_split_planes_h2t", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, pl.plane, _p(amax), _p(pl.inv),
               _stream())
     return pl
@@ -696,7 +706,7 @@ def _p2_block_plans(x2, w2, want_stats=False):
     return {"nt": tuple(plans[0]), "nn": tuple(plans[1]), "tn": tuple(plans[2])}
 
 
-def spectral_fwd(x2, w2, stats=None):
+def spectral_fwd(x2, w2, stats=None, x_absmax=None):
     """y[M, N] = x[M, K] @ w[N, K]^T (a 1x1 conv; the spectral convs are the square case) and the context of its backward.
     stats: BatchNorm accumulator of the result (gemm_nt's contract: returns ((y, done), ctx))"""
     ctx = SpectralCtx()
@@ -707,28 +717,28 @@ def spectral_fwd(x2, w2, stats=None):
     if ctx.plans is None:
         ctx.x, ctx.w = x2, w2
         return gemm_nt(x2, w2, stats=stats), ctx
-    ctx.x, ctx.w = split_planes(x2, prec=2), split_planes(w2, prec=2)
+    ctx.x, ctx.w = split_planes(x2, prec=2, absmax=x_absmax), split_planes(w2, prec=2)
     return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, x2, stats=stats), ctx
 
 
-def _spectral_dy(ctx, dy2):
+def _spectral_dy(ctx, dy2, absmax=None):
     if ctx.dy is None:
-        ctx.dy = split_planes(dy2, prec=2)
+        ctx.dy = split_planes(dy2, prec=2, absmax=absmax)
     return ctx.dy
 
 
-def spectral_dgrad(ctx, dy2, out=None):
+def spectral_dgrad(ctx, dy2, out=None, dy_absmax=None):
     """dx[M, K] = dy[M, N] @ w[N, K]   (out: a term of the same gradient to add onto, in place)"""
     if ctx.plans is None:
         return gemm_nn(dy2, ctx.w, out=out, accumulate=out is not None)
-    return _p2_run("nn", ctx.plans["nn"], _spectral_dy(ctx, dy2), ctx.w, ctx.M, ctx.K, ctx.N, dy2, out=out)
+    return _p2_run("nn", ctx.plans["nn"], _spectral_dy(ctx, dy2, dy_absmax), ctx.w, ctx.M, ctx.K, ctx.N, dy2, out=out)
 
 
-def spectral_wgrad(ctx, dy2):
+def spectral_wgrad(ctx, dy2, dy_absmax=None):
     """dw[N, K] = dy[M, N]^T @ x[M, K]"""
     if ctx.plans is None:
         return gemm_tn(dy2, ctx.x)
-    return _p2_run("tn", ctx.plans["tn"], _spectral_dy(ctx, dy2), ctx.x, ctx.N, ctx.K, ctx.M, dy2)
+    return _p2_run("tn", ctx.plans["tn"], _spectral_dy(ctx, dy2, dy_absmax), ctx.x, ctx.N, ctx.K, ctx.M, dy2)
 
 
 def _p2_tune(key, x2, w2, M, N, Kd, forced, want_stats=False):
@@ -1153,15 +1163,17 @@ def _fft_ws(N, S, Cc, like):
     return empty((N, S, S // 2 + 1, 2 * Cc), like, torch.float32)
 
 
-def rfft2(x, scale, w_interior=1.0):
-    """x[N,S,S,C] -> Y[N,S,S/2+1,2C] (Re | Im channel halves)."""
+def rfft2(x, scale, w_interior=1.0, want_absmax=False):
+    """x[N,S,S,C] -> Y[N,S,S/2+1,2C] (Re | Im channel halves).  want_absmax: Y._ud_absmax = 256 slots of |Y|max."""
+    if want_absmax and amax_slots(x) is not None:
+        return rfft2_ex(x, scale, w_interior, want_absmax=True)[0]
     h = _act(x)
     N, S, S2, Cc = x.shape
     assert S == S2
     Y = empty((N, S, S // 2 + 1, 2 * Cc), x, x.dtype)
     if _fft_two_pass("rfft", S, h):
         _call("ud_rfft2_two_pass", _p(x), _p(Y), _p(_fft_ws(N, S, Cc, x)), N, S, Cc, scale, w_interior, None, None, None, 0,
-              None, None, h, _stream())
+              None, None, h, None, _stream())
         return Y
     _call("ud_rfft2", _p(x), _p(Y), N, S, Cc, scale, w_interior, h, _stream())
     return Y
@@ -1719,20 +1731,24 @@ def bn_apply(x, bn, G, R, update=False):
     return y
 
 
-def se_scale_bn(x, bn, s, G, R):
+def se_scale_bn(x, bn, s, G, R, want_absmax=False):
     h = _act(x)
     _chk(s)
     y = torch.empty_like(x)
-    _call("ud_se_scale_bn", _p(x), C.byref(bn.ref()), _p(s), _p(y), G, R, x.shape[-1], h, _stream())
+    amax = amax_slots(x, want_absmax)
+    _call("ud_se_scale_bn", _p(x), C.byref(bn.ref()), _p(s), _p(y), G, R, x.shape[-1], h, _p(amax), _stream())
+    y._ud_absmax = amax
     return y
 
 
-def residual_bn(x, bn, keep, inv_keep, skip, G, R, update=False):
+def residual_bn(x, bn, keep, inv_keep, skip, G, R, update=False, want_absmax=False):
     h = _act(x, skip)
     _chk(keep)
     out = torch.empty_like(x)
+    amax = amax_slots(x, want_absmax)
     _call("ud_residual_bn", _p(x), C.byref(bn.ref(update)), _p(keep), float(inv_keep), _p(skip), _p(out), G, R,
-          x.shape[-1], h, _stream())
+          x.shape[-1], h, _p(amax), _stream())
+    out._ud_absmax = amax
     return out
 
 
@@ -1745,7 +1761,7 @@ def normbwd_sums(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc):
           _pd(sacc), _pd(sacc, Cc), _fused_ws(x, G, R, Cc, False), h, _stream())
 
 
-def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=None, want_dbeta=True):
+def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=None, want_dbeta=True, want_absmax=False):
     """Returns (dx, dgamma, dbeta).  sacc: sums over all ranks; sacc_local: this rank's (default: the same)."""
     h = _act(x, dy)
     _chk(keep)
@@ -1754,8 +1770,10 @@ def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=No
     dx = torch.empty_like(x)
     dg = empty((Cc,), x)
     db = empty((Cc,), x) if want_dbeta else None
+    amax = amax_slots(x, want_absmax)
     _call("ud_normbwd_apply", _p(x), _p(dy), _p(keep), float(inv_keep), C.byref(bn.ref()), int(dy_is_dz), _pd(sacc),
-          _pd(sacc, Cc), _pd(loc), _pd(loc, Cc), G, R, Cc, _p(dx), _p(dg), _p(db), h, _stream())
+          _pd(sacc, Cc), _pd(loc), _pd(loc, Cc), G, R, Cc, _p(dx), _p(dg), _p(db), h, _p(amax), _stream())
+    dx._ud_absmax = amax
     return dx, dg, db
 
 
@@ -1843,7 +1861,7 @@ def dwconv_bwd_weight_ex(x, dy, gate_alpha, gate_mode, K, stride, pad_t, pad_l):
 
 
 def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None, gate_mode=0, update=False,
-             gate_acc=None):
+             gate_acc=None, want_absmax=False):
     """rfft2 of act(bn(x)) (bn optional) [* gate].  Returns (Y, activated input or None[, gate gradient when gate_acc:
     sigmoid'(alpha) * sum of the 64 accumulator slots])."""
     h = _act(x)
@@ -1852,8 +1870,10 @@ def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None,
     Y = empty((N, S, S // 2 + 1, 2 * Cc), x, x.dtype)
     act = torch.empty_like(x) if (want_act and bn is not None) else None
     ggrad = empty((), x) if gate_acc is not None else None
+    amax = amax_slots(x, want_absmax)
+    Y._ud_absmax = amax
     tail = (C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode),
-            _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), h, _stream())
+            _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), h, _p(amax), _stream())
     if _fft_two_pass("rfft_ex", S, h):
         _call("ud_rfft2_two_pass", _p(x), _p(Y), _p(_fft_ws(N, S, Cc, x)), N, S, Cc, float(scale), float(w_interior), *tail)
     else:

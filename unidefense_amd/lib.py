@@ -130,10 +130,10 @@ _SIGNATURES = {
     "ud_colsum_bn": [_P, _BN, _I, _I, _I, _P, _P, _I, _P],
     "ud_coldot_bn": [_P, _P, _BN, _I, _I, _I, _P, _P, _I, _P],
     "ud_fc_fwd_d": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
-    "ud_se_scale_bn": [_P, _BN, _P, _P, _I, _I, _I, _I, _P],
-    "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P],
+    "ud_se_scale_bn": [_P, _BN, _P, _P, _I, _I, _I, _I, _P, _P],
+    "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P],
     "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _I, _P],
-    "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
+    "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "ud_gate_grad_from_acc": [_P, _P, _P, _P],
     "ud_se_bwd_a": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
@@ -144,9 +144,9 @@ _SIGNATURES = {
     "ud_dwconv_bwd_data_bn_ws_doubles": [_I, _I, _I, _I, _I],
     "ud_dwconv_bwd_data_ex": [_P, _P, _I, _P, _P, _P] + [_I] * 10 + [_I, _P],
     "ud_dwconv_bwd_weight_ex": [_P, _P, _P, _I, _P, _P, _I] + [_I] * 10 + [_I, _P],
-    "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P],
+    "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P, _P],
     "ud_irfft2_mix": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
-    "ud_rfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P],
+    "ud_rfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P, _P],
     "ud_irfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "ud_fft2_two_pass_ws_floats": [_I, _I, _I],
     "ud_dwtile_ws_doubles": [_I, _I, _I, _I],

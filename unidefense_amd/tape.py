@@ -893,7 +893,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         We = blk._expand_conv.weight.view(Ce, Cin)
         x2 = x.view(M, Cin)
         acc0 = K.zeros64(2 * Ce, x)
-        (e, done), ectx = K.spectral_fwd(x2, We, stats=acc0)          # BN0 statistics in the GEMM epilogue where the launch is plain
+        (e, done), ectx = K.spectral_fwd(x2, We, stats=acc0, x_absmax=getattr(x, "_ud_absmax", None))          # BN0 statistics in the GEMM epilogue where the launch is plain
         if not done:
             K.colstats(e, acc0)
         e = e.view(N, H, W, Ce)
@@ -914,15 +914,15 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         t_fwd, t_wg, t_bwd = _dw_tile_policy(True, k, stride, H, x.dtype == torch.float16)
         if src_bn is not None:
             # a strip kernel needs a = swish(bn0(e)) materialised (rfft2_ex writes it); the tiled ones apply it on load
-            xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=not (t_fwd and t_wg), update=True)
+            xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=not (t_fwd and t_wg), update=True, want_absmax=True)
         else:
-            xf, a = K.rfft2(src, s_f, 1.0), src
+            xf, a = K.rfft2(src, s_f, 1.0, want_absmax=True), src
         if t_fwd:
             spat = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn, stride=stride)
         else:
             spat = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
         Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
-        yf, sctx = K.spectral_fwd(xf.view(-1, 2 * Ce), Wf)
+        yf, sctx = K.spectral_fwd(xf.view(-1, 2 * Ce), Wf, x_absmax=getattr(xf, "_ud_absmax", None))
         yf = yf.view(xf.shape)
         xf_shape, xf = xf.shape, None          # the context holds what the backward needs of it
         if stride == 1:
@@ -955,19 +955,19 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
     K.colsum_bn(d, bn1, N, HWo, pool, update=True)
     s1 = K.fc_fwd_d(pool, 1.0 / HWo, wr2, blk._se_reduce.bias, N)
     s2 = K.fc_fwd(s1, we2, blk._se_expand.bias, 1)
-    c = K.se_scale_bn(d, bn1, s2, N, HWo)
+    c = K.se_scale_bn(d, bn1, s2, N, HWo, want_absmax=True)
 
     # ---- project + BN2 + drop-connect + skip
     Wp = blk._project_conv.weight.view(Co, Ce)
     c2 = c.view(Mo, Ce)
     acc2 = K.zeros64(2 * Co, x)
-    (p, done), pctx = K.spectral_fwd(c2, Wp, stats=acc2)
+    (p, done), pctx = K.spectral_fwd(c2, Wp, stats=acc2, x_absmax=getattr(c, "_ud_absmax", None))
     if not done:
         K.colstats(p, acc2)
     dp.reduce(acc2)
     bn2 = _bn_of(blk._bn2, acc2, Mo * dp.world, 0)
     p4 = p.view(N, Ho, Wo, Co)
-    out = K.residual_bn(p4, bn2, keep, inv_keep, x if sp.skip else None, N, HWo, update=True)
+    out = K.residual_bn(p4, bn2, keep, inv_keep, x if sp.skip else None, N, HWo, update=True, want_absmax=True)
     if not _needs(tape):
         return out
 
@@ -981,12 +981,13 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         sb2 = K.zeros64(2 * Co, x)
         K.normbwd_sums(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2)
         loc2 = dp.reduce(sb2, keep_local=True)
-        dp_, dg2, db2 = K.normbwd_apply(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2, loc2)
+        dp_, dg2, db2 = K.normbwd_apply(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2, loc2, want_absmax=True)
+        dp_amax = getattr(dp_, "_ud_absmax", None)
         tape.add_param_grad(blk._bn2.weight, dg2)
         tape.add_param_grad(blk._bn2.bias, db2)
         dp2 = dp_.view(Mo, Co)
-        tape.wgrad(blk._project_conv.weight, lambda: K.spectral_wgrad(pctx, dp2), dp2)
-        dc = K.spectral_dgrad(pctx, dp2).view(N, Ho, Wo, Ce)
+        tape.wgrad(blk._project_conv.weight, lambda: K.spectral_wgrad(pctx, dp2, dp_amax), dp2)
+        dc = K.spectral_dgrad(pctx, dp2, dy_absmax=dp_amax).view(N, Ho, Wo, Ce)
         # ---- squeeze-excite backward
         dgate = K.zeros64(N * Ce, x)
         K.coldot_bn(dc, d, bn1, N, HWo, dgate)
@@ -1005,17 +1006,17 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 dacc = K.zeros64(64, x)
                 dd, dg1, db1 = K.normbwd_apply_mix(d, dz1, bn1, N, HWo, sb1, fr, dacc, loc1)
                 # adjoint of irfft2, x sigmoid(a); the same launch turns the accumulator slots into the gate's gradient
-                dyf, _, dalpha = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc)
+                dyf, _, dalpha = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc, want_absmax=True)
                 tape.add_param_grad(alpha, dalpha)
                 g_sp, g_alpha, g_mode = dd, alpha, 2                                   # spatial branch: x (1 - sigmoid(a))
             else:
                 dd, dg1, db1 = K.normbwd_apply(d, dz1, None, 1.0, bn1, True, N, HWo, sb1, loc1)
                 g_sp, dfr, dalpha = K.sfmix_bwd(spat, fr, alpha, dd, True)
                 tape.add_param_grad(alpha, dalpha)
-                dyf = K.rfft2(dfr, s_i, 2.0)
-            dyf2 = dyf.view(-1, 2 * Ce)
-            tape.wgrad(dwm.freq_conv.weight, lambda: K.spectral_wgrad(sctx, dyf2), dyf2)
-            dxf = K.spectral_dgrad(sctx, dyf2).view(xf_shape)
+                dyf = K.rfft2(dfr, s_i, 2.0, want_absmax=True)
+            dyf2, dyf_amax = dyf.view(-1, 2 * Ce), getattr(dyf, "_ud_absmax", None)
+            tape.wgrad(dwm.freq_conv.weight, lambda: K.spectral_wgrad(sctx, dyf2, dyf_amax), dyf2)
+            dxf = K.spectral_dgrad(sctx, dyf2, dy_absmax=dyf_amax).view(xf_shape)
             da_f = K.irfft2(dxf, s_f, 0.5)                                             # adjoint of rfft2
         else:
             dd, dg1, db1 = K.normbwd_apply(d, dz1, None, 1.0, bn1, True, N, HWo, sb1, loc1)
@@ -1044,15 +1045,16 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 lazy_in.backward(dz0, sb0, is_dz)
                 return
             loc0 = dp.reduce(sb0, keep_local=True)
-            de, dg0, db0 = K.normbwd_apply(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0)
+            de, dg0, db0 = K.normbwd_apply(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0, want_absmax=True)
+            de_amax = getattr(de, "_ud_absmax", None)
             tape.add_param_grad(blk._bn0.weight, dg0)
             tape.add_param_grad(blk._bn0.bias, db0)
             de2 = de.view(M, Ce)
-            tape.wgrad(blk._expand_conv.weight, lambda: K.spectral_wgrad(ectx, de2), de2)
+            tape.wgrad(blk._expand_conv.weight, lambda: K.spectral_wgrad(ectx, de2, de_amax), de2)
             if sp.skip and tape.watch is None and getattr(dout, "_ud_owned", False):
-                dx = K.spectral_dgrad(ectx, de2, out=dout.view(M, Cin)).view(x.shape)    # + skip gradient
+                dx = K.spectral_dgrad(ectx, de2, out=dout.view(M, Cin), dy_absmax=de_amax).view(x.shape)    # + skip gradient
             else:
-                dx = K.spectral_dgrad(ectx, de2).view(x.shape)
+                dx = K.spectral_dgrad(ectx, de2, dy_absmax=de_amax).view(x.shape)
                 if sp.skip:
                     dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
         else:
