@@ -127,7 +127,9 @@ int ud_gemm_query_path(const ud_gemm_desc* d);
  * (a_mode, b_mode): prec 3 any; prec 2 (0,0) (0,1) (1,1).  K % 32 == 0.  *_npanel: panels reachable from the pointer (mode 1 clamps
  * its tile to them).  out_mode / split_k / slice_stride / stat_sum / stat_sumsq as in ud_gemm_desc (statistics: out_mode 0,
  * split_k 1; one slot array [N] while M <= 64 * 128, else 64 slots).
- * tile_cfg bit 8: each XCD takes a contiguous range of the tile order; bit 11 (0x800): stream-K — one workgroup per CU, the
+ * tile_cfg bit 8: each XCD takes a contiguous range of the tile order; bit 9 (0x200): XCD-aware grouped raster — XCD x takes a
+ * contiguous range of an order that walks groups of GM = bits 12-15 (0: 4) tile rows column by column, so the workgroups of one L2
+ * share GM A panels and 32 / GM B panels; bit 11 (0x800): stream-K — one workgroup per CU, the
  * (tile, K-tile) units dealt evenly; out_mode 0 (C zeroed by the caller: whole-tile segments store, partial ones add
  * atomically) or 1 (C holds a term to add to); split_k 1, no statistics. */
 typedef struct {

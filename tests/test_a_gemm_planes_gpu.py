@@ -196,3 +196,32 @@ def test_row_offsets_tail_plan_and_epilogue_statistics():
             got = K._p2_run(kind, plan, pa, pb, m, n, k, x)
             torch.cuda.synchronize()
             assert ((got - ref).abs().max() / ref.abs().max()).item() < 5e-6, (kind, plan)
+
+
+@pytest.mark.parametrize("kind,M,N,Kd", [("nt", 128 * 11 + 40, 128 * 5, 96), ("tn", 128 * 7, 128 * 9 + 8, 512), ("nn", 128 * 3, 128 * 2, 64)])
+def test_xcd_raster_is_a_permutation_of_the_tiles(kind, M, N, Kd):
+    """tile_cfg bit 9 only changes WHICH workgroup computes which tile (groups of GM tile rows, one contiguous range per XCD):
+    every tile still computed exactly once — the result is bitwise the round-robin deal's, for tile counts that are not
+    multiples of 8 or of GM, plain and split-K (ordered slices), statistics included."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(6)
+    a, b, am, bm = _operands(kind, M, N, Kd, dev)
+    ap, bp = K.split_planes(a, prec=2), K.split_planes(b, prec=2)
+    saved = K._P3_RASTER
+    try:
+        outs = []
+        for ras in (0,) + tuple(0x200 | gm << 12 for gm in (1, 2, 3, 4, 7, 8, 15)):
+            K._P3_RASTER = ras
+            o = torch.full((M, N), float("nan"), device=dev)
+            acc = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+            K._gemm_p3(ap, bp, o, M, N, Kd, am, bm, stats=acc if kind == "nt" else None)
+            s = K.split_out((M, N), a)
+            K._gemm_p3(ap, bp, s, M, N, Kd, am, bm, 2, 2)
+            torch.cuda.synchronize()
+            outs.append((o, s.clone(), acc))
+        for o, s, acc in outs[1:]:
+            assert torch.equal(o, outs[0][0]) and (s - outs[0][1]).abs().max().item() <= 1e-5 * outs[0][1].abs().max().item()
+            assert ((acc - outs[0][2]).abs().max() <= 1e-12 * outs[0][2].abs().max().clamp_min(1e-300)).item()
+    finally:
+        K._P3_RASTER = saved

@@ -1,16 +1,15 @@
 #!/bin/bash
-# Per-dispatch kernel trace of a few graph-replayed bench steps (rocprofv3 --kernel-trace): tools/trace_timeline.py
-# turns one replay into a timeline (start, gap, duration, workgroups, kernel).  Output: gpurun_out/$1/
-tag=${1:-trace}
+# kernel timeline of the bench (hipGraph replays): union / overlap / idle accounting.  usage: tools/gpu_trace.sh <tag> [bench args]
+tag=${1:-tr}; shift
 out=gpurun_out/$tag
 mkdir -p $out
 export PYTHONDONTWRITEBYTECODE=1
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $out/bench.log 2>&1
-echo "rocprof exit $?"; tail -2 $out/bench.log | cut -c1-400
+rocprofv3 --kernel-trace --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra "$@" > $out/bench.log 2>&1
+echo "rocprof exit $?"
+ms=$(python3 -c "import json;print([json.loads(l) for l in open('$out/bench.log') if l.startswith('{')][-1]['ms_per_step'])")
 f=$(find $out/prof -name "*kernel_trace.csv" | head -1)
-[ -n "$f" ] && mv "$f" $out/kernel_trace.csv && gzip -f $out/kernel_trace.csv
-f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" $out/kernel_stats.csv
-ls -la $out
+head -2 $f | cut -c1-400
+python3 tools/trace_overlap.py $f 10 $ms | tee $out/overlap.txt
+rm -rf $out/prof

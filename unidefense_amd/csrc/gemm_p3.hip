@@ -441,11 +441,24 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
             const int Tn = tiles_m * tiles_n, q = Tn >> 3, r = Tn & 7, x = bt & 7;
             bt = x * q + (x < r ? x : r) + (bt >> 3);
         }
+        int tile_m = bt % tiles_m, tile_n = bt / tiles_m;
+        if (d.tile_cfg & 0x200) {
+            // XCD-aware raster: XCD x (= blockIdx % 8, its own L2) takes a CONTIGUOUS range of an order that walks groups of GM
+            // tile rows column by column, so the ~32 workgroups it runs at a time cover a GM x (32 / GM) block of tiles — they
+            // step through K together and share GM A panels + 32 / GM B panels in that L2 instead of ~9 + 8 of the round-robin deal
+            const int GM = (d.tile_cfg >> 12) & 15 ? (d.tile_cfg >> 12) & 15 : 4;
+            const int Tn = tiles_m * tiles_n, q = Tn >> 3, r = Tn & 7, x = blockIdx.x & 7;
+            const int o = x * q + (x < r ? x : r) + ((int)blockIdx.x >> 3);
+            const int per_group = GM * tiles_n, g = o / per_group, first_m = g * GM;
+            const int gm = min(GM, tiles_m - first_m), in = o - g * per_group;
+            tile_n = in / gm;
+            tile_m = first_m + in - tile_n * gm;
+        }
         const int split = blockIdx.y;
         const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
         const int kt0 = split * kt_per;
         const int nkt = min(kt_per, kt_total - kt0);
-        segment(bt % tiles_m, bt / tiles_m, kt0, nkt, d.out_mode == 3 ? 0 : d.out_mode,
+        segment(tile_m, tile_n, kt0, nkt, d.out_mode == 3 ? 0 : d.out_mode,
                 d.C + (d.out_mode == 3 ? (long)split * d.slice_stride : 0L), true);
     } else {
         const int G = gridDim.x, b = blockIdx.x;

@@ -536,29 +536,52 @@ __global__ __launch_bounds__(NTHREADS, (kWavesPerSimd<BM, BN>)) void gemm_x3_ker
             }
         }
     }
+    // The output form and "whole tile inside C" are decided ONCE per workgroup (descriptor fields as values, a row pointer
+    // advanced by constants): the form decided per element cost ~40 scalar instructions and ten branches per stored value —
+    // a third of a thin-K workgroup's life.
+    const int dM = d.M, dN = d.N;
+    const long ldc = d.ldc;
+    const int mode = d.out_mode == 3 ? 0 : d.out_mode;
+    auto store_all = [&](auto mode_c, auto inside_c) {
+        constexpr int MODE = decltype(mode_c)::value;          // 0 store, 1 +=, 2 atomic, 4 half store, 5 half +=
+        constexpr bool INSIDE = decltype(inside_c)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+                const int row0 = m0 + wm * (TM * 32) + i * 32 + 4 * half;
+                const long off0 = (long)row0 * ldc + col;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < d.M && col < d.N) {
-                    float v = acc[i][j][r];
-                    if (c_half) {          // out_mode 0 / 1 only (ud_gemm rejects atomics onto half)
-                        _Float16* p = reinterpret_cast<_Float16*>(Cp) + (long)row * d.ldc + col;
-                        *p = (_Float16)(d.out_mode == 0 ? v : v + (float)*p);
-                    } else {
-                        float* p = Cp + (long)row * d.ldc + col;
-                        if (d.out_mode == 0 || d.out_mode == 3) *p = v;
-                        else if (d.out_mode == 1) *p += v;
-                        else atomicAdd(p, v);
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (INSIDE || (row0 + dr < dM && col < dN)) {
+                        const float v = acc[i][j][r];
+                        if constexpr (MODE >= 4) {
+                            _Float16* p = reinterpret_cast<_Float16*>(Cp) + off0 + (long)dr * ldc;
+                            *p = (_Float16)(MODE == 4 ? v : v + (float)*p);
+                        } else {
+                            float* p = Cp + off0 + (long)dr * ldc;
+                            if constexpr (MODE == 0) *p = v;
+                            else if constexpr (MODE == 1) *p += v;
+                            else atomicAdd(p, v);
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    using std::integral_constant;
+    auto store_mode = [&](auto inside_c) {
+        if (c_half) {          // out_mode 0 / 1 only (ud_gemm rejects atomics onto half)
+            if (mode == 0) store_all(integral_constant<int, 4>{}, inside_c);
+            else store_all(integral_constant<int, 5>{}, inside_c);
+        } else if (mode == 0) store_all(integral_constant<int, 0>{}, inside_c);
+        else if (mode == 1) store_all(integral_constant<int, 1>{}, inside_c);
+        else store_all(integral_constant<int, 2>{}, inside_c);
+    };
+    if (m0 + BM <= dM && n0 + BN <= dN) store_mode(integral_constant<bool, true>{});
+    else store_mode(integral_constant<bool, false>{});
 }
 
 template <int BM, int BN, int AMODE, int BMODE, int PREC, bool AH = false, bool BH = false>

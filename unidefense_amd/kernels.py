@@ -260,6 +260,11 @@ def p3_ok(M, N, K):
     return K % 32 == 0 and min(M, N) >= 128 and K >= 128
 
 
+# XCD-aware tile raster of ud_gemm_p3's plain / split-K launches: 0x200 | GM << 12 (groups of GM tile rows; see gemm_p3.hip).
+# Per shape 0-15 % faster than the round-robin deal (tools/probe_p3_raster.py; GM 2..8 alike), never slower; UD_P3_RASTER=0: off
+_P3_RASTER = int(os.environ.get("UD_P3_RASTER", "0x4200"), 0)
+
+
 def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=None, a_row0=0, cfg=0):
     """Cout[M][N] (+)= A . B from pre-split operands.  a_row0: first GEMM row of A used (a multiple of 128; mode 0: a row
     offset inside every panel, mode 1: whole panels).  stats as in _gemm."""
@@ -277,7 +282,7 @@ def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=N
     d.a_panel, d.a_plane, d.b_panel, d.b_plane = A.panel, A.plane, B.panel, B.plane
     d.ldc = N
     d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
-    d.tile_cfg = cfg | (0x100 if _XCD_CONTIGUOUS else 0)
+    d.tile_cfg = cfg | (0x100 if _XCD_CONTIGUOUS else 0) | (_P3_RASTER if not cfg & 0x800 else 0)
     assert A.prec == B.prec
     d.prec = A.prec
     if A.prec == 2:
