@@ -228,6 +228,11 @@ int ud_rfft2(const void* x, void* Y, int N, int S, int C, float scale, float w_i
     stream);
 int ud_irfft2(const void* Y, void* x, int N, int S, int C, float scale, float w_interior, int f16, ud_stream_t
     stream);
+/* S = 32: the transform may be shared by a LANE PAIR (lanes l and l ^ 32 hold the even / odd decimated samples, the last
+ * radix-2 stage crosses the halves with wavefront shuffles; a wave owns 32 channels = whole 128-byte lines).  0 auto (where the
+ * 32-channel groups are full and fit one round of workgroups), 1 never, 2 always (env UD_FFT32_WAVE = 0 / 1: never / always).
+ * Returns the previous mode. */
+int ud_fft32_set_wave(int mode);
 
 /* ---- small FC: y[n][o] = sum_i act_in(x[n][i]) W[o][i] + b[o]  (SE 1x1 convs, classifier) ------
  * model/efficientnet/model.py:119-121; model/modules.py:27.  Any of dx / dW / db may be NULL. */

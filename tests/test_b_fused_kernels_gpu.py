@@ -639,3 +639,60 @@ def test_producers_report_the_absmax_of_what_they_wrote(two_pass):
         g, x, gamma, beta = _mk(2, 256, 48, 7, dev)
         bn = _deferred(K, x, gamma, beta, 1e-3, 1)
         assert K.se_scale_bn(x, bn, torch.zeros(2, 48, device=dev), 2, 256, want_absmax=True)._ud_absmax is None
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["fp32", "half"])
+@pytest.mark.parametrize("Cc,N", [(336, 3), (192, 2), (40, 2), (36, 1)])
+def test_fft32_lane_pair_form_equals_one_lane_form(Cc, N, half):
+    """S = 32: the transform shared by a lane pair (even / odd decimated samples on lanes l and l ^ 32, the last radix-2 stage
+    across the halves by wavefront shuffles: rfft2_wave_kernel / irfft2_wave_kernel) runs the same butterflies on the same values
+    as the one-lane-per-row kernels: every output agrees to the last bit or two, with every fused prologue / epilogue (deferred
+    BN + swish + activated copy + running statistics, gate factor and gate gradient, |Y|max slots; SF mix + freq - spat + BN
+    sums), channel counts that do not fill the 32-channel groups, both storage types.  Against float64:
+    test_fft_fused_variants / test_half_storage_kernels (whichever form the policy picks)."""
+    from unidefense_amd import kernels as K
+    from unidefense_amd import lib
+    from unidefense_amd.config import override
+    dev = _dev()
+    K.reset_zero_pool()
+    S = 32
+    dt = torch.float16 if half else torch.float32
+    g = torch.Generator().manual_seed(S + Cc)
+    x = torch.randn(N, S, S, Cc, generator=g).to(dev).to(dt)
+    gamma, beta = (1.0 + 0.2 * torch.randn(Cc, generator=g)).to(dev), (0.1 * torch.randn(Cc, generator=g)).to(dev)
+    alpha = torch.tensor(-0.3, device=dev)
+    Yin = torch.randn(N, S, S // 2 + 1, 2 * Cc, generator=g).to(dev).to(dt)
+    spat = torch.randn(N, S, S, Cc, generator=g).to(dev).to(dt)
+    slots = torch.randn(64, generator=g, dtype=torch.float64).to(dev)
+
+    def run(mode):
+        prev = lib.call("ud_fft32_set_wave", mode)
+        saved = K._FFT_TWO_PASS
+        K._FFT_TWO_PASS = False
+        try:
+            with override(spectral_p2="on"):
+                out = {}
+                out["rfft"] = K.rfft2(x, 1.0 / S, 2.0)
+                out["irfft"] = K.irfft2(Yin, 1.0 / S, 0.5)
+                rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+                bn = _deferred(K, x.view(N, S * S, Cc), gamma, beta, 1e-3, 1, rm, rv, 0.01)
+                out["ex Y"], out["ex act"] = K.rfft2_ex(x, 1.0 / S, 1.0, bn=bn, want_act=True, update=True, want_absmax=not half)
+                if not half:
+                    out["ex |Y|max"] = out["ex Y"]._ud_absmax.max().reshape(1)
+                out["ex running_mean"], out["ex running_var"] = rm, rv
+                out["gate Y"], _, out["gate grad"] = K.rfft2_ex(x, 1.0 / S, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=slots)
+                acc = K.zeros64(2 * Cc, x)
+                out["mix y"], out["mix diff"] = K.irfft2_mix(Yin, 1.0 / S, spat, alpha, acc)
+                torch.cuda.synchronize()
+                return out, acc.clone()
+        finally:
+            K._FFT_TWO_PASS = saved
+            lib.call("ud_fft32_set_wave", prev)
+    o1, a1 = run(1)
+    o2, a2 = run(2)
+    ulp = 2.0 ** -10 if half else 2.0 ** -23
+    for k in o1:
+        scale = float(o1[k].double().abs().max())
+        e = float((o1[k].double() - o2[k].double()).abs().max()) / (scale if scale > 0 else 1.0)
+        assert e <= 2.0 * ulp, (k, e)
+    assert _rel(a2, a1) < (1e-3 if half else 1e-6)

@@ -229,17 +229,21 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
     float re[S], im[S];
     // ---- pass 1: rows   (S * CB may be < 512 for the 5*2^k sizes: q >= S idles)
     if (q < S) {
-        const T* src = x + (((long)n * S + q) * S) * C + ch;
+        const int chl = cok ? ch : C - 1;          // loads unconditional and inside the tensor; stores predicated
+        const T* src = x + (((long)n * S + q) * S) * C + chl;
+        // all S loads first: the BatchNorm coefficients (fp64 division and square root) are computed while they are in flight
+#pragma unroll
+        for (int w = 0; w < S; ++w) re[brev<S>(w)] = (float)src[(long)w * C];
         float mu = 0.f, is = 1.f, ga = 1.f, be = 0.f;
-        if (EX && has_bn && cok) {
-            const double m = bn.sum[ch] * bn.inv_count;
-            double vv = bn.sumsq[ch] * bn.inv_count - m * m;
+        if (EX && has_bn) {
+            const double m = bn.sum[chl] * bn.inv_count;
+            double vv = bn.sumsq[chl] * bn.inv_count - m * m;
             if (vv < 0.0) vv = 0.0;
             mu = (float)m;
             is = (float)(1.0 / sqrt(vv + (double)bn.eps));
-            ga = bn.gamma[ch];
-            be = bn.beta[ch];
-            if (n == 0 && q == 0 && bn.running_mean) {          // one thread per channel
+            ga = bn.gamma[chl];
+            be = bn.beta[chl];
+            if (n == 0 && q == 0 && cok && bn.running_mean) {          // one thread per channel
                 bn.running_mean[ch] = (1.f - bn.momentum) * bn.running_mean[ch] + bn.momentum * (float)m;
                 bn.running_var[ch] = (1.f - bn.momentum) * bn.running_var[ch] + bn.momentum * (float)(vv * bn.unbias);
             }
@@ -247,12 +251,12 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
         T* aout = (EX && act_out) ? act_out + (((long)n * S + q) * S) * C + ch : nullptr;
 #pragma unroll
         for (int w = 0; w < S; ++w) {
-            float v = cok ? (float)src[(long)w * C] : 0.f;
+            float v = re[brev<S>(w)];
             if (EX && has_bn) {
                 v = ud_rounded<T>(ud_act(ga * ((v - mu) * is) + be, bn.act));     // transform what the other branch reads
                 if (aout && cok) aout[(long)w * C] = (T)v;
             }
-            re[brev<S>(w)] = v;
+            re[brev<S>(w)] = cok ? v : 0.f;
             im[brev<S>(w)] = 0.f;
         }
         fft_inreg<S, false>(re, im);
@@ -719,6 +723,304 @@ int irfft2_two_pass(const T* Y, T* x, float* Z, int N, int C, float scale, float
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// S = 32, the transform SHARED BY A LANE PAIR (the plane laid across the wave).
+// With one lane per (row, channel) a 32 x 32 plane group of 512 threads takes 16 channels: 64-byte runs per pixel, every
+// 128-byte line pulled by two workgroups (33-39 % of HBM peak, profiles/r03/hbm_bw_by_kernel.txt).  Here lanes l and l ^ 32
+// share one 32-point transform: lane half hh = l >> 5 holds the decimated sequence x[2j + hh] (16 values), runs the
+// 16-point radix-2 network in registers, and the LAST butterfly stage  X[k] = E[k] + W^k O[k],  X[k + 16] = E[k] - W^k O[k]
+// crosses the two lane halves with wavefront shuffles (__shfl_xor 32).  Half the registers per lane, so a workgroup is
+// 1024 threads = 16 waves, a wave = 32 CHANNELS (one whole 128-byte line per pixel) x the two halves: every global access
+// of a wave is two full lines.  LDS as in the one-lane form ([kx][h][c], 17 x 32 x 32 complex fp32 = 136 KB: one workgroup
+// per CU, 16 waves).  Same butterflies on the same values in the same order as fft_inreg<32>: results equal to the last bit
+// or two (the compiler contracts different multiply-adds).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int NTW = 1024;
+constexpr int CBW = 32;
+struct LdsW {
+    static constexpr int KSTRIDE = 32 * CBW;
+    static constexpr int PLANE = 17 * KSTRIDE;
+    static constexpr size_t BYTES = 2ull * PLANE * sizeof(float);
+};
+
+// on entry lane half hh holds x[2j + hh] in slot brev<16>(j); on exit half 0 holds X[0..15], half 1 holds X[16..31]
+template <bool INV>
+__device__ __forceinline__ void fft32_pair(float (&re)[16], float (&im)[16], int hh) {
+    fft_inreg<16, INV>(re, im);          // E (even samples) on half 0, O (odd samples) on half 1
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float wr = TW_RE[2 * k], wi = INV ? -TW_IM[2 * k] : TW_IM[2 * k];          // W_32^k
+        const float tr = wr * re[k] - wi * im[k], ti = wr * im[k] + wi * re[k];
+        const float ar = hh ? tr : re[k], ai = hh ? ti : im[k];          // half 0 contributes E[k], half 1 contributes W^k O[k]
+        const float br = __shfl_xor(ar, 32, 64), bi = __shfl_xor(ai, 32, 64);
+        re[k] = hh ? br - ar : ar + br;
+        im[k] = hh ? bi - ai : ai + bi;
+    }
+}
+
+template <typename T, bool EX>
+__global__ __launch_bounds__(NTW) void rfft2_wave_kernel(const T* __restrict__ x, T* __restrict__ Y, int C, float scale,
+                                                         float w_int, ud_bn_ref bn, int has_bn, T* __restrict__ act_out,
+                                                         const float* __restrict__ gate_alpha, int gate_mode,
+                                                         const double* __restrict__ gate_acc, float* __restrict__ gate_grad,
+                                                         uint32_t* __restrict__ amax) {
+    constexpr int S = 32, WH = 17;
+    using L = LdsW;
+    if (EX && gate_grad && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {          // see rfft2_kernel
+        const double tot = ud_wave_sum_d(gate_acc[threadIdx.x]);
+        if (threadIdx.x == 0) {
+            const double a = 1.0 / (1.0 + exp(-(double)gate_alpha[0]));
+            gate_grad[0] = (float)(tot * a * (1.0 - a));
+        }
+    }
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Lre = lds;
+    float* Lim = lds + L::PLANE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int n = blockIdx.y;
+    const int ch = blockIdx.x * CBW + c;
+    const bool cok = ch < C;
+    const int chl = cok ? ch : C - 1;          // loads stay inside the tensor and unconditional; stores are predicated
+    float re[16], im[16];
+    // ---- pass 1: rows q = wave, wave + 16 — the loads of both rows are issued before anything waits for them
+    float v[2][16];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const T* src = x + (((long)n * S + wave + 16 * it) * S + hh) * C + chl;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[it][j] = (float)src[(long)(2 * j) * C];
+    }
+    float mu = 0.f, is = 1.f, ga = 1.f, be = 0.f;
+    if (EX && has_bn) {
+        const double m = bn.sum[chl] * bn.inv_count;
+        double vv = bn.sumsq[chl] * bn.inv_count - m * m;
+        if (vv < 0.0) vv = 0.0;
+        mu = (float)m;
+        is = (float)(1.0 / sqrt(vv + (double)bn.eps));
+        ga = bn.gamma[chl];
+        be = bn.beta[chl];
+        if (n == 0 && wave == 0 && hh == 0 && cok && bn.running_mean) {          // one thread per channel
+            bn.running_mean[ch] = (1.f - bn.momentum) * bn.running_mean[ch] + bn.momentum * (float)m;
+            bn.running_var[ch] = (1.f - bn.momentum) * bn.running_var[ch] + bn.momentum * (float)(vv * bn.unbias);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int q = wave + 16 * it;
+        T* aout = (EX && act_out) ? act_out + (((long)n * S + q) * S + hh) * C + ch : nullptr;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float u = v[it][j];
+            if (EX && has_bn) {
+                u = ud_rounded<T>(ud_act(ga * ((u - mu) * is) + be, bn.act));          // transform what the other branch reads
+                if (aout && cok) {
+                    *aout = (T)u;
+                    aout += 2L * C;
+                }
+            }
+            re[brev<16>(j)] = cok ? u : 0.f;
+            im[brev<16>(j)] = 0.f;
+        }
+        fft32_pair<false>(re, im, hh);
+        // half 0 holds kx = 0..15, half 1 holds kx = 16 (its slot 0) and the mirrored rest
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (hh == 0 || k == 0) {
+                Lre[(k + 16 * hh) * L::KSTRIDE + q * CBW + c] = re[k];
+                Lim[(k + 16 * hh) * L::KSTRIDE + q * CBW + c] = im[k];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: columns kx = wave (wave 0 also takes kx = 16)
+    float mabs = 0.f;
+    float gf = 1.f;
+    if (EX && gate_mode != 0) {
+        const float a = ud_sigmoid(gate_alpha[0]);
+        gf = (gate_mode == 1) ? a : 1.f - a;
+    }
+#pragma unroll 1
+    for (int kx = wave; kx < WH; kx += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            re[brev<16>(j)] = Lre[kx * L::KSTRIDE + (2 * j + hh) * CBW + c];
+            im[brev<16>(j)] = Lim[kx * L::KSTRIDE + (2 * j + hh) * CBW + c];
+        }
+        fft32_pair<false>(re, im, hh);
+        const float f = ((kx == 0 || kx == S / 2) ? scale : scale * w_int) * gf;
+        if (cok) {
+            T* dst = Y + (((long)n * S + 16 * hh) * WH + kx) * (2L * C) + ch;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                dst[0] = (T)(re[k] * f);
+                dst[C] = (T)(im[k] * f);
+                dst += (long)WH * 2 * C;
+                if (EX) mabs = fmaxf(mabs, fmaxf(fabsf(re[k] * f), fabsf(im[k] * f)));
+            }
+        }
+    }
+    if (EX) ud_absmax_commit(mabs, amax);
+}
+
+template <typename T, bool MIX>
+__global__ __launch_bounds__(NTW) void irfft2_wave_kernel(const T* __restrict__ Y, T* __restrict__ x, int C, float scale,
+                                                          float w_int, const T* __restrict__ spat,
+                                                          const float* __restrict__ alpha, T* __restrict__ freq_out,
+                                                          double* __restrict__ sum, double* __restrict__ sumsq) {
+    constexpr int S = 32, WH = 17;
+    using L = LdsW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Lre = lds;
+    float* Lim = lds + L::PLANE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int n = blockIdx.y;
+    const int ch = blockIdx.x * CBW + c;
+    const bool cok = ch < C;
+    const int chl = cok ? ch : C - 1;
+    float re[16], im[16];
+    // ---- pass 1: inverse transform along ky of the kept columns kx = wave (wave 0 also kx = 16)
+#pragma unroll 1
+    for (int kx = wave; kx < WH; kx += 16) {
+        const T* src = Y + (((long)n * S + hh) * WH + kx) * (2L * C) + chl;
+        const float f = (kx == 0 || kx == S / 2) ? 1.f : w_int;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            re[brev<16>(j)] = (float)src[(long)(2 * j) * WH * 2 * C];
+            im[brev<16>(j)] = (float)src[(long)(2 * j) * WH * 2 * C + C];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            re[k] = cok ? re[k] * f : 0.f;
+            im[k] = cok ? im[k] * f : 0.f;
+        }
+        fft32_pair<true>(re, im, hh);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            Lre[kx * L::KSTRIDE + (k + 16 * hh) * CBW + c] = re[k];
+            Lim[kx * L::KSTRIDE + (k + 16 * hh) * CBW + c] = im[k];
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: Hermitian-extended inverse transform along kx of rows h = wave, wave + 16; real part only
+    double tot1 = 0.0, tot2 = 0.0;
+    float a = 0.f;
+    if (MIX) a = ud_sigmoid(alpha[0]);
+#pragma unroll 1
+    for (int h = wave; h < S; h += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int kx = 2 * j + hh;                      // this lane's decimated sample
+            const int kk = kx <= S / 2 ? kx : S - kx;       // X[S - kx] = conj(X[kx])
+            const float zr = Lre[kk * L::KSTRIDE + h * CBW + c];
+            float zi = Lim[kk * L::KSTRIDE + h * CBW + c];
+            zi = (kk == 0 || kk == S / 2) ? 0.f : (kx <= S / 2 ? zi : -zi);          // c2r ignores the imaginary parts of kx = 0, S/2
+            re[brev<16>(j)] = zr;
+            im[brev<16>(j)] = zi;
+        }
+        fft32_pair<true>(re, im, hh);
+        if (cok) {
+            // uniform plane base + 32-bit lane offsets (global_load saddr + voffset): 64-bit lane addresses, hoisted out of the
+            // row loop for 3 tensors x 16 pixels, spilled a hundred registers at 1024 threads
+            const long plane = (long)n * S * S * C;
+            unsigned o = (unsigned)((h * S + 16 * hh) * C + ch);
+            T* dst = x + plane;
+            if (!MIX) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dst[o + (unsigned)(k * C)] = (T)(re[k] * scale);
+            } else {
+                const T* sp = spat + plane;
+                T* fo = freq_out + plane;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const unsigned ok = o + (unsigned)(k * C);
+                    const float fr = re[k] * scale, spv = (float)sp[ok];
+                    const float y = ud_rounded<T>(spv * (1.f - a) + fr * a);
+                    fo[ok] = (T)(fr - spv);
+                    dst[ok] = (T)y;
+                    tot1 += (double)y;
+                    tot2 += (double)y * (double)y;
+                }
+            }
+        }
+    }
+    if (MIX) {
+        // per-channel totals: the two lane halves by a wavefront shuffle, the 16 waves through LDS (the planes are free now)
+        tot1 += __shfl_xor(tot1, 32, 64);
+        tot2 += __shfl_xor(tot2, 32, 64);
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);
+        if (hh == 0) {
+            red[(wave * CBW + c) * 2] = tot1;
+            red[(wave * CBW + c) * 2 + 1] = tot2;
+        }
+        __syncthreads();
+        if (wave == 0 && hh == 0 && cok) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int r = 0; r < 16; ++r) {
+                t1 += red[(r * CBW + c) * 2];
+                t2 += red[(r * CBW + c) * 2 + 1];
+            }
+            unsafeAtomicAdd(sum + ch, t1);
+            unsafeAtomicAdd(sumsq + ch, t2);
+        }
+    }
+}
+
+template <typename K>
+int wave_lds_attr(K kernel) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LdsW::BYTES);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+template <typename T, bool EX>
+int launch_rfft2_wave_t(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx& ex, hipStream_t s) {
+    static int attr = wave_lds_attr(&rfft2_wave_kernel<T, EX>);
+    if (attr) return attr;
+    dim3 grid((unsigned)ud_cdiv(C, CBW), (unsigned)N);
+    ud_bn_ref none{};
+    hipLaunchKernelGGL((rfft2_wave_kernel<T, EX>), grid, dim3(NTW), LdsW::BYTES, s, x, Y, C, scale, w_int, ex.bn ? *ex.bn : none,
+                       ex.bn ? 1 : 0, (T*)ex.act_out, ex.gate_alpha, ex.gate_mode, ex.gate_acc, ex.gate_grad, ex.absmax);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int launch_rfft2_wave(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
+    if (ex) return launch_rfft2_wave_t<T, true>(x, Y, N, C, scale, w_int, *ex, s);
+    return launch_rfft2_wave_t<T, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr}, s);
+}
+template <typename T, bool MIX>
+int launch_irfft2_wave_t(const T* Y, T* x, int N, int C, float scale, float w_int, const IrfftMix& m, hipStream_t s) {
+    static int attr = wave_lds_attr(&irfft2_wave_kernel<T, MIX>);
+    if (attr) return attr;
+    dim3 grid((unsigned)ud_cdiv(C, CBW), (unsigned)N);
+    hipLaunchKernelGGL((irfft2_wave_kernel<T, MIX>), grid, dim3(NTW), LdsW::BYTES, s, Y, x, C, scale, w_int, (const T*)m.spat,
+                       m.alpha, (T*)m.freq_out, m.sum, m.sumsq);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int launch_irfft2_wave(const T* Y, T* x, int N, int C, float scale, float w_int, const IrfftMix* m, hipStream_t s) {
+    if (m) return launch_irfft2_wave_t<T, true>(Y, x, N, C, scale, w_int, *m, s);
+    return launch_irfft2_wave_t<T, false>(Y, x, N, C, scale, w_int, IrfftMix{nullptr, nullptr, nullptr, nullptr, nullptr}, s);
+}
+
+// Which S = 32 form runs.  Measured on an MI355X (profiles/r04/fft32_wave.txt): the lane-pair form wins where its 32-channel
+// groups fill whole lines AND the launch is a single round of workgroups (one 136 KB workgroup per CU) — N 32 x C 192:
+// irfft2_mix 28.0 -> 24.2 us, irfft2 15.9 -> 14.9 — and loses on the step's own 32 x 32 shape, C = 336 = 10.5 groups: 352
+// workgroups are 1.4 rounds of 256 CUs with a half-empty last group (rfft2 19.6 -> 28.0 us).  So: auto = lane pairs only for
+// C % 32 == 0 and N * C / 32 <= 256.  UD_FFT32_WAVE = 0 / 1 (or ud_fft32_set_wave) forces a form.
+int g_fft32_wave = [] {
+    const char* e = getenv("UD_FFT32_WAVE");
+    return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
+}();
+inline bool fft32_wave_on(int N, int C) {
+    if (g_fft32_wave >= 0) return g_fft32_wave != 0;
+    return C % CBW == 0 && (long)N * (C / CBW) <= 256;
+}
+
 // half storage: the power-of-two sizes of the EfficientNet trunk only (the ResNet models' 5*2^k maps stay fp32)
 template <typename T>
 int rfft2_dispatch(const T* x, T* Y, int N, int S, int C, float scale, float w_interior, const RfftEx* ex,
@@ -726,7 +1028,9 @@ int rfft2_dispatch(const T* x, T* Y, int N, int S, int C, float scale, float w_i
     switch (S) {
         case 8: return launch_rfft2<T, 8, 64>(x, Y, N, C, scale, w_interior, ex, s);
         case 16: return launch_rfft2<T, 16, 32>(x, Y, N, C, scale, w_interior, ex, s);
-        case 32: return launch_rfft2<T, 32, 16>(x, Y, N, C, scale, w_interior, ex, s);
+        case 32:
+            if (fft32_wave_on(N, C)) return launch_rfft2_wave<T>(x, Y, N, C, scale, w_interior, ex, s);
+            return launch_rfft2<T, 32, 16>(x, Y, N, C, scale, w_interior, ex, s);
         case 64: return launch_rfft2<T, 64, 8>(x, Y, N, C, scale, w_interior, ex, s);
         default: break;
     }
@@ -748,7 +1052,9 @@ int irfft2_dispatch(const T* Y, T* x, int N, int S, int C, float scale, float w_
     switch (S) {
         case 8: return launch_irfft2<T, 8, 64>(Y, x, N, C, scale, w_interior, m, s);
         case 16: return launch_irfft2<T, 16, 32>(Y, x, N, C, scale, w_interior, m, s);
-        case 32: return launch_irfft2<T, 32, 16>(Y, x, N, C, scale, w_interior, m, s);
+        case 32:
+            if (fft32_wave_on(N, C)) return launch_irfft2_wave<T>(Y, x, N, C, scale, w_interior, m, s);
+            return launch_irfft2<T, 32, 16>(Y, x, N, C, scale, w_interior, m, s);
         case 64: return launch_irfft2<T, 64, 8>(Y, x, N, C, scale, w_interior, m, s);
         default: break;
     }
@@ -767,6 +1073,15 @@ int irfft2_dispatch(const T* Y, T* x, int N, int S, int C, float scale, float w_
 }  // namespace
 
 extern "C" {
+
+// form of the S = 32 transforms: 0 auto (default), 1 one lane per image row, 2 lane pairs (rfft2_wave_kernel); returns the
+// previous setting
+int ud_fft32_set_wave(int mode) {
+    const int prev = g_fft32_wave < 0 ? 0 : g_fft32_wave == 0 ? 1 : 2;
+    if (mode < 0 || mode > 2) return UD_EINVAL;
+    g_fft32_wave = mode - 1 < 0 ? -1 : mode - 1;
+    return prev;
+}
 
 int ud_rfft2(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, int f16, ud_stream_t stream) {
     if (N < 1 || C < 1) return UD_EINVAL;

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "ud_absmax": [_P, _L, _I, _L, _P, _P],
     "ud_split_planes_h2t": [_P, _L, _I, _L, _P, _L, _L, _P, _P, _P],
     "ud_gemm_set_path": [C.c_int],
+    "ud_fft32_set_wave": [C.c_int],
     "ud_gemm_query_path": [C.POINTER(GemmDesc)],
     "ud_gemm_stats_slots": [C.POINTER(GemmDesc)],
     "ud_stat_slots_fold": [_P, _P, _I, _I, _P, _P, _P],
@@ -169,7 +170,7 @@ _SIGNATURES = {
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_fft32_set_wave", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
                 "ud_conv_small_wgrad_ws_floats", "ud_xchg_bytes"}
 _LONG_FUNCS = {"ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
