@@ -160,6 +160,18 @@ int ud_split_planes_h2(const float* x, long R, int C, long ld, uint16_t* planes,
 int ud_absmax(const float* x, long R, int C, long ld, uint32_t* absmax, ud_stream_t stream);
 int ud_split_planes_h2t(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,
                         const uint32_t* absmax, float* inv_scale, ud_stream_t stream);
+/* Every weight matrix of a step in TWO launches (an absmax pass and a split pass over all of them) instead of two per matrix:
+ * `items` is a DEVICE array of n descriptors sorted by their block prefixes — item i owns absmax blocks [amax_block0,
+ * amax_block0 + amax_blocks) (amax_blocks <= 256: block b writes slot b of the item's 256 slots; the caller zeroes the
+ * n * 256 slots ONCE, the unused ones stay zero) and split blocks [split_block0, split_block0 + split_bx * ceil(C / 32)),
+ * split_bx = ceil(R / 64).  Same planes and scales as ud_absmax + ud_split_planes_h2t per matrix (tested bitwise). */
+typedef struct {
+    const float* x; uint16_t* out; float* inv_scale;
+    long R, ld, panel, plane;
+    int C, amax_block0, amax_blocks, split_block0, split_bx, pad_;
+} ud_split_item;
+int ud_split_planes_h2t_multi(const ud_split_item* items_dev, int n, uint32_t* slots, int amax_blocks_total,
+                              int split_blocks_total, ud_stream_t stream);
 
 /* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------
  * Every reduction is a partial pass (fp64 per-workgroup totals stored into the scratch `ws`) plus a small

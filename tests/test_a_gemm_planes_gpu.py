@@ -225,3 +225,87 @@ def test_xcd_raster_is_a_permutation_of_the_tiles(kind, M, N, Kd):
             assert ((acc - outs[0][2]).abs().max() <= 1e-12 * outs[0][2].abs().max().clamp_min(1e-300)).item()
     finally:
         K._P3_RASTER = saved
+
+
+def test_weight_planes_of_a_step_in_two_launches():
+    """ud_split_planes_h2t_multi (kernels._WeightPlaneBatch): the planes of all registered weight matrices from one absmax and
+    one split launch equal the per-matrix ud_absmax + ud_split_planes_h2t planes BITWISE (scale included) for assorted shapes
+    (rows not a multiple of 64, columns not a multiple of 32, one-block and 256-block matrices); they are handed out only while
+    the parameter is unchanged — after an in-place update the caller gets a fresh split, the next begin_forward() re-splits."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(7)
+    batch = K._WeightPlaneBatch()
+    saved = K._WEIGHT_PLANES
+    K._WEIGHT_PLANES = batch
+    try:
+        shapes = [(1920, 1920), (160, 960), (272, 1632), (672, 112), (64, 64), (3264, 3264), (100, 36), (36, 100)]
+        params = [torch.nn.Parameter(torch.randn(r, c, device=dev) * (10.0 ** (i - 3))) for i, (r, c) in enumerate(shapes)]
+        views = [p.view(p.shape[0], p.shape[1]) for p in params]
+
+        def rows(pl):
+            return pl.buf.view(2, pl.npanel, pl.panel // 32, 32)[:, :, :pl.R]
+        for v in views:
+            assert batch.lookup(v) is None
+            K.weight_planes(v)                                  # first use: its own split, and it registers
+        assert len(batch.entries) == len(shapes)
+        K.begin_forward()
+        torch.cuda.synchronize()
+        for v in views:
+            got, ref = batch.lookup(v), K.split_planes(v, prec=2)
+            torch.cuda.synchronize()
+            assert got is not None and torch.equal(rows(got), rows(ref)) and torch.equal(got.inv, ref.inv), tuple(v.shape)
+            assert K.weight_planes(v) is got
+        # an optimizer-like in-place update: the batch's planes are stale and must not be handed out
+        with torch.no_grad():
+            params[1].mul_(3.0)
+        assert batch.lookup(views[1]) is None and batch.lookup(views[0]) is not None
+        fresh = K.weight_planes(views[1])
+        K.begin_forward()
+        torch.cuda.synchronize()
+        again = batch.lookup(views[1])
+        assert again is not None and torch.equal(rows(again), rows(fresh)) and torch.equal(again.inv, fresh.inv)
+        # a parameter that goes away leaves the table
+        del params[2:4], views[2:4], v, got, ref
+        import gc
+        gc.collect()
+        K.begin_forward()
+        torch.cuda.synchronize()
+        assert len(batch.entries) == len(shapes) - 2
+        for v in views:
+            got, ref = batch.lookup(v), K.split_planes(v, prec=2)
+            torch.cuda.synchronize()
+            assert got is not None and torch.equal(rows(got), rows(ref))
+    finally:
+        K._WEIGHT_PLANES = saved
+
+
+def test_weight_plane_batch_survives_dead_and_moved_parameters():
+    """every registered parameter gone -> begin_forward() is a no-op (no empty table); a parameter whose storage was replaced
+    (p.data = ...) leaves the table and re-registers on its next use"""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    batch = K._WeightPlaneBatch()
+    saved = K._WEIGHT_PLANES
+    K._WEIGHT_PLANES = batch
+    try:
+        p = torch.nn.Parameter(torch.randn(128, 64, device=dev))
+        K.weight_planes(p.view(128, 64))
+        K.begin_forward()
+        assert batch.lookup(p.view(128, 64)) is not None
+        p.data = torch.randn(128, 64, device=dev)                  # new storage, same version
+        assert batch.lookup(p.view(128, 64)) is None
+        K.begin_forward()
+        assert len(batch.entries) == 0
+        ref = K.split_planes(p.view(128, 64), prec=2)
+        got = K.weight_planes(p.view(128, 64))                     # own split; registers again
+        torch.cuda.synchronize()
+        assert torch.equal(got.buf, ref.buf) and len(batch.entries) == 1
+        del p, got, ref
+        import gc
+        gc.collect()
+        K.begin_forward()
+        K.begin_forward()
+        assert len(batch.entries) == 0
+    finally:
+        K._WEIGHT_PLANES = saved

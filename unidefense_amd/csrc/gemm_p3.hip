@@ -685,7 +685,91 @@ __global__ __launch_bounds__(256) void split_h2_tensor_kernel(const float* __res
     *reinterpret_cast<u32x4*>(o + plane) = u32x4{b[0], b[1], b[2], b[3]};
 }
 
+// ---- all weight matrices of a step in two launches -------------------------------------------------------------------
+// A train step splits ~50 weight matrices, each with an absmax launch and a split launch of a few microseconds.  The items
+// (pointers, shapes, first-block prefixes) live in a device table built once; block -> item by bisection of the prefixes.
+__device__ __forceinline__ int item_of_block(const ud_split_item* __restrict__ it, int n, int b, bool split) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((split ? it[mid].split_block0 : it[mid].amax_block0) <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(1024) void absmax_multi_kernel(const ud_split_item* __restrict__ items, int n,
+                                                            uint32_t* __restrict__ slots) {
+    __shared__ float red[16];
+    const int i = item_of_block(items, n, blockIdx.x, false);
+    const ud_split_item it = items[i];
+    const int bl = blockIdx.x - it.amax_block0, nb = it.amax_blocks;
+    const int cq = it.C >> 2;
+    const long nq = it.R * (long)cq, stride = (long)nb * 1024;
+    float m = 0.f;
+    for (long q = (long)bl * 1024 + threadIdx.x; q < nq; q += stride) {
+        const long r = q / cq;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(it.x + r * it.ld + (q - r * cq) * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    m = ud_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = red[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t = fmaxf(t, red[k]);
+        slots[(long)i * ABSMAX_SLOTS + bl] = __float_as_uint(t);          // slots >= amax_blocks stay zero (zeroed once by the caller)
+    }
+}
+
+__global__ __launch_bounds__(256) void split_h2_multi_kernel(const ud_split_item* __restrict__ items, int n,
+                                                             const uint32_t* __restrict__ slots) {
+    const int i = item_of_block(items, n, blockIdx.x, true);
+    const ud_split_item it = items[i];
+    const int bl = blockIdx.x - it.split_block0;
+    const int pan = bl / it.split_bx, bx = bl - pan * it.split_bx;
+    const int tid = threadIdx.x;
+    const long row = (long)bx * 64 + (tid >> 2);
+    const int c0 = pan * 32 + (tid & 3) * 8;
+    const uint32_t* absmax = slots + (long)i * ABSMAX_SLOTS;
+    uint32_t mb = 0;
+#pragma unroll
+    for (int k = 0; k < ABSMAX_SLOTS / 64; ++k) mb = max(mb, absmax[(tid & 63) + 64 * k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, o, 64));
+    float s, inv;
+    h2_scale(mb, s, inv);
+    if (bl == 0 && tid == 0) *it.inv_scale = inv;
+    if (row >= it.R) return;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + 8 <= it.C) {
+        v0 = *reinterpret_cast<const f32x4*>(it.x + row * it.ld + c0);
+        v1 = *reinterpret_cast<const f32x4*>(it.x + row * it.ld + c0 + 4);
+    } else if (c0 + 4 <= it.C) {
+        v0 = *reinterpret_cast<const f32x4*>(it.x + row * it.ld + c0);
+    }
+    uint32_t a[4], b[4];
+    split2h(v0[0] * s, v0[1] * s, a[0], b[0]);
+    split2h(v0[2] * s, v0[3] * s, a[1], b[1]);
+    split2h(v1[0] * s, v1[1] * s, a[2], b[2]);
+    split2h(v1[2] * s, v1[3] * s, a[3], b[3]);
+    uint16_t* o = it.out + (long)pan * it.panel + row * 32 + (tid & 3) * 8;
+    *reinterpret_cast<u32x4*>(o) = u32x4{a[0], a[1], a[2], a[3]};
+    *reinterpret_cast<u32x4*>(o + it.plane) = u32x4{b[0], b[1], b[2], b[3]};
+}
+
 }  // namespace
+
+extern "C" int ud_split_planes_h2t_multi(const ud_split_item* items_dev, int n, uint32_t* slots, int amax_blocks_total,
+                                         int split_blocks_total, ud_stream_t stream) {
+    if (!items_dev || !slots || n < 1 || amax_blocks_total < n || split_blocks_total < n) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(absmax_multi_kernel, dim3((unsigned)amax_blocks_total), dim3(1024), 0, s, items_dev, n, slots);
+    hipLaunchKernelGGL(split_h2_multi_kernel, dim3((unsigned)split_blocks_total), dim3(256), 0, s, items_dev, n, slots);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ud_absmax(const float* x, long R, int C, long ld, uint32_t* out, ud_stream_t stream) {
     if (!x || !out || R <= 0 || C <= 0 || C % 4 != 0 || ld % 4 != 0 || ld < C) return UD_EINVAL;

@@ -255,6 +255,108 @@ def split_planes(x2, out=None, prec=3, per_row=False, absmax=None):
     return pl
 
 
+class _WeightPlaneBatch:
+    """The planes of every weight matrix the planes GEMMs use, made by TWO launches at the start of a forward
+    (ud_split_planes_h2t_multi) instead of an absmax + a split launch per matrix (~50 matrices per step).  A weight registers on
+    its first use (an eager step: never inside a graph capture); its planes live in a persistent buffer; begin() re-splits all
+    registered weights from their CURRENT values and records each parameter's version, lookup() hands the planes out only while
+    that version still holds (an optimizer step in between -> the caller splits the matrix itself).  Entries die with their
+    parameter (weak references).  cfg.weight_plane_batch = False: off."""
+
+    def __init__(self):
+        self.entries = {}          # id(param) -> [weakref(param), Planes, version at the last begin(), shape2, data_ptr]
+        self.table = self.slots = None
+        self.dirty = False
+        self.totals = (0, 0)
+
+    def _base(self, w2):
+        b = w2._base if w2._base is not None else w2
+        return b if isinstance(b, torch.nn.Parameter) and b.is_contiguous() and b.dtype == torch.float32 else None
+
+    def lookup(self, w2):
+        b = self._base(w2)
+        if b is None:
+            return None
+        e = self.entries.get(id(b))
+        if e is None or e[0]() is not b:
+            return None
+        return e[1] if (e[2] == b._version and e[3] == tuple(w2.shape) and e[4] == b.data_ptr()) else None
+
+    def register(self, w2):
+        b = self._base(w2)
+        if b is None or not CFG.weight_plane_batch or torch.cuda.is_current_stream_capturing() or w2.numel() != b.numel():
+            return
+        e = self.entries.get(id(b))
+        if e is not None and e[0]() is b and e[3] == tuple(w2.shape) and e[4] == b.data_ptr():
+            return
+        import weakref
+        R, Cc = w2.shape
+        self.entries[id(b)] = [weakref.ref(b), Planes(R, Cc, w2, 2, False), -1, (R, Cc), b.data_ptr()]
+        self.dirty = True
+
+    def begin(self):
+        if not self.entries or not CFG.weight_plane_batch:
+            return
+        # a parameter that died, or whose storage was replaced (p.data = ..., a device move), invalidates the device table
+        stale = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[4]]
+        if stale or self.dirty:
+            if torch.cuda.is_current_stream_capturing():
+                return                                   # the table is rebuilt on the next eager step; this one splits per matrix
+            for k in stale:
+                del self.entries[k]
+            self.dirty = True
+            if not self.entries:
+                self.table = self.slots = None
+                return
+            self._build()
+        _call("ud_split_planes_h2t_multi", _p(self.table), len(self.entries), _p(self.slots), self.totals[0], self.totals[1],
+              _stream())
+        for e in self.entries.values():
+            e[2] = e[0]()._version
+
+    def _build(self):
+        from .lib import SplitItem
+        items = (SplitItem * len(self.entries))()
+        a0 = s0 = 0
+        dev = None
+        for i, e in enumerate(self.entries.values()):
+            b, pl = e[0](), e[1]
+            R, Cc = e[3]
+            dev = b.device
+            it = items[i]
+            it.x, it.out, it.inv_scale = b.data_ptr(), pl.buf.data_ptr(), pl.inv.data_ptr()
+            it.R, it.ld, it.panel, it.plane, it.C = R, Cc, pl.panel, pl.plane, Cc
+            it.amax_block0, it.amax_blocks = a0, max(1, min(256, -(-(R * (Cc // 4)) // 4096)))
+            it.split_block0, it.split_bx = s0, -(-R // 64)
+            a0 += it.amax_blocks
+            s0 += it.split_bx * pl.npanel
+            e[2] = -1
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self.table = raw.to(dev)
+        self.slots = torch.zeros(256 * len(self.entries), dtype=torch.int32, device=dev)
+        self.totals = (a0, s0)
+        self.dirty = False
+
+
+_WEIGHT_PLANES = _WeightPlaneBatch()
+
+
+def begin_forward():
+    """start of a model forward: fresh zero blocks, and the planes of all registered weight matrices in two launches"""
+    reset_zero_pool()
+    _WEIGHT_PLANES.begin()
+
+
+def weight_planes(w2):
+    """prec-2 planes (one scale for the tensor) of a conv weight [Cout, Cin]: the step's batch if it covers this weight as it is
+    now, else a split of its own (and the weight joins the batch from the next forward on)"""
+    pl = _WEIGHT_PLANES.lookup(w2)
+    if pl is not None:
+        return pl
+    _WEIGHT_PLANES.register(w2)
+    return split_planes(w2, prec=2)
+
+
 def p3_ok(M, N, K):
     """shapes ud_gemm_p3 takes and is worth taking: whole 32-deep K-tiles, the large spectral GEMMs"""
     return K % 32 == 0 and min(M, N) >= 128 and K >= 128
@@ -722,7 +824,7 @@ def spectral_fwd(x2, w2, stats=None, x_absmax=None):
     if ctx.plans is None:
         ctx.x, ctx.w = x2, w2
         return gemm_nt(x2, w2, stats=stats), ctx
-    ctx.x, ctx.w = split_planes(x2, prec=2, absmax=x_absmax), split_planes(w2, prec=2)
+    ctx.x, ctx.w = split_planes(x2, prec=2, absmax=x_absmax), weight_planes(w2)
     return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, x2, stats=stats), ctx
 
 

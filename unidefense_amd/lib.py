@@ -30,6 +30,14 @@ class GemmDesc(C.Structure):
                 ("g", ConvGeom), ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("half_mask", C.c_int), ("tile_cfg", C.c_int), ("slice_stride", C.c_long)]
 
 
+class SplitItem(C.Structure):
+    """ud_split_item of include/unidefense_hip.h (one weight matrix of ud_split_planes_h2t_multi's device table)"""
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("inv_scale", C.c_void_p),
+                ("R", C.c_long), ("ld", C.c_long), ("panel", C.c_long), ("plane", C.c_long),
+                ("C", C.c_int), ("amax_block0", C.c_int), ("amax_blocks", C.c_int), ("split_block0", C.c_int),
+                ("split_bx", C.c_int), ("pad_", C.c_int)]
+
+
 class GemmP3Desc(C.Structure):
     """ud_gemm_p3_desc: GEMM on pre-split bf16 planes (P32 layout), include/unidefense_hip.h."""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
@@ -61,6 +69,7 @@ _SIGNATURES = {
     "ud_absmax": [_P, _L, _I, _L, _P, _P],
     "ud_split_planes_h2t": [_P, _L, _I, _L, _P, _L, _L, _P, _P, _P],
     "ud_gemm_set_path": [C.c_int],
+    "ud_split_planes_h2t_multi": [_P, C.c_int, _P, C.c_int, C.c_int, _P],
     "ud_fft32_set_wave": [C.c_int],
     "ud_gemm_query_path": [C.POINTER(GemmDesc)],
     "ud_gemm_stats_slots": [C.POINTER(GemmDesc)],

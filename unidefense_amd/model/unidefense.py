@@ -114,7 +114,7 @@ def _half_storage(model):
 class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, noise_x, rng, *params):
-        K.reset_zero_pool()          # a (possibly graph-captured) step zero-fills every block it carves outputs from
+        K.begin_forward()          # fresh zero blocks (a captured step fills every block it carves from); weight planes in two launches
         tape = T.Tape()
         debug = getattr(model, "_debug_watch", False)
         if debug:
