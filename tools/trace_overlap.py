@@ -59,3 +59,20 @@ if gaps:
         sum(1 for g in gaps if g > 5000) / steps, sum(g for g in gaps if g > 5000) / 1e6 / steps))
 for q, (t, n) in sorted(perq.items(), key=lambda kv: -kv[1][0]):
     print("queue %s: %.2f ms/step in %.0f kernels/step" % (q, t / 1e6 / steps, n / steps))
+
+# launches of the replayed step by kernel family
+import re
+fam = collections.defaultdict(lambda: [0, 0])
+for s_, e_, _, n in sel:
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    base = re.split(r"[<(]", n)[0]
+    if base.startswith("at::native") or "rocclr" in base:
+        base = "torch / rocclr: " + base
+    fam[base][0] += e_ - s_
+    fam[base][1] += 1
+tor = sum(v[1] for k, v in fam.items() if k.startswith("torch / rocclr")) / steps
+tort = sum(v[0] for k, v in fam.items() if k.startswith("torch / rocclr")) / 1e6 / steps
+print("torch / rocclr kernels in the replayed step: %.0f launches, %.2f ms" % (tor, tort))
+for k, (t, c) in sorted(fam.items(), key=lambda kv: -kv[1][0])[:40]:
+    print("%8.3f ms %7.1f launches  %s" % (t / 1e6 / steps, c / steps, k[:90]))
