@@ -256,6 +256,9 @@ def test_weight_planes_of_a_step_in_two_launches():
             torch.cuda.synchronize()
             assert got is not None and torch.equal(rows(got), rows(ref)) and torch.equal(got.inv, ref.inv), tuple(v.shape)
             assert K.weight_planes(v) is got
+        K.end_forward()                                         # outside the forward that made them: not handed out
+        assert all(batch.lookup(v) is None for v in views)
+        K.begin_forward()
         # an optimizer-like in-place update: the batch's planes are stale and must not be handed out
         with torch.no_grad():
             params[1].mul_(3.0)

@@ -238,3 +238,36 @@ def test_train_grads_vs_oracle_elementwise(variant, n, seeds, run_mode):
     loose = [r[1] for r in rows if not r[2] <= GRAD_RTOL * r[3] + GRAD_ATOL]
     assert within("tensors outside the plain 1e-3 bound (all of them scalar sf_coef gradients), of 32", len(loose), 32)
     assert all(k.endswith("sf_coef") for k in loose), loose
+
+
+def test_weight_planes_follow_raw_pointer_weight_updates():
+    """The planes of all conv weights are re-made by two launches at the start of EVERY forward — train and eval — and handed out
+    only inside that forward (kernels._WeightPlaneBatch).  The HIP optimizer writes weights through raw pointers, which no
+    Tensor._version sees: after such an update an eval forward must see the NEW weights.  Simulated with `.data` writes on the
+    spectral / expand / project weights; the outputs must equal, bit for bit, those of the same forward with the batch off."""
+    from unidefense_amd import kernels as K
+    from unidefense_amd.config import override
+    dev = _dev()
+    torch.manual_seed(3)
+    with override(spectral_p2="on", deterministic=True, gemm_tune=False):
+        m = _model(dev, 0.0, 0.3)
+        x = param_fill.make_input(2, 256, seed=5).to(dev)
+        tgt = param_fill.make_labels(2).to(dev)
+        m.train()
+        for _ in range(2):                       # first forward registers the weights, the second runs the batch
+            out = m(x, rng=ou.make_rng(2, 12, 0.5))
+            (out["cls_out"].sum() + out["loss_dict"]["spatial"].mean()).backward()
+        batch = m.__dict__["_ud_weight_planes"]
+        assert len(batch.entries) >= 60 and not batch.active
+        with torch.no_grad():
+            for n_, p in m.named_parameters():
+                if n_.endswith(("freq_conv.weight", "_expand_conv.weight", "_project_conv.weight")):
+                    p.data.mul_(1.25)            # like ud_adamw_multi: the version counter does not move
+        m.eval()
+        with torch.no_grad():
+            got = m(x)
+            with override(weight_plane_batch=False):
+                want = m(x)
+        torch.cuda.synchronize()
+        assert torch.equal(got["cls_out"], want["cls_out"]) and torch.equal(got["rec"], want["rec"])
+        assert not batch.active

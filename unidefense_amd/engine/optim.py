@@ -179,6 +179,8 @@ class HipAdamW(torch.optim.Optimizer):
                  float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), int(bool(ams)), int(bool(g0["maximize"])),
                  dp(grad_scale), dp(found_inf), s_in, s_out, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         self._cur = 1 - self._cur
+        # the kernel wrote the parameters through raw pointers: tell autograd (and anything keyed on Tensor._version)
+        torch._C._increment_version([p_ for group in self.param_groups for p_ in group["params"] if p_.grad is not None])
         return loss
 
     def step_count(self):

@@ -260,14 +260,19 @@ class _WeightPlaneBatch:
     (ud_split_planes_h2t_multi) instead of an absmax + a split launch per matrix (~50 matrices per step).  A weight registers on
     its first use (an eager step: never inside a graph capture); its planes live in a persistent buffer; begin() re-splits all
     registered weights from their CURRENT values and records each parameter's version, lookup() hands the planes out only while
-    that version still holds (an optimizer step in between -> the caller splits the matrix itself).  Entries die with their
-    parameter (weak references).  cfg.weight_plane_batch = False: off."""
+    that version still holds (an optimizer step in between -> the caller splits the matrix itself) AND only inside the forward
+    that made them (begin_forward ... end_forward: the HIP optimizer writes weights through raw pointers, which no version counter
+    sees).  One batch per model (kept on the module): a step captured into a hipGraph touches its own model's weights and plane
+    buffers only, which live as long as the model; device tables replaced by a rebuild are kept alive for graphs captured with
+    them.  Entries die with their parameter (weak references).  cfg.weight_plane_batch = False: off."""
 
     def __init__(self):
         self.entries = {}          # id(param) -> [weakref(param), Planes, version at the last begin(), shape2, data_ptr]
         self.table = self.slots = None
         self.dirty = False
         self.totals = (0, 0)
+        self.active = False        # inside the forward whose begin() made the planes
+        self.retired = []          # tables / slots of earlier builds (captured graphs may still launch with them)
 
     def _base(self, w2):
         b = w2._base if w2._base is not None else w2
@@ -278,7 +283,7 @@ class _WeightPlaneBatch:
         if b is None:
             return None
         e = self.entries.get(id(b))
-        if e is None or e[0]() is not b:
+        if e is None or e[0]() is not b or not self.active:
             return None
         return e[1] if (e[2] == b._version and e[3] == tuple(w2.shape) and e[4] == b.data_ptr()) else None
 
@@ -295,6 +300,7 @@ class _WeightPlaneBatch:
         self.dirty = True
 
     def begin(self):
+        self.active = False
         if not self.entries or not CFG.weight_plane_batch:
             return
         # a parameter that died, or whose storage was replaced (p.data = ..., a device move), invalidates the device table
@@ -313,6 +319,7 @@ class _WeightPlaneBatch:
               _stream())
         for e in self.entries.values():
             e[2] = e[0]()._version
+        self.active = True
 
     def _build(self):
         from .lib import SplitItem
@@ -332,19 +339,33 @@ class _WeightPlaneBatch:
             s0 += it.split_bx * pl.npanel
             e[2] = -1
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        if self.table is not None:
+            self.retired.append((self.table, self.slots))
         self.table = raw.to(dev)
         self.slots = torch.zeros(256 * len(self.entries), dtype=torch.int32, device=dev)
         self.totals = (a0, s0)
         self.dirty = False
 
 
-_WEIGHT_PLANES = _WeightPlaneBatch()
+_WEIGHT_PLANES = _WeightPlaneBatch()          # the batch of the forward in progress (default: a process-wide one for direct callers)
 
 
-def begin_forward():
-    """start of a model forward: fresh zero blocks, and the planes of all registered weight matrices in two launches"""
+def begin_forward(owner=None):
+    """start of a model forward: fresh zero blocks, and the planes of all of `owner`'s registered weight matrices in two
+    launches (owner: the nn.Module whose forward this is; its batch lives on it)"""
+    global _WEIGHT_PLANES
     reset_zero_pool()
+    if owner is not None:
+        batch = owner.__dict__.get("_ud_weight_planes")
+        if batch is None:
+            batch = owner.__dict__["_ud_weight_planes"] = _WeightPlaneBatch()
+        _WEIGHT_PLANES = batch
     _WEIGHT_PLANES.begin()
+
+
+def end_forward():
+    """end of the forward: the batch's planes are not handed out any more (weights may change before the next forward)"""
+    _WEIGHT_PLANES.active = False
 
 
 def weight_planes(w2):

@@ -114,12 +114,15 @@ def _half_storage(model):
 class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, noise_x, rng, *params):
-        K.begin_forward()          # fresh zero blocks (a captured step fills every block it carves from); weight planes in two launches
+        K.begin_forward(model)     # fresh zero blocks (a captured step fills every block it carves from); weight planes in two launches
         tape = T.Tape()
         debug = getattr(model, "_debug_watch", False)
         if debug:
             tape.kinks = {}
-        outs = model._run(x, tape, rng, noise_x)
+        try:
+            outs = model._run(x, tape, rng, noise_x)
+        finally:
+            K.end_forward()
         if debug:                                            # tests: capture activation gradients / ReLU patterns
             tape.watch = {id(t): k for k, t in outs["_feats"].items()}
             model._debug_tape = tape
@@ -262,7 +265,11 @@ class UniDefenseModelEb4(nn.Module):
             outs = dict(zip(self._out_keys, vals))
         else:
             with torch.no_grad():
-                outs = self._run(x, None, rng, noise_x)
+                K.begin_forward(self)
+                try:
+                    outs = self._run(x, None, rng, noise_x)
+                finally:
+                    K.end_forward()
         pending = self.__dict__.pop("_nbt_pending", None)
         if pending:
             torch._foreach_add_(pending, 1)
