@@ -271,3 +271,43 @@ def test_weight_planes_follow_raw_pointer_weight_updates():
         torch.cuda.synchronize()
         assert torch.equal(got["cls_out"], want["cls_out"]) and torch.equal(got["rec"], want["rec"])
         assert not batch.active
+
+
+def test_eval_mode_backward_vs_oracle():
+    """Backward through an EVAL-mode forward (BatchNorm on its running statistics, no dropout / drop-connect; the reference is
+    plain autograd, so fine-tuning on frozen statistics works there): parameter gradients of a smooth scalar of the outputs
+    against the oracle's autograd in float64, held to the same per-tensor bar as the training gradients."""
+    dev = _dev()
+    n = 2
+    m = _model(dev, 0.0, 0.3).eval()
+    x = param_fill.make_input(n, 256, 7)
+    sd = ou.oracle_state(0.0, 0.3, dtype=torch.float64, requires_grad=True)
+
+    def scalar(o):
+        ld = o["loss_dict"]
+        return (o["cls_out"] * o["cls_out"]).sum() + 10.0 * (o["rec"] * o["rec"]).mean() + ld["freq_mask"].mean() \
+            + ld["spat_mask"].mean() + sum((f * f).mean() for f in ld["triplet"])
+    ref = eb4.forward_eb4(sd, x.double(), training=False)
+    scalar(ref).backward()
+    out = m(x.to(dev))
+    assert out["cls_out"].requires_grad
+    scalar(out).backward()
+    torch.cuda.synchronize()
+    params = dict(m.named_parameters())
+    worst, bad, seen = 0.0, [], 0
+    for k, v in sd.items():
+        if not v.requires_grad or v.grad is None or k not in params:
+            continue
+        g, r = params[k].grad, v.grad
+        if g is None:
+            bad.append((k, "no gradient"))
+            continue
+        seen += 1
+        rn = float(r.abs().max())
+        e = float((g.double().cpu() - r).abs().max()) / (rn + 1e-30)
+        if rn > 1e-6:
+            worst = max(worst, e)
+            if e > GRAD_RTOL and float((g.double().cpu() - r).abs().max()) > GRAD_ATOL:
+                bad.append((k, e))
+    assert seen >= 480 and not bad, bad[:10]
+    assert within("eval-mode backward: worst gradient tensor, max|d| / max|ref|", worst, 1e-2)

@@ -259,7 +259,9 @@ class UniDefenseModelEb4(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("unidefense_amd runs on the GPU only (no CPU path); move the model and input to cuda")
         x = x.contiguous().to(torch.float32)
-        if self.training and torch.is_grad_enabled():
+        # a tape is built whenever autograd would record: training, or an eval-mode forward outside no_grad() whose
+        # parameters require gradients (fine-tuning on frozen BatchNorm statistics; the reference is plain autograd)
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
             params = tuple(self.parameters())
             vals = _NetFunction.apply(self, x, noise_x, rng, *params)
             outs = dict(zip(self._out_keys, vals))

@@ -412,14 +412,17 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
     if act == 2 and tape is not None and tape.kinks is not None:
         tape.kinks[id(weight)] = y
     if _needs(tape):
-        if not training:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
-
         def bwd():
             dy = tape.pop_grad(y)
             if dy is None:
                 return
-            if synced:
+            if not training:
+                # eval mode: the statistics are constants (running_mean / running_var), so dx = gamma * invstd * dz with
+                # dz = dy * act'(z) — the training formula with its two mean terms dropped (sums passed as zeros) — and
+                # dgamma = sum dz * xhat, dbeta = sum dz as in training
+                s, dg, db = K.norm_bwd_sums(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
+                dx = K.norm_bwd_apply(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, torch.zeros_like(s), 0.0, act)
+            elif synced:
                 import torch.distributed as dist
                 s, dg, db = K.norm_bwd_sums(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
                 dist.all_reduce(s, group=sync_group)           # sum_dz, sum_dz_xhat over all ranks
