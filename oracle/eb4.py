@@ -102,7 +102,7 @@ def batch_norm(x: Tensor, sd: Dict[str, Tensor], prefix: str, training: bool, ep
                momentum: float = 0.01, update_running: bool = False) -> Tensor:
     """nn.BatchNorm2d/1d (model.py:67,77,91,186,222; unidefense.py:104): batch statistics
     (biased var) in training, running stats in eval."""
-    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    w, b = sd.get(prefix + ".weight"), sd.get(prefix + ".bias")          # absent: norm(affine=False) (unidefense.py:38,61,116)
     dims = [0] + list(range(2, x.dim()))
     shape = [1, -1] + [1] * (x.dim() - 2)
     if training:
@@ -116,14 +116,15 @@ def batch_norm(x: Tensor, sd: Dict[str, Tensor], prefix: str, training: bool, ep
     else:
         mean, var = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
     xh = (x - mean.reshape(shape)) / torch.sqrt(var.reshape(shape) + eps)
-    return xh * w.reshape(shape) + b.reshape(shape)
+    return xh if w is None else xh * w.reshape(shape) + b.reshape(shape)
 
 
-def instance_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
-    """nn.InstanceNorm2d(affine=True), no running stats (model/unidefense.py:54,61)."""
+def instance_norm(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], eps: float = 1e-5) -> Tensor:
+    """nn.InstanceNorm2d(affine=affine), no running stats (model/unidefense.py:54,61); w = b = None: affine=False."""
     mean = x.mean((2, 3), keepdim=True)
     var = x.var((2, 3), unbiased=False, keepdim=True)
-    return (x - mean) / torch.sqrt(var + eps) * w.reshape(1, -1, 1, 1) + b.reshape(1, -1, 1, 1)
+    xh = (x - mean) / torch.sqrt(var + eps)
+    return xh if w is None else xh * w.reshape(1, -1, 1, 1) + b.reshape(1, -1, 1, 1)
 
 
 def conv_static_same(x: Tensor, w: Tensor, stride: int, pad, groups: int = 1, bias=None) -> Tensor:
@@ -196,14 +197,15 @@ def interpolate(x: Tensor, size) -> Tensor:
 def decoder_block(x: Tensor, sd: Dict[str, Tensor], prefix: str, last: bool) -> Tensor:
     """dec_block{1,2,3} (model/unidefense.py:59-102): conv3x3-IN-swish, convT(k3,s2,p1,op1)-IN-swish,
     conv3x3-IN-swish [, conv3x3 -> tanh]."""
-    x = F.conv2d(x, sd[prefix + ".0.weight"], None, 1, 1)
-    x = swish(instance_norm(x, sd[prefix + ".1.weight"], sd[prefix + ".1.bias"]))
-    x = F.conv_transpose2d(x, sd[prefix + ".3.weight"], None, 2, 1, 1)
-    x = swish(instance_norm(x, sd[prefix + ".4.weight"], sd[prefix + ".4.bias"]))
-    x = F.conv2d(x, sd[prefix + ".6.weight"], None, 1, 1)
-    x = swish(instance_norm(x, sd[prefix + ".7.weight"], sd[prefix + ".7.bias"]))
+    g = sd.get                                           # conv biases (bias=True) and norm affines (affine=True) are optional keys
+    x = F.conv2d(x, sd[prefix + ".0.weight"], g(prefix + ".0.bias"), 1, 1)
+    x = swish(instance_norm(x, g(prefix + ".1.weight"), g(prefix + ".1.bias")))
+    x = F.conv_transpose2d(x, sd[prefix + ".3.weight"], g(prefix + ".3.bias"), 2, 1, 1)
+    x = swish(instance_norm(x, g(prefix + ".4.weight"), g(prefix + ".4.bias")))
+    x = F.conv2d(x, sd[prefix + ".6.weight"], g(prefix + ".6.bias"), 1, 1)
+    x = swish(instance_norm(x, g(prefix + ".7.weight"), g(prefix + ".7.bias")))
     if last:
-        x = torch.tanh(F.conv2d(x, sd[prefix + ".9.weight"], None, 1, 1))
+        x = torch.tanh(F.conv2d(x, sd[prefix + ".9.weight"], g(prefix + ".9.bias"), 1, 1))
     return x
 
 
@@ -217,10 +219,10 @@ def dynamic_filter_generic(x: Tensor, diff: Tensor, sd: Dict[str, Tensor], prefi
                            pad: int, act) -> Dict[str, Tensor]:
     """FrequencyDynamicFilter / SpatialDynamicFilter .forward (model/modules.py:91-105, 120-134).
     att_norm = nn.BatchNorm2d with default eps 1e-5 (unidefense.py:55)."""
-    p = F.conv2d(x, sd[prefix + ".layer1.0.weight"], None, 1, pad)
+    p = F.conv2d(x, sd[prefix + ".layer1.0.weight"], sd.get(prefix + ".layer1.0.bias"), 1, pad)
     p = act(batch_norm(p, sd, prefix + ".layer1.1", training, 1e-5))
     pre = torch.cat([p.mean(1, keepdim=True), p.max(1, keepdim=True).values, diff], dim=1)
-    mask = torch.sigmoid(F.conv2d(pre, sd[prefix + ".layer2.0.weight"]))
+    mask = torch.sigmoid(F.conv2d(pre, sd[prefix + ".layer2.0.weight"], sd.get(prefix + ".layer2.0.bias")))
     return {"mask": mask, "out": mask * x, "proj": p}
 
 
@@ -331,8 +333,10 @@ def forward_eb4(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
 # --------------------------------------------------------------------------------------
 # State-dict shapes (so that weights can be generated without the reference present)
 # --------------------------------------------------------------------------------------
-def eb4_state_shapes(num_classes: int = 2, freq_norm: Optional[str] = "ortho") -> Dict[str, tuple]:
-    """{key: shape} for UniDefenseModelEb4 — 802 keys (SURVEY.md §5 'Checkpoint')."""
+def eb4_state_shapes(num_classes: int = 2, freq_norm: Optional[str] = "ortho", bias: bool = False,
+                     affine: bool = True) -> Dict[str, tuple]:
+    """{key: shape} for UniDefenseModelEb4 — 802 keys with the default bias=False, affine=True (SURVEY.md §5 'Checkpoint');
+    bias / affine: the constructor variants of model/unidefense.py:36-38 (decoder and filter convs, their norms)."""
     arch = eb4_arch(freq_norm=freq_norm)
     sh: Dict[str, tuple] = {}
 
@@ -367,14 +371,15 @@ def eb4_state_shapes(num_classes: int = 2, freq_norm: Optional[str] = "ortho") -
     bn("backbone._bn1", hd["cout"])
 
     def dec(prefix, cin, cout, last):
-        sh[prefix + ".0.weight"] = (cout, cin, 3, 3)
-        sh[prefix + ".1.weight"] = (cout,); sh[prefix + ".1.bias"] = (cout,)
-        sh[prefix + ".3.weight"] = (cout, cout, 3, 3)
-        sh[prefix + ".4.weight"] = (cout,); sh[prefix + ".4.bias"] = (cout,)
-        sh[prefix + ".6.weight"] = (cout, cout, 3, 3)
-        sh[prefix + ".7.weight"] = (cout,); sh[prefix + ".7.bias"] = (cout,)
-        if last:
-            sh[prefix + ".9.weight"] = (3, cout, 3, 3)
+        convs = [("0", (cout, cin, 3, 3)), ("3", (cout, cout, 3, 3)), ("6", (cout, cout, 3, 3))] + ([("9", (3, cout, 3, 3))] if last else [])
+        for i, shp in convs:
+            sh[f"{prefix}.{i}.weight"] = shp
+            if bias:
+                sh[f"{prefix}.{i}.bias"] = (shp[1] if i == "3" else shp[0],)          # ConvTranspose2d weight is [Cin, Cout, k, k]
+        if affine:
+            for i in ("1", "4", "7"):
+                sh[f"{prefix}.{i}.weight"] = (cout,)
+                sh[f"{prefix}.{i}.bias"] = (cout,)
 
     dec("dec_block1", 160, 80, False)
     dec("dec_block2", 80, 40, False)
@@ -383,11 +388,20 @@ def eb4_state_shapes(num_classes: int = 2, freq_norm: Optional[str] = "ortho") -
     sh["classifier.fc.weight"] = (num_classes, hd["cout"])
     sh["classifier.fc.bias"] = (num_classes,)
     d = 272
+    def bn_filter(prefix, c):
+        bn(prefix, c)
+        if not affine:
+            del sh[prefix + ".weight"], sh[prefix + ".bias"]
     sh["freq_filter.layer1.0.weight"] = (2 * d, 2 * d, 1, 1)
-    bn("freq_filter.layer1.1", 2 * d)
+    bn_filter("freq_filter.layer1.1", 2 * d)
     sh["freq_filter.layer2.0.weight"] = (1, 8, 1, 1)
     sh["spat_filter.layer1.0.weight"] = (d, d, 3, 3)
-    bn("spat_filter.layer1.1", d)
+    bn_filter("spat_filter.layer1.1", d)
     sh["spat_filter.layer2.0.weight"] = (1, 5, 1, 1)
+    if bias:
+        sh["freq_filter.layer1.0.bias"] = (2 * d,)
+        sh["freq_filter.layer2.0.bias"] = (1,)
+        sh["spat_filter.layer1.0.bias"] = (d,)
+        sh["spat_filter.layer2.0.bias"] = (1,)
     sh["fuse_coef"] = ()
     return sh

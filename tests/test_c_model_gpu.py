@@ -311,3 +311,68 @@ def test_eval_mode_backward_vs_oracle():
                 bad.append((k, e))
     assert seen >= 480 and not bad, bad[:10]
     assert within("eval-mode backward: worst gradient tensor, max|d| / max|ref|", worst, 1e-2)
+
+
+def _variant_model(dev, bias, affine):
+    from unidefense_amd.model import load_model
+    m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5, bias=bias, affine=affine)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("tag,bias,affine", [("bias_noaffine", True, False), ("bias", True, True), ("noaffine", False, False)])
+def test_constructor_variants_eval_vs_reference_golden(golden_dir, tag, bias, affine):
+    """The constructor variants no shipped YAML uses (model/unidefense.py:36-38: bias=True on the decoder / filter convs,
+    affine=False on their InstanceNorms / BatchNorms) against vectors recorded from the REFERENCE built the same way
+    (oracle/make_golden_variants.py, which also pins the oracle's handling of the two flags); state-dict keys as the reference's."""
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, f"udeb4_eval_n2_{tag}.npz"))
+    n, size, seed = [int(v) for v in g["meta"]]
+    m = _variant_model(dev, bias, affine).eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == eb4.eb4_state_shapes(2, bias=bias, affine=affine)
+    x = param_fill.make_input(n, size, seed).to(dev)
+    with torch.no_grad():
+        out = m(x)
+    _check_outputs(out, g)
+
+
+def test_constructor_variant_train_vs_reference_golden(golden_dir):
+    """bias=True + affine=False, train-mode forward + smooth pass-1 loss + backward at N = 2: outputs, losses and every
+    parameter gradient (norm + first 8 elements; the conv biases among them) against the reference's — the bar of the default
+    model's golden test."""
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "udeb4_train_n2_bias_noaffine.npz"))
+    n, size, seed, mseed = [int(v) for v in g["meta"]]
+    m = _variant_model(dev, True, False).train()
+    x = param_fill.make_input(n, size, seed).to(dev)
+    tgt = param_fill.make_labels(n).to(dev)
+    out = m(x, rng=ou.make_rng(n, mseed, 0.5))
+    _check_outputs(out, g)
+    ls = _pass1_loss(out, tgt, ou.SMOOTH_LAMBDAS)
+    for k, v in ls.items():
+        _, e = _close(v, g["smooth_loss_" + k], k)
+        assert within("loss " + k, e, RTOL), (k, e)
+    ls["total_loss"].backward()
+    names = [str(s) for s in g["grad_names"]]
+    params = dict(m.named_parameters())
+    assert sum(1 for k in names if k.endswith((".0.bias", ".3.bias", ".6.bias", ".9.bias"))) >= 13          # the conv biases
+    rows = []
+    for i, k in enumerate(names):
+        gr = params[k].grad
+        assert gr is not None, k
+        ref_norm = float(g["smooth_grad_norms"][i])
+        err = abs(gr.double().norm().item() - ref_norm)
+        head = gr.flatten()[:8].cpu().numpy()
+        herr = float(np.abs(head - g["smooth_grad_heads"][i][: head.size]).max())
+        rows.append((max(err, herr) / (ref_norm + GRAD_ATOL / GRAD_RTOL), k, err, herr, ref_norm))
+    rows.sort(reverse=True)
+    for r in rows[:8]:
+        print("  rel %.3e  %-58s norm err %.3e head err %.3e ref norm %.3e" % r)
+    # Batch statistics over a batch of 2: the reference's own fp32 run is off by up to ~3e-3 on the scalar sf_coef gradients
+    # (global sums with heavy cancellation; see the header) and a golden cannot supply the oracle's fp32-vs-fp64 yardstick —
+    # so the sf_coef scalars are held to 1e-2 here and every other tensor (the conv biases among them) to 3e-3.
+    scal = [r for r in rows if r[1].endswith("sf_coef")]
+    rest = [r for r in rows if not r[1].endswith("sf_coef")]
+    assert within("variant model, worst sf_coef gradient", scal[0][0], 1e-2)
+    assert within("variant model, worst other gradient tensor: max(norm err, head err) / (ref norm + floor)", rest[0][0], 3e-3)
+    assert len(rows) == len(names) >= 490

@@ -190,8 +190,6 @@ class UniDefenseModelEb4(nn.Module):
                  freq_norm: str = 'ortho',
                  **kwargs):
         super().__init__()
-        if bias or not affine:
-            raise NotImplementedError("the HIP path implements the reference's configs: bias=False, affine=True")
         self.arch = build_arch(extractor, freq_norm, kwargs.pop("image_size", None))
         if "drop_connect_rate" in kwargs:
             self.arch["drop_connect_rate"] = kwargs.pop("drop_connect_rate")
@@ -351,14 +349,15 @@ class UniDefenseModelEb4(nn.Module):
         return group
 
     def _decoder(self, tape, x, dec, last):
-        x = T.conv_dense(tape, x, dec[0].weight, 1, 1, 1, x.shape[1], x.shape[2])
+        # conv biases (bias=True) and norm affines (affine=False: weight / bias are None) follow the constructor variant
+        x = T.bias_add(tape, T.conv_dense(tape, x, dec[0].weight, 1, 1, 1, x.shape[1], x.shape[2]), dec[0].bias)
         x = T.instancenorm_act(tape, x, dec[1].weight, dec[1].bias, dec[1].eps, 1)
-        x = T.conv_transpose_s2(tape, x, dec[3].weight)
+        x = T.bias_add(tape, T.conv_transpose_s2(tape, x, dec[3].weight), dec[3].bias)
         x = T.instancenorm_act(tape, x, dec[4].weight, dec[4].bias, dec[4].eps, 1)
-        x = T.conv_dense(tape, x, dec[6].weight, 1, 1, 1, x.shape[1], x.shape[2])
+        x = T.bias_add(tape, T.conv_dense(tape, x, dec[6].weight, 1, 1, 1, x.shape[1], x.shape[2]), dec[6].bias)
         x = T.instancenorm_act(tape, x, dec[7].weight, dec[7].bias, dec[7].eps, 1)
         if last:
-            x = T.conv_dense(tape, x, dec[9].weight, 1, 1, 1, x.shape[1], x.shape[2])
+            x = T.bias_add(tape, T.conv_dense(tape, x, dec[9].weight, 1, 1, 1, x.shape[1], x.shape[2]), dec[9].bias)
         return x
 
     def _attention(self, tape, pred_planes, x_planes, emb, rng):
@@ -371,16 +370,16 @@ class UniDefenseModelEb4(nn.Module):
         freq_diff = K.absdiff(K.rfft2(pred, sf), K.rfft2(xs, sf))       # [N,h,w/2+1,6]
         emb_freq = T.rfft2_cat(tape, emb, norm)                         # [N,h,w/2+1,2C]
         ff = self.freq_filter
-        proj = T.conv1x1(tape, emb_freq, ff.layer1[0].weight)
+        proj = T.bias_add(tape, T.conv1x1(tape, emb_freq, ff.layer1[0].weight), ff.layer1[0].bias)
         proj = self._bn(tape, proj, ff.layer1[1], 1)
-        f_out, freq_mask = T.dynamic_filter(tape, emb_freq, proj, freq_diff, ff.layer2[0].weight)
+        f_out, freq_mask = T.dynamic_filter(tape, emb_freq, proj, freq_diff, ff.layer2[0].weight, ff.layer2[0].bias)
         freq_filtered = T.irfft2_split(tape, f_out, norm)
 
         spat_diff = K.absdiff(pred, xs)                                  # [N,h,w,3]
         sfm = self.spat_filter
-        proj = T.conv_dense(tape, emb, sfm.layer1[0].weight, 1, 1, 1, h, w)
+        proj = T.bias_add(tape, T.conv_dense(tape, emb, sfm.layer1[0].weight, 1, 1, 1, h, w), sfm.layer1[0].bias)
         proj = self._bn(tape, proj, sfm.layer1[1], 1)
-        s_out, spat_mask = T.dynamic_filter(tape, emb, proj, spat_diff, sfm.layer2[0].weight)
+        s_out, spat_mask = T.dynamic_filter(tape, emb, proj, spat_diff, sfm.layer2[0].weight, sfm.layer2[0].bias)
 
         out = T.gate_mix(tape, s_out, freq_filtered, self.fuse_coef)
         e = emb

@@ -119,6 +119,36 @@ def _needs(tape):
 # ---------------------------------------------------------------------------------------------
 # GEMM-shaped ops
 # ---------------------------------------------------------------------------------------------
+_CONST_AFFINE = {}
+
+
+def _const_affine(Cc, like):
+    """gamma = 1, beta = 0 for a norm built with affine=False (model/unidefense.py:38,61,116): constants, no gradients"""
+    key = (Cc, like.device)
+    v = _CONST_AFFINE.get(key)
+    if v is None:
+        v = _CONST_AFFINE[key] = (torch.ones(Cc, device=like.device), torch.zeros(Cc, device=like.device))
+    return v
+
+
+def bias_add(tape, y, b):
+    """+ the bias of a conv built with bias=True (model/unidefense.py:36,60-100; modules.py:82,87,111,116) on channel-last y.
+    No shipped config of the reference uses the variant, so these are plain device ops: a broadcast add, and a column sum for
+    the bias gradient."""
+    if b is None:
+        return y
+    out = y + b
+    if _needs(tape):
+        def bwd():
+            d = tape.pop_grad(out)
+            if d is None:
+                return
+            tape.add_grad(y, d)
+            tape.add_param_grad(b, d.reshape(-1, d.shape[-1]).sum(0))
+        tape.record(bwd)
+    return out
+
+
 def conv1x1(tape, x, w, need_dx=True):
     """F.conv2d with a [Cout,Cin,1,1] weight on pixel-major x[...,Cin] (model/efficientnet/model.py:108,125;
     exp.py:57; model/modules.py:82).  Backward = convolution_backward: dX = dY W, dW = dY^T X."""
@@ -387,13 +417,16 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
     Cc = x.shape[-1]
     x2 = x.view(-1, Cc)
     R = x2.shape[0]
+    affine = weight is not None
+    if not affine:
+        weight, bias = _const_affine(Cc, x)
     synced = False
     if training and sync_group is not None:
         import torch.distributed as dist
         synced = dist.get_world_size(sync_group) > 1 or cfg.force_collectives
     if synced and Cc % 4 == 0:
         return _syncbn_act(tape, x, x2, R, Cc, weight, bias, running_mean, running_var, eps, momentum, act, sync_group,
-                           exchange)
+                           exchange, affine)
     if synced:
         # channel counts the column kernels do not take (never in the reference's models): (mean, var) all_gather form
         world = dist.get_world_size(sync_group)
@@ -431,14 +464,16 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
             else:
                 dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
             tape.add_grad(x, dx.view(x.shape))
-            tape.add_param_grad(weight, dg)
-            if bias.requires_grad:
-                tape.add_param_grad(bias, db)
+            if affine:
+                tape.add_param_grad(weight, dg)
+                if bias.requires_grad:
+                    tape.add_param_grad(bias, db)
         tape.record(bwd)
     return y
 
 
-def _syncbn_act(tape, x, x2, R, Cc, weight, bias, running_mean, running_var, eps, momentum, act, sync_group, exchange):
+def _syncbn_act(tape, x, x2, R, Cc, weight, bias, running_mean, running_var, eps, momentum, act, sync_group, exchange,
+                affine=True):
     """SyncBatchNorm of the operator path (attention, head, the ResNet models) on the deferred-BatchNorm kernels of the
     fused path: fp64 column sums -> summed over the ranks in place (DataParallelCtx.reduce: BnExchange's mailbox kernel or
     one all_reduce) -> one apply pass that also moves the running statistics; the backward sums the same way.  Every rank
@@ -464,17 +499,21 @@ def _syncbn_act(tape, x, x2, R, Cc, weight, bias, running_mean, running_var, eps
             loc = dp.reduce(sb, keep_local=True)
             dx, dg, db = K.normbwd_apply(x2, dy2, None, 1.0, bn, False, 1, R, sb, loc, want_dbeta=bias.requires_grad)
             tape.add_grad(x, dx.view(x.shape))
-            tape.add_param_grad(weight, dg)
-            if bias.requires_grad:
-                tape.add_param_grad(bias, db)
+            if affine:
+                tape.add_param_grad(weight, dg)
+                if bias.requires_grad:
+                    tape.add_param_grad(bias, db)
         tape.record(bwd)
     return y
 
 
 def instancenorm_act(tape, x, weight, bias, eps, act):
-    """nn.InstanceNorm2d(affine=True) (+swish) on x[N,H,W,C]  (model/unidefense.py:61-70)."""
+    """nn.InstanceNorm2d(affine=affine) (+swish) on x[N,H,W,C]  (model/unidefense.py:61-70); weight = bias = None: affine=False."""
     N, H, W, Cc = x.shape
     x2 = x.view(-1, Cc)
+    affine = weight is not None
+    if not affine:
+        weight, bias = _const_affine(Cc, x)
     mean, invstd = K.norm_stats(x2, N, H * W, eps)
     y = K.norm_apply(x2, N, H * W, mean, invstd, weight, bias, act).view(x.shape)
     if act == 2 and tape is not None and tape.kinks is not None:
@@ -486,8 +525,9 @@ def instancenorm_act(tape, x, weight, bias, eps, act):
                 return
             dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), N, H * W, mean, invstd, weight, bias, act)
             tape.add_grad(x, dx.view(x.shape))
-            tape.add_param_grad(weight, dg)
-            tape.add_param_grad(bias, db)
+            if affine:
+                tape.add_param_grad(weight, dg)
+                tape.add_param_grad(bias, db)
         tape.record(bwd)
     return y
 
@@ -662,12 +702,16 @@ def rec_losses(tape, rec, x, norm):
     return spatial, freq
 
 
-def dynamic_filter(tape, x, proj, diff, w2):
-    """mask = sigmoid(conv1x1([mean_c proj, max_c proj, diff])), out = mask * x
-    (model/modules.py:94-104, 123-133).  x, proj: [N,h,w,*]; diff: [N,h,w,D] (no grad); w2: [1,2+D,1,1]."""
+def dynamic_filter(tape, x, proj, diff, w2, b2=None):
+    """mask = sigmoid(conv1x1([mean_c proj, max_c proj, diff]) (+ b2)), out = mask * x
+    (model/modules.py:94-104, 123-133).  x, proj: [N,h,w,*]; diff: [N,h,w,D] (no grad); w2: [1,2+D,1,1]; b2: [1] — the bias of
+    the bias=True variant rides as the weight of one more, constant-1 difference channel (the kernels take any D)."""
     Cx, Cp, D = x.shape[-1], proj.shape[-1], diff.shape[-1]
     x2, p2, d2 = x.view(-1, Cx), proj.view(-1, Cp), diff.view(-1, D)
     w2f = w2.view(-1)
+    if b2 is not None:
+        d2 = torch.cat([d2, torch.ones_like(d2[:, :1])], 1)
+        w2f = torch.cat([w2f.detach(), b2.detach().view(-1)])
     out2, mask, pre, argmax = K.dynfilter_fwd(p2, d2, w2f, x2)
     out = out2.view(x.shape)
     mask4 = mask.view(*x.shape[:-1], 1)
@@ -684,7 +728,12 @@ def dynamic_filter(tape, x, proj, diff, w2):
             tape.add_grad(x, dx.view(x.shape))
             tape.add_grad(proj, dproj.view(proj.shape))
             # dw2[j] = sum_m dlogit[m] * pre[m][j]   (8 or 5 numbers)
-            tape.add_param_grad(w2, K.gemm_tn(dlogit.view(-1, 1), pre).view(w2.shape))
+            g = K.gemm_tn(dlogit.view(-1, 1), pre)                 # [1, 2 + D (+ 1)]
+            if b2 is None:
+                tape.add_param_grad(w2, g.view(w2.shape))
+            else:
+                tape.add_param_grad(w2, g[:, :-1].reshape(w2.shape))
+                tape.add_param_grad(b2, g[:, -1].reshape(b2.shape))
         tape.record(bwd)
     return out, mask4
 
