@@ -85,5 +85,37 @@ def main():
         print(f"wrote udeb4_train_n2_{tag}.npz ({len(names)} grads)")
 
 
+def main_res():
+    """eval goldens of the two ResNet models built with bias=True, affine=False (model/unidefense.py:268-270, 448-450)"""
+    from oracle import r18, r50
+    from oracle.make_golden_r18 import pack
+    ref_model, _ = ref_import.import_reference()
+    torch.manual_seed(0)
+    for name, ctor, shapes, fwd, size in (("udr18", dict(extractor="resnet18"), r18.r18_state_shapes, r18.forward_r18, 128),
+                                          ("udr50", dict(extractor="resnet50"), r50.r50_state_shapes, r50.forward_r50, 256)):
+        m = ref_model.load_model("UDR18" if name == "udr18" else "UDR50")(num_classes=2, drop_rate=0.5, bias=True, affine=False,
+                                                                           **ctor)
+        want = shapes(2, bias=True, affine=False)
+        have = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert want == have, (sorted(set(want) ^ set(have))[:10], [k for k in want if k in have and want[k] != have[k]][:10])
+        param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+        x = param_fill.make_input(2, size, seed=3)
+        m.eval()
+        store = {}
+        with torch.no_grad():
+            out = m(x)
+            pack(out, store, "eval_")
+            ora = fwd(param_fill.fill_state_dict(want, 0.0, 0.3), x, training=False)
+        for k in ("cls_out", "rec"):
+            e = ((ora[k] - out[k]).abs().max() / out[k].abs().max()).item()
+            assert e < 1e-4, (name, k, e)
+        store["meta"] = np.array([2, size, 3], dtype=np.int64)
+        np.savez_compressed(os.path.join(OUT, f"{name}_eval_n2_bias_noaffine.npz"), **store)
+        print(f"wrote {name}_eval_n2_bias_noaffine.npz (oracle == reference on the eval outputs)")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "res":
+        main_res()
+    else:
+        main()

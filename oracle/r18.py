@@ -46,7 +46,7 @@ def _dep(pins):
 
 def sfconv2d(x: Tensor, sd: Dict[str, Tensor], prefix: str, stride: int, norm) -> Tensor:
     """SFConv2d.forward (model/resnet/exp.py:36-54): dense 3x3 conv (pad 1) + spectral 1x1 branch."""
-    spat = F.conv2d(x, sd[prefix + ".weight"], None, stride, 1)
+    spat = F.conv2d(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"), stride, 1)          # bias: the spatial branch only (exp.py:33,39)
     fx = rfft2_cat(x, norm)
     fx = F.conv2d(fx, sd[prefix + ".freq_conv.weight"])
     fx = irfft2_split(fx, x.shape[-2:], norm)
@@ -59,7 +59,7 @@ def sfconv2d(x: Tensor, sd: Dict[str, Tensor], prefix: str, stride: int, norm) -
 def _conv(x, sd, prefix, stride, norm):
     if prefix + ".sf_coef" in sd:
         return sfconv2d(x, sd, prefix, stride, norm)
-    return F.conv2d(x, sd[prefix + ".weight"], None, stride, 1)
+    return F.conv2d(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"), stride, 1)
 
 
 def basic_block(x: Tensor, sd, prefix: str, stride: int, training: bool, norm, pins=None) -> Tensor:
@@ -114,11 +114,11 @@ def max_pool_3s2_pinned(z: Tensor, sel: Tensor, tie_tol: float = 1e-4, stats: Op
 
 def emb_block1(x: Tensor, sd, training: bool, pool_sel: Optional[Tensor] = None, pins=None) -> Tensor:
     """EmbedderRes18Layer1.forward (module_exp.py:77-89); its SFConv2d has freq_norm=None (:68)."""
-    o = F.conv2d(x, sd["emb_block1.conv1.weight"], None, 2, 1)
+    o = F.conv2d(x, sd["emb_block1.conv1.weight"], sd.get("emb_block1.conv1.bias"), 2, 1)
     o = relu_site(batch_norm(o, sd, "emb_block1.norm1", training, 1e-5), "emb_block1.norm1", pins)
     o = sfconv2d(o, sd, "emb_block1.conv2", 1, None)
     o = batch_norm(o, sd, "emb_block1.norm2", training, 1e-5)
-    idt = F.conv2d(x, sd["emb_block1.downsample.0.weight"])
+    idt = F.conv2d(x, sd["emb_block1.downsample.0.weight"], sd.get("emb_block1.downsample.0.bias"))
     idt = batch_norm(idt, sd, "emb_block1.downsample.1", training, 1e-5)
     idt = F.max_pool2d(idt, 3, 2, 1) if pool_sel is None else max_pool_3s2_pinned(idt, pool_sel, stats=_dep(pins))
     return relu_site(o + idt, "emb_block1.add", pins)
@@ -128,15 +128,15 @@ def emb_block2(x: Tensor, sd, training: bool, pins=None) -> Tensor:
     """EmbedderRes18Layer2.forward (module_exp.py:100-111)."""
     o = sfconv2d(x, sd, "emb_block2.conv1", 1, None)
     o = relu_site(batch_norm(o, sd, "emb_block2.norm1", training, 1e-5), "emb_block2.norm1", pins)
-    o = F.conv2d(o, sd["emb_block2.conv2.weight"], None, 1, 1)
+    o = F.conv2d(o, sd["emb_block2.conv2.weight"], sd.get("emb_block2.conv2.bias"), 1, 1)
     o = batch_norm(o, sd, "emb_block2.norm2", training, 1e-5)
     return relu_site(o + x, "emb_block2.add", pins)
 
 
 def _dec(x, sd, prefix, idx_conv, transposed=False, pins=None):
-    w = sd[f"{prefix}.{idx_conv}.weight"]
-    x = F.conv_transpose2d(x, w, None, 2, 1, 1) if transposed else F.conv2d(x, w, None, 1, 1)
-    return relu_site(instance_norm(x, sd[f"{prefix}.{idx_conv + 1}.weight"], sd[f"{prefix}.{idx_conv + 1}.bias"]),
+    w, b = sd[f"{prefix}.{idx_conv}.weight"], sd.get(f"{prefix}.{idx_conv}.bias")
+    x = F.conv_transpose2d(x, w, b, 2, 1, 1) if transposed else F.conv2d(x, w, b, 1, 1)
+    return relu_site(instance_norm(x, sd.get(f"{prefix}.{idx_conv + 1}.weight"), sd.get(f"{prefix}.{idx_conv + 1}.bias")),
                      f"{prefix}.{idx_conv + 1}", pins)
 
 
@@ -159,7 +159,7 @@ def forward_r18(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
     d = _dec(dec1, sd, "dec_block2", 0, pins=pins)
     d = _dec(d, sd, "dec_block2", 3, transposed=True, pins=pins)
     d = _dec(d, sd, "dec_block2", 6, pins=pins)
-    dec2 = torch.tanh(F.conv2d(d, sd["dec_block2.9.weight"], None, 1, 1))
+    dec2 = torch.tanh(F.conv2d(d, sd["dec_block2.9.weight"], sd.get("dec_block2.9.bias"), 1, 1))
 
     emb = emb_block1(ext, sd, training, rng.get("pool_sel"), pins)
     # attention (model/unidefense.py:326-361): ReLU filters, att_depth 512
@@ -203,7 +203,8 @@ def forward_r18(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
             "_feats": {"ext": ext, "emb": emb, "dec1": dec1, "dec2": dec2, "att_out": att}}
 
 
-def r18_state_shapes(num_classes: int = 2, mid_depth: int = 448) -> Dict[str, tuple]:
+def r18_state_shapes(num_classes: int = 2, mid_depth: int = 448, bias: bool = False, affine: bool = True) -> Dict[str, tuple]:
+    """bias / affine: the constructor variants of model/unidefense.py:268-270 (embedder, decoder and filter convs; their norms)"""
     sh: Dict[str, tuple] = {}
 
     def bn(p, c):
@@ -236,22 +237,32 @@ def r18_state_shapes(num_classes: int = 2, mid_depth: int = 448) -> Dict[str, tu
                 sh[p + ".downsample.0.weight"] = (planes, cin, 1, 1)
                 bn(p + ".downsample.1", planes)
         inpl = planes
-    sh["emb_block1.conv1.weight"] = (512, mid_depth, 3, 3)
-    bn("emb_block1.norm1", 512)
-    sf("emb_block1.conv2", 512)
-    bn("emb_block1.norm2", 512)
-    sh["emb_block1.downsample.0.weight"] = (512, mid_depth, 1, 1)
-    bn("emb_block1.downsample.1", 512)
-    sf("emb_block2.conv1", 512)
-    bn("emb_block2.norm1", 512)
-    sh["emb_block2.conv2.weight"] = (512, 512, 3, 3)
-    bn("emb_block2.norm2", 512)
+    def nrm(p, c):          # a norm the affine flag reaches
+        bn(p, c)
+        if not affine:
+            del sh[p + ".weight"], sh[p + ".bias"]
+
+    def cb(p, c):           # a conv the bias flag reaches
+        if bias:
+            sh[p + ".bias"] = (c,)
+
+    sh["emb_block1.conv1.weight"] = (512, mid_depth, 3, 3); cb("emb_block1.conv1", 512)
+    nrm("emb_block1.norm1", 512)
+    sf("emb_block1.conv2", 512); cb("emb_block1.conv2", 512)
+    nrm("emb_block1.norm2", 512)
+    sh["emb_block1.downsample.0.weight"] = (512, mid_depth, 1, 1); cb("emb_block1.downsample.0", 512)
+    nrm("emb_block1.downsample.1", 512)
+    sf("emb_block2.conv1", 512); cb("emb_block2.conv1", 512)
+    nrm("emb_block2.norm1", 512)
+    sh["emb_block2.conv2.weight"] = (512, 512, 3, 3); cb("emb_block2.conv2", 512)
+    nrm("emb_block2.norm2", 512)
 
     def dec(prefix, specs):
         for idx, (co, ci) in specs:
             sh[f"{prefix}.{idx}.weight"] = (co, ci, 3, 3)
-            if idx != 9:
-                sh[f"{prefix}.{idx + 1}.weight"] = (co,) if idx != 3 else (co,)
+            cb(f"{prefix}.{idx}", co)
+            if idx != 9 and affine:
+                sh[f"{prefix}.{idx + 1}.weight"] = (co,)
                 sh[f"{prefix}.{idx + 1}.bias"] = (co,)
 
     dec("dec_block1", [(0, (128, mid_depth)), (3, (128, 128)), (6, (128, 128))])
@@ -259,10 +270,10 @@ def r18_state_shapes(num_classes: int = 2, mid_depth: int = 448) -> Dict[str, tu
     bn("bottleneck", 512)
     sh["classifier.fc.weight"] = (num_classes, 512)
     sh["classifier.fc.bias"] = (num_classes,)
-    sh["freq_filter.layer1.0.weight"] = (1024, 1024, 1, 1)
-    bn("freq_filter.layer1.1", 1024)
-    sh["freq_filter.layer2.0.weight"] = (1, 8, 1, 1)
-    sh["spat_filter.layer1.0.weight"] = (512, 512, 3, 3)
-    bn("spat_filter.layer1.1", 512)
-    sh["spat_filter.layer2.0.weight"] = (1, 5, 1, 1)
+    sh["freq_filter.layer1.0.weight"] = (1024, 1024, 1, 1); cb("freq_filter.layer1.0", 1024)
+    nrm("freq_filter.layer1.1", 1024)
+    sh["freq_filter.layer2.0.weight"] = (1, 8, 1, 1); cb("freq_filter.layer2.0", 1)
+    sh["spat_filter.layer1.0.weight"] = (512, 512, 3, 3); cb("spat_filter.layer1.0", 512)
+    nrm("spat_filter.layer1.1", 512)
+    sh["spat_filter.layer2.0.weight"] = (1, 5, 1, 1); cb("spat_filter.layer2.0", 1)
     return sh

@@ -51,13 +51,13 @@ def extractor(x: Tensor, sd, training: bool, norm, pins=None, pool_sel=None) -> 
 
 def emb_block1(x: Tensor, sd, training: bool, pool_sel=None, pins=None) -> Tensor:
     """EmbedderRes50Layer1.forward (module_exp.py:131-148); its SFConv2d has freq_norm=None and stride 2."""
-    o = F.conv2d(x, sd["emb_block1.conv1.weight"])
+    o = F.conv2d(x, sd["emb_block1.conv1.weight"], sd.get("emb_block1.conv1.bias"))
     o = relu_site(batch_norm(o, sd, "emb_block1.norm1", training, 1e-5), "emb_block1.norm1", pins)
     o = _conv(o, sd, "emb_block1.conv2", 2, None)
     o = relu_site(batch_norm(o, sd, "emb_block1.norm2", training, 1e-5), "emb_block1.norm2", pins)
-    o = F.conv2d(o, sd["emb_block1.conv3.weight"])
+    o = F.conv2d(o, sd["emb_block1.conv3.weight"], sd.get("emb_block1.conv3.bias"))
     o = batch_norm(o, sd, "emb_block1.norm3", training, 1e-5)
-    idt = F.conv2d(x, sd["emb_block1.downsample.0.weight"])
+    idt = F.conv2d(x, sd["emb_block1.downsample.0.weight"], sd.get("emb_block1.downsample.0.bias"))
     idt = batch_norm(idt, sd, "emb_block1.downsample.1", training, 1e-5)
     idt = _pool(idt, pool_sel, pins)
     return relu_site(o + idt, "emb_block1.add", pins)
@@ -65,11 +65,11 @@ def emb_block1(x: Tensor, sd, training: bool, pool_sel=None, pins=None) -> Tenso
 
 def emb_block2(x: Tensor, sd, training: bool, pins=None) -> Tensor:
     """EmbedderRes50Layer2.forward (module_exp.py:163-177)."""
-    o = F.conv2d(x, sd["emb_block2.conv1.weight"])
+    o = F.conv2d(x, sd["emb_block2.conv1.weight"], sd.get("emb_block2.conv1.bias"))
     o = relu_site(batch_norm(o, sd, "emb_block2.norm1", training, 1e-5), "emb_block2.norm1", pins)
     o = _conv(o, sd, "emb_block2.conv2", 1, None)
     o = relu_site(batch_norm(o, sd, "emb_block2.norm2", training, 1e-5), "emb_block2.norm2", pins)
-    o = F.conv2d(o, sd["emb_block2.conv3.weight"])
+    o = F.conv2d(o, sd["emb_block2.conv3.weight"], sd.get("emb_block2.conv3.bias"))
     o = batch_norm(o, sd, "emb_block2.norm3", training, 1e-5)
     return relu_site(o + x, "emb_block2.add", pins)
 
@@ -94,7 +94,7 @@ def forward_r50(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
     d = _dec(dec2, sd, "dec_block3", 0, pins=pins)
     d = _dec(d, sd, "dec_block3", 3, transposed=True, pins=pins)
     d = _dec(d, sd, "dec_block3", 6, pins=pins)
-    dec3 = torch.tanh(F.conv2d(d, sd["dec_block3.9.weight"], None, 1, 1))
+    dec3 = torch.tanh(F.conv2d(d, sd["dec_block3.9.weight"], sd.get("dec_block3.9.bias"), 1, 1))
 
     emb = emb_block1(ext, sd, training, psel.get("emb"), pins)
     size = emb.shape[-2:]
@@ -137,7 +137,7 @@ def forward_r50(sd: Dict[str, Tensor], x: Tensor, training: bool = False, drop_r
             "_feats": {"ext": ext, "emb": emb, "dec1": dec1, "dec3": dec3, "att_out": att}}
 
 
-def r50_state_shapes(num_classes: int = 2, mid_depth: int = 1024) -> Dict[str, tuple]:
+def r50_state_shapes(num_classes: int = 2, mid_depth: int = 1024, bias: bool = False, affine: bool = True) -> Dict[str, tuple]:
     sh: Dict[str, tuple] = {}
 
     def bn(p, c):
@@ -168,20 +168,30 @@ def r50_state_shapes(num_classes: int = 2, mid_depth: int = 1024) -> Dict[str, t
                 sh[p + ".downsample.0.weight"] = (planes * 4, cin, 1, 1)
                 bn(p + ".downsample.1", planes * 4)
         inpl = planes * 4
+    def nrm(p, c):          # a norm the affine flag reaches (model/unidefense.py:450,461-495)
+        bn(p, c)
+        if not affine:
+            del sh[p + ".weight"], sh[p + ".bias"]
+
+    def cb(p, c):           # a conv the bias flag reaches
+        if bias:
+            sh[p + ".bias"] = (c,)
+
     for blk, cin in (("emb_block1", mid_depth), ("emb_block2", 2048)):
-        sh[f"{blk}.conv1.weight"] = (512, cin, 1, 1)
-        bn(f"{blk}.norm1", 512)
-        sf(f"{blk}.conv2", 512)
-        bn(f"{blk}.norm2", 512)
-        sh[f"{blk}.conv3.weight"] = (2048, 512, 1, 1)
-        bn(f"{blk}.norm3", 2048)
-    sh["emb_block1.downsample.0.weight"] = (2048, mid_depth, 1, 1)
-    bn("emb_block1.downsample.1", 2048)
+        sh[f"{blk}.conv1.weight"] = (512, cin, 1, 1); cb(f"{blk}.conv1", 512)
+        nrm(f"{blk}.norm1", 512)
+        sf(f"{blk}.conv2", 512); cb(f"{blk}.conv2", 512)
+        nrm(f"{blk}.norm2", 512)
+        sh[f"{blk}.conv3.weight"] = (2048, 512, 1, 1); cb(f"{blk}.conv3", 2048)
+        nrm(f"{blk}.norm3", 2048)
+    sh["emb_block1.downsample.0.weight"] = (2048, mid_depth, 1, 1); cb("emb_block1.downsample.0", 2048)
+    nrm("emb_block1.downsample.1", 2048)
 
     def dec(prefix, specs):
         for idx, (co, ci) in specs:
             sh[f"{prefix}.{idx}.weight"] = (ci, co, 3, 3) if idx == 3 else (co, ci, 3, 3)     # idx 3: ConvTranspose2d
-            if not (prefix == "dec_block3" and idx == 9):
+            cb(f"{prefix}.{idx}", co)
+            if not (prefix == "dec_block3" and idx == 9) and affine:
                 sh[f"{prefix}.{idx + 1}.weight"] = (co,)
                 sh[f"{prefix}.{idx + 1}.bias"] = (co,)
 
@@ -191,10 +201,10 @@ def r50_state_shapes(num_classes: int = 2, mid_depth: int = 1024) -> Dict[str, t
     bn("bottleneck", 2048)
     sh["classifier.fc.weight"] = (num_classes, 2048)
     sh["classifier.fc.bias"] = (num_classes,)
-    sh["freq_filter.layer1.0.weight"] = (4096, 4096, 1, 1)
-    bn("freq_filter.layer1.1", 4096)
-    sh["freq_filter.layer2.0.weight"] = (1, 8, 1, 1)
-    sh["spat_filter.layer1.0.weight"] = (2048, 2048, 3, 3)
-    bn("spat_filter.layer1.1", 2048)
-    sh["spat_filter.layer2.0.weight"] = (1, 5, 1, 1)
+    sh["freq_filter.layer1.0.weight"] = (4096, 4096, 1, 1); cb("freq_filter.layer1.0", 4096)
+    nrm("freq_filter.layer1.1", 4096)
+    sh["freq_filter.layer2.0.weight"] = (1, 8, 1, 1); cb("freq_filter.layer2.0", 1)
+    sh["spat_filter.layer1.0.weight"] = (2048, 2048, 3, 3); cb("spat_filter.layer1.0", 2048)
+    nrm("spat_filter.layer1.1", 2048)
+    sh["spat_filter.layer2.0.weight"] = (1, 5, 1, 1); cb("spat_filter.layer2.0", 1)
     return sh

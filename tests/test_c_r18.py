@@ -247,3 +247,34 @@ def test_r18_vs_reference_golden_and_oracle(golden_dir):
     within("worst gradient tensor: max err / max(floor, 5 x oracle fp32 err, 5 x one-ulp sensitivity)", rows[0][0], 1.0)
     bad = [r for r in rows if not r[0] < 1.0]
     assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size", [("UDR18", 128), ("UDR50", 256)])
+def test_resnet_constructor_variant_eval_vs_reference_golden(golden_dir, name, size):
+    """bias=True + affine=False on the embedder / decoder / filter convs and norms of the two ResNet models (model/unidefense.py:
+    268-270, 448-450; resnet/module_exp.py:62-75: the SFConv's bias sits on its spatial branch) against eval outputs recorded
+    from the reference built the same way (oracle/make_golden_variants.py res); state-dict keys as the reference's; and a
+    train-mode backward runs through every bias (their gradients are finite and non-zero)."""
+    dev = _dev()
+    from unidefense_amd.model import load_model
+    from oracle import r50
+    g = np.load(os.path.join(golden_dir, f"{name.lower()}_eval_n2_bias_noaffine.npz"))
+    n, sz, seed = [int(v) for v in g["meta"]]
+    assert sz == size
+    m = load_model(name)(num_classes=2, drop_rate=0.5, bias=True, affine=False)
+    want = (r18.r18_state_shapes if name == "UDR18" else r50.r50_state_shapes)(2, bias=True, affine=False)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev)
+    x = param_fill.make_input(n, size, seed).to(dev)
+    with torch.no_grad():
+        _check_outputs(m.eval()(x), g, "eval_", 1e-3)
+    m.train()
+    out = m(x)
+    (out["cls_out"].sum() + out["rec"].mean() + out["loss_dict"]["freq_mask"].mean() + out["loss_dict"]["spat_mask"].mean()).backward()
+    biases = [(k, p) for k, p in m.named_parameters() if k.endswith(".bias") and k.split(".")[0] in
+              ("emb_block1", "emb_block2", "dec_block1", "dec_block2", "dec_block3", "freq_filter", "spat_filter")]
+    assert len(biases) >= 16
+    for k, p in biases:
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k

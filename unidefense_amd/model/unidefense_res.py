@@ -18,8 +18,8 @@ from .unidefense import Classifier, UniDefenseModelEb4, _FilterParams
 class _SFConv2dParams(nn.Conv2d):
     """model/resnet/exp.py:21-34 (SFConv2d: dense conv weight + freq_conv + sf_coef)."""
 
-    def __init__(self, cin, cout, k=3, freq_norm=None):
-        super().__init__(cin, cout, k, padding=1, bias=False)
+    def __init__(self, cin, cout, k=3, freq_norm=None, bias=False):
+        super().__init__(cin, cout, k, padding=1, bias=bias)
         self.freq_norm = freq_norm
         self.freq_conv = nn.Conv2d(cin * 2, cout * 2, kernel_size=1, bias=False)
         self.sf_coef = nn.Parameter(torch.tensor(-10.0))
@@ -64,39 +64,39 @@ class _ExtractorRes18(nn.Module):
 class _Emb1Params(nn.Module):
     """EmbedderRes18Layer1 (module_exp.py:62-75)."""
 
-    def __init__(self, in_depth):
+    def __init__(self, in_depth, bias=False, affine=True):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_depth, 512, 3, 2, padding=1, bias=False)
-        self.norm1 = nn.BatchNorm2d(512)
-        self.conv2 = _SFConv2dParams(512, 512, 3, None)
-        self.norm2 = nn.BatchNorm2d(512)
-        self.downsample = nn.Sequential(nn.Conv2d(in_depth, 512, 1, bias=False), nn.BatchNorm2d(512), nn.Identity())
+        self.conv1 = nn.Conv2d(in_depth, 512, 3, 2, padding=1, bias=bias)
+        self.norm1 = nn.BatchNorm2d(512, affine=affine)
+        self.conv2 = _SFConv2dParams(512, 512, 3, None, bias=bias)
+        self.norm2 = nn.BatchNorm2d(512, affine=affine)
+        self.downsample = nn.Sequential(nn.Conv2d(in_depth, 512, 1, bias=bias), nn.BatchNorm2d(512, affine=affine), nn.Identity())
 
 
 class _Emb2Params(nn.Module):
     """EmbedderRes18Layer2 (module_exp.py:92-98)."""
 
-    def __init__(self):
+    def __init__(self, bias=False, affine=True):
         super().__init__()
-        self.conv1 = _SFConv2dParams(512, 512, 3, None)
-        self.norm1 = nn.BatchNorm2d(512)
-        self.conv2 = nn.Conv2d(512, 512, 3, 1, padding=1, bias=False)
-        self.norm2 = nn.BatchNorm2d(512)
+        self.conv1 = _SFConv2dParams(512, 512, 3, None, bias=bias)
+        self.norm1 = nn.BatchNorm2d(512, affine=affine)
+        self.conv2 = nn.Conv2d(512, 512, 3, 1, padding=1, bias=bias)
+        self.norm2 = nn.BatchNorm2d(512, affine=affine)
 
 
-def _dec1(cin):
-    return nn.Sequential(nn.Conv2d(cin, 128, 3, 1, 1, bias=False), nn.InstanceNorm2d(128, affine=True), nn.Identity(),
-                         nn.ConvTranspose2d(128, 128, 3, 2, 1, output_padding=1, bias=False),
-                         nn.InstanceNorm2d(128, affine=True), nn.Identity(),
-                         nn.Conv2d(128, 128, 3, 1, 1, bias=False), nn.InstanceNorm2d(128, affine=True), nn.Identity())
+def _dec1(cin, bias=False, affine=True):
+    return nn.Sequential(nn.Conv2d(cin, 128, 3, 1, 1, bias=bias), nn.InstanceNorm2d(128, affine=affine), nn.Identity(),
+                         nn.ConvTranspose2d(128, 128, 3, 2, 1, output_padding=1, bias=bias),
+                         nn.InstanceNorm2d(128, affine=affine), nn.Identity(),
+                         nn.Conv2d(128, 128, 3, 1, 1, bias=bias), nn.InstanceNorm2d(128, affine=affine), nn.Identity())
 
 
-def _dec2():
-    return nn.Sequential(nn.Conv2d(128, 64, 3, 1, 1, bias=False), nn.InstanceNorm2d(64, affine=True), nn.Identity(),
-                         nn.ConvTranspose2d(64, 64, 3, 2, 1, output_padding=1, bias=False),
-                         nn.InstanceNorm2d(64, affine=True), nn.Identity(),
-                         nn.Conv2d(64, 32, 3, 1, 1, bias=False), nn.InstanceNorm2d(32, affine=True), nn.Identity(),
-                         nn.Conv2d(32, 3, 3, 1, 1, bias=False), nn.Identity())
+def _dec2(bias=False, affine=True):
+    return nn.Sequential(nn.Conv2d(128, 64, 3, 1, 1, bias=bias), nn.InstanceNorm2d(64, affine=affine), nn.Identity(),
+                         nn.ConvTranspose2d(64, 64, 3, 2, 1, output_padding=1, bias=bias),
+                         nn.InstanceNorm2d(64, affine=affine), nn.Identity(),
+                         nn.Conv2d(64, 32, 3, 1, 1, bias=bias), nn.InstanceNorm2d(32, affine=affine), nn.Identity(),
+                         nn.Conv2d(32, 3, 3, 1, 1, bias=bias), nn.Identity())
 
 
 class UniDefenseModelRes18(nn.Module):
@@ -123,15 +123,15 @@ class UniDefenseModelRes18(nn.Module):
                  freq_norm: str = 'ortho',
                  **kwargs):
         super().__init__()
-        if bias or not affine or extractor != "resnet18":
-            raise NotImplementedError("HIP path implements the reference's UDR18 config: resnet18, bias=False, affine=True")
+        if extractor != "resnet18":
+            raise NotImplementedError("HIP path implements the reference's UDR18 config: resnet18")
         self.freq_norm = freq_norm
         self.drop_rate = drop_rate
         self.extractor = _ExtractorRes18(freq_norm)
-        self.emb_block1 = _Emb1Params(mid_depth)
-        self.emb_block2 = _Emb2Params()
-        self.dec_block1 = _dec1(mid_depth)
-        self.dec_block2 = _dec2()
+        self.emb_block1 = _Emb1Params(mid_depth, bias, affine)
+        self.emb_block2 = _Emb2Params(bias, affine)
+        self.dec_block1 = _dec1(mid_depth, bias, affine)
+        self.dec_block2 = _dec2(bias, affine)
         self.bottleneck = nn.BatchNorm1d(512)
         self.bottleneck.bias.requires_grad_(False)
         nn.init.constant_(self.bottleneck.weight, 1.0)
@@ -151,8 +151,8 @@ class UniDefenseModelRes18(nn.Module):
     # ---------------------------------------------------------------------------------------
     def _conv(self, tape, x, conv, stride):
         if isinstance(conv, _SFConv2dParams):
-            return T.sfconv_dense(tape, x, conv.weight, conv.freq_conv.weight, conv.sf_coef, stride, conv.freq_norm)
-        return T.conv_dense_any(tape, x, conv.weight, stride, conv.padding[0])
+            return T.sfconv_dense(tape, x, conv.weight, conv.freq_conv.weight, conv.sf_coef, stride, conv.freq_norm, conv.bias)
+        return T.bias_add(tape, T.conv_dense_any(tape, x, conv.weight, stride, conv.padding[0]), conv.bias)
 
     def _basic_block(self, tape, x, blk):
         """BasicBlock.forward (model/resnet/exp.py:127-149)."""
@@ -175,6 +175,7 @@ class UniDefenseModelRes18(nn.Module):
     def _dec(self, tape, x, dec, idx, transposed=False):
         x = T.conv_transpose_s2(tape, x, dec[idx].weight) if transposed else \
             T.conv_dense_any(tape, x, dec[idx].weight, 1, 1)
+        x = T.bias_add(tape, x, dec[idx].bias)
         return T.instancenorm_act(tape, x, dec[idx + 1].weight, dec[idx + 1].bias, dec[idx + 1].eps, 2)
 
     def _prepare_rng(self, rng):
@@ -204,16 +205,16 @@ class UniDefenseModelRes18(nn.Module):
         d = self._dec(tape, dec1, self.dec_block2, 0)
         d = self._dec(tape, d, self.dec_block2, 3, transposed=True)
         d = self._dec(tape, d, self.dec_block2, 6)
-        d = T.conv_dense_any(tape, d, self.dec_block2[9].weight, 1, 1)
+        d = T.bias_add(tape, T.conv_dense_any(tape, d, self.dec_block2[9].weight, 1, 1), self.dec_block2[9].bias)
         dec2 = T.tanh_to_planes(tape, d)                                 # [N,3,H/2,W/2]
 
         # EmbedderRes18Layer1 (module_exp.py:77-89)
         e1 = self.emb_block1
-        o = T.conv_dense_any(tape, ext, e1.conv1.weight, 2, 1)
+        o = T.bias_add(tape, T.conv_dense_any(tape, ext, e1.conv1.weight, 2, 1), e1.conv1.bias)
         o = self._bn(tape, o, e1.norm1, 2)
         o = self._conv(tape, o, e1.conv2, 1)
         o = self._bn(tape, o, e1.norm2, 0)
-        idt = T.conv1x1(tape, ext, e1.downsample[0].weight)
+        idt = T.bias_add(tape, T.conv1x1(tape, ext, e1.downsample[0].weight), e1.downsample[0].bias)
         idt = self._bn(tape, idt, e1.downsample[1], 0)
         idt, pool_sel = T.maxpool3s2(tape, idt, return_arg=True)
         emb = T.add_relu(tape, o, idt, site="emb_block1.add")
@@ -227,15 +228,15 @@ class UniDefenseModelRes18(nn.Module):
         freq_diff = K.absdiff(K.rfft2(pred, sf), K.rfft2(xs, sf))
         emb_freq = T.rfft2_cat(tape, emb, norm)
         ff = self.freq_filter
-        proj = T.conv1x1(tape, emb_freq, ff.layer1[0].weight)
+        proj = T.bias_add(tape, T.conv1x1(tape, emb_freq, ff.layer1[0].weight), ff.layer1[0].bias)
         proj = self._bn(tape, proj, ff.layer1[1], 2)
-        f_out, freq_mask = T.dynamic_filter(tape, emb_freq, proj, freq_diff, ff.layer2[0].weight)
+        f_out, freq_mask = T.dynamic_filter(tape, emb_freq, proj, freq_diff, ff.layer2[0].weight, ff.layer2[0].bias)
         freq_filtered = T.irfft2_split(tape, f_out, norm)
         spat_diff = K.absdiff(pred, xs)
         sfm = self.spat_filter
-        proj = T.conv_dense_any(tape, emb, sfm.layer1[0].weight, 1, 1)
+        proj = T.bias_add(tape, T.conv_dense_any(tape, emb, sfm.layer1[0].weight, 1, 1), sfm.layer1[0].bias)
         proj = self._bn(tape, proj, sfm.layer1[1], 2)
-        s_out, spat_mask = T.dynamic_filter(tape, emb, proj, spat_diff, sfm.layer2[0].weight)
+        s_out, spat_mask = T.dynamic_filter(tape, emb, proj, spat_diff, sfm.layer2[0].weight, sfm.layer2[0].bias)
         att = T.gate_mix(tape, s_out, freq_filtered, self.fuse_coef)
         e = emb
         if self.training and self.drop_rate > 0:
@@ -246,7 +247,7 @@ class UniDefenseModelRes18(nn.Module):
         e2 = self.emb_block2
         o = self._conv(tape, att, e2.conv1, 1)
         o = self._bn(tape, o, e2.norm1, 2)
-        o = T.conv_dense_any(tape, o, e2.conv2.weight, 1, 1)
+        o = T.bias_add(tape, T.conv_dense_any(tape, o, e2.conv2.weight, 1, 1), e2.conv2.bias)
         o = self._bn(tape, o, e2.norm2, 0)
         h = T.add_relu(tape, o, att, site="emb_block2.add")
 

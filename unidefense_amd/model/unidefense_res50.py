@@ -63,25 +63,26 @@ class _ExtractorRes50(nn.Module):
 class _Emb50Params(nn.Module):
     """EmbedderRes50Layer1 / Layer2 (module_exp.py:112-129, 151-161)."""
 
-    def __init__(self, in_depth, downsample):
+    def __init__(self, in_depth, downsample, bias=False, affine=True):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_depth, 512, 1, bias=False)
-        self.norm1 = nn.BatchNorm2d(512)
-        self.conv2 = _SFConv2dParams(512, 512, 3, None)
-        self.norm2 = nn.BatchNorm2d(512)
-        self.conv3 = nn.Conv2d(512, 2048, 1, bias=False)
-        self.norm3 = nn.BatchNorm2d(2048)
+        self.conv1 = nn.Conv2d(in_depth, 512, 1, bias=bias)
+        self.norm1 = nn.BatchNorm2d(512, affine=affine)
+        self.conv2 = _SFConv2dParams(512, 512, 3, None, bias=bias)
+        self.norm2 = nn.BatchNorm2d(512, affine=affine)
+        self.conv3 = nn.Conv2d(512, 2048, 1, bias=bias)
+        self.norm3 = nn.BatchNorm2d(2048, affine=affine)
         if downsample:
-            self.downsample = nn.Sequential(nn.Conv2d(in_depth, 2048, 1, bias=False), nn.BatchNorm2d(2048), nn.Identity())
+            self.downsample = nn.Sequential(nn.Conv2d(in_depth, 2048, 1, bias=bias), nn.BatchNorm2d(2048, affine=affine),
+                                            nn.Identity())
 
 
-def _dec(cin, c1, c2, last=None):
-    mods = [nn.Conv2d(cin, c1, 3, 1, 1, bias=False), nn.InstanceNorm2d(c1, affine=True), nn.Identity(),
-            nn.ConvTranspose2d(c1, c1, 3, 2, 1, output_padding=1, bias=False), nn.InstanceNorm2d(c1, affine=True),
+def _dec(cin, c1, c2, last=None, bias=False, affine=True):
+    mods = [nn.Conv2d(cin, c1, 3, 1, 1, bias=bias), nn.InstanceNorm2d(c1, affine=affine), nn.Identity(),
+            nn.ConvTranspose2d(c1, c1, 3, 2, 1, output_padding=1, bias=bias), nn.InstanceNorm2d(c1, affine=affine),
             nn.Identity(),
-            nn.Conv2d(c1, c2, 3, 1, 1, bias=False), nn.InstanceNorm2d(c2, affine=True), nn.Identity()]
+            nn.Conv2d(c1, c2, 3, 1, 1, bias=bias), nn.InstanceNorm2d(c2, affine=affine), nn.Identity()]
     if last is not None:
-        mods += [nn.Conv2d(c2, last, 3, 1, 1, bias=False), nn.Identity()]
+        mods += [nn.Conv2d(c2, last, 3, 1, 1, bias=bias), nn.Identity()]
     return nn.Sequential(*mods)
 
 
@@ -99,16 +100,16 @@ class UniDefenseModelRes50(UniDefenseModelRes18):
                  freq_norm: str = 'ortho',
                  **kwargs):
         nn.Module.__init__(self)
-        if bias or not affine or extractor != "resnet50":
-            raise NotImplementedError("HIP path implements the reference's UDR50 config: resnet50, bias=False, affine=True")
+        if extractor != "resnet50":
+            raise NotImplementedError("HIP path implements the reference's UDR50 config: resnet50")
         self.freq_norm = freq_norm
         self.drop_rate = drop_rate
         self.extractor = _ExtractorRes50(freq_norm)
-        self.emb_block1 = _Emb50Params(mid_depth, True)
-        self.emb_block2 = _Emb50Params(2048, False)
-        self.dec_block1 = _dec(mid_depth, 256, 256)
-        self.dec_block2 = _dec(256, 128, 128)
-        self.dec_block3 = _dec(128, 64, 32, last=3)
+        self.emb_block1 = _Emb50Params(mid_depth, True, bias, affine)
+        self.emb_block2 = _Emb50Params(2048, False, bias, affine)
+        self.dec_block1 = _dec(mid_depth, 256, 256, bias=bias, affine=affine)
+        self.dec_block2 = _dec(256, 128, 128, bias=bias, affine=affine)
+        self.dec_block3 = _dec(128, 64, 32, last=3, bias=bias, affine=affine)
         self.bottleneck = nn.BatchNorm1d(2048)
         self.bottleneck.bias.requires_grad_(False)
         nn.init.constant_(self.bottleneck.weight, 1.0)
@@ -142,15 +143,15 @@ class UniDefenseModelRes50(UniDefenseModelRes18):
         return T.add_relu(tape, y, sc, site=self._block_name(blk) + ".add")
 
     def _embedder(self, tape, x, e, stride, name):
-        o = T.conv1x1(tape, x, e.conv1.weight)
+        o = T.bias_add(tape, T.conv1x1(tape, x, e.conv1.weight), e.conv1.bias)
         o = self._bn(tape, o, e.norm1, 2)
         o = self._conv(tape, o, e.conv2, stride)
         o = self._bn(tape, o, e.norm2, 2)
-        o = T.conv1x1(tape, o, e.conv3.weight)
+        o = T.bias_add(tape, T.conv1x1(tape, o, e.conv3.weight), e.conv3.bias)
         o = self._bn(tape, o, e.norm3, 0)
         sel = None
         if stride == 2:                      # EmbedderRes50Layer1: 1x1 conv + BN + 3x3/2 max-pool on the identity
-            idt = T.conv1x1(tape, x, e.downsample[0].weight)
+            idt = T.bias_add(tape, T.conv1x1(tape, x, e.downsample[0].weight), e.downsample[0].bias)
             idt = self._bn(tape, idt, e.downsample[1], 0)
             idt, sel = T.maxpool3s2(tape, idt, return_arg=True)
         else:
@@ -187,7 +188,7 @@ class UniDefenseModelRes50(UniDefenseModelRes18):
         d = self._dec(tape, d, self.dec_block3, 0)
         d = self._dec(tape, d, self.dec_block3, 3, transposed=True)
         d = self._dec(tape, d, self.dec_block3, 6)
-        d = T.conv_dense_any(tape, d, self.dec_block3[9].weight, 1, 1)
+        d = T.bias_add(tape, T.conv_dense_any(tape, d, self.dec_block3[9].weight, 1, 1), self.dec_block3[9].bias)
         dec3 = T.tanh_to_planes(tape, d)                                 # [N,3,H/2,W/2]
 
         emb, sel_emb = self._embedder(tape, ext, self.emb_block1, 2, "emb_block1")
@@ -201,15 +202,15 @@ class UniDefenseModelRes50(UniDefenseModelRes18):
         freq_diff = K.absdiff(K.rfft2(pred, sf), K.rfft2(xs, sf))
         emb_freq = T.rfft2_cat(tape, emb, norm)
         ff = self.freq_filter
-        proj = T.conv1x1(tape, emb_freq, ff.layer1[0].weight)
+        proj = T.bias_add(tape, T.conv1x1(tape, emb_freq, ff.layer1[0].weight), ff.layer1[0].bias)
         proj = self._bn(tape, proj, ff.layer1[1], 2)
-        f_out, freq_mask = T.dynamic_filter(tape, emb_freq, proj, freq_diff, ff.layer2[0].weight)
+        f_out, freq_mask = T.dynamic_filter(tape, emb_freq, proj, freq_diff, ff.layer2[0].weight, ff.layer2[0].bias)
         freq_filtered = T.irfft2_split(tape, f_out, norm)
         spat_diff = K.absdiff(pred, xs)
         sfm = self.spat_filter
-        proj = T.conv_dense_any(tape, emb, sfm.layer1[0].weight, 1, 1)
+        proj = T.bias_add(tape, T.conv_dense_any(tape, emb, sfm.layer1[0].weight, 1, 1), sfm.layer1[0].bias)
         proj = self._bn(tape, proj, sfm.layer1[1], 2)
-        s_out, spat_mask = T.dynamic_filter(tape, emb, proj, spat_diff, sfm.layer2[0].weight)
+        s_out, spat_mask = T.dynamic_filter(tape, emb, proj, spat_diff, sfm.layer2[0].weight, sfm.layer2[0].bias)
         att = T.gate_mix(tape, s_out, freq_filtered, self.fuse_coef)
         e = emb
         if self.training and self.drop_rate > 0:

@@ -767,9 +767,9 @@ def conv_dense_any(tape, x, w, stride, pad, need_dx=True):
     return y
 
 
-def sfconv_dense(tape, x, w, w_freq, alpha, stride, norm):
-    """SFConv2d.forward (model/resnet/exp.py:36-54): dense 3x3 conv (padding 1) + spectral 1x1 branch."""
-    spat = conv_dense_any(tape, x, w, stride, 1)
+def sfconv_dense(tape, x, w, w_freq, alpha, stride, norm, bias=None):
+    """SFConv2d.forward (model/resnet/exp.py:36-54): dense 3x3 conv (padding 1; + its bias, :39) + spectral 1x1 branch."""
+    spat = bias_add(tape, conv_dense_any(tape, x, w, stride, 1), bias)
     xf = rfft2_cat(tape, x, norm)
     yf = conv1x1(tape, xf, w_freq)
     fr = irfft2_split(tape, yf, norm)
