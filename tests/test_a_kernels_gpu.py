@@ -507,7 +507,10 @@ def test_instancenorm_swish(N, H, C):
                                       (16, 40, None), (32, 336, "ortho"), (64, 192, "ortho"), (32, 20, None),
                                       # 5 * 2^k sizes (ResNet50 variant at 320 x 320): mixed-radix in-register DFT
                                       (10, 512, "ortho"), (10, 3, None), (20, 256, "ortho"), (40, 128, None),
-                                      (80, 128, "ortho"), (80, 7, "ortho")])
+                                      (80, 128, "ortho"), (80, 7, "ortho"),
+                                      # 3 * 2^k sizes (EfficientNet-b4 at its native 380 x 380: maps of 48 / 24 / 12)
+                                      (12, 1632, "ortho"), (12, 272, None), (24, 672, "ortho"), (24, 960, "ortho"),
+                                      (48, 336, "ortho"), (48, 5, None)])
 def test_rfft2_irfft2(S, C, norm):
     dev = _dev()
     from unidefense_amd import tape as T

@@ -209,7 +209,7 @@ def test_dwconv_backward_through_deferred_bn(N, H, Cc, k, stride, pad, gate_mode
     assert _rel(dw.view(Cc, k, k), wd.grad.view(Cc, k, k)) < 2e-5
 
 
-@pytest.mark.parametrize("S,Cc,N", [(8, 24, 3), (16, 40, 2), (32, 48, 2), (64, 8, 1)])
+@pytest.mark.parametrize("S,Cc,N", [(8, 24, 3), (16, 40, 2), (32, 48, 2), (64, 8, 1), (12, 48, 3), (24, 44, 2), (48, 24, 2), (20, 24, 2)])
 def test_fft_fused_variants(S, Cc, N):
     """ud_rfft2_ex (deferred BN + swish on load, activated side output, gate factor) and ud_irfft2_mix (irfft2 + SF mix +
     BN statistics) against torch.fft in float64."""

@@ -1,4 +1,4 @@
-// Batched small real 2-D FFT (S x S, S = 8, 16, 32, 64 and 10, 20, 40, 80) on pixel-major [N][S][S][C] fp32, and its inverse.
+// Batched small real 2-D FFT (S x S, S = 8, 16, 32, 64; 10, 20, 40, 80; 12, 24, 48) on pixel-major [N][S][S][C] fp32, and its inverse.
 //
 // Serves torch.fft.rfft2 / irfft2 of SFConv2dStaticSamePadding.forward (model/efficientnet/exp.py:55,60),
 // of UniDefenseModelEb4.attention (model/unidefense.py:130-145), and both autograd adjoints:
@@ -84,18 +84,43 @@ __device__ constexpr float TW80_IM[80] = {
     5.877852523e-01f, 5.224985647e-01f, 4.539904997e-01f, 3.826834324e-01f, 3.090169944e-01f, 2.334453639e-01f,
     1.564344650e-01f, 7.845909573e-02f};
 
-// S = 2^k, or 5 * 2^k (10, 20, 40, 80: the feature maps of the ResNet50 variant at 320 x 320 inputs)
+// exp(-2*pi*i*j/48), j = 0..47  (mixed-radix sizes 12, 24, 48: the feature maps of the EfficientNet-b4 trunk at its native 380 x 380)
+__device__ constexpr float TW48_RE[48] = {
+    1.000000000e+00f, 9.914448614e-01f, 9.659258263e-01f, 9.238795325e-01f, 8.660254038e-01f, 7.933533403e-01f,
+    7.071067812e-01f, 6.087614290e-01f, 5.000000000e-01f, 3.826834324e-01f, 2.588190451e-01f, 1.305261922e-01f,
+    6.123233996e-17f, -1.305261922e-01f, -2.588190451e-01f, -3.826834324e-01f, -5.000000000e-01f, -6.087614290e-01f,
+    -7.071067812e-01f, -7.933533403e-01f, -8.660254038e-01f, -9.238795325e-01f, -9.659258263e-01f, -9.914448614e-01f,
+    -1.000000000e+00f, -9.914448614e-01f, -9.659258263e-01f, -9.238795325e-01f, -8.660254038e-01f, -7.933533403e-01f,
+    -7.071067812e-01f, -6.087614290e-01f, -5.000000000e-01f, -3.826834324e-01f, -2.588190451e-01f, -1.305261922e-01f,
+    -1.836970199e-16f, 1.305261922e-01f, 2.588190451e-01f, 3.826834324e-01f, 5.000000000e-01f, 6.087614290e-01f,
+    7.071067812e-01f, 7.933533403e-01f, 8.660254038e-01f, 9.238795325e-01f, 9.659258263e-01f, 9.914448614e-01f};
+__device__ constexpr float TW48_IM[48] = {
+    -0.000000000e+00f, -1.305261922e-01f, -2.588190451e-01f, -3.826834324e-01f, -5.000000000e-01f, -6.087614290e-01f,
+    -7.071067812e-01f, -7.933533403e-01f, -8.660254038e-01f, -9.238795325e-01f, -9.659258263e-01f, -9.914448614e-01f,
+    -1.000000000e+00f, -9.914448614e-01f, -9.659258263e-01f, -9.238795325e-01f, -8.660254038e-01f, -7.933533403e-01f,
+    -7.071067812e-01f, -6.087614290e-01f, -5.000000000e-01f, -3.826834324e-01f, -2.588190451e-01f, -1.305261922e-01f,
+    -1.224646799e-16f, 1.305261922e-01f, 2.588190451e-01f, 3.826834324e-01f, 5.000000000e-01f, 6.087614290e-01f,
+    7.071067812e-01f, 7.933533403e-01f, 8.660254038e-01f, 9.238795325e-01f, 9.659258263e-01f, 9.914448614e-01f,
+    1.000000000e+00f, 9.914448614e-01f, 9.659258263e-01f, 9.238795325e-01f, 8.660254038e-01f, 7.933533403e-01f,
+    7.071067812e-01f, 6.087614290e-01f, 5.000000000e-01f, 3.826834324e-01f, 2.588190451e-01f, 1.305261922e-01f};
+
+// S = 2^k, 5 * 2^k (10, 20, 40, 80: the feature maps of the ResNet50 variant at 320 x 320 inputs) or 3 * 2^k (12, 24, 48: the
+// EfficientNet-b4 trunk at 380 x 380)
 template <int S>
 struct Radix {
-    static constexpr bool MIXED = (S % 5 == 0);
-    static constexpr int P = MIXED ? S / 5 : S;            // length of the radix-2 part
+    static constexpr int R = (S % 5 == 0) ? 5 : (S % 3 == 0) ? 3 : 1;      // the odd factor
+    static constexpr bool MIXED = R > 1;
+    static constexpr int P = S / R;                         // length of the radix-2 part
+    static constexpr int L = R == 5 ? 80 : 48;              // length of the twiddle table W_L^j the size draws from
 };
+template <int S> __device__ __forceinline__ constexpr float tw_re(int m) { return Radix<S>::R == 5 ? TW80_RE[m] : TW48_RE[m]; }
+template <int S> __device__ __forceinline__ constexpr float tw_im(int m) { return Radix<S>::R == 5 ? TW80_IM[m] : TW48_IM[m]; }
 
 // register slot of input element i: bit reversal for 2^k; for 5*P the decimated sequence r = i % 5 occupies slots
 // [r*P, (r+1)*P) in bit-reversed order of n2 = i / 5
 template <int S>
 __device__ __forceinline__ constexpr int brev(int i) {
-    if (Radix<S>::MIXED) return (i % 5) * Radix<S>::P + brev2<Radix<S>::P>(i / 5);
+    if (Radix<S>::MIXED) return (i % Radix<S>::R) * Radix<S>::P + brev2<Radix<S>::P>(i / Radix<S>::R);
     return brev2<S>(i);
 }
 
@@ -126,39 +151,47 @@ __device__ __forceinline__ void fft_pow2(float (&re)[S], float (&im)[S]) {
     }
 }
 
-// S-point DFT in registers, input in brev<S> slots, output in natural order.  5*P sizes: Cooley-Tukey with N1 = 5:
-// five P-point FFTs of the decimated sequences, twiddles W_S^(r*k2), then a 5-point DFT across r for every k2 —
-// X[k2 + P*k1] = sum_r W_5^(r*k1) W_S^(r*k2) Y_r[k2] lands in the slots its inputs came from.
+// S-point DFT in registers, input in brev<S> slots, output in natural order.  R*P sizes (R = 5 or 3): Cooley-Tukey with N1 = R:
+// R P-point FFTs of the decimated sequences, twiddles W_S^(r*k2), then an R-point DFT across r for every k2 —
+// X[k2 + P*k1] = sum_r W_R^(r*k1) W_S^(r*k2) Y_r[k2] lands in the slots its inputs came from.
+template <int S, int P, int RR, bool INV>
+struct SubFfts {
+    static __device__ __forceinline__ void run(float (&re)[S], float (&im)[S]) {
+        SubFfts<S, P, RR - 1, INV>::run(re, im);
+        fft_pow2<S, P, (RR - 1) * P, INV>(re, im);
+    }
+};
+template <int S, int P, bool INV>
+struct SubFfts<S, P, 0, INV> {
+    static __device__ __forceinline__ void run(float (&)[S], float (&)[S]) {}
+};
+
 template <int S, bool INV>
 __device__ __forceinline__ void fft_inreg(float (&re)[S], float (&im)[S]) {
-    constexpr int P = Radix<S>::P;
+    constexpr int P = Radix<S>::P, R = Radix<S>::R, L = Radix<S>::L;
     if constexpr (!Radix<S>::MIXED) {
         fft_pow2<S, P, 0, INV>(re, im);
     } else {
-        fft_pow2<S, P, 0 * P, INV>(re, im);
-        fft_pow2<S, P, 1 * P, INV>(re, im);
-        fft_pow2<S, P, 2 * P, INV>(re, im);
-        fft_pow2<S, P, 3 * P, INV>(re, im);
-        fft_pow2<S, P, 4 * P, INV>(re, im);
-        constexpr int TS = 80 / S;                         // W_S^m = W_80^(m*TS)
+        SubFfts<S, P, R, INV>::run(re, im);
+        constexpr int TS = L / S;                          // W_S^m = W_L^(m*TS)
 #pragma unroll
         for (int k2 = 0; k2 < P; ++k2) {
-            float yr[5], yi[5];
+            float yr[R], yi[R];
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int m = (r * k2 * TS) % 80;
-                const float wr = TW80_RE[m], wi = INV ? -TW80_IM[m] : TW80_IM[m];
+            for (int r = 0; r < R; ++r) {
+                const int m = (r * k2 * TS) % L;
+                const float wr = tw_re<S>(m), wi = INV ? -tw_im<S>(m) : tw_im<S>(m);
                 const float xr = re[r * P + k2], xi = im[r * P + k2];
                 yr[r] = wr * xr - wi * xi;
                 yi[r] = wr * xi + wi * xr;
             }
 #pragma unroll
-            for (int k1 = 0; k1 < 5; ++k1) {
+            for (int k1 = 0; k1 < R; ++k1) {
                 float ar = yr[0], ai = yi[0];
 #pragma unroll
-                for (int r = 1; r < 5; ++r) {
-                    const int m = (16 * r * k1) % 80;      // W_5^(r*k1)
-                    const float wr = TW80_RE[m], wi = INV ? -TW80_IM[m] : TW80_IM[m];
+                for (int r = 1; r < R; ++r) {
+                    const int m = ((L / R) * r * k1) % L;  // W_R^(r*k1)
+                    const float wr = tw_re<S>(m), wi = INV ? -tw_im<S>(m) : tw_im<S>(m);
                     ar += wr * yr[r] - wi * yi[r];
                     ai += wr * yi[r] + wi * yr[r];
                 }
@@ -1036,6 +1069,9 @@ int rfft2_dispatch(const T* x, T* Y, int N, int S, int C, float scale, float w_i
     }
     if constexpr (std::is_same<T, float>::value) {
         switch (S) {
+            case 12: return launch_rfft2<T, 12, 42>(x, Y, N, C, scale, w_interior, ex, s);
+            case 24: return launch_rfft2<T, 24, 21>(x, Y, N, C, scale, w_interior, ex, s);
+            case 48: return launch_rfft2<T, 48, 10>(x, Y, N, C, scale, w_interior, ex, s);
             case 10: return launch_rfft2<T, 10, 51>(x, Y, N, C, scale, w_interior, ex, s);
             case 20: return launch_rfft2<T, 20, 25>(x, Y, N, C, scale, w_interior, ex, s);
             case 40: return launch_rfft2<T, 40, 12>(x, Y, N, C, scale, w_interior, ex, s);
@@ -1060,6 +1096,9 @@ int irfft2_dispatch(const T* Y, T* x, int N, int S, int C, float scale, float w_
     }
     if constexpr (std::is_same<T, float>::value) {
         switch (S) {
+            case 12: return launch_irfft2<T, 12, 42>(Y, x, N, C, scale, w_interior, m, s);
+            case 24: return launch_irfft2<T, 24, 21>(Y, x, N, C, scale, w_interior, m, s);
+            case 48: return launch_irfft2<T, 48, 10>(Y, x, N, C, scale, w_interior, m, s);
             case 10: return launch_irfft2<T, 10, 51>(Y, x, N, C, scale, w_interior, m, s);
             case 20: return launch_irfft2<T, 20, 25>(Y, x, N, C, scale, w_interior, m, s);
             case 40: return launch_irfft2<T, 40, 12>(Y, x, N, C, scale, w_interior, m, s);
