@@ -510,7 +510,9 @@ def test_instancenorm_swish(N, H, C):
                                       (80, 128, "ortho"), (80, 7, "ortho"),
                                       # 3 * 2^k sizes (EfficientNet-b4 at its native 380 x 380: maps of 48 / 24 / 12)
                                       (12, 1632, "ortho"), (12, 272, None), (24, 672, "ortho"), (24, 960, "ortho"),
-                                      (48, 336, "ortho"), (48, 5, None)])
+                                      (48, 336, "ortho"), (48, 5, None),
+                                      # any other side: DFT matrices on the GEMM kernels (95 = 5 * 19: the 380 x 380 trunk's first SF block)
+                                      (95, 192, "ortho"), (95, 8, None), (14, 24, "ortho")])
 def test_rfft2_irfft2(S, C, norm):
     dev = _dev()
     from unidefense_amd import tape as T

@@ -1291,8 +1291,54 @@ def _fft_ws(N, S, Cc, like):
     return empty((N, S, S // 2 + 1, 2 * Cc), like, torch.float32)
 
 
+_FFT_KERNEL_SIZES = (8, 16, 32, 64, 10, 20, 40, 80, 12, 24, 48)          # csrc/fft.hip: 2^k, 5 * 2^k, 3 * 2^k in registers
+
+
+def fft_kernel_size(S):
+    """True where csrc/fft.hip transforms S x S maps in registers; other sides (95 = 5 * 19 of the EfficientNet-b4 trunk at
+    380 x 380) go through DFT matrices on the GEMM kernels (_rfft2_generic / _irfft2_generic) — correct, not fast"""
+    return S in _FFT_KERNEL_SIZES
+
+
+def _fft_col_weights(S, w_interior, like, twice):
+    """per-kx factors of the half spectrum: 1 on the self-conjugate columns (kx = 0, and S/2 for even S), w_interior elsewhere
+    (x 2 for the inverse: the Hermitian extension the kernels make explicitly)"""
+    Wh = S // 2 + 1
+    f = torch.full((Wh,), float(w_interior) * (2.0 if twice else 1.0), device=like.device)
+    f[0] = 1.0
+    if S % 2 == 0:
+        f[Wh - 1] = 1.0
+    return f
+
+
+def _rfft2_generic(x, scale, w_interior):
+    """rfft2 of ud_rfft2's contract for any side: pixel-major -> planes, three DFT-matrix GEMMs (dft_rfft2_planes), back"""
+    N, S, _, Cc = x.shape
+    Wh = S // 2 + 1
+    d = x.float().permute(0, 3, 1, 2).reshape(N * Cc, S, S).contiguous()
+    Yp = dft_rfft2_planes(d, ortho=False)                                    # [P, 2S, Whp]: rows Re(ky) | Im(ky)
+    Y = Yp.view(N, Cc, 2, S, Yp.shape[-1])[..., :Wh].permute(0, 3, 4, 2, 1)      # [N, S, Wh, 2, C]
+    Y = Y * (_fft_col_weights(S, w_interior, x, False) * float(scale)).view(1, 1, Wh, 1, 1)
+    return Y.reshape(N, S, Wh, 2 * Cc).contiguous().to(x.dtype)
+
+
+def _irfft2_generic(Y, scale, w_interior):
+    """irfft2 of ud_irfft2's contract for any side: x = scale * F^T(m f Y), F the unnormalised rfft2 (its adjoint on the GEMM
+    kernels: dft_rfft2_planes_adjoint), m the Hermitian multiplicity, f = w_interior off the self-conjugate columns"""
+    N, S, Wh, C2 = Y.shape
+    Cc = C2 // 2
+    Whp = -(-Wh // 4) * 4
+    Yw = Y.float().view(N, S, Wh, 2, Cc) * (_fft_col_weights(S, w_interior, Y, True) * float(scale)).view(1, 1, Wh, 1, 1)
+    dY = torch.zeros((N, Cc, 2, S, Whp), device=Y.device)
+    dY[..., :Wh] = Yw.permute(0, 4, 3, 1, 2)
+    x = dft_rfft2_planes_adjoint(dY.view(N * Cc, 2 * S, Whp), S, ortho=False)         # [P, S, S]
+    return x.view(N, Cc, S, S).permute(0, 2, 3, 1).contiguous().to(Y.dtype)
+
+
 def rfft2(x, scale, w_interior=1.0, want_absmax=False):
     """x[N,S,S,C] -> Y[N,S,S/2+1,2C] (Re | Im channel halves).  want_absmax: Y._ud_absmax = 256 slots of |Y|max."""
+    if not fft_kernel_size(x.shape[1]):
+        return _rfft2_generic(x, scale, w_interior)
     if want_absmax and amax_slots(x) is not None:
         return rfft2_ex(x, scale, w_interior, want_absmax=True)[0]
     h = _act(x)
@@ -1312,6 +1358,8 @@ def irfft2(Y, scale, w_interior=1.0):
     h = _act(Y)
     N, S, Wh, C2 = Y.shape
     assert Wh == S // 2 + 1 and C2 % 2 == 0
+    if not fft_kernel_size(S):
+        return _irfft2_generic(Y, scale, w_interior)
     x = empty((N, S, S, C2 // 2), Y, Y.dtype)
     if _fft_two_pass("irfft", S, h):
         _call("ud_irfft2_two_pass", _p(Y), _p(x), _p(_fft_ws(N, S, C2 // 2, Y)), N, S, C2 // 2, scale, w_interior, None, None,
