@@ -141,16 +141,17 @@ def train_step_measure(bs):
             "value": bs / dt, "unit": "train images/sec (each image goes through 2 passes)", "steps": n}
 
 
-def extra_measurements(budget_s=75):
+def extra_measurements(budget_s=90):
     """Driver-visible numbers of the other BASELINE configs: bounded 5-step runs in CHILD processes after the timed region
-    (configs[4] f16 bs 64, configs[3] UDR50 320^2 bs 16, configs[0] UDR18 128^2 bs 8, the two-pass train step)."""
+    (configs[4] f16 bs 64, configs[3] UDR50 320^2 bs 16, configs[0] UDR18 128^2 bs 8, the two-pass train step, UDEB4 at 380^2)."""
     import subprocess
     me = os.path.abspath(__file__)
     common = ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extra"]
     jobs = [("configs[4]: UDEB4 256x256 fp16 MFMA + half storage, bs 64", ["--dtype", "f16", "--batch", "64"] + common),
             ("configs[3]: UDR50 320x320 bs 16", ["--model", "UDR50", "--size", "320", "--batch", "16"] + common),
             ("configs[0]: UDR18 128x128 bs 8", ["--model", "UDR18", "--size", "128", "--batch", "8"] + common),
-            ("two-pass train step", ["--train-step"])]
+            ("two-pass train step", ["--train-step"]),
+            ("UDEB4 at the reference YAMLs' 380x380, bs 32", ["--size", "380"] + common)]
     out, t_start = [], time.perf_counter()
     for name, argv in jobs:
         left = budget_s - (time.perf_counter() - t_start)

@@ -114,8 +114,82 @@ def main_res():
         print(f"wrote {name}_eval_n2_bias_noaffine.npz (oracle == reference on the eval outputs)")
 
 
+def make_rng_sized(n, seed, drop_rate, size, nblk=32, dc_rate=0.2):
+    """make_golden.make_rng for any input size: the keep-masks follow the maps (x_b4: size / 16 rounded up, x_b5: size / 32)"""
+    g = torch.Generator().manual_seed(seed)
+
+    def bern(shape, keep):
+        return (torch.rand(shape, generator=g) < keep).float()
+    s4, s5 = -(-size // 16), -(-size // 32)
+    rng = {"dec_keep": bern((n, 160, s4, s4), 0.8), "emb_keep": bern((n, 272, s5, s5), 1.0 - drop_rate),
+           "feat_keep": bern((n, 1792), 1.0 - drop_rate), "drop_connect": {}}
+    for idx in range(1, nblk):
+        rng["drop_connect"][idx] = bern((n,), 1.0 - dc_rate * idx / nblk)
+    return rng
+
+
+def main_380():
+    """UDEB4 at the reference's native resolution (config_template/uniatt/Prot1/data_ffpp.yml:71-72: 380 x 380; feature maps
+    190 / 95 / 48 / 24 / 12): eval outputs and a train step (smooth pass-1 loss, all gradients) at N = 2"""
+    ref_model, ref_loss = ref_import.import_reference()
+    torch.manual_seed(0)
+    drop_rate, size, n = 0.5, 380, 2
+    m = ref_model.load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=drop_rate)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    sd = param_fill.fill_state_dict(eb4.eb4_state_shapes(2), 0.0, 0.3)
+    x = param_fill.make_input(n, size, seed=1)
+    m.eval()
+    store = {}
+    with torch.no_grad():
+        out = m(x)
+        pack_outputs(out, "", store)
+        ora = eb4.forward_eb4(sd, x, training=False)
+    for k in ("cls_out", "rec"):
+        e = ((ora[k] - out[k]).abs().max() / out[k].abs().max()).item()
+        assert e < 1e-4, (k, e)
+    store["meta"] = np.array([n, size, 1], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "udeb4_eval_n2_s380.npz"), **store)
+    print("wrote udeb4_eval_n2_s380.npz (oracle == reference on the eval outputs)")
+    # train step: seeds searched for a safe arg-max gap in the dynamic filters
+    for in_seed in range(60, 80):
+        x = param_fill.make_input(n, size, seed=in_seed)
+        rng = make_rng_sized(n, 100 + in_seed, drop_rate, size)
+        with torch.no_grad():
+            gap = eb4.forward_eb4(sd, x, training=True, drop_rate=drop_rate, rng=rng)["_max_gap"].item()
+        print("seed", in_seed, "top-2 gap %.2e" % gap, flush=True)
+        if gap > 1.5e-3:
+            break
+    else:
+        raise SystemExit("no seed with a safe gap")
+    tgt = param_fill.make_labels(n)
+    lam = dict(LAMBDAS, lambda_recons=0.0, lambda_freq=0.0)
+    out, losses = run_reference_train(m, ref_loss, x, tgt, rng, drop_rate, lam)
+    store = {}
+    pack_outputs(out, "", store)
+    for k, v in losses.items():
+        store["smooth_loss_" + k] = np.array(v.item(), dtype=np.float64)
+    names, norms, heads = [], [], []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(p.grad.double().norm().item())
+        h = torch.zeros(8)
+        f = p.grad.flatten()[:8]
+        h[: f.numel()] = f
+        heads.append(h.numpy())
+    store["grad_names"] = np.array(names)
+    store["smooth_grad_norms"] = np.array(norms, dtype=np.float64)
+    store["smooth_grad_heads"] = np.stack(heads)
+    store["meta"] = np.array([n, size, in_seed, 100 + in_seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "udeb4_train_n2_s380.npz"), **store)
+    print(f"wrote udeb4_train_n2_s380.npz ({len(names)} grads)")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "res":
+    if len(sys.argv) > 1 and sys.argv[1] == "380":
+        main_380()
+    elif len(sys.argv) > 1 and sys.argv[1] == "res":
         main_res()
     else:
         main()

@@ -331,8 +331,9 @@ class UniDefenseModelEb4(nn.Module):
             rate = rate0 * float(idx) / nblk if rate0 else 0.0
             keep = rng["drop_connect"].get(idx) if (self.training and rate) else None
             blk = self.backbone._blocks[idx]
-            if fused is not None:
-                # training mode: one tape node per block, BatchNorms deferred into their consumers (tape.mbconv_fused)
+            if fused is not None and (blk.spec.sf_norm is None or K.fft_kernel_size(x.shape[1])):
+                # training mode: one tape node per block, BatchNorms deferred into their consumers (tape.mbconv_fused); an SF block
+                # on a map side fft.hip has no in-register transform for (95 at 380 x 380) takes the operator path below
                 pend = self.__dict__.setdefault("_nbt_pending", [])
                 pend.extend(b.num_batches_tracked for b in (getattr(blk, "_bn0", None), blk._bn1, blk._bn2)
                             if b is not None and b.num_batches_tracked is not None)

@@ -347,8 +347,27 @@ def irfft2_split(tape, y, norm):
     return x
 
 
+def adaptive_avgpool(tape, x, Ho, Wo):
+    """F.adaptive_avg_pool2d to a size that does not divide the input (exp.py:61-62 on the 95 x 95 map of the 380 x 380 trunk's
+    stride-2 SF block: 95 -> 48, windows of 2 and 3 that overlap) — one block of one resolution, so ATen's kernel on the
+    channels-last view; the 2 x 2 case of the 256 x 256 trunk is fused into ud_sfmix."""
+    xn = x.permute(0, 3, 1, 2)                                   # NCHW view of the pixel-major tensor (channels_last strides)
+    y = torch._adaptive_avg_pool2d(xn, (Ho, Wo)).permute(0, 2, 3, 1).contiguous()
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dx = torch.ops.aten._adaptive_avg_pool2d_backward(dy.permute(0, 3, 1, 2), xn)
+            tape.add_grad(x, dx.permute(0, 2, 3, 1).contiguous())
+        tape.record(bwd)
+    return y
+
+
 def sfmix(tape, spat, freq, alpha):
     """(1 - sigmoid(a)) * spat + sigmoid(a) * [avg-pooled] freq  (exp.py:61-65)."""
+    if freq.shape[1] != spat.shape[1] and (freq.shape[1] != 2 * spat.shape[1] or freq.shape[2] != 2 * spat.shape[2]):
+        freq = adaptive_avgpool(tape, freq, spat.shape[1], spat.shape[2])
     pool = freq.shape[1] != spat.shape[1]
     if pool:
         assert freq.shape[1] == 2 * spat.shape[1] and freq.shape[2] == 2 * spat.shape[2]
