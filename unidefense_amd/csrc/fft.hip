@@ -1065,13 +1065,13 @@ int rfft2_dispatch(const T* x, T* Y, int N, int S, int C, float scale, float w_i
             if (fft32_wave_on(N, C)) return launch_rfft2_wave<T>(x, Y, N, C, scale, w_interior, ex, s);
             return launch_rfft2<T, 32, 16>(x, Y, N, C, scale, w_interior, ex, s);
         case 64: return launch_rfft2<T, 64, 8>(x, Y, N, C, scale, w_interior, ex, s);
+        case 12: return launch_rfft2<T, 12, 42>(x, Y, N, C, scale, w_interior, ex, s);          // 3 * 2^k: both storage types (the 380 x 380 trunk)
+        case 24: return launch_rfft2<T, 24, 21>(x, Y, N, C, scale, w_interior, ex, s);
+        case 48: return launch_rfft2<T, 48, 10>(x, Y, N, C, scale, w_interior, ex, s);
         default: break;
     }
     if constexpr (std::is_same<T, float>::value) {
         switch (S) {
-            case 12: return launch_rfft2<T, 12, 42>(x, Y, N, C, scale, w_interior, ex, s);
-            case 24: return launch_rfft2<T, 24, 21>(x, Y, N, C, scale, w_interior, ex, s);
-            case 48: return launch_rfft2<T, 48, 10>(x, Y, N, C, scale, w_interior, ex, s);
             case 10: return launch_rfft2<T, 10, 51>(x, Y, N, C, scale, w_interior, ex, s);
             case 20: return launch_rfft2<T, 20, 25>(x, Y, N, C, scale, w_interior, ex, s);
             case 40: return launch_rfft2<T, 40, 12>(x, Y, N, C, scale, w_interior, ex, s);
@@ -1092,13 +1092,13 @@ int irfft2_dispatch(const T* Y, T* x, int N, int S, int C, float scale, float w_
             if (fft32_wave_on(N, C)) return launch_irfft2_wave<T>(Y, x, N, C, scale, w_interior, m, s);
             return launch_irfft2<T, 32, 16>(Y, x, N, C, scale, w_interior, m, s);
         case 64: return launch_irfft2<T, 64, 8>(Y, x, N, C, scale, w_interior, m, s);
+        case 12: return launch_irfft2<T, 12, 42>(Y, x, N, C, scale, w_interior, m, s);          // 3 * 2^k: both storage types (the 380 x 380 trunk)
+        case 24: return launch_irfft2<T, 24, 21>(Y, x, N, C, scale, w_interior, m, s);
+        case 48: return launch_irfft2<T, 48, 10>(Y, x, N, C, scale, w_interior, m, s);
         default: break;
     }
     if constexpr (std::is_same<T, float>::value) {
         switch (S) {
-            case 12: return launch_irfft2<T, 12, 42>(Y, x, N, C, scale, w_interior, m, s);
-            case 24: return launch_irfft2<T, 24, 21>(Y, x, N, C, scale, w_interior, m, s);
-            case 48: return launch_irfft2<T, 48, 10>(Y, x, N, C, scale, w_interior, m, s);
             case 10: return launch_irfft2<T, 10, 51>(Y, x, N, C, scale, w_interior, m, s);
             case 20: return launch_irfft2<T, 20, 25>(Y, x, N, C, scale, w_interior, m, s);
             case 40: return launch_irfft2<T, 40, 12>(Y, x, N, C, scale, w_interior, m, s);

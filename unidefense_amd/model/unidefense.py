@@ -340,7 +340,12 @@ class UniDefenseModelEb4(nn.Module):
                 x = T.mbconv_fused(tape, x, blk, keep, 1.0 - rate, fused["wt"][id(blk._depthwise_conv.weight)],
                                    fused["dp"], lazy_in if idx == 0 else None)
             else:
+                dt = x.dtype                                   # the operator path computes in fp32 storage
+                if dt != torch.float32:
+                    x = T.cast(tape, x, torch.float32)
                 x = self._mbconv(tape, x, blk, keep, 1.0 - rate)
+                if dt != torch.float32:
+                    x = T.cast(tape, x, dt)
         return x
 
     def _sync_group(self, bn):
