@@ -1300,14 +1300,22 @@ def fft_kernel_size(S):
     return S in _FFT_KERNEL_SIZES
 
 
+_FFT_COLW = {}
+
+
 def _fft_col_weights(S, w_interior, like, twice):
     """per-kx factors of the half spectrum: 1 on the self-conjugate columns (kx = 0, and S/2 for even S), w_interior elsewhere
-    (x 2 for the inverse: the Hermitian extension the kernels make explicitly)"""
-    Wh = S // 2 + 1
-    f = torch.full((Wh,), float(w_interior) * (2.0 if twice else 1.0), device=like.device)
-    f[0] = 1.0
-    if S % 2 == 0:
-        f[Wh - 1] = 1.0
+    (x 2 for the inverse: the Hermitian extension the kernels make explicitly).  Built on the host once per (S, w, device): an
+    element assignment on a device tensor is a synchronous copy, which a graph capture refuses."""
+    key = (S, float(w_interior), bool(twice), str(like.device))
+    f = _FFT_COLW.get(key)
+    if f is None:
+        Wh = S // 2 + 1
+        h = torch.full((Wh,), float(w_interior) * (2.0 if twice else 1.0))
+        h[0] = 1.0
+        if S % 2 == 0:
+            h[Wh - 1] = 1.0
+        f = _FFT_COLW[key] = h.to(like.device)
     return f
 
 
