@@ -1587,23 +1587,26 @@ _DFT_CACHE = {}
 
 
 def _dft_mats(S, device, ortho=True):
+    """(fw_cos [Whp, Sp], fw_sin [Whp, Sp], fh [2S, 2 Sp]) with Sp = S rounded up to 4 and zero padding: every row stride stays a
+    multiple of 16 bytes for odd sides too (95), so the products run on the matrix-pipe kernels, not the scalar-load fp32 one"""
     key = (S, str(device), ortho)
     if key in _DFT_CACHE:
         return _DFT_CACHE[key]
     Wh = S // 2 + 1
     Whp = -(-Wh // 4) * 4
+    Sp = -(-S // 4) * 4
     s = 1.0 / math.sqrt(S) if ortho else 1.0
     k = torch.arange(S, dtype=torch.float64)
     ang = 2.0 * math.pi * torch.outer(k, k) / S          # [k][w]
     cosm, sinm = torch.cos(ang) * s, torch.sin(ang) * s
-    fw_cos = torch.zeros(Whp, S, dtype=torch.float64)
-    fw_sin = torch.zeros(Whp, S, dtype=torch.float64)
-    fw_cos[:Wh] = cosm[:Wh]
-    fw_sin[:Wh] = -sinm[:Wh]                               # Im of e^{-i t} = -sin
+    fw_cos = torch.zeros(Whp, Sp, dtype=torch.float64)
+    fw_sin = torch.zeros(Whp, Sp, dtype=torch.float64)
+    fw_cos[:Wh, :S] = cosm[:Wh]
+    fw_sin[:Wh, :S] = -sinm[:Wh]                           # Im of e^{-i t} = -sin
     # column transform on stacked [Re; Im]:  Yre = C Tre + S Tim ;  Yim = C Tim - S Tre
-    fh = torch.zeros(2 * S, 2 * S, dtype=torch.float64)
-    fh[:S, :S], fh[:S, S:] = cosm, sinm
-    fh[S:, :S], fh[S:, S:] = -sinm, cosm
+    fh = torch.zeros(2 * S, 2 * Sp, dtype=torch.float64)
+    fh[:S, :S], fh[:S, Sp:Sp + S] = cosm, sinm
+    fh[S:, :S], fh[S:, Sp:Sp + S] = -sinm, cosm
     mats = tuple(m.to(torch.float32).to(device).contiguous() for m in (fw_cos, fw_sin, fh))
     _DFT_CACHE[key] = mats
     return mats
@@ -1632,16 +1635,20 @@ def dft_rfft2_planes(d, ortho=True):
         _call("ud_rfft2_planes", _p(d), _p(Y), _p(_fft_planes_ws(d, P, S)), P, S, (1.0 / S) if ortho else 1.0, _stream())
         return Y
     fw_cos, fw_sin, fh = _dft_mats(S, d.device, ortho)
-    Whp = fw_cos.shape[0]
-    d2 = d.view(P * S, S)
+    Whp, Sp = fw_cos.shape
+    if Sp != S:                                     # rows padded to a multiple of 4 floats (zeros times zero columns)
+        dp = torch.zeros((P, S, Sp), device=d.device)
+        dp[..., :S] = d
+        d = dp
+    d2 = d.view(P * S, Sp)
     t_re = gemm_nt(d2, fw_cos)                      # [P*S, Whp]
     t_im = gemm_nt(d2, fw_sin)
     Y = empty((P, 2 * S, Whp), d)
-    # Y_p = fh[:, :S] @ Tre_p + fh[:, S:] @ Tim_p     (batched over planes; A shared)
-    _gemm(fh, t_re, Y, 2 * S, Whp, S, 2 * S, Whp, Whp, 0, 1, 0, batch=P, strideA=0, strideB=S * Whp,
+    # Y_p = fh[:, :S] @ Tre_p + fh[:, Sp:Sp+S] @ Tim_p     (batched over planes; A shared)
+    _gemm(fh, t_re, Y, 2 * S, Whp, S, 2 * Sp, Whp, Whp, 0, 1, 0, batch=P, strideA=0, strideB=S * Whp,
           strideC=2 * S * Whp)
-    _gemm(fh, t_im, Y, 2 * S, Whp, S, 2 * S, Whp, Whp, 0, 1, 1, batch=P, strideA=0, strideB=S * Whp,
-          strideC=2 * S * Whp, a_off=S)
+    _gemm(fh, t_im, Y, 2 * S, Whp, S, 2 * Sp, Whp, Whp, 0, 1, 1, batch=P, strideA=0, strideB=S * Whp,
+          strideC=2 * S * Whp, a_off=Sp)
     return Y
 
 
@@ -1655,17 +1662,18 @@ def dft_rfft2_planes_adjoint(dY, S, ortho=True):
               _stream())
         return dd
     fw_cos, fw_sin, fh = _dft_mats(S, dY.device, ortho)
-    Whp = fw_cos.shape[0]
+    Whp, Sp = fw_cos.shape
     dt_re = empty((P * S, Whp), dY)
     dt_im = empty((P * S, Whp), dY)
-    # dTre_p = fh[:, :S]^T @ dY_p ;  dTim_p = fh[:, S:]^T @ dY_p        (A[k][m] = fh[k][m(+S)])
-    _gemm(fh, dY, dt_re, S, Whp, 2 * S, 2 * S, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
+    # dTre_p = fh[:, :S]^T @ dY_p ;  dTim_p = fh[:, Sp:Sp+S]^T @ dY_p        (A[k][m] = fh[k][m(+Sp)])
+    _gemm(fh, dY, dt_re, S, Whp, 2 * S, 2 * Sp, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
           strideC=S * Whp)
-    _gemm(fh, dY, dt_im, S, Whp, 2 * S, 2 * S, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
-          strideC=S * Whp, a_off=S)
-    dd = gemm_nn(dt_re, fw_cos)                     # [P*S, Whp] @ [Whp, S]
+    _gemm(fh, dY, dt_im, S, Whp, 2 * S, 2 * Sp, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
+          strideC=S * Whp, a_off=Sp)
+    dd = gemm_nn(dt_re, fw_cos)                     # [P*S, Whp] @ [Whp, Sp]
     gemm_nn(dt_im, fw_sin, out=dd, accumulate=True)
-    return dd.view(P, S, S)
+    dd = dd.view(P, S, Sp)
+    return dd if Sp == S else dd[..., :S].contiguous()
 
 
 # ---------------------------------------------------------------------------------------------
