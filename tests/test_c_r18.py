@@ -278,3 +278,32 @@ def test_resnet_constructor_variant_eval_vs_reference_golden(golden_dir, name, s
     assert len(biases) >= 16
     for k, p in biases:
         assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size", [("UDR50", 224), ("UDR18", 224)])
+def test_resnet_models_at_sizes_without_an_in_register_fft(name, size):
+    """224 x 224 (feature maps 56 / 28 / 14 / 7): no side has an in-register transform in csrc/fft.hip, every SFConv goes through
+    DFT matrices on the GEMM kernels (kernels._rfft2_generic / _irfft2_generic) — eval outputs against the oracle, and a train
+    step runs with finite gradients for every parameter that takes one"""
+    dev = _dev()
+    from unidefense_amd.model import load_model
+    from oracle import r50
+    shapes, fwd = (r18.r18_state_shapes, r18.forward_r18) if name == "UDR18" else (r50.r50_state_shapes, r50.forward_r50)
+    m = load_model(name)(num_classes=2, drop_rate=0.5)
+    param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+    m = m.to(dev)
+    x = param_fill.make_input(2, size, seed=5)
+    sd = param_fill.fill_state_dict(shapes(2), 0.0, 0.3)
+    with torch.no_grad():
+        ref = fwd(sd, x, training=False)
+        got = m.eval()(x.to(dev))
+    for k in ("cls_out", "rec"):
+        assert within(f"{name} at {size}: eval {k} vs oracle", _rel(got[k], ref[k]), 1e-3)
+    for k in ("freq_mask", "spat_mask", "spatial", "freq"):
+        assert within(f"{name} at {size}: eval {k} vs oracle", _rel(got["loss_dict"][k], ref["loss_dict"][k]), 1e-3)
+    m.train()
+    out = m(x.to(dev))
+    (out["cls_out"].sum() + out["rec"].mean() + out["loss_dict"]["freq"].mean()).backward()
+    grads = [p.grad for p in m.parameters() if p.grad is not None]
+    assert len(grads) >= 100 and all(torch.isfinite(g_).all() for g_ in grads)

@@ -162,9 +162,9 @@ class UniDefenseModelRes50(UniDefenseModelRes18):
         """The whole forward (model/unidefense.py:556-631) on HIP kernels.  x: [N,3,H,W] planes; noise_x: the
         perturbed encoder input (the clean x stays the target of the attention residuals and the losses)."""
         N, _, H, W = x.shape
-        if H != W or H not in (256, 320):
-            raise NotImplementedError(f"UDR50 on the HIP path runs at 256x256 (FFT sizes 64/32/16/8) and 320x320 "
-                                      f"(80/40/20/10, BASELINE configs[3]); got {H}x{W}")
+        if H != W or H % 32:
+            raise NotImplementedError(f"UDR50 on the HIP path takes square inputs whose side is a multiple of 32 (256: FFT sizes "
+                                      f"64/32/16/8 and 320: 80/40/20/10 in registers; other sides through DFT matrices); got {H}x{W}")
         rng = self._prepare_rng(rng)
         ex = self.extractor
         x_pix = K.planes_to_pix(x if noise_x is None else noise_x)
