@@ -48,13 +48,13 @@ __device__ __forceinline__ void block_fold(const RedGeom& q, int ri, bool active
 
 // Decomposition: a workgroup owns CW float4 columns (<= 64 channels) and one row-chunk; ~target workgroups,
 // >= 8 rows per thread where the tensor allows, at most max_p chunks per group.
-inline RedGeom make_geom_ex(int G, int R, int C, long target_blocks, long max_p, int min_rows = 8) {
+inline RedGeom make_geom_ex(int G, int R, int C, long target_blocks, long max_p, int min_rows = 8, int cw_limit = 16) {
     RedGeom q;
     q.G = G; q.R = R; q.C4 = C / 4;
-    // float4 columns per workgroup: 16 (256-byte row segments, 16 rows per iteration) measured best on the bench
+    // float4 columns per workgroup (cw_limit): 16 (256-byte row segments, 16 rows per iteration) measured best for the REDUCTIONS
     // (8: +0.4 %, 32: +0.4 %, 64: +0.5 %, 128: +1.1 % step time).  The columns are spread
     // evenly over the groups (C4 = 36 -> 3 groups of 12, not 16 + 16 + 4 with a quarter-filled last workgroup).
-    constexpr int cw_max = 16;
+    const int cw_max = cw_limit;
     const int ngroups = (q.C4 + cw_max - 1) / cw_max;
     q.CW = (q.C4 + ngroups - 1) / ngroups;
     q.rpi = UD_COL_NT / q.CW;

@@ -706,7 +706,11 @@ inline int finish_reduce(const RedPlan& pl, int nq, bool per_group, int C, const
     UD_LAUNCH_CHECK();
     return 0;
 }
-inline RedGeom geom_ew(int G, int R, int C, int min_rows = 4) { return make_geom_ex(G, R, C, 2048, 4096, min_rows); }
+// The element-wise kernels (no reduction) take whole rows up to 512 channels per workgroup (128 float4 columns): a workgroup then
+// streams contiguous memory like a plain copy, where the reductions' 256-byte column strips touch 16 rows x 256 B spread over
+// 16 row pitches per iteration — normbwd_apply on 32 x 1024 x 336: 29.8 -> 23.7 us (4.4 -> 5.6 TB/s; torch's add on the same
+// bytes: 6.4), whole step 26.67 -> 26.52 ms (tools/probe_stream_bw.py; the reductions are faster on the narrow strips).
+inline RedGeom geom_ew(int G, int R, int C, int min_rows = 4) { return make_geom_ex(G, R, C, 2048, 4096, min_rows, 128); }
 
 }  // namespace
 
