@@ -693,7 +693,8 @@ inline RedPlan plan_reduce(int G, int R, int C, bool per_group, const double* ws
     const long contrib = per_group ? qa.P : (long)qa.G * qa.P;
     // >= 16 MB (row_elems pixels per row item): the pass is bandwidth-bound and wants ~2000 workgroups; its finalize
     // launch is noise
-    const bool big = (long)G * R * row_elems * (C / 4) >= big_elems;
+    // (per-group accumulators — the squeeze-excite sums: [G][C] — see only P adds per address whatever the size: one launch)
+    const bool big = !per_group && (long)G * R * row_elems * (C / 4) >= big_elems;
     if ((contrib <= lim && !big) || !ws) return RedPlan{qa, false};
     return RedPlan{make_geom_ex(G, R, C, 2048, 512, min_rows), true};
 }
