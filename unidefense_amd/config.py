@@ -22,8 +22,9 @@ through the environment (tools/run_with.py does).  Anything not listed here is a
 | spectral_p2 | UD_SPECTRAL_P2 | auto | the spectral 1x1 convs' forward / data-gradient GEMMs from pre-split fp16 x 2 planes (ud_gemm_p3 prec 2): `auto` where measured (or, untuned, estimated) faster than the in-kernel bf16 x 3 split, `on` wherever the kernel takes the shape, `off` never |
 | weight_plane_batch | UD_WEIGHT_PLANE_BATCH | 1 | the planes of all conv weights on the planes path made by two launches at the start of a forward (ud_split_planes_h2t_multi) instead of two per weight; a weight joins on its first eager use, planes are handed out only while the parameter's version is the one they were made from |
 
-The shared library itself reads three variables when it is loaded, for hosts that do not go through Python:
-UD_GEMM_PATH (the initial `ud_gemm_set_path` value: 0 auto, 1 fp32 pipe, 2 split-bf16 everywhere, 3 fp16 MFMA) and the
+The shared library itself reads four variables when it is loaded, for hosts that do not go through Python:
+UD_GEMM_PATH (the initial `ud_gemm_set_path` value: 0 auto, 1 fp32 pipe, 2 split-bf16 everywhere, 3 fp16 MFMA), UD_FFT32_WAVE
+(the initial `ud_fft32_set_wave` form of the 32 x 32 transforms: 0 one lane per row, 1 lane pairs; unset: per shape) and the
 kernel-bench overrides UD_GEMM_CFG / UD_GEMM_X3_CFG (force one tile configuration; tools/bench_gemm.py).
 """
 import os

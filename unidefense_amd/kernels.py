@@ -384,8 +384,9 @@ def p3_ok(M, N, K):
 
 
 # XCD-aware tile raster of ud_gemm_p3's plain / split-K launches: 0x200 | GM << 12 (groups of GM tile rows; see gemm_p3.hip).
-# Per shape 0-15 % faster than the round-robin deal (tools/probe_p3_raster.py; GM 2..8 alike), never slower; UD_P3_RASTER=0: off
-_P3_RASTER = int(os.environ.get("UD_P3_RASTER", "0x4200"), 0)
+# Per shape 0-15 % faster than the round-robin deal (tools/probe_p3_raster.py; GM 2..8 alike), never slower; 0: off
+# (A/B: tools/run_with.py unidefense_amd.kernels._P3_RASTER=0 -- python bench.py)
+_P3_RASTER = 0x4200
 
 
 def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=None, a_row0=0, cfg=0):
