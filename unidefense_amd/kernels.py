@@ -1321,27 +1321,33 @@ def _fft_col_weights(S, w_interior, like, twice):
 
 
 def _rfft2_generic(x, scale, w_interior):
-    """rfft2 of ud_rfft2's contract for any side: pixel-major -> planes, three DFT-matrix GEMMs (dft_rfft2_planes), back"""
+    """rfft2 of ud_rfft2's contract for any side: pixel-major -> (padded) planes in one strided copy, three DFT-matrix GEMMs
+    (_dft_planes_fwd), planes -> pixel-major with the column weights in one pass"""
     N, S, _, Cc = x.shape
     Wh = S // 2 + 1
-    d = x.float().permute(0, 3, 1, 2).reshape(N * Cc, S, S).contiguous()
-    Yp = dft_rfft2_planes(d, ortho=False)                                    # [P, 2S, Whp]: rows Re(ky) | Im(ky)
-    Y = Yp.view(N, Cc, 2, S, Yp.shape[-1])[..., :Wh].permute(0, 3, 4, 2, 1)      # [N, S, Wh, 2, C]
-    Y = Y * (_fft_col_weights(S, w_interior, x, False) * float(scale)).view(1, 1, Wh, 1, 1)
-    return Y.reshape(N, S, Wh, 2 * Cc).contiguous().to(x.dtype)
+    Sp = -(-S // 4) * 4
+    dp = torch.zeros((N, Cc, Sp, Sp), device=x.device) if Sp != S else torch.empty((N, Cc, S, S), device=x.device)
+    dp[:, :, :S, :S] = x.permute(0, 3, 1, 2)
+    Yp = _dft_planes_fwd(dp.view(N * Cc, Sp, Sp), S, ortho=False)             # [P, 2S, Whp]: rows Re(ky) | Im(ky)
+    Y = torch.empty((N, S, Wh, 2, Cc), device=x.device, dtype=x.dtype)
+    torch.mul(Yp.view(N, Cc, 2, S, Yp.shape[-1])[..., :Wh].permute(0, 3, 4, 2, 1),
+              (_fft_col_weights(S, w_interior, x, False) * float(scale)).view(1, 1, Wh, 1, 1), out=Y)
+    return Y.view(N, S, Wh, 2 * Cc)
 
 
 def _irfft2_generic(Y, scale, w_interior):
     """irfft2 of ud_irfft2's contract for any side: x = scale * F^T(m f Y), F the unnormalised rfft2 (its adjoint on the GEMM
-    kernels: dft_rfft2_planes_adjoint), m the Hermitian multiplicity, f = w_interior off the self-conjugate columns"""
+    kernels: _dft_planes_adj), m the Hermitian multiplicity, f = w_interior off the self-conjugate columns"""
     N, S, Wh, C2 = Y.shape
     Cc = C2 // 2
     Whp = -(-Wh // 4) * 4
-    Yw = Y.float().view(N, S, Wh, 2, Cc) * (_fft_col_weights(S, w_interior, Y, True) * float(scale)).view(1, 1, Wh, 1, 1)
-    dY = torch.zeros((N, Cc, 2, S, Whp), device=Y.device)
-    dY[..., :Wh] = Yw.permute(0, 4, 3, 1, 2)
-    x = dft_rfft2_planes_adjoint(dY.view(N * Cc, 2 * S, Whp), S, ortho=False)         # [P, S, S]
-    return x.view(N, Cc, S, S).permute(0, 2, 3, 1).contiguous().to(Y.dtype)
+    dY = torch.zeros((N, Cc, 2, S, Whp), device=Y.device) if Whp != Wh else torch.empty((N, Cc, 2, S, Whp), device=Y.device)
+    torch.mul(Y.view(N, S, Wh, 2, Cc).permute(0, 4, 3, 1, 2),
+              (_fft_col_weights(S, w_interior, Y, True) * float(scale)).view(1, 1, 1, 1, Wh), out=dY[..., :Wh])
+    xp = _dft_planes_adj(dY.view(N * Cc, 2 * S, Whp), S, ortho=False)          # [P, Sp, Sp], the transform in [:S, :S]
+    x = torch.empty((N, S, S, Cc), device=Y.device, dtype=Y.dtype)
+    x.copy_(xp.view(N, Cc, xp.shape[-2], xp.shape[-1])[:, :, :S, :S].permute(0, 2, 3, 1))
+    return x
 
 
 def rfft2(x, scale, w_interior=1.0, want_absmax=False):
@@ -1635,20 +1641,28 @@ def dft_rfft2_planes(d, ortho=True):
         Y = empty((P, 2 * S, -(-(S // 2 + 1) // 4) * 4), d)
         _call("ud_rfft2_planes", _p(d), _p(Y), _p(_fft_planes_ws(d, P, S)), P, S, (1.0 / S) if ortho else 1.0, _stream())
         return Y
-    fw_cos, fw_sin, fh = _dft_mats(S, d.device, ortho)
-    Whp, Sp = fw_cos.shape
-    if Sp != S:                                     # rows padded to a multiple of 4 floats (zeros times zero columns)
-        dp = torch.zeros((P, S, Sp), device=d.device)
-        dp[..., :S] = d
+    Sp = -(-S // 4) * 4
+    if Sp != S:                                     # rows and columns padded to a multiple of 4 floats (zeros)
+        dp = torch.zeros((P, Sp, Sp), device=d.device)
+        dp[:, :S, :S] = d
         d = dp
-    d2 = d.view(P * S, Sp)
-    t_re = gemm_nt(d2, fw_cos)                      # [P*S, Whp]
+    return _dft_planes_fwd(d, S, ortho)
+
+
+def _dft_planes_fwd(dp, S, ortho):
+    """dp: [P, Sp, Sp] planes holding the S x S data in [:S, :S] and zeros around (Sp = S rounded up to 4: every stride AND
+    every reduction length a multiple of 4 floats, the matrix-pipe kernels' condition) -> Y [P, 2S, Whp]"""
+    P, Sp, _ = dp.shape
+    fw_cos, fw_sin, fh = _dft_mats(S, dp.device, ortho)
+    Whp = fw_cos.shape[0]
+    d2 = dp.view(P * Sp, Sp)
+    t_re = gemm_nt(d2, fw_cos)                      # [P*Sp, Whp]; rows >= S of a plane are zero
     t_im = gemm_nt(d2, fw_sin)
-    Y = empty((P, 2 * S, Whp), d)
-    # Y_p = fh[:, :S] @ Tre_p + fh[:, Sp:Sp+S] @ Tim_p     (batched over planes; A shared)
-    _gemm(fh, t_re, Y, 2 * S, Whp, S, 2 * Sp, Whp, Whp, 0, 1, 0, batch=P, strideA=0, strideB=S * Whp,
+    Y = empty((P, 2 * S, Whp), dp)
+    # Y_p = fh[:, :Sp] @ Tre_p + fh[:, Sp:] @ Tim_p     (batched over planes; A shared; the zero columns meet the zero rows)
+    _gemm(fh, t_re, Y, 2 * S, Whp, Sp, 2 * Sp, Whp, Whp, 0, 1, 0, batch=P, strideA=0, strideB=Sp * Whp,
           strideC=2 * S * Whp)
-    _gemm(fh, t_im, Y, 2 * S, Whp, S, 2 * Sp, Whp, Whp, 0, 1, 1, batch=P, strideA=0, strideB=S * Whp,
+    _gemm(fh, t_im, Y, 2 * S, Whp, Sp, 2 * Sp, Whp, Whp, 0, 1, 1, batch=P, strideA=0, strideB=Sp * Whp,
           strideC=2 * S * Whp, a_off=Sp)
     return Y
 
@@ -1662,19 +1676,25 @@ def dft_rfft2_planes_adjoint(dY, S, ortho=True):
         _call("ud_rfft2_planes_adjoint", _p(dY), _p(dd), _p(_fft_planes_ws(dY, P, S)), P, S, (1.0 / S) if ortho else 1.0,
               _stream())
         return dd
+    dd = _dft_planes_adj(dY, S, ortho)
+    return dd if dd.shape[-1] == S else dd[:, :S, :S].contiguous()
+
+
+def _dft_planes_adj(dY, S, ortho):
+    """adjoint of _dft_planes_fwd: dY [P, 2S, Whp] -> [P, Sp, Sp] with the S x S result in [:S, :S] (zeros around)"""
+    P = dY.shape[0]
     fw_cos, fw_sin, fh = _dft_mats(S, dY.device, ortho)
     Whp, Sp = fw_cos.shape
-    dt_re = empty((P * S, Whp), dY)
-    dt_im = empty((P * S, Whp), dY)
-    # dTre_p = fh[:, :S]^T @ dY_p ;  dTim_p = fh[:, Sp:Sp+S]^T @ dY_p        (A[k][m] = fh[k][m(+Sp)])
-    _gemm(fh, dY, dt_re, S, Whp, 2 * S, 2 * Sp, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
-          strideC=S * Whp)
-    _gemm(fh, dY, dt_im, S, Whp, 2 * S, 2 * Sp, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
-          strideC=S * Whp, a_off=Sp)
-    dd = gemm_nn(dt_re, fw_cos)                     # [P*S, Whp] @ [Whp, Sp]
+    dt_re = empty((P * Sp, Whp), dY)
+    dt_im = empty((P * Sp, Whp), dY)
+    # dTre_p = fh[:, :Sp]^T @ dY_p ;  dTim_p = fh[:, Sp:]^T @ dY_p        (A[k][m] = fh[k][m(+Sp)]; rows m >= S come out zero)
+    _gemm(fh, dY, dt_re, Sp, Whp, 2 * S, 2 * Sp, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
+          strideC=Sp * Whp)
+    _gemm(fh, dY, dt_im, Sp, Whp, 2 * S, 2 * Sp, Whp, Whp, 1, 1, 0, batch=P, strideA=0, strideB=2 * S * Whp,
+          strideC=Sp * Whp, a_off=Sp)
+    dd = gemm_nn(dt_re, fw_cos)                     # [P*Sp, Whp] @ [Whp, Sp]
     gemm_nn(dt_im, fw_sin, out=dd, accumulate=True)
-    dd = dd.view(P, S, Sp)
-    return dd if Sp == S else dd[..., :S].contiguous()
+    return dd.view(P, Sp, Sp)
 
 
 # ---------------------------------------------------------------------------------------------
