@@ -7,10 +7,15 @@ engine/abstract_engine.py:210-281 in the reference) at 256x256, bs=32 per GPU, f
 
 Prints ONE JSON line on rank 0 (metric/unit from BASELINE.json; value = whole-job images/s with inputs
 resident in HBM; weak scaling: bs=32 per GPU).  Extra objects:
-  roofline     — dominant kernel = gemm_x3_kernel (fp32 GEMM on the BF16 matrix pipe, six bf16 MFMAs per fp32 product
-                 tile): algorithmic FLOPs (2MNK) of its launches / their HIP-event durations (3 eager instrumented steps
-                 after the timed region), against the pipe's dense BF16 peak / 6 (= 416.7 TFLOP/s); `hbm`: the same
-                 launches' algorithmic bytes against 8 TB/s; `traffic`: PMC-measured HBM bytes per launch (profiles/).
+  roofline     — dominant kernels = the matrix-pipe GEMM family: gemm_p3_kernel<prec 2> (operands pre-split into two fp16
+                 planes, THREE fp16 MFMAs per fp32 product tile) + gemm_x3_kernel (in-kernel bf16 x 3 split, SIX MFMAs):
+                 algorithmic FLOPs (2MNK) of their launches / their HIP-event durations (3 eager instrumented steps after
+                 the timed region); peak = the pipe's dense 16-bit peak (2.5 PFLOP/s) / executed MFMAs per algorithmic
+                 product, so frac = executed MFMA work / pipe peak (`frac_six_product_equiv`: the same work priced at six
+                 MFMAs per product, the round-3 definition); `hbm`: the same launches' algorithmic bytes against 8 TB/s;
+                 `traffic`: PMC-measured HBM bytes per launch (profiles/).
+  extra        — bounded child-process measurements of the other BASELINE configs ([4] f16 bs 64, [3] UDR50 320^2 bs 16,
+                 [0] UDR18 128^2 bs 8), the engine's two-pass train step and UDEB4 at 380^2 (N = 1 only).
   cpu_baseline — the oracle (CPU restatement, "port") timed on the host cores (CPU quota of the job) on a bounded
                  sample (bs 8, ~10 s), in a child process after the timed region.
 """
