@@ -16,6 +16,10 @@ if ROOT not in sys.path:
 os.environ["UD_DETERMINISTIC"] = os.environ.get("UD_TEST_DETERMINISTIC", "1")
 os.environ.setdefault("UD_GEMM_TUNE", "0")
 
+from tests import oracle_util as _ou      # noqa: E402
+
+_ou.fit_cpu_threads()                      # the CPU oracle on the job's CPU quota, not on every logical CPU of the host
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -1,7 +1,33 @@
 """Helpers shared by the tests: build oracle state, run oracle fwd/bwd with seeded masks."""
+import os
+
 import torch
 
 from oracle import eb4, losses, param_fill
+
+def job_cores():
+    """CPU cores this process may really use: min(affinity mask, cgroup-v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def fit_cpu_threads():
+    """The CPU oracle on the cores of the JOB.  The GPU boxes show 256 logical CPUs under a 16-CPU quota and torch starts 128
+    threads there: the float64 oracle of one element-wise gradient test then takes 51 s instead of 3.4 s (tools/
+    probe_oracle_threads.py) — two thirds of the GPU suite's wall time were throttled OpenMP threads.  Children inherit the count
+    through OMP_NUM_THREADS."""
+    n = job_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return n
+
 
 LAMBDAS = dict(lambda_triplet=0.1, lambda_recons=0.1, lambda_freq=1.0, lambda_mask=0.1, lambda_fac=0.1)
 
