@@ -522,6 +522,14 @@ int ud_adamw_multi(const void* table, const void* chunk_map, int n_chunks, const
                    double beta1, double beta2, double eps, int amsgrad, int maximize, const float* grad_scale,
                    const float* found_inf, const int* step_in, int* step_out, ud_stream_t stream);
 
+/* ---- gradient accumulation of a second backward (csrc/optim.hip) --------------------------------------------------
+ * The train step calls backward() twice per zero_grad() (engine/abstract_engine.py:281 and :374 under the one
+ * optimizer.zero_grad() of engine/forgery_engine.py:241): torch's AccumulateGrad adds the second backward's gradients with one
+ * launch per parameter tensor.  ud_multi_add: dst[i][0..numel[i]) += src[i][0..numel[i]) for n fp32 tensors in ceil(n / 120)
+ * launches; dst / src / numel are HOST arrays (device pointers inside), read at call time — nothing staged on the device, so the
+ * call can sit inside a captured step.  numel[i] < 2^31. */
+int ud_multi_add(void* const* dst, const void* const* src, const long* numel, int n, ud_stream_t stream);
+
 /* ---- LDS-tiled depthwise conv, stride 1 (csrc/dwtile.hip) -----------------------------------------------------------
  * The depthwise k x k conv of MBConvBlock.forward (model/efficientnet/model.py:112-115; SFConv's spatial branch
  * exp.py:49-51) with a halo tile of 32 channels staged in LDS once per workgroup, act(bn_in(src)) applied while staging

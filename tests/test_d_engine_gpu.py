@@ -136,6 +136,49 @@ def test_graph_captured_step_equals_eager_step():
     assert all(ok)      # observed (atomics mode): 3e-6 / 8e-4 / 5e-2
 
 
+def test_second_backward_accumulates_in_one_launch_like_autograd():
+    """The train step's second backward adds onto the first's gradients (one zero_grad per step, engine/forgery_engine.py:241;
+    backward at abstract_engine.py:281 and :374).  The engine lets the model do that with ONE multi-tensor launch
+    (model/unidefense.py:_accumulate_in_place, csrc/optim.hip:ud_multi_add) instead of autograd's AccumulateGrad launch per
+    parameter: same gradients bit for bit (fp32 a + b either way), hence the same parameters after the step; and the launch
+    count of the eager step falls by the ~500 adds."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    dev = torch.device("cuda:0")
+    from unidefense_amd.config import override
+    from unidefense_amd.model import perturb
+    from unidefense_amd.model import unidefense as U
+    n = 4
+    tgt = param_fill.make_labels(n).to(dev)
+    x = param_fill.make_input(n, 256, 61).to(dev)
+    orig, orig_min = perturb.perturb_input, U._MULTI_ADD_MIN
+    perturb.perturb_input = lambda x_, a, b, c: perturb.downscale(x_)
+    res = {}
+    try:
+        with override(deterministic=True, gemm_tune=False):
+            for mode in ("autograd", "multi"):
+                U._MULTI_ADD_MIN = 10 ** 9 if mode == "autograd" else orig_min
+                eng = _make_engine(dev, False)
+                scaler = torch.amp.GradScaler("cuda", init_scale=2 ** 10, enabled=True)
+                calls = []
+                real = U.K.multi_add
+                U.K.multi_add = lambda d, s_: (calls.append(len(d)), real(d, s_))[1]
+                try:
+                    eng.optimizer.zero_grad()
+                    eng.train_unidefense_model(x, tgt, 50, scaler, n // 2, n // 2)
+                finally:
+                    U.K.multi_add = real
+                res[mode] = ({k: p.grad.detach().clone() for k, p in eng.model.named_parameters() if p.grad is not None},
+                             {k: p.detach().clone() for k, p in eng.model.named_parameters()}, calls)
+    finally:
+        perturb.perturb_input, U._MULTI_ADD_MIN = orig, orig_min
+    assert res["autograd"][2] == [] and len(res["multi"][2]) == 1 and res["multi"][2][0] >= 490, (res["autograd"][2], res["multi"][2])
+    for k, g in res["autograd"][0].items():
+        assert torch.equal(g, res["multi"][0][k]), k
+    for k, p in res["autograd"][1].items():
+        assert torch.equal(p, res["multi"][1][k]), k
+
+
 def _engine_for(m, dev, num_steps):
     from unidefense_amd.engine import AbstractEngine
     from unidefense_amd.engine.optim import build_optimizer

@@ -137,3 +137,46 @@ def test_state_dict_round_trip_and_interchange_with_torch_adamw(amsgrad):
     ref.step()
     hip3.step()
     assert hip3.step_count() == 7 and all(_rel(e, a) <= 2e-6 for e, a in zip(pe, pa))
+
+
+def test_multi_add_equals_per_tensor_add():
+    """ud_multi_add (csrc/optim.hip: the gradient accumulation of the train step's second backward, engine/abstract_engine.py:281
+    and :374 under one zero_grad) against torch's `dst += src` per tensor: bit-identical, for 300 tensors (three launches of up to
+    120 items) of ragged sizes — scalars, lengths that are not multiples of 4 or of the 16384-element chunk, one of 11 M elements,
+    empty ones, and views whose base address is only 4-byte aligned; captured into a hipGraph and replayed too."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidefense_amd import kernels as K
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 3, 4, 5, 24, 1000, 16383, 16384, 16385, 65537, 0, 3264 * 3264, 131075, 7, 48 * 27]
+    sizes = (sizes * 20)[:300]
+    sizes[40] = 0
+    dst, src = [], []
+    for i, n in enumerate(sizes):
+        n = n if (n < 10 ** 6 or i < 15) else 1000           # the 11 M tensor once
+        d, s = torch.randn(n + 3, generator=g).to(dev), torch.randn(n + 3, generator=g).to(dev)
+        o = i % 3                                             # offsets 0 / 4 / 8 bytes: aligned and unaligned bases mixed
+        dst.append(d[o:o + n])
+        src.append(s[(o + 1) % 3:(o + 1) % 3 + n])
+    want = [d + s for d, s in zip(dst, src)]
+    keep = [d.clone() for d in dst]
+    K.multi_add(dst, src)
+    torch.cuda.synchronize()
+    for i, (d, w) in enumerate(zip(dst, want)):
+        assert torch.equal(d, w), (i, sizes[i])
+    # replayed from a graph: the (dst, src, numel) triples travel in the kernel arguments, nothing is staged on the device
+    for d, k in zip(dst, keep):
+        d.copy_(k)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            K.multi_add(dst, src)
+        gr.replay()                                           # the capture itself does not execute
+    torch.cuda.synchronize()
+    for i, (d, w) in enumerate(zip(dst, want)):
+        assert torch.equal(d, w), ("graph", i, sizes[i])
+    with pytest.raises(ValueError):
+        K.multi_add([dst[0]], [src[0].double()])

@@ -24,8 +24,9 @@ def step(i):
     eng.optimizer.zero_grad()
     return eng.train_unidefense_model(x, tgt, 200 + i, scaler, bs // 2, bs // 2)
 for i in range(3): step(i)
+torch.manual_seed(int(os.environ.get("UD_BENCH_SEED", "0")))      # the same sequence of host-random perturbation branches in every run (A/B)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 8
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 for i in range(n): r = step(i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print("two-pass train step: %.1f ms  ->  %.1f train images/s (each image goes through 2 passes); total_loss %.4f" % (dt * 1e3, bs / dt, float(r["total_loss"])))

@@ -146,6 +146,12 @@ class AbstractEngine(object):
         hipGraph on the second call with a given shape and replayed afterwards; perturbation, optimizer, scaler and
         scheduler calls stay outside the graphs (host-side randomness / synchronisation)."""
         kl = cur_step > self.num_steps * 0.1
+        # the second backward of the step adds onto the first's gradients: one multi-tensor launch instead of autograd's 504
+        # AccumulateGrad launches (model/unidefense.py:_accumulate_in_place) — unless torch's DDP wraps the model (its reducer
+        # hooks hang on those very nodes)
+        core = getattr(self.model, "module", self.model)
+        if hasattr(core, "_run"):
+            core._ud_inplace_accumulate = not isinstance(self.model, torch.nn.parallel.DistributedDataParallel)
         if self.use_graphs and not getattr(self.model, "rng_queue", None) and in_data.is_cuda:
             return self._train_graphed(in_data, in_tgt, cur_step, grad_scalar, sum_real, sum_fake, kl)
         # ---------------- pass 1: clean input ------------------------------------------------------

@@ -1488,6 +1488,21 @@ def axpby(a, alpha, b=None, beta=1.0, out=None):
     return out
 
 
+def multi_add(dsts, srcs):
+    """dsts[i] += srcs[i] for lists of contiguous fp32 device tensors of equal sizes, in ceil(n / 120) launches (the gradient
+    accumulation of the train step's second backward: torch's AccumulateGrad launches once per parameter)"""
+    n = len(dsts)
+    if n == 0:
+        return
+    for d, s_ in zip(dsts, srcs):
+        if not (d.is_cuda and s_.is_cuda and d.dtype == s_.dtype == torch.float32 and d.is_contiguous() and s_.is_contiguous()
+                and d.numel() == s_.numel() and d.device == s_.device):
+            raise ValueError("multi_add: contiguous float32 device tensors of equal sizes only")
+    PA, LA = C.c_void_p * n, C.c_long * n
+    _call("ud_multi_add", PA(*[d.data_ptr() for d in dsts]), PA(*[s_.data_ptr() for s_ in srcs]),
+          LA(*[d.numel() for d in dsts]), n, _stream())
+
+
 def mask_scale(x, mask, scale):
     _chk(x, mask)
     out = torch.empty_like(x)

@@ -168,6 +168,7 @@ _SIGNATURES = {
     "ud_rfft2_planes_adjoint": [_P, _P, _P, _L, _I, _F, _P],
     "ud_adamw_chunk_elems": [],
     "ud_adamw_multi": [_P, _P, _I, _P, _P, _I, C.c_double, C.c_double, C.c_double, _I, _I, _P, _P, _P, _P, _P],
+    "ud_multi_add": [_P, _P, _P, _I, _P],
     "ud_gemm_get_path": [],
     "ud_sum_slices": [_P, _P, _I, _L, _L, _I, _P],
     "ud_xchg_bytes": [_I, _I, _I],
