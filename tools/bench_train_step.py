@@ -1,6 +1,8 @@
 """GPU, informational: the full two-pass train step of the engine (AbstractEngine.train_unidefense_model: clean pass +
-perturbed pass, two fused-AdamW steps) on UDEB4 256x256 bs 32, eager launches (the step has host-side random
-control flow, so it is not graph-captured)."""
+perturbed pass, two fused-AdamW steps) on UDEB4 256x256, the engine's default execution (each pass replayed from its
+hipGraph; perturbation / optimizer / scheduler between them on the host's schedule).
+usage: bench_train_step.py [batch=32] [steps=8]      UD_BENCH_SEED seeds the host RNG of the timed steps (A/B runs see the
+same sequence of perturbation branches)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
