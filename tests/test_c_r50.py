@@ -15,6 +15,10 @@ from tests import oracle_util as ou
 from tests.margins import within
 
 GRAD_RTOL, GRAD_ATOL = 1e-3, 2e-5
+# full loss variant: the L1 reconstruction / frequency tails make the decoder gradients sums of unit-modulus terms — two fp32
+# evaluations (the oracle's own included) differ by ~1e-2 of the tensor there, so the bound is led by the 5 x oracle-fp32 yardstick;
+# this is its floor (tests/test_c_model_gpu.py uses the same value for UDEB4)
+FULL_RTOL = 2e-2
 
 
 FIXTURES = ["udr50_n4.npz", "udr50_n4_s320.npz"]      # 256x256, and BASELINE configs[3]'s 320x320 (5*2^k FFT sizes)
@@ -88,7 +92,7 @@ def test_oracle_r50_matches_reference_golden(golden_dir, fixture):
         if variant == "full":
             _check_outputs(out, g, "f64_train_", 1e-8)
         total = _loss(out, tgt, lam)
-        ref_total = float(g[f"f64_{variant}_loss_total_loss"])
+        ref_total = float(g[f"{variant}_loss_total_loss"])
         assert abs(total.item() - ref_total) <= 1e-10 * abs(ref_total)
         total.backward()
         for i, k in enumerate(str(s) for s in g["grad_names"]):
@@ -115,9 +119,14 @@ def to_nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
+# the full variant (round 4): the L1 reconstruction / frequency tails' backward at 320 x 320 through the WHOLE model, not only
+# through the kernel-level adjoint test of the 320-point transforms
+CASES = [("udr50_n4.npz", "smooth"), ("udr50_n4_s320.npz", "smooth"), ("udr50_n4_s320.npz", "full")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture", FIXTURES)
-def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
+@pytest.mark.parametrize("fixture,variant", CASES)
+def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture, variant):
     dev = _dev()
     from unidefense_amd.loss import LOSSES
     from unidefense_amd.model import load_model
@@ -131,7 +140,7 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
     m = m.to(dev)
     with torch.no_grad():
         _check_outputs(m.eval()(x.to(dev)), g, "eval_", 1e-3)
-    lam = ou.SMOOTH_LAMBDAS
+    lam = ou.SMOOTH_LAMBDAS if variant == "smooth" else ou.LAMBDAS
     m.train()
     m._debug_watch = True
     out = m(x.to(dev), rng=rng)
@@ -175,8 +184,13 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
     trip = sum(LOSSES["aw_triplet"](f, t) for f in ld["triplet"])
     total = LOSSES["cross_entropy"](out["cls_out"], t) + lam["lambda_mask"] * (ld["freq_mask"].mean() + ld["spat_mask"].mean()) \
         + lam["lambda_triplet"] * trip
-    e = abs(total.item() - float(g["smooth_loss_total_loss"])) / abs(float(g["smooth_loss_total_loss"]))
-    assert within("smooth total loss", e, 1e-3), e
+    if variant == "full":
+        n_real = n // 2
+        total = total + lam["lambda_recons"] * ld["spatial"].narrow(0, 0, n_real).mean() \
+            + lam["lambda_freq"] * ld["freq"].narrow(0, 0, n_real).mean()
+    ref_total = float(g[f"f64_{variant}_loss_total_loss"])
+    e = abs(total.item() - ref_total) / abs(ref_total)
+    assert within(f"{variant} total loss", e, 1e-3), e
     total.backward()
     rows = []
     coef_scale = max(sd64[k].grad.abs().max().item() for k, p in m.named_parameters()
@@ -191,13 +205,14 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture):
         # on the pinned piece the problem is smooth: 1e-4 of the tensor's scale (observed: <= 2e-5), never looser
         # than 5x what the CPU fp32 run or a one-ulp input perturbation do to the same gradient
         # (the scalar mixing coefficients are global sums with heavy cancellation: 1e-3 of their magnitude)
+        rt = 1e-4 if variant == "smooth" else FULL_RTOL
         if k.endswith(("sf_coef", "fuse_coef")):
             # each is ONE sum of ~1e6 products dd * (freq - spat) that cancels to a layer-dependent degree (|ref| from
             # 0.05 to 3 in this model): the error scales with the terms, not with what is left of their sum — measure it
             # against the common scale of these gradients, not only against the tensor's own remainder
-            floor = 1e-3 * max(s, 0.2 * coef_scale) + 2e-6
+            floor = max(1e-3, rt) * max(s, 0.2 * coef_scale) + 2e-6
         else:
-            floor = 1e-4 * s + 2e-6
+            floor = rt * s + 2e-6
         rows.append((d / max(floor, 5.0 * d32, 5.0 * sens.get(k, 0.0)), k, d, s, d32, sens.get(k, 0.0)))
     rows.sort(reverse=True)
     for r in rows[:10]:
