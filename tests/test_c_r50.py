@@ -92,7 +92,7 @@ def test_oracle_r50_matches_reference_golden(golden_dir, fixture):
         if variant == "full":
             _check_outputs(out, g, "f64_train_", 1e-8)
         total = _loss(out, tgt, lam)
-        ref_total = float(g[f"{variant}_loss_total_loss"])
+        ref_total = float(g[f"f64_{variant}_loss_total_loss"])
         assert abs(total.item() - ref_total) <= 1e-10 * abs(ref_total)
         total.backward()
         for i, k in enumerate(str(s) for s in g["grad_names"]):
@@ -188,7 +188,7 @@ def test_r50_vs_reference_golden_and_oracle(golden_dir, fixture, variant):
         n_real = n // 2
         total = total + lam["lambda_recons"] * ld["spatial"].narrow(0, 0, n_real).mean() \
             + lam["lambda_freq"] * ld["freq"].narrow(0, 0, n_real).mean()
-    ref_total = float(g[f"f64_{variant}_loss_total_loss"])
+    ref_total = float(g[f"{variant}_loss_total_loss"])
     e = abs(total.item() - ref_total) / abs(ref_total)
     assert within(f"{variant} total loss", e, 1e-3), e
     total.backward()
