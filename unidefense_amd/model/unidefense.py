@@ -127,7 +127,7 @@ def _accumulate_in_place(model, params, grads):
     idx = [i for i, (p, g) in enumerate(zip(params, grads))
            if g is not None and p.grad is not None and p.grad.dtype == torch.float32 and g.dtype == torch.float32
            and p.grad.is_contiguous() and p.grad.shape == g.shape and p.grad.device == g.device and not p.grad.requires_grad
-           and not p._backward_hooks]
+           and not p._backward_hooks and not getattr(p, "_post_accumulate_grad_hooks", None)]
     if len(idx) < _MULTI_ADD_MIN:
         return grads
     K.multi_add([params[i].grad for i in idx], [grads[i].contiguous() for i in idx])
