@@ -202,19 +202,37 @@ def self_launch(n):
     return subprocess.run(cmd, env=env, cwd=ROOT).returncode
 
 
-def _pmc_traffic(args, bs, family="gemm_x3_kernel"):
+def _gemm_src_sha():
+    """sha256 over the GEMM kernels' sources (csrc/gemm*.hip / .h): what a PMC summary must have been measured on"""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "unidefense_amd", "csrc", "gemm*"))):
+        if f.endswith((".hip", ".h")):
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_traffic(args, bs, family=None):
     """roofline.traffic: HBM bytes per GEMM launch from the committed PMC summary of this same workload
     (tools/gpu_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 half-count correction).  PMC passes
-    cannot run inside the timed bench, so the number is read from profiles/; None when no summary matches."""
+    cannot run inside the timed bench, so the number is read from profiles/ — and only from a summary stamped with the
+    hash of the GEMM sources this tree builds (`gemm_src_sha`): a summary of other kernels is not these kernels' traffic.
+    family: a key of the summary's `families` (one kernel), None: the matrix-pipe family.  (None, None) when nothing matches."""
     if (args.model, args.size, bs) != ("UDEB4", 256, 32):
         return None, None
     import glob
     root = os.path.dirname(os.path.abspath(__file__))
+    sha = _gemm_src_sha()
     for f in sorted(glob.glob(os.path.join(root, "profiles", "r*", "hbm_traffic_gemm.json")), reverse=True):
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            fam = d.get("families", {}).get(family) or d.get("gemm_family")       # the roofline's kernel family
+            if d.get("gemm_src_sha") != sha:
+                continue
+            fam = d.get("families", {}).get(family) if family else d.get("gemm_family")
             if fam is None:
                 continue
             return float(fam["hbm_bytes_per_launch"]), os.path.relpath(f, root)
@@ -376,11 +394,34 @@ def main():
     # ---- roofline of the dominant kernel: the same step, eager, every ud_gemm launch bracketed by HIP events
     # on its launch stream (events cannot be read back from inside a replayed graph)
     prof_steps = min(args.steps, 3)
+    from unidefense_amd import tape as T
     K.GEMM_PROFILE = []
+    if dist.is_initialized():
+        T.DP_PROFILE = {"bn": [], "ar": []}
     for _ in range(prof_steps):
         step()
     torch.cuda.synchronize()
     prof, K.GEMM_PROFILE = K.GEMM_PROFILE, None
+    # ---- data-parallel diagnostics (N > 1, or UD_FORCE_COLLECTIVES=1 on one GPU): the same eager instrumented steps.
+    # syncbn_exchange_ms: device time of the ~210 SyncBN sums of a step (HIP events around each on its stream: at N > 1 this
+    # INCLUDES the wait for the slowest peer, i.e. rank skew + xGMI latency on the forward's / backward's dependency chain);
+    # allreduce_exposed_ms: end of the backward's own kernels -> last gradient collective waited for (what the overlap did
+    # not hide); both the MAX over the ranks.
+    dp_diag = None
+    if T.DP_PROFILE is not None:
+        dpp, T.DP_PROFILE = T.DP_PROFILE, None
+        bn_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in dpp["bn"]) / prof_steps
+        ar_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in dpp["ar"]) / prof_steps
+        worst = torch.tensor([bn_ms, ar_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        dp_diag = {"syncbn_exchanges_per_step": len(dpp["bn"]) / prof_steps,
+                   "syncbn_exchange_ms": float(worst[0]), "syncbn_exchange_ms_rank0": bn_ms,
+                   "syncbn_doubles_per_step": sum(n for _, _, n in dpp["bn"]) / prof_steps,
+                   "allreduce_exposed_ms": float(worst[1]), "allreduce_exposed_ms_rank0": ar_ms,
+                   "allreduce_bytes": sum(b for _, _, b, _ in dpp["ar"]) / prof_steps,
+                   "allreduce_collectives": sum(c for _, _, _, c in dpp["ar"]) / prof_steps,
+                   "measured": f"{prof_steps} eager instrumented steps after the timed region, HIP events on the launch stream; "
+                               "MAX over the ranks"}
 
     if rank == 0 and args.gemm_table:
         agg = {}
@@ -440,7 +481,7 @@ def main():
         alg_bytes = dom["algorithmic_bytes_per_launch"]
         hbm_gbs = dom["hbm_gbs"]
         n_dom = dom["launches_per_step"]
-        traffic, traffic_src = _pmc_traffic(args, bs, dom_name)
+        traffic, traffic_src = _pmc_traffic(args, bs)
         line = {
             "metric": ("images/sec fwd+bwd (256x256, EffNet-b4)" if (args.model, args.size) == ("UDEB4", 256)
                        else f"images/sec fwd+bwd ({args.size}x{args.size}, {args.model})")
@@ -506,6 +547,8 @@ def main():
                                      "graph-replayed steps of this same command (tools/gpu_round.sh), and "
                                      "tools/roofline_from_rocprof.py recomputes these numbers from it"},
         }
+        if dp_diag is not None:
+            line["data_parallel"] = dp_diag
         if args.dtype == "f16":
             # informational f16 line: the HBM side is the roofline (bound "hbm"); the matrix-pipe numbers move to "mfma"
             r = line["roofline"]

@@ -38,7 +38,52 @@ def test_scheduler_factory():
     c.step()
     assert c.get_last_lr() == [0.3]
     with pytest.raises(KeyError):
-        build_scheduler(opt, {"name": "TimmCosineLR"})
+        build_scheduler(opt, {"name": "NoSuchLR"})
+
+
+def test_timm_schedulers_follow_the_published_formulas():
+    """TimmStepLR / TimmCosineLR of the reference's table (scheduler/__init__.py:24,31): closed-form values of
+    timm.scheduler.StepLRScheduler / CosineLRScheduler (timm is absent here: parity unpinned), driven the way the reference's
+    engines drive every scheduler — step() with no argument, get_last_lr()."""
+    import math
+    from unidefense_amd.engine.optim import SCHEDULERS, build_scheduler
+    assert set(SCHEDULERS) == {"ConstantLR", "StepLR", "TimmStepLR", "MultiStepLR", "CosineAnnealingLR",
+                               "CosineAnnealingWarmRestarts", "ExponentialLR", "ReduceLROnPlateau", "TimmCosineLR"}
+    p = torch.nn.Parameter(torch.zeros(2))
+    opt = torch.optim.SGD([{"params": [p], "lr": 0.2}, {"params": [torch.nn.Parameter(torch.zeros(1))], "lr": 0.1}], lr=0.2)
+    s = build_scheduler(opt, {"name": "TimmStepLR", "decay_t": 3, "decay_rate": 0.5, "warmup_t": 2, "warmup_lr_init": 0.0})
+    assert s.get_last_lr() == [0.0, 0.0]                                    # the warm-up's start value is set at construction
+    seen = []
+    for _ in range(9):
+        s.step()
+        seen.append(s.get_last_lr()[0])
+    # t = 1: warm-up 0.1; from t = 2 the decay clock runs on t - 2 (warmup_prefix): 0.2 x 0.5 ** ((t - 2) // 3)
+    want = [0.1] + [0.2 * 0.5 ** ((t - 2) // 3) for t in range(2, 10)]
+    assert seen == pytest.approx(want, abs=1e-15)
+    assert s.get_last_lr()[1] == pytest.approx(want[-1] / 2)                # every group from its own initial_lr
+    opt = torch.optim.SGD([p], lr=1.0)
+    c = build_scheduler(opt, {"name": "TimmCosineLR", "t_initial": 4, "lr_min": 0.1, "cycle_decay": 0.5, "cycle_limit": 2})
+    got = []
+    for _ in range(9):
+        c.step()
+        got.append(c.get_last_lr()[0])
+    want = []
+    for t in range(1, 10):
+        i, tc = divmod(t, 4)
+        want.append(0.1 if i >= 2 else 0.1 + 0.5 * (0.5 ** i - 0.1) * (1 + math.cos(math.pi * tc / 4)))
+    assert got == pytest.approx(want, abs=1e-15)
+    c.step(epoch=2)                                                         # timm's own calling convention still works
+    assert c.get_last_lr()[0] == pytest.approx(0.1 + 0.45 * (1 + math.cos(math.pi / 2)))
+    m = build_scheduler(torch.optim.SGD([p], lr=1.0), {"name": "TimmCosineLR", "t_initial": 2, "cycle_mul": 2.0, "cycle_limit": 3})
+    vals = []
+    for _ in range(7):
+        m.step()
+        vals.append(m.get_last_lr()[0])
+    # cycles of length 2, 4, 8 starting at t = 0, 2, 6
+    assert vals == pytest.approx([0.5, 1.0, 0.5 * (1 + math.cos(math.pi / 4)), 0.5, 0.5 * (1 + math.cos(3 * math.pi / 4)), 1.0,
+                                  0.5 * (1 + math.cos(math.pi / 8))], abs=1e-12)
+    with pytest.raises(TypeError):
+        build_scheduler(opt, {"name": "TimmStepLR", "decay_t": 1, "noise_range_t": 3})
 
 
 @pytest.mark.gpu

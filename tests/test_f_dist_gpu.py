@@ -54,6 +54,17 @@ def test_bench_line_contract():
     assert set(fams) == {"gemm_p3_kernel<prec 2>", "gemm_x3_kernel"}
     assert fams["gemm_p3_kernel<prec 2>"]["mfma_per_product"] == 3 and fams["gemm_x3_kernel"]["mfma_per_product"] == 6
     assert "traffic" in r and line["config"]["n_ranks_seen"] == 1
+    assert "data_parallel" not in line                                   # a plain one-rank run issues no collective
+    # the same line with the data-parallel path forced on (RCCL process group of one rank): the diagnostics that make the
+    # first real N > 1 run readable — how many SyncBN sums, their device time, the exposed tail of the gradient exchange
+    forced, err = _bench({"UD_FORCE_COLLECTIVES": "1", "MASTER_PORT": "29543"})
+    d = forced["data_parallel"]
+    for k in ("syncbn_exchanges_per_step", "syncbn_exchange_ms", "allreduce_exposed_ms", "allreduce_bytes", "allreduce_collectives"):
+        assert isinstance(d[k], float) and d[k] >= 0.0, (k, d)
+    assert 150 <= d["syncbn_exchanges_per_step"] <= 260, d              # 99 BatchNorms: forward + backward sums
+    assert 0.0 < d["syncbn_exchange_ms"] < 10.0, d
+    assert abs(d["allreduce_bytes"] - 4 * 128.31e6) < 2e6, d             # every trainable parameter's gradient, fp32, once
+    assert 20 <= d["allreduce_collectives"] <= 80, d                     # ~34 in-place spectral weights + the packed buckets
 
 
 @pytest.mark.parametrize("flags", [(), ("--eager",)])

@@ -9,7 +9,7 @@ mkdir -p $out
 export PYTHONDONTWRITEBYTECODE=1
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-export UD_GEMM_TUNE_CACHE=${UD_GEMM_TUNE_CACHE:-$PWD/profiles/r04/gemm_plans.json}     # no tuner launches among the counted ones
+export UD_GEMM_TUNE_CACHE=${UD_GEMM_TUNE_CACHE:-$PWD/profiles/r04/gemm_plans_retuned.json}     # no tuner launches among the counted ones
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -o $c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --eager $BENCH_ARGS > $out/$c.log 2>&1
   echo "$c pass exit $?"
@@ -28,7 +28,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                    "gemm_kernel" if "gemm_kernel" in name else "other")
             a = agg[fam]; a[0] += 1; a[1] += float(r["Counter_Value"])
     tot[c] = {k: v for k, v in agg.items()}
-res = {"recipe": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
+import hashlib
+def gemm_src_sha():          # bench.py:_gemm_src_sha — the summary belongs to these kernel sources and no others
+    h = hashlib.sha256()
+    for f in sorted(glob.glob("unidefense_amd/csrc/gemm*")):
+        if f.endswith((".hip", ".h")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+res = {"gemm_src_sha": gemm_src_sha(), "recipe": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
                  "--warmup 1 --no-cpu-baseline --eager; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE "
                  "half-count correction of MI355X_MICROARCH.md)", "families": {}}
 for fam in ("gemm_p3_kernel", "gemm_x3_kernel", "gemm_kernel", "other"):

@@ -1,6 +1,6 @@
 """Merge measured GEMM plans (a UD_GEMM_TUNE_CACHE file written on an MI355X) into the shipped defaults
 (unidefense_amd/gemm_plans_gfx950.json).  usage: python tools/merge_plans.py <cache.json> [prefix ...]
-With prefixes, only keys whose kind starts with one of them are taken (e.g. `p2sf`: the spectral-conv plane plans)."""
+With prefixes, only keys whose kind starts with one of them are taken (e.g. `p2c`: the spectral-conv plane plans)."""
 import json
 import os
 import sys

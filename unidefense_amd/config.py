@@ -17,7 +17,6 @@ through the environment (tools/run_with.py does).  Anything not listed here is a
 | syncbn_exchange | UD_SYNCBN_EXCHANGE | 1 | SyncBN sums through the peer-mapped mailbox kernel (0: dist.all_reduce) |
 | force_collectives | UD_FORCE_COLLECTIVES | 0 | issue the data-parallel collectives even in a world of one rank (single-GPU test of the RCCL path) |
 | hip_adamw | UD_HIP_ADAMW | 1 | build_optimizer returns the multi-tensor HIP AdamW for 'adamw' on the GPU |
-| wgrad_stream | UD_WGRAD_STREAM | 0 | weight-gradient kernels on a second stream (measured slower; kept for A/B) |
 | lib_path (import) | UD_LIB_PATH | unset | load another build of libunidefense_hip.so (A/B of kernel builds) |
 | spectral_p2 | UD_SPECTRAL_P2 | auto | the spectral 1x1 convs' forward / data-gradient GEMMs from pre-split fp16 x 2 planes (ud_gemm_p3 prec 2): `auto` where measured (or, untuned, estimated) faster than the in-kernel bf16 x 3 split, `on` wherever the kernel takes the shape, `off` never |
 | weight_plane_batch | UD_WEIGHT_PLANE_BATCH | 1 | the planes of all conv weights on the planes path made by two launches at the start of a forward (ud_split_planes_h2t_multi) instead of two per weight; a weight joins on its first eager use, planes are handed out only while the parameter's version is the one they were made from |
@@ -48,7 +47,6 @@ class Config:
     syncbn_exchange: bool = True
     force_collectives: bool = False
     hip_adamw: bool = True
-    wgrad_stream: bool = False
     lib_path: Optional[str] = None
     spectral_p2: str = "auto"
     weight_plane_batch: bool = True
@@ -62,6 +60,8 @@ class Config:
                 setattr(c, f.name, _flag(env, f.default))
             else:
                 setattr(c, f.name, os.environ.get(env) or f.default)
+        if c.spectral_p2 not in ("auto", "on", "off"):
+            raise ValueError(f"UD_SPECTRAL_P2 must be auto, on or off, got {c.spectral_p2!r}")
         return c
 
     def describe(self):

@@ -82,8 +82,23 @@ class AbstractEngine(object):
             t["cls"] = self.loss_criterion["softmax"](cls_out, in_tgt)
         return t
 
+    def _backward(self, scaled_loss):
+        """backward() of one pass.  The step's second backward adds onto the first's gradients with one multi-tensor launch
+        instead of autograd's 504 AccumulateGrad launches (model/unidefense.py:_accumulate_in_place); the model's opt-in flag is
+        set for the duration of THIS call only, so a user's own torch.autograd.grad / backward(inputs=...) through the model
+        always takes autograd's road — and never under torch's DDP, whose reducer hooks hang on the AccumulateGrad nodes."""
+        core = getattr(self.model, "module", self.model)
+        own = hasattr(core, "_run") and not isinstance(self.model, torch.nn.parallel.DistributedDataParallel)
+        if own:
+            core._ud_inplace_accumulate = True
+        try:
+            scaled_loss.backward()
+        finally:
+            if own:
+                core._ud_inplace_accumulate = False
+
     def _backward_and_step(self, total_loss, grad_scalar):
-        grad_scalar.scale(total_loss).backward()
+        self._backward(grad_scalar.scale(total_loss))
         grad_scalar.step(self.optimizer)
         grad_scalar.update()
 
@@ -146,12 +161,8 @@ class AbstractEngine(object):
         hipGraph on the second call with a given shape and replayed afterwards; perturbation, optimizer, scaler and
         scheduler calls stay outside the graphs (host-side randomness / synchronisation)."""
         kl = cur_step > self.num_steps * 0.1
-        # the second backward of the step adds onto the first's gradients: one multi-tensor launch instead of autograd's 504
-        # AccumulateGrad launches (model/unidefense.py:_accumulate_in_place) — unless torch's DDP wraps the model (its reducer
-        # hooks hang on those very nodes)
-        core = getattr(self.model, "module", self.model)
-        if hasattr(core, "_run"):
-            core._ud_inplace_accumulate = not isinstance(self.model, torch.nn.parallel.DistributedDataParallel)
+        if hasattr(self, "_select_gemm_path"):
+            self._select_gemm_path()          # this engine's arithmetic, also when the step is called directly
         if self.use_graphs and not getattr(self.model, "rng_queue", None) and in_data.is_cuda:
             return self._train_graphed(in_data, in_tgt, cur_step, grad_scalar, sum_real, sum_fake, kl)
         # ---------------- pass 1: clean input ------------------------------------------------------
@@ -215,7 +226,7 @@ class AbstractEngine(object):
             st["g1"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(st["g1"], capture_error_mode=mode):
                 ret1, gts, total1 = self._pass1(st["x"], st["tgt"], sum_real, sum_fake)
-                grad_scalar.scale(total1).backward()
+                self._backward(grad_scalar.scale(total1))
             st["ret1"], st["gts"] = ret1, gts
             st["grads"] = [p.grad for p in params]          # static buffers the replays write
             st["pool"] = st["g1"].pool()
@@ -234,7 +245,7 @@ class AbstractEngine(object):
             with torch.cuda.graph(st["g2"], pool=st["pool"], capture_error_mode=mode):
                 out_dict = self.model(st["x"], noise_x=st["noise"])
                 ret2, total2 = self._pass2(out_dict, st["tgt"], sum_real, sum_fake, st["gts"], kl)
-                grad_scalar.scale(total2).backward()       # accumulates in place onto the pass-1 gradient buffers
+                self._backward(grad_scalar.scale(total2))  # accumulates in place onto the pass-1 gradient buffers
             st["ret2"] = ret2
         st["g2"].replay()
         grad_scalar.step(self.optimizer)

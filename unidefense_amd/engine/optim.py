@@ -2,6 +2,8 @@
 groups as timm's ``param_groups_weight_decay`` builds them, AdamW(amsgrad) and StepLR from the YAML keys.
 AdamW on the GPU is the multi-tensor HIP kernel of csrc/optim.hip; other optimizers and CPU
 parameters use torch's."""
+import math
+
 import torch
 
 from ..config import cfg as _cfg
@@ -221,23 +223,124 @@ class ConstantLR(torch.optim.lr_scheduler.LRScheduler):
         return list(self.base_lrs)
 
 
+class _TimmScheduler:
+    """Base of the two timm schedulers in the reference's table (scheduler/__init__.py:9-10,24,31; timm 0.9.16 per README.md:64,
+    THIRD-PARTY SOURCE ABSENT from this image: the published algorithm of timm/scheduler/{scheduler,step_lr,cosine_lr}.py is
+    restated here, parity unpinned).  timm's `step(epoch)` wants the epoch; the reference's engines call `scheduler.step()` with
+    no argument (engine/abstract_engine.py:203,378 — a TypeError on the real timm class) and read `get_last_lr()`
+    (uniattack_engine.py:347), so `step()` without an argument counts its own calls and `get_last_lr()` exists.  The lr-noise
+    options are not restated (no shipped YAML uses these schedulers at all)."""
+
+    def __init__(self, optimizer, warmup_t=0, warmup_lr_init=0.0, warmup_prefix=False, t_in_epochs=True, initialize=True, **kw):
+        if kw:
+            raise TypeError(f"{type(self).__name__}: unsupported arguments {sorted(kw)} (the lr-noise options of timm are not restated)")
+        self.optimizer, self.t_in_epochs = optimizer, t_in_epochs
+        for g in optimizer.param_groups:
+            if initialize:
+                g.setdefault("initial_lr", g["lr"])
+            elif "initial_lr" not in g:
+                raise KeyError("initial_lr is not specified in a param_group of the optimizer")
+        self.base_values = [g["initial_lr"] for g in optimizer.param_groups]
+        self.warmup_t, self.warmup_lr_init, self.warmup_prefix = warmup_t, warmup_lr_init, warmup_prefix
+        self._t = 0
+        if warmup_t:
+            self.warmup_steps = [(v - warmup_lr_init) / warmup_t for v in self.base_values]
+            self._set([warmup_lr_init] * len(self.base_values))
+        else:
+            self.warmup_steps = [1.0 for _ in self.base_values]
+
+    def _set(self, values):
+        for g, v in zip(self.optimizer.param_groups, values):
+            g["lr"] = v
+
+    def _lr_at(self, t):
+        if t < self.warmup_t:
+            return [self.warmup_lr_init + t * s for s in self.warmup_steps]
+        return self._decayed(t - self.warmup_t if self.warmup_prefix else t)
+
+    def step(self, epoch=None, metric=None):
+        if epoch is None:
+            self._t += 1
+            epoch = self._t
+        else:
+            self._t = epoch
+        if self.t_in_epochs:
+            self._set(self._lr_at(epoch))
+
+    def step_update(self, num_updates, metric=None):
+        if not self.t_in_epochs:
+            self._set(self._lr_at(num_updates))
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, state):
+        self.__dict__.update(state)
+
+
+class TimmStepLR(_TimmScheduler):
+    """timm.scheduler.StepLRScheduler: lr = base * decay_rate ** (t // decay_t) after a linear warm-up of warmup_t steps from
+    warmup_lr_init (warmup_prefix defaults to True there: the decay clock starts when the warm-up ends)."""
+
+    def __init__(self, optimizer, decay_t, decay_rate=1.0, warmup_t=0, warmup_lr_init=0.0, warmup_prefix=True, **kw):
+        self.decay_t, self.decay_rate = decay_t, decay_rate
+        super().__init__(optimizer, warmup_t, warmup_lr_init, warmup_prefix, **kw)
+
+    def _decayed(self, t):
+        return [v * (self.decay_rate ** (t // self.decay_t)) for v in self.base_values]
+
+
+class TimmCosineLR(_TimmScheduler):
+    """timm.scheduler.CosineLRScheduler (SGDR with cycle_mul / cycle_decay / cycle_limit and the k-decay exponent):
+    lr = lr_min + (lr_max * cycle_decay**i - lr_min) / 2 * (1 + cos(pi * t_curr**k / t_i**k)) inside cycle i < cycle_limit,
+    lr_min afterwards."""
+
+    def __init__(self, optimizer, t_initial, lr_min=0.0, cycle_mul=1.0, cycle_decay=1.0, cycle_limit=1, warmup_t=0,
+                 warmup_lr_init=0.0, warmup_prefix=False, k_decay=1.0, **kw):
+        assert t_initial > 0 and lr_min >= 0
+        self.t_initial, self.lr_min, self.cycle_mul, self.cycle_decay = t_initial, lr_min, cycle_mul, cycle_decay
+        self.cycle_limit, self.k_decay = cycle_limit, k_decay
+        super().__init__(optimizer, warmup_t, warmup_lr_init, warmup_prefix, **kw)
+
+    def _decayed(self, t):
+        if self.cycle_mul != 1:
+            i = math.floor(math.log(1 - t / self.t_initial * (1 - self.cycle_mul), self.cycle_mul))
+            t_i = self.cycle_mul ** i * self.t_initial
+            t_curr = t - (1 - self.cycle_mul ** i) / (1 - self.cycle_mul) * self.t_initial
+        else:
+            i = t // self.t_initial
+            t_i = self.t_initial
+            t_curr = t - self.t_initial * i
+        if i >= self.cycle_limit:
+            return [self.lr_min for _ in self.base_values]
+        gamma, k = self.cycle_decay ** i, self.k_decay
+        return [self.lr_min + 0.5 * (v * gamma - self.lr_min) * (1 + math.cos(math.pi * t_curr ** k / t_i ** k))
+                for v in self.base_values]
+
+
 SCHEDULERS = {
     "ConstantLR": ConstantLR,
     "StepLR": torch.optim.lr_scheduler.StepLR,
+    "TimmStepLR": TimmStepLR,
     "MultiStepLR": torch.optim.lr_scheduler.MultiStepLR,
     "ExponentialLR": torch.optim.lr_scheduler.ExponentialLR,
     "CosineAnnealingLR": torch.optim.lr_scheduler.CosineAnnealingLR,
     "CosineAnnealingWarmRestarts": torch.optim.lr_scheduler.CosineAnnealingWarmRestarts,
+    "ReduceLROnPlateau": torch.optim.lr_scheduler.ReduceLROnPlateau,
+    "TimmCosineLR": TimmCosineLR,
 }
 
 
 def build_scheduler(optimizer, sched_cfg):
-    """scheduler.get_scheduler (scheduler/__init__.py:33-40): the YAML's config.scheduler dict (name + kwargs) or None.
-    The timm schedulers of the reference's table (TimmStepLR, TimmCosineLR) are not available in this image."""
+    """scheduler.get_scheduler (scheduler/__init__.py:33-40): the YAML's config.scheduler dict (name + kwargs) or None; the
+    reference's nine names."""
     if sched_cfg is None:
         return ConstantLR(optimizer)
     cfg = dict(sched_cfg)
     name = cfg.pop("name")
     if name not in SCHEDULERS:
-        raise KeyError(f"scheduler '{name}' is not available here; known: {sorted(SCHEDULERS)}")
+        raise KeyError(f"scheduler '{name}' is not one of the reference's: {sorted(SCHEDULERS)}")
     return SCHEDULERS[name](optimizer, **cfg)

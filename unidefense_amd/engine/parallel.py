@@ -47,11 +47,14 @@ class GradReducer:
 
     def begin(self):
         self.bucket, self.size, self.pending, self.done = [], 0, [], set()
+        self.bytes = self.collectives = 0          # of this backward (bench.py's diagnostics)
 
     def ready(self, key, g):
         self.done.add(key)
         nbytes = g.numel() * g.element_size()
+        self.bytes += nbytes
         if nbytes >= self.direct_bytes and g.is_contiguous():
+            self.collectives += 1
             work = dist.all_reduce(g, group=self.group, async_op=True)
             self.pending.append((work, g.view(-1), [(key, g)]))
             return
@@ -64,6 +67,7 @@ class GradReducer:
         if not self.bucket:
             return
         flat = torch.cat([g.reshape(-1) for _, g in self.bucket])
+        self.collectives += 1
         work = dist.all_reduce(flat, group=self.group, async_op=True)
         self.pending.append((work, flat, self.bucket))
         self.bucket, self.size = [], 0
@@ -71,6 +75,10 @@ class GradReducer:
     def finish(self):
         self.flush()
         out = {}
+        prof = T.DP_PROFILE if (T.DP_PROFILE is not None and torch.cuda.is_available()) else None
+        if prof is not None:                 # the backward's own kernels end here; what follows is the EXPOSED part of the exchange
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for work, flat, bucket in self.pending:
             work.wait()                      # GPU: the current stream waits for the collective's stream
             off = 0
@@ -78,6 +86,9 @@ class GradReducer:
                 n = g.numel()
                 out[key] = flat[off:off + n].view(g.shape)
                 off += n
+        if prof is not None:
+            e1.record()
+            prof["ar"].append((e0, e1, self.bytes, self.collectives))
         self.pending = []
         return out
 

@@ -74,10 +74,12 @@ class TrainEngine(AbstractEngine):
         if self.precision not in ("fp32", "fp16"):
             raise ValueError(f"config.precision must be 'fp32' or 'fp16', got {self.precision!r}")
         # The GEMM path is process-wide state of the library: an fp16 engine wants the fp16-MFMA kernel (3), an fp32 engine the
-        # path the process started with (UD_GEMM_PATH, default 0).  Building an engine does not touch it (an engine that still
-        # lives keeps its arithmetic); each engine selects its own on entry to train() / test() / validate(), so two engines
+        # path in force when it is built (the library's UD_GEMM_PATH default or a caller's ud_gemm_set_path; never another engine's 3).  Building an engine does not touch it (an engine that still
+        # lives keeps its arithmetic); each engine selects its own on entry to train() / test() / validate() / train_unidefense_model(), so two engines
         # of different precision in one process (an A/B run, a notebook) each compute in theirs.
-        self._gemm_path = 3 if self.precision == "fp16" else int(os.environ.get("UD_GEMM_PATH", "0") or 0)
+        from .. import lib as _lib
+        cur = _lib.call("ud_gemm_get_path")          # what the process (UD_GEMM_PATH at load) or a caller's ud_gemm_set_path chose
+        self._gemm_path = 3 if self.precision == "fp16" else (cur if cur != 3 else 0)
         if self.precision == "fp16":
             self.model.half_storage = True
         self.model_without_ddp = self.model
@@ -232,6 +234,7 @@ class TrainEngine(AbstractEngine):
     def validate(self, step, batches=4):
         """The reference's validate (forgery_engine.py:320-421) without the figure / wandb plumbing: metrics over all
         ranks, best-so-far record (AUC + ACC), best_model.bin / latest_model.bin on rank 0."""
+        self._select_gemm_path()
         self._check_exchange()
         ret = self.test(batches)
         if "AUC" in ret and ret["AUC"] + ret["ACC"] > self.best_auc + self.best_acc:

@@ -724,7 +724,7 @@ def gemm_nn(a, w, out=None, accumulate=False):
 # three products over the SAME three matrices (x_freq [pixels x 2C], the weight [2C x 2C], dY [pixels x 2C]).  Each matrix is
 # split ONCE into two fp16 pieces with one power-of-two scale for the tensor (ud_absmax + ud_split_planes_h2t; the planes then
 # serve every GEMM mode) and the products run on three fp16 MFMAs per tile instead of six bf16 ones; the fp32 tensors are not
-# kept.  Which blocks take this path, and each product's launch plan, is measured per shape on first use (`p2sf` entries of the
+# kept.  Which blocks take this path, and each product's launch plan, is measured per shape on first use (`p2c` entries of the
 # plan table) like the tile / split-K plans of the in-kernel-split GEMMs.
 _P2_MIN = (1024, 512)          # untuned `auto`: M and min(N, K) from which the planes path is taken
 _P2_SPLITS = (2, 3, 4, 6, 8)

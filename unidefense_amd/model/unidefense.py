@@ -174,7 +174,7 @@ class _NetFunction(torch.autograd.Function):
         uses = getattr(model, "_param_uses", None)
         if reducer is not None:
             reducer.begin()
-            if uses is not None and not cfg.wgrad_stream:
+            if uses is not None:
                 tape.param_uses, tape.param_ready = uses, reducer.ready
         for k, g in zip(ctx.keys, gouts):
             if g is not None:

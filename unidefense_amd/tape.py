@@ -16,19 +16,6 @@ from . import kernels as K
 from .config import cfg
 
 
-# cfg.wgrad_stream, off by default: measured on MI355X (bs 32, whole step replayed as a hipGraph) the forked
-# weight-gradient branch made the step SLOWER (46.3 vs 43.6 ms) — the large GEMMs already fill the chip and the extra
-# graph edges cost more than the overlap with the bandwidth-bound kernels returns.
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    s = _SIDE_STREAMS.get(device)
-    if s is None:
-        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return s
-
-
 class Tape:
     """Records backward closures; gradients are keyed by tensor identity."""
 
@@ -42,8 +29,6 @@ class Tape:
         self.kinks = None        # parity tests: {site: ReLU output} (site = id(norm weight) or an explicit name)
         self.gate_cond = {}      # parity tests (watch set): {id(sf_coef): sigmoid'(a) * sum |dy| |freq - spat|}, the
         #                          conditioning of that scalar gradient (a global sum that cancels heavily)
-        self._side = None        # second stream carrying the weight-gradient kernels of this backward
-        self._side_keep = []
         # data parallel (engine/parallel.py): param_ready(id(p), g) is called the moment p's gradient is final, i.e.
         # after its param_uses[id(p)]-th contribution (counts learned from the first backward: param_seen)
         self.param_ready = None
@@ -79,34 +64,18 @@ class Tape:
         if self.param_ready is not None and n == self.param_uses.get(id(p)):
             self.param_ready(id(p), g)
 
-    # -- side stream for weight gradients --------------------------------------------------
+    # -- weight gradients -------------------------------------------------------------------
     def wgrad(self, p, fn, *inputs):
-        """Enqueue `fn()` (the weight-gradient kernels of parameter p) on a second stream, ordered after everything
-        enqueued so far on the current one.  Nothing on the backward's critical path reads a weight gradient, so
-        these launches (a third of the GEMM time) overlap the data-gradient chain — the bandwidth-bound norm /
-        depthwise / SE kernels leave the matrix cores idle.  `inputs` are kept alive until the streams re-join
-        in backward() (their memory must not be recycled by the main stream meanwhile)."""
-        if not cfg.wgrad_stream:
-            self.add_param_grad(p, fn())
-            return
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = _side_stream(main.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self._side.wait_event(ev)
-        with torch.cuda.stream(self._side):
-            self.add_param_grad(p, fn())
-        self._side_keep.extend(inputs)
+        """Run `fn()` (the weight-gradient kernels of parameter p) and record the result.  One queue: a second stream for
+        these launches was measured slower in rounds 1, 2 and 4 (46.3 vs 43.6, 36.15 vs 34.70, 29.1 vs 27.2 ms per step: the
+        GEMMs own the CU's registers and LDS, nothing co-schedules) and is gone — with it the ordering hazard of operand
+        planes made lazily on whichever stream touched them first."""
+        self.add_param_grad(p, fn())
 
     # -- replay ----------------------------------------------------------------------------
     def backward(self):
         for fn in reversed(self.nodes):
             fn()
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._side = None
-            self._side_keep = []
         self.nodes = []
         self.grads = {}
         self._keep = []
@@ -862,6 +831,11 @@ def concat_channels(tape, parts):
 # ---------------------------------------------------------------------------------------------
 # Fused MBConv block: deferred BatchNorm, one tape node per block (csrc/fused.hip)
 # ---------------------------------------------------------------------------------------------
+# bench.py's data-parallel diagnostics: when set to {"bn": [], "ar": []}, every SyncBN sum is bracketed by HIP events on its launch
+# stream — (start, end, doubles) — and GradReducer.finish() appends (backward end, last collective waited for, bytes, collectives)
+DP_PROFILE = None
+
+
 class DataParallelCtx:
     """SyncBatchNorm context of the fused path: the fp64 accumulators are summed over the ranks in place (one
     all_reduce between the producing and the consuming kernels), counts are multiplied by the world size."""
@@ -879,11 +853,18 @@ class DataParallelCtx:
         if not self.synced:
             return None
         loc = acc.clone() if keep_local else None
+        prof = DP_PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self.exchange is not None and acc.numel() <= self.exchange.MAX_DOUBLES:
             self.exchange.allreduce(acc)
         else:
             import torch.distributed as dist
             dist.all_reduce(acc, group=self.group)
+        if prof is not None:
+            e1.record()
+            prof["bn"].append((e0, e1, acc.numel()))
         return loc
 
 
