@@ -553,6 +553,15 @@ long ud_dwtile_wgrad_part_rows(int N, int Ho, int Wo);
 int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, const float* gate_alpha, int gate_mode,
                     float* dwt, float* part, long part_rows, int N, int Hs, int Ws, int C, int Ho, int Wo, int K, int P_t,
                     int P_l, int stride, int f16, ud_stream_t stream);
+/* Backward of the stride-1 depthwise conv (autograd of model/efficientnet/model.py:112-115 / exp.py:49-51) in ONE pass over its
+ * operands: both halo tiles (dy, act(bn(x))) staged once per image and workgroup;
+ *   dz = (gate * conv_flipped(dy) [+ add]) * act'(bn(x))   (bn NULL: no activation factor, x is the conv's input itself),
+ *   s1 += sum dz, s2 += sum dz * xhat (bn given; ws: ud_dwtile_ws_doubles(N, H, W, C) doubles),
+ *   dwt[C][K*K] = gate * sum_pixels act(bn(x))(oh + i - P_t, ow + j - P_l) * dy(oh, ow)
+ * (ud_dwtile epi 2 + ud_dwtile_wgrad, which read each operand twice).  wpart: ud_dwtile_wgrad_part_rows(N, H, W) rows. */
+int ud_dwtile_bwd(const void* dy, const void* x, const ud_bn_ref* bn, const float* wt, const float* gate_alpha, int gate_mode,
+                  const void* add, void* dz, float* dwt, float* wpart, long part_rows, double* s1, double* s2, double* ws,
+                  int N, int H, int W, int C, int K, int P_t, int P_l, int f16, ud_stream_t stream);
 
 /* ---- large real 2-D FFT of image planes (csrc/fft_large.hip), S in {128, 256, 320} ------------------------------------
  * torch.fft.rfft2 on [N,3,S,S] images: the frequency reconstruction loss (model/unidefense.py:246-253; ResNet variants

@@ -519,6 +519,22 @@ def test_tiled_depthwise_kernels(N, H, W, Cc, k, half):
     assert _rel(da, da_ref) < tol
     dw = K.dwtile_bwd_weight(xg, dyg, k, pad, pad, bn=bn, gate_alpha=alpha.to(dev), gate_mode=2)
     assert _rel(dw.view(Cc, k, k), gate * wd.grad.view(Cc, k, k)) < (1e-3 if half else 2e-5)
+    # ---- round 5: both gradients from ONE kernel (dw_tile_bwd_kernel: both halo tiles staged once)
+    sacc2 = K.zeros64(2 * Cc, xg)
+    dz2, dw2 = K.dwtile_bwd(dyg, xg, wt, k, pad, pad, bn=bn, gate_alpha=alpha.to(dev), gate_mode=2, add=addg, sacc=sacc2)
+    assert dz2.dtype == st and _rel(dz2, dz_ref) < tol
+    assert torch.equal(dz2, dz)                                   # the same arithmetic in the same order as ud_dwtile epi 2
+    assert _rel(sacc2[:Cc], dz_ref.sum((0, 1, 2))) < stol and _rel(sacc2[Cc:], (dz_ref * xh).sum((0, 1, 2))) < stol
+    assert _rel(sacc2[:Cc], dzd.sum((0, 1, 2))) < 1e-6
+    assert _rel(dw2.view(Cc, k, k), gate * wd.grad.view(Cc, k, k)) < (1e-3 if half else 2e-5)
+    # ... and without a deferred BatchNorm in front of the conv (x is the conv's input itself: MBConv blocks with expand ratio 1)
+    wd2 = w.double().requires_grad_(True)
+    (F.conv2d(xd.permute(0, 3, 1, 2), wd2, padding=pad, groups=Cc).permute(0, 2, 3, 1) * dy.double()).sum().backward()
+    da2, dw3 = K.dwtile_bwd(dyg, xg, wt, k, pad, pad, gate_alpha=alpha.to(dev), gate_mode=2, add=addg)
+    assert _rel(da2, da_ref) < tol and torch.equal(da2, da)
+    assert _rel(dw3.view(Cc, k, k), gate * wd2.grad.view(Cc, k, k)) < (1e-3 if half else 2e-5)
+    da3, _ = K.dwtile_bwd(dyg, xg, wt, k, pad, pad)               # no gate, nothing added
+    assert _rel(da3, a.grad) < tol
 
 
 @pytest.mark.parametrize("N,H,Cc,k,pad", [(2, 32, 24, 3, (0, 1, 0, 1)), (2, 16, 40, 5, (2, 2, 2, 2)), (1, 64, 8, 3, (0, 1, 0, 1)),

@@ -127,16 +127,17 @@ def test_eval_intermediates_vs_oracle():
     assert not bad, bad
 
 
-@pytest.mark.parametrize("variant", ["smooth", "full"])
-def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant, run_mode):
-    """Outputs, losses and all 504 parameter gradients (norm + first 8 elements) of the train-mode step vs the
+@pytest.mark.parametrize("variant,fname", [("smooth", "udeb4_train_n4.npz"), ("full", "udeb4_train_n4.npz"),
+                                           ("smooth", "udeb4_train_n8.npz"), ("full", "udeb4_train_n8.npz")])
+def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant, fname, run_mode):
+    """(udeb4_train_n8.npz, round 5: batch statistics over EIGHT samples, oracle/make_golden_n8.py.)  Outputs, losses and all 504 parameter gradients (norm + first 8 elements) of the train-mode step vs the
     vectors recorded from the reference (fp32 CPU): EVERY tensor within 1e-3 of its norm (+ the 2e-5 floor), both loss
     variants (observed: 3.5e-4 smooth / 7.4e-4 full at worst).  The floor matters for exactly one family: BN2's bias in
     the stages whose output only ever feeds another BatchNorm (blocks 0-15, 30, 31) has a gradient that is
     analytically ZERO (1e-15 in the float64 oracle: a per-channel shift is removed by the next normalisation); the
     reference's fp32 run and this one both hold ~5e-6 of rounding noise there."""
     dev = _dev()
-    g = np.load(os.path.join(golden_dir, "udeb4_train_n4.npz"))
+    g = np.load(os.path.join(golden_dir, fname))
     n, size, seed, mseed = [int(v) for v in g["meta"]]
     lam = ou.LAMBDAS if variant == "full" else ou.SMOOTH_LAMBDAS
     rtol = GRAD_RTOL
@@ -167,7 +168,7 @@ def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant, run_mode):
     print(f"  {within_1e3}/{len(rows)} gradient tensors within 1e-3 of the reference; worst:")
     for r in rows[:12]:
         print("  rel %.3e  %-58s norm err %.3e head err %.3e ref norm %.3e" % r)
-    within("worst of 504 gradient tensors: max(norm err, head err) / (ref norm + floor)", rows[0][0], rtol)
+    within(f"worst of 504 gradient tensors (N = {n}): max(norm err, head err) / (ref norm + floor)", rows[0][0], rtol)
     bad = [r for r in rows if not r[0] <= rtol]
     assert not bad, bad[:10]
     assert len(rows) == 504 and within_1e3 == len(rows)
@@ -240,6 +241,44 @@ def test_train_grads_vs_oracle_elementwise(variant, n, seeds, run_mode):
     loose = [r[1] for r in rows if not r[2] <= GRAD_RTOL * r[3] + GRAD_ATOL]
     assert within("tensors outside the plain 1e-3 bound (all of them scalar sf_coef gradients), of 32", len(loose), 32)
     assert all(k.endswith("sf_coef") for k in loose), loose
+
+
+@pytest.mark.parametrize("variant", ["smooth", "full"])
+def test_train_grads_vs_oracle_elementwise_n8_plain_bound(variant, run_mode):
+    """The same element-wise comparison at N = 8 (seeds of tests/golden/udeb4_train_n8.npz) held to the PLAIN bound
+    max|d| <= rtol * max|ref| + 2e-5 for every one of the 504 tensors — no `5 x the oracle's own fp32 error` clause: with
+    batch statistics over eight samples the step is conditioned well enough that the escape is not needed (rtol 1e-3 smooth;
+    the L1 tails' sign() gradients keep 2e-2 for the full loss, see the header).  The count of tensors outside the bound is
+    recorded (profiles/r05/margins.md) and must be zero."""
+    dev = _dev()
+    n, seeds = 8, (130, 230)
+    lam = ou.SMOOTH_LAMBDAS if variant == "smooth" else ou.LAMBDAS
+    rtol = GRAD_RTOL if variant == "smooth" else FULL_RTOL
+    x = param_fill.make_input(n, 256, seeds[0])
+    tgt = param_fill.make_labels(n)
+    rng = ou.make_rng(n, seeds[1], 0.5)
+    sd, sd32 = _oracle_grads(variant, n, seeds)
+    m = _model(dev, 0.0, 0.3).train()
+    out = m(x.to(dev), rng=rng)
+    _pass1_loss(out, tgt.to(dev), lam)["total_loss"].backward()
+    rows = []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        ref = sd[k].grad
+        d = (p.grad.detach().double().cpu() - ref).abs().max().item()
+        s = ref.abs().max().item()
+        d32 = (sd32[k].grad.double() - ref).abs().max().item()
+        rows.append((d / (rtol * s + GRAD_ATOL), k, d, s, d32))
+    rows.sort(reverse=True)
+    for r in rows[:10]:
+        print("  %.3f  %-58s maxerr %.3e  maxref %.3e  cpu-fp32-err %.3e" % r)
+    loose = [r for r in rows if not r[0] <= 1.0]
+    oracle_loose = sum(1 for r in rows if r[4] > rtol * r[3] + GRAD_ATOL)
+    print(f"  outside the plain bound: {len(loose)} of {len(rows)} (the oracle's own fp32 run: {oracle_loose})")
+    assert len(rows) == 504
+    within(f"N = 8 {variant}: worst gradient tensor, max err / (rtol * scale + floor), no fp32-yardstick clause", rows[0][0], 1.0)
+    assert within(f"N = 8 {variant}: tensors outside the plain bound, of 504", len(loose), 0), loose[:8]
 
 
 def test_weight_planes_follow_raw_pointer_weight_updates():

@@ -128,3 +128,70 @@ def test_half_step_backward_is_linear_in_the_loss_scale():
     ok = [within("gradients at loss scale 2^12 vs 2^10, median relative L2", med, 8e-3),
           within("gradients at loss scale 2^12 vs 2^10, worst relative L2", rows[0][0], 5e-2)]
     assert all(ok), rows[:4]
+
+
+def test_fp16_half_storage_step_vs_float64_oracle():
+    """BASELINE configs[4] held to the ORACLE, not to another HIP run: fp16 MFMA operands + half storage of the trunk, N = 4
+    (the seeds of tests/golden/udeb4_train_n4.npz, smooth loss variant: no sign() gradients), loss scale 2^10, against
+    oracle/eb4.py in FLOAT64 on the CPU (the run test_c_model_gpu's element-wise test makes and caches).  The reference has no
+    such mode (autocast(enabled=False), engine/abstract_engine.py:208), so these are STATED bars of a reduced-precision mode, not
+    the 1e-3 of the fp32 path: outputs and the loss in relative L2, the well-defined parameter gradients (BN2 biases with a
+    structurally zero gradient and the cancelling scalar gates excluded, as everywhere in this file) by the median / 90th
+    percentile / maximum of their per-tensor relative L2.  Observed (round 5): outputs 0.6-1.6e-2, loss 2e-3, gradients 7 % /
+    17 % / 60 % — batch statistics over FOUR samples amplify the fp16 roundings about twice as much as the bs-64 step above."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests.test_c_model_gpu import _oracle_grads, _pass1_loss
+    from unidefense_amd import lib
+    from unidefense_amd.model import load_model
+    dev = torch.device("cuda:0")
+    n, seeds, scale = 4, (38, 138), 1024.0
+    sd, _ = _oracle_grads("smooth", n, seeds)
+    x = param_fill.make_input(n, 256, seeds[0])
+    tgt = param_fill.make_labels(n)
+    rng = ou.make_rng(n, seeds[1], 0.5)
+    with torch.no_grad():
+        from oracle import eb4
+        ref = eb4.forward_eb4({k: v.detach() for k, v in sd.items()}, x.double(), training=True, drop_rate=0.5, rng=rng)
+    lib.call("ud_gemm_set_path", 3)
+    try:
+        m = load_model("UDEB4")(extractor="efficientnet-b4", num_classes=2, drop_rate=0.5)
+        param_fill.fill_module_(m, sf_coef=0.0, fuse_coef=0.3)
+        m = m.to(dev).train()
+        m.half_storage = True
+        out = m(x.to(dev), rng=rng)
+        ls = _pass1_loss(out, tgt.to(dev), ou.SMOOTH_LAMBDAS)
+        (ls["total_loss"] * scale).backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.call("ud_gemm_set_path", 0)
+    from oracle import losses as olosses
+    ref_ls = olosses.pass1_loss(ref, tgt, n // 2, n // 2, ou.SMOOTH_LAMBDAS)
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    outs = {"cls_out": rel(out["cls_out"], ref["cls_out"]), "rec": rel(out["rec"], ref["rec"]),
+            "factorization": rel(out["loss_dict"]["factorization"], ref["loss_dict"]["factorization"]),
+            "spatial": rel(out["loss_dict"]["spatial"], ref["loss_dict"]["spatial"]),
+            "freq": rel(out["loss_dict"]["freq"], ref["loss_dict"]["freq"])}
+    loss_err = abs(float(ls["total_loss"]) - float(ref_ls["total_loss"])) / abs(float(ref_ls["total_loss"]))
+    r = []
+    for k, p in m.named_parameters():
+        if p.grad is None or k.endswith("._bn2.bias") or k.endswith("_coef"):
+            continue
+        g64 = sd[k].grad
+        if float(g64.norm()) < 1e-6:
+            continue
+        assert torch.isfinite(p.grad).all(), k
+        r.append(float((p.grad.double().cpu() / scale - g64).norm() / g64.norm()))
+    r = np.array(r)
+    stats = {"median": float(np.percentile(r, 50)), "90 %": float(np.percentile(r, 90)), "max": float(r.max())}
+    print("  outputs vs float64 oracle (relative L2):", {k: f"{v:.2e}" for k, v in outs.items()}, f"loss {loss_err:.2e}")
+    print("  gradients vs float64 oracle (per-tensor relative L2):", {k: f"{v:.3g}" for k, v in stats.items()}, f"over {len(r)} tensors")
+    ok = [within(f"fp16 + half storage vs float64 oracle, N = 4: {k} relative L2", v, 5e-2) for k, v in outs.items()]
+    ok.append(within("fp16 + half storage vs float64 oracle, N = 4: total loss", loss_err, 2e-2))
+    ok.append(within("fp16 + half storage vs float64 oracle, N = 4: gradient relative L2, median", stats["median"], 0.15))
+    ok.append(within("fp16 + half storage vs float64 oracle, N = 4: gradient relative L2, 90th percentile", stats["90 %"], 0.35))
+    ok.append(within("fp16 + half storage vs float64 oracle, N = 4: gradient relative L2, max", stats["max"], 1.5))
+    assert all(ok) and len(r) >= 440

@@ -43,9 +43,10 @@ def test_eval_matches_reference(golden_dir, fname, sf, fuse):
     _check_outputs(out, g)
 
 
-@pytest.mark.parametrize("variant", ["full", "smooth"])
-def test_train_fwd_bwd_matches_reference(golden_dir, variant):
-    g = np.load(os.path.join(golden_dir, "udeb4_train_n4.npz"))
+@pytest.mark.parametrize("variant,fname", [("full", "udeb4_train_n4.npz"), ("smooth", "udeb4_train_n4.npz"),
+                                           ("smooth", "udeb4_train_n8.npz")])
+def test_train_fwd_bwd_matches_reference(golden_dir, variant, fname):
+    g = np.load(os.path.join(golden_dir, fname))
     n, size, seed, mseed = [int(v) for v in g["meta"]]
     lam = ou.LAMBDAS if variant == "full" else ou.SMOOTH_LAMBDAS
     sd = ou.oracle_state(0.0, 0.3, requires_grad=True)

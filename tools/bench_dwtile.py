@@ -83,51 +83,56 @@ def stride2():
             name, H, Cc, k, r[0], r[1], r[2], r[3], r[4], r[5], x.numel() * x.element_size() / 1e6))
 
 
-print("storage", st, "batch", N)
-if "--stride2" in sys.argv:
-    stride2()
-    sys.exit(0)
-print("%-8s %4s %5s %2s | %-26s | %-26s | %-20s" % ("blocks", "H", "C", "k", "fwd old / new (us)", "bwd-data+bn old / new", "wgrad old / new"))
-for name, H, Cc, k, plain in SHAPES:
-    x = torch.randn(N, H, H, Cc, device=dev).to(st)
-    dy = torch.randn(N, H, H, Cc, device=dev).to(st)
-    add = torch.randn(N, H, H, Cc, device=dev).to(st)
-    wt = torch.randn(k * k, Cc, device=dev) * 0.2
-    gamma, beta = torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.1
-    alpha = torch.tensor([0.3], device=dev)
-    pad = (k - 1) // 2
-    M = N * H * H
-    acc = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
-    K.colstats(x.view(M, Cc), acc)
-    bn = K.DeferredBN(acc, Cc, M, gamma, beta, 1e-3, 1)
-    a = K.bn_apply(x, bn, 1, M)
+def main():
+    print("storage", st, "batch", N)
+    if "--stride2" in sys.argv:
+        stride2()
+        sys.exit(0)
+    print("%-8s %4s %5s %2s | %-26s | %-26s | %-20s" % ("blocks", "H", "C", "k", "fwd old / new (us)", "bwd-data+bn old / new", "wgrad old / new"))
+    for name, H, Cc, k, plain in SHAPES:
+        x = torch.randn(N, H, H, Cc, device=dev).to(st)
+        dy = torch.randn(N, H, H, Cc, device=dev).to(st)
+        add = torch.randn(N, H, H, Cc, device=dev).to(st)
+        wt = torch.randn(k * k, Cc, device=dev) * 0.2
+        gamma, beta = torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.1
+        alpha = torch.tensor([0.3], device=dev)
+        pad = (k - 1) // 2
+        M = N * H * H
+        acc = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+        K.colstats(x.view(M, Cc), acc)
+        bn = K.DeferredBN(acc, Cc, M, gamma, beta, 1e-3, 1)
+        a = K.bn_apply(x, bn, 1, M)
 
-    def fwd_old():
-        a_ = K.bn_apply(x, bn, 1, M)                       # plain blocks materialise swish(bn0(e)); SF blocks get it from rfft2_ex
-        d = K.dwconv_fwd(a_, wt, k, 1, pad, pad, H, H)
-        if plain:
-            K.colstats(d.view(M, Cc), K.zeros64(2 * Cc, x))
+        def fwd_old():
+            a_ = K.bn_apply(x, bn, 1, M)                       # plain blocks materialise swish(bn0(e)); SF blocks get it from rfft2_ex
+            d = K.dwconv_fwd(a_, wt, k, 1, pad, pad, H, H)
+            if plain:
+                K.colstats(d.view(M, Cc), K.zeros64(2 * Cc, x))
 
-    def fwd_old_nobn():
-        d = K.dwconv_fwd(a, wt, k, 1, pad, pad, H, H)
-        if plain:
-            K.colstats(d.view(M, Cc), K.zeros64(2 * Cc, x))
+        def fwd_old_nobn():
+            d = K.dwconv_fwd(a, wt, k, 1, pad, pad, H, H)
+            if plain:
+                K.colstats(d.view(M, Cc), K.zeros64(2 * Cc, x))
 
-    def fwd_new():
-        K.dwtile_fwd(x, wt, k, pad, pad, H, H, bn=bn, stats=K.zeros64(2 * Cc, x) if plain else None)
+        def fwd_new():
+            K.dwtile_fwd(x, wt, k, pad, pad, H, H, bn=bn, stats=K.zeros64(2 * Cc, x) if plain else None)
 
-    def bwd_old():
-        K.dwconv_bwd_data_bn(dy, alpha, 2, wt, add, x, bn, k, 1, pad, pad, K.zeros64(2 * Cc, x))
+        def bwd_old():
+            K.dwconv_bwd_data_bn(dy, alpha, 2, wt, add, x, bn, k, 1, pad, pad, K.zeros64(2 * Cc, x))
 
-    def bwd_new():
-        K.dwtile_bwd_data(dy, wt, k, pad, pad, H, H, alpha, 2, add, x, bn, K.zeros64(2 * Cc, x))
+        def bwd_new():
+            K.dwtile_bwd_data(dy, wt, k, pad, pad, H, H, alpha, 2, add, x, bn, K.zeros64(2 * Cc, x))
 
-    def wg_old():
-        K.dwconv_bwd_weight_ex(a, dy, alpha, 2, k, 1, pad, pad)
+        def wg_old():
+            K.dwconv_bwd_weight_ex(a, dy, alpha, 2, k, 1, pad, pad)
 
-    def wg_new():
-        K.dwtile_bwd_weight(x, dy, k, pad, pad, bn=bn, gate_alpha=alpha, gate_mode=2)
-    r = [timed(f) for f in (fwd_old, fwd_old_nobn, fwd_new, bwd_old, bwd_new, wg_old, wg_new)]
-    mb = x.numel() * x.element_size() / 1e6
-    print("%-8s %4d %5d %2d | %7.1f (%6.1f) / %7.1f | %9.1f / %9.1f     | %8.1f / %8.1f   (%.0f MB per tensor)" % (
-        name, H, Cc, k, r[0], r[1], r[2], r[3], r[4], r[5], r[6], mb))
+        def wg_new():
+            K.dwtile_bwd_weight(x, dy, k, pad, pad, bn=bn, gate_alpha=alpha, gate_mode=2)
+        r = [timed(f) for f in (fwd_old, fwd_old_nobn, fwd_new, bwd_old, bwd_new, wg_old, wg_new)]
+        mb = x.numel() * x.element_size() / 1e6
+        print("%-8s %4d %5d %2d | %7.1f (%6.1f) / %7.1f | %9.1f / %9.1f     | %8.1f / %8.1f   (%.0f MB per tensor)" % (
+            name, H, Cc, k, r[0], r[1], r[2], r[3], r[4], r[5], r[6], mb))
+
+
+if __name__ == "__main__":
+    main()

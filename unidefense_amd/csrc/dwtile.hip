@@ -334,6 +334,188 @@ __global__ __launch_bounds__(NT, 2) void dw_tile_wgrad_kernel(TileGeom g, const 
     }
 }
 
+// Round 5: data gradient AND weight gradient of a stride-1 depthwise conv in ONE pass over its operands.  The two kernels
+// above each stage a halo tile and stream the other operand: dy (+ halo) and x for the data gradient, act(bn(x)) (+ halo) and
+// dy for the weight gradient — every element of both tensors crosses the memory system twice, on tensors of 13 - 300 MB.
+// Here a workgroup stages BOTH halo tiles once per image — tileA = dy (zero outside the image), tileB = act(bn_in(x)) — and
+//   phase 1  da = gate * conv_flipped(tileA) [+ add];  dz = da * act'(bn_in(x)); dz stored; BatchNorm backward sums of dz
+//   phase 2  acc_w[i][j] += tileB(window + (i, j)) * tileA(centre)               (the dy strip comes out of the staged tile)
+// over images n0, n0 + n_step, ...; one fp32 partial row [K*K][C] per workgroup for dw_tile_wgrad_finalize and one fp64
+// partial (or atomics, <= 64 workgroups per channel) of the sums.  Tiles of (CQ, SW) = (8, 4): 16 x 8 outputs of 32 channels,
+// two halo tiles = 67 KB at K = 5 (two workgroups per CU); maps up to 8 x 8: (16, 4), the whole map of 64 channels.
+template <typename T, int K, int CQ, int SW>
+__global__ __launch_bounds__(NT, 2) void dw_tile_bwd_kernel(TileGeom g, const T* __restrict__ dy, const T* __restrict__ x,
+                                                         ud_bn_ref bn, int has_bn, const float* __restrict__ wt,
+                                                         const float* __restrict__ gate_alpha, int gate_mode,
+                                                         const T* __restrict__ add, T* __restrict__ dz, int n_step,
+                                                         float* __restrict__ wpart, double* __restrict__ spart,
+                                                         double* __restrict__ s1, double* __restrict__ s2) {
+    using L = Lds<K, CQ, SW, 1>;
+    using S = TileShape<CQ, SW>;
+    constexpr int PTH = S::PTH;
+    constexpr int NIN = SW - 1 + K;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* tileA = reinterpret_cast<f32x4*>(smem);
+    f32x4* tileB = tileA + L::TILE_Q;
+    f32x4* taps = tileB + L::TILE_Q;
+    const int cq = threadIdx.x % CQ, p = threadIdx.x / CQ;
+    const int cq0 = blockIdx.y * CQ;
+    const int c4 = cq0 + cq;
+    const bool cok = c4 < g.C4;
+    const int tiles = g.tiles_h * g.tiles_w;
+    const int tsp = blockIdx.x % tiles, nb = blockIdx.x / tiles;
+    const int oh0 = (tsp / g.tiles_w) * S::TH_, ow0 = (tsp % g.tiles_w) * S::TW_;
+    const int row = p % S::TH_, col0 = (p / S::TH_) * SW;
+    const int oh = oh0 + row;
+    const In4<T> add4{add}, x4{x};
+    const Out4<T> o4{dz};
+    Bn4 cb;
+    if (has_bn && cok) cb = bn_load(bn, 0, g.C4, c4, false);
+    const float gs = gate_factor(gate_alpha, gate_mode);
+    // geometry of the two stagings: the data gradient reads dy through the flipped window (pads K-1 - P), the weight gradient
+    // reads act(bn(x)) through the forward window (pads P)
+    TileGeom ga = g, gb = g;
+    ga.P_t = K - 1 - g.P_t;
+    ga.P_l = K - 1 - g.P_l;
+    ga.flip = 1;
+    stage_taps<K, CQ>(wt, g.C4, cq0, 1, taps);
+    // phase 2's decomposition: a pixel-thread owns ONE tap row ti and every GP-th tile row (K accumulator quads instead of the
+    // K * K of dw_tile_wgrad_kernel: with the data gradient's window in the same kernel those 100 registers spilled)
+    constexpr int GP = PTH / K;                                  // pixel-threads per tap row; PTH - GP * K of them sit phase 2 out
+    constexpr int NRW = (S::TH_ + GP - 1) / GP;                  // tile rows per thread, at most
+    const int ti = p / GP, pg = p % GP;
+    const bool wact = p < GP * K;
+    f32x4 accw[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) accw[j] = f32x4{0, 0, 0, 0};
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ud_bn_ref none{};
+    for (int n = nb; n < g.N; n += n_step) {
+        const long obase = (((long)n * g.Ho + (oh < g.Ho ? oh : 0)) * g.Wo) * g.C4 + (cok ? c4 : 0);
+        __syncthreads();                                       // the previous image's tiles are consumed
+        stage_tile<T, K, CQ, SW, 1>(ga, dy, none, false, cb, n, oh0, ow0, cq0, tileA);
+        stage_tile<T, K, CQ, SW, 1>(gb, x, bn, has_bn != 0, cb, n, oh0, ow0, cq0, tileB);
+        __syncthreads();
+        // ---- phase 1: data gradient of this thread's strip
+        {
+            f32x4 acc[SW];
+#pragma unroll
+            for (int o = 0; o < SW; ++o) acc[o] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const f32x4* rowp = tileA + ((row + i) * L::PITCH + col0) * CQ + cq;
+                f32x4 in[NIN], w[K];
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) in[j] = rowp[j * CQ];
+#pragma unroll
+                for (int j = 0; j < K; ++j) w[j] = taps[(i * K + j) * CQ + cq];
+#pragma unroll
+                for (int o = 0; o < SW; ++o)
+#pragma unroll
+                    for (int j = 0; j < K; ++j) acc[o] += in[o + j] * w[j];
+#pragma unroll
+                for (int o = 0; o < SW; ++o) asm volatile("" : "+v"(acc[o]));          // one window row at a time (see dw_tile_kernel)
+            }
+            // the epilogue's operands only now: fetched before the staging they would sit in 32 VGPRs across both stagings and
+            // the window loop, next to the 25 tap accumulators of phase 2 (K = 5: 70 - 100 spilled registers); x was read by the
+            // staging a moment ago, so these loads hit the L2
+            f32x4 pre_add[SW], pre_x[SW];
+#pragma unroll
+            for (int o = 0; o < SW; ++o) {
+                int ow = ow0 + col0 + o;
+                if (ow >= g.Wo) ow = g.Wo - 1;
+                if (add) pre_add[o] = add4[obase + (long)ow * g.C4];
+                if (has_bn) pre_x[o] = x4[obase + (long)ow * g.C4];
+            }
+            if (cok && oh < g.Ho) {
+#pragma unroll
+                for (int o = 0; o < SW; ++o) {
+                    const int ow = ow0 + col0 + o;
+                    if (ow >= g.Wo) continue;
+                    f32x4 r = acc[o] * gs;
+                    if (add) r += pre_add[o];
+                    if (has_bn) {
+                        const f32x4 a = pre_x[o];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float xh = (a[e] - cb.mu[e]) * cb.is[e];
+                            float d = r[e];
+                            if (bn.act) d *= ud_act_grad_fast(cb.ga[e] * xh + cb.be[e], bn.act);
+                            d = ud_rounded<T>(d);
+                            r[e] = d;
+                            v[e] += (double)d;
+                            v[4 + e] += (double)d * (double)xh;
+                        }
+                    }
+                    o4.st(obase + (long)ow * g.C4, r);
+                }
+            }
+        }
+        // ---- phase 2: weight gradient of tap row ti over tile rows pg, pg + GP, ...; dy is the centre of tileA (zero outside
+        // the image), in strips of 4 columns
+        if (wact) {
+#pragma unroll
+            for (int rr = 0; rr < NRW; ++rr) {
+                const int r = pg + rr * GP;
+                if (r >= S::TH_) break;
+#pragma unroll
+                for (int h = 0; h < S::TW_ / 4; ++h) {
+                    const f32x4* cp = tileA + ((r + ga.P_t) * L::PITCH + h * 4 + ga.P_l) * CQ + cq;
+                    const f32x4* rowp = tileB + ((r + ti) * L::PITCH + h * 4) * CQ + cq;
+                    f32x4 gy[4], in[3 + K];
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) gy[o] = cp[o * CQ];
+#pragma unroll
+                    for (int j = 0; j < 3 + K; ++j) in[j] = rowp[j * CQ];
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) accw[j] += in[o + j] * gy[o];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) asm volatile("" : "+v"(accw[j]));
+                }
+            }
+        }
+    }
+    // ---- fold the weight-gradient partials of a tap over its GP pixel-threads through LDS: [p][j][cq] quads
+    __syncthreads();
+    {
+        f32x4* sm = reinterpret_cast<f32x4*>(smem);
+        if (wact) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) sm[(p * K + j) * CQ + cq] = accw[j];
+        }
+        __syncthreads();
+        const float* smf = reinterpret_cast<const float*>(smem);
+        for (int i = threadIdx.x; i < K * K * CQ * 4; i += NT) {
+            const int e = i % 4, q = (i / 4) % CQ, tap = i / (4 * CQ);
+            if (cq0 + q >= g.C4) continue;
+            const int ti_ = tap / K, j = tap % K;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < GP; ++k) t += smf[(((ti_ * GP + k) * K + j) * CQ + q) * 4 + e];
+            wpart[((long)blockIdx.x * K * K + tap) * ((long)g.C4 * 4) + (cq0 + q) * 4 + e] = t;
+        }
+    }
+    if (has_bn) {
+        __syncthreads();
+        double* sm = reinterpret_cast<double*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm[(e * PTH + p) * CQ + cq] = v[e];
+        __syncthreads();
+        if (threadIdx.x < 8 * CQ) {
+            const int e = threadIdx.x / CQ, q = threadIdx.x % CQ;
+            double t = 0.0;
+            for (int k = 0; k < PTH; ++k) t += sm[(e * PTH + k) * CQ + q];
+            if (cq0 + q < g.C4) {
+                const long C = (long)g.C4 * 4, P = gridDim.x;
+                if (spart) spart[((long)(e / 4) * P + blockIdx.x) * C + (cq0 + q) * 4 + e % 4] = t;
+                else atomic_add_f64((e < 4 ? s1 : s2) + (cq0 + q) * 4 + e % 4, t);
+            }
+        }
+    }
+}
+
 // dw[c][tap] = gate * sum_p part[p][tap][c]   (fp64 accumulation; the parameter's own layout [C][K*K])
 __global__ __launch_bounds__(NT) void dw_tile_wgrad_finalize(int nparts, int KK, int C, const float* __restrict__ part,
                                                              const float* __restrict__ gate_alpha, int gate_mode,
@@ -441,6 +623,48 @@ int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, 
     return 0;
 }
 
+template <typename T, int K, int CQ, int SW>
+int launch_bwd(TileGeom g, const T* dy, const T* x, const ud_bn_ref* bn, const float* wt, const float* gate_alpha,
+               int gate_mode, const T* add, T* dz, float* wpart, long part_rows, float* dwt, double* s1, double* s2,
+               double* ws, hipStream_t s) {
+    using L = Lds<K, CQ, SW, 1>;
+    tile_counts<CQ, SW>(g.Ho, g.Wo, g.tiles_h, g.tiles_w);
+    const int tiles = g.tiles_h * g.tiles_w;
+    const int cblocks = ud_cdiv(g.C4, CQ);
+    // ~1024 workgroups; every workgroup folds N / n_step images before it writes its partials
+    int n_step = (int)((1024 + (long)tiles * cblocks - 1) / ((long)tiles * cblocks));
+    if (n_step < 1) n_step = 1;
+    if (n_step > g.N) n_step = g.N;
+    const long nparts = (long)tiles * n_step;
+    if (nparts > part_rows) return UD_EINVAL;
+    size_t lds = (size_t)(2 * L::TILE_Q + L::W_Q) * 16;
+    const size_t fold_w = (size_t)(NT / CQ) * K * CQ * 16, fold_s = (size_t)(8 * NT) * 8;
+    if (lds < fold_w) lds = fold_w;
+    if (lds < fold_s) lds = fold_s;
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_tile_bwd_kernel<T, K, CQ, SW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    ud_bn_ref none{};
+    const bool use_part = bn && nparts > 64;          // the rule of fused.hip's plan_reduce
+    dim3 grid((unsigned)nparts, (unsigned)cblocks);
+    hipLaunchKernelGGL((dw_tile_bwd_kernel<T, K, CQ, SW>), grid, dim3(NT), lds, s, g, dy, x, bn ? *bn : none, bn ? 1 : 0, wt,
+                       gate_alpha, gate_mode, add, dz, n_step, wpart, use_part ? ws : nullptr, s1, s2);
+    UD_LAUNCH_CHECK();
+    const int C = g.C4 * 4, KKC = K * K * C;
+    hipLaunchKernelGGL(dw_tile_wgrad_finalize, dim3(ud_cdiv(KKC, 64)), dim3(NT), 0, s, (int)nparts, K * K, C, wpart,
+                       gate_alpha, gate_mode, dwt);
+    UD_LAUNCH_CHECK();
+    if (use_part) {
+        hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv(C, 8)), dim3(NT), 0, s, 2, 1, C, (int)nparts, ws, s1, s2);
+        UD_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -509,6 +733,24 @@ int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, con
     if (sm) UD_WG(5, 16, 4);
     UD_WG(5, 8, 4);
 #undef UD_WG
+}
+
+int ud_dwtile_bwd(const void* dy, const void* x, const ud_bn_ref* bn, const float* wt, const float* gate_alpha, int gate_mode,
+                  const void* add, void* dz, float* dwt, float* wpart, long part_rows, double* s1, double* s2, double* ws,
+                  int N, int H, int W, int C, int K, int P_t, int P_l, int f16, ud_stream_t stream) {
+    if (!tile_args_ok(N, H, W, C, H, W, K) || !dy || !x || !wt || !dz || !dwt || !wpart || part_rows < 1) return UD_EINVAL;
+    if (P_t < 0 || P_t > K - 1 || P_l < 0 || P_l > K - 1) return UD_EINVAL;
+    if (bn && (bn->G != 1 || !s1 || !s2 || !ws)) return UD_EINVAL;
+    TileGeom g{N, H, W, C / 4, H, W, P_t, P_l, 0, 0, 0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    const bool sm = small_map(H, W, C);
+#define UD_BW(KK, QQ, SS)                                                                                             \
+    UD_STORAGE_DISPATCH(f16, return (launch_bwd<T, KK, QQ, SS>(g, (const T*)dy, (const T*)x, bn, wt, gate_alpha, gate_mode, \
+                                                                (const T*)add, (T*)dz, wpart, part_rows, dwt, s1, s2, ws, s)))
+    if (K == 3) { if (sm) UD_BW(3, 16, 4); UD_BW(3, 8, 4); }
+    if (sm) UD_BW(5, 16, 4);
+    UD_BW(5, 8, 4);
+#undef UD_BW
 }
 
 }  // extern "C"

@@ -366,8 +366,10 @@ __device__ __forceinline__ float dpre_of(const double* dgate, const float* s2, l
     return (float)dgate[i] * g * (1.f - g);
 }
 
-// blocks [0, N * chunks): sample n, chunk of 256 channels: ds1_acc[n][i] += sum_{c in chunk} dpre[n][c] We[c][i]
-//            (dpre of the chunk staged in LDS; threads = (i, channel slice); fp64 atomics, C / 256 adds per address)
+// blocks [0, N * chunks): sample n, chunk of CH = 32 * NSL channels: ds1_acc[n][i] += sum_{c in chunk} dpre[n][c] We[c][i]
+//            (dpre of the chunk staged in LDS; threads = (i, channel slice); fp64 atomics, C / CH adds per address).  A thread
+//            walks 32 channels: round 4's chunks of 256 left each of the NSL = 2 slices of the wide (IP = 128) form a chain of 128
+//            dependent-latency loads — 19 us for the 8 x 8 stage's 1632 x 68 FC against 8 us for everything else in the launch
 // blocks beyond: dW_e[c][i] = sum_n dpre[n][c] swish(s1[n][i]), db_e[c] = sum_n dpre[n][c] for NT / IP channels each
 template <int IP>
 __global__ __launch_bounds__(NT) void se_bwd_a_kernel(const double* __restrict__ dgate, const float* __restrict__ s2,
@@ -375,13 +377,14 @@ __global__ __launch_bounds__(NT) void se_bwd_a_kernel(const double* __restrict__
                                                       double* __restrict__ ds1_acc, float* __restrict__ dWe,
                                                       float* __restrict__ dbe, int N, int C, int Cs) {
     constexpr int NSL = NT / IP;
+    constexpr int CH = 32 * NSL;
     __shared__ float sh[NT];
     __shared__ float red[NT];
     const int i = threadIdx.x % IP, sl = threadIdx.x / IP;
-    const int chunks = (C + NT - 1) / NT;
+    const int chunks = (C + CH - 1) / CH;
     if ((int)blockIdx.x < N * chunks) {
-        const int n = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * NT;
-        const int cn = min(NT, C - c0);
+        const int n = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * CH;
+        const int cn = min(CH, C - c0);
         if ((int)threadIdx.x < cn) sh[threadIdx.x] = dpre_of(dgate, s2, (long)n * C + c0 + threadIdx.x);
         __syncthreads();
         float acc = 0.f;
@@ -867,7 +870,7 @@ int ud_se_bwd_a(const double* dgate, const float* s2, const float* s1, const flo
                 float* dbe, int N, int C, int Cs, ud_stream_t stream) {
     if (N < 1 || C < 1 || Cs < 1 || Cs > 128 || !dgate || !s2 || !s1 || !We || !ds1_acc || !dWe || !dbe) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int role1 = N * ud_cdiv(C, NT);
+    const int role1 = N * ud_cdiv(C, Cs <= 64 ? 32 * (NT / 64) : 32 * (NT / 128));
     if (Cs <= 64) {
         dim3 grid((unsigned)(role1 + ud_cdiv(C, NT / 64)));
         hipLaunchKernelGGL(se_bwd_a_kernel<64>, grid, dim3(NT), 0, s, dgate, s2, s1, We, ds1_acc, dWe, dbe, N, C, Cs);

@@ -2182,3 +2182,26 @@ def dwtile_bwd_weight(x, dy, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mod
     _call("ud_dwtile_wgrad", _p(x), _bnp(bn), _p(dy), _p(gate_alpha), int(gate_mode), _p(dwt), _p(part), rows, N, H, W, Cc,
           Ho, Wo, K, pad_t, pad_l, int(stride), h, _stream())
     return dwt
+
+
+def dwtile_bwd(dy, x, wt, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0, add=None, sacc=None):
+    """Data gradient AND weight gradient of a stride-1 'same' depthwise conv in one pass over (dy, x) (csrc/dwtile.hip,
+    dw_tile_bwd_kernel): da = gate * dwconv_bwd_data(dy) [+ add]; with bn (the deferred BatchNorm in front of the conv, x its
+    RAW input): dz = da * act'(bn(x)), sacc += the BatchNorm backward sums of dz, and dw[C, K*K] = gate * sum act(bn(x))(window) * dy;
+    without bn: dz = da, the conv's input is x itself.  Returns (dz, dw)."""
+    h = _act(dy, x, add)
+    _chk(wt)
+    N, H, W, Cc = x.shape
+    assert dy.shape == x.shape
+    rows = _call("ud_dwtile_wgrad_part_rows", N, H, W)
+    need = rows * K * K * Cc
+    part = _DWTILE_PART.get(x.device.index)
+    if part is None or part.numel() < need:
+        part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
+    dz = empty((N, H, W, Cc), dy, dy.dtype)
+    dwt = empty((Cc, K * K), x)
+    ws = _ws64(dy, _call("ud_dwtile_ws_doubles", N, H, W, Cc)) if bn is not None else None
+    _call("ud_dwtile_bwd", _p(dy), _p(x), _bnp(bn), _p(wt), _p(gate_alpha), int(gate_mode), _p(add), _p(dz), _p(dwt), _p(part),
+          rows, _pd(sacc) if bn is not None else None, _pd(sacc, Cc) if bn is not None else None, ws, N, H, W, Cc, K, pad_t,
+          pad_l, h, _stream())
+    return dz, dwt

@@ -438,11 +438,11 @@ class UniDefenseModelEb4(nn.Module):
                 if b.skip and rate0 and idx > 0]
         fresh = None
         if any(given.get(idx) is None for idx, _ in todo):
-            # all Bernoulli draws of the step in three launches (rand, compare, cast) instead of three per block
+            # all Bernoulli draws of the step in ONE launch (torch.bernoulli of a probability tensor; rounds 1-4: rand, compare, cast)
             keep_p = getattr(self, "_dc_keep_p", None)
-            if keep_p is None or keep_p.device != device:
-                keep_p = self._dc_keep_p = torch.tensor([1.0 - r for _, r in todo], device=device).view(-1, 1)
-            fresh = (torch.rand((len(todo), n), device=device) < keep_p).to(torch.float32)
+            if keep_p is None or keep_p.device != device or keep_p.shape[1] != n:
+                keep_p = self._dc_keep_p = torch.tensor([1.0 - r for _, r in todo], device=device).view(-1, 1).expand(-1, n).contiguous()
+            fresh = torch.bernoulli(keep_p)
         for j, (idx, rate) in enumerate(todo):
             k_ = given.get(idx)
             out["drop_connect"][idx] = k_.to(device=device, dtype=torch.float32).contiguous() if k_ is not None \
@@ -456,7 +456,7 @@ class UniDefenseModelEb4(nn.Module):
             m = self._to_pix_mask(m.to(device=like.device, dtype=torch.float32))
             assert m.shape == like.shape, (name, tuple(m.shape), tuple(like.shape))
             return m
-        return (torch.rand(like.shape, device=like.device) < keep_p).to(torch.float32)
+        return torch.empty(like.shape, dtype=torch.float32, device=like.device).bernoulli_(keep_p)      # one launch
 
     def _run(self, x, tape, rng, noise_x=None):
         """The whole forward on HIP kernels.  x: [N,3,H,W] planes; noise_x: perturbed encoder input or None."""

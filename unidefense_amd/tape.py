@@ -245,6 +245,27 @@ def _dw_tile_policy(sf, k, stride, H, half):
     return (fwd or not sf), not sf, bwd
 
 
+# Round 5: the stride-1 blocks' depthwise data gradient and weight gradient as ONE kernel (kernels.dwtile_bwd: both halo tiles
+# staged once; the separate kernels read dy and the conv's input twice each).  Where it is used: _dw_bwd_fused_policy.
+_DW_BWD_FUSED = True
+
+
+def _dw_bwd_fused_policy(sf, k, stride, H, half):
+    """data + weight gradient of this depthwise conv in one launch (csrc/dwtile.hip: dw_tile_bwd_kernel)?  Measured per shape
+    against the pair of kernels _dw_tile_policy picks (tools/bench_dwbwd.py on an MI355X, profiles/r05/dwbwd_*.txt; us, pair ->
+    fused): fp32 bs 32: 128^2 187 -> 151 and 74 -> 61, 32^2 k5 100 -> 81, 16^2 k5 70 -> 63, 16^2 k3 47 -> 45, 8^2 k3 47 -> 45;
+    NOT the 64^2 k3 blocks (132 vs 134: two halo tiles of a 16 x 8 tile are 1.4x its pixels, twice) and NOT the 8^2 k5 blocks
+    (48 vs 60: one workgroup per CU next to the strip kernels' eight).  Half storage bs 64: 328 -> 260, 90 -> 80, 224 -> 211,
+    163 -> 156, 73 -> 71; a tie at 16^2 k5 and 8^2 k3, 72 vs 96 at 8^2 k5."""
+    if not _DW_BWD_FUSED or stride != 1:
+        return False
+    if H <= 8:
+        return k == 3 and not half
+    if half:
+        return True
+    return not (k == 3 and H == 64)
+
+
 DW_WT = {}            # {id(w): (w, w._version, tap-major wt)} for the forward in flight (kernels.dw_weights_tapmajor)
 
 
@@ -964,9 +985,10 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         s_f, s_i = _fft_scales(S, sp.sf_norm)
         alpha = dwm.sf_coef
         t_fwd, t_wg, t_bwd = _dw_tile_policy(True, k, stride, H, x.dtype == torch.float16)
+        t_fused = _dw_bwd_fused_policy(True, k, stride, H, x.dtype == torch.float16)
         if src_bn is not None:
             # a strip kernel needs a = swish(bn0(e)) materialised (rfft2_ex writes it); the tiled ones apply it on load
-            xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=not (t_fwd and t_wg), update=True, want_absmax=True)
+            xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=not (t_fwd and (t_wg or t_fused)), update=True, want_absmax=True)
         else:
             xf, a = K.rfft2(src, s_f, 1.0, want_absmax=True), src
         if t_fwd:
@@ -988,6 +1010,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
     else:
         alpha = None
         t_fwd, t_wg, t_bwd = _dw_tile_policy(False, k, stride, H, x.dtype == torch.float16)
+        t_fused = _dw_bwd_fused_policy(False, k, stride, H, x.dtype == torch.float16)
         if t_fwd:
             # halo tile staged in LDS with swish(bn0(e)) applied on the way in; BN1 statistics out of the epilogue
             a = None
@@ -1075,21 +1098,41 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
             g_sp = dd
         tape.add_param_grad(blk._bn1.weight, dg1)
         tape.add_param_grad(blk._bn1.bias, db1)
-        if t_wg:
+        dz0 = dw_f = None
+        if t_fused:
+            # ---- depthwise data + weight gradient in one pass over (dd, src)
+            if src_bn is not None:
+                sb0 = K.zeros64(2 * src.shape[-1], x)
+                dz0, dw_f = K.dwtile_bwd(g_sp, src, wt, k, pt, pl, bn=src_bn, gate_alpha=g_alpha, gate_mode=g_mode, add=da_f,
+                                         sacc=sb0)
+                is_dz = True
+            else:
+                add = da_f
+                if sp.skip and add is None:
+                    add, skip_done = dout, True
+                else:
+                    skip_done = not sp.skip
+                dx, dw_f = K.dwtile_bwd(g_sp, src, wt, k, pt, pl, gate_alpha=g_alpha, gate_mode=g_mode, add=add)
+            tape.add_param_grad(dwm.weight, dw_f)
+        elif t_wg:
             tape.add_param_grad(dwm.weight, K.dwtile_bwd_weight(src, g_sp, k, pt, pl, bn=src_bn, gate_alpha=g_alpha,
                                                                 gate_mode=g_mode, stride=stride))
         else:
             tape.add_param_grad(dwm.weight, K.dwconv_bwd_weight_ex(a, g_sp, g_alpha, g_mode, k, stride, pt, pl))
         # ---- depthwise data gradient (+ spectral branch), through swish(bn0(.)) when the input is deferred
         if src_bn is not None:
-            sb0 = K.zeros64(2 * src.shape[-1], x)
-            if t_bwd:
+            if dz0 is not None:
+                pass                                       # the fused kernel above made dz0 and the BatchNorm sums
+            elif t_bwd:
+                sb0 = K.zeros64(2 * src.shape[-1], x)
                 dz0 = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, da_f, src, src_bn, sb0, stride=stride)
                 is_dz = True
             elif stride == 1:
+                sb0 = K.zeros64(2 * src.shape[-1], x)
                 dz0 = K.dwconv_bwd_data_bn(g_sp, g_alpha, g_mode, wt, da_f, src, src_bn, k, stride, pt, pl, sb0)
                 is_dz = True
             else:       # stride 2 (4 of 32 blocks): gather kernel, then the sums as a pass of their own
+                sb0 = K.zeros64(2 * src.shape[-1], x)
                 dz0 = K.dwconv_bwd_data(g_sp, wt, k, stride, pt, pl, H, W, add=da_f)
                 K.normbwd_sums(src, dz0, None, 1.0, src_bn, False, 1, M, sb0)
                 is_dz = False
@@ -1110,15 +1153,16 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 if sp.skip:
                     dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
         else:
-            add = da_f
-            if sp.skip and add is None:
-                add, skip_done = dout, True
-            else:
-                skip_done = not sp.skip
-            if t_bwd:
-                dx = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, add, stride=stride)
-            else:
-                dx = K.dwconv_bwd_data_ex(g_sp, g_alpha, g_mode, wt, add, k, stride, pt, pl, H, W)
+            if dw_f is None:
+                add = da_f
+                if sp.skip and add is None:
+                    add, skip_done = dout, True
+                else:
+                    skip_done = not sp.skip
+                if t_bwd:
+                    dx = K.dwtile_bwd_data(g_sp, wt, k, pt, pl, H, W, g_alpha, g_mode, add, stride=stride)
+                else:
+                    dx = K.dwconv_bwd_data_ex(g_sp, g_alpha, g_mode, wt, add, k, stride, pt, pl, H, W)
             if not skip_done:
                 dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
         dx._ud_owned = True
