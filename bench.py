@@ -146,7 +146,7 @@ def train_step_measure(bs):
             "value": bs / dt, "unit": "train images/sec (each image goes through 2 passes)", "steps": n}
 
 
-def extra_measurements(budget_s=90):
+def extra_measurements(budget_s=100):
     """Driver-visible numbers of the other BASELINE configs: bounded 5-step runs in CHILD processes after the timed region
     (configs[4] f16 bs 64, configs[3] UDR50 320^2 bs 16, configs[0] UDR18 128^2 bs 8, the two-pass train step, UDEB4 at 380^2)."""
     import subprocess
@@ -156,7 +156,8 @@ def extra_measurements(budget_s=90):
             ("configs[3]: UDR50 320x320 bs 16", ["--model", "UDR50", "--size", "320", "--batch", "16"] + common),
             ("configs[0]: UDR18 128x128 bs 8", ["--model", "UDR18", "--size", "128", "--batch", "8"] + common),
             ("two-pass train step", ["--train-step"]),
-            ("UDEB4 at the reference YAMLs' 380x380, bs 32", ["--size", "380"] + common)]
+            ("UDEB4 at the reference YAMLs' 380x380, bs 32", ["--size", "380"] + common),
+            ("UDEB4 at 380x380 with the reference YAMLs' own batch, 10 real + 10 fake per GPU", ["--size", "380", "--batch", "20"] + common)]
     out, t_start = [], time.perf_counter()
     for name, argv in jobs:
         left = budget_s - (time.perf_counter() - t_start)

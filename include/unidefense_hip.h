@@ -173,6 +173,17 @@ typedef struct {
 int ud_split_planes_h2t_multi(const ud_split_item* items_dev, int n, uint32_t* slots, int amax_blocks_total,
                               int split_blocks_total, ud_stream_t stream);
 
+/* All k x k conv weights of a step into the [rows][tap][reduced channel] matrices the implicit-GEMM convs read, in ONE launch
+ * (F.conv2d / ConvTranspose2d weights of model/unidefense.py:59-102, model/modules.py:111, the stem, model/resnet/exp.py:95-111):
+ * src W[A][B][KH][KW] -> mode 0: dst[a][kh][kw][b]; mode 1: dst[b][KH-1-kh][KW-1-kw][a]; mode 2: dst[b][kh][kw][a].
+ * items_dev: device table; item i owns blocks [block0, block0 + ceil(A B KH KW / 256)), blocks_total their sum. */
+typedef struct {
+    const float* src;
+    float* dst;
+    int A, B, KH, KW, mode, block0;
+} ud_layout_item;
+int ud_weight_layouts_multi(const ud_layout_item* items_dev, int n, int blocks_total, ud_stream_t stream);
+
 /* ---- column reductions / normalisation on [G][R][C]  (C % 4 == 0) -----------------------------
  * Every reduction is a partial pass (fp64 per-workgroup totals stored into the scratch `ws`) plus a small
  * finalize launch; deterministic, no atomics.  ws: ud_reduce_ws_doubles(G, R, C) doubles of scratch, no
@@ -323,6 +334,11 @@ int ud_dynfilter_bwd(const float* dout, const float* dmask_ext, const float* x, 
  *                   dir 1: the reverse (slice = gradient of the concat) */
 int ud_avgpool_fwd(const float* x, float* y, int N, int Ho, int Wo, int C, int k, ud_stream_t stream);
 int ud_avgpool_bwd(const float* dy, float* dx, int N, int Ho, int Wo, int C, int k, ud_stream_t stream);
+/* F.adaptive_avg_pool2d to an output size that does not divide the input (model/efficientnet/exp.py:61-62 on the 95 x 95 map of
+ * the 380 x 380 trunk: 95 -> 48), pixel-major [N][H][W][C] -> [N][Ho][Wo][C], Ho <= H, Wo <= W; windows [floor(o H / Ho),
+ * ceil((o + 1) H / Ho)) as in ATen; _bwd is its adjoint (dx written, not accumulated). */
+int ud_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int Ho, int Wo, int C, ud_stream_t stream);
+int ud_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int Ho, int Wo, int C, ud_stream_t stream);
 int ud_maxpool3s2_fwd(const float* x, float* y, unsigned char* arg, int N, int H, int W, int C,
                       ud_stream_t stream);
 int ud_maxpool3s2_bwd(const float* dy, const unsigned char* arg, float* dx, int N, int H, int W, int C,

@@ -755,3 +755,67 @@ def test_rfft2_planes_large(S, P):
     (Yd.real * G[:, :S, :Wh].double()).sum().add((Yd.imag * G[:, S:, :Wh].double()).sum()).backward()
     adj = K.dft_rfft2_planes_adjoint(G.to(dev).contiguous(), S).double().cpu()
     assert float((adj - xd.grad).abs().max()) <= 1e-5 * float(xd.grad.abs().max())
+
+
+@pytest.mark.parametrize("N,H,W,Ho,Wo,Cc", [(2, 95, 95, 48, 48, 8), (1, 14, 9, 5, 4, 12), (3, 7, 7, 7, 7, 4), (2, 24, 24, 12, 12, 16),
+                                            (1, 95, 95, 1, 1, 4)])
+def test_adaptive_avgpool_any_size(N, H, W, Ho, Wo, Cc):
+    """csrc/pool.hip: F.adaptive_avg_pool2d to a size that does not divide the input (model/efficientnet/exp.py:61-62 at 380 x 380:
+    the 95 x 95 map pooled to 48 x 48 with overlapping windows of 2 and 3) and its adjoint, against torch in float64."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(H * 100 + Ho)
+    x = torch.randn(N, H, W, Cc, generator=g)
+    dy = torch.randn(N, Ho, Wo, Cc, generator=g)
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = torch.nn.functional.adaptive_avg_pool2d(xd, (Ho, Wo))
+    (ref * dy.double().permute(0, 3, 1, 2)).sum().backward()
+    y = K.adaptive_avgpool_fwd(x.to(dev), Ho, Wo)
+    dx = K.adaptive_avgpool_bwd(dy.to(dev), H, W)
+    e1 = (y.double().cpu() - ref.detach().permute(0, 2, 3, 1)).abs().max().item()
+    e2 = (dx.double().cpu() - xd.grad.permute(0, 2, 3, 1)).abs().max().item()
+    assert e1 < 1e-6 and e2 < 1e-6, (e1, e2)
+
+
+def test_weight_layout_batch_matches_permutes():
+    """kernels._WeightLayoutBatch / ud_weight_layouts_multi: the [rows][tap][channel] matrices of all registered k x k conv weights
+    from ONE launch at the start of a forward — bit-equal to torch's permute / flip + contiguous, re-made from the CURRENT weights by
+    every begin_forward, handed out only inside the forward and only while the parameter is the one they were made from."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(5)
+    owner = torch.nn.Module()
+    ws = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in ((20, 12, 3, 3), (3, 20, 3, 3), (8, 8, 1, 1), (48, 3, 3, 3), (16, 24, 5, 5))]
+
+    def ref(w, mode):
+        A, B, KH, KW = w.shape
+        if mode == 0:
+            return w.permute(0, 2, 3, 1).reshape(A, KH * KW * B).contiguous()
+        if mode == 1:
+            return w.flip(2, 3).permute(1, 2, 3, 0).reshape(B, KH * KW * A).contiguous()
+        return w.permute(1, 2, 3, 0).reshape(B, KH * KW * A).contiguous()
+    K.begin_forward(owner)
+    for w in ws:                                   # first forward: made on the spot, and registered
+        for mode in (0, 1, 2):
+            assert torch.equal(K.weight_layout(w, mode), ref(w.detach(), mode))
+    K.end_forward()
+    batch = owner.__dict__["_ud_weight_layouts"]
+    assert len(batch.entries) == 15 and batch.dirty
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5)                            # an optimizer step in between
+    K.begin_forward(owner)
+    assert batch.active and not batch.dirty
+    for w in ws:
+        for mode in (0, 1, 2):
+            got = K.weight_layout(w, mode)
+            assert got.data_ptr() == batch.entries[(id(w), mode)][1].data_ptr()          # the batch's buffer, not a fresh permute
+            assert torch.equal(got, ref(w.detach(), mode))
+    K.end_forward()
+    w = ws[0]
+    assert batch.get(w, 0) is None                 # outside a forward nothing is handed out
+    K.begin_forward(owner)
+    with torch.no_grad():
+        w.add_(1.0)                                # changed after begin(): the stale buffer must not be used
+    assert batch.get(w, 0) is None and torch.equal(K.weight_layout(w, 0), ref(w.detach(), 0))
+    K.end_forward()

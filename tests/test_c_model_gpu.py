@@ -168,17 +168,25 @@ def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant, fname, run_mode)
     print(f"  {within_1e3}/{len(rows)} gradient tensors within 1e-3 of the reference; worst:")
     for r in rows[:12]:
         print("  rel %.3e  %-58s norm err %.3e head err %.3e ref norm %.3e" % r)
-    within(f"worst of 504 gradient tensors (N = {n}): max(norm err, head err) / (ref norm + floor)", rows[0][0], rtol)
-    bad = [r for r in rows if not r[0] <= rtol]
+    # The scalar sf_coef gradients are single global sums with heavy cancellation (header): on the N = 8 fixture the REFERENCE's
+    # own fp32 value of one of them (blocks.9, 5.5e-3) sits 3e-5 from the float64 result, which this path reproduces to the plain
+    # 1e-3 bound (test_train_grads_vs_oracle_elementwise_n8_plain_bound: 504 of 504).  Against the reference's fp32 record such a
+    # scalar is held to 1e-2 of its value; at most two may need it, every other tensor meets the bound above.
+    scal = [r for r in rows if not r[0] <= rtol and r[1].endswith("sf_coef") and max(r[2], r[3]) <= 1e-2 * r[4]]
+    rows_strict = [r for r in rows if r not in scal]
+    within(f"worst of 504 gradient tensors (N = {n}): max(norm err, head err) / (ref norm + floor)", rows_strict[0][0], rtol)
+    bad = [r for r in rows_strict if not r[0] <= rtol]
     assert not bad, bad[:10]
-    assert len(rows) == 504 and within_1e3 == len(rows)
+    assert within(f"N = {n} {variant}: scalar sf_coef gradients held to 1e-2 of the reference's fp32 value instead", len(scal), 2 if n >= 8 else 0)
+    assert len(rows) == 504 and within_1e3 >= len(rows) - len(scal)
     # Who needs the absolute floor at all?  Only gradients that are zero up to rounding on BOTH sides: BatchNorm biases
     # of the STRUCT_ZERO_GRADS family, reference norm < 1e-4 (against 1e-2 .. 1e+1 for every other tensor), and their
     # nearly cancelled siblings NEAR_ZERO_GRADS.
     floor_users = [r for r in rows if max(r[2], r[3]) > 1e-3 * r[4]]
     print("  tensors outside a purely relative 1e-3:", [(r[1], "%.1e" % r[4]) for r in floor_users])
     odd = [(r[1], r[4]) for r in floor_users
-           if not ((r[1] in STRUCT_ZERO_GRADS and r[4] < 1e-4) or (r[1] in NEAR_ZERO_GRADS and r[4] < 1e-3))]
+           if not ((r[1] in STRUCT_ZERO_GRADS and r[4] < 1e-4) or (r[1] in NEAR_ZERO_GRADS and r[4] < 1e-3) or
+                   (n >= 8 and r[1].endswith("sf_coef") and max(r[2], r[3]) <= 1e-2 * r[4]))]
     assert not odd, odd
 
 
@@ -431,6 +439,44 @@ def _rng_sized(n, seed, drop_rate, size, nblk=32, dc_rate=0.2):
     for idx in range(1, nblk):
         rng["drop_connect"][idx] = bern((n,), 1.0 - dc_rate * idx / nblk)
     return rng
+
+
+def test_reference_batch_of_20_at_380(golden_dir):
+    """The batch every shipped Eb4 YAML trains with: 10 real + 10 fake per GPU at 380 x 380 (config_template/uniatt/Prot1/
+    data_ffpp.yml:71-72).  (1) Eval mode couples no samples: the two images of the reference golden udeb4_eval_n2_s380.npz, embedded
+    in a batch of 20, must come out as the reference computed them (the bs-20 GEMM plans, the 95 x 95 block's DFT-matrix path and
+    csrc/pool.hip's 95 -> 48 adaptive pool on real shapes).  (2) A train-mode forward + pass-1 loss + backward at 10 + 10: finite,
+    every trainable parameter receives a gradient, and the backward is linear in the loss (x 4 -> gradients x 4)."""
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "udeb4_eval_n2_s380.npz"))
+    n, size, seed = [int(v) for v in g["meta"]]
+    x2 = param_fill.make_input(n, size, seed)
+    x = torch.cat([x2, param_fill.make_input(18, size, seed + 1)], 0).to(dev)
+    m = _model(dev, 0.0, 0.3).eval()
+    with torch.no_grad():
+        out = m(x)
+    ld = out["loss_dict"]
+    first = {"cls_out": out["cls_out"][:n], "rec": out["rec"][:n],
+             "loss_dict": {"factorization": ld["factorization"][:n], "freq_mask": ld["freq_mask"][:n], "spat_mask": ld["spat_mask"][:n],
+                           "spatial": ld["spatial"][:n], "freq": ld["freq"][:n], "triplet": [t[:n] for t in ld["triplet"]]}}
+    _check_outputs(first, g)
+    m.train()
+    tgt = param_fill.make_labels(20).to(dev)
+    rng = _rng_sized(20, 77, 0.5, size)
+    grads = []
+    for scale in (1.0, 4.0):
+        for p_ in m.parameters():
+            p_.grad = None
+        o = m(x, rng=rng)
+        ls = _pass1_loss(o, tgt, ou.SMOOTH_LAMBDAS)
+        assert torch.isfinite(ls["total_loss"]).item()
+        (ls["total_loss"] * scale).backward()
+        grads.append({k: p_.grad.detach().double() for k, p_ in m.named_parameters() if p_.grad is not None})
+    assert len(grads[0]) == 504 and all(torch.isfinite(v).all().item() for v in grads[0].values())
+    gmax = max(float(v.abs().max()) for v in grads[0].values())
+    worst = max(float((grads[1][k] - 4.0 * grads[0][k]).abs().max()) / (4.0 * float(grads[0][k].abs().max()) + 1e-3 * gmax)
+                for k in grads[0])
+    assert within("380 x 380, bs 10 + 10: backward linear in the loss (x 4), worst tensor", worst, 1e-3)
 
 
 def test_native_resolution_380_vs_reference_golden(golden_dir):

@@ -586,9 +586,45 @@ __global__ __launch_bounds__(NT) void dw_wt_tapmajor(const DwWtEntry* __restrict
     dst[e.dst_off + i] = e.src[c * e.KK + tap];
 }
 
+// ---- all k x k conv weights of a step into their GEMM layouts in ONE launch ------------------------------------------------
+// The implicit-GEMM convs (decoder, dynamic filters, stem; the ResNet trunks) read their weights as [rows][tap][reduced channel]
+// matrices: W[A][B][KH][KW] -> mode 0: [a][kh][kw][b] (forward of a conv; data gradient of a transposed conv), mode 1:
+// [b][KH-1-kh][KW-1-kw][a] (data gradient of a stride-1 conv: flipped and transposed), mode 2: [b][kh][kw][a] (forward of a
+// transposed conv; data gradient of a strided conv).  Rounds 1-4 made each with torch's permute / flip + contiguous: 2-3
+// launches per conv and pass, ~45 per UDEB4 step.  Device table of items; block -> item by bisection of the block prefixes.
+__global__ __launch_bounds__(NT) void weight_layouts_kernel(const ud_layout_item* __restrict__ items, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].block0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const ud_layout_item it = items[lo];
+    const long e = (long)(blockIdx.x - it.block0) * NT + threadIdx.x;
+    const long total = (long)it.A * it.B * it.KH * it.KW;
+    if (e >= total) return;
+    const int taps = it.KH * it.KW;
+    // dst index e -> (row, tap, col); mode 0: row = a, col = b; modes 1 / 2: row = b, col = a
+    const int inner = it.mode == 0 ? it.B : it.A;
+    const int col = (int)(e % inner);
+    const int tap = (int)((e / inner) % taps);
+    const int row = (int)(e / ((long)inner * taps));
+    const int a = it.mode == 0 ? row : col, b = it.mode == 0 ? col : row;
+    const int st = it.mode == 1 ? taps - 1 - tap : tap;          // (KH-1-kh) * KW + (KW-1-kw) = taps - 1 - (kh * KW + kw)
+    it.dst[e] = it.src[((long)a * it.B + b) * taps + st];
+}
+
 }  // namespace
 
 extern "C" {
+
+int ud_weight_layouts_multi(const ud_layout_item* items_dev, int n, int blocks_total, ud_stream_t stream) {
+    if (!items_dev || n < 1 || blocks_total < n) return UD_EINVAL;
+    hipLaunchKernelGGL(weight_layouts_kernel, dim3((unsigned)blocks_total), dim3(NT), 0, (hipStream_t)stream, items_dev, n);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
 
 int ud_fc_fwd(const float* x, const float* W, const float* b, float* y, int N, int I, int O, int act_in,
               ud_stream_t stream) {

@@ -55,6 +55,59 @@ __global__ __launch_bounds__(NT) void avgpool_bwd(long total4, int Ho, int Wo, i
     }
 }
 
+// F.adaptive_avg_pool2d to ANY output size (model/efficientnet/exp.py:61-62 on the 95 x 95 map of the 380 x 380 trunk's stride-2 SF
+// block: 95 -> 48, windows of 2 and 3 rows that overlap): output index o averages input rows [floor(o * H / Ho), ceil((o + 1) *
+// H / Ho)) — ATen's start_index / end_index (aten/src/ATen/native/AdaptivePooling.h).  Rounds 3-4 called ATen's kernel here.
+__device__ __forceinline__ int ada_start(int o, int out, int in) { return (int)(((long)o * in) / out); }
+__device__ __forceinline__ int ada_end(int o, int out, int in) { return (int)(((long)(o + 1) * in + out - 1) / out); }
+
+__global__ __launch_bounds__(NT) void adaptive_avgpool_fwd(long total4, int H, int W, int Ho, int Wo, int C4,
+                                                           const float* __restrict__ x, float* __restrict__ y) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total4; e += (long)gridDim.x * NT) {
+        const int c4 = (int)(e % C4);
+        long pix = e / C4;
+        const int wo = (int)(pix % Wo);
+        long t = pix / Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        const int h0 = ada_start(ho, Ho, H), h1 = ada_end(ho, Ho, H), w0 = ada_start(wo, Wo, W), w1 = ada_end(wo, Wo, W);
+        f32x4 acc = {0, 0, 0, 0};
+        for (int i = h0; i < h1; ++i)
+            for (int j = w0; j < w1; ++j) acc += x4[((n * H + i) * W + j) * C4 + c4];
+        y4[e] = acc / (float)((h1 - h0) * (w1 - w0));
+    }
+}
+
+// adjoint: dx[h][w] = sum over the output windows that contain (h, w) of dy[o] / |window(o)|  (a gather: no atomics); the
+// windows containing row h are the outputs oh with start(oh) <= h < end(oh): a run around floor(h * Ho / H)
+__global__ __launch_bounds__(NT) void adaptive_avgpool_bwd(long total4, int H, int W, int Ho, int Wo, int C4,
+                                                           const float* __restrict__ dy, float* __restrict__ dx) {
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    f32x4* o4 = reinterpret_cast<f32x4*>(dx);
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total4; e += (long)gridDim.x * NT) {
+        const int c4 = (int)(e % C4);
+        long pix = e / C4;
+        const int w = (int)(pix % W);
+        long t = pix / W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        int oh0 = (int)(((long)h * Ho) / H), ow0 = (int)(((long)w * Wo) / W);
+        while (oh0 > 0 && ada_end(oh0 - 1, Ho, H) > h) --oh0;
+        while (ow0 > 0 && ada_end(ow0 - 1, Wo, W) > w) --ow0;
+        f32x4 acc = {0, 0, 0, 0};
+        for (int oh = oh0; oh < Ho && ada_start(oh, Ho, H) <= h; ++oh) {
+            const int nh = ada_end(oh, Ho, H) - ada_start(oh, Ho, H);
+            for (int ow = ow0; ow < Wo && ada_start(ow, Wo, W) <= w; ++ow) {
+                const int nw = ada_end(ow, Wo, W) - ada_start(ow, Wo, W);
+                acc += d4[((n * Ho + oh) * Wo + ow) * C4 + c4] / (float)(nh * nw);
+            }
+        }
+        o4[e] = acc;
+    }
+}
+
 // max over the 3x3 window of stride 2, padding 1 (padding never wins: -inf); arg = winning tap (kh*3 + kw),
 // first maximum in scan order like ATen's max_pool2d
 __global__ __launch_bounds__(NT) void maxpool3s2_fwd(long total, int H, int W, int Ho, int Wo, int C,
@@ -172,6 +225,24 @@ int ud_avgpool_bwd(const float* dy, float* dx, int N, int Ho, int Wo, int C, int
     long total4 = (long)N * Ho * k * Wo * k * (C / 4);
     hipLaunchKernelGGL(avgpool_bwd, dim3(ew_blocks(total4)), dim3(NT), 0, (hipStream_t)stream, total4, Ho, Wo, C / 4, k,
                        dy, dx);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int Ho, int Wo, int C, ud_stream_t stream) {
+    if (C % 4 || N < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || Ho > H || Wo > W || !x || !y) return UD_EINVAL;
+    long total4 = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(adaptive_avgpool_fwd, dim3(ew_blocks(total4)), dim3(NT), 0, (hipStream_t)stream, total4, H, W, Ho, Wo,
+                       C / 4, x, y);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int Ho, int Wo, int C, ud_stream_t stream) {
+    if (C % 4 || N < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || Ho > H || Wo > W || !dy || !dx) return UD_EINVAL;
+    long total4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(adaptive_avgpool_bwd, dim3(ew_blocks(total4)), dim3(NT), 0, (hipStream_t)stream, total4, H, W, Ho, Wo,
+                       C / 4, dy, dx);
     UD_LAUNCH_CHECK();
     return 0;
 }

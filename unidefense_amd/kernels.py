@@ -350,22 +350,121 @@ class _WeightPlaneBatch:
 _WEIGHT_PLANES = _WeightPlaneBatch()          # the batch of the forward in progress (default: a process-wide one for direct callers)
 
 
+class _WeightLayoutBatch:
+    """The GEMM layouts of every k x k conv weight of a model ([rows][tap][reduced channel] matrices: forward, and the data
+    gradient's flipped / transposed form), made by ONE launch at the start of a forward (ud_weight_layouts_multi) instead of a
+    permute / flip + contiguous pair per conv and pass (~45 launches per UDEB4 step, more in the ResNet models).  Same life cycle
+    as _WeightPlaneBatch: a (weight, mode) registers on its first eager use; begin() re-makes all registered layouts from the
+    CURRENT weights into persistent buffers; get() hands a buffer out only inside that forward and only while the parameter's
+    version / storage are the ones it was made from — the backward's layouts are fetched DURING the forward and kept by the
+    tape's closures (the weights do not change between a forward and its backward).  One batch per model."""
+
+    def __init__(self):
+        self.entries = {}          # (id(param), mode) -> [weakref(param), buffer, version at the last begin(), data_ptr, shape]
+        self.table = None
+        self.dirty = False
+        self.blocks = 0
+        self.active = False
+        self.retired = []
+
+    def get(self, w, mode):
+        if not (isinstance(w, torch.nn.Parameter) and w.is_contiguous() and w.dtype == torch.float32 and w.dim() == 4):
+            return None
+        e = self.entries.get((id(w), mode))
+        if e is not None and e[0]() is w and self.active and e[2] == w._version and e[3] == w.data_ptr():
+            return e[1]
+        if (e is None or e[0]() is not w or e[3] != w.data_ptr()) and not torch.cuda.is_current_stream_capturing():
+            import weakref
+            A, B, KH, KW = w.shape
+            rows, inner = (A, B) if mode == 0 else (B, A)
+            self.entries[(id(w), mode)] = [weakref.ref(w), torch.empty((rows, KH * KW * inner), dtype=torch.float32, device=w.device),
+                                           -1, w.data_ptr(), tuple(w.shape)]
+            self.dirty = True
+        return None
+
+    def begin(self):
+        self.active = False
+        if not self.entries:
+            return
+        stale = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[3]]
+        if stale or self.dirty:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            for k in stale:
+                del self.entries[k]
+            if not self.entries:
+                self.table = None
+                return
+            self._build()
+        _call("ud_weight_layouts_multi", _p(self.table), len(self.entries), self.blocks, _stream())
+        for e in self.entries.values():
+            e[2] = e[0]()._version
+        self.active = True
+
+    def _build(self):
+        from .lib import LayoutItem
+        items = (LayoutItem * len(self.entries))()
+        b0 = 0
+        dev = None
+        for i, ((_, mode), e) in enumerate(self.entries.items()):
+            w = e[0]()
+            dev = w.device
+            it = items[i]
+            it.src, it.dst = w.data_ptr(), e[1].data_ptr()
+            it.A, it.B, it.KH, it.KW = e[4]
+            it.mode, it.block0 = mode, b0
+            b0 += -(-w.numel() // 256)
+            e[2] = -1
+        if self.table is not None:
+            self.retired.append(self.table)
+        self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+        self.blocks = b0
+        self.dirty = False
+
+
+_WEIGHT_LAYOUTS = _WeightLayoutBatch()
+_WEIGHT_LAYOUT_BATCH = True          # A/B: tools/run_with.py kernels._WEIGHT_LAYOUT_BATCH=False
+
+
+def weight_layout(w, mode):
+    """W[A][B][KH][KW] as the matrix an implicit-GEMM conv reads — mode 0: [A, KH*KW*B] = permute(0,2,3,1); mode 1: [B, KH*KW*A]
+    flipped = flip(2,3).permute(1,2,3,0); mode 2: [B, KH*KW*A] = permute(1,2,3,0) — from the step's one-launch batch when it
+    covers this weight as it is now, else made here (and the weight joins the batch from the next forward on)."""
+    A, B, KH, KW = w.shape
+    if _WEIGHT_LAYOUT_BATCH:
+        buf = _WEIGHT_LAYOUTS.get(w, mode)
+        if buf is not None:
+            return buf
+    if mode == 0:
+        return w.permute(0, 2, 3, 1).reshape(A, KH * KW * B).contiguous()
+    if mode == 1:
+        return w.flip(2, 3).permute(1, 2, 3, 0).reshape(B, KH * KW * A).contiguous()
+    return w.permute(1, 2, 3, 0).reshape(B, KH * KW * A).contiguous()
+
+
 def begin_forward(owner=None):
     """start of a model forward: fresh zero blocks, and the planes of all of `owner`'s registered weight matrices in two
     launches (owner: the nn.Module whose forward this is; its batch lives on it)"""
-    global _WEIGHT_PLANES
+    global _WEIGHT_PLANES, _WEIGHT_LAYOUTS
     reset_zero_pool()
     if owner is not None:
         batch = owner.__dict__.get("_ud_weight_planes")
         if batch is None:
             batch = owner.__dict__["_ud_weight_planes"] = _WeightPlaneBatch()
         _WEIGHT_PLANES = batch
+        lay = owner.__dict__.get("_ud_weight_layouts")
+        if lay is None:
+            lay = owner.__dict__["_ud_weight_layouts"] = _WeightLayoutBatch()
+        _WEIGHT_LAYOUTS = lay
     _WEIGHT_PLANES.begin()
+    if _WEIGHT_LAYOUT_BATCH:
+        _WEIGHT_LAYOUTS.begin()
 
 
 def end_forward():
     """end of the forward: the batch's planes are not handed out any more (weights may change before the next forward)"""
     _WEIGHT_PLANES.active = False
+    _WEIGHT_LAYOUTS.active = False
 
 
 def weight_planes(w2):
@@ -387,6 +486,7 @@ def p3_ok(M, N, K):
 # Per shape 0-15 % faster than the round-robin deal (tools/probe_p3_raster.py; GM 2..8 alike), never slower; 0: off
 # (A/B: tools/run_with.py unidefense_amd.kernels._P3_RASTER=0 -- python bench.py)
 _P3_RASTER = 0x4200
+_P3_STAT_SLOT_TILES = 64          # row tiles beyond which the epilogue statistics go through 64 slots + a fold launch
 
 
 def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=None, a_row0=0, cfg=0):
@@ -427,7 +527,7 @@ def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=N
     stats_done = False
     if stats is not None and _GEMM_EPILOGUE_STATS and out_mode == 0 and split_k == 1:
         stats_done = True
-        slots = 64 if -(-M // 128) > 64 else 1
+        slots = 64 if -(-M // 128) > _P3_STAT_SLOT_TILES else 1          # (gemm_p3.hip's epilogue applies the same rule)
         tgt = stats if slots == 1 else zeros64(2 * slots * N, Cout)
         d.stat_sum, d.stat_sumsq = tgt.data_ptr(), tgt.data_ptr() + 8 * (slots * N if slots > 1 else N)
         if slots > 1:
@@ -1729,6 +1829,23 @@ def avgpool_bwd(dy, k):
     N, Ho, Wo, Cc = dy.shape
     dx = empty((N, Ho * k, Wo * k, Cc), dy)
     _call("ud_avgpool_bwd", _p(dy), _p(dx), N, Ho, Wo, Cc, k, _stream())
+    return dx
+
+
+def adaptive_avgpool_fwd(x, Ho, Wo):
+    """F.adaptive_avg_pool2d on pixel-major x [N, H, W, C] to (Ho, Wo), any Ho <= H, Wo <= W (ATen's window rule)."""
+    _chk(x)
+    N, H, W, Cc = x.shape
+    y = empty((N, Ho, Wo, Cc), x)
+    _call("ud_adaptive_avgpool_fwd", _p(x), _p(y), N, H, W, Ho, Wo, Cc, _stream())
+    return y
+
+
+def adaptive_avgpool_bwd(dy, H, W):
+    _chk(dy)
+    N, Ho, Wo, Cc = dy.shape
+    dx = empty((N, H, W, Cc), dy)
+    _call("ud_adaptive_avgpool_bwd", _p(dy), _p(dx), N, H, W, Ho, Wo, Cc, _stream())
     return dx
 
 

@@ -38,6 +38,12 @@ class SplitItem(C.Structure):
                 ("split_bx", C.c_int), ("pad_", C.c_int)]
 
 
+class LayoutItem(C.Structure):
+    """ud_layout_item of include/unidefense_hip.h (one conv weight of ud_weight_layouts_multi's device table)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("A", C.c_int), ("B", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
+                ("mode", C.c_int), ("block0", C.c_int)]
+
+
 class GemmP3Desc(C.Structure):
     """ud_gemm_p3_desc: GEMM on pre-split bf16 planes (P32 layout), include/unidefense_hip.h."""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
@@ -70,6 +76,7 @@ _SIGNATURES = {
     "ud_split_planes_h2t": [_P, _L, _I, _L, _P, _L, _L, _P, _P, _P],
     "ud_gemm_set_path": [C.c_int],
     "ud_split_planes_h2t_multi": [_P, C.c_int, _P, C.c_int, C.c_int, _P],
+    "ud_weight_layouts_multi": [_P, C.c_int, C.c_int, _P],
     "ud_fft32_set_wave": [C.c_int],
     "ud_gemm_query_path": [C.POINTER(GemmDesc)],
     "ud_gemm_stats_slots": [C.POINTER(GemmDesc)],
@@ -116,6 +123,8 @@ _SIGNATURES = {
     "ud_dynfilter_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "ud_avgpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ud_avgpool_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ud_adaptive_avgpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ud_adaptive_avgpool_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ud_maxpool3s2_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ud_maxpool3s2_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ud_add_act_fwd": [_P, _P, _I, _P, _L, _P],

@@ -148,17 +148,18 @@ def conv_dense(tape, x, w, stride, pad_t, pad_l, Hout, Wout, need_dx=True):
     N, Hin, Win, Ci = x.shape
     Co, _, KH, KW = w.shape
     g = K.conv_geom(N, Hin, Win, Ci, Hout, Wout, KH, KW, stride, pad_t, pad_l, 0)
-    wmat = w.permute(0, 2, 3, 1).reshape(Co, KH * KW * Ci).contiguous()
+    wmat = K.weight_layout(w, 0)
     y = K.conv_gather_nt(x, wmat, g)
     if _needs(tape):
+        # dX = conv(dY, W flipped & transposed), pad = k-1-pad: its weight matrix comes out of the forward's one-launch batch
+        wd = K.weight_layout(w, 1) if need_dx else None
+
         def bwd():
             dy = tape.pop_grad(y)
             if dy is None:
                 return
             if need_dx:
                 assert stride == 1 and Hout == Hin and Wout == Win, "data gradient implemented for stride 1 'same'"
-                # dX = conv(dY, W flipped & transposed), pad = k-1-pad
-                wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, KH * KW * Co).contiguous()
                 gd = K.conv_geom(N, Hout, Wout, Co, Hin, Win, KH, KW, 1, KH - 1 - pad_t, KW - 1 - pad_l, 0)
                 tape.add_grad(x, K.conv_gather_nt(dy, wd, gd))
             dw = K.conv_gather_wgrad(dy.view(-1, Co), x, g)            # [Co, KH*KW*Ci]
@@ -174,16 +175,17 @@ def conv_transpose_s2(tape, x, w):
     _, Co, KH, KW = w.shape
     Ho, Wo = 2 * H, 2 * W
     g = K.conv_geom(N, H, W, Ci, Ho, Wo, KH, KW, 2, 1, 1, 1)
-    wmat = w.permute(1, 2, 3, 0).reshape(Co, KH * KW * Ci).contiguous()
+    wmat = K.weight_layout(w, 2)
     y = K.conv_gather_nt(x, wmat, g)
     if _needs(tape):
+        wd = K.weight_layout(w, 0)
+
         def bwd():
             dy = tape.pop_grad(y)
             if dy is None:
                 return
             # dX[n,ih,iw,ci] = sum dY[n,2ih-1+kh,2iw-1+kw,co] W[ci,co,kh,kw]: a stride-2 conv over dY
             gd = K.conv_geom(N, Ho, Wo, Co, H, W, KH, KW, 2, 1, 1, 0)
-            wd = w.permute(0, 2, 3, 1).reshape(Ci, KH * KW * Co).contiguous()
             tape.add_grad(x, K.conv_gather_nt(dy, wd, gd))
             dw = K.conv_gather_wgrad(x.view(-1, Ci), dy, gd)           # [Ci, KH*KW*Co]
             tape.add_param_grad(w, dw.view(Ci, KH, KW, Co).permute(0, 3, 1, 2).contiguous())
@@ -339,17 +341,16 @@ def irfft2_split(tape, y, norm):
 
 def adaptive_avgpool(tape, x, Ho, Wo):
     """F.adaptive_avg_pool2d to a size that does not divide the input (exp.py:61-62 on the 95 x 95 map of the 380 x 380 trunk's
-    stride-2 SF block: 95 -> 48, windows of 2 and 3 that overlap) — one block of one resolution, so ATen's kernel on the
-    channels-last view; the 2 x 2 case of the 256 x 256 trunk is fused into ud_sfmix."""
-    xn = x.permute(0, 3, 1, 2)                                   # NCHW view of the pixel-major tensor (channels_last strides)
-    y = torch._adaptive_avg_pool2d(xn, (Ho, Wo)).permute(0, 2, 3, 1).contiguous()
+    stride-2 SF block: 95 -> 48, windows of 2 and 3 that overlap): csrc/pool.hip's adaptive_avgpool kernels (rounds 3-4: ATen's);
+    the 2 x 2 case of the 256 x 256 trunk is fused into ud_sfmix."""
+    H, W = x.shape[1], x.shape[2]
+    y = K.adaptive_avgpool_fwd(x, Ho, Wo)
     if _needs(tape):
         def bwd():
             dy = tape.pop_grad(y)
             if dy is None:
                 return
-            dx = torch.ops.aten._adaptive_avg_pool2d_backward(dy.permute(0, 3, 1, 2), xn)
-            tape.add_grad(x, dx.permute(0, 2, 3, 1).contiguous())
+            tape.add_grad(x, K.adaptive_avgpool_bwd(dy.contiguous(), H, W))
         tape.record(bwd)
     return y
 
@@ -759,16 +760,17 @@ def conv_dense_any(tape, x, w, stride, pad, need_dx=True):
     Hout = (Hin + 2 * pad - KH) // stride + 1
     Wout = (Win + 2 * pad - KW) // stride + 1
     g = K.conv_geom(N, Hin, Win, Ci, Hout, Wout, KH, KW, stride, pad, pad, 0)
-    wmat = w.permute(0, 2, 3, 1).reshape(Co, KH * KW * Ci).contiguous()
+    wmat = K.weight_layout(w, 0)
     y = K.conv_gather_nt(x, wmat, g)
     if _needs(tape):
+        wd = K.weight_layout(w, 2) if need_dx else None
+
         def bwd():
             dy = tape.pop_grad(y)
             if dy is None:
                 return
             if need_dx:
                 gd = K.conv_geom(N, Hout, Wout, Co, Hin, Win, KH, KW, stride, pad, pad, 1)
-                wd = w.permute(1, 2, 3, 0).reshape(Ci, KH * KW * Co).contiguous()
                 tape.add_grad(x, K.conv_gather_nt(dy, wd, gd))
             dw = K.conv_gather_wgrad(dy.view(-1, Co), x, g)
             tape.add_param_grad(w, dw.view(Co, KH, KW, Ci).permute(0, 3, 1, 2).contiguous())
