@@ -478,10 +478,11 @@ int ud_se_scale_bwd_bn(const void* dc, const void* x, const ud_bn_ref* bn, const
     stream);
 /* ud_normbwd_apply (dy_is_dz) fused with the gradient of the SF mix y = (1-a) spat + a freq (exp.py:61-65):
  * writes dd = dL/dy and accumulates sum dd * diff, diff = freq - spat as stored by ud_irfft2_mix, into the 64 slots
- * dalpha_acc[0..64) (zeroed by the caller) */
+ * dalpha_acc[0..64) (zeroed by the caller); energy (optional, C doubles zeroed by the caller): += sum_rows dd_c^2, rounded up —
+ * the per-channel energy bound ud_rfft2_ex_planes takes for the transform of dd that follows */
 int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
     const double* s1_local, const double* s2_local, const void* diff, int G, int R, int C, void* dd,
-    double* dalpha_acc, float* dgamma, float* dbeta, int f16, ud_stream_t stream);
+    double* dalpha_acc, float* dgamma, float* dbeta, double* energy, int f16, ud_stream_t stream);
 /* out[0] = sigmoid'(alpha[0]) * sum(acc[0..64))      (sf_coef gradient from the accumulator above) */
 int ud_gate_grad_from_acc(const double* acc, const float* alpha, float* out, ud_stream_t stream);
 /* y = act(bn(x)): the materialised form for consumers that re-read their input per tap (a plain depthwise conv and its
@@ -508,6 +509,17 @@ int ud_dwconv_bwd_weight_ex(const void* x, const void* dy, const float* gate_alp
 int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
     void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad, int f16,
     uint32_t* absmax, ud_stream_t stream);
+/* ud_rfft2_ex whose result goes DIRECTLY into the fp16 x 2 planes ud_gemm_p3 (prec 2) reads — P32 panel layout over the matrix
+ * [N S (S/2+1)] x [Re 0..C | Im 0..C], one power-of-two scale for the tensor — instead of fp32 + ud_split_planes_h2t (the
+ * spectral 1x1 conv's operand, model/efficientnet/exp.py:55-57, and its output gradient in the backward).  The scale is taken
+ * from an a-priori UPPER BOUND of |Y|: bound_pre * sqrt(max_c e_c) with e_c = gamma_c^2 + beta_c^2 (bn given: the input is
+ * act(bn(x)), |act(z)| <= |z|; bound_pre = f_max S sqrt(count)) or e_c = energy[c] >= sum_{n,h,w} x_c^2 (bound_pre = f_max S);
+ * a bound 2^b above the true maximum moves the 2^-18 window of full 22-bit precision up by b binades and changes nothing for
+ * the large elements.  S in {8, 16, 32, 12, 24, 48}, (2 C) % 32 == 0, fp32 storage; *inv_scale receives 1 / scale. */
+int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long plane_stride, float* inv_scale, float bound_pre,
+                       const double* energy, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
+                       void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
+                       ud_stream_t stream);
 /* irfft2 + SF mix + BN1 statistics (exp.py:60-65, stride 1):  freq = irfft2(Y) * scale;
  * y = (1 - a) spat + a freq, a = sigmoid(alpha[0]);  diff_out = freq - spat (what the backward needs of the two
  * branches: neither has to be kept);  sum[c] += sum y, sumsq[c] += sum y^2 */

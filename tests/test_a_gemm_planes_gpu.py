@@ -10,6 +10,8 @@ weight gradient).
   2^-21 of the scale's maximum), the scale must put the maximum into [2^14, 2^15).
 * stream-K, split-K (atomics and ordered slices), tail plan, row offsets, epilogue statistics.
 """
+import math
+
 import pytest
 import torch
 
@@ -312,3 +314,74 @@ def test_weight_plane_batch_survives_dead_and_moved_parameters():
         assert len(batch.entries) == 0
     finally:
         K._WEIGHT_PLANES = saved
+
+
+@pytest.mark.parametrize("N,S,C", [(2, 8, 64), (3, 16, 48), (2, 32, 16), (32, 8, 1632), (2, 12, 32)])
+def test_rfft2_writes_the_gemm_planes_itself(N, S, C):
+    """csrc/fft.hip PlanesOut (round 5): ud_rfft2_ex_planes writes rfft2(act(bn(x))) straight into the fp16 x 2 planes of the
+    spectral GEMM, scaled by a power of two taken from an a-priori BOUND of |Y| (count (gamma^2 + beta^2) per channel) instead of the
+    exact maximum a pass over the result would give.  Checked: (1) the planes re-assemble to ud_rfft2_ex's fp32 result — every
+    element to 2^-21 of the tensor's maximum times the bound's looseness, the LARGE elements (within 2^-10 of the maximum) to 22 bits
+    of their own value; (2) nothing overflows: the scaled maximum stays below 2^15; (3) the bound is within 2^7 of the true maximum
+    on these inputs (N <= 32: ~2 sqrt(N) expected); (4) the GEMM on these planes agrees with the GEMM on the split of the fp32
+    result to 1e-6 of its scale; (5) the activated input written on the side is the one ud_rfft2_ex writes."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(S * 1000 + C + N)
+    x = torch.randn(N, S, S, C, generator=g).to(dev)
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.2 * torch.randn(C, generator=g)).to(dev)
+    M = N * S * S
+    acc = K.zeros64(2 * C, x)
+    K.colstats(x.view(M, C), acc)
+    bn = K.DeferredBN(acc, C, M, gamma, beta, 1e-3, 1)
+    sf = 1.0 / S
+    Y, a_ref = K.rfft2_ex(x, sf, 1.0, bn=bn, want_act=True)
+    pl, a = K.rfft2_ex_planes(x, sf, 1.0, bn=bn, want_act=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a_ref)
+    R = N * S * (S // 2 + 1)
+    assert pl.R == R and pl.C == 2 * C
+    h = pl.buf.view(2, pl.npanel, pl.panel // 32, 32)[:, :, :R].view(torch.float16).permute(0, 2, 1, 3).reshape(2, R, 2 * C).double()
+    inv = float(pl.inv)
+    back = (h[0] + h[1] / 2048.0) * inv
+    Yd = Y.view(R, 2 * C).double()
+    top = float(Yd.abs().max())
+    scaled_max = top / inv
+    loose = 2.0 ** 15 / scaled_max          # how far above the exact maximum the bound sits (>= 1)
+    assert math.log2(1.0 / inv) == round(math.log2(1.0 / inv)) and scaled_max < 2.0 ** 15
+    assert 1.0 <= loose < 2.0 ** 7, loose
+    err = (back - Yd).abs()
+    assert float(err.max()) <= 2.0 ** -21 * top * loose
+    big = Yd.abs() >= top * 2.0 ** -10
+    assert float((err[big] / Yd.abs()[big]).max()) < 2.0 ** -21
+    # the product: planes from the transform vs planes split from the fp32 result, the same weights
+    w = (torch.randn(2 * C, 2 * C, generator=g) / math.sqrt(2 * C)).to(dev)
+    wp = K.split_planes(w, prec=2)
+    ref = Yd @ w.double().t()
+    got = K._gemm_p3(pl, wp, torch.empty(R, 2 * C, device=dev), R, 2 * C, -(-2 * C // 32) * 32, 0, 0)
+    got2 = K._gemm_p3(K.split_planes(Y.view(R, 2 * C), prec=2), wp, torch.empty(R, 2 * C, device=dev), R, 2 * C, -(-2 * C // 32) * 32, 0, 0)
+    scale = float(ref.abs().max())
+    e1, e2 = float((got.double() - ref).abs().max()) / scale, float((got2.double() - ref).abs().max()) / scale
+    print(f"  bound / max = 2^{math.log2(loose):.1f};  GEMM error / scale: planes from the transform {e1:.2e}, from the split {e2:.2e}")
+    assert e1 < 1e-6 and e1 < 4 * e2 + 1e-7
+    # ---- the backward's use: no BatchNorm in front, a per-channel ENERGY bound handed in (what ud_normbwd_apply_mix sums), the
+    # gate factor sigmoid(alpha) applied to the result and to the bound, interior columns doubled
+    dd = torch.randn(N, S, S, C, generator=g).to(dev) * torch.exp(torch.randn(C, generator=g)).to(dev)
+    alpha = torch.tensor([-3.0], device=dev)
+    en = (dd.double() ** 2).sum((0, 1, 2)) * 1.0001
+    Y2, _ = K.rfft2_ex(dd, sf, 2.0, gate_alpha=alpha, gate_mode=1)
+    pl2, _ = K.rfft2_ex_planes(dd, sf, 2.0, gate_alpha=alpha, gate_mode=1, energy=en.contiguous())
+    torch.cuda.synchronize()
+    h2 = pl2.buf.view(2, pl2.npanel, pl2.panel // 32, 32)[:, :, :R].view(torch.float16).permute(0, 2, 1, 3).reshape(2, R, 2 * C).double()
+    inv2 = float(pl2.inv)
+    Y2d = Y2.view(R, 2 * C).double()
+    top2 = float(Y2d.abs().max())
+    loose2 = 2.0 ** 15 / (top2 / inv2)
+    err2 = ((h2[0] + h2[1] / 2048.0) * inv2 - Y2d).abs()
+    assert 1.0 <= loose2 < 2.0 ** 8, loose2
+    assert float(err2.max()) <= 2.0 ** -21 * top2 * loose2
+    big2 = Y2d.abs() >= top2 * 2.0 ** -10
+    assert float((err2[big2] / Y2d.abs()[big2]).max()) < 2.0 ** -21
+

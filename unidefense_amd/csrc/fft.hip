@@ -233,14 +233,44 @@ struct Lds {
 // f(kx) = scale for kx in {0, S/2}, scale * w_int otherwise.
 // EX: the input is act(bn(x)) of a deferred BatchNorm (coefficients from the fp64 sums, one channel per thread),
 // optionally also written out (act_out), and the result carries the gate factor (include/unidefense_hip.h).
+// Round 5: the result written DIRECTLY as the fp16 x 2 planes the spectral GEMM reads (ud_gemm_p3 prec 2, P32 panel layout over the
+// matrix [N S (S/2+1)] x [Re 0..C | Im 0..C]) instead of fp32 + a split pass (ud_split_planes_h2t: one more read and write of the
+// tensor, 48 launches per step).  The planes' power-of-two scale needs the tensor's |Y|max BEFORE the first element is written;
+// an UPPER BOUND serves as well — it costs log2(bound / max) of the 18 binades in which an element keeps its full 22 bits, nothing
+// of the precision of the large elements — and one is known a priori: |Y[k]| <= f_max S sqrt(sum_hw a^2) (Cauchy-Schwarz), and
+// the energy of ONE plane is at most the channel's over the whole batch:
+//   input a = act(bn(x)), |act(z)| <= |z|:   sum a_c^2 <= count (gamma_c^2 + beta_c^2)              (energy == NULL)
+//   any input with a per-channel energy bound handed in:   sum a_c^2 <= energy[c]                  (energy != NULL)
+// -> bound = pre * sqrt(max_c ...), pre = f_max * S [* sqrt(count)] from the host.  Every workgroup derives the same bound from
+// the same numbers (a scan of C values), so all write with one scale; block (0, 0) stores 1 / scale.
+struct PlanesOut {
+    uint16_t* buf;          // NULL: fp32 result in Y
+    long panel, plane;      // strides of the P32 layout (16-bit elements)
+    float* inv_scale;
+    float pre;
+    const double* energy;
+};
+
 template <typename T, int S, int CB, bool EX>
 __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* __restrict__ Y, int C,
                                                    float scale, float w_int, ud_bn_ref bn, int has_bn,
                                                    T* __restrict__ act_out, const float* __restrict__ gate_alpha,
                                                    int gate_mode, const double* __restrict__ gate_acc,
                                                    float* __restrict__ gate_grad, int xcd_remap,
-                                                   uint32_t* __restrict__ amax) {
+                                                   uint32_t* __restrict__ amax, PlanesOut po) {
     using L = Lds<S, CB>;
+    __shared__ float po_red[NT / 64];
+    if (EX && po.buf) {
+        // max over ALL channels of the per-channel energy bound: this thread's share, folded per wave; the workgroup's fold
+        // happens behind the barrier between the two passes
+        float gm = 0.f;
+        for (int i = threadIdx.x; i < C; i += NT) {
+            if (po.energy) gm = fmaxf(gm, (float)po.energy[i]);
+            else gm = fmaxf(gm, bn.gamma[i] * bn.gamma[i] + bn.beta[i] * bn.beta[i]);
+        }
+        gm = ud_wave_max(gm);
+        if ((threadIdx.x & 63) == 0) po_red[threadIdx.x >> 6] = gm;
+    }
     // EX, backward of the SF mix: the 64 slots a preceding kernel (ud_normbwd_apply_mix) filled with
     // sum dd * (freq - spat) become the gate's gradient here, by one wave, instead of a launch of their own
     if (EX && gate_grad && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
@@ -310,16 +340,43 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
         }
         fft_inreg<S, false>(re, im);
         float f = (q == 0 || q == S / 2) ? scale : scale * w_int;
+        float gf = 1.f;
         if (EX && gate_mode != 0) {
             const float a = ud_sigmoid(gate_alpha[0]);
-            f *= (gate_mode == 1) ? a : 1.f - a;
+            gf = (gate_mode == 1) ? a : 1.f - a;
+            f *= gf;
         }
-        T* dst = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
+        if (EX && po.buf) {
+            float gm = po_red[0];
 #pragma unroll
-        for (int ky = 0; ky < S; ++ky) {
-            dst[(long)ky * L::WH * 2 * C] = (T)(re[ky] * f);
-            dst[(long)ky * L::WH * 2 * C + C] = (T)(im[ky] * f);
-            if (EX) mabs = fmaxf(mabs, fmaxf(fabsf(re[ky] * f), fabsf(im[ky] * f)));
+            for (int i = 1; i < NT / 64; ++i) gm = fmaxf(gm, po_red[i]);
+            float ps, pinv;
+            ud_h2_scale(__float_as_uint(po.pre * gf * sqrtf(gm) * 1.002f), ps, pinv);      // (the 0.2 %: fp32 rounding of the transform)
+            if (blockIdx.x == 0 && blockIdx.y == 0 && q == 0 && c == 0) *po.inv_scale = pinv;
+            f *= ps;
+            const long row0 = ((long)n * S) * L::WH + q;
+            const int cim = C + ch;
+            uint16_t* pre_ = po.buf + (long)(ch >> 5) * po.panel + row0 * 32 + (ch & 31);
+            uint16_t* pim_ = po.buf + (long)(cim >> 5) * po.panel + row0 * 32 + (cim & 31);
+#pragma unroll
+            for (int ky = 0; ky < S; ++ky) {
+                uint16_t a0, a1, b0, b1;
+                ud_split_h2(re[ky] * f, a0, a1);
+                ud_split_h2(im[ky] * f, b0, b1);
+                const long o = (long)ky * L::WH * 32;
+                pre_[o] = a0;
+                pre_[o + po.plane] = a1;
+                pim_[o] = b0;
+                pim_[o + po.plane] = b1;
+            }
+        } else {
+            T* dst = Y + (((long)n * S) * L::WH + q) * (2L * C) + ch;
+#pragma unroll
+            for (int ky = 0; ky < S; ++ky) {
+                dst[(long)ky * L::WH * 2 * C] = (T)(re[ky] * f);
+                dst[(long)ky * L::WH * 2 * C + C] = (T)(im[ky] * f);
+                if (EX) mabs = fmaxf(mabs, fmaxf(fabsf(re[ky] * f), fabsf(im[ky] * f)));
+            }
         }
     }
     if (EX) ud_absmax_commit(mabs, amax);
@@ -456,6 +513,7 @@ struct RfftEx {
     const double* gate_acc;
     float* gate_grad;
     uint32_t* absmax;          // 256 slots: |Y|max as a side output (ud_absmax_commit), or NULL
+    PlanesOut planes = PlanesOut{nullptr, 0, 0, nullptr, 0.f, nullptr};
 };
 
 template <typename T, int S, int CB, bool EX>
@@ -472,7 +530,7 @@ int launch_rfft2_t(const T* x, T* Y, int N, int C, float scale, float w_int, con
     ud_bn_ref none{};
     hipLaunchKernelGGL((rfft2_kernel<T, S, CB, EX>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
                        ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, (T*)ex.act_out, ex.gate_alpha, ex.gate_mode, ex.gate_acc,
-                       ex.gate_grad, xcd_remap_on(CB * (int)sizeof(T)), ex.absmax);
+                       ex.gate_grad, xcd_remap_on(CB * (int)sizeof(T)), ex.absmax, ex.planes);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -480,7 +538,7 @@ int launch_rfft2_t(const T* x, T* Y, int N, int C, float scale, float w_int, con
 template <typename T, int S, int CB>
 int launch_rfft2(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
     if (ex) return launch_rfft2_t<T, S, CB, true>(x, Y, N, C, scale, w_int, *ex, s);
-    return launch_rfft2_t<T, S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr}, s);
+    return launch_rfft2_t<T, S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, PlanesOut{nullptr, 0, 0, nullptr, 0.f, nullptr}}, s);
 }
 
 struct IrfftMix {
@@ -1022,7 +1080,7 @@ int launch_rfft2_wave_t(const T* x, T* Y, int N, int C, float scale, float w_int
 template <typename T>
 int launch_rfft2_wave(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
     if (ex) return launch_rfft2_wave_t<T, true>(x, Y, N, C, scale, w_int, *ex, s);
-    return launch_rfft2_wave_t<T, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr}, s);
+    return launch_rfft2_wave_t<T, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, PlanesOut{nullptr, 0, 0, nullptr, 0.f, nullptr}}, s);
 }
 template <typename T, bool MIX>
 int launch_irfft2_wave_t(const T* Y, T* x, int N, int C, float scale, float w_int, const IrfftMix& m, hipStream_t s) {
@@ -1062,7 +1120,7 @@ int rfft2_dispatch(const T* x, T* Y, int N, int S, int C, float scale, float w_i
         case 8: return launch_rfft2<T, 8, 64>(x, Y, N, C, scale, w_interior, ex, s);
         case 16: return launch_rfft2<T, 16, 32>(x, Y, N, C, scale, w_interior, ex, s);
         case 32:
-            if (fft32_wave_on(N, C)) return launch_rfft2_wave<T>(x, Y, N, C, scale, w_interior, ex, s);
+            if (fft32_wave_on(N, C) && !(ex && ex->planes.buf)) return launch_rfft2_wave<T>(x, Y, N, C, scale, w_interior, ex, s);
             return launch_rfft2<T, 32, 16>(x, Y, N, C, scale, w_interior, ex, s);
         case 64: return launch_rfft2<T, 64, 8>(x, Y, N, C, scale, w_interior, ex, s);
         case 12: return launch_rfft2<T, 12, 42>(x, Y, N, C, scale, w_interior, ex, s);          // 3 * 2^k: both storage types (the 380 x 380 trunk)
@@ -1145,6 +1203,25 @@ int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float 
     RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad, absmax};
     UD_STORAGE_DISPATCH(f16, return rfft2_dispatch<T>((const T*)x, (T*)Y, N, S, C, scale, w_interior, &ex,
                                                       (hipStream_t)stream));
+}
+
+int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long plane_stride, float* inv_scale, float bound_pre,
+                       const double* energy, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
+                       void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
+                       ud_stream_t stream) {
+    if (N < 1 || C < 4 || (2 * C) % 32 || !x || !planes || !inv_scale || !(bound_pre > 0.f)) return UD_EINVAL;
+    if (S != 8 && S != 16 && S != 32 && S != 12 && S != 24 && S != 48) return UD_EINVAL;          // the one-kernel forms
+    if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
+    if (bn && bn->G != 1) return UD_EINVAL;
+    if (!bn && !energy) return UD_EINVAL;          // a bound needs one of the two
+    if (act_out && !bn) return UD_EINVAL;
+    if (gate_grad && (!gate_acc || !gate_alpha)) return UD_EINVAL;
+    const long rows = (long)N * S * (S / 2 + 1);
+    if (panel_stride < rows * 32 || panel_stride % 8 || plane_stride % 8 || plane_stride < (long)(2 * C / 32) * panel_stride)
+        return UD_EINVAL;
+    RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad, nullptr,
+              PlanesOut{planes, panel_stride, plane_stride, inv_scale, bound_pre, energy}};
+    return rfft2_dispatch<float>((const float*)x, (float*)nullptr, N, S, C, scale, w_interior, &ex, (hipStream_t)stream);
 }
 
 int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, float w_interior, const void* spat,

@@ -256,13 +256,14 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
                                                            const T* __restrict__ freq,
                                                            T* __restrict__ dx, double* __restrict__ dalpha_acc,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           uint32_t* __restrict__ amax) {
+                                                           uint32_t* __restrict__ amax, double* __restrict__ energy) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
     const In4<T> x4{x}, d4{dy}, fr4{freq};
     const Out4<T> o4{dx};
     double acc = 0.0;
     float mo = 0.f;
+    f32x4 en = {0.f, 0.f, 0.f, 0.f};          // MIX, energy != NULL: sum of dx^2 per channel over this thread's rows
     if (active) {
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
         const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
@@ -292,7 +293,18 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
                 f32x4 f = fr4[w.idx];                    // freq - spat (ud_irfft2_mix)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc += (double)ud_rounded<T>(o[e]) * (double)f[e];
+                en += o * o;
             }
+        }
+    }
+    if (MIX && energy) {
+        // per-channel energy of the result (the a-priori bound of the transform that follows: ud_rfft2_ex_planes); rounded UP a
+        // little so that the fp32 partial sums never under-estimate
+        double v[8] = {(double)en[0] * 1.0001, (double)en[1] * 1.0001, (double)en[2] * 1.0001, (double)en[3] * 1.0001, 0, 0, 0, 0};
+        block_fold<4>(q, ri, active, v);
+        if (active && ri == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomic_add_f64(energy + (long)c4 * 4 + e, v[e]);
         }
     }
     if (MIX) {
@@ -839,14 +851,15 @@ int ud_normbwd_apply(const void* x, const void* dy, const float* keep, float inv
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, false>), red_grid(q), dim3(NT), 0,
                                                 (hipStream_t)stream, q, (const T*)x, (const T*)dy, keep, inv_keep, *bn,
                                                 dy_is_dz, s1, s2, s1_local, s2_local, (const T*)nullptr, (T*)dx,
-                                                (double*)nullptr, dgamma, dbeta, absmax));
+                                                (double*)nullptr, dgamma, dbeta, absmax, (double*)nullptr));
     UD_LAUNCH_CHECK();
     return 0;
 }
 
 int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
                          const double* s1_local, const double* s2_local, const void* diff, int G, int R, int C,
-                         void* dd, double* dalpha_acc, float* dgamma, float* dbeta, int f16, ud_stream_t stream) {
+                         void* dd, double* dalpha_acc, float* dgamma, float* dbeta, double* energy, int f16,
+                         ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !dz || !bn || !s1 || !s2 || !dd || !diff || !dalpha_acc || bn->G != 1)
         return UD_EINVAL;
     if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
@@ -854,7 +867,7 @@ int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, con
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, true>), red_grid(q), dim3(NT), 0,
                                                 (hipStream_t)stream, q, (const T*)x, (const T*)dz, (const float*)nullptr,
                                                 1.f, *bn, 1, s1, s2, s1_local, s2_local, (const T*)diff, (T*)dd,
-                                                dalpha_acc, dgamma, dbeta, (uint32_t*)nullptr));
+                                                dalpha_acc, dgamma, dbeta, (uint32_t*)nullptr, energy));
     UD_LAUNCH_CHECK();
     return 0;
 }

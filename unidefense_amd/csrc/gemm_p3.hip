@@ -643,13 +643,7 @@ __global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ 
 
 // scale of a tensor whose |x|max has the bit pattern `bits`: the power of two taking it into [2^14, 2^15) (exponent field
 // 268 - e, kept inside the normal range; all zeros: 1); inv = 1 / scale.  NaN / inf maxima end up as NaN / inf pieces.
-__device__ __forceinline__ void h2_scale(uint32_t bits, float& s, float& inv) {
-    const int e = (int)(bits >> 23) & 0xff;
-    int fs = bits ? 268 - e : 127;
-    fs = fs < 1 ? 1 : fs > 254 ? 254 : fs;
-    s = __uint_as_float((uint32_t)fs << 23);
-    inv = __uint_as_float((uint32_t)(254 - fs) << 23);
-}
+__device__ __forceinline__ void h2_scale(uint32_t bits, float& s, float& inv) { ud_h2_scale(bits, s, inv); }
 
 // fp32 [R][C] -> two fp16 planes of s * x with ONE scale for the tensor (any GEMM mode may read them); thread = 8 columns of a row
 __global__ __launch_bounds__(256) void split_h2_tensor_kernel(const float* __restrict__ x, long R, int C, long ld,

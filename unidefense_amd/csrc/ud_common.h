@@ -125,3 +125,21 @@ __device__ __forceinline__ void ud_absmax_commit(float m, uint32_t* __restrict__
     if (threadIdx.x == 0 && threadIdx.y == 0 && ud_sm_absmax)
         atomicMax(slots + ((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & 255u), ud_sm_absmax);
 }
+
+// ---- fp16 x 2 planes of ud_gemm_p3 prec 2 (csrc/gemm_p3.hip), for producers that write their result as planes themselves ----
+// scale of a tensor whose |x|max (or an UPPER BOUND of it) has the bit pattern `bits`: the power of two taking it into
+// [2^14, 2^15) (exponent field 268 - e, kept inside the normal range; all zeros: 1); inv = 1 / scale.
+__device__ __forceinline__ void ud_h2_scale(uint32_t bits, float& s, float& inv) {
+    const int e = (int)(bits >> 23) & 0xff;
+    int fs = bits ? 268 - e : 127;
+    fs = fs < 1 ? 1 : fs > 254 ? 254 : fs;
+    s = __uint_as_float((uint32_t)fs << 23);
+    inv = __uint_as_float((uint32_t)(254 - fs) << 23);
+}
+// the two pieces of the SCALED value xs: h0 = fp16(xs), h1 = fp16(2^11 (xs - h0))  (exact residual; gemm_p3.hip: split2h)
+__device__ __forceinline__ void ud_split_h2(float xs, uint16_t& h0, uint16_t& h1) {
+    const _Float16 a = (_Float16)xs;
+    const _Float16 b = (_Float16)((xs - (float)a) * 2048.f);
+    h0 = __builtin_bit_cast(uint16_t, a);
+    h1 = __builtin_bit_cast(uint16_t, b);
+}

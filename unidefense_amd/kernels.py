@@ -915,15 +915,22 @@ def _p2_block_plans(x2, w2, want_stats=False):
     """None (in-kernel split) or {"nt": plan, "nn": plan, "tn": plan} for a 1x1 conv of this shape.  want_stats: the forward
     launch is to fill BatchNorm statistics in its epilogue (a plain launch does; other plans are charged a ud_colstats pass)"""
     M, Kd = x2.shape
-    N = w2.shape[0]
+    if x2.dtype != torch.float32:
+        return None
+    return _p2_plans_for(M, w2.shape[0], Kd, want_stats, w2, x2)
+
+
+def _p2_plans_for(M, N, Kd, want_stats, w2, x2, tune=True):
+    """x2: the fp32 operand the on-line tuner may measure with (None: a producer-made Planes operand / a query — an unknown shape
+    then takes the untuned rule)"""
     mode = CFG.spectral_p2
-    if (mode == "off" or x2.dtype != torch.float32 or w2.dtype != torch.float32 or not _p2_shape_ok(M, N, Kd) or
+    if (mode == "off" or w2.dtype != torch.float32 or not _p2_shape_ok(M, N, Kd) or
             _call("ud_gemm_get_path") not in (0, 2)):
         return None
     key = ("p2c", M, N, Kd, bool(CFG.deterministic), mode == "on", bool(want_stats))
     plans = _TUNED.get(key, "?")
     if plans == "?":
-        if CFG.gemm_tune and not torch.cuda.is_current_stream_capturing():
+        if tune and x2 is not None and CFG.gemm_tune and not torch.cuda.is_current_stream_capturing():
             plans = _p2_tune(key, x2, w2, M, N, Kd, mode == "on", want_stats)
         elif mode == "on" or (M >= _P2_MIN[0] and min(N, Kd) >= _P2_MIN[1]):
             plans = [("plain",) if want_stats else _p2_default_plan("nt", M, N, Kd), _p2_default_plan("nn", M, Kd, N),
@@ -937,17 +944,30 @@ def _p2_block_plans(x2, w2, want_stats=False):
 
 def spectral_fwd(x2, w2, stats=None, x_absmax=None):
     """y[M, N] = x[M, K] @ w[N, K]^T (a 1x1 conv; the spectral convs are the square case) and the context of its backward.
-    stats: BatchNorm accumulator of the result (gemm_nt's contract: returns ((y, done), ctx))"""
+    stats: BatchNorm accumulator of the result (gemm_nt's contract: returns ((y, done), ctx)).
+    x2: the fp32 matrix, or Planes its producer wrote itself (only for shapes spectral_takes_planes accepts)."""
     ctx = SpectralCtx()
-    ctx.M, ctx.K = x2.shape
     ctx.N = w2.shape[0]
-    ctx.plans = _p2_block_plans(x2, w2, stats is not None)
     ctx.dy = None
+    if isinstance(x2, Planes):
+        ctx.M, ctx.K = x2.R, x2.C
+        ctx.plans = _p2_plans_for(ctx.M, ctx.N, ctx.K, stats is not None, w2, None)
+        assert ctx.plans is not None
+        ctx.x, ctx.w = x2, weight_planes(w2)
+        return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, w2, stats=stats), ctx
+    ctx.M, ctx.K = x2.shape
+    ctx.plans = _p2_block_plans(x2, w2, stats is not None)
     if ctx.plans is None:
         ctx.x, ctx.w = x2, w2
         return gemm_nt(x2, w2, stats=stats), ctx
     ctx.x, ctx.w = split_planes(x2, prec=2, absmax=x_absmax), weight_planes(w2)
     return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, x2, stats=stats), ctx
+
+
+def spectral_takes_planes(M, N, Kd, w2, want_stats=False):
+    """does the 1x1 conv [M, Kd] x [N, Kd]^T run on the planes GEMM with the plans known NOW (shipped / cached / heuristic — no
+    tuning launch: a producer asks before it decides how to write its result)?"""
+    return _p2_plans_for(M, N, Kd, want_stats, w2, None, tune=False) is not None
 
 
 def _spectral_dy(ctx, dy2, absmax=None):
@@ -2122,8 +2142,8 @@ def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=No
     return dx, dg, db
 
 
-def normbwd_apply_mix(x, dz, bn, G, R, sacc, diff, dalpha_acc, sacc_local=None):
-    """diff = freq - spat (irfft2_mix)."""
+def normbwd_apply_mix(x, dz, bn, G, R, sacc, diff, dalpha_acc, sacc_local=None, energy=None):
+    """diff = freq - spat (irfft2_mix).  energy: C zeroed doubles that receive sum_rows dd^2 per channel (rfft2_ex_planes' bound)."""
     h = _act(x, dz, diff)
     Cc = x.shape[-1]
     loc = sacc if sacc_local is None else sacc_local
@@ -2131,7 +2151,7 @@ def normbwd_apply_mix(x, dz, bn, G, R, sacc, diff, dalpha_acc, sacc_local=None):
     dg = empty((Cc,), x)
     db = empty((Cc,), x)
     _call("ud_normbwd_apply_mix", _p(x), _p(dz), C.byref(bn.ref()), _pd(sacc), _pd(sacc, Cc), _pd(loc), _pd(loc, Cc),
-          _p(diff), G, R, Cc, _p(dd), _pd(dalpha_acc), _p(dg), _p(db), h, _stream())
+          _p(diff), G, R, Cc, _p(dd), _pd(dalpha_acc), _p(dg), _p(db), _pd(energy) if energy is not None else None, h, _stream())
     return dd, dg, db
 
 
@@ -2224,6 +2244,40 @@ def rfft2_ex(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None,
     else:
         _call("ud_rfft2_ex", _p(x), _p(Y), N, S, Cc, float(scale), float(w_interior), *tail)
     return (Y, act, ggrad) if gate_acc is not None else (Y, act)
+
+
+_RFFT_PLANES = True          # A/B: tools/run_with.py kernels._RFFT_PLANES=False
+
+
+def rfft2_planes_ok(x, bn, stride_ok=True):
+    """can ud_rfft2_ex_planes write this transform's result as the spectral GEMM's planes?  (fp32 storage, the one-kernel
+    transform sizes, whole 32-column panels, and a conv shape the planes GEMM takes at all: spectral_takes_planes)"""
+    if not (_RFFT_PLANES and x.dtype == torch.float32 and CFG.spectral_p2 != "off"):
+        return False
+    N, S, _, Cc = x.shape
+    return S in (8, 16, 32, 12, 24, 48) and (2 * Cc) % 32 == 0 and not _fft_two_pass("rfft_ex", S, 0)
+
+
+def rfft2_ex_planes(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None, gate_mode=0, update=False,
+                    gate_acc=None, energy=None):
+    """rfft2_ex whose result is written straight into fp16 x 2 planes (P32 layout over [N S (S/2+1)] x 2C, prec 2) with the scale
+    of an a-priori BOUND of |Y| (csrc/fft.hip: PlanesOut) instead of fp32 + ud_split_planes_h2t.  bn given: the bound comes from
+    count (gamma^2 + beta^2); else energy [C] fp64: a per-channel upper bound of sum_{n,h,w} x^2 (the kernel multiplies the bound by
+    the gate factor it applies to the result).  Returns (Planes, activated input or None[, gate gradient])."""
+    _chk(x)
+    N, S, S2, Cc = x.shape
+    assert S == S2 and (bn is not None or energy is not None)
+    R = N * S * (S // 2 + 1)
+    pl = Planes(R, 2 * Cc, x, 2, False)
+    act = torch.empty_like(x) if (want_act and bn is not None) else None
+    ggrad = empty((), x) if gate_acc is not None else None
+    pre = float(scale) * max(1.0, float(w_interior)) * S
+    if energy is None:
+        pre *= math.sqrt(float(bn.count))
+    _call("ud_rfft2_ex_planes", _p(x), _p(pl.buf), pl.panel, pl.plane, _p(pl.inv), pre, _pd(energy) if energy is not None else None,
+          N, S, Cc, float(scale), float(w_interior), C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha),
+          int(gate_mode), _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), _stream())
+    return (pl, act, ggrad) if gate_acc is not None else (pl, act)
 
 
 def irfft2_mix(Y, scale, spat, alpha, acc):

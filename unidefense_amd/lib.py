@@ -153,7 +153,7 @@ _SIGNATURES = {
     "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P],
     "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P],
-    "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "ud_gate_grad_from_acc": [_P, _P, _P, _P],
     "ud_se_bwd_a": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "ud_se_bwd_b": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P],
@@ -164,6 +164,7 @@ _SIGNATURES = {
     "ud_dwconv_bwd_data_ex": [_P, _P, _I, _P, _P, _P] + [_I] * 10 + [_I, _P],
     "ud_dwconv_bwd_weight_ex": [_P, _P, _P, _I, _P, _P, _I] + [_I] * 10 + [_I, _P],
     "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P, _P],
+    "ud_rfft2_ex_planes": [_P, _P, _L, _L, _P, _F, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _P],
     "ud_irfft2_mix": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "ud_rfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P, _P],
     "ud_irfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],

@@ -988,19 +988,28 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         alpha = dwm.sf_coef
         t_fwd, t_wg, t_bwd = _dw_tile_policy(True, k, stride, H, x.dtype == torch.float16)
         t_fused = _dw_bwd_fused_policy(True, k, stride, H, x.dtype == torch.float16)
+        Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
         if src_bn is not None:
             # a strip kernel needs a = swish(bn0(e)) materialised (rfft2_ex writes it); the tiled ones apply it on load
-            xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=not (t_fwd and (t_wg or t_fused)), update=True, want_absmax=True)
+            want_a = not (t_fwd and (t_wg or t_fused))
+            if K.rfft2_planes_ok(src, src_bn) and K.spectral_takes_planes(N * S * (S // 2 + 1), 2 * Ce, 2 * Ce, Wf):
+                # the transform writes the spectral GEMM's fp16 x 2 planes itself (scale from an a-priori bound): no split pass
+                xf, a = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
+            else:
+                xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True, want_absmax=True)
         else:
             xf, a = K.rfft2(src, s_f, 1.0, want_absmax=True), src
         if t_fwd:
             spat = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn, stride=stride)
         else:
             spat = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
-        Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
-        yf, sctx = K.spectral_fwd(xf.view(-1, 2 * Ce), Wf, x_absmax=getattr(xf, "_ud_absmax", None))
-        yf = yf.view(xf.shape)
-        xf_shape, xf = xf.shape, None          # the context holds what the backward needs of it
+        xf_shape = (N, S, S // 2 + 1, 2 * Ce)
+        if isinstance(xf, K.Planes):
+            yf, sctx = K.spectral_fwd(xf, Wf)
+        else:
+            yf, sctx = K.spectral_fwd(xf.view(-1, 2 * Ce), Wf, x_absmax=getattr(xf, "_ud_absmax", None))
+        yf = yf.view(xf_shape)
+        xf = None          # the context holds what the backward needs of it
         if stride == 1:
             d, fr = K.irfft2_mix(yf, s_i, spat, alpha, acc1)          # fr: freq - spat (neither branch is kept)
             spat = None
@@ -1081,9 +1090,15 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         if sf:
             if stride == 1:
                 dacc = K.zeros64(64, x)
-                dd, dg1, db1 = K.normbwd_apply_mix(d, dz1, bn1, N, HWo, sb1, fr, dacc, loc1)
+                dyf_pl = sctx.plans is not None and K.rfft2_planes_ok(d, None)
+                en = K.zeros64(Ce, x) if dyf_pl else None
+                dd, dg1, db1 = K.normbwd_apply_mix(d, dz1, bn1, N, HWo, sb1, fr, dacc, loc1, energy=en)
                 # adjoint of irfft2, x sigmoid(a); the same launch turns the accumulator slots into the gate's gradient
-                dyf, _, dalpha = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc, want_absmax=True)
+                if dyf_pl:
+                    # ... and writes the GEMMs' planes itself: scale from the energy of dd the apply pass just summed
+                    dyf, _, dalpha = K.rfft2_ex_planes(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc, energy=en)
+                else:
+                    dyf, _, dalpha = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc, want_absmax=True)
                 tape.add_param_grad(alpha, dalpha)
                 g_sp, g_alpha, g_mode = dd, alpha, 2                                   # spatial branch: x (1 - sigmoid(a))
             else:
@@ -1091,7 +1106,11 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 g_sp, dfr, dalpha = K.sfmix_bwd(spat, fr, alpha, dd, True)
                 tape.add_param_grad(alpha, dalpha)
                 dyf = K.rfft2(dfr, s_i, 2.0, want_absmax=True)
-            dyf2, dyf_amax = dyf.view(-1, 2 * Ce), getattr(dyf, "_ud_absmax", None)
+            if isinstance(dyf, K.Planes):
+                sctx.dy = dyf                                          # the products' dy operand, already in planes
+                dyf2, dyf_amax = sctx.w.buf, None                      # (an fp32 tensor of the right device for the launch wrappers)
+            else:
+                dyf2, dyf_amax = dyf.view(-1, 2 * Ce), getattr(dyf, "_ud_absmax", None)
             tape.wgrad(dwm.freq_conv.weight, lambda: K.spectral_wgrad(sctx, dyf2, dyf_amax), dyf2)
             dxf = K.spectral_dgrad(sctx, dyf2, dy_absmax=dyf_amax).view(xf_shape)
             da_f = K.irfft2(dxf, s_f, 0.5)                                             # adjoint of rfft2
