@@ -450,6 +450,15 @@ int ud_fc_fwd_d(const double* xsum, float xscale, const float* W, const float* b
  * ud_split_planes_h2t without a pass of its own, for results that feed a 1x1 conv on ud_gemm_p3 */
 int ud_se_scale_bn(const void* x, const ud_bn_ref* bn, const float* s, void* y, int G, int R, int C, int f16,
     uint32_t* absmax, ud_stream_t stream);
+/* ud_colsum_bn (fp32 storage) that also leaves max |act(bn(x))| in the 256 caller-zeroed slots `absmax`, and ud_se_scale_bn
+ * writing its result y = act(bn(x)) * sigmoid(s) DIRECTLY as the fp16 x 2 planes of the project conv's operand (ud_gemm_p3 prec 2,
+ * P32 layout over [G R] x C, C % 32 == 0) with the scale that maximum gives (|y| <= it: the gate is a sigmoid) — the SE squeeze
+ * pass has just read the whole tensor, so the split pass (ud_split_planes_h2t) and the fp32 tensor between them are not needed. */
+int ud_colsum_bn_amax(const void* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws, uint32_t* absmax,
+                      ud_stream_t stream);
+int ud_se_scale_bn_planes(const void* x, const ud_bn_ref* bn, const float* s, uint16_t* planes, long panel_stride,
+                          long plane_stride, float* inv_scale, const uint32_t* amax_in, int G, int R, int C,
+                          ud_stream_t stream);
 /* out = bn(x) * (keep[g] * inv_keep) + skip   (BN2 + drop_connect + residual, model.py:126-134; keep / skip may be
  * NULL; bn->running_* are updated here) */
 int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const void* skip,

@@ -712,3 +712,39 @@ def test_fft32_lane_pair_form_equals_one_lane_form(Cc, N, half):
         e = float((o1[k].double() - o2[k].double()).abs().max()) / (scale if scale > 0 else 1.0)
         assert e <= 2.0 * ulp, (k, e)
     assert _rel(a2, a1) < (1e-3 if half else 1e-6)
+
+
+@pytest.mark.parametrize("N,HW,Cc", [(2, 64, 96), (3, 100, 64), (32, 64, 1632)])
+def test_se_scale_writes_the_project_planes_itself(N, HW, Cc):
+    """ud_colsum_bn_amax + ud_se_scale_bn_planes (round 5): the SE squeeze pass leaves max |swish(bn1(d))| behind, and the gate pass
+    writes c = swish(bn1(d)) * sigmoid(s) straight into the project conv's fp16 x 2 planes with the scale that maximum gives.  The
+    pooled sums equal ud_colsum_bn's; the planes re-assemble to ud_se_scale_bn's fp32 result (2^-21 of the maximum, the scale at
+    most two binades above the exact one); the slots hold exactly max |swish(bn1(d))|."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N + HW + Cc)
+    x = torch.randn(N, HW, Cc, generator=g).to(dev)
+    s = torch.randn(N, Cc, generator=g).to(dev)
+    gamma, beta = (1.0 + 0.3 * torch.randn(Cc, generator=g)).to(dev), (0.2 * torch.randn(Cc, generator=g)).to(dev)
+    acc = K.zeros64(2 * Cc, x)
+    K.colstats(x.view(-1, Cc), acc)
+    bn = K.DeferredBN(acc, Cc, N * HW, gamma, beta, 1e-3, 1)
+    pool_ref = K.zeros64(N * Cc, x)
+    K.colsum_bn(x, bn, N, HW, pool_ref)
+    pool = K.zeros64(N * Cc, x)
+    amax = K.colsum_bn_amax(x, bn, N, HW, pool)
+    y = K.se_scale_bn(x, bn, s, N, HW)
+    pl = K.se_scale_bn_planes(x, bn, s, N, HW, amax)
+    a = K.bn_apply(x, bn, N, HW)
+    torch.cuda.synchronize()
+    assert torch.equal(pool, pool_ref)
+    assert float(amax.view(torch.float32).max()) == float(a.abs().max())
+    R = N * HW
+    h = pl.buf.view(2, pl.npanel, pl.panel // 32, 32)[:, :, :R].view(torch.float16).permute(0, 2, 1, 3).reshape(2, R, Cc).double()
+    inv = float(pl.inv)
+    yd = y.view(R, Cc).double()
+    top = float(yd.abs().max())
+    loose = 2.0 ** 15 / (top / inv)
+    assert 1.0 <= loose < 8.0, loose
+    assert float(((h[0] + h[1] / 2048.0) * inv - yd).abs().max()) <= 2.0 ** -21 * top * loose

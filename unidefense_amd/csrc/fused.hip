@@ -97,11 +97,13 @@ __global__ __launch_bounds__(NT) void colstats_kernel(RedGeom q, const T* __rest
 template <typename T, bool DOT>
 __global__ __launch_bounds__(NT) void colsum_bn_kernel(RedGeom q, const T* __restrict__ x,
                                                        const T* __restrict__ dy, ud_bn_ref bn,
-                                                       double* __restrict__ out, double* __restrict__ part) {
+                                                       double* __restrict__ out, double* __restrict__ part,
+                                                       uint32_t* __restrict__ amax) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
     const In4<T> x4{x}, d4{dy};
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mo = 0.f;          // !DOT, amax: max |act(bn(x))| as a side output (the scale of the planes ud_se_scale_bn_planes writes)
     if (active) {
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, !DOT && is_updater(ri));
         Rows w = rows_of(q, ri, c4);
@@ -115,10 +117,12 @@ __global__ __launch_bounds__(NT) void colsum_bn_kernel(RedGeom q, const T* __res
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += (double)a[e];
+                mo = fmaxf(mo, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
             }
         }
     }
     red_out<4>(q, ri, active, c4, v, out, nullptr, part, true);
+    if (!DOT) ud_absmax_commit(mo, amax);
 }
 
 // y[n][o] = sum_i (xsum[n][i] * xscale) W[o][i] + b[o]; one wave per output
@@ -160,6 +164,44 @@ __global__ __launch_bounds__(NT) void se_scale_bn_kernel(RedGeom q, const T* __r
         }
     }
     ud_absmax_commit(m, amax);
+}
+
+// The same pass writing its result DIRECTLY as the fp16 x 2 planes of the project conv's GEMM operand (ud_gemm_p3 prec 2, P32
+// layout over [G R] x C): |y| <= max |act(bn(x))| (the gate is a sigmoid), and that maximum is the side output of ud_colsum_bn_amax,
+// the SE squeeze pass that read the whole tensor a moment ago — the scale is the one the exact maximum of y would give, or one
+// binade or two above.  amax_in: its 256 slots; *inv_scale receives 1 / scale.
+__global__ __launch_bounds__(NT) void se_scale_bn_planes_kernel(RedGeom q, const float* __restrict__ x, ud_bn_ref bn,
+                                                                const float* __restrict__ s, uint16_t* __restrict__ planes,
+                                                                long panel, long plane, const uint32_t* __restrict__ amax_in,
+                                                                float* __restrict__ inv_scale) {
+    uint32_t mb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mb = max(mb, amax_in[(threadIdx.x & 63) + 64 * i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, o, 64));
+    float ps, pinv;
+    ud_h2_scale(mb, ps, pinv);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *inv_scale = pinv;
+    int ri, c4;
+    if (!thread_coords(q, ri, c4)) return;
+    const In4<float> x4{x};
+    const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
+    f32x4 gate = reinterpret_cast<const f32x4*>(s)[(long)blockIdx.z * q.C4 + c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gate[e] = ud_sigmoid_fast(gate[e]) * ps;
+    Rows w = rows_of(q, ri, c4);
+    uint16_t* o = planes + (long)(c4 >> 3) * panel + (c4 & 7) * 4;
+    long row = (long)blockIdx.z * q.R + w.r;
+#pragma unroll 4
+    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step, row += q.rpi) {
+        const f32x4 v = bn_apply(x4[w.idx], cb, bn.act) * gate;
+        uint16_t h0[4], h1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ud_split_h2(v[e], h0[e], h1[e]);
+        typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u16x4*>(o + row * 32) = u16x4{h0[0], h0[1], h0[2], h0[3]};
+        *reinterpret_cast<u16x4*>(o + row * 32 + plane) = u16x4{h1[0], h1[1], h1[2], h1[3]};
+    }
 }
 
 template <typename T>
@@ -773,7 +815,19 @@ int ud_colsum_bn(const void* x, const ud_bn_ref* bn, int G, int R, int C, double
     hipStream_t s = (hipStream_t)stream;
     RedPlan pl = plan_reduce(G, R, C, true, ws);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((colsum_bn_kernel<T, false>), red_grid(pl.q), dim3(NT), 0, s, pl.q,
-                                                (const T*)x, (const T*)nullptr, *bn, out, pl.use_part ? ws : nullptr));
+                                                (const T*)x, (const T*)nullptr, *bn, out, pl.use_part ? ws : nullptr,
+                                                (uint32_t*)nullptr));
+    UD_LAUNCH_CHECK();
+    return finish_reduce(pl, 1, true, C, ws, out, nullptr, s);
+}
+
+int ud_colsum_bn_amax(const void* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws, uint32_t* absmax,
+                      ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !bn || !out || !absmax) return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    RedPlan pl = plan_reduce(G, R, C, true, ws);
+    hipLaunchKernelGGL((colsum_bn_kernel<float, false>), red_grid(pl.q), dim3(NT), 0, s, pl.q, (const float*)x,
+                       (const float*)nullptr, *bn, out, pl.use_part ? ws : nullptr, absmax);
     UD_LAUNCH_CHECK();
     return finish_reduce(pl, 1, true, C, ws, out, nullptr, s);
 }
@@ -784,7 +838,8 @@ int ud_coldot_bn(const void* dy, const void* x, const ud_bn_ref* bn, int G, int 
     hipStream_t s = (hipStream_t)stream;
     RedPlan pl = plan_reduce(G, R, C, true, ws);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((colsum_bn_kernel<T, true>), red_grid(pl.q), dim3(NT), 0, s, pl.q,
-                                                (const T*)x, (const T*)dy, *bn, out, pl.use_part ? ws : nullptr));
+                                                (const T*)x, (const T*)dy, *bn, out, pl.use_part ? ws : nullptr,
+                                                (uint32_t*)nullptr));
     UD_LAUNCH_CHECK();
     return finish_reduce(pl, 1, true, C, ws, out, nullptr, s);
 }
@@ -814,6 +869,19 @@ int ud_se_scale_bn(const void* x, const ud_bn_ref* bn, const float* s, void* y, 
     RedGeom q = geom_ew(G, R, C);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(se_scale_bn_kernel<T>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
                                                 (const T*)x, *bn, s, (T*)y, absmax));
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_se_scale_bn_planes(const void* x, const ud_bn_ref* bn, const float* s, uint16_t* planes, long panel_stride,
+                          long plane_stride, float* inv_scale, const uint32_t* amax_in, int G, int R, int C,
+                          ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || C % 32 || !x || !bn || !s || !planes || !inv_scale || !amax_in) return UD_EINVAL;
+    if (panel_stride < (long)G * R * 32 || panel_stride % 8 || plane_stride % 8 || plane_stride < (long)(C / 32) * panel_stride)
+        return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL(se_scale_bn_planes_kernel, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, (const float*)x, *bn, s,
+                       planes, panel_stride, plane_stride, amax_in, inv_scale);
     UD_LAUNCH_CHECK();
     return 0;
 }

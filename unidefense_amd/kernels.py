@@ -2073,6 +2073,25 @@ def colsum_bn(x, bn, G, R, out, update=False):
     _call("ud_colsum_bn", _p(x), C.byref(bn.ref(update)), G, R, Cc, _pd(out), _fused_ws(x, G, R, Cc, True), h, _stream())
 
 
+def colsum_bn_amax(x, bn, G, R, out, update=False):
+    """colsum_bn (fp32) + the 256 slots holding max |act(bn(x))| (returned): the scale se_scale_bn_planes writes its planes with"""
+    _chk(x)
+    Cc = x.shape[-1]
+    amax = zeros((256,), x)
+    _call("ud_colsum_bn_amax", _p(x), C.byref(bn.ref(update)), G, R, Cc, _pd(out), _fused_ws(x, G, R, Cc, True), _p(amax), _stream())
+    return amax
+
+
+def se_scale_bn_planes(x, bn, s, G, R, amax):
+    """act(bn(x)) * sigmoid(s) written straight into prec-2 Planes over [G R] x C (the project conv's GEMM operand)"""
+    _chk(x, s)
+    Cc = x.shape[-1]
+    pl = Planes(G * R, Cc, x, 2, False)
+    _call("ud_se_scale_bn_planes", _p(x), C.byref(bn.ref()), _p(s), _p(pl.buf), pl.panel, pl.plane, _p(pl.inv), _p(amax), G, R, Cc,
+          _stream())
+    return pl
+
+
 def coldot_bn(dy, x, bn, G, R, out):
     h = _act(dy, x)
     Cc = x.shape[-1]

@@ -150,6 +150,8 @@ _SIGNATURES = {
     "ud_coldot_bn": [_P, _P, _BN, _I, _I, _I, _P, _P, _I, _P],
     "ud_fc_fwd_d": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
     "ud_se_scale_bn": [_P, _BN, _P, _P, _I, _I, _I, _I, _P, _P],
+    "ud_colsum_bn_amax": [_P, _BN, _I, _I, _I, _P, _P, _P, _P],
+    "ud_se_scale_bn_planes": [_P, _BN, _P, _P, _L, _L, _P, _P, _I, _I, _I, _P],
     "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P],
     "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P],

@@ -1038,16 +1038,26 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
     Cs = sp.cse
     wr2, we2 = blk._se_reduce.weight.view(Cs, Ce), blk._se_expand.weight.view(Ce, Cs)
     pool = K.zeros64(N * Ce, x)
-    K.colsum_bn(d, bn1, N, HWo, pool, update=True)
+    Wp = blk._project_conv.weight.view(Co, Ce)
+    # project conv on the planes GEMM: the gated tensor c is written as its planes by se_scale_bn itself, scaled by
+    # max |swish(bn1(d))| — which the SE squeeze pass leaves behind (kernels.colsum_bn_amax)
+    c_pl = (K._RFFT_PLANES and d.dtype == torch.float32 and Ce % 32 == 0 and cfg.spectral_p2 != "off"
+            and K.spectral_takes_planes(Mo, Co, Ce, Wp, want_stats=True))
+    if c_pl:
+        c_amax = K.colsum_bn_amax(d, bn1, N, HWo, pool, update=True)
+    else:
+        K.colsum_bn(d, bn1, N, HWo, pool, update=True)
     s1 = K.fc_fwd_d(pool, 1.0 / HWo, wr2, blk._se_reduce.bias, N)
     s2 = K.fc_fwd(s1, we2, blk._se_expand.bias, 1)
-    c = K.se_scale_bn(d, bn1, s2, N, HWo, want_absmax=True)
 
     # ---- project + BN2 + drop-connect + skip
-    Wp = blk._project_conv.weight.view(Co, Ce)
-    c2 = c.view(Mo, Ce)
     acc2 = K.zeros64(2 * Co, x)
-    (p, done), pctx = K.spectral_fwd(c2, Wp, stats=acc2, x_absmax=getattr(c, "_ud_absmax", None))
+    if c_pl:
+        c = K.se_scale_bn_planes(d, bn1, s2, N, HWo, c_amax)
+        (p, done), pctx = K.spectral_fwd(c, Wp, stats=acc2)
+    else:
+        c = K.se_scale_bn(d, bn1, s2, N, HWo, want_absmax=True)
+        (p, done), pctx = K.spectral_fwd(c.view(Mo, Ce), Wp, stats=acc2, x_absmax=getattr(c, "_ud_absmax", None))
     if not done:
         K.colstats(p, acc2)
     dp.reduce(acc2)
