@@ -524,11 +524,14 @@ int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float 
  * from an a-priori UPPER BOUND of |Y|: bound_pre * sqrt(max_c e_c) with e_c = gamma_c^2 + beta_c^2 (bn given: the input is
  * act(bn(x)), |act(z)| <= |z|; bound_pre = f_max S sqrt(count)) or e_c = energy[c] >= sum_{n,h,w} x_c^2 (bound_pre = f_max S);
  * a bound 2^b above the true maximum moves the 2^-18 window of full 22-bit precision up by b binades and changes nothing for
- * the large elements.  S in {8, 16, 32, 12, 24, 48}, (2 C) % 32 == 0, fp32 storage; *inv_scale receives 1 / scale. */
+ * the large elements.  S in {8, 16, 32, 12, 24, 48}, (2 C) % 32 == 0, fp32 storage; *inv_scale receives 1 / scale.
+ * dw_k = 3 / 5 (S in {8, 16, 32}; 0: off): the kernel ALSO writes dw_out[N][S][S][C] = the stride-1 depthwise dw_k x dw_k conv
+ * (pads (dw_k - 1) / 2, taps dw_wt tap-major [dw_k^2][C]) of the same activated plane act(bn(x)) — SFConv's spatial branch
+ * (exp.py:49-51) without a kernel of its own. */
 int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long plane_stride, float* inv_scale, float bound_pre,
                        const double* energy, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
                        void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
-                       ud_stream_t stream);
+                       const float* dw_wt, void* dw_out, int dw_k, ud_stream_t stream);
 /* irfft2 + SF mix + BN1 statistics (exp.py:60-65, stride 1):  freq = irfft2(Y) * scale;
  * y = (1 - a) spat + a freq, a = sigmoid(alpha[0]);  diff_out = freq - spat (what the backward needs of the two
  * branches: neither has to be kept);  sum[c] += sum y, sumsq[c] += sum y^2 */

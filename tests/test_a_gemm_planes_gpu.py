@@ -385,3 +385,31 @@ def test_rfft2_writes_the_gemm_planes_itself(N, S, C):
     big2 = Y2d.abs() >= top2 * 2.0 ** -10
     assert float((err2[big2] / Y2d.abs()[big2]).max()) < 2.0 ** -21
 
+
+
+@pytest.mark.parametrize("N,S,C,k", [(2, 8, 64, 5), (3, 16, 48, 3), (2, 16, 32, 5), (2, 32, 16, 5), (2, 32, 32, 3), (4, 8, 80, 3)])
+def test_rfft2_also_computes_the_depthwise_conv(N, S, C, k):
+    """ud_rfft2_ex_planes with dw_k (round 5): the kernel that transforms act(bn(x)) also writes the stride-1 depthwise conv of the
+    same activated plane (SFConv's spatial branch) — against F.conv2d in float64 on the activation ud_rfft2_ex materialises, and
+    the planes / activated output unchanged by the addition."""
+    import torch.nn.functional as F
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(S * 100 + C + k)
+    x = torch.randn(N, S, S, C, generator=g).to(dev)
+    w = (0.3 * torch.randn(C, 1, k, k, generator=g))
+    wt = w.view(C, k * k).t().contiguous().to(dev)
+    gamma, beta = (1.0 + 0.3 * torch.randn(C, generator=g)).to(dev), (0.2 * torch.randn(C, generator=g)).to(dev)
+    acc = K.zeros64(2 * C, x)
+    K.colstats(x.view(-1, C), acc)
+    bn = K.DeferredBN(acc, C, N * S * S, gamma, beta, 1e-3, 1)
+    pl0, a0 = K.rfft2_ex_planes(x, 1.0 / S, 1.0, bn=bn, want_act=True)
+    pl1, a1, spat = K.rfft2_ex_planes(x, 1.0 / S, 1.0, bn=bn, want_act=True, dw_wt=wt, dw_k=k)
+    torch.cuda.synchronize()
+    R = N * S * (S // 2 + 1)
+    valid = lambda pl: pl.buf.view(2, pl.npanel, pl.panel // 32, 32)[:, :, :R]          # (rows up to the next multiple of 128 are slack)
+    assert torch.equal(a0, a1) and torch.equal(valid(pl0), valid(pl1)) and torch.equal(pl0.inv, pl1.inv)
+    ref = F.conv2d(a0.double().cpu().permute(0, 3, 1, 2), w.double(), padding=(k - 1) // 2, groups=C).permute(0, 2, 3, 1)
+    err = float((spat.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-6, err

@@ -251,14 +251,24 @@ struct PlanesOut {
     const double* energy;
 };
 
-template <typename T, int S, int CB, bool EX>
+// DW = 3 / 5 (round 5): the stride-1 depthwise conv of the SAME activated plane (SFConv's spatial branch, exp.py:49-51, pads
+// (DW - 1) / 2) computed by this kernel too: the (n, c) plane act(bn(x)) is in this workgroup's registers anyway, so after the
+// transform it is laid into the (now free) LDS planes and every row-thread slides the DW x DW window over it — the separate conv
+// kernel (one more read of x with the BatchNorm + activation re-evaluated, one launch) is not needed.
+struct DwOut {
+    const float* wt;          // tap-major [DW*DW][C]
+    void* out;                // [N][S][S][C], storage type T
+};
+
+template <typename T, int S, int CB, bool EX, int DW = 0>
 __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* __restrict__ Y, int C,
                                                    float scale, float w_int, ud_bn_ref bn, int has_bn,
                                                    T* __restrict__ act_out, const float* __restrict__ gate_alpha,
                                                    int gate_mode, const double* __restrict__ gate_acc,
                                                    float* __restrict__ gate_grad, int xcd_remap,
-                                                   uint32_t* __restrict__ amax, PlanesOut po) {
+                                                   uint32_t* __restrict__ amax, PlanesOut po, DwOut dwo) {
     using L = Lds<S, CB>;
+    static_assert(DW == 0 || (size_t)S * S * CB * sizeof(float) <= L::BYTES, "the activated plane fits the transform's LDS planes");
     __shared__ float po_red[NT / 64];
     if (EX && po.buf) {
         // max over ALL channels of the per-channel energy bound: this thread's share, folded per wave; the workgroup's fold
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
     const int ch = cgroup * CB + c;
     const bool cok = ch < C;
     float re[S], im[S];
+    float va[DW ? S : 1];          // DW: this thread's activated row, kept for the conv
     // ---- pass 1: rows   (S * CB may be < 512 for the 5*2^k sizes: q >= S idles)
     if (q < S) {
         const int chl = cok ? ch : C - 1;          // loads unconditional and inside the tensor; stores predicated
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
             }
             re[brev<S>(w)] = cok ? v : 0.f;
             im[brev<S>(w)] = 0.f;
+            if (DW) va[w] = cok ? v : 0.f;
         }
         fft_inreg<S, false>(re, im);
 #pragma unroll
@@ -380,6 +392,39 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
         }
     }
     if (EX) ud_absmax_commit(mabs, amax);
+    if constexpr (DW != 0) {
+        constexpr int P = (DW - 1) / 2;
+        __syncthreads();                                   // every column transform has read the planes
+        float* A = lds;                                    // [h][w][c]
+        if (q < S) {
+#pragma unroll
+            for (int w = 0; w < S; ++w) A[(q * S + w) * CB + c] = va[w];
+        }
+        __syncthreads();
+        if (q < S && cok) {
+            float tp[DW * DW];
+#pragma unroll
+            for (int i = 0; i < DW * DW; ++i) tp[i] = dwo.wt[(long)i * C + ch];
+            float acc[S];
+#pragma unroll
+            for (int w = 0; w < S; ++w) acc[w] = 0.f;
+#pragma unroll
+            for (int i = 0; i < DW; ++i) {
+                const int ih = q + i - P;
+                if (ih < 0 || ih >= S) continue;
+                float in[S + DW - 1];
+#pragma unroll
+                for (int j = 0; j < S + DW - 1; ++j) in[j] = (j >= P && j < S + P) ? A[(ih * S + j - P) * CB + c] : 0.f;
+#pragma unroll
+                for (int w = 0; w < S; ++w)
+#pragma unroll
+                    for (int j = 0; j < DW; ++j) acc[w] += in[w + j] * tp[i * DW + j];
+            }
+            T* o = reinterpret_cast<T*>(dwo.out) + (((long)n * S + q) * S) * C + ch;
+#pragma unroll
+            for (int w = 0; w < S; ++w) o[(long)w * C] = (T)acc[w];
+        }
+    }
 }
 
 // x[n][h][w][c] = scale * C2R( f(kx) * Y[n][ky][kx][c] )   with the Hermitian extension along kx
@@ -514,23 +559,24 @@ struct RfftEx {
     float* gate_grad;
     uint32_t* absmax;          // 256 slots: |Y|max as a side output (ud_absmax_commit), or NULL
     PlanesOut planes = PlanesOut{nullptr, 0, 0, nullptr, 0.f, nullptr};
+    DwOut dw = DwOut{nullptr, nullptr};
 };
 
-template <typename T, int S, int CB, bool EX>
+template <typename T, int S, int CB, bool EX, int DW = 0>
 int launch_rfft2_t(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx& ex, hipStream_t s) {
     using L = Lds<S, CB>;
     static bool attr_set = false;
     if (L::BYTES > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfft2_kernel<T, S, CB, EX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfft2_kernel<T, S, CB, EX, DW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
     ud_bn_ref none{};
-    hipLaunchKernelGGL((rfft2_kernel<T, S, CB, EX>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
+    hipLaunchKernelGGL((rfft2_kernel<T, S, CB, EX, DW>), grid, dim3(NT), L::BYTES, s, x, Y, C, scale, w_int,
                        ex.bn ? *ex.bn : none, ex.bn ? 1 : 0, (T*)ex.act_out, ex.gate_alpha, ex.gate_mode, ex.gate_acc,
-                       ex.gate_grad, xcd_remap_on(CB * (int)sizeof(T)), ex.absmax, ex.planes);
+                       ex.gate_grad, xcd_remap_on(CB * (int)sizeof(T)), ex.absmax, ex.planes, ex.dw);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -538,7 +584,7 @@ int launch_rfft2_t(const T* x, T* Y, int N, int C, float scale, float w_int, con
 template <typename T, int S, int CB>
 int launch_rfft2(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
     if (ex) return launch_rfft2_t<T, S, CB, true>(x, Y, N, C, scale, w_int, *ex, s);
-    return launch_rfft2_t<T, S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, PlanesOut{nullptr, 0, 0, nullptr, 0.f, nullptr}}, s);
+    return launch_rfft2_t<T, S, CB, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, PlanesOut{nullptr, 0, 0, nullptr, 0.f, nullptr}, DwOut{nullptr, nullptr}}, s);
 }
 
 struct IrfftMix {
@@ -1080,7 +1126,7 @@ int launch_rfft2_wave_t(const T* x, T* Y, int N, int C, float scale, float w_int
 template <typename T>
 int launch_rfft2_wave(const T* x, T* Y, int N, int C, float scale, float w_int, const RfftEx* ex, hipStream_t s) {
     if (ex) return launch_rfft2_wave_t<T, true>(x, Y, N, C, scale, w_int, *ex, s);
-    return launch_rfft2_wave_t<T, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, PlanesOut{nullptr, 0, 0, nullptr, 0.f, nullptr}}, s);
+    return launch_rfft2_wave_t<T, false>(x, Y, N, C, scale, w_int, RfftEx{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, PlanesOut{nullptr, 0, 0, nullptr, 0.f, nullptr}, DwOut{nullptr, nullptr}}, s);
 }
 template <typename T, bool MIX>
 int launch_irfft2_wave_t(const T* Y, T* x, int N, int C, float scale, float w_int, const IrfftMix& m, hipStream_t s) {
@@ -1208,7 +1254,8 @@ int ud_rfft2_ex(const void* x, void* Y, int N, int S, int C, float scale, float 
 int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long plane_stride, float* inv_scale, float bound_pre,
                        const double* energy, int N, int S, int C, float scale, float w_interior, const ud_bn_ref* bn,
                        void* act_out, const float* gate_alpha, int gate_mode, const double* gate_acc, float* gate_grad,
-                       ud_stream_t stream) {
+                       const float* dw_wt, void* dw_out, int dw_k, ud_stream_t stream) {
+    if (dw_k != 0 && (!dw_wt || !dw_out || (dw_k != 3 && dw_k != 5) || (S != 8 && S != 16 && S != 32))) return UD_EINVAL;
     if (N < 1 || C < 4 || (2 * C) % 32 || !x || !planes || !inv_scale || !(bound_pre > 0.f)) return UD_EINVAL;
     if (S != 8 && S != 16 && S != 32 && S != 12 && S != 24 && S != 48) return UD_EINVAL;          // the one-kernel forms
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
@@ -1220,8 +1267,20 @@ int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long 
     if (panel_stride < rows * 32 || panel_stride % 8 || plane_stride % 8 || plane_stride < (long)(2 * C / 32) * panel_stride)
         return UD_EINVAL;
     RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad, nullptr,
-              PlanesOut{planes, panel_stride, plane_stride, inv_scale, bound_pre, energy}};
-    return rfft2_dispatch<float>((const float*)x, (float*)nullptr, N, S, C, scale, w_interior, &ex, (hipStream_t)stream);
+              PlanesOut{planes, panel_stride, plane_stride, inv_scale, bound_pre, energy}, DwOut{dw_wt, dw_out}};
+    hipStream_t st = (hipStream_t)stream;
+    const float* xf = (const float*)x;
+    if (dw_k == 3) {
+        if (S == 8) return launch_rfft2_t<float, 8, 64, true, 3>(xf, nullptr, N, C, scale, w_interior, ex, st);
+        if (S == 16) return launch_rfft2_t<float, 16, 32, true, 3>(xf, nullptr, N, C, scale, w_interior, ex, st);
+        return launch_rfft2_t<float, 32, 16, true, 3>(xf, nullptr, N, C, scale, w_interior, ex, st);
+    }
+    if (dw_k == 5) {
+        if (S == 8) return launch_rfft2_t<float, 8, 64, true, 5>(xf, nullptr, N, C, scale, w_interior, ex, st);
+        if (S == 16) return launch_rfft2_t<float, 16, 32, true, 5>(xf, nullptr, N, C, scale, w_interior, ex, st);
+        return launch_rfft2_t<float, 32, 16, true, 5>(xf, nullptr, N, C, scale, w_interior, ex, st);
+    }
+    return rfft2_dispatch<float>(xf, (float*)nullptr, N, S, C, scale, w_interior, &ex, st);
 }
 
 int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, float w_interior, const void* spat,

@@ -2277,12 +2277,22 @@ def rfft2_planes_ok(x, bn, stride_ok=True):
     return S in (8, 16, 32, 12, 24, 48) and (2 * Cc) % 32 == 0 and not _fft_two_pass("rfft_ex", S, 0)
 
 
+_RFFT_DW = True          # A/B: tools/run_with.py kernels._RFFT_DW=False
+
+
+def rfft2_dw_ok(S, k, stride, pad):
+    """can rfft2_ex_planes compute the depthwise conv of the same plane too?  (the 256 x 256 trunk's power-of-two maps, stride 1,
+    'same' pads)"""
+    return _RFFT_DW and stride == 1 and S in (8, 16, 32) and k in (3, 5) and tuple(pad) == ((k - 1) // 2,) * 4
+
+
 def rfft2_ex_planes(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None, gate_mode=0, update=False,
-                    gate_acc=None, energy=None):
+                    gate_acc=None, energy=None, dw_wt=None, dw_k=0):
     """rfft2_ex whose result is written straight into fp16 x 2 planes (P32 layout over [N S (S/2+1)] x 2C, prec 2) with the scale
     of an a-priori BOUND of |Y| (csrc/fft.hip: PlanesOut) instead of fp32 + ud_split_planes_h2t.  bn given: the bound comes from
     count (gamma^2 + beta^2); else energy [C] fp64: a per-channel upper bound of sum_{n,h,w} x^2 (the kernel multiplies the bound by
-    the gate factor it applies to the result).  Returns (Planes, activated input or None[, gate gradient])."""
+    the gate factor it applies to the result).  dw_wt / dw_k: also the stride-1 depthwise conv of the activated plane (taps
+    tap-major [k*k][C]); its result is appended.  Returns (Planes, activated input or None[, gate gradient][, conv result])."""
     _chk(x)
     N, S, S2, Cc = x.shape
     assert S == S2 and (bn is not None or energy is not None)
@@ -2293,10 +2303,12 @@ def rfft2_ex_planes(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alph
     pre = float(scale) * max(1.0, float(w_interior)) * S
     if energy is None:
         pre *= math.sqrt(float(bn.count))
+    spat = torch.empty_like(x) if dw_k else None
     _call("ud_rfft2_ex_planes", _p(x), _p(pl.buf), pl.panel, pl.plane, _p(pl.inv), pre, _pd(energy) if energy is not None else None,
           N, S, Cc, float(scale), float(w_interior), C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha),
-          int(gate_mode), _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), _stream())
-    return (pl, act, ggrad) if gate_acc is not None else (pl, act)
+          int(gate_mode), _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), _p(dw_wt), _p(spat), int(dw_k), _stream())
+    out = (pl, act, ggrad) if gate_acc is not None else (pl, act)
+    return out + (spat,) if dw_k else out
 
 
 def irfft2_mix(Y, scale, spat, alpha, acc):

@@ -166,7 +166,7 @@ _SIGNATURES = {
     "ud_dwconv_bwd_data_ex": [_P, _P, _I, _P, _P, _P] + [_I] * 10 + [_I, _P],
     "ud_dwconv_bwd_weight_ex": [_P, _P, _P, _I, _P, _P, _I] + [_I] * 10 + [_I, _P],
     "ud_rfft2_ex": [_P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P, _P],
-    "ud_rfft2_ex_planes": [_P, _P, _L, _L, _P, _F, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _P],
+    "ud_rfft2_ex_planes": [_P, _P, _L, _L, _P, _F, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "ud_irfft2_mix": [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "ud_rfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _I, _P, _P],
     "ud_irfft2_two_pass": [_P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _I, _P],

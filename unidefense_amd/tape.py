@@ -993,13 +993,20 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
             # a strip kernel needs a = swish(bn0(e)) materialised (rfft2_ex writes it); the tiled ones apply it on load
             want_a = not (t_fwd and (t_wg or t_fused))
             if K.rfft2_planes_ok(src, src_bn) and K.spectral_takes_planes(N * S * (S // 2 + 1), 2 * Ce, 2 * Ce, Wf):
-                # the transform writes the spectral GEMM's fp16 x 2 planes itself (scale from an a-priori bound): no split pass
-                xf, a = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
+                # the transform writes the spectral GEMM's fp16 x 2 planes itself (scale from an a-priori bound): no split pass —
+                # and, stride 1, the depthwise conv of the plane it holds anyway: no conv kernel either
+                if K.rfft2_dw_ok(S, k, stride, sp.pad):
+                    xf, a, spat = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=not (t_wg or t_fused), update=True, dw_wt=wt,
+                                                    dw_k=k)
+                else:
+                    xf, a = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
             else:
                 xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True, want_absmax=True)
         else:
             xf, a = K.rfft2(src, s_f, 1.0, want_absmax=True), src
-        if t_fwd:
+        if spat is not None:
+            pass
+        elif t_fwd:
             spat = K.dwtile_fwd(src, wt, k, pt, pl, Ho, Wo, bn=src_bn, stride=stride)
         else:
             spat = K.dwconv_fwd(a, wt, k, stride, pt, pl, Ho, Wo)
