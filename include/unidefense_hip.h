@@ -602,6 +602,19 @@ int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, con
 int ud_dwtile_bwd(const void* dy, const void* x, const ud_bn_ref* bn, const float* wt, const float* gate_alpha, int gate_mode,
                   const void* add, void* dz, float* dwt, float* wpart, long part_rows, double* s1, double* s2, double* ws,
                   int N, int H, int W, int C, int K, int P_t, int P_l, int f16, ud_stream_t stream);
+/* dwt[C][K*K] = gate * sum_p part[p][K*K][C] (fp64 accumulation): the fold of per-workgroup weight-gradient partials, for kernels
+ * outside csrc/dwtile.hip that produce them (ud_irfft2_dwbwd) */
+int ud_dwtile_wgrad_finalize(const float* part, int nparts, int K, int C, const float* gate_alpha, int gate_mode, float* dwt,
+                             ud_stream_t stream);
+/* Backward of an SF block's spatial branch inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel; S = 8, K in {3, 5},
+ * fp32): da_f = scale * C2R(f(kx) Y) as ud_irfft2 (the adjoint of rfft2: w_interior = 1/2), then with dd = dL/d(conv output)
+ * [N][S][S][C], x the conv's raw input and bn the BatchNorm in front of it:
+ *   dz = (gate * conv_flipped(dd) + da_f) * act'(bn(x));  s1 += sum dz, s2 += sum dz * xhat;
+ *   wpart[n][K*K][C] = sum_pixels act(bn(x))(window) * dd   of image n  (ud_dwtile_wgrad_finalize sums the N rows).
+ * Replaces ud_irfft2 + the depthwise weight-gradient kernel + its finalize + the depthwise data-gradient kernel. */
+int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,
+                    const ud_bn_ref* bn, const float* wt, int K, const float* gate_alpha, int gate_mode, void* dz, double* s1,
+                    double* s2, float* wpart, ud_stream_t stream);
 
 /* ---- large real 2-D FFT of image planes (csrc/fft_large.hip), S in {128, 256, 320} ------------------------------------
  * torch.fft.rfft2 on [N,3,S,S] images: the frequency reconstruction loss (model/unidefense.py:246-253; ResNet variants

@@ -748,3 +748,35 @@ def test_se_scale_writes_the_project_planes_itself(N, HW, Cc):
     loose = 2.0 ** 15 / (top / inv)
     assert 1.0 <= loose < 8.0, loose
     assert float(((h[0] + h[1] / 2048.0) * inv - yd).abs().max()) <= 2.0 ** -21 * top * loose
+
+
+@pytest.mark.parametrize("N,Cc,k", [(2, 64, 5), (3, 40, 3), (32, 96, 5)])
+def test_adjoint_transform_does_the_depthwise_backward(N, Cc, k):
+    """ud_irfft2_dwbwd (csrc/fft.hip, round 5; the 8 x 8 maps): ONE kernel = ud_irfft2 (adjoint of rfft2) + the depthwise data
+    gradient with gate, the added spectral-branch gradient, act'(bn(x)) and the BatchNorm backward sums + the depthwise weight
+    gradient.  Against the separate kernels (themselves held to float64 autograd above): dz and the sums to 1e-6, the weight
+    gradient to 2e-6 of its scale."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    S = 8
+    g = torch.Generator().manual_seed(N * 10 + Cc + k)
+    x = torch.randn(N, S, S, Cc, generator=g).to(dev)
+    dd = torch.randn(N, S, S, Cc, generator=g).to(dev)
+    Yf = torch.randn(N, S, S // 2 + 1, 2 * Cc, generator=g).to(dev)
+    wt = (0.3 * torch.randn(k * k, Cc, generator=g)).to(dev)
+    gamma, beta = (1.0 + 0.3 * torch.randn(Cc, generator=g)).to(dev), (0.2 * torch.randn(Cc, generator=g)).to(dev)
+    alpha = torch.tensor([0.4], device=dev)
+    acc = K.zeros64(2 * Cc, x)
+    K.colstats(x.view(-1, Cc), acc)
+    bn = K.DeferredBN(acc, Cc, N * S * S, gamma, beta, 1e-3, 1)
+    pad = (k - 1) // 2
+    da_f = K.irfft2(Yf, 1.0 / S, 0.5)
+    s_ref = K.zeros64(2 * Cc, x)
+    dz_ref, dw_ref = K.dwtile_bwd(dd, x, wt, k, pad, pad, bn=bn, gate_alpha=alpha, gate_mode=2, add=da_f, sacc=s_ref)
+    s_new = K.zeros64(2 * Cc, x)
+    dz, dw = K.irfft2_dwbwd(Yf, 1.0 / S, 0.5, dd, x, bn, wt, k, alpha, 2, s_new)
+    torch.cuda.synchronize()
+    assert _rel(dz, dz_ref.double().cpu()) < 2e-6
+    assert _rel(s_new, s_ref.cpu()) < 1e-6
+    assert _rel(dw, dw_ref.double().cpu()) < 2e-6

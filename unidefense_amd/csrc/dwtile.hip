@@ -753,4 +753,13 @@ int ud_dwtile_bwd(const void* dy, const void* x, const ud_bn_ref* bn, const floa
 #undef UD_BW
 }
 
+int ud_dwtile_wgrad_finalize(const float* part, int nparts, int K, int C, const float* gate_alpha, int gate_mode, float* dwt,
+                             ud_stream_t stream) {
+    if (!part || nparts < 1 || (K != 3 && K != 5) || C < 4 || C % 4 || !dwt) return UD_EINVAL;
+    hipLaunchKernelGGL(dw_tile_wgrad_finalize, dim3(ud_cdiv(K * K * C, 64)), dim3(NT), 0, (hipStream_t)stream, nparts, K * K, C,
+                       part, gate_alpha, gate_mode, dwt);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // extern "C"

@@ -26,6 +26,12 @@ namespace {
 
 constexpr int NT = 512;
 
+__device__ __forceinline__ float gate_factor_f(const float* alpha, int mode) {
+    if (mode == 0 || !alpha) return 1.f;
+    const float a = ud_sigmoid(alpha[0]);
+    return mode == 1 ? a : 1.f - a;
+}
+
 // exp(-2*pi*i*j/64), j = 0..31
 __device__ constexpr float TW_RE[32] = {
     1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f,
@@ -548,6 +554,224 @@ __global__ __launch_bounds__(NT) void irfft2_kernel(const T* __restrict__ Y, T* 
 // remap only where a workgroup's run of channels is shorter than a 128-byte line
 inline int xcd_remap_on(int run_bytes) {
     return run_bytes < 128;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 5: the backward of an SF block's spatial branch inside the ADJOINT transform.  After the spectral conv's data gradient the
+// step ran: irfft2 (adjoint of rfft2: da_f) -> depthwise weight gradient -> its finalize -> depthwise data gradient (+ da_f,
+// x act'(bn0(e)), BatchNorm backward sums): four launches over (n, c) planes of 8 x 8 pixels — 57 us for 13 MB tensors.  Here the
+// workgroup that produces the da_f plane of (n, 64 channels) also stages the planes dd (the conv's output gradient) and a =
+// act(bn0(e)) in LDS and finishes the job: dz = (gate * conv_flipped(dd) + da_f) * act'(bn0(e)), its BatchNorm sums (fp64 atomics,
+// N workgroups per channel), and the weight-gradient partial [K*K][64] of its image (summed over N by dw_tile_wgrad_finalize).
+// Thread (h, c): row h of channel c throughout.  LDS: the transform's planes, then (aliased) the two staged planes, then the folds.
+// ---------------------------------------------------------------------------------------------------------
+template <int S, int CB, int K>
+struct LdsBwd {
+    using L = Lds<S, CB>;
+    static constexpr size_t PLANES = 2ull * S * S * CB * sizeof(float);
+    static constexpr size_t FOLD = (size_t)S * K * K * CB * sizeof(float);
+    static constexpr size_t BYTES = L::BYTES > PLANES ? (L::BYTES > FOLD ? L::BYTES : FOLD) : (PLANES > FOLD ? PLANES : FOLD);
+};
+
+template <int S, int CB, int K>
+__global__ __launch_bounds__(NT) void irfft2_dwbwd_kernel(const float* __restrict__ Y, int C, float scale, float w_int,
+                                                         const float* __restrict__ dd, const float* __restrict__ x,
+                                                         ud_bn_ref bn, const float* __restrict__ wt,
+                                                         const float* __restrict__ gate_alpha, int gate_mode,
+                                                         float* __restrict__ dz, double* __restrict__ s1,
+                                                         double* __restrict__ s2, float* __restrict__ wpart, int xcd_remap) {
+    using L = Lds<S, CB>;
+    static_assert(S * CB == NT, "one row-thread per (h, c)");
+    constexpr int P = (K - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Lre = lds;
+    float* Lim = lds + L::PLANE;
+    const int t = threadIdx.x;
+    const int c = t % CB, q = t / CB;
+    int cgroup, n;
+    work_item(xcd_remap, cgroup, n);
+    const int ch = cgroup * CB + c;
+    const bool cok = ch < C;
+    const int chl = cok ? ch : C - 1;
+    float re[S], im[S];
+    // ---- the adjoint transform, exactly irfft2_kernel<float, S, CB, false>
+    constexpr int NHELP = S - (S / 2 + 1);
+    if (q > S / 2) {
+        const int kx = q - (S / 2 + 1);
+        const float* src = Y + (((long)n * S) * L::WH + kx) * (2L * C) + chl + C;
+#pragma unroll
+        for (int ky = 0; ky < S; ++ky) re[ky] = cok ? src[(long)ky * L::WH * 2 * C] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < S; ++ky) Lim[kx * L::KSTRIDE + ky * CB + c] = re[ky];
+    } else {
+        const float* src = Y + (((long)n * S) * L::WH + q) * (2L * C) + chl;
+#pragma unroll
+        for (int ky = 0; ky < S; ++ky) re[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C] : 0.f;
+        if (q >= NHELP) {
+#pragma unroll
+            for (int ky = 0; ky < S; ++ky) im[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C + C] : 0.f;
+        }
+    }
+    // this thread's rows of the conv's output gradient and of the conv's raw input: in flight behind the transform
+    float ddr[S], er[S];
+    {
+        const long o = (((long)n * S + q) * S) * C + chl;
+#pragma unroll
+        for (int w = 0; w < S; ++w) {
+            ddr[w] = dd[o + (long)w * C];
+            er[w] = x[o + (long)w * C];
+        }
+    }
+    __syncthreads();
+    if (q <= S / 2) {
+        const float f = (q == 0 || q == S / 2) ? 1.f : w_int;
+        if (q < NHELP) {
+#pragma unroll
+            for (int ky = 0; ky < S; ++ky) im[brev<S>(ky)] = Lim[q * L::KSTRIDE + ky * CB + c];
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            re[k] *= f;
+            im[k] *= f;
+        }
+        fft_inreg<S, true>(re, im);
+#pragma unroll
+        for (int h = 0; h < S; ++h) {
+            Lre[q * L::KSTRIDE + h * CB + c] = re[h];
+            Lim[q * L::KSTRIDE + h * CB + c] = im[h];
+        }
+    }
+    __syncthreads();
+    {
+#pragma unroll
+        for (int kx = 0; kx <= S / 2; ++kx) {
+            const float zr = Lre[kx * L::KSTRIDE + q * CB + c];
+            const float zi = Lim[kx * L::KSTRIDE + q * CB + c];
+            re[brev<S>(kx)] = zr;
+            im[brev<S>(kx)] = (kx == 0 || kx == S / 2) ? 0.f : zi;
+            if (kx > 0 && kx < S / 2) {
+                re[brev<S>(S - kx)] = zr;
+                im[brev<S>(S - kx)] = -zi;
+            }
+        }
+        fft_inreg<S, true>(re, im);          // re[w] * scale = da_f(h = q, w)
+    }
+    // ---- BatchNorm in front of the conv: coefficients of this channel
+    float mu, is, ga, be;
+    {
+        const double m = bn.sum[chl] * bn.inv_count;
+        double vv = bn.sumsq[chl] * bn.inv_count - m * m;
+        if (vv < 0.0) vv = 0.0;
+        mu = (float)m;
+        is = (float)(1.0 / sqrt(vv + (double)bn.eps));
+        ga = bn.gamma[chl];
+        be = bn.beta[chl];
+    }
+    __syncthreads();                                    // the transform's planes are free: stage a and dd, [h][w][c]
+    float* A = lds;
+    float* D = lds + S * S * CB;
+#pragma unroll
+    for (int w = 0; w < S; ++w) {
+        A[(q * S + w) * CB + c] = cok ? ud_act(ga * ((er[w] - mu) * is) + be, bn.act) : 0.f;
+        D[(q * S + w) * CB + c] = cok ? ddr[w] : 0.f;
+    }
+    __syncthreads();
+    float tp[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) tp[i] = wt[(long)i * C + chl];
+    // ---- data gradient of row q: flipped taps over dd, + da_f, through act'(bn(x)); BatchNorm backward sums
+    double v1 = 0.0, v2 = 0.0;
+    {
+        float acc[S];
+#pragma unroll
+        for (int w = 0; w < S; ++w) acc[w] = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int ih = q + i - P;
+            if (ih < 0 || ih >= S) continue;
+            float in[S + K - 1];
+#pragma unroll
+            for (int j = 0; j < S + K - 1; ++j) in[j] = (j >= P && j < S + P) ? D[(ih * S + j - P) * CB + c] : 0.f;
+#pragma unroll
+            for (int w = 0; w < S; ++w)
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[w] += in[w + j] * tp[K * K - 1 - (i * K + j)];
+        }
+        const float gs = gate_factor_f(gate_alpha, gate_mode);
+        if (cok) {
+            float* o = dz + (((long)n * S + q) * S) * C + ch;
+#pragma unroll
+            for (int w = 0; w < S; ++w) {
+                const float xh = (er[w] - mu) * is;
+                float d = acc[w] * gs + re[w] * scale;
+                if (bn.act) d *= ud_act_grad_fast(ga * xh + be, bn.act);
+                o[(long)w * C] = d;
+                v1 += (double)d;
+                v2 += (double)d * (double)xh;
+            }
+        }
+    }
+    // ---- weight gradient of this image: accw[i][j] = sum_w a(q + i - P, w + j - P) * dd(q, w)
+    float accw[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) accw[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int ih = q + i - P;
+        if (ih < 0 || ih >= S) continue;
+        float in[S + K - 1];
+#pragma unroll
+        for (int j = 0; j < S + K - 1; ++j) in[j] = (j >= P && j < S + P) ? A[(ih * S + j - P) * CB + c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int w = 0; w < S; ++w) accw[i * K + j] += in[w + j] * ddr[w];
+    }
+    __syncthreads();                                    // A and D are consumed: fold the S row-threads of every channel
+    float* F = lds;                                     // [q][tap][c]
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) F[(q * K * K + i) * CB + c] = cok ? accw[i] : 0.f;
+    __syncthreads();
+    for (int i = t; i < K * K * CB; i += NT) {
+        const int tap = i / CB, cc = i % CB;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < S; ++r) sum += F[(r * K * K + tap) * CB + cc];
+        if (cgroup * CB + cc < C) wpart[((long)n * K * K + tap) * C + cgroup * CB + cc] = sum;
+    }
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(lds);
+    red[(q * CB + c) * 2] = v1;
+    red[(q * CB + c) * 2 + 1] = v2;
+    __syncthreads();
+    if (cok && q == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int r = 0; r < S; ++r) {
+            t1 += red[(r * CB + c) * 2];
+            t2 += red[(r * CB + c) * 2 + 1];
+        }
+        unsafeAtomicAdd(s1 + ch, t1);
+        unsafeAtomicAdd(s2 + ch, t2);
+    }
+}
+
+template <int S, int CB, int K>
+int launch_irfft2_dwbwd(const float* Y, int N, int C, float scale, float w_int, const float* dd, const float* x,
+                        const ud_bn_ref& bn, const float* wt, const float* gate_alpha, int gate_mode, float* dz, double* s1,
+                        double* s2, float* wpart, hipStream_t s) {
+    using LB = LdsBwd<S, CB, K>;
+    static bool attr_set = false;
+    if (LB::BYTES > 65536 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&irfft2_dwbwd_kernel<S, CB, K>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB::BYTES);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
+    hipLaunchKernelGGL((irfft2_dwbwd_kernel<S, CB, K>), grid, dim3(NT), LB::BYTES, s, Y, C, scale, w_int, dd, x, bn, wt,
+                       gate_alpha, gate_mode, dz, s1, s2, wpart, xcd_remap_on(CB * (int)sizeof(float)));
+    UD_LAUNCH_CHECK();
+    return 0;
 }
 
 struct RfftEx {
@@ -1281,6 +1505,21 @@ int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long 
         return launch_rfft2_t<float, 32, 16, true, 5>(xf, nullptr, N, C, scale, w_interior, ex, st);
     }
     return rfft2_dispatch<float>(xf, (float*)nullptr, N, S, C, scale, w_interior, &ex, st);
+}
+
+int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,
+                    const ud_bn_ref* bn, const float* wt, int K, const float* gate_alpha, int gate_mode, void* dz, double* s1,
+                    double* s2, float* wpart, ud_stream_t stream) {
+    if (N < 1 || C < 1 || !Y || !dd || !x || !bn || bn->G != 1 || !wt || !dz || !s1 || !s2 || !wpart) return UD_EINVAL;
+    if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (S == 8 && K == 5)
+        return launch_irfft2_dwbwd<8, 64, 5>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
+                                             gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
+    if (S == 8 && K == 3)
+        return launch_irfft2_dwbwd<8, 64, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
+                                             gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
+    return UD_EINVAL;
 }
 
 int ud_irfft2_mix(const void* Y, void* y, int N, int S, int C, float scale, float w_interior, const void* spat,

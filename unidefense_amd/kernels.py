@@ -2407,3 +2407,33 @@ def dwtile_bwd(dy, x, wt, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0
           rows, _pd(sacc) if bn is not None else None, _pd(sacc, Cc) if bn is not None else None, ws, N, H, W, Cc, K, pad_t,
           pad_l, h, _stream())
     return dz, dwt
+
+
+_IRFFT_DWBWD = True          # A/B: tools/run_with.py kernels._IRFFT_DWBWD=False
+
+
+def irfft2_dwbwd_ok(S, k, stride, pad, dtype):
+    """the SF block's spatial-branch backward inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel): the 8 x 8 maps"""
+    return (_IRFFT_DWBWD and S == 8 and k in (3, 5) and stride == 1 and tuple(pad) == ((k - 1) // 2,) * 4
+            and dtype == torch.float32)
+
+
+def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, sacc):
+    """da_f = irfft2(Y) (the adjoint of rfft2), dz = (gate * dwconv_bwd_data(dd) + da_f) * act'(bn(x)), sacc += BatchNorm backward
+    sums of dz, dw[C, k*k] = gate * sum act(bn(x))(window) * dd — ONE kernel over the (n, c) planes + the partials' fold.
+    Returns (dz, dw)."""
+    _chk(Y, dd, x, wt)
+    N, S, Wh, C2 = Y.shape
+    Cc = C2 // 2
+    assert dd.shape == (N, S, S, Cc) and x.shape == dd.shape
+    need = N * k * k * Cc
+    part = _DWTILE_PART.get(x.device.index)
+    if part is None or part.numel() < need:
+        part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
+    dz = torch.empty_like(dd)
+    dwt = empty((Cc, k * k), x)
+    _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
+          _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), _p(part), _stream())
+    _call("ud_dwtile_wgrad_finalize", _p(part), N, int(k), Cc, _p(gate_alpha), int(gate_mode), _p(dwt), _stream())
+    return dz, dwt
+

@@ -991,12 +991,13 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         Wf = dwm.freq_conv.weight.view(2 * Ce, 2 * Ce)
         if src_bn is not None:
             # a strip kernel needs a = swish(bn0(e)) materialised (rfft2_ex writes it); the tiled ones apply it on load
-            want_a = not (t_fwd and (t_wg or t_fused))
+            bwd_in_fft = K.irfft2_dwbwd_ok(S, k, stride, sp.pad, x.dtype)          # (the backward then needs no materialised a)
+            want_a = not (t_fwd and (t_wg or t_fused or bwd_in_fft))
             if K.rfft2_planes_ok(src, src_bn) and K.spectral_takes_planes(N * S * (S // 2 + 1), 2 * Ce, 2 * Ce, Wf):
                 # the transform writes the spectral GEMM's fp16 x 2 planes itself (scale from an a-priori bound): no split pass —
                 # and, stride 1, the depthwise conv of the plane it holds anyway: no conv kernel either
                 if K.rfft2_dw_ok(S, k, stride, sp.pad):
-                    xf, a, spat = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=not (t_wg or t_fused), update=True, dw_wt=wt,
+                    xf, a, spat = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=not (t_wg or t_fused or bwd_in_fft), update=True, dw_wt=wt,
                                                     dw_k=k)
                 else:
                     xf, a = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
@@ -1130,14 +1131,22 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 dyf2, dyf_amax = dyf.view(-1, 2 * Ce), getattr(dyf, "_ud_absmax", None)
             tape.wgrad(dwm.freq_conv.weight, lambda: K.spectral_wgrad(sctx, dyf2, dyf_amax), dyf2)
             dxf = K.spectral_dgrad(sctx, dyf2, dy_absmax=dyf_amax).view(xf_shape)
-            da_f = K.irfft2(dxf, s_f, 0.5)                                             # adjoint of rfft2
+            # 8 x 8 maps: the adjoint transform's kernel also does the depthwise conv's backward over the planes it holds
+            irdw = src_bn is not None and K.irfft2_dwbwd_ok(S, k, stride, sp.pad, x.dtype)
+            if not irdw:
+                da_f = K.irfft2(dxf, s_f, 0.5)                                         # adjoint of rfft2
         else:
             dd, dg1, db1 = K.normbwd_apply(d, dz1, None, 1.0, bn1, True, N, HWo, sb1, loc1)
             g_sp = dd
         tape.add_param_grad(blk._bn1.weight, dg1)
         tape.add_param_grad(blk._bn1.bias, db1)
         dz0 = dw_f = None
-        if t_fused:
+        if sf and irdw:
+            sb0 = K.zeros64(2 * src.shape[-1], x)
+            dz0, dw_f = K.irfft2_dwbwd(dxf, s_f, 0.5, g_sp, src, src_bn, wt, k, g_alpha, g_mode, sb0)
+            is_dz = True
+            tape.add_param_grad(dwm.weight, dw_f)
+        elif t_fused:
             # ---- depthwise data + weight gradient in one pass over (dd, src)
             if src_bn is not None:
                 sb0 = K.zeros64(2 * src.shape[-1], x)
