@@ -750,8 +750,8 @@ def test_se_scale_writes_the_project_planes_itself(N, HW, Cc):
     assert float(((h[0] + h[1] / 2048.0) * inv - yd).abs().max()) <= 2.0 ** -21 * top * loose
 
 
-@pytest.mark.parametrize("N,Cc,k", [(2, 64, 5), (3, 40, 3), (32, 96, 5)])
-def test_adjoint_transform_does_the_depthwise_backward(N, Cc, k):
+@pytest.mark.parametrize("N,S,Cc,k", [(2, 8, 64, 5), (3, 8, 40, 3), (32, 8, 96, 5), (2, 16, 32, 5), (3, 16, 48, 3), (8, 16, 96, 5)])
+def test_adjoint_transform_does_the_depthwise_backward(N, S, Cc, k):
     """ud_irfft2_dwbwd (csrc/fft.hip, round 5; the 8 x 8 maps): ONE kernel = ud_irfft2 (adjoint of rfft2) + the depthwise data
     gradient with gate, the added spectral-branch gradient, act'(bn(x)) and the BatchNorm backward sums + the depthwise weight
     gradient.  Against the separate kernels (themselves held to float64 autograd above): dz and the sums to 1e-6, the weight
@@ -759,7 +759,6 @@ def test_adjoint_transform_does_the_depthwise_backward(N, Cc, k):
     from unidefense_amd import kernels as K
     dev = _dev()
     K.reset_zero_pool()
-    S = 8
     g = torch.Generator().manual_seed(N * 10 + Cc + k)
     x = torch.randn(N, S, S, Cc, generator=g).to(dev)
     dd = torch.randn(N, S, S, Cc, generator=g).to(dev)

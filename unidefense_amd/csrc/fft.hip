@@ -574,7 +574,7 @@ struct LdsBwd {
 };
 
 template <int S, int CB, int K>
-__global__ __launch_bounds__(NT) void irfft2_dwbwd_kernel(const float* __restrict__ Y, int C, float scale, float w_int,
+__global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __restrict__ Y, int C, float scale, float w_int,
                                                          const float* __restrict__ dd, const float* __restrict__ x,
                                                          ud_bn_ref bn, const float* __restrict__ wt,
                                                          const float* __restrict__ gate_alpha, int gate_mode,
@@ -1519,6 +1519,12 @@ int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_int
     if (S == 8 && K == 3)
         return launch_irfft2_dwbwd<8, 64, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
+    if (S == 16 && K == 5)
+        return launch_irfft2_dwbwd<16, 32, 5>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
+                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
+    if (S == 16 && K == 3)
+        return launch_irfft2_dwbwd<16, 32, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
+                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
     return UD_EINVAL;
 }
 

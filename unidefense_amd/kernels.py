@@ -2410,11 +2410,12 @@ def dwtile_bwd(dy, x, wt, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0
 
 
 _IRFFT_DWBWD = True          # A/B: tools/run_with.py kernels._IRFFT_DWBWD=False
+_IRFFT_DWBWD_SIZES = (8, 16)
 
 
 def irfft2_dwbwd_ok(S, k, stride, pad, dtype):
     """the SF block's spatial-branch backward inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel): the 8 x 8 maps"""
-    return (_IRFFT_DWBWD and S == 8 and k in (3, 5) and stride == 1 and tuple(pad) == ((k - 1) // 2,) * 4
+    return (_IRFFT_DWBWD and S in _IRFFT_DWBWD_SIZES and k in (3, 5) and stride == 1 and tuple(pad) == ((k - 1) // 2,) * 4
             and dtype == torch.float32)
 
 
