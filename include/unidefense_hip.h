@@ -610,11 +610,12 @@ int ud_dwtile_wgrad_finalize(const float* part, int nparts, int K, int C, const 
  * fp32): da_f = scale * C2R(f(kx) Y) as ud_irfft2 (the adjoint of rfft2: w_interior = 1/2), then with dd = dL/d(conv output)
  * [N][S][S][C], x the conv's raw input and bn the BatchNorm in front of it:
  *   dz = (gate * conv_flipped(dd) + da_f) * act'(bn(x));  s1 += sum dz, s2 += sum dz * xhat;
- *   wpart[n][K*K][C] = sum_pixels act(bn(x))(window) * dd   of image n  (ud_dwtile_wgrad_finalize sums the N rows).
+ *   wpart[n][K*K][C] = sum_pixels act(bn(x))(window) * dd   of image n  (ud_dwtile_wgrad_finalize sums the N rows) — or, wacc
+ *   given (C * K*K floats, zeroed): wacc[c][tap] += gate * that sum by fp32 atomics, no fold launch (N adds per address).
  * Replaces ud_irfft2 + the depthwise weight-gradient kernel + its finalize + the depthwise data-gradient kernel. */
 int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,
                     const ud_bn_ref* bn, const float* wt, int K, const float* gate_alpha, int gate_mode, void* dz, double* s1,
-                    double* s2, float* wpart, ud_stream_t stream);
+                    double* s2, float* wpart, float* wacc, ud_stream_t stream);
 
 /* ---- large real 2-D FFT of image planes (csrc/fft_large.hip), S in {128, 256, 320} ------------------------------------
  * torch.fft.rfft2 on [N,3,S,S] images: the frequency reconstruction loss (model/unidefense.py:246-253; ResNet variants

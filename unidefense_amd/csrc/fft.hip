@@ -579,9 +579,11 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
                                                          ud_bn_ref bn, const float* __restrict__ wt,
                                                          const float* __restrict__ gate_alpha, int gate_mode,
                                                          float* __restrict__ dz, double* __restrict__ s1,
-                                                         double* __restrict__ s2, float* __restrict__ wpart, int xcd_remap) {
+                                                         double* __restrict__ s2, float* __restrict__ wpart,
+                                                         float* __restrict__ wacc, int xcd_remap) {
     using L = Lds<S, CB>;
     static_assert(S * CB == NT, "one row-thread per (h, c)");
+    const float gsw = gate_factor_f(gate_alpha, gate_mode);
     constexpr int P = (K - 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Lre = lds;
@@ -737,7 +739,12 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < S; ++r) sum += F[(r * K * K + tap) * CB + cc];
-        if (cgroup * CB + cc < C) wpart[((long)n * K * K + tap) * C + cgroup * CB + cc] = sum;
+        if (cgroup * CB + cc < C) {
+            // wacc: fp32 atomics straight onto the parameter-layout gradient [C][K*K] (zeroed by the caller; N adds per address,
+            // the gate applied here) instead of a partial row + the fold launch — the default; cfg.deterministic keeps the fold
+            if (wacc) atomicAdd(wacc + (long)(cgroup * CB + cc) * K * K + tap, sum * gsw);
+            else wpart[((long)n * K * K + tap) * C + cgroup * CB + cc] = sum;
+        }
     }
     __syncthreads();
     double* red = reinterpret_cast<double*>(lds);
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
 template <int S, int CB, int K>
 int launch_irfft2_dwbwd(const float* Y, int N, int C, float scale, float w_int, const float* dd, const float* x,
                         const ud_bn_ref& bn, const float* wt, const float* gate_alpha, int gate_mode, float* dz, double* s1,
-                        double* s2, float* wpart, hipStream_t s) {
+                        double* s2, float* wpart, float* wacc, hipStream_t s) {
     using LB = LdsBwd<S, CB, K>;
     static bool attr_set = false;
     if (LB::BYTES > 65536 && !attr_set) {
@@ -769,7 +776,7 @@ int launch_irfft2_dwbwd(const float* Y, int N, int C, float scale, float w_int, 
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
     hipLaunchKernelGGL((irfft2_dwbwd_kernel<S, CB, K>), grid, dim3(NT), LB::BYTES, s, Y, C, scale, w_int, dd, x, bn, wt,
-                       gate_alpha, gate_mode, dz, s1, s2, wpart, xcd_remap_on(CB * (int)sizeof(float)));
+                       gate_alpha, gate_mode, dz, s1, s2, wpart, wacc, xcd_remap_on(CB * (int)sizeof(float)));
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -1509,22 +1516,22 @@ int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long 
 
 int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,
                     const ud_bn_ref* bn, const float* wt, int K, const float* gate_alpha, int gate_mode, void* dz, double* s1,
-                    double* s2, float* wpart, ud_stream_t stream) {
-    if (N < 1 || C < 1 || !Y || !dd || !x || !bn || bn->G != 1 || !wt || !dz || !s1 || !s2 || !wpart) return UD_EINVAL;
+                    double* s2, float* wpart, float* wacc, ud_stream_t stream) {
+    if (N < 1 || C < 1 || !Y || !dd || !x || !bn || bn->G != 1 || !wt || !dz || !s1 || !s2 || (!wpart && !wacc)) return UD_EINVAL;
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (S == 8 && K == 5)
         return launch_irfft2_dwbwd<8, 64, 5>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                             gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
+                                             gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, wacc, st);
     if (S == 8 && K == 3)
         return launch_irfft2_dwbwd<8, 64, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                             gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
+                                             gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, wacc, st);
     if (S == 16 && K == 5)
         return launch_irfft2_dwbwd<16, 32, 5>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
+                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, wacc, st);
     if (S == 16 && K == 3)
         return launch_irfft2_dwbwd<16, 32, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, st);
+                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, wacc, st);
     return UD_EINVAL;
 }
 

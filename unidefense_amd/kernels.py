@@ -2427,14 +2427,20 @@ def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, 
     N, S, Wh, C2 = Y.shape
     Cc = C2 // 2
     assert dd.shape == (N, S, S, Cc) and x.shape == dd.shape
+    dz = torch.empty_like(dd)
+    if not CFG.deterministic:
+        # the weight gradient by fp32 atomics onto a zeroed [C, k*k] (N adds per address): no partial rows, no fold launch
+        dwt = zeros((Cc, k * k), x)
+        _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
+              _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), None, _p(dwt), _stream())
+        return dz, dwt
     need = N * k * k * Cc
     part = _DWTILE_PART.get(x.device.index)
     if part is None or part.numel() < need:
         part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
-    dz = torch.empty_like(dd)
     dwt = empty((Cc, k * k), x)
     _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
-          _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), _p(part), _stream())
+          _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), _p(part), None, _stream())
     _call("ud_dwtile_wgrad_finalize", _p(part), N, int(k), Cc, _p(gate_alpha), int(gate_mode), _p(dwt), _stream())
     return dz, dwt
 

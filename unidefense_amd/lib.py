@@ -176,7 +176,7 @@ _SIGNATURES = {
     "ud_dwtile_wgrad_part_rows": [_I, _I, _I],
     "ud_dwtile_wgrad": [_P, _BN, _P, _P, _I, _P, _P, _L] + [_I] * 9 + [_I, _I, _P],
     "ud_dwtile_wgrad_finalize": [_P, _I, _I, _I, _P, _I, _P, _P],
-    "ud_irfft2_dwbwd": [_P, _I, _I, _I, _F, _F, _P, _P, _BN, _P, _I, _P, _I, _P, _P, _P, _P, _P],
+    "ud_irfft2_dwbwd": [_P, _I, _I, _I, _F, _F, _P, _P, _BN, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     "ud_dwtile_bwd": [_P, _P, _BN, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P] + [_I] * 8 + [_P],
     "ud_rfft2_planes_ws_floats": [_L, _I],
     "ud_rfft2_planes": [_P, _P, _P, _L, _I, _F, _P],
