@@ -173,6 +173,15 @@ typedef struct {
 int ud_split_planes_h2t_multi(const ud_split_item* items_dev, int n, uint32_t* slots, int amax_blocks_total,
                               int split_blocks_total, ud_stream_t stream);
 
+/* A k x k conv (F.conv2d, any stride; model/resnet/exp.py:95-111, model/modules.py:111, the decoders) as a 1x1 conv on ud_gemm_p3:
+ * ud_im2col_planes writes its im2col matrix [N Hout Wout] x [KH KW Cin] (g->transposed == 0, Cin % 32 == 0) DIRECTLY as prec-2
+ * planes (P32 layout, one scale from `absmax`: 256 slots holding |x|max of the conv's input) — forward = planes . W^T, weight
+ * gradient = dY^T . planes, data gradient = ud_col2im(dY . W): dx[n][ih][iw][ci] = sum over the taps of the [N Hout Wout] x
+ * [KH KW Cin] fp32 matrix dcol (the gather adjoint to the im2col; dx written). */
+int ud_im2col_planes(const float* x, const ud_conv_geom* g, uint16_t* planes, long panel_stride, long plane_stride,
+                     const uint32_t* absmax, float* inv_scale, ud_stream_t stream);
+int ud_col2im(const float* dcol, const ud_conv_geom* g, float* dx, ud_stream_t stream);
+
 /* All k x k conv weights of a step into the [rows][tap][reduced channel] matrices the implicit-GEMM convs read, in ONE launch
  * (F.conv2d / ConvTranspose2d weights of model/unidefense.py:59-102, model/modules.py:111, the stem, model/resnet/exp.py:95-111):
  * src W[A][B][KH][KW] -> mode 0: dst[a][kh][kw][b]; mode 1: dst[b][KH-1-kh][KW-1-kw][a]; mode 2: dst[b][kh][kw][a].

@@ -819,3 +819,36 @@ def test_weight_layout_batch_matches_permutes():
         w.add_(1.0)                                # changed after begin(): the stale buffer must not be used
     assert batch.get(w, 0) is None and torch.equal(K.weight_layout(w, 0), ref(w.detach(), 0))
     K.end_forward()
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,k,stride,pad", [(8, 10, 128, 96, 3, 1, 1), (4, 16, 128, 160, 3, 2, 1), (2, 8, 64, 64, 5, 1, 2),
+                                                    (16, 10, 256, 128, 3, 1, 1)])
+def test_conv_as_im2col_planes_gemm(N, H, Ci, Co, k, stride, pad):
+    """k x k conv = 1x1 conv over its im2col matrix on the planes GEMM (round 5: kernels.im2col_planes -> ud_gemm_p3; data gradient =
+    GEMM + ud_col2im) — the path tape.conv_dense_any takes for Cin % 32 == 0 and KH KW Cin >= 1152: output, data gradient and
+    weight gradient against F.conv2d in float64, stride 1 and 2, 3 x 3 and 5 x 5; and the SAME conv on the in-kernel-split gather
+    GEMM (the path it replaces) for the record."""
+    dev = _dev()
+    from unidefense_amd import kernels as Kk
+    from unidefense_amd import tape as T
+    x = rnd(N, Ci, H, H, seed=11)
+    w = rnd(Co, Ci, k, k, seed=12, scale=0.05)
+    Ho = (H + 2 * pad - k) // stride + 1
+    gy = rnd(N, Co, Ho, Ho, seed=13)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    yr.backward(gy.double())
+    g = Kk.conv_geom(N, H, H, Ci, Ho, Ho, k, k, stride, pad, pad, 0)
+    min_flop = Kk._CONV_IM2COL_MIN_FLOP
+    for on in (True, False):
+        Kk._CONV_IM2COL, Kk._CONV_IM2COL_MIN_FLOP = on, 0.0          # (the test shapes are below the launch-bound threshold)
+        try:
+            assert Kk.conv_im2col_ok(g, Co, to_pix(x).to(dev)) == on
+            outs, gin, gp = run_tape(lambda t, a, b: T.conv_dense_any(t, a, b, stride, pad), [to_pix(x).to(dev)], [w.to(dev)],
+                                     lambda o: [to_pix(gy).to(dev)])
+        finally:
+            Kk._CONV_IM2COL, Kk._CONV_IM2COL_MIN_FLOP = True, min_flop
+        tag = "im2col planes" if on else "gather"
+        check(f"{tag}: y", to_nchw(outs[0]), yr)
+        check(f"{tag}: dx", to_nchw(gin[0]), xr.grad)
+        check(f"{tag}: dw", gp[0], wr.grad)

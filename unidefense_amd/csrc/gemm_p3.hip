@@ -679,6 +679,84 @@ __global__ __launch_bounds__(256) void split_h2_tensor_kernel(const float* __res
     *reinterpret_cast<u32x4*>(o + plane) = u32x4{b[0], b[1], b[2], b[3]};
 }
 
+// ---- a k x k conv as a 1x1 conv on the planes GEMM (round 5): its im2col matrix [N Hout Wout] x [KH KW Cin] written DIRECTLY as
+// fp16 x 2 planes (one scale for the tensor: |x|max of the conv's input, `absmax` slots as for split_h2_tensor_kernel).  The deep
+// 3 x 3 convs of the ResNet variants (model/resnet/exp.py:95-111; the 2048 -> 2048 filter conv of model/modules.py:111 at
+// 10 x 10) ran at 93-135 TFLOP/s-equivalent on the in-kernel-split gather GEMM; from this matrix all three products of the conv
+// (forward, data gradient as a GEMM + ud_col2im, weight gradient) run on ud_gemm_p3.  Cin % 32 == 0: a 32-column panel lies
+// inside one tap.  thread = 8 columns of a row, as in the split kernel; out-of-image taps are zeros.
+__global__ __launch_bounds__(256) void im2col_planes_kernel(const float* __restrict__ x, ud_conv_geom g, uint16_t* __restrict__ out,
+                                                            long panel, long plane, const uint32_t* __restrict__ absmax,
+                                                            float* __restrict__ inv_scale) {
+    const int tid = threadIdx.x;
+    const long M = (long)g.N * g.Hout * g.Wout;
+    const long row = (long)blockIdx.x * 64 + (tid >> 2);
+    const int pan = blockIdx.y;
+    const int col0 = pan * 32;                          // first column of the panel: tap col0 / Cin, channel col0 % Cin
+    const int tap = col0 / g.Cin, ci = col0 % g.Cin + (tid & 3) * 8;
+    const int kh = tap / g.KW, kw = tap % g.KW;
+    uint32_t mb = 0;
+#pragma unroll
+    for (int i = 0; i < ABSMAX_SLOTS / 64; ++i) mb = max(mb, absmax[(tid & 63) + 64 * i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, o, 64));
+    float s, inv;
+    h2_scale(mb, s, inv);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *inv_scale = inv;
+    if (row >= M) return;
+    const int ow = (int)(row % g.Wout);
+    const long t = row / g.Wout;
+    const int oh = (int)(t % g.Hout);
+    const long n = t / g.Hout;
+    const int ih = oh * g.stride - g.pad_t + kh, iw = ow * g.stride - g.pad_l + kw;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (ih >= 0 && ih < g.Hin && iw >= 0 && iw < g.Win) {
+        const float* src = x + ((n * g.Hin + ih) * g.Win + iw) * g.Cin + ci;
+        v0 = *reinterpret_cast<const f32x4*>(src);
+        v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+    uint32_t a[4], b[4];
+    split2h(v0[0] * s, v0[1] * s, a[0], b[0]);
+    split2h(v0[2] * s, v0[3] * s, a[1], b[1]);
+    split2h(v1[0] * s, v1[1] * s, a[2], b[2]);
+    split2h(v1[2] * s, v1[3] * s, a[3], b[3]);
+    uint16_t* o = out + (long)pan * panel + row * 32 + (tid & 3) * 8;
+    *reinterpret_cast<u32x4*>(o) = u32x4{a[0], a[1], a[2], a[3]};
+    *reinterpret_cast<u32x4*>(o + plane) = u32x4{b[0], b[1], b[2], b[3]};
+}
+
+// dx[n][ih][iw][ci] = sum over the taps of dcol[(n, oh, ow)][(kh KW + kw) Cin + ci] with (oh, ow) the output pixel whose window
+// holds (ih, iw) at that tap (stride 1 or 2): the adjoint of the im2col gather, a gather itself (no atomics)
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, ud_conv_geom g, float* __restrict__ dx) {
+    const int C4 = g.Cin / 4;
+    const long total = (long)g.N * g.Hin * g.Win * C4;
+    const long Kc = (long)g.KH * g.KW * g.Cin;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c4 = (int)(e % C4);
+        long pix = e / C4;
+        const int iw = (int)(pix % g.Win);
+        long t = pix / g.Win;
+        const int ih = (int)(t % g.Hin);
+        const long n = t / g.Hin;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < g.KH; ++kh) {
+            const int th = ih + g.pad_t - kh;
+            if (th < 0 || th % g.stride) continue;
+            const int oh = th / g.stride;
+            if (oh >= g.Hout) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                const int tw = iw + g.pad_l - kw;
+                if (tw < 0 || tw % g.stride) continue;
+                const int ow = tw / g.stride;
+                if (ow >= g.Wout) continue;
+                acc += *reinterpret_cast<const f32x4*>(dcol + ((n * g.Hout + oh) * g.Wout + ow) * Kc +
+                                                        (long)(kh * g.KW + kw) * g.Cin + c4 * 4);
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[e] = acc;
+    }
+}
+
 // ---- all weight matrices of a step in two launches -------------------------------------------------------------------
 // A train step splits ~50 weight matrices, each with an absmax launch and a split launch of a few microseconds.  The items
 // (pointers, shapes, first-block prefixes) live in a device table built once; block -> item by bisection of the prefixes.
@@ -761,6 +839,30 @@ extern "C" int ud_split_planes_h2t_multi(const ud_split_item* items_dev, int n, 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(absmax_multi_kernel, dim3((unsigned)amax_blocks_total), dim3(1024), 0, s, items_dev, n, slots);
     hipLaunchKernelGGL(split_h2_multi_kernel, dim3((unsigned)split_blocks_total), dim3(256), 0, s, items_dev, n, slots);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ud_im2col_planes(const float* x, const ud_conv_geom* g, uint16_t* planes, long panel_stride, long plane_stride,
+                                const uint32_t* absmax, float* inv_scale, ud_stream_t stream) {
+    if (!x || !g || !planes || !absmax || !inv_scale || g->transposed || g->Cin < 32 || g->Cin % 32 || g->N < 1 || g->Hin < 1 ||
+        g->Win < 1 || g->Hout < 1 || g->Wout < 1 || g->KH < 1 || g->KW < 1 || g->stride < 1)
+        return UD_EINVAL;
+    const long M = (long)g->N * g->Hout * g->Wout, Kc = (long)g->KH * g->KW * g->Cin;
+    if (panel_stride < M * 32 || panel_stride % 8 || plane_stride % 8 || plane_stride < (Kc / 32) * panel_stride) return UD_EINVAL;
+    dim3 grid((unsigned)ud_cdiv(M, 64), (unsigned)(Kc / 32));
+    hipLaunchKernelGGL(im2col_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, *g, planes, panel_stride, plane_stride,
+                       absmax, inv_scale);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ud_col2im(const float* dcol, const ud_conv_geom* g, float* dx, ud_stream_t stream) {
+    if (!dcol || !g || !dx || g->transposed || g->Cin % 4 || g->stride < 1) return UD_EINVAL;
+    const long total = (long)g->N * g->Hin * g->Win * (g->Cin / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dcol, *g, dx);
     UD_LAUNCH_CHECK();
     return 0;
 }

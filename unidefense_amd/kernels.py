@@ -920,7 +920,7 @@ def _p2_block_plans(x2, w2, want_stats=False):
     return _p2_plans_for(M, w2.shape[0], Kd, want_stats, w2, x2)
 
 
-def _p2_plans_for(M, N, Kd, want_stats, w2, x2, tune=True):
+def _p2_plans_for(M, N, Kd, want_stats, w2, x2, tune=True, force=False):
     """x2: the fp32 operand the on-line tuner may measure with (None: a producer-made Planes operand / a query — an unknown shape
     then takes the untuned rule)"""
     mode = CFG.spectral_p2
@@ -932,7 +932,7 @@ def _p2_plans_for(M, N, Kd, want_stats, w2, x2, tune=True):
     if plans == "?":
         if tune and x2 is not None and CFG.gemm_tune and not torch.cuda.is_current_stream_capturing():
             plans = _p2_tune(key, x2, w2, M, N, Kd, mode == "on", want_stats)
-        elif mode == "on" or (M >= _P2_MIN[0] and min(N, Kd) >= _P2_MIN[1]):
+        elif mode == "on" or force or (M >= _P2_MIN[0] and min(N, Kd) >= _P2_MIN[1]):
             plans = [("plain",) if want_stats else _p2_default_plan("nt", M, N, Kd), _p2_default_plan("nn", M, Kd, N),
                      _p2_default_plan("tn", N, Kd, M)]
         else:
@@ -942,7 +942,7 @@ def _p2_plans_for(M, N, Kd, want_stats, w2, x2, tune=True):
     return {"nt": tuple(plans[0]), "nn": tuple(plans[1]), "tn": tuple(plans[2])}
 
 
-def spectral_fwd(x2, w2, stats=None, x_absmax=None):
+def spectral_fwd(x2, w2, stats=None, x_absmax=None, force=False):
     """y[M, N] = x[M, K] @ w[N, K]^T (a 1x1 conv; the spectral convs are the square case) and the context of its backward.
     stats: BatchNorm accumulator of the result (gemm_nt's contract: returns ((y, done), ctx)).
     x2: the fp32 matrix, or Planes its producer wrote itself (only for shapes spectral_takes_planes accepts)."""
@@ -951,7 +951,7 @@ def spectral_fwd(x2, w2, stats=None, x_absmax=None):
     ctx.dy = None
     if isinstance(x2, Planes):
         ctx.M, ctx.K = x2.R, x2.C
-        ctx.plans = _p2_plans_for(ctx.M, ctx.N, ctx.K, stats is not None, w2, None)
+        ctx.plans = _p2_plans_for(ctx.M, ctx.N, ctx.K, stats is not None, w2, None, force=force)
         assert ctx.plans is not None
         ctx.x, ctx.w = x2, weight_planes(w2)
         return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, w2, stats=stats), ctx
@@ -2443,4 +2443,42 @@ def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, 
           _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), _p(part), None, _stream())
     _call("ud_dwtile_wgrad_finalize", _p(part), N, int(k), Cc, _p(gate_alpha), int(gate_mode), _p(dwt), _stream())
     return dz, dwt
+
+
+# ---- k x k convs as 1x1 convs on the planes GEMM: im2col written as planes (csrc/gemm_p3.hip: im2col_planes_kernel) ---------------
+_CONV_IM2COL = True                  # A/B: tools/run_with.py kernels._CONV_IM2COL=False
+_CONV_IM2COL_MIN_K = 1152            # reduction length KH*KW*Cin from which the im2col form is taken
+_CONV_IM2COL_MAX_BYTES = 768 << 20   # ... and the largest im2col matrix (4 bytes per element as planes)
+_CONV_IM2COL_MIN_FLOP = 5e9          # 2 M K N below which the conv is launch-bound: the gather GEMM is ONE launch (UDR18 bs 8 at 2.4 GFLOP per conv, the UDEB4 decoder at 3.8: slower as im2col; UDR50 bottlenecks at 7.5: faster)
+
+
+def conv_im2col_ok(g, Co, x):
+    """does this conv (ud_conv_geom g, Co output channels) run as im2col planes + ud_gemm_p3?  fp32, F.conv2d geometry, whole
+    32-channel panels per tap, a deep reduction (the shallow ones are HBM-bound: a 9x larger operand loses), pixel count a
+    multiple of 32 (whole K-tiles for the weight gradient)."""
+    M, Kc = g.N * g.Hout * g.Wout, g.KH * g.KW * g.Cin
+    return (_CONV_IM2COL and x.dtype == torch.float32 and not g.transposed and g.KH * g.KW > 1 and g.Cin % 32 == 0 and
+            Kc >= _CONV_IM2COL_MIN_K and 4 * M * Kc <= _CONV_IM2COL_MAX_BYTES and 2.0 * M * Kc * Co >= _CONV_IM2COL_MIN_FLOP and
+            CFG.spectral_p2 != "off" and
+            _p2_shape_ok(M, Co, Kc) and _call("ud_gemm_get_path") in (0, 2))
+
+
+def im2col_planes(x, g, absmax=None):
+    """the conv's im2col matrix [N Hout Wout, KH KW Cin] as prec-2 Planes (scale from |x|max: `absmax` slots or a pass here)"""
+    _chk(x)
+    M, Kc = g.N * g.Hout * g.Wout, g.KH * g.KW * g.Cin
+    if absmax is None:
+        absmax = empty((256,), x)
+        x2 = x.view(-1, g.Cin)
+        _call("ud_absmax", _p(x2), x2.shape[0], g.Cin, g.Cin, _p(absmax), _stream())
+    pl = Planes(M, Kc, x, 2, False)
+    _call("ud_im2col_planes", _p(x), C.byref(g), _p(pl.buf), pl.panel, pl.plane, _p(absmax), _p(pl.inv), _stream())
+    return pl
+
+
+def col2im(dcol, g):
+    _chk(dcol)
+    dx = empty((g.N, g.Hin, g.Win, g.Cin), dcol)
+    _call("ud_col2im", _p(dcol), C.byref(g), _p(dx), _stream())
+    return dx
 

@@ -77,6 +77,8 @@ _SIGNATURES = {
     "ud_gemm_set_path": [C.c_int],
     "ud_split_planes_h2t_multi": [_P, C.c_int, _P, C.c_int, C.c_int, _P],
     "ud_weight_layouts_multi": [_P, C.c_int, C.c_int, _P],
+    "ud_im2col_planes": [_P, C.POINTER(ConvGeom), _P, _L, _L, _P, _P, _P],
+    "ud_col2im": [_P, C.POINTER(ConvGeom), _P, _P],
     "ud_fft32_set_wave": [C.c_int],
     "ud_gemm_query_path": [C.POINTER(GemmDesc)],
     "ud_gemm_stats_slots": [C.POINTER(GemmDesc)],

@@ -142,6 +142,29 @@ def conv1x1(tape, x, w, need_dx=True):
     return y
 
 
+def _conv_im2col(tape, x, w, wmat, g, need_dx):
+    """A k x k conv as a 1x1 conv over its im2col matrix on the planes GEMM (kernels.im2col_planes): forward, weight gradient and
+    data gradient (a GEMM + col2im) share the three operands' planes like tape.conv1x1's."""
+    Co, Ci, KH, KW = w.shape
+    xcol = K.im2col_planes(x, g)
+    y2, ctx = K.spectral_fwd(xcol, wmat, force=True)
+    y = y2.view(g.N, g.Hout, g.Wout, Co)
+    if _needs(tape):
+        def bwd():
+            dy = tape.pop_grad(y)
+            if dy is None:
+                return
+            dy2 = dy.reshape(-1, Co)
+            if not dy2.is_contiguous():
+                dy2 = dy2.contiguous()
+            dw = K.spectral_wgrad(ctx, dy2)                            # [Co, KH*KW*Ci]
+            tape.add_param_grad(w, dw.view(Co, KH, KW, Ci).permute(0, 3, 1, 2).contiguous())
+            if need_dx:
+                tape.add_grad(x, K.col2im(K.spectral_dgrad(ctx, dy2), g))
+        tape.record(bwd)
+    return y
+
+
 def conv_dense(tape, x, w, stride, pad_t, pad_l, Hout, Wout, need_dx=True):
     """Dense k x k F.conv2d (weight [Cout,Cin,kh,kw]) as an implicit GEMM (model/unidefense.py:60,67,...;
     model/modules.py:111; stem conv model/efficientnet/model.py:185 with its static asymmetric pad)."""
@@ -149,6 +172,8 @@ def conv_dense(tape, x, w, stride, pad_t, pad_l, Hout, Wout, need_dx=True):
     Co, _, KH, KW = w.shape
     g = K.conv_geom(N, Hin, Win, Ci, Hout, Wout, KH, KW, stride, pad_t, pad_l, 0)
     wmat = K.weight_layout(w, 0)
+    if K.conv_im2col_ok(g, Co, x):
+        return _conv_im2col(tape, x, w, wmat, g, need_dx)
     y = K.conv_gather_nt(x, wmat, g)
     if _needs(tape):
         # dX = conv(dY, W flipped & transposed), pad = k-1-pad: its weight matrix comes out of the forward's one-launch batch
@@ -761,6 +786,8 @@ def conv_dense_any(tape, x, w, stride, pad, need_dx=True):
     Wout = (Win + 2 * pad - KW) // stride + 1
     g = K.conv_geom(N, Hin, Win, Ci, Hout, Wout, KH, KW, stride, pad, pad, 0)
     wmat = K.weight_layout(w, 0)
+    if K.conv_im2col_ok(g, Co, x):
+        return _conv_im2col(tape, x, w, wmat, g, need_dx)
     y = K.conv_gather_nt(x, wmat, g)
     if _needs(tape):
         wd = K.weight_layout(w, 2) if need_dx else None
