@@ -512,7 +512,8 @@ def test_instancenorm_swish(N, H, C):
                                       (12, 1632, "ortho"), (12, 272, None), (24, 672, "ortho"), (24, 960, "ortho"),
                                       (48, 336, "ortho"), (48, 5, None),
                                       # any other side: DFT matrices on the GEMM kernels (95 = 5 * 19: the 380 x 380 trunk's first SF block)
-                                      (95, 192, "ortho"), (95, 8, None), (14, 24, "ortho")])
+                                      # (two batched GEMMs on the pixel-major tensor; 13: matrix rows padded to 4; C = 6: the plane-copy form)
+                                      (95, 192, "ortho"), (95, 8, None), (14, 24, "ortho"), (13, 12, None), (14, 6, "ortho")])
 def test_rfft2_irfft2(S, C, norm):
     dev = _dev()
     from unidefense_amd import tape as T

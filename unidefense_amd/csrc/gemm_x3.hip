@@ -649,7 +649,10 @@ bool ud_gemm_x3_eligible(const ud_gemm_desc& d, bool a_vec, bool b_vec) {
         return false;
     if (!a_vec || !b_vec) return false;
     if ((d.a_mode == 0 || d.b_mode == 0) && d.K % 4 != 0) return false;
-    if (d.a_mode == 1 && d.M % 4 != 0) return false;
+    // row-contiguous A ([K][lda], rows of the product along the contiguous index): the loads are 2 / 4 consecutive m wide, so M is
+    // a multiple of 4 — or the rows carry slack up to the next multiple (lda >= ceil4(M): the DFT matrices of kernels.py, padded
+    // with zeros by their maker); what the slack holds only reaches product rows >= M, which are not stored
+    if (d.a_mode == 1 && d.M % 4 != 0 && d.lda < ((d.M + 3) & ~3)) return false;
     if (d.b_mode == 1 && d.N % 4 != 0) return false;
     return true;
 }

@@ -1440,9 +1440,101 @@ def _fft_col_weights(S, w_interior, like, twice):
     return f
 
 
+_DFT_PIXEL_CACHE = {}
+
+
+def _ceil4(v):
+    return -(-v // 4) * 4
+
+
+def _dft_pixel_mats(S, scale, w_interior, inverse, device):
+    """The two matrices of a pixel-major 2-D real DFT done as two batched GEMMs on the tensor AS IT LIES ([N, S, S, C] <->
+    [N, S, S/2+1, 2C]; no plane copies), stored k-major [K][ceil4(M)] (ud_gemm a_mode 1: no condition on the reduction length, the
+    slack columns zero) — float64 on the host, once per (S, scale, w, direction, device):
+      forward   pass 1, per image, along h:      T[(ky, ri), (w, c)]  = sum_h   A1[(ky, ri), h]      x[h, (w, c)]
+                pass 2, per (image, ky), along w: Y[(kx, ri), c]       = sum_{ri', w} A2[(kx, ri), (ri', w)] T[(ri', w), c]
+                (scale and the half spectrum's column weights folded into A2)
+      inverse   pass 1, per (image, ky), along kx: U[(ri', w), c]      = sum_{kx, ri} A3[(ri', w), (kx, ri)] Y[(kx, ri), c]
+                (Hermitian multiplicity x column weight folded in; U complex: x = Re sum_ky e^{+i theta} U)
+                pass 2, per image, along ky:      x[h, (w, c)]         = sum_{ky, ri'} A4[h, (ky, ri')]    U[(ky, ri'), (w, c)]"""
+    key = (S, float(scale), float(w_interior), bool(inverse), str(device))
+    m = _DFT_PIXEL_CACHE.get(key)
+    if m is not None:
+        return m
+    Wh = S // 2 + 1
+    k = torch.arange(S, dtype=torch.float64)
+    ang = 2.0 * math.pi * torch.outer(k, k) / S                     # [k][position]
+    cs, sn = torch.cos(ang), torch.sin(ang)
+    selfconj = torch.zeros(Wh, dtype=torch.bool)
+    selfconj[0] = True
+    if S % 2 == 0:
+        selfconj[Wh - 1] = True
+    colw = torch.where(selfconj, torch.ones(Wh, dtype=torch.float64), torch.full((Wh,), float(w_interior), dtype=torch.float64))
+    if not inverse:
+        a1 = torch.zeros(S, _ceil4(2 * S), dtype=torch.float64)            # [h][(ky, ri)]
+        a1[:, 0:2 * S:2] = cs.t()                                          # e^{-i theta}: Re = cos, Im = -sin
+        a1[:, 1:2 * S:2] = -sn.t()
+        g = colw * float(scale)
+        a2 = torch.zeros(2 * S, _ceil4(2 * Wh), dtype=torch.float64)       # [(ri', w)][(kx, ri)]
+        c2, s2 = (cs[:Wh] * g[:, None]).t(), (sn[:Wh] * g[:, None]).t()    # [w][kx]
+        a2[:S, 0:2 * Wh:2], a2[S:, 0:2 * Wh:2] = c2, s2                    # Re Y = g (Tr cos + Ti sin)
+        a2[:S, 1:2 * Wh:2], a2[S:, 1:2 * Wh:2] = -s2, c2                   # Im Y = g (Ti cos - Tr sin)
+        mats = (a1, a2)
+    else:
+        mf = colw * torch.where(selfconj, 1.0, 2.0)
+        a3 = torch.zeros(2 * Wh, _ceil4(2 * S), dtype=torch.float64)       # [(kx, ri)][(ri', w)]
+        c3, s3 = cs[:Wh] * mf[:, None], sn[:Wh] * mf[:, None]              # [kx][w]
+        a3[0::2, :S], a3[1::2, :S] = c3, -s3                               # Re U = mf (Yr cos - Yi sin)
+        a3[0::2, S:2 * S], a3[1::2, S:2 * S] = s3, c3                      # Im U = mf (Yr sin + Yi cos)
+        a4 = torch.zeros(2 * S, _ceil4(S), dtype=torch.float64)            # [(ky, ri')][h]
+        a4[0::2, :S] = cs * float(scale)                                   # x = scale (Ur cos - Ui sin)
+        a4[1::2, :S] = -sn * float(scale)
+        mats = (a3, a4)
+    m = _DFT_PIXEL_CACHE[key] = tuple(t.to(torch.float32).to(device).contiguous() for t in mats)
+    return m
+
+
+_FFT_GENERIC_PIXEL = True          # A/B: tools/run_with.py kernels._FFT_GENERIC_PIXEL=False (the plane-copy form)
+
+
 def _rfft2_generic(x, scale, w_interior):
-    """rfft2 of ud_rfft2's contract for any side: pixel-major -> (padded) planes in one strided copy, three DFT-matrix GEMMs
-    (_dft_planes_fwd), planes -> pixel-major with the column weights in one pass"""
+    """rfft2 of ud_rfft2's contract for any side (95 = 5 * 19 of the 380 x 380 trunk): two batched GEMMs against DFT matrices on
+    the pixel-major tensor itself (_dft_pixel_mats) — no plane copies, no torch kernel"""
+    N, S, _, Cc = x.shape
+    if not (_FFT_GENERIC_PIXEL and Cc % 4 == 0):
+        return _rfft2_generic_planes(x, scale, w_interior)
+    Wh = S // 2 + 1
+    xs = x if x.dtype == torch.float32 else x.float()
+    a1, a2 = _dft_pixel_mats(S, scale, w_interior, False, x.device)
+    T = empty((N, 2 * S, S, Cc), xs)
+    _gemm(a1, xs, T, 2 * S, S * Cc, S, a1.shape[1], S * Cc, S * Cc, 1, 1, 0, batch=N, strideA=0, strideB=S * S * Cc,
+          strideC=2 * S * S * Cc)
+    Y = empty((N, S, Wh, 2 * Cc), xs)
+    _gemm(a2, T, Y, 2 * Wh, Cc, 2 * S, a2.shape[1], Cc, Cc, 1, 1, 0, batch=N * S, strideA=0, strideB=2 * S * Cc,
+          strideC=2 * Wh * Cc)
+    return Y if x.dtype == torch.float32 else Y.to(x.dtype)
+
+
+def _irfft2_generic(Y, scale, w_interior):
+    """irfft2 of ud_irfft2's contract for any side: x = scale * C2R(f Y), as two batched GEMMs on the pixel-major tensors"""
+    N, S, Wh, C2 = Y.shape
+    Cc = C2 // 2
+    if not (_FFT_GENERIC_PIXEL and Cc % 4 == 0):
+        return _irfft2_generic_planes(Y, scale, w_interior)
+    Ys = Y if Y.dtype == torch.float32 else Y.float()
+    a3, a4 = _dft_pixel_mats(S, scale, w_interior, True, Y.device)
+    U = empty((N, S, 2 * S, Cc), Ys)                       # [n][ky][(ri', w)][c]
+    _gemm(a3, Ys, U, 2 * S, Cc, 2 * Wh, a3.shape[1], Cc, Cc, 1, 1, 0, batch=N * S, strideA=0, strideB=2 * Wh * Cc,
+          strideC=2 * S * Cc)
+    x = empty((N, S, S, Cc), Ys)
+    _gemm(a4, U, x, S, S * Cc, 2 * S, a4.shape[1], S * Cc, S * Cc, 1, 1, 0, batch=N, strideA=0, strideB=2 * S * S * Cc,
+          strideC=S * S * Cc)
+    return x if Y.dtype == torch.float32 else x.to(Y.dtype)
+
+
+def _rfft2_generic_planes(x, scale, w_interior):
+    """the plane-copy form (channel counts that are not multiples of 4): pixel-major -> (padded) planes in one strided copy, three
+    DFT-matrix GEMMs (_dft_planes_fwd), planes -> pixel-major with the column weights in one pass"""
     N, S, _, Cc = x.shape
     Wh = S // 2 + 1
     Sp = -(-S // 4) * 4
@@ -1455,9 +1547,9 @@ def _rfft2_generic(x, scale, w_interior):
     return Y.view(N, S, Wh, 2 * Cc)
 
 
-def _irfft2_generic(Y, scale, w_interior):
-    """irfft2 of ud_irfft2's contract for any side: x = scale * F^T(m f Y), F the unnormalised rfft2 (its adjoint on the GEMM
-    kernels: _dft_planes_adj), m the Hermitian multiplicity, f = w_interior off the self-conjugate columns"""
+def _irfft2_generic_planes(Y, scale, w_interior):
+    """x = scale * F^T(m f Y), F the unnormalised rfft2 (its adjoint on the GEMM kernels: _dft_planes_adj), m the Hermitian
+    multiplicity, f = w_interior off the self-conjugate columns"""
     N, S, Wh, C2 = Y.shape
     Cc = C2 // 2
     Whp = -(-Wh // 4) * 4
