@@ -473,14 +473,25 @@ int ud_se_scale_bn_planes(const void* x, const ud_bn_ref* bn, const float* s, ui
 int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const void* skip,
     void* out, int G, int R, int C, int f16, uint32_t* absmax, ud_stream_t stream);
 /* BatchNorm backward, reductions: dz = dy * (keep[g] * inv_keep) * act'(z)  (dy_is_dz: dz = dy);
- * s1[c] += sum dz, s2[c] += sum dz * xhat */
+ * s1[c] += sum dz, s2[c] += sum dz * xhat;  s3 (optional) [c] += sum dz^2, rounded up (ud_normbwd_apply_planes' energy) */
 int ud_normbwd_sums(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn, int
-    dy_is_dz, int G, int R, int C, double* s1, double* s2, double* ws, int f16, ud_stream_t stream);
+    dy_is_dz, int G, int R, int C, double* s1, double* s2, double* s3, double* ws, int f16, ud_stream_t stream);
 /* dx = gamma invstd (dz - s1 inv_count - xhat s2 inv_count); s1/s2: sums over ALL ranks, s1_local/s2_local: this
  * rank's sums -> dbeta / dgamma (NULL: not written) */
 int ud_normbwd_apply(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn, int
     dy_is_dz, const double* s1, const double* s2, const double* s1_local, const double* s2_local, int G, int R,
     int C, void* dx, float* dgamma, float* dbeta, int f16, uint32_t* absmax, ud_stream_t stream);
+/* ud_normbwd_apply (fp32) writing dx DIRECTLY as the fp16 x 2 planes of the GEMMs that read it (the 1x1 conv's weight and data
+ * gradient on ud_gemm_p3 prec 2; P32 layout over [G R] x C, pad columns of the last panel zero) — no fp32 dx, no split pass.  One
+ * power-of-two scale for the tensor from an a-priori bound: dx_c = gamma_c invstd_c P(dz_c) with P a contraction, so
+ * |dx| <= max_c |gamma_c invstd_c| sqrt(energy[c]), energy[c] >= sum_rows dz_c^2 over the whole batch (ud_normbwd_sums' s3 or
+ * ud_irfft2_dwbwd's s3, reduced over the ranks like s1 / s2); *inv_scale receives 1 / scale.  A bound above the true maximum
+ * costs log2(bound / max) of the 18 binades in which an element keeps its 22 bits, nothing of the large elements' precision. */
+int ud_normbwd_apply_planes(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                            int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
+                            const double* s2_local, const double* energy, int G, int R, int C, uint16_t* planes,
+                            long panel_stride, long plane_stride, float* inv_scale, float* dgamma, float* dbeta,
+                            ud_stream_t stream);
 /* SE backward, the two small FC layers (model.py:119-121) in two launches:
  *   a: dpre = dgate[n][c] * sigmoid'(s2);  ds1[n][i] = swish'(s1) sum_c dpre W_e[c][i];
  *      dW_e[c][i] = sum_n dpre swish(s1[n][i]);  db_e[c] = sum_n dpre
@@ -618,13 +629,14 @@ int ud_dwtile_wgrad_finalize(const float* part, int nparts, int K, int C, const 
 /* Backward of an SF block's spatial branch inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel; S = 8, K in {3, 5},
  * fp32): da_f = scale * C2R(f(kx) Y) as ud_irfft2 (the adjoint of rfft2: w_interior = 1/2), then with dd = dL/d(conv output)
  * [N][S][S][C], x the conv's raw input and bn the BatchNorm in front of it:
- *   dz = (gate * conv_flipped(dd) + da_f) * act'(bn(x));  s1 += sum dz, s2 += sum dz * xhat;
+ *   dz = (gate * conv_flipped(dd) + da_f) * act'(bn(x));  s1 += sum dz, s2 += sum dz * xhat;  s3 (optional) += sum dz^2, rounded
+ *   up (the energy bound ud_normbwd_apply_planes takes);
  *   wpart[n][K*K][C] = sum_pixels act(bn(x))(window) * dd   of image n  (ud_dwtile_wgrad_finalize sums the N rows) — or, wacc
  *   given (C * K*K floats, zeroed): wacc[c][tap] += gate * that sum by fp32 atomics, no fold launch (N adds per address).
  * Replaces ud_irfft2 + the depthwise weight-gradient kernel + its finalize + the depthwise data-gradient kernel. */
 int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,
                     const ud_bn_ref* bn, const float* wt, int K, const float* gate_alpha, int gate_mode, void* dz, double* s1,
-                    double* s2, float* wpart, float* wacc, ud_stream_t stream);
+                    double* s2, double* s3, float* wpart, float* wacc, ud_stream_t stream);
 
 /* ---- large real 2-D FFT of image planes (csrc/fft_large.hip), S in {128, 256, 320} ------------------------------------
  * torch.fft.rfft2 on [N,3,S,S] images: the frequency reconstruction loss (model/unidefense.py:246-253; ResNet variants

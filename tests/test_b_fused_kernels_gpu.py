@@ -775,7 +775,68 @@ def test_adjoint_transform_does_the_depthwise_backward(N, S, Cc, k):
     dz_ref, dw_ref = K.dwtile_bwd(dd, x, wt, k, pad, pad, bn=bn, gate_alpha=alpha, gate_mode=2, add=da_f, sacc=s_ref)
     s_new = K.zeros64(2 * Cc, x)
     dz, dw = K.irfft2_dwbwd(Yf, 1.0 / S, 0.5, dd, x, bn, wt, k, alpha, 2, s_new)
+    # a 3C accumulator also receives the energy of dz per channel, rounded up (ud_normbwd_apply_planes' bound)
+    s_en = K.zeros64(3 * Cc, x)
+    K.irfft2_dwbwd(Yf, 1.0 / S, 0.5, dd, x, bn, wt, k, alpha, 2, s_en)
     torch.cuda.synchronize()
     assert _rel(dz, dz_ref.double().cpu()) < 2e-6
     assert _rel(s_new, s_ref.cpu()) < 1e-6
     assert _rel(dw, dw_ref.double().cpu()) < 2e-6
+    assert _rel(s_en[:2 * Cc], s_ref.cpu()) < 1e-6
+    en_ref = dz.double().pow(2).sum((0, 1, 2))
+    ratio = (s_en[2 * Cc:] / en_ref).cpu()
+    assert float(ratio.min()) >= 1.0 and float(ratio.max()) < 1.001, (float(ratio.min()), float(ratio.max()))
+
+
+@pytest.mark.parametrize("N,HW,Cc,act,dz", [(2, 64, 96, 0, False), (3, 100, 40, 1, True), (32, 64, 272, 0, False), (4, 256, 960, 1, True)])
+def test_normbwd_apply_writes_the_gemm_planes_itself(N, HW, Cc, act, dz):
+    """ud_normbwd_sums' third sum + ud_normbwd_apply_planes (round 5): the BatchNorm backward in front of a 1x1 conv writes its
+    result straight into the fp16 x 2 planes the conv's weight / data gradient GEMMs read, scaled by the a-priori bound
+    max_c |gamma_c invstd_c| sqrt(sum dz_c^2).  The sums equal the two-sum launch's; the energy is sum dz^2 rounded up; the planes
+    re-assemble to ud_normbwd_apply's fp32 result to 2^-21 of the scale; the bound holds and is within 2^7 of the exact maximum;
+    the pad columns of the last 32-wide panel are zero (they multiply as k in the data gradient)."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N + HW + Cc)
+    x = torch.randn(N, HW, Cc, generator=g).to(dev)
+    dy = torch.randn(N, HW, Cc, generator=g).to(dev) * torch.rand(Cc, generator=g).to(dev)
+    keep = (torch.rand(N, generator=g) < 0.8).float().to(dev) if not dz else None
+    inv_keep = 1.25 if not dz else 1.0
+    gamma, beta = (1.0 + 0.3 * torch.randn(Cc, generator=g)).to(dev), (0.2 * torch.randn(Cc, generator=g)).to(dev)
+    acc = K.zeros64(2 * Cc, x)
+    K.colstats(x.view(-1, Cc), acc)
+    bn = K.DeferredBN(acc, Cc, N * HW, gamma, beta, 1e-3, act)
+    s2 = K.zeros64(2 * Cc, x)
+    K.normbwd_sums(x, dy, keep, inv_keep, bn, dz, N, HW, s2)
+    s3 = K.zeros64(3 * Cc, x)
+    K.normbwd_sums(x, dy, keep, inv_keep, bn, dz, N, HW, s3)
+    ref, dg_ref, db_ref = K.normbwd_apply(x, dy, keep, inv_keep, bn, dz, N, HW, s2)
+    pl, dg, db = K.normbwd_apply_planes(x, dy, keep, inv_keep, bn, dz, N, HW, s3)
+    # the incoming gradient as the kernels see it (dz): from the fp32 kernel with gamma = invstd-free identity is not available, so
+    # restate it: dy * keep * inv_keep * act'(bn(x))
+    xd = x.double()
+    mean, var = xd.mean((0, 1)), xd.var((0, 1), unbiased=False)
+    xh = (xd - mean) / torch.sqrt(var + 1e-3)
+    z = gamma.double() * xh + beta.double()
+    gin = dy.double()
+    if not dz:
+        gin = gin * (keep.double() * inv_keep).view(N, 1, 1)
+        if act:
+            sg = torch.sigmoid(z)
+            gin = gin * (sg * (1 + z * (1 - sg)))
+    torch.cuda.synchronize()
+    assert _rel(s3[:2 * Cc], s2.cpu()) < 1e-12
+    ratio = (s3[2 * Cc:] / gin.pow(2).sum((0, 1))).cpu()
+    assert float(ratio.min()) >= 1.0 - 1e-6 and float(ratio.max()) < 1.001, (float(ratio.min()), float(ratio.max()))
+    assert _rel(dg, dg_ref.double().cpu()) < 1e-6 and _rel(db, db_ref.double().cpu()) < 1e-6
+    R = N * HW
+    full = pl.buf.view(2, pl.npanel, pl.panel // 32, 32)[:, :, :R].view(torch.float16).permute(0, 2, 1, 3).reshape(2, R, pl.npanel * 32)
+    h = full[:, :, :Cc].double()
+    assert float(full[:, :, Cc:].abs().max() if pl.npanel * 32 > Cc else 0.0) == 0.0
+    inv = float(pl.inv)
+    yd = ref.view(R, Cc).double()
+    top = float(yd.abs().max())
+    loose = 2.0 ** 15 / (top / inv)
+    assert 1.0 <= loose < 128.0, loose
+    assert float(((h[0] + h[1] / 2048.0) * inv - yd).abs().max()) <= 2.0 ** -21 * top * loose

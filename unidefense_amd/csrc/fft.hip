@@ -579,8 +579,8 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
                                                          ud_bn_ref bn, const float* __restrict__ wt,
                                                          const float* __restrict__ gate_alpha, int gate_mode,
                                                          float* __restrict__ dz, double* __restrict__ s1,
-                                                         double* __restrict__ s2, float* __restrict__ wpart,
-                                                         float* __restrict__ wacc, int xcd_remap) {
+                                                         double* __restrict__ s2, double* __restrict__ s3,
+                                                         float* __restrict__ wpart, float* __restrict__ wacc, int xcd_remap) {
     using L = Lds<S, CB>;
     static_assert(S * CB == NT, "one row-thread per (h, c)");
     const float gsw = gate_factor_f(gate_alpha, gate_mode);
@@ -683,6 +683,7 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
     for (int i = 0; i < K * K; ++i) tp[i] = wt[(long)i * C + chl];
     // ---- data gradient of row q: flipped taps over dd, + da_f, through act'(bn(x)); BatchNorm backward sums
     double v1 = 0.0, v2 = 0.0;
+    float v3 = 0.f;          // s3 != NULL: sum dz^2, the energy bound ud_normbwd_apply_planes scales its planes by
     {
         float acc[S];
 #pragma unroll
@@ -710,6 +711,7 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
                 o[(long)w * C] = d;
                 v1 += (double)d;
                 v2 += (double)d * (double)xh;
+                v3 += d * d;
             }
         }
     }
@@ -748,24 +750,27 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
     }
     __syncthreads();
     double* red = reinterpret_cast<double*>(lds);
-    red[(q * CB + c) * 2] = v1;
-    red[(q * CB + c) * 2 + 1] = v2;
+    red[(q * CB + c) * 3] = v1;
+    red[(q * CB + c) * 3 + 1] = v2;
+    red[(q * CB + c) * 3 + 2] = (double)v3 * 1.0001;          // rounded up: an upper bound
     __syncthreads();
     if (cok && q == 0) {
-        double t1 = 0.0, t2 = 0.0;
+        double t1 = 0.0, t2 = 0.0, t3 = 0.0;
         for (int r = 0; r < S; ++r) {
-            t1 += red[(r * CB + c) * 2];
-            t2 += red[(r * CB + c) * 2 + 1];
+            t1 += red[(r * CB + c) * 3];
+            t2 += red[(r * CB + c) * 3 + 1];
+            t3 += red[(r * CB + c) * 3 + 2];
         }
         unsafeAtomicAdd(s1 + ch, t1);
         unsafeAtomicAdd(s2 + ch, t2);
+        if (s3) unsafeAtomicAdd(s3 + ch, t3);
     }
 }
 
 template <int S, int CB, int K>
 int launch_irfft2_dwbwd(const float* Y, int N, int C, float scale, float w_int, const float* dd, const float* x,
                         const ud_bn_ref& bn, const float* wt, const float* gate_alpha, int gate_mode, float* dz, double* s1,
-                        double* s2, float* wpart, float* wacc, hipStream_t s) {
+                        double* s2, double* s3, float* wpart, float* wacc, hipStream_t s) {
     using LB = LdsBwd<S, CB, K>;
     static bool attr_set = false;
     if (LB::BYTES > 65536 && !attr_set) {
@@ -776,7 +781,7 @@ int launch_irfft2_dwbwd(const float* Y, int N, int C, float scale, float w_int, 
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
     hipLaunchKernelGGL((irfft2_dwbwd_kernel<S, CB, K>), grid, dim3(NT), LB::BYTES, s, Y, C, scale, w_int, dd, x, bn, wt,
-                       gate_alpha, gate_mode, dz, s1, s2, wpart, wacc, xcd_remap_on(CB * (int)sizeof(float)));
+                       gate_alpha, gate_mode, dz, s1, s2, s3, wpart, wacc, xcd_remap_on(CB * (int)sizeof(float)));
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -1516,22 +1521,22 @@ int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long 
 
 int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,
                     const ud_bn_ref* bn, const float* wt, int K, const float* gate_alpha, int gate_mode, void* dz, double* s1,
-                    double* s2, float* wpart, float* wacc, ud_stream_t stream) {
+                    double* s2, double* s3, float* wpart, float* wacc, ud_stream_t stream) {
     if (N < 1 || C < 1 || !Y || !dd || !x || !bn || bn->G != 1 || !wt || !dz || !s1 || !s2 || (!wpart && !wacc)) return UD_EINVAL;
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (S == 8 && K == 5)
         return launch_irfft2_dwbwd<8, 64, 5>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                             gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, wacc, st);
+                                             gate_alpha, gate_mode, (float*)dz, s1, s2, s3, wpart, wacc, st);
     if (S == 8 && K == 3)
         return launch_irfft2_dwbwd<8, 64, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                             gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, wacc, st);
+                                             gate_alpha, gate_mode, (float*)dz, s1, s2, s3, wpart, wacc, st);
     if (S == 16 && K == 5)
         return launch_irfft2_dwbwd<16, 32, 5>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, wacc, st);
+                                              gate_alpha, gate_mode, (float*)dz, s1, s2, s3, wpart, wacc, st);
     if (S == 16 && K == 3)
         return launch_irfft2_dwbwd<16, 32, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                              gate_alpha, gate_mode, (float*)dz, s1, s2, wpart, wacc, st);
+                                              gate_alpha, gate_mode, (float*)dz, s1, s2, s3, wpart, wacc, st);
     return UD_EINVAL;
 }
 

@@ -265,11 +265,12 @@ __global__ __launch_bounds__(NT) void normbwd_sums_kernel(RedGeom q, const T* __
                                                           const T* __restrict__ dy, const float* __restrict__ keep,
                                                           float inv_keep, ud_bn_ref bn, int dy_is_dz,
                                                           double* __restrict__ s1, double* __restrict__ s2,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ s3, double* __restrict__ part) {
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
     const In4<T> x4{x}, d4{dy};
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 en = {0.f, 0.f, 0.f, 0.f};          // s3 != NULL: sum dz^2 (the energy bound of ud_normbwd_apply_planes' scale)
     if (active) {
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
         const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
@@ -283,13 +284,35 @@ __global__ __launch_bounds__(NT) void normbwd_sums_kernel(RedGeom q, const T* __
                 v[e] += (double)dz[e];
                 v[4 + e] += (double)dz[e] * (double)xh[e];
             }
+            en += dz * dz;
+        }
+    }
+    if (s3) {          // (uniform) rounded UP a little: the fp32 partial sums must never under-estimate
+        double ev[8] = {(double)en[0] * 1.0001, (double)en[1] * 1.0001, (double)en[2] * 1.0001, (double)en[3] * 1.0001, 0, 0, 0, 0};
+        block_fold<4>(q, ri, active, ev);
+        if (active && ri == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomic_add_f64(s3 + (long)c4 * 4 + e, ev[e]);
         }
     }
     red_out<8>(q, ri, active, c4, v, s1, s2, part, false);      // batch-norm sums: one set for all groups
 }
 
+// PL (round 5): the result written DIRECTLY as the fp16 x 2 planes of the GEMMs that consume it (the conv's weight and data
+// gradient: ud_gemm_p3 prec 2, P32 layout over [G R] x C, pad columns of the last panel zero) instead of fp32 + a split pass.
+// The scale comes from an a-priori bound: dx_c = gamma_c invstd_c P(dz_c), P a contraction (the projection off 1 and xhat), so
+// |dx| <= max_c |gamma_c invstd_c| sqrt(E_c), E_c >= sum_rows dz_c^2 over the WHOLE batch (all ranks) — `energy`, summed by the
+// kernel that produced dz (ud_normbwd_sums' s3, ud_irfft2_dwbwd's sum_dz2).  Every workgroup derives the same bound (a scan of C
+// values); block (0,0,0) stores 1 / scale.
+struct PlanesDst {
+    uint16_t* buf;
+    long panel, plane;
+    float* inv_scale;
+    const double* energy;
+};
+
 // MIX: also the SF-mix gradient: acc += dd * diff, diff = freq - spat as written by ud_irfft2_mix
-template <typename T, bool MIX>
+template <typename T, bool MIX, bool PL = false>
 __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* __restrict__ x,
                                                            const T* __restrict__ dy, const float* __restrict__ keep,
                                                            float inv_keep, ud_bn_ref bn, int dy_is_dz,
@@ -298,7 +321,29 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
                                                            const T* __restrict__ freq,
                                                            T* __restrict__ dx, double* __restrict__ dalpha_acc,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           uint32_t* __restrict__ amax, double* __restrict__ energy) {
+                                                           uint32_t* __restrict__ amax, double* __restrict__ energy,
+                                                           PlanesDst pd) {
+    float ps = 1.f;
+    if constexpr (PL) {
+        __shared__ float pl_red[NT / 64];
+        float gm = 0.f;
+        for (int i = threadIdx.x; i < q.C4 * 4; i += NT) {
+            const double m = bn.sum[i] * bn.inv_count;
+            double vv = bn.sumsq[i] * bn.inv_count - m * m;
+            if (vv < 0.0) vv = 0.0;
+            const float gi = bn.gamma[i] * rsqrtf((float)(vv + (double)bn.eps));          // (bn_load's own form)
+            gm = fmaxf(gm, gi * gi * (float)pd.energy[i]);
+        }
+        gm = ud_wave_max(gm);
+        if ((threadIdx.x & 63) == 0) pl_red[threadIdx.x >> 6] = gm;
+        __syncthreads();
+        gm = pl_red[0];
+#pragma unroll
+        for (int i = 1; i < NT / 64; ++i) gm = fmaxf(gm, pl_red[i]);
+        float pinv;
+        ud_h2_scale(__float_as_uint(sqrtf(gm) * 1.002f), ps, pinv);          // (the 0.2 %: rsqrtf / fp32 rounding of the apply)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *pd.inv_scale = pinv;
+    }
     int ri, c4;
     const bool active = thread_coords(q, ri, c4);
     const In4<T> x4{x}, d4{dy}, fr4{freq};
@@ -323,12 +368,29 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
             }
         }
         Rows w = rows_of(q, ri, c4);
+        // PL: this thread's quad of the panel; the thread of the LAST quad also zeroes the panel's pad quads
+        uint16_t* po = PL ? pd.buf + (long)(c4 >> 3) * pd.panel + (c4 & 7) * 4 : nullptr;
+        const int npad = (PL && c4 == q.C4 - 1) ? 7 - (c4 & 7) : 0;
+        long prow = (long)blockIdx.z * q.R + w.r;
 #pragma unroll kRowUnroll<T>
-        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step, prow += q.rpi) {
             f32x4 dz, xh, o;
             dz_terms(x4[w.idx], d4[w.idx], cb, bn.act, dy_is_dz != 0, sc, dz, xh);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = cb.ga[e] * cb.is[e] * (dz[e] - t1[e] - xh[e] * t2[e]);
+            if constexpr (PL) {
+                typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+                uint16_t h0[4], h1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ud_split_h2(o[e] * ps, h0[e], h1[e]);
+                *reinterpret_cast<u16x4*>(po + prow * 32) = u16x4{h0[0], h0[1], h0[2], h0[3]};
+                *reinterpret_cast<u16x4*>(po + prow * 32 + pd.plane) = u16x4{h1[0], h1[1], h1[2], h1[3]};
+                for (int z = 1; z <= npad; ++z) {
+                    *reinterpret_cast<u16x4*>(po + prow * 32 + 4 * z) = u16x4{0, 0, 0, 0};
+                    *reinterpret_cast<u16x4*>(po + prow * 32 + 4 * z + pd.plane) = u16x4{0, 0, 0, 0};
+                }
+                continue;
+            }
             o4.st(w.idx, o);
             mo = fmaxf(mo, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
             if (MIX) {
@@ -897,13 +959,13 @@ int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float 
 }
 
 int ud_normbwd_sums(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
-                    int dy_is_dz, int G, int R, int C, double* s1, double* s2, double* ws, int f16,
+                    int dy_is_dz, int G, int R, int C, double* s1, double* s2, double* s3, double* ws, int f16,
                     ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !dy || !bn || !s1 || !s2 || bn->G != 1) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     RedPlan pl = plan_reduce(G, R, C, false, ws);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(normbwd_sums_kernel<T>, red_grid(pl.q), dim3(NT), 0, s, pl.q, (const T*)x,
-                                                (const T*)dy, keep, inv_keep, *bn, dy_is_dz, s1, s2,
+                                                (const T*)dy, keep, inv_keep, *bn, dy_is_dz, s1, s2, s3,
                                                 pl.use_part ? ws : nullptr));
     UD_LAUNCH_CHECK();
     return finish_reduce(pl, 2, false, C, ws, s1, s2, s);
@@ -919,7 +981,27 @@ int ud_normbwd_apply(const void* x, const void* dy, const float* keep, float inv
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, false>), red_grid(q), dim3(NT), 0,
                                                 (hipStream_t)stream, q, (const T*)x, (const T*)dy, keep, inv_keep, *bn,
                                                 dy_is_dz, s1, s2, s1_local, s2_local, (const T*)nullptr, (T*)dx,
-                                                (double*)nullptr, dgamma, dbeta, absmax, (double*)nullptr));
+                                                (double*)nullptr, dgamma, dbeta, absmax, (double*)nullptr,
+                                                PlanesDst{nullptr, 0, 0, nullptr, nullptr}));
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_normbwd_apply_planes(const float* x, const float* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                            int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
+                            const double* s2_local, const double* energy, int G, int R, int C, uint16_t* planes,
+                            long panel_stride, long plane_stride, float* inv_scale, float* dgamma, float* dbeta,
+                            ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !dy || !bn || !s1 || !s2 || !energy || !planes || !inv_scale || bn->G != 1 || !bn->gamma)
+        return UD_EINVAL;
+    if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
+    const long rows = (long)G * R;
+    if (panel_stride < 32 * rows || plane_stride < (long)ud_cdiv(C, 32) * panel_stride) return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL((normbwd_apply_kernel<float, false, true>), red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, dy, keep,
+                       inv_keep, *bn, dy_is_dz, s1, s2, s1_local, s2_local, (const float*)nullptr, (float*)nullptr,
+                       (double*)nullptr, dgamma, dbeta, (uint32_t*)nullptr, (double*)nullptr,
+                       PlanesDst{planes, panel_stride, plane_stride, inv_scale, energy});
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -935,7 +1017,8 @@ int ud_normbwd_apply_mix(const void* x, const void* dz, const ud_bn_ref* bn, con
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL((normbwd_apply_kernel<T, true>), red_grid(q), dim3(NT), 0,
                                                 (hipStream_t)stream, q, (const T*)x, (const T*)dz, (const float*)nullptr,
                                                 1.f, *bn, 1, s1, s2, s1_local, s2_local, (const T*)diff, (T*)dd,
-                                                dalpha_acc, dgamma, dbeta, (uint32_t*)nullptr, energy));
+                                                dalpha_acc, dgamma, dbeta, (uint32_t*)nullptr, energy,
+                                                PlanesDst{nullptr, 0, 0, nullptr, nullptr}));
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -2229,12 +2229,41 @@ def residual_bn(x, bn, keep, inv_keep, skip, G, R, update=False, want_absmax=Fal
 
 
 def normbwd_sums(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc):
-    """sacc[0:C] += sum dz, sacc[C:2C] += sum dz * xhat."""
+    """sacc[0:C] += sum dz, sacc[C:2C] += sum dz * xhat; a 3C accumulator also receives sacc[2C:3C] += sum dz^2 (rounded up: the
+    energy normbwd_apply_planes bounds its result by)."""
     h = _act(x, dy)
     _chk(keep)
     Cc = x.shape[-1]
     _call("ud_normbwd_sums", _p(x), _p(dy), _p(keep), float(inv_keep), C.byref(bn.ref()), int(dy_is_dz), G, R, Cc,
-          _pd(sacc), _pd(sacc, Cc), _fused_ws(x, G, R, Cc, False), h, _stream())
+          _pd(sacc), _pd(sacc, Cc), _pd(sacc, 2 * Cc) if sacc.numel() >= 3 * Cc else None, _fused_ws(x, G, R, Cc, False), h,
+          _stream())
+
+
+_NORMBWD_PLANES = True          # A/B: tools/run_with.py kernels._NORMBWD_PLANES=False
+
+
+def normbwd_planes_ok(x, ctx):
+    """does the BatchNorm backward in front of a 1x1 conv write its result as that conv's GEMM planes itself?  (the conv's
+    backward runs on the planes GEMM — ctx.plans — and the tensor is fp32 with whole channel quads)"""
+    return (_NORMBWD_PLANES and _RFFT_PLANES and ctx.plans is not None and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and
+            CFG.spectral_p2 != "off")
+
+
+def normbwd_apply_planes(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=None):
+    """normbwd_apply whose result is prec-2 Planes over [G R] x C (no fp32 tensor, no split pass); sacc: 3C sums over all ranks
+    (sum dz | sum dz xhat | energy sum dz^2).  Returns (Planes, dgamma, dbeta)."""
+    _chk(x, dy, keep)
+    assert x.dtype == torch.float32 and dy.dtype == torch.float32
+    Cc = x.shape[-1]
+    assert sacc.numel() >= 3 * Cc
+    loc = sacc if sacc_local is None else sacc_local
+    pl = Planes(G * R, Cc, x, 2, False)
+    dg = empty((Cc,), x)
+    db = empty((Cc,), x)
+    _call("ud_normbwd_apply_planes", _p(x), _p(dy), _p(keep), float(inv_keep), C.byref(bn.ref()), int(dy_is_dz), _pd(sacc),
+          _pd(sacc, Cc), _pd(loc), _pd(loc, Cc), _pd(sacc, 2 * Cc), G, R, Cc, _p(pl.buf), pl.panel, pl.plane, _p(pl.inv), _p(dg),
+          _p(db), _stream())
+    return pl, dg, db
 
 
 def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=None, want_dbeta=True, want_absmax=False):
@@ -2513,18 +2542,19 @@ def irfft2_dwbwd_ok(S, k, stride, pad, dtype):
 
 def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, sacc):
     """da_f = irfft2(Y) (the adjoint of rfft2), dz = (gate * dwconv_bwd_data(dd) + da_f) * act'(bn(x)), sacc += BatchNorm backward
-    sums of dz, dw[C, k*k] = gate * sum act(bn(x))(window) * dd — ONE kernel over the (n, c) planes + the partials' fold.
-    Returns (dz, dw)."""
+    sums of dz (a 3C accumulator: + its energy), dw[C, k*k] = gate * sum act(bn(x))(window) * dd — ONE kernel over the (n, c)
+    planes + the partials' fold.  Returns (dz, dw)."""
     _chk(Y, dd, x, wt)
     N, S, Wh, C2 = Y.shape
     Cc = C2 // 2
     assert dd.shape == (N, S, S, Cc) and x.shape == dd.shape
     dz = torch.empty_like(dd)
+    en = _pd(sacc, 2 * Cc) if sacc.numel() >= 3 * Cc else None          # a 3C accumulator: + sum dz^2 (normbwd_apply_planes' bound)
     if not CFG.deterministic:
         # the weight gradient by fp32 atomics onto a zeroed [C, k*k] (N adds per address): no partial rows, no fold launch
         dwt = zeros((Cc, k * k), x)
         _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
-              _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), None, _p(dwt), _stream())
+              _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), en, None, _p(dwt), _stream())
         return dz, dwt
     need = N * k * k * Cc
     part = _DWTILE_PART.get(x.device.index)
@@ -2532,7 +2562,7 @@ def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, 
         part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
     dwt = empty((Cc, k * k), x)
     _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
-          _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), _p(part), None, _stream())
+          _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), en, _p(part), None, _stream())
     _call("ud_dwtile_wgrad_finalize", _p(part), N, int(k), Cc, _p(gate_alpha), int(gate_mode), _p(dwt), _stream())
     return dz, dwt
 

@@ -1109,14 +1109,20 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         if not (dout.is_contiguous() and dout.shape == out.shape):
             dout = dout.reshape(out.shape).contiguous()
         # ---- BN2 (+ drop-connect scale) backward
-        sb2 = K.zeros64(2 * Co, x)
+        # the project conv's backward on the planes GEMM: the apply pass writes its operand's planes itself, scaled by the bound
+        # the sums pass leaves behind (the energy of the incoming gradient: a third sum)
+        dp_pl = K.normbwd_planes_ok(p4, pctx)
+        sb2 = K.zeros64((3 if dp_pl else 2) * Co, x)
         K.normbwd_sums(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2)
         loc2 = dp.reduce(sb2, keep_local=True)
-        dp_, dg2, db2 = K.normbwd_apply(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2, loc2, want_absmax=True)
-        dp_amax = getattr(dp_, "_ud_absmax", None)
+        if dp_pl:
+            pctx.dy, dg2, db2 = K.normbwd_apply_planes(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2, loc2)
+            dp2, dp_amax = pctx.w.buf, None                        # (a tensor of the right device for the launch wrappers)
+        else:
+            dp_, dg2, db2 = K.normbwd_apply(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2, loc2, want_absmax=True)
+            dp2, dp_amax = dp_.view(Mo, Co), getattr(dp_, "_ud_absmax", None)
         tape.add_param_grad(blk._bn2.weight, dg2)
         tape.add_param_grad(blk._bn2.bias, db2)
-        dp2 = dp_.view(Mo, Co)
         tape.wgrad(blk._project_conv.weight, lambda: K.spectral_wgrad(pctx, dp2, dp_amax), dp2)
         dc = K.spectral_dgrad(pctx, dp2, dy_absmax=dp_amax).view(N, Ho, Wo, Ce)
         # ---- squeeze-excite backward
@@ -1168,8 +1174,11 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         tape.add_param_grad(blk._bn1.weight, dg1)
         tape.add_param_grad(blk._bn1.bias, db1)
         dz0 = dw_f = None
+        de_pl = False
         if sf and irdw:
-            sb0 = K.zeros64(2 * src.shape[-1], x)
+            # (+ the energy of dz0 where the expand conv's backward takes its operand as planes: K.normbwd_apply_planes below)
+            de_pl = lazy_in is None and K.normbwd_planes_ok(src, ectx)
+            sb0 = K.zeros64((3 if de_pl else 2) * src.shape[-1], x)
             dz0, dw_f = K.irfft2_dwbwd(dxf, s_f, 0.5, g_sp, src, src_bn, wt, k, g_alpha, g_mode, sb0)
             is_dz = True
             tape.add_param_grad(dwm.weight, dw_f)
@@ -1214,11 +1223,14 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 lazy_in.backward(dz0, sb0, is_dz)
                 return
             loc0 = dp.reduce(sb0, keep_local=True)
-            de, dg0, db0 = K.normbwd_apply(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0, want_absmax=True)
-            de_amax = getattr(de, "_ud_absmax", None)
+            if de_pl:
+                ectx.dy, dg0, db0 = K.normbwd_apply_planes(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0)
+                de2, de_amax = ectx.w.buf, None
+            else:
+                de, dg0, db0 = K.normbwd_apply(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0, want_absmax=True)
+                de2, de_amax = de.view(M, Ce), getattr(de, "_ud_absmax", None)
             tape.add_param_grad(blk._bn0.weight, dg0)
             tape.add_param_grad(blk._bn0.bias, db0)
-            de2 = de.view(M, Ce)
             tape.wgrad(blk._expand_conv.weight, lambda: K.spectral_wgrad(ectx, de2, de_amax), de2)
             if sp.skip and tape.watch is None and getattr(dout, "_ud_owned", False):
                 dx = K.spectral_dgrad(ectx, de2, out=dout.view(M, Cin), dy_absmax=de_amax).view(x.shape)    # + skip gradient
