@@ -618,7 +618,8 @@ int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, con
  *   dz = (gate * conv_flipped(dy) [+ add]) * act'(bn(x))   (bn NULL: no activation factor, x is the conv's input itself),
  *   s1 += sum dz, s2 += sum dz * xhat (bn given; ws: ud_dwtile_ws_doubles(N, H, W, C) doubles),
  *   dwt[C][K*K] = gate * sum_pixels act(bn(x))(oh + i - P_t, ow + j - P_l) * dy(oh, ow)
- * (ud_dwtile epi 2 + ud_dwtile_wgrad, which read each operand twice).  wpart: ud_dwtile_wgrad_part_rows(N, H, W) rows. */
+ * (ud_dwtile epi 2 + ud_dwtile_wgrad, which read each operand twice).  wpart: ud_dwtile_wgrad_part_rows(N, H, W) rows.
+ * dwt == NULL: the partial rows are left for ud_dwtile_wgrad_finalize_multi and their number is returned. */
 int ud_dwtile_bwd(const void* dy, const void* x, const ud_bn_ref* bn, const float* wt, const float* gate_alpha, int gate_mode,
                   const void* add, void* dz, float* dwt, float* wpart, long part_rows, double* s1, double* s2, double* ws,
                   int N, int H, int W, int C, int K, int P_t, int P_l, int f16, ud_stream_t stream);
@@ -626,6 +627,17 @@ int ud_dwtile_bwd(const void* dy, const void* x, const ud_bn_ref* bn, const floa
  * outside csrc/dwtile.hip that produce them (ud_irfft2_dwbwd) */
 int ud_dwtile_wgrad_finalize(const float* part, int nparts, int K, int C, const float* gate_alpha, int gate_mode, float* dwt,
                              ud_stream_t stream);
+/* The folds of ALL depthwise convs of a backward pass in one launch per 48 items (the items travel by value in the kernel
+ * arguments: capturable).  ud_dwtile_wgrad / ud_dwtile_bwd called with dwt == NULL leave their partial rows in `part` / `wpart` and
+ * RETURN their number (> 0) instead of folding; ud_irfft2_dwbwd's wpart holds N rows.  The partial buffers must stay untouched
+ * until this call. */
+typedef struct {
+    const float* part;          /* [nparts][K*K][C] */
+    float* dwt;                 /* [C][K*K] */
+    const float* gate_alpha;    /* gate_mode != 0 */
+    int nparts, K, C, gate_mode;
+} ud_wgrad_fold;
+int ud_dwtile_wgrad_finalize_multi(const ud_wgrad_fold* items, int n, ud_stream_t stream);
 /* Backward of an SF block's spatial branch inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel; S = 8, K in {3, 5},
  * fp32): da_f = scale * C2R(f(kx) Y) as ud_irfft2 (the adjoint of rfft2: w_interior = 1/2), then with dd = dL/d(conv output)
  * [N][S][S][C], x the conv's raw input and bn the BatchNorm in front of it:

@@ -788,6 +788,50 @@ def test_adjoint_transform_does_the_depthwise_backward(N, S, Cc, k):
     assert float(ratio.min()) >= 1.0 and float(ratio.max()) < 1.001, (float(ratio.min()), float(ratio.max()))
 
 
+def test_depthwise_weight_gradient_folds_deferred_to_one_launch():
+    """ud_dwtile_wgrad_finalize_multi (round 5): between kernels.begin_wgrad_folds() and flush_wgrad_folds() the depthwise weight
+    gradients of ud_dwtile_bwd / ud_dwtile_wgrad / ud_irfft2_dwbwd stay partial rows in buffers of their own (the entry points return
+    the row count), and ONE launch folds them all — bit for bit the per-conv folds (same kernel body, same order of the rows)."""
+    from unidefense_amd import kernels as K
+    from unidefense_amd.config import override
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(5)
+    alpha = torch.tensor([0.3], device=dev)
+
+    def run():
+        out = []
+        for (N, S, Cc, k) in ((2, 16, 64, 3), (3, 32, 40, 5), (4, 8, 96, 5)):
+            x = torch.randn(N, S, S, Cc, generator=g).to(dev)
+            dy = torch.randn(N, S, S, Cc, generator=g).to(dev)
+            wt = (0.3 * torch.randn(k * k, Cc, generator=g)).to(dev)
+            gamma, beta = (1.0 + 0.3 * torch.randn(Cc, generator=g)).to(dev), (0.2 * torch.randn(Cc, generator=g)).to(dev)
+            acc = K.zeros64(2 * Cc, x)
+            K.colstats(x.view(-1, Cc), acc)
+            bn = K.DeferredBN(acc, Cc, N * S * S, gamma, beta, 1e-3, 1)
+            pad = (k - 1) // 2
+            out.append(K.dwtile_bwd(dy, x, wt, k, pad, pad, bn=bn, gate_alpha=alpha, gate_mode=2, sacc=K.zeros64(2 * Cc, x))[1])
+            out.append(K.dwtile_bwd_weight(x, dy, k, pad, pad, bn=bn, gate_alpha=alpha, gate_mode=1))
+            out.append(K.dwtile_bwd(dy, x, wt, k, pad, pad)[1])
+            if S in (8, 16):
+                Yf = torch.randn(N, S, S // 2 + 1, 2 * Cc, generator=g).to(dev)
+                out.append(K.irfft2_dwbwd(Yf, 1.0 / S, 0.5, dy, x, bn, wt, k, alpha, 2, K.zeros64(2 * Cc, x))[1])
+        return out
+
+    with override(deterministic=True):          # ordered sums everywhere: the two runs differ in the folds' launches only
+        g.manual_seed(5)
+        ref = run()
+        g.manual_seed(5)
+        K.begin_wgrad_folds()
+        got = run()
+        assert all(getattr(t, "_ud_deferred", False) for t in got) and len(K._WGRAD_FOLDS) == len(got)
+        K.flush_wgrad_folds(end=True)
+    torch.cuda.synchronize()
+    assert K._WGRAD_FOLDS is None and len(ref) == 11
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("N,HW,Cc,act,dz", [(2, 64, 96, 0, False), (3, 100, 40, 1, True), (32, 64, 272, 0, False), (4, 256, 960, 1, True)])
 def test_normbwd_apply_writes_the_gemm_planes_itself(N, HW, Cc, act, dz):
     """ud_normbwd_sums' third sum + ud_normbwd_apply_planes (round 5): the BatchNorm backward in front of a 1x1 conv writes its

@@ -94,3 +94,39 @@ def test_tape_cast_converts_values_and_gradients():
         fn()
     gx = tape.pop_grad(x)
     assert gx.dtype == torch.float32 and torch.equal(gx, gy.float())
+
+
+def test_pixel_major_dft_matrices_against_torch_fft():
+    """kernels._dft_pixel_mats: the matrices of the any-side rfft2 / irfft2 done as two batched GEMMs on the pixel-major tensor
+    (the 95 x 95 map of the 380 x 380 trunk, model/efficientnet/exp.py:55-62).  The two GEMMs of each direction are restated here
+    with einsum in float64 — ud_gemm's a_mode 1 reads A k-major: product = A[:, :M]^T B — and held to torch.fft with ud_rfft2's /
+    ud_irfft2's contract (scale, column weight off the self-conjugate columns, Hermitian multiplicity).  Sides: 95 (odd), 14 (even:
+    a Nyquist column), 13 (odd half width: the matrix rows are padded to a multiple of 4 and the slack must be zero)."""
+    import torch
+    from unidefense_amd import kernels as K
+    g = torch.Generator().manual_seed(0)
+    for S in (95, 14, 13):
+        N, C = 2, 8
+        Wh = S // 2 + 1
+        scale, wi = 0.37, 1.7
+        colw = torch.full((Wh,), wi, dtype=torch.float64)
+        colw[0] = 1.0
+        if S % 2 == 0:
+            colw[-1] = 1.0
+        x = torch.randn(N, S, S, C, generator=g, dtype=torch.float64)
+        a1, a2 = [t.double() for t in K._dft_pixel_mats(S, scale, wi, False, "cpu")]
+        assert a1.shape == (S, -(-2 * S // 4) * 4) and a2.shape == (2 * S, -(-2 * Wh // 4) * 4)
+        assert float(a1[:, 2 * S:].abs().sum()) == 0.0 and float(a2[:, 2 * Wh:].abs().sum()) == 0.0
+        T = torch.einsum("hm,nhq->nmq", a1[:, :2 * S], x.reshape(N, S, S * C)).reshape(N, S, 2 * S, C)      # [n][ky][(ri, w)][c]
+        Y = torch.einsum("km,nykc->nymc", a2[:, :2 * Wh], T).reshape(N, S, Wh, 2 * C)
+        ref = torch.fft.rfft2(x.permute(0, 3, 1, 2)) * (scale * colw)
+        ref = torch.stack([ref.real, ref.imag], -1).permute(0, 2, 3, 4, 1).reshape(N, S, Wh, 2 * C)
+        assert float((Y - ref).abs().max()) < 2e-5 * float(ref.abs().max())                                # fp32 matrices
+        Yin = torch.randn(N, S, Wh, 2 * C, generator=g, dtype=torch.float64)
+        a3, a4 = [t.double() for t in K._dft_pixel_mats(S, scale, wi, True, "cpu")]
+        assert float(a3[:, 2 * S:].abs().sum()) == 0.0 and float(a4[:, S:].abs().sum()) == 0.0
+        U = torch.einsum("km,nykc->nymc", a3[:, :2 * S], Yin.reshape(N, S, 2 * Wh, C))                      # [n][ky][(ri, w)][c]
+        xo = torch.einsum("kh,nkq->nhq", a4[:, :S], U.reshape(N, 2 * S, S * C)).reshape(N, S, S, C)
+        Yc = torch.complex(Yin.reshape(N, S, Wh, 2, C)[:, :, :, 0], Yin.reshape(N, S, Wh, 2, C)[:, :, :, 1]).permute(0, 3, 1, 2)
+        refx = (torch.fft.irfft2(Yc * colw, s=(S, S), norm="forward") * scale).permute(0, 2, 3, 1)
+        assert float((xo - refx).abs().max()) < 2e-5 * float(refx.abs().max())

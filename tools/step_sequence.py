@@ -2,7 +2,7 @@
 grid, workgroup, kernel name — the step runs on one queue, so the order is the tape's.  The step is cut at the one
 `split_h2_multi_kernel` launch every forward starts with (the batch split of all weight planes); the LAST complete step of the
 trace's densest stretch (the timed hipGraph replays) is written, with the median duration of each position over the last
-`steps` replays.  usage: python3 tools/step_sequence.py <kernel_trace.csv> <out.txt> [steps=8]"""
+`steps` replays.  usage: python3 tools/step_sequence.py <kernel_trace.csv> <out.txt> [steps=8] [marker kernel=split_h2_multi_kernel]"""
 import csv
 import re
 import statistics
@@ -10,6 +10,7 @@ import sys
 
 path, out = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+marker = sys.argv[4] if len(sys.argv) > 4 else "split_h2_multi_kernel"      # a kernel launched exactly once per step
 rows = []
 with open(path) as fh:
     for r in csv.DictReader(fh):
@@ -17,7 +18,7 @@ with open(path) as fh:
         w = [int(r.get(k, 0) or 0) for k in ("Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z")]
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], g, w))
 rows.sort(key=lambda t: t[0])
-marks = [i for i, r in enumerate(rows) if "split_h2_multi_kernel" in r[2]]
+marks = [i for i, r in enumerate(rows) if marker in r[2]]
 segs = [(a, b) for a, b in zip(marks[:-1], marks[1:])]
 # replayed steps are the shortest segments in wall time with the modal launch count
 from collections import Counter

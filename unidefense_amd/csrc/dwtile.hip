@@ -546,6 +546,46 @@ __global__ __launch_bounds__(NT) void dw_tile_wgrad_finalize(int nparts, int KK,
     }
 }
 
+// The same fold for EVERY depthwise conv of a backward pass in one launch (ud_dwtile_wgrad_finalize_multi): the items travel by
+// value in the kernel arguments (no device table: the launch sits inside a captured graph), a workgroup finds its item by a scan
+// of the (uniform) block prefix.
+constexpr int FOLD_MAX = 48;
+struct FoldArgs {
+    ud_wgrad_fold it[FOLD_MAX];
+    int block0[FOLD_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(NT) void dw_tile_wgrad_finalize_multi(const FoldArgs a) {
+    __shared__ double sm[16][16][4];
+    int j = 0;
+    while (j + 1 < a.n && (int)blockIdx.x >= a.block0[j + 1]) ++j;
+    const ud_wgrad_fold& f = a.it[j];
+    const int KK = f.K * f.K, C = f.C, KKC = KK * C, nparts = f.nparts;
+    const int lane = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = (((int)blockIdx.x - a.block0[j]) * 16 + lane) * 4;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (i < KKC) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(f.part + i);
+        const long step = (long)KKC / 4;
+        for (int p = sl; p < nparts; p += 16) {
+            const f32x4 w = p4[(long)p * step];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (double)w[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[sl][lane][e] = v[e];
+    __syncthreads();
+    if (sl < 4 && i < KKC) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][lane][sl];
+        const int o = i + sl, tap = o / C, c = o % C;
+        f.dwt[(long)c * KK + tap] = (float)(t * (double)gate_factor(f.gate_alpha, f.gate_mode));
+    }
+}
+
 inline bool tile_args_ok(int N, int Hs, int Ws, int C, int Ho, int Wo, int K) {
     return N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0 && C >= 4 && C % 4 == 0 && (K == 3 || K == 5);
 }
@@ -616,6 +656,7 @@ int launch_wgrad(TileGeom g, const T* src, const ud_bn_ref* bn_in, const T* dy, 
     hipLaunchKernelGGL((dw_tile_wgrad_kernel<T, K, CQ, SW, ST>), grid, dim3(NT), lds, s, g, src, bi, bn_in ? 1 : 0, dy,
                        n_step, part);
     UD_LAUNCH_CHECK();
+    if (!dw) return (int)nparts;          // the caller folds the partial rows later (ud_dwtile_wgrad_finalize_multi)
     const int KKC = K * K * g.C4 * 4;
     hipLaunchKernelGGL(dw_tile_wgrad_finalize, dim3(ud_cdiv(KKC, 64)), dim3(NT), 0, s, (int)nparts, K * K, g.C4 * 4, part,
                        gate_alpha, gate_mode, dw);
@@ -655,14 +696,16 @@ int launch_bwd(TileGeom g, const T* dy, const T* x, const ud_bn_ref* bn, const f
                        gate_alpha, gate_mode, add, dz, n_step, wpart, use_part ? ws : nullptr, s1, s2);
     UD_LAUNCH_CHECK();
     const int C = g.C4 * 4, KKC = K * K * C;
-    hipLaunchKernelGGL(dw_tile_wgrad_finalize, dim3(ud_cdiv(KKC, 64)), dim3(NT), 0, s, (int)nparts, K * K, C, wpart,
-                       gate_alpha, gate_mode, dwt);
-    UD_LAUNCH_CHECK();
+    if (dwt) {
+        hipLaunchKernelGGL(dw_tile_wgrad_finalize, dim3(ud_cdiv(KKC, 64)), dim3(NT), 0, s, (int)nparts, K * K, C, wpart,
+                           gate_alpha, gate_mode, dwt);
+        UD_LAUNCH_CHECK();
+    }
     if (use_part) {
         hipLaunchKernelGGL(partials_to_acc, dim3(ud_cdiv(C, 8)), dim3(NT), 0, s, 2, 1, C, (int)nparts, ws, s1, s2);
         UD_LAUNCH_CHECK();
     }
-    return 0;
+    return dwt ? 0 : (int)nparts;          // no dwt: the caller folds the partial rows later (ud_dwtile_wgrad_finalize_multi)
 }
 
 }  // namespace
@@ -715,7 +758,7 @@ int ud_dwtile(const void* src, const ud_bn_ref* bn_in, const float* wt, void* ou
 int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, const float* gate_alpha, int gate_mode,
                     float* dwt, float* part, long part_rows, int N, int Hs, int Ws, int C, int Ho, int Wo, int K, int P_t,
                     int P_l, int stride, int f16, ud_stream_t stream) {
-    if (!tile_args_ok(N, Hs, Ws, C, Ho, Wo, K) || !src || !dy || !dwt || !part || part_rows < 1) return UD_EINVAL;
+    if (!tile_args_ok(N, Hs, Ws, C, Ho, Wo, K) || !src || !dy || !part || part_rows < 1) return UD_EINVAL;
     if (bn_in && bn_in->G != 1) return UD_EINVAL;
     if (stride != 1 && stride != 2) return UD_EINVAL;
     TileGeom g{N, Hs, Ws, C / 4, Ho, Wo, P_t, P_l, 0, 0, 0, 0};
@@ -738,7 +781,7 @@ int ud_dwtile_wgrad(const void* src, const ud_bn_ref* bn_in, const void* dy, con
 int ud_dwtile_bwd(const void* dy, const void* x, const ud_bn_ref* bn, const float* wt, const float* gate_alpha, int gate_mode,
                   const void* add, void* dz, float* dwt, float* wpart, long part_rows, double* s1, double* s2, double* ws,
                   int N, int H, int W, int C, int K, int P_t, int P_l, int f16, ud_stream_t stream) {
-    if (!tile_args_ok(N, H, W, C, H, W, K) || !dy || !x || !wt || !dz || !dwt || !wpart || part_rows < 1) return UD_EINVAL;
+    if (!tile_args_ok(N, H, W, C, H, W, K) || !dy || !x || !wt || !dz || !wpart || part_rows < 1) return UD_EINVAL;
     if (P_t < 0 || P_t > K - 1 || P_l < 0 || P_l > K - 1) return UD_EINVAL;
     if (bn && (bn->G != 1 || !s1 || !s2 || !ws)) return UD_EINVAL;
     TileGeom g{N, H, W, C / 4, H, W, P_t, P_l, 0, 0, 0, 0};
@@ -751,6 +794,30 @@ int ud_dwtile_bwd(const void* dy, const void* x, const ud_bn_ref* bn, const floa
     if (sm) UD_BW(5, 16, 4);
     UD_BW(5, 8, 4);
 #undef UD_BW
+}
+
+int ud_dwtile_wgrad_finalize_multi(const ud_wgrad_fold* items, int n, ud_stream_t stream) {
+    if (!items || n < 1) return UD_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const ud_wgrad_fold& f = items[i];
+        if (!f.part || !f.dwt || f.nparts < 1 || (f.K != 3 && f.K != 5) || f.C < 4 || f.C % 4 || f.gate_mode < 0 || f.gate_mode > 2 ||
+            (f.gate_mode != 0 && !f.gate_alpha))
+            return UD_EINVAL;
+    }
+    for (int i0 = 0; i0 < n; i0 += FOLD_MAX) {
+        FoldArgs a;
+        a.n = n - i0 < FOLD_MAX ? n - i0 : FOLD_MAX;
+        int b = 0;
+        for (int j = 0; j < a.n; ++j) {
+            a.it[j] = items[i0 + j];
+            a.block0[j] = b;
+            b += ud_cdiv(a.it[j].K * a.it[j].K * a.it[j].C, 64);
+        }
+        a.block0[a.n] = b;
+        hipLaunchKernelGGL(dw_tile_wgrad_finalize_multi, dim3((unsigned)b), dim3(NT), 0, (hipStream_t)stream, a);
+        UD_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 int ud_dwtile_wgrad_finalize(const float* part, int nparts, int K, int C, const float* gate_alpha, int gate_mode, float* dwt,

@@ -2491,19 +2491,63 @@ def dwtile_bwd_data(dy, wt, K, pad_t, pad_l, H, W, gate_alpha=None, gate_mode=0,
 _DWTILE_PART = {}
 
 
+# The depthwise weight gradients come out of their kernels as partial rows [parts][K*K][C] that a small launch folds into the
+# parameter's layout: 47 such launches per UDEB4 backward (~5 us each, the floor).  While a tape's backward collects them
+# (begin_wgrad_folds ... flush_wgrad_folds: Tape.backward), every conv keeps its rows in a buffer of its own and ONE launch folds
+# them all at the end (ud_dwtile_wgrad_finalize_multi).  A gradient that is read before the end — a second use of the parameter,
+# a data-parallel reducer taking it as soon as it is complete — flushes first (Tape.add_param_grad).
+_WGRAD_FOLDS = None
+_WGRAD_FOLD_DEFER = True          # A/B: tools/run_with.py kernels._WGRAD_FOLD_DEFER=False
+
+
+def begin_wgrad_folds():
+    global _WGRAD_FOLDS
+    _WGRAD_FOLDS = [] if _WGRAD_FOLD_DEFER else None
+
+
+def flush_wgrad_folds(end=False):
+    """fold every collected weight gradient now (end: and stop collecting)"""
+    global _WGRAD_FOLDS
+    items = _WGRAD_FOLDS
+    if items:
+        from .lib import WgradFold
+        arr = (WgradFold * len(items))()
+        for a, (part, nparts, K_, Cc, alpha, mode, dwt) in zip(arr, items):
+            a.part, a.dwt, a.gate_alpha = part.data_ptr(), dwt.data_ptr(), (alpha.data_ptr() if alpha is not None else None)
+            a.nparts, a.K, a.C, a.gate_mode = int(nparts), int(K_), int(Cc), int(mode)
+        _call("ud_dwtile_wgrad_finalize_multi", arr, len(items), _stream())
+        for it in items:
+            it[6]._ud_deferred = False
+    _WGRAD_FOLDS = None if (end or items is None) else []
+
+
+def _wgrad_part(like, need):
+    """the partial-row buffer of one depthwise weight gradient: the shared scratch, or (folds being collected) its own"""
+    if _WGRAD_FOLDS is not None:
+        return torch.empty(need, dtype=torch.float32, device=like.device), True
+    part = _DWTILE_PART.get(like.device.index)
+    if part is None or part.numel() < need:
+        part = _DWTILE_PART[like.device.index] = torch.empty(need, dtype=torch.float32, device=like.device)
+    return part, False
+
+
+def _defer_wgrad_fold(part, nparts, K_, Cc, gate_alpha, gate_mode, dwt):
+    dwt._ud_deferred = True
+    _WGRAD_FOLDS.append((part, nparts, K_, Cc, gate_alpha if gate_mode else None, gate_mode, dwt))
+
+
 def dwtile_bwd_weight(x, dy, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0, stride=1):
     """dw[C, K*K] = gate * sum act(bn(x))(window) * dy, stride 1; x: the conv's RAW input when bn is given."""
     h = _act(x, dy)
     N, H, W, Cc = x.shape
     _, Ho, Wo, _ = dy.shape
     rows = _call("ud_dwtile_wgrad_part_rows", N, Ho, Wo)
-    need = rows * K * K * Cc
-    part = _DWTILE_PART.get(x.device.index)
-    if part is None or part.numel() < need:
-        part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
+    part, defer = _wgrad_part(x, rows * K * K * Cc)
     dwt = empty((Cc, K * K), x)
-    _call("ud_dwtile_wgrad", _p(x), _bnp(bn), _p(dy), _p(gate_alpha), int(gate_mode), _p(dwt), _p(part), rows, N, H, W, Cc,
-          Ho, Wo, K, pad_t, pad_l, int(stride), h, _stream())
+    nparts = _call("ud_dwtile_wgrad", _p(x), _bnp(bn), _p(dy), _p(gate_alpha), int(gate_mode), None if defer else _p(dwt), _p(part),
+                   rows, N, H, W, Cc, Ho, Wo, K, pad_t, pad_l, int(stride), h, _stream())
+    if defer:
+        _defer_wgrad_fold(part, nparts, K, Cc, gate_alpha, gate_mode, dwt)
     return dwt
 
 
@@ -2517,21 +2561,25 @@ def dwtile_bwd(dy, x, wt, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0
     N, H, W, Cc = x.shape
     assert dy.shape == x.shape
     rows = _call("ud_dwtile_wgrad_part_rows", N, H, W)
-    need = rows * K * K * Cc
-    part = _DWTILE_PART.get(x.device.index)
-    if part is None or part.numel() < need:
-        part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
+    part, defer = _wgrad_part(x, rows * K * K * Cc)
     dz = empty((N, H, W, Cc), dy, dy.dtype)
     dwt = empty((Cc, K * K), x)
     ws = _ws64(dy, _call("ud_dwtile_ws_doubles", N, H, W, Cc)) if bn is not None else None
-    _call("ud_dwtile_bwd", _p(dy), _p(x), _bnp(bn), _p(wt), _p(gate_alpha), int(gate_mode), _p(add), _p(dz), _p(dwt), _p(part),
-          rows, _pd(sacc) if bn is not None else None, _pd(sacc, Cc) if bn is not None else None, ws, N, H, W, Cc, K, pad_t,
-          pad_l, h, _stream())
+    nparts = _call("ud_dwtile_bwd", _p(dy), _p(x), _bnp(bn), _p(wt), _p(gate_alpha), int(gate_mode), _p(add), _p(dz),
+                   None if defer else _p(dwt), _p(part), rows, _pd(sacc) if bn is not None else None,
+                   _pd(sacc, Cc) if bn is not None else None, ws, N, H, W, Cc, K, pad_t, pad_l, h, _stream())
+    if defer:
+        _defer_wgrad_fold(part, nparts, K, Cc, gate_alpha, gate_mode, dwt)
     return dz, dwt
 
 
 _IRFFT_DWBWD = True          # A/B: tools/run_with.py kernels._IRFFT_DWBWD=False
 _IRFFT_DWBWD_SIZES = (8, 16)
+# weight gradient of ud_irfft2_dwbwd by fp32 atomics onto the parameter-layout gradient instead of partial rows + the fold launch:
+# OFF — 1600 device-scope atomics per workgroup make the 8 x 8 kernel 81-92 us instead of 29 (16 x 16, k 5: 63 vs 52); the step
+# with the 18 fold launches is 25.93 ms against 26.28 (profiles/r05/dwbwd_wgrad_atomics_ab.txt; A/B: tools/run_with.py
+# kernels._IRFFT_DWBWD_ATOMIC=True)
+_IRFFT_DWBWD_ATOMIC = False
 
 
 def irfft2_dwbwd_ok(S, k, stride, pad, dtype):
@@ -2550,20 +2598,20 @@ def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, 
     assert dd.shape == (N, S, S, Cc) and x.shape == dd.shape
     dz = torch.empty_like(dd)
     en = _pd(sacc, 2 * Cc) if sacc.numel() >= 3 * Cc else None          # a 3C accumulator: + sum dz^2 (normbwd_apply_planes' bound)
-    if not CFG.deterministic:
+    if _IRFFT_DWBWD_ATOMIC and not CFG.deterministic:
         # the weight gradient by fp32 atomics onto a zeroed [C, k*k] (N adds per address): no partial rows, no fold launch
         dwt = zeros((Cc, k * k), x)
         _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
               _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), en, None, _p(dwt), _stream())
         return dz, dwt
-    need = N * k * k * Cc
-    part = _DWTILE_PART.get(x.device.index)
-    if part is None or part.numel() < need:
-        part = _DWTILE_PART[x.device.index] = torch.empty(need, dtype=torch.float32, device=x.device)
+    part, defer = _wgrad_part(x, N * k * k * Cc)
     dwt = empty((Cc, k * k), x)
     _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
           _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), en, _p(part), None, _stream())
-    _call("ud_dwtile_wgrad_finalize", _p(part), N, int(k), Cc, _p(gate_alpha), int(gate_mode), _p(dwt), _stream())
+    if defer:
+        _defer_wgrad_fold(part, N, int(k), Cc, gate_alpha, gate_mode, dwt)
+    else:
+        _call("ud_dwtile_wgrad_finalize", _p(part), N, int(k), Cc, _p(gate_alpha), int(gate_mode), _p(dwt), _stream())
     return dz, dwt
 
 

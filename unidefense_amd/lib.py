@@ -63,6 +63,12 @@ class BnRef(C.Structure):
                 ("act", C.c_int), ("G", C.c_int), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
 
 
+class WgradFold(C.Structure):
+    """ud_wgrad_fold: one depthwise weight-gradient fold of ud_dwtile_wgrad_finalize_multi"""
+    _fields_ = [("part", C.c_void_p), ("dwt", C.c_void_p), ("gate_alpha", C.c_void_p), ("nparts", C.c_int), ("K", C.c_int),
+                ("C", C.c_int), ("gate_mode", C.c_int)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_long, C.c_float
 _BN = C.POINTER(BnRef)
 
@@ -179,6 +185,7 @@ _SIGNATURES = {
     "ud_dwtile_wgrad_part_rows": [_I, _I, _I],
     "ud_dwtile_wgrad": [_P, _BN, _P, _P, _I, _P, _P, _L] + [_I] * 9 + [_I, _I, _P],
     "ud_dwtile_wgrad_finalize": [_P, _I, _I, _I, _P, _I, _P, _P],
+    "ud_dwtile_wgrad_finalize_multi": [C.POINTER(WgradFold), _I, _P],
     "ud_irfft2_dwbwd": [_P, _I, _I, _I, _F, _F, _P, _P, _BN, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "ud_dwtile_bwd": [_P, _P, _BN, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P] + [_I] * 8 + [_P],
     "ud_rfft2_planes_ws_floats": [_L, _I],
@@ -198,7 +205,7 @@ _SIGNATURES = {
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_fft32_set_wave", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_dwtile_wgrad", "ud_dwtile_bwd", "ud_fft32_set_wave", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
                 "ud_conv_small_wgrad_ws_floats", "ud_xchg_bytes"}
 _LONG_FUNCS = {"ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",

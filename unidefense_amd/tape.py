@@ -57,6 +57,8 @@ class Tape:
 
     def add_param_grad(self, p, g: torch.Tensor):
         cur = self.param_grads.get(p)
+        if getattr(g, "_ud_deferred", False) and (cur is not None or self.param_ready is not None):
+            K.flush_wgrad_folds()          # read right away (summed with an earlier use / handed to the gradient reducer): fold now
         g = g.reshape(p.shape)
         g = g if cur is None else K.axpby(cur, 1.0, g, 1.0)
         self.param_grads[p] = g
@@ -74,8 +76,12 @@ class Tape:
 
     # -- replay ----------------------------------------------------------------------------
     def backward(self):
-        for fn in reversed(self.nodes):
-            fn()
+        K.begin_wgrad_folds()          # the depthwise weight gradients' folds: one launch at the end instead of one per conv
+        try:
+            for fn in reversed(self.nodes):
+                fn()
+        finally:
+            K.flush_wgrad_folds(end=True)
         self.nodes = []
         self.grads = {}
         self._keep = []
