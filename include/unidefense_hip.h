@@ -147,6 +147,11 @@ typedef struct {
     int a_scale_stride, b_scale_stride;         /* 0: one scale for the operand; 1: one per GEMM row */
 } ud_gemm_p3_desc;
 int ud_gemm_p3(const ud_gemm_p3_desc* d, ud_stream_t stream);
+/* TWO products in one launch: the data gradient (nn: a_mode 0, b_mode 1) and the weight gradient (tn: a_mode 1, b_mode 1) of one
+ * 1x1 conv — prec 2, out_mode 0 / 1 / 2, split_k >= 1, no stream-K form, no epilogue statistics.  The weight gradient's workgroups
+ * follow the data gradient's in the same grid, so they start on the CUs the data gradient's last round of tiles leaves idle
+ * (540 + 225 tiles on 256 CUs: 3 rounds instead of 3 + 1).  Results are those of two ud_gemm_p3 calls. */
+int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc* tn, ud_stream_t stream);
 /* x fp32 [R][C] (row stride ld; C, ld multiples of 4) -> three bf16 planes in the P32 layout above; columns C .. 32*ceil(C/32)-1
  * are written as zeros, slack rows are left untouched. */
 int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,

@@ -229,6 +229,45 @@ def test_xcd_raster_is_a_permutation_of_the_tiles(kind, M, N, Kd):
         K._P3_RASTER = saved
 
 
+@pytest.mark.parametrize("M,N,Kd,pn,pt,acc", [(128 * 7 + 40, 128 * 3, 128 * 5, ("plain",), ("plain",), False),
+                                              (128 * 9, 128 * 2 + 16, 128 * 4 + 32, ("plain",), ("split", 3), True),
+                                              (128 * 5, 128 * 6, 128 * 3, ("split", 2), ("split", 2), False),
+                                              (4608, 1920, 1920, ("plain",), ("plain",), False)])
+def test_data_and_weight_gradient_in_one_launch(M, N, Kd, pn, pt, acc):
+    """ud_gemm_p3_pair (round 5): the data gradient dx[M, K] = dy . w and the weight gradient dw[N, K] = dy^T . x of a 1x1 conv as
+    ONE grid — the weight gradient's workgroups follow the data gradient's.  Every tile is computed by the same code on the same
+    operands as in two ud_gemm_p3 launches: plain stores are bitwise equal, atomic split-K sums agree to the order of the adds;
+    ragged tile edges, an existing term to add onto, both problems with their own XCD raster."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(11)
+    x, w, dy = torch.randn(M, Kd, device=dev), torch.randn(N, Kd, device=dev) * 0.05, torch.randn(M, N, device=dev)
+    term = torch.randn(M, Kd, device=dev) if acc else None
+    ctx = K.SpectralCtx()
+    ctx.M, ctx.N, ctx.K, ctx.dy = M, N, Kd, None
+    ctx.x, ctx.w = K.split_planes(x, prec=2), K.split_planes(w, prec=2)
+    ctx.plans = {"nt": ("plain",), "nn": pn, "tn": pt}
+    saved = K._P3_PAIR
+    try:
+        K._P3_PAIR = False
+        dx0, dw0 = K.spectral_bwd(ctx, dy, out=term.clone() if acc else None)
+        K._P3_PAIR = True
+        dx1, dw1 = K.spectral_bwd(ctx, dy, out=term.clone() if acc else None)
+        torch.cuda.synchronize()
+    finally:
+        K._P3_PAIR = saved
+    for got, ref, plan in ((dx1, dx0, pn), (dw1, dw0, pt)):
+        if plan[0] == "plain":
+            assert torch.equal(got, ref)
+        else:
+            assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    want = dy.double() @ w.double() + (term.double() if acc else 0.0)
+    assert ((dx1.double() - want).abs().max() / want.abs().max()).item() < 5e-6
+    want = dy.double().t() @ x.double()
+    assert ((dw1.double() - want).abs().max() / want.abs().max()).item() < 5e-6
+    assert K._p3_pair_ok(("plain",), ("split", 2)) and not K._p3_pair_ok(("sk",), ("plain",))      # no stream-K / tail form
+
+
 def test_weight_planes_of_a_step_in_two_launches():
     """ud_split_planes_h2t_multi (kernels._WeightPlaneBatch): the planes of all registered weight matrices from one absmax and
     one split launch equal the per-matrix ud_absmax + ud_split_planes_h2t planes BITWISE (scale included) for assorted shapes

@@ -178,11 +178,12 @@ __device__ __forceinline__ void mma_one(f32x16 (&acc)[2][2], f32x16 (&lo)[2][2],
 //             (blockIdx % 8) take CONSECUTIVE ranges and the tile order walks 8-wide column bands row by row.  Measured: it pays
 //             only where the tile count sits just above a multiple of the CUs (260 tiles: 1.2x); elsewhere workers that share a
 //             panel no longer stream the same k at the same time and the L2 hit rate falls (540 tiles: 0.95x).
-template <int PREC, int AMODE, int BMODE, bool SK = false>
-__global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d, int tiles_m, int tiles_n) {
+// The kernel's body: workgroup bx of gx (and split-K slice by) of the problem d; L: the workgroup's NSTAGE * STAGE bytes of LDS.
+// A device function so that gemm_p3_pair_kernel can run two problems' workgroups in one launch.
+template <int PREC, int AMODE, int BMODE, bool SK>
+__device__ __forceinline__ void p3_body(const ud_gemm_p3_desc& d, int tiles_m, int tiles_n, char* L, int bx, int by, int gx) {
     using CF = Cfg<PREC>;
     constexpr int NPL = CF::NPL, OP_IMG = CF::OP_IMG, STAGE = CF::STAGE, NSTAGE = CF::NSTAGE, PT = CF::PT;
-    __shared__ __attribute__((aligned(1024))) char L[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
     };
 
     if constexpr (!SK) {
-        int bt = blockIdx.x;
+        int bt = bx;
         if (d.tile_cfg & 0x100) {          // each XCD takes a contiguous range of the tile order (see gemm_x3.hip)
             const int Tn = tiles_m * tiles_n, q = Tn >> 3, r = Tn & 7, x = bt & 7;
             bt = x * q + (x < r ? x : r) + (bt >> 3);
@@ -447,21 +448,21 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
             // tile rows column by column, so the ~32 workgroups it runs at a time cover a GM x (32 / GM) block of tiles — they
             // step through K together and share GM A panels + 32 / GM B panels in that L2 instead of ~9 + 8 of the round-robin deal
             const int GM = (d.tile_cfg >> 12) & 15 ? (d.tile_cfg >> 12) & 15 : 4;
-            const int Tn = tiles_m * tiles_n, q = Tn >> 3, r = Tn & 7, x = blockIdx.x & 7;
-            const int o = x * q + (x < r ? x : r) + ((int)blockIdx.x >> 3);
+            const int Tn = tiles_m * tiles_n, q = Tn >> 3, r = Tn & 7, x = bx & 7;
+            const int o = x * q + (x < r ? x : r) + (bx >> 3);
             const int per_group = GM * tiles_n, g = o / per_group, first_m = g * GM;
             const int gm = min(GM, tiles_m - first_m), in = o - g * per_group;
             tile_n = in / gm;
             tile_m = first_m + in - tile_n * gm;
         }
-        const int split = blockIdx.y;
+        const int split = by;
         const int kt_per = (kt_total + d.split_k - 1) / d.split_k;
         const int kt0 = split * kt_per;
         const int nkt = min(kt_per, kt_total - kt0);
         segment(tile_m, tile_n, kt0, nkt, d.out_mode == 3 ? 0 : d.out_mode,
                 d.C + (d.out_mode == 3 ? (long)split * d.slice_stride : 0L), true);
     } else {
-        const int G = gridDim.x, b = blockIdx.x;
+        const int G = gx, b = bx;
         const int g = (b & 7) * (G >> 3) + (b >> 3);
         const long U = (long)tiles_m * tiles_n * kt_total;
         long u = g * U / G;
@@ -480,6 +481,35 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
             first = false;
             u += kt_e - kt_b;
         }
+    }
+}
+
+template <int PREC, int AMODE, int BMODE, bool SK = false>
+__global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d, int tiles_m, int tiles_n) {
+    using CF = Cfg<PREC>;
+    __shared__ __attribute__((aligned(1024))) char L[CF::NSTAGE * CF::STAGE];
+    p3_body<PREC, AMODE, BMODE, SK>(d, tiles_m, tiles_n, L, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// TWO problems in one launch (ud_gemm_p3_pair): the data gradient (modes 0 / 1) and the weight gradient (modes 1 / 1) of one 1x1
+// conv share dy and nothing else, and each alone leaves CUs idle in its last round of tiles (540 tiles on 256 CUs are 2.1 rounds: the
+// third runs 28 workgroups) — two queues would fill the holes but a fork / join costs ~24 us on this runtime (profiles/r05/
+// spectral_pair_streams_ab.txt).  Here the second problem's workgroups simply follow the first's in ONE grid: workgroups
+// [0, n0) = problem 0 (tile, split-K slice) pairs, the rest problem 1; the dispatcher hands them out in order, so problem 1 starts on
+// the CUs problem 0's last round leaves free.  Each problem keeps its own XCD-aware raster over its LOCAL index (the hardware XCD
+// is (local + n0) % 8: the ranges stay contiguous per XCD, rotated).
+template <int PREC>
+__global__ __launch_bounds__(NT, 1) void gemm_p3_pair_kernel(const ud_gemm_p3_desc d0, int tm0, int tn0, int n0,
+                                                              const ud_gemm_p3_desc d1, int tm1, int tn1) {
+    using CF = Cfg<PREC>;
+    __shared__ __attribute__((aligned(1024))) char L[CF::NSTAGE * CF::STAGE];
+    const int b = (int)blockIdx.x;
+    if (b < n0) {
+        const int T = tm0 * tn0;
+        p3_body<PREC, 0, 1, false>(d0, tm0, tn0, L, b % T, b / T, T);
+    } else {
+        const int l = b - n0, T = tm1 * tn1;
+        p3_body<PREC, 1, 1, false>(d1, tm1, tn1, L, l % T, l / T, T);
     }
 }
 
@@ -911,20 +941,42 @@ extern "C" int ud_split_planes_h2(const float* x, long R, int C, long ld, uint16
     return 0;
 }
 
-extern "C" int ud_gemm_p3(const ud_gemm_p3_desc* dp, ud_stream_t stream) {
-    if (!dp) return UD_EINVAL;
-    const ud_gemm_p3_desc& d = *dp;
+static bool p3_desc_ok(const ud_gemm_p3_desc& d);
+
+extern "C" int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc* tn, ud_stream_t stream) {
+    if (!nn || !tn || !p3_desc_ok(*nn) || !p3_desc_ok(*tn)) return UD_EINVAL;
+    const ud_gemm_p3_desc &d0 = *nn, &d1 = *tn;
+    if (d0.prec != 2 || d1.prec != 2 || d0.a_mode != 0 || d0.b_mode != 1 || d1.a_mode != 1 || d1.b_mode != 1) return UD_EINVAL;
+    if ((d0.tile_cfg | d1.tile_cfg) & 0x800) return UD_EINVAL;          // no stream-K form
+    if (d0.stat_sum || d1.stat_sum || d0.out_mode == 3 || d1.out_mode == 3) return UD_EINVAL;
+    const int tm0 = ud_cdiv(d0.M, BM), tn0 = ud_cdiv(d0.N, BN), tm1 = ud_cdiv(d1.M, BM), tn1 = ud_cdiv(d1.N, BN);
+    const long n0 = (long)tm0 * tn0 * d0.split_k, n1 = (long)tm1 * tn1 * d1.split_k;
+    if (n0 + n1 > 0x7fffffffL) return UD_EINVAL;
+    hipLaunchKernelGGL((gemm_p3_pair_kernel<2>), dim3((unsigned)(n0 + n1)), dim3(NT), 0, (hipStream_t)stream, d0, tm0, tn0, (int)n0,
+                       d1, tm1, tn1);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+static bool p3_desc_ok(const ud_gemm_p3_desc& d) {
     if (!d.A || !d.B || !d.C || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.K % BK != 0 || d.split_k < 1 ||
         d.split_k > d.K / BK || d.out_mode < 0 || d.out_mode > 3 || d.a_mode < 0 || d.a_mode > 1 || d.b_mode < 0 ||
         d.b_mode > 1 || d.a_panel % 8 != 0 || d.b_panel % 8 != 0 || d.a_plane % 8 != 0 || d.b_plane % 8 != 0 ||
         d.a_npanel < 1 || d.b_npanel < 1 || (d.prec != 2 && d.prec != 3))
-        return UD_EINVAL;
+        return false;
     if (d.prec == 2 && (!d.a_inv_scale || !d.b_inv_scale || d.a_scale_stride < 0 || d.a_scale_stride > 1 ||
                         d.b_scale_stride < 0 || d.b_scale_stride > 1))
-        return UD_EINVAL;
-    if (d.stat_sum && (d.out_mode != 0 || d.split_k != 1 || !d.stat_sumsq || (d.tile_cfg & 0x800))) return UD_EINVAL;
-    if ((d.tile_cfg & 0x800) && (d.out_mode > 1 || d.split_k != 1)) return UD_EINVAL;          // stream-K: store-onto-zeros or add
-    if (d.out_mode == 3 && d.slice_stride < (long)d.M * d.ldc) return UD_EINVAL;
+        return false;
+    if (d.stat_sum && (d.out_mode != 0 || d.split_k != 1 || !d.stat_sumsq || (d.tile_cfg & 0x800))) return false;
+    if ((d.tile_cfg & 0x800) && (d.out_mode > 1 || d.split_k != 1)) return false;          // stream-K: store-onto-zeros or add
+    if (d.out_mode == 3 && d.slice_stride < (long)d.M * d.ldc) return false;
+    return true;
+}
+
+extern "C" int ud_gemm_p3(const ud_gemm_p3_desc* dp, ud_stream_t stream) {
+    if (!dp) return UD_EINVAL;
+    const ud_gemm_p3_desc& d = *dp;
+    if (!p3_desc_ok(d)) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (d.prec == 2) {
         if (d.a_mode == 0 && d.b_mode == 0) return launch<2, 0, 0>(d, s);

@@ -489,9 +489,8 @@ _P3_RASTER = 0x4200
 _P3_STAT_SLOT_TILES = 64          # row tiles beyond which the epilogue statistics go through 64 slots + a fold launch
 
 
-def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=None, a_row0=0, cfg=0):
-    """Cout[M][N] (+)= A . B from pre-split operands.  a_row0: first GEMM row of A used (a multiple of 128; mode 0: a row
-    offset inside every panel, mode 1: whole panels).  stats as in _gemm."""
+def _p3_desc(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, a_row0=0, cfg=0):
+    """the ud_gemm_p3_desc of Cout[M][N] (+)= A . B from pre-split operands (see _gemm_p3)"""
     d = GemmP3Desc()
     if a_mode == 0:
         d.A = A.buf.data_ptr() + 2 * (a_row0 * 32)
@@ -514,6 +513,52 @@ def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=N
         d.a_inv_scale = A.inv.data_ptr() + 4 * a_row0 * A.scale_stride
         d.b_inv_scale = B.inv.data_ptr()
         d.a_scale_stride, d.b_scale_stride = A.scale_stride, B.scale_stride
+    return d
+
+
+_P3_PAIR = True          # A/B: tools/run_with.py kernels._P3_PAIR=False
+
+
+def _p3_pair_ok(pn, pt):
+    """can the data gradient and the weight gradient of a 1x1 conv go out as ONE launch of the planes kernel (ud_gemm_p3_pair)?
+    Both plans plain or split-K (no stream-K / tail form).  Measured on the bench: pairing only where the two grids together fill
+    fewer rounds of 256 workgroups than apart (540 + 225 tiles: 3 instead of 3 + 1) 25.85 -> 25.69 ms, pairing always 25.61 — the
+    second problem's workgroups start wherever the first's last round leaves a CU free, and a launch is saved"""
+    return pn[0] in ("plain", "split") and pt[0] in ("plain", "split")
+
+
+def spectral_bwd(ctx, dy2, out=None, dy_absmax=None):
+    """(dx, dw) of a 1x1 conv: spectral_dgrad + spectral_wgrad — as ONE launch of the planes kernel where both plans allow
+    (ud_gemm_p3_pair: the weight gradient's workgroups follow the data gradient's in one grid)"""
+    if (ctx.plans is None or not _P3_PAIR or CFG.deterministic or GEMM_PROFILE is not None or
+            not _p3_pair_ok(ctx.plans["nn"], ctx.plans["tn"])):
+        dw = spectral_wgrad(ctx, dy2, dy_absmax)
+        return spectral_dgrad(ctx, dy2, out=out, dy_absmax=dy_absmax), dw
+    dy = _spectral_dy(ctx, dy2, dy_absmax)
+    pn, pt = ctx.plans["nn"], ctx.plans["tn"]
+    M, N, Kd = ctx.M, ctx.N, ctx.K
+    acc = out is not None
+    # nn: dx[M, Kd] = dy[M, N] . w[N, Kd] (reduction N);  tn: dw[N, Kd] = dy[M, N]^T . x[M, Kd] (reduction M)
+    if pn[0] == "plain":
+        dx = out if acc else empty((M, Kd), dy2)
+        d0 = _p3_desc(dy, ctx.w, dx, M, Kd, -(-N // 32) * 32, 0, 1, 1 if acc else 0, 1)
+    else:
+        dx = out if acc else split_out((M, Kd), dy2)
+        d0 = _p3_desc(dy, ctx.w, dx, M, Kd, -(-N // 32) * 32, 0, 1, 2, int(pn[1]))
+    if pt[0] == "plain":
+        dw = empty((N, Kd), dy2)
+        d1 = _p3_desc(dy, ctx.x, dw, N, Kd, -(-M // 32) * 32, 1, 1, 0, 1)
+    else:
+        dw = split_out((N, Kd), dy2)
+        d1 = _p3_desc(dy, ctx.x, dw, N, Kd, -(-M // 32) * 32, 1, 1, 2, int(pt[1]))
+    _call("ud_gemm_p3_pair", C.byref(d0), C.byref(d1), _stream())
+    return dx, dw
+
+
+def _gemm_p3(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, stats=None, a_row0=0, cfg=0):
+    """Cout[M][N] (+)= A . B from pre-split operands.  a_row0: first GEMM row of A used (a multiple of 128; mode 0: a row
+    offset inside every panel, mode 1: whole panels).  stats as in _gemm."""
+    d = _p3_desc(A, B, Cout, M, N, K, a_mode, b_mode, out_mode, split_k, a_row0, cfg)
     slices = None
     if CFG.deterministic and out_mode == 2:
         total = M * N

@@ -76,6 +76,7 @@ _BN = C.POINTER(BnRef)
 _SIGNATURES = {
     "ud_gemm": [C.POINTER(GemmDesc), _P],
     "ud_gemm_p3": [C.POINTER(GemmP3Desc), _P],
+    "ud_gemm_p3_pair": [C.POINTER(GemmP3Desc), C.POINTER(GemmP3Desc), _P],
     "ud_split_planes": [_P, _L, _I, _L, _P, _L, _L, _P],
     "ud_split_planes_h2": [_P, _L, _I, _L, _P, _L, _L, _P, _P],
     "ud_absmax": [_P, _L, _I, _L, _P, _P],

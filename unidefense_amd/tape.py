@@ -141,9 +141,12 @@ def conv1x1(tape, x, w, need_dx=True):
         if dy is None:
             return
         dy2 = dy.reshape(-1, Co)
-        tape.wgrad(w, lambda: K.spectral_wgrad(ctx, dy2), dy2)
         if need_dx:
-            tape.add_grad(x, K.spectral_dgrad(ctx, dy2).view(x.shape))
+            dx, dw = K.spectral_bwd(ctx, dy2)          # (one launch on the planes GEMM where both plans allow)
+            tape.add_param_grad(w, dw)
+            tape.add_grad(x, dx.view(x.shape))
+        else:
+            tape.wgrad(w, lambda: K.spectral_wgrad(ctx, dy2), dy2)
     tape.record(bwd)
     return y
 
@@ -163,10 +166,13 @@ def _conv_im2col(tape, x, w, wmat, g, need_dx):
             dy2 = dy.reshape(-1, Co)
             if not dy2.is_contiguous():
                 dy2 = dy2.contiguous()
-            dw = K.spectral_wgrad(ctx, dy2)                            # [Co, KH*KW*Ci]
+            if need_dx:
+                dcol, dw = K.spectral_bwd(ctx, dy2)                    # dw [Co, KH*KW*Ci]
+            else:
+                dcol, dw = None, K.spectral_wgrad(ctx, dy2)
             tape.add_param_grad(w, dw.view(Co, KH, KW, Ci).permute(0, 3, 1, 2).contiguous())
             if need_dx:
-                tape.add_grad(x, K.col2im(K.spectral_dgrad(ctx, dy2), g))
+                tape.add_grad(x, K.col2im(dcol, g))
         tape.record(bwd)
     return y
 
@@ -1129,8 +1135,9 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
             dp2, dp_amax = dp_.view(Mo, Co), getattr(dp_, "_ud_absmax", None)
         tape.add_param_grad(blk._bn2.weight, dg2)
         tape.add_param_grad(blk._bn2.bias, db2)
-        tape.wgrad(blk._project_conv.weight, lambda: K.spectral_wgrad(pctx, dp2, dp_amax), dp2)
-        dc = K.spectral_dgrad(pctx, dp2, dy_absmax=dp_amax).view(N, Ho, Wo, Ce)
+        dc, dWp = K.spectral_bwd(pctx, dp2, dy_absmax=dp_amax)          # (one launch for both where that fills the chip better)
+        tape.add_param_grad(blk._project_conv.weight, dWp)
+        dc = dc.view(N, Ho, Wo, Ce)
         # ---- squeeze-excite backward
         dgate = K.zeros64(N * Ce, x)
         K.coldot_bn(dc, d, bn1, N, HWo, dgate)
@@ -1168,8 +1175,9 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 dyf2, dyf_amax = sctx.w.buf, None                      # (an fp32 tensor of the right device for the launch wrappers)
             else:
                 dyf2, dyf_amax = dyf.view(-1, 2 * Ce), getattr(dyf, "_ud_absmax", None)
-            tape.wgrad(dwm.freq_conv.weight, lambda: K.spectral_wgrad(sctx, dyf2, dyf_amax), dyf2)
-            dxf = K.spectral_dgrad(sctx, dyf2, dy_absmax=dyf_amax).view(xf_shape)
+            dxf, dWf = K.spectral_bwd(sctx, dyf2, dy_absmax=dyf_amax)
+            tape.add_param_grad(dwm.freq_conv.weight, dWf)
+            dxf = dxf.view(xf_shape)
             # 8 x 8 maps: the adjoint transform's kernel also does the depthwise conv's backward over the planes it holds
             irdw = src_bn is not None and K.irfft2_dwbwd_ok(S, k, stride, sp.pad, x.dtype)
             if not irdw:
@@ -1237,13 +1245,15 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 de2, de_amax = de.view(M, Ce), getattr(de, "_ud_absmax", None)
             tape.add_param_grad(blk._bn0.weight, dg0)
             tape.add_param_grad(blk._bn0.bias, db0)
-            tape.wgrad(blk._expand_conv.weight, lambda: K.spectral_wgrad(ectx, de2, de_amax), de2)
             if sp.skip and tape.watch is None and getattr(dout, "_ud_owned", False):
-                dx = K.spectral_dgrad(ectx, de2, out=dout.view(M, Cin), dy_absmax=de_amax).view(x.shape)    # + skip gradient
+                dx, dWe = K.spectral_bwd(ectx, de2, out=dout.view(M, Cin), dy_absmax=de_amax)    # + skip gradient
+                dx = dx.view(x.shape)
             else:
-                dx = K.spectral_dgrad(ectx, de2, dy_absmax=de_amax).view(x.shape)
+                dx, dWe = K.spectral_bwd(ectx, de2, dy_absmax=de_amax)
+                dx = dx.view(x.shape)
                 if sp.skip:
                     dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
+            tape.add_param_grad(blk._expand_conv.weight, dWe)
         else:
             if dw_f is None:
                 add = da_f
