@@ -232,7 +232,8 @@ def test_xcd_raster_is_a_permutation_of_the_tiles(kind, M, N, Kd):
 @pytest.mark.parametrize("M,N,Kd,pn,pt,acc", [(128 * 7 + 40, 128 * 3, 128 * 5, ("plain",), ("plain",), False),
                                               (128 * 9, 128 * 2 + 16, 128 * 4 + 32, ("plain",), ("split", 3), True),
                                               (128 * 5, 128 * 6, 128 * 3, ("split", 2), ("split", 2), False),
-                                              (4608, 1920, 1920, ("plain",), ("plain",), False)])
+                                              (4608, 1920, 1920, ("plain",), ("plain",), False),
+                                              (1280, 3264, 3264, ("sk",), ("plain",), False)])
 def test_data_and_weight_gradient_in_one_launch(M, N, Kd, pn, pt, acc):
     """ud_gemm_p3_pair (round 5): the data gradient dx[M, K] = dy . w and the weight gradient dw[N, K] = dy^T . x of a 1x1 conv as
     ONE grid — the weight gradient's workgroups follow the data gradient's.  Every tile is computed by the same code on the same
@@ -257,7 +258,7 @@ def test_data_and_weight_gradient_in_one_launch(M, N, Kd, pn, pt, acc):
     finally:
         K._P3_PAIR = saved
     for got, ref, plan in ((dx1, dx0, pn), (dw1, dw0, pt)):
-        if plan[0] == "plain":
+        if plan[0] == "plain":          # (a stream-K reference sums its K segments by atomics)
             assert torch.equal(got, ref)
         else:
             assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
@@ -265,7 +266,8 @@ def test_data_and_weight_gradient_in_one_launch(M, N, Kd, pn, pt, acc):
     assert ((dx1.double() - want).abs().max() / want.abs().max()).item() < 5e-6
     want = dy.double().t() @ x.double()
     assert ((dw1.double() - want).abs().max() / want.abs().max()).item() < 5e-6
-    assert K._p3_pair_ok(("plain",), ("split", 2)) and not K._p3_pair_ok(("sk",), ("plain",))      # no stream-K / tail form
+    assert K._p3_pair_ok(("plain",), ("split", 2)) and K._p3_pair_ok(("sk",), ("plain",))      # (stream-K: as plain tiles in the pair)
+    assert not K._p3_pair_ok(("tail", 1024, 2), ("plain",)) and not K._p3_pair_ok(("plain",), ("sk",))
 
 
 def test_weight_planes_of_a_step_in_two_launches():

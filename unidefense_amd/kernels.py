@@ -517,14 +517,18 @@ def _p3_desc(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, a_row0=
 
 
 _P3_PAIR = True          # A/B: tools/run_with.py kernels._P3_PAIR=False
+_P3_PAIR_SK = True       # ... also the shapes whose data gradient alone runs stream-K (as plain tiles in the pair: 25.67 -> 25.39 ms)
 
 
 def _p3_pair_ok(pn, pt):
     """can the data gradient and the weight gradient of a 1x1 conv go out as ONE launch of the planes kernel (ud_gemm_p3_pair)?
-    Both plans plain or split-K (no stream-K / tail form).  Measured on the bench: pairing only where the two grids together fill
+    Both plans plain or split-K, or a stream-K data gradient (run as plain tiles: the weight gradient's workgroups even out its
+    last round instead); no tail form.  Measured on the bench: pairing only where the two grids together fill
     fewer rounds of 256 workgroups than apart (540 + 225 tiles: 3 instead of 3 + 1) 25.85 -> 25.69 ms, pairing always 25.61 — the
-    second problem's workgroups start wherever the first's last round leaves a CU free, and a launch is saved"""
-    return pn[0] in ("plain", "split") and pt[0] in ("plain", "split")
+    second problem's workgroups start wherever the first's last round leaves a CU free, and a launch is saved.  The weight
+    gradient keeps the split-K factor tuned for its own launch: x 0.5 / 0.25 and x 1.5 / 2 / 3 all measured slower (25.4 ->
+    25.9 / 26.5 and 25.9 / 26.1 / 26.4 ms, profiles/r05/p3_pair_ab.txt)"""
+    return pn[0] in (("plain", "split", "sk") if _P3_PAIR_SK else ("plain", "split")) and pt[0] in ("plain", "split")
 
 
 def spectral_bwd(ctx, dy2, out=None, dy_absmax=None):
@@ -536,6 +540,8 @@ def spectral_bwd(ctx, dy2, out=None, dy_absmax=None):
         return spectral_dgrad(ctx, dy2, out=out, dy_absmax=dy_absmax), dw
     dy = _spectral_dy(ctx, dy2, dy_absmax)
     pn, pt = ctx.plans["nn"], ctx.plans["tn"]
+    if pn[0] == "sk":
+        pn = ("plain",)          # stream-K evens out ONE launch's last round; in the pair the other problem's tiles do
     M, N, Kd = ctx.M, ctx.N, ctx.K
     acc = out is not None
     # nn: dx[M, Kd] = dy[M, N] . w[N, Kd] (reduction N);  tn: dw[N, Kd] = dy[M, N]^T . x[M, Kd] (reduction M)
