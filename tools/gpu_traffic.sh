@@ -24,9 +24,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] != c:
                 continue
             name = r["Kernel_Name"]
-            fam = ("gemm_p3_kernel" if "gemm_p3_kernel" in name else "gemm_x3_kernel" if "gemm_x3_kernel" in name else
+            pair = "gemm_p3_pair_kernel" in name          # two products (data + weight gradient) in one grid: counted as two launches
+            fam = ("gemm_p3_kernel" if ("gemm_p3_kernel" in name or pair) else "gemm_x3_kernel" if "gemm_x3_kernel" in name else
                    "gemm_kernel" if "gemm_kernel" in name else "other")
-            a = agg[fam]; a[0] += 1; a[1] += float(r["Counter_Value"])
+            a = agg[fam]; a[0] += 2 if pair else 1; a[1] += float(r["Counter_Value"])
     tot[c] = {k: v for k, v in agg.items()}
 import hashlib
 def gemm_src_sha():          # bench.py:_gemm_src_sha — the summary belongs to these kernel sources and no others

@@ -17,7 +17,7 @@ def main(stats_csv, table_txt, steps):
         for row in csv.DictReader(fh):
             ns = float(row["TotalDurationNs"])
             total_ns += ns
-            if "gemm_p3_kernel" in row["Name"]:
+            if "gemm_p3_kernel" in row["Name"] or "gemm_p3_pair_kernel" in row["Name"]:          # (pair: two products in one grid)
                 p3_ns += ns
             elif "gemm_x3_kernel" in row["Name"]:
                 x3_ns += ns
