@@ -434,8 +434,9 @@ def main():
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
         with open(args.gemm_table, "w") as fh:
-            fh.write("# per-shape GEMM timing, %d eager instrumented steps; pipe: 4 = gemm_p3_kernel<prec 2> (pre-split fp16 x 2 planes, "
-                     "3 MFMAs per product), 2 = gemm_x3_kernel (in-kernel bf16 x 3 split, 6 MFMAs), 1 = gemm_kernel (fp32 pipe)\n" % prof_steps)
+            fh.write("# per-shape GEMM timing, %d eager instrumented steps; pipe: 4 = the planes kernel gemm_p3_kernel (f32 mode: prec 2, pre-split fp16 x 2 "
+                     "planes, 3 MFMAs per product; --dtype f16: prec 1, one fp16 plane, 1 MFMA), 2 = gemm_x3_kernel (in-kernel bf16 x 3 "
+                     "split, 6 MFMAs), 3 = gemm_x3_kernel's fp16 form (--dtype f16), 1 = gemm_kernel (fp32 pipe)\n" % prof_steps)
             fh.write("M N K a_mode b_mode split batch pipe | calls ms_total ms_per_step TFLOP/s gflop_per_step\n")
             for key, (cnt, ms, fl) in rows:
                 fh.write("%7d %5d %6d %d %d %3d %3d %d | %4d %8.3f %8.3f %7.1f %9.3f\n" %

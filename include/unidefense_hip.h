@@ -122,6 +122,10 @@ int ud_gemm_query_path(const ud_gemm_desc* d);
  *           scale per tensor a GEMM row lying 2^-24 below the largest keeps ~16 bits; with a scale per row every row keeps 22), the
  *           dropped a1b1 < 2^-24 |ab|, fp32 accumulation: the accuracy of an
  *           fp32 GEMM (measured at or below ud_gemm's error on every operand distribution tried) at half the matrix work.
+ *   prec 1: ONE fp16 plane per operand — the first plane of prec-2 operands (or planes written by ud_planes_from_half, scale 1):
+ *           one product per tile on the fp16 matrix pipe, fp32 accumulation, the result times the two inverse scales — the
+ *           mixed-precision mode (BASELINE configs[4]: fp16 MFMA operands), 530-770 TFLOP/s on the spectral convs' shapes against
+ *           290-530 of ud_gemm's path 3 (tools/bench_p3_prec1.py).  (a_mode, b_mode) as prec 2; c_half: a half-stored result.
  *   mode 0: GEMM row = row of X, k = column of X     (activations [pixels][C] as A; weights [Cout][Cin] as B)
  *   mode 1: GEMM row = column of X, k = row of X     (dY / X of a weight gradient; weights of a data gradient)
  * (a_mode, b_mode): prec 3 any; prec 2 (0,0) (0,1) (1,1).  K % 32 == 0.  *_npanel: panels reachable from the pointer (mode 1 clamps
@@ -142,9 +146,10 @@ typedef struct {
     double* stat_sum; double* stat_sumsq;
     int tile_cfg;
     long slice_stride;
-    int prec;                                   /* 3 or 2 */
-    const float* a_inv_scale; const float* b_inv_scale;   /* prec 2 */
+    int prec;                                   /* 3, 2 or 1 */
+    const float* a_inv_scale; const float* b_inv_scale;   /* prec 2 / 1 */
     int a_scale_stride, b_scale_stride;         /* 0: one scale for the operand; 1: one per GEMM row */
+    int c_half;                                 /* prec 1: C is _Float16 (out_mode 0 / 1, split_k 1, no stream-K) */
 } ud_gemm_p3_desc;
 int ud_gemm_p3(const ud_gemm_p3_desc* d, ud_stream_t stream);
 /* TWO products in one launch: the data gradient (nn: a_mode 0, b_mode 1) and the weight gradient (tn: a_mode 1, b_mode 1) of one
@@ -152,6 +157,11 @@ int ud_gemm_p3(const ud_gemm_p3_desc* d, ud_stream_t stream);
  * follow the data gradient's in the same grid, so they start on the CUs the data gradient's last round of tiles leaves idle
  * (540 + 225 tiles on 256 CUs: 3 rounds instead of 3 + 1).  Results are those of two ud_gemm_p3 calls. */
 int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc* tn, ud_stream_t stream);
+/* A half-stored matrix X[R][C] (row stride ld elements, C % 8 == 0, 16-byte aligned) as ONE fp16 plane in the P32 layout, values
+ * unchanged (*inv_scale = 1): the operand of ud_gemm_p3 prec 1 for the activations of the mixed-precision mode (BASELINE
+ * configs[4]); pad columns of the last panel zero. */
+int ud_planes_from_half(const void* x, long R, int C, long ld, uint16_t* planes, long panel_stride, float* inv_scale,
+                        ud_stream_t stream);
 /* x fp32 [R][C] (row stride ld; C, ld multiples of 4) -> three bf16 planes in the P32 layout above; columns C .. 32*ceil(C/32)-1
  * are written as zeros, slack rows are left untouched. */
 int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride, long plane_stride,

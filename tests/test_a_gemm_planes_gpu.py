@@ -270,6 +270,47 @@ def test_data_and_weight_gradient_in_one_launch(M, N, Kd, pn, pt, acc):
     assert not K._p3_pair_ok(("tail", 1024, 2), ("plain",)) and not K._p3_pair_ok(("plain",), ("sk",))
 
 
+@pytest.mark.parametrize("kind,M,N,Kd", [("nt", 128 * 9 + 32, 128 * 5, 512), ("nn", 128 * 6, 128 * 3 + 64, 768), ("tn", 128 * 4, 128 * 5, 2048)])
+def test_prec1_is_the_fp16_operand_gemm(kind, M, N, Kd):
+    """ud_gemm_p3 prec 1 (round 5; the mixed-precision mode, BASELINE configs[4]): ONE fp16 plane per operand, one product per tile,
+    fp32 accumulation.  Its operands: a half-stored activation through ud_planes_from_half (a layout pass, values unchanged) and
+    the FIRST plane of prec-2 planes (weights).  Held to the float64 product of the fp16-ROUNDED operands to fp32-accumulation
+    accuracy (1e-5 of the result's scale), fp32 and half-stored results, ragged edges; the layout pass round-trips bit for bit."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(7)
+    a, b, am, bm = _operands(kind, M, N, Kd, dev)
+    ah = a.half()
+    ap = K.planes_from_half(ah)                                    # activation operand: one plane, scale 1
+    bp = K.split_planes(b.contiguous(), prec=2)                    # weight-like operand: prec-2 planes, first plane read
+    R, Cc = ah.shape
+    plane0 = ap.buf.view(ap.npanel, ap.panel // 32, 32)[:, :R].view(torch.float16).permute(1, 0, 2).reshape(R, ap.npanel * 32)
+    torch.cuda.synchronize()
+    assert torch.equal(plane0[:, :Cc], ah) and float(ap.inv) == 1.0
+    binv = float(bp.inv)
+    b0 = bp.buf.view(2, bp.npanel, bp.panel // 32, 32)[0, :, :b.shape[0]].view(torch.float16).permute(1, 0, 2).reshape(b.shape[0], bp.npanel * 32)
+    b_eff = b0[:, :b.shape[1]].double() * binv                     # what the kernel multiplies by
+    if kind == "nt":
+        want = ah.double() @ b_eff.t()
+    elif kind == "nn":
+        want = ah.double() @ b_eff
+    else:
+        want = ah.double().t() @ b_eff
+    o32 = torch.full((M, N), float("nan"), device=dev)
+    K._gemm_p3(ap, bp, o32, M, N, -(-Kd // 32) * 32, am, bm)
+    torch.cuda.synchronize()
+    assert ((o32.double() - want).abs().max() / want.abs().max()).item() < 1e-5
+    if kind != "tn":
+        o16 = torch.full((M, N), float("nan"), device=dev, dtype=torch.float16)
+        K._gemm_p3(ap, bp, o16, M, N, -(-Kd // 32) * 32, am, bm)
+        term = torch.randn(M, N, device=dev).half()
+        acc = term.clone()
+        K._gemm_p3(ap, bp, acc, M, N, -(-Kd // 32) * 32, am, bm, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(o16, o32.half())
+        assert torch.equal(acc, (o32 + term.float()).half())
+
+
 def test_weight_planes_of_a_step_in_two_launches():
     """ud_split_planes_h2t_multi (kernels._WeightPlaneBatch): the planes of all registered weight matrices from one absmax and
     one split launch equal the per-matrix ud_absmax + ud_split_planes_h2t planes BITWISE (scale included) for assorted shapes

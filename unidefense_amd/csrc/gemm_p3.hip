@@ -46,9 +46,9 @@ template <int PREC> struct Cfg {
     static constexpr int NPL = PREC;                    // planes per operand
     static constexpr int OP_IMG = NPL * PLANE_IMG;      // one operand, all planes
     static constexpr int STAGE = 2 * OP_IMG;            // A then B
-    static constexpr int NSTAGE = PREC == 3 ? 3 : 4;    // 144 KiB / 128 KiB of LDS
+    static constexpr int NSTAGE = PREC == 3 ? 3 : 4;    // 144 KiB / 128 KiB of LDS (PREC 1: 64 KiB)
     static constexpr int PT = 4 * NPL;                  // DMA pieces per tile and loader wave
-    static constexpr int NTERM = PREC == 3 ? 6 : 3;     // piece products per 32x32x16
+    static constexpr int NTERM = PREC == 3 ? 6 : PREC == 2 ? 3 : 1;     // piece products per 32x32x16
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -131,7 +131,7 @@ struct Reader {
     template <int S, int NPL>
     __device__ __forceinline__ void read(const lds_char* img, Frags<NPL>& f) const {
         read_one<S, 0, 0>(img, f); read_one<S, 1, 0>(img, f);
-        read_one<S, 0, 1>(img, f); read_one<S, 1, 1>(img, f);
+        if constexpr (NPL >= 2) { read_one<S, 0, 1>(img, f); read_one<S, 1, 1>(img, f); }
         if constexpr (NPL == 3) { read_one<S, 0, 2>(img, f); read_one<S, 1, 2>(img, f); }
     }
 };
@@ -146,8 +146,8 @@ __device__ __forceinline__ unsigned dma_lane_offset(int lane) {
 // planes of the TERM-th piece product, smallest first.  PREC 3 (gemm_x3.hip's order): a2b0, a0b2, a1b1, a1b0, a0b1, a0b0;
 // PREC 2: a1b0, a0b1, a0b0
 template <int PREC, int TERM> struct Term {
-    static constexpr int pa = PREC == 3 ? (TERM == 0 ? 2 : (TERM == 1 || TERM >= 4) ? 0 : 1) : (TERM == 0 ? 1 : 0);
-    static constexpr int pb = PREC == 3 ? (TERM == 0 ? 0 : TERM == 1 ? 2 : (TERM == 2 || TERM == 4) ? 1 : 0) : (TERM == 1 ? 1 : 0);
+    static constexpr int pa = PREC == 3 ? (TERM == 0 ? 2 : (TERM == 1 || TERM >= 4) ? 0 : 1) : PREC == 2 ? (TERM == 0 ? 1 : 0) : 0;
+    static constexpr int pb = PREC == 3 ? (TERM == 0 ? 0 : TERM == 1 ? 2 : (TERM == 2 || TERM == 4) ? 1 : 0) : PREC == 2 ? (TERM == 1 ? 1 : 0) : 0;
 };
 
 // MFMA number Mi of a k-step: product term Mi / 4 of accumulator Mi % 4 (the accumulators are interleaved, every one sees
@@ -159,6 +159,9 @@ __device__ __forceinline__ void mma_one(f32x16 (&acc)[2][2], f32x16 (&lo)[2][2],
     if constexpr (PREC == 3) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v[i][Tm::pa]),
                                                             __builtin_bit_cast(bf16x8, b.v[j][Tm::pb]), acc[i][j], 0, 0, 0);
+    } else if constexpr (PREC == 1) {          // the first fp16 piece only: one product (mixed precision, BASELINE configs[4])
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v[i][0]),
+                                                           __builtin_bit_cast(f16x8, b.v[j][0]), acc[i][j], 0, 0, 0);
     } else if constexpr (term < 2) {
         lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v[i][Tm::pa]),
                                                           __builtin_bit_cast(f16x8, b.v[j][Tm::pb]), lo[i][j], 0, 0, 0);
@@ -194,6 +197,7 @@ __device__ __forceinline__ void p3_body(const ud_gemm_p3_desc& d, int tiles_m, i
     // re-loaded d.ldc from the argument segment (and waited for it) before EVERY one of a lane's 64 stores — 9 us per tile
     const int dM = d.M, dN = d.N;
     const long ldc = d.ldc;
+    const bool c_half = d.c_half != 0;
     double* const stat_sum = d.stat_sum;
     double* const stat_sumsq = d.stat_sumsq;
     const float* const a_inv = d.a_inv_scale;
@@ -297,25 +301,25 @@ __device__ __forceinline__ void p3_body(const ud_gemm_p3_desc& d, int tiles_m, i
                              const lds_char* img) {
                 constexpr int RS = decltype(rs_c)::value;
                 constexpr bool RD = decltype(do_read_c)::value;
-                constexpr int NSLOT = 2 * NPL, PER = 4 * CF::NTERM / NSLOT;          // 6 slots of 4 MFMAs / 4 slots of 3
+                constexpr int NSLOT = 2 * NPL, PER = 4 * CF::NTERM / NSLOT;          // 6 slots of 4 MFMAs / 4 slots of 3 / 2 slots of 2
                 auto slot = [&](auto k_c) {
                     constexpr int k = decltype(k_c)::value;
                     // fragment pair k: row block k & 1; planes in the order of first use (PREC 3: A 2,0,1 / B 0,2,1; PREC 2: A 1,0 / B 0,1)
                     constexpr int ai = k & 1, bi = k & 1;
-                    constexpr int apl = NPL == 3 ? (k < 2 ? 2 : k < 4 ? 0 : 1) : (k < 2 ? 1 : 0);
-                    constexpr int bpl = NPL == 3 ? (k < 2 ? 0 : k < 4 ? 2 : 1) : (k < 2 ? 0 : 1);
+                    constexpr int apl = NPL == 3 ? (k < 2 ? 2 : k < 4 ? 0 : 1) : NPL == 2 ? (k < 2 ? 1 : 0) : 0;
+                    constexpr int bpl = NPL == 3 ? (k < 2 ? 0 : k < 4 ? 2 : 1) : NPL == 2 ? (k < 2 ? 0 : 1) : 0;
                     if constexpr (RD) {
                         ra.template read_one<RS, ai, apl>(img, na);
                         rb.template read_one<RS, bi, bpl>(img + OP_IMG, nb);
                     }
                     mma_one<PREC, PER * k>(acc, lo2, ca, cb);
                     mma_one<PREC, PER * k + 1>(acc, lo2, ca, cb);
-                    mma_one<PREC, PER * k + 2>(acc, lo2, ca, cb);
+                    if constexpr (PER >= 3) mma_one<PREC, PER * k + 2>(acc, lo2, ca, cb);
                     if constexpr (PER == 4) mma_one<PREC, PER * k + 3>(acc, lo2, ca, cb);
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                slot(integral_constant<int, 0>{}); slot(integral_constant<int, 1>{}); slot(integral_constant<int, 2>{});
-                slot(integral_constant<int, 3>{});
+                slot(integral_constant<int, 0>{}); slot(integral_constant<int, 1>{});
+                if constexpr (NSLOT >= 4) { slot(integral_constant<int, 2>{}); slot(integral_constant<int, 3>{}); }
                 if constexpr (NSLOT == 6) { slot(integral_constant<int, 4>{}); slot(integral_constant<int, 5>{}); }
             };
             // iteration t (fragments of (t, k-step 0) in fa0 / fb0):
@@ -333,7 +337,7 @@ __device__ __forceinline__ void p3_body(const ud_gemm_p3_desc& d, int tiles_m, i
 
         // ---- epilogue: D[i][j], j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
         if (nkt <= 0 && ep != 0) return;
-        if constexpr (PREC == 2) {
+        if constexpr (PREC <= 2) {
             // undo the operands' power-of-two scales (exact); rows / columns beyond the matrix were fed from slack: zero.
             // The scales are loaded UNCONDITIONALLY from clamped addresses, all of them before the first use: a load under a
             // per-element select (`ok ? scale[row] : 0`) made hipcc branch around each one and wait for it on the spot —
@@ -364,7 +368,9 @@ __device__ __forceinline__ void p3_body(const ud_gemm_p3_desc& d, int tiles_m, i
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float v = (acc[i][j][r] + 0x1p-11f * lo[i][j][r]) * (ia[i][r] * ib[j]);
+                        float v = acc[i][j][r];
+                        if constexpr (PREC == 2) v += 0x1p-11f * lo[i][j][r];
+                        v *= ia[i][r] * ib[j];
                         asm volatile("" : "+v"(v));          // computed, then selected: no branch around the arithmetic
                         acc[i][j][r] = (cok && row < dM) ? v : 0.f;
                     }
@@ -409,23 +415,37 @@ __device__ __forceinline__ void p3_body(const ud_gemm_p3_desc& d, int tiles_m, i
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = n0 + wn * 64 + j * 32 + l31;
-                    float* pc = Cp + (long)(m0 + wm * 64 + i * 32 + 4 * half) * ldc + col;
+                    const long off0 = (long)(m0 + wm * 64 + i * 32 + 4 * half) * ldc + col;
+                    float* pc = Cp + off0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dr = (r & 3) + 8 * (r >> 2);
                         if (INSIDE || (m0 + wm * 64 + i * 32 + 4 * half + dr < dM && col < dN)) {
                             const float v = acc[i][j][r];
-                            float* p = pc + (long)dr * ldc;
-                            if constexpr (MODE == 0) *p = v;
-                            else if constexpr (MODE == 1) *p += v;
-                            else atomicAdd(p, v);
+                            if constexpr (MODE >= 4) {          // half-stored result (the mixed-precision mode's activations)
+                                _Float16* p = reinterpret_cast<_Float16*>(Cp) + off0 + (long)dr * ldc;
+                                *p = (_Float16)(MODE == 4 ? v : v + (float)*p);
+                            } else {
+                                float* p = pc + (long)dr * ldc;
+                                if constexpr (MODE == 0) *p = v;
+                                else if constexpr (MODE == 1) *p += v;
+                                else atomicAdd(p, v);
+                            }
                         }
                     }
                 }
             }
         };
         const bool inside = m0 + BM <= dM && n0 + BN <= dN;
-        if (inside) {
+        if (PREC == 1 && c_half) {          // out_mode 0 / 1 only (ud_gemm_p3 rejects atomics onto a half result)
+            if (inside) {
+                if (ep == 0) store_all(integral_constant<int, 4>{}, T{});
+                else store_all(integral_constant<int, 5>{}, T{});
+            } else {
+                if (ep == 0) store_all(integral_constant<int, 4>{}, F{});
+                else store_all(integral_constant<int, 5>{}, F{});
+            }
+        } else if (inside) {
             if (ep == 0) store_all(integral_constant<int, 0>{}, T{});
             else if (ep == 1) store_all(integral_constant<int, 1>{}, T{});
             else store_all(integral_constant<int, 2>{}, T{});
@@ -709,6 +729,21 @@ __global__ __launch_bounds__(256) void split_h2_tensor_kernel(const float* __res
     *reinterpret_cast<u32x4*>(o + plane) = u32x4{b[0], b[1], b[2], b[3]};
 }
 
+// half-stored [R][C] (row stride ld) -> ONE fp16 plane in the P32 layout, values as they are (scale 1): the operand form of
+// ud_gemm_p3 prec 1 for the mixed-precision mode's activations; thread = 8 columns of a row (16 bytes in, 16 bytes out)
+__global__ __launch_bounds__(256) void planes_from_half_kernel(const uint16_t* __restrict__ x, long R, int C, long ld,
+                                                               uint16_t* __restrict__ out, long panel,
+                                                               float* __restrict__ inv_scale) {
+    const int tid = threadIdx.x;
+    const long row = (long)blockIdx.x * 64 + (tid >> 2);
+    const int pan = blockIdx.y, c0 = pan * 32 + (tid & 3) * 8;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *inv_scale = 1.f;
+    if (row >= R) return;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (c0 + 8 <= C) v = *reinterpret_cast<const u32x4*>(x + row * ld + c0);
+    *reinterpret_cast<u32x4*>(out + (long)pan * panel + row * 32 + (tid & 3) * 8) = v;
+}
+
 // ---- a k x k conv as a 1x1 conv on the planes GEMM (round 5): its im2col matrix [N Hout Wout] x [KH KW Cin] written DIRECTLY as
 // fp16 x 2 planes (one scale for the tensor: |x|max of the conv's input, `absmax` slots as for split_h2_tensor_kernel).  The deep
 // 3 x 3 convs of the ResNet variants (model/resnet/exp.py:95-111; the 2048 -> 2048 filter conv of model/modules.py:111 at
@@ -917,6 +952,18 @@ extern "C" int ud_split_planes_h2t(const float* x, long R, int C, long ld, uint1
     return 0;
 }
 
+extern "C" int ud_planes_from_half(const void* x, long R, int C, long ld, uint16_t* planes, long panel_stride, float* inv_scale,
+                                   ud_stream_t stream) {
+    if (!x || !planes || !inv_scale || R < 1 || C < 8 || C % 8 || ld < C || ld % 8 || panel_stride < 32 * R || panel_stride % 8 ||
+        ((uintptr_t)x & 15))
+        return UD_EINVAL;
+    dim3 grid((unsigned)ud_cdiv(R, 64), (unsigned)ud_cdiv(C, 32));
+    hipLaunchKernelGGL(planes_from_half_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, R, C, ld, planes,
+                       panel_stride, inv_scale);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ud_split_planes(const float* x, long R, int C, long ld, uint16_t* planes, long panel_stride,
                                long plane_stride, ud_stream_t stream) {
     if (!x || !planes || R <= 0 || C <= 0 || C % 4 != 0 || ld % 4 != 0 || ld < C || panel_stride < R * 32 ||
@@ -946,14 +993,18 @@ static bool p3_desc_ok(const ud_gemm_p3_desc& d);
 extern "C" int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc* tn, ud_stream_t stream) {
     if (!nn || !tn || !p3_desc_ok(*nn) || !p3_desc_ok(*tn)) return UD_EINVAL;
     const ud_gemm_p3_desc &d0 = *nn, &d1 = *tn;
-    if (d0.prec != 2 || d1.prec != 2 || d0.a_mode != 0 || d0.b_mode != 1 || d1.a_mode != 1 || d1.b_mode != 1) return UD_EINVAL;
+    if ((d0.prec != 2 && d0.prec != 1) || d1.prec != d0.prec || d0.a_mode != 0 || d0.b_mode != 1 || d1.a_mode != 1 || d1.b_mode != 1) return UD_EINVAL;
     if ((d0.tile_cfg | d1.tile_cfg) & 0x800) return UD_EINVAL;          // no stream-K form
     if (d0.stat_sum || d1.stat_sum || d0.out_mode == 3 || d1.out_mode == 3) return UD_EINVAL;
     const int tm0 = ud_cdiv(d0.M, BM), tn0 = ud_cdiv(d0.N, BN), tm1 = ud_cdiv(d1.M, BM), tn1 = ud_cdiv(d1.N, BN);
     const long n0 = (long)tm0 * tn0 * d0.split_k, n1 = (long)tm1 * tn1 * d1.split_k;
     if (n0 + n1 > 0x7fffffffL) return UD_EINVAL;
-    hipLaunchKernelGGL((gemm_p3_pair_kernel<2>), dim3((unsigned)(n0 + n1)), dim3(NT), 0, (hipStream_t)stream, d0, tm0, tn0, (int)n0,
-                       d1, tm1, tn1);
+    if (d0.prec == 1)
+        hipLaunchKernelGGL((gemm_p3_pair_kernel<1>), dim3((unsigned)(n0 + n1)), dim3(NT), 0, (hipStream_t)stream, d0, tm0, tn0,
+                           (int)n0, d1, tm1, tn1);
+    else
+        hipLaunchKernelGGL((gemm_p3_pair_kernel<2>), dim3((unsigned)(n0 + n1)), dim3(NT), 0, (hipStream_t)stream, d0, tm0, tn0,
+                           (int)n0, d1, tm1, tn1);
     UD_LAUNCH_CHECK();
     return 0;
 }
@@ -962,14 +1013,15 @@ static bool p3_desc_ok(const ud_gemm_p3_desc& d) {
     if (!d.A || !d.B || !d.C || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.K % BK != 0 || d.split_k < 1 ||
         d.split_k > d.K / BK || d.out_mode < 0 || d.out_mode > 3 || d.a_mode < 0 || d.a_mode > 1 || d.b_mode < 0 ||
         d.b_mode > 1 || d.a_panel % 8 != 0 || d.b_panel % 8 != 0 || d.a_plane % 8 != 0 || d.b_plane % 8 != 0 ||
-        d.a_npanel < 1 || d.b_npanel < 1 || (d.prec != 2 && d.prec != 3))
+        d.a_npanel < 1 || d.b_npanel < 1 || d.prec < 1 || d.prec > 3)
         return false;
-    if (d.prec == 2 && (!d.a_inv_scale || !d.b_inv_scale || d.a_scale_stride < 0 || d.a_scale_stride > 1 ||
+    if (d.prec <= 2 && (!d.a_inv_scale || !d.b_inv_scale || d.a_scale_stride < 0 || d.a_scale_stride > 1 ||
                         d.b_scale_stride < 0 || d.b_scale_stride > 1))
         return false;
     if (d.stat_sum && (d.out_mode != 0 || d.split_k != 1 || !d.stat_sumsq || (d.tile_cfg & 0x800))) return false;
     if ((d.tile_cfg & 0x800) && (d.out_mode > 1 || d.split_k != 1)) return false;          // stream-K: store-onto-zeros or add
     if (d.out_mode == 3 && d.slice_stride < (long)d.M * d.ldc) return false;
+    if (d.c_half && (d.prec != 1 || d.out_mode > 1 || d.split_k != 1 || (d.tile_cfg & 0x800))) return false;   // no atomics onto half
     return true;
 }
 
@@ -978,6 +1030,12 @@ extern "C" int ud_gemm_p3(const ud_gemm_p3_desc* dp, ud_stream_t stream) {
     const ud_gemm_p3_desc& d = *dp;
     if (!p3_desc_ok(d)) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (d.prec == 1) {          // the first plane of prec-2 operands: one fp16 product (mixed precision)
+        if (d.a_mode == 0 && d.b_mode == 0) return launch<1, 0, 0>(d, s);
+        if (d.a_mode == 0 && d.b_mode == 1) return launch<1, 0, 1>(d, s);
+        if (d.a_mode == 1 && d.b_mode == 1) return launch<1, 1, 1>(d, s);
+        return UD_EINVAL;
+    }
     if (d.prec == 2) {
         if (d.a_mode == 0 && d.b_mode == 0) return launch<2, 0, 0>(d, s);
         if (d.a_mode == 0 && d.b_mode == 1) return launch<2, 0, 1>(d, s);

@@ -222,7 +222,7 @@ class Planes:
             # read as k (mode 1) the matrix is walked in whole 32-row K-tiles: the rows that pad the last one must multiply as zeros
             self.buf.view(prec, self.npanel, self.panel // 32, 32)[:, :, R:-(-R // 32) * 32].zero_()
         self.scale_stride = 1 if per_row else 0
-        self.inv = torch.empty(R if per_row else 1, dtype=torch.float32, device=like.device) if prec == 2 else None
+        self.inv = torch.empty(R if per_row else 1, dtype=torch.float32, device=like.device) if prec <= 2 else None
 
 
 def amax_slots(like, want=True):
@@ -506,9 +506,10 @@ def _p3_desc(A, B, Cout, M, N, K, a_mode, b_mode, out_mode=0, split_k=1, a_row0=
     d.ldc = N
     d.a_mode, d.b_mode, d.out_mode, d.split_k = a_mode, b_mode, out_mode, split_k
     d.tile_cfg = cfg | (0x100 if _XCD_CONTIGUOUS else 0) | (_P3_RASTER if not cfg & 0x800 else 0)
-    assert A.prec == B.prec
-    d.prec = A.prec
-    if A.prec == 2:
+    assert A.prec == B.prec or max(A.prec, B.prec) <= 2
+    d.prec = min(A.prec, B.prec)          # (a prec-1 operand with prec-2 weight planes: the weights' first plane is read)
+    d.c_half = 1 if Cout.dtype == torch.float16 else 0
+    if d.prec <= 2:          # (prec 1: the first plane of prec-2 planes, one product — the mixed-precision mode)
         assert (a_mode == 0 or not A.scale_stride) and (b_mode == 0 or not B.scale_stride)
         d.a_inv_scale = A.inv.data_ptr() + 4 * a_row0 * A.scale_stride
         d.b_inv_scale = B.inv.data_ptr()
@@ -546,7 +547,7 @@ def spectral_bwd(ctx, dy2, out=None, dy_absmax=None):
     acc = out is not None
     # nn: dx[M, Kd] = dy[M, N] . w[N, Kd] (reduction N);  tn: dw[N, Kd] = dy[M, N]^T . x[M, Kd] (reduction M)
     if pn[0] == "plain":
-        dx = out if acc else empty((M, Kd), dy2)
+        dx = out if acc else empty((M, Kd), dy2, torch.float16 if dy2.dtype == torch.float16 else torch.float32)
         d0 = _p3_desc(dy, ctx.w, dx, M, Kd, -(-N // 32) * 32, 0, 1, 1 if acc else 0, 1)
     else:
         dx = out if acc else split_out((M, Kd), dy2)
@@ -918,8 +919,12 @@ def _p2_run(kind, plan, ap, bp, M, N, K, like, stats=None, out=None):
     how = plan[0]
     acc = out is not None
     assert not (acc and stats is not None)
+    # the mixed-precision mode (prec-1 operands of half-stored activations): activations come out half-stored too, weight
+    # gradients fp32; half results take plain launches only
+    odt = torch.float16 if (like.dtype == torch.float16 and kind != "tn") else torch.float32
+    assert odt == torch.float32 or how == "plain"
     if how == "plain":
-        return _gemm_p3(ap, bp, out if acc else empty((M, N), like), M, N, Kp, am, bm, 1 if acc else 0, 1, stats=stats)
+        return _gemm_p3(ap, bp, out if acc else empty((M, N), like, odt), M, N, Kp, am, bm, 1 if acc else 0, 1, stats=stats)
     res = None
     if how == "split":
         res = _gemm_p3(ap, bp, out if acc else split_out((M, N), like), M, N, Kp, am, bm, 2, int(plan[1]))
@@ -957,6 +962,31 @@ def _p2_default_plan(kind, M, N, K):
     return ("plain",)
 
 
+def planes_from_half(x2):
+    """a half-stored [R, C] matrix as the ONE fp16 plane ud_gemm_p3 prec 1 reads (P32 layout, values unchanged)"""
+    R, Cc = x2.shape
+    assert x2.is_cuda and x2.dtype == torch.float16 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
+    pl = Planes(R, Cc, x2, 1, False)
+    _call("ud_planes_from_half", _p(x2), R, Cc, x2.stride(0), _p(pl.buf), pl.panel, _p(pl.inv), _stream())
+    return pl
+
+
+# The mixed-precision mode (ud_gemm path 3, BASELINE configs[4]) on the planes kernel: one fp16 plane per operand, one product per
+# tile — 530-770 TFLOP/s on the spectral convs' shapes against 290-530 of gemm_x3_kernel's fp16 form (tools/bench_p3_prec1.py).
+# The half-stored activation becomes a plane by a layout pass (ud_planes_from_half), the weights' planes come from the step's
+# batch (their first plane), half results are stored by the epilogue: plain launches only (no atomics onto half).
+_P1_PLANES = True          # A/B: tools/run_with.py kernels._P1_PLANES=False
+_P1_MIN = (1024, 128)      # M, min(N, K) from which the layout pass pays (f16 bs 64: (1024, 512) 32.5 ms, (1024, 256) 32.0,
+#                            (1024, 128) 31.9, (4096, 64) 33.2; without the path 35.4 — profiles/r05/f16_p1_planes_ab.txt)
+
+
+def _p1_plans_for(M, N, Kd):
+    if not (_P1_PLANES and CFG.spectral_p2 != "off" and _call("ud_gemm_get_path") == 3 and _p2_shape_ok(M, N, Kd) and
+            Kd % 8 == 0 and N % 8 == 0 and M >= _P1_MIN[0] and min(N, Kd) >= _P1_MIN[1]):
+        return None
+    return {"nt": ("plain",), "nn": ("plain",), "tn": _p2_default_plan("tn", N, Kd, M)}
+
+
 class SpectralCtx:
     """what the backward of one 1x1 conv needs: the planes (or, on the in-kernel-split path, the fp32 operands)"""
     __slots__ = ("plans", "x", "w", "dy", "M", "N", "K")
@@ -967,7 +997,7 @@ def _p2_block_plans(x2, w2, want_stats=False):
     launch is to fill BatchNorm statistics in its epilogue (a plain launch does; other plans are charged a ud_colstats pass)"""
     M, Kd = x2.shape
     if x2.dtype != torch.float32:
-        return None
+        return _p1_plans_for(M, w2.shape[0], Kd) if (x2.dtype == torch.float16 and w2.dtype == torch.float32) else None
     return _p2_plans_for(M, w2.shape[0], Kd, want_stats, w2, x2)
 
 
@@ -1011,7 +1041,10 @@ def spectral_fwd(x2, w2, stats=None, x_absmax=None, force=False):
     if ctx.plans is None:
         ctx.x, ctx.w = x2, w2
         return gemm_nt(x2, w2, stats=stats), ctx
-    ctx.x, ctx.w = split_planes(x2, prec=2, absmax=x_absmax), weight_planes(w2)
+    if x2.dtype == torch.float16:
+        ctx.x, ctx.w = planes_from_half(x2), weight_planes(w2)
+    else:
+        ctx.x, ctx.w = split_planes(x2, prec=2, absmax=x_absmax), weight_planes(w2)
     return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, x2, stats=stats), ctx
 
 
@@ -1023,7 +1056,7 @@ def spectral_takes_planes(M, N, Kd, w2, want_stats=False):
 
 def _spectral_dy(ctx, dy2, absmax=None):
     if ctx.dy is None:
-        ctx.dy = split_planes(dy2, prec=2, absmax=absmax)
+        ctx.dy = planes_from_half(dy2) if dy2.dtype == torch.float16 else split_planes(dy2, prec=2, absmax=absmax)
     return ctx.dy
 
 

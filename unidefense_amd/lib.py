@@ -53,7 +53,7 @@ class GemmP3Desc(C.Structure):
                 ("a_mode", C.c_int), ("b_mode", C.c_int), ("out_mode", C.c_int), ("split_k", C.c_int),
                 ("stat_sum", C.c_void_p), ("stat_sumsq", C.c_void_p), ("tile_cfg", C.c_int), ("slice_stride", C.c_long),
                 ("prec", C.c_int), ("a_inv_scale", C.c_void_p), ("b_inv_scale", C.c_void_p),
-                ("a_scale_stride", C.c_int), ("b_scale_stride", C.c_int)]
+                ("a_scale_stride", C.c_int), ("b_scale_stride", C.c_int), ("c_half", C.c_int)]
 
 
 class BnRef(C.Structure):
@@ -77,6 +77,7 @@ _SIGNATURES = {
     "ud_gemm": [C.POINTER(GemmDesc), _P],
     "ud_gemm_p3": [C.POINTER(GemmP3Desc), _P],
     "ud_gemm_p3_pair": [C.POINTER(GemmP3Desc), C.POINTER(GemmP3Desc), _P],
+    "ud_planes_from_half": [_P, _L, _I, _L, _P, _L, _P, _P],
     "ud_split_planes": [_P, _L, _I, _L, _P, _L, _L, _P],
     "ud_split_planes_h2": [_P, _L, _I, _L, _P, _L, _L, _P, _P],
     "ud_absmax": [_P, _L, _I, _L, _P, _P],
