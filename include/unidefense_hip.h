@@ -507,6 +507,12 @@ int ud_normbwd_apply_planes(const float* x, const float* dy, const float* keep, 
                             const double* s2_local, const double* energy, int G, int R, int C, uint16_t* planes,
                             long panel_stride, long plane_stride, float* inv_scale, float* dgamma, float* dbeta,
                             ud_stream_t stream);
+/* Half storage (the mixed-precision mode): ud_normbwd_apply whose half result is laid straight into the ONE fp16 plane (P32 layout,
+ * scale 1) that ud_gemm_p3 prec 1 reads — the row-major tensor and the ud_planes_from_half pass over it are not needed. */
+int ud_normbwd_apply_plane_half(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                                int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
+                                const double* s2_local, int G, int R, int C, uint16_t* plane, long panel_stride,
+                                float* inv_scale, float* dgamma, float* dbeta, ud_stream_t stream);
 /* SE backward, the two small FC layers (model.py:119-121) in two launches:
  *   a: dpre = dgate[n][c] * sigmoid'(s2);  ds1[n][i] = swish'(s1) sum_c dpre W_e[c][i];
  *      dW_e[c][i] = sum_n dpre swish(s1[n][i]);  db_e[c] = sum_n dpre
@@ -653,6 +659,12 @@ typedef struct {
     int nparts, K, C, gate_mode;
 } ud_wgrad_fold;
 int ud_dwtile_wgrad_finalize_multi(const ud_wgrad_fold* items, int n, ud_stream_t stream);
+/* Half storage (the mixed-precision mode): ud_rfft2_ex of a half-stored x whose half result is laid straight into the ONE fp16
+ * plane (P32 layout over [N S (S/2+1)] x 2C, scale 1) that ud_gemm_p3 prec 1 reads — no row-major spectrum, no layout pass.  The
+ * one-kernel transform sizes (8, 16, 32, 12, 24, 48). */
+int ud_rfft2_ex_plane_half(const void* x, uint16_t* plane, long panel_stride, float* inv_scale, int N, int S, int C, float scale,
+                           float w_interior, const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode,
+                           const double* gate_acc, float* gate_grad, ud_stream_t stream);
 /* Backward of an SF block's spatial branch inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel; S = 8, K in {3, 5},
  * fp32): da_f = scale * C2R(f(kx) Y) as ud_irfft2 (the adjoint of rfft2: w_interior = 1/2), then with dd = dL/d(conv output)
  * [N][S][S][C], x the conv's raw input and bn the BatchNorm in front of it:

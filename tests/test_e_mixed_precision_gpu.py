@@ -196,3 +196,54 @@ def test_fp16_half_storage_step_vs_float64_oracle():
     ok.append(within("fp16 + half storage vs float64 oracle, N = 4: gradient relative L2, 90th percentile", stats["90 %"], 0.2))
     ok.append(within("fp16 + half storage vs float64 oracle, N = 4: gradient relative L2, max", stats["max"], 0.6))
     assert all(ok) and len(r) >= 430
+
+
+def _plane0(pl, R, Cc):
+    """the first plane of a Planes object as a [R, C] half tensor"""
+    return pl.buf[:pl.plane].view(pl.npanel, pl.panel // 32, 32)[:, :R].view(torch.float16).permute(1, 0, 2).reshape(R, pl.npanel * 32)[:, :Cc]
+
+
+def test_half_producers_lay_their_results_into_the_gemm_plane():
+    """Round 5, the mixed-precision mode on the planes kernel (ud_gemm_p3 prec 1): the transform and the BatchNorm backward lay their
+    half results straight into the one fp16 plane the GEMM reads (ud_rfft2_ex_plane_half, ud_normbwd_apply_plane_half) — bit for bit
+    what the row-major kernels write followed by the layout pass ud_planes_from_half, pad columns zero."""
+    from unidefense_amd import kernels as K
+    dev = torch.device("cuda:0")
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(3)
+    # transform: deferred BatchNorm + swish on load, gate on the result
+    N, S, Cc = 3, 16, 48
+    x = torch.randn(N, S, S, Cc, generator=g).to(dev).half()
+    gamma, beta = (1.0 + 0.3 * torch.randn(Cc, generator=g)).to(dev), (0.2 * torch.randn(Cc, generator=g)).to(dev)
+    acc = K.zeros64(2 * Cc, x)
+    K.colstats(x.view(-1, Cc), acc)
+    bn = K.DeferredBN(acc, Cc, N * S * S, gamma, beta, 1e-3, 1)
+    alpha = torch.tensor([0.3], device=dev)
+    ref, act_ref = K.rfft2_ex(x, 1.0 / S, 1.0, bn=bn, want_act=True)
+    pl, act = K.rfft2_ex_plane_half(x, 1.0 / S, 1.0, bn=bn, want_act=True)
+    slots = K.zeros64(64, x)
+    ref_g, _, _ = K.rfft2_ex(x, 1.0 / S, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=slots)
+    pl_g, _, _ = K.rfft2_ex_plane_half(x, 1.0 / S, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=slots)
+    torch.cuda.synchronize()
+    R = N * S * (S // 2 + 1)
+    assert torch.equal(_plane0(pl, R, 2 * Cc), ref.view(R, 2 * Cc)) and torch.equal(act, act_ref) and float(pl.inv) == 1.0
+    assert torch.equal(_plane0(pl_g, R, 2 * Cc), ref_g.view(R, 2 * Cc))
+    assert torch.equal(_plane0(K.planes_from_half(ref.view(R, 2 * Cc)), R, 2 * Cc), ref.view(R, 2 * Cc))
+    # BatchNorm backward, 40 channels: the last 32-wide panel is padded with zero columns
+    G, HW, Co = 4, 64, 40
+    p = torch.randn(G, HW, Co, generator=g).to(dev).half()
+    dy = torch.randn(G, HW, Co, generator=g).to(dev).half()
+    keep = (torch.rand(G, generator=g) < 0.8).float().to(dev)
+    ga, be = (1.0 + 0.3 * torch.randn(Co, generator=g)).to(dev), (0.2 * torch.randn(Co, generator=g)).to(dev)
+    acc2 = K.zeros64(2 * Co, p)
+    K.colstats(p.view(-1, Co), acc2)
+    bn2 = K.DeferredBN(acc2, Co, G * HW, ga, be, 1e-3, 0)
+    s = K.zeros64(2 * Co, p)
+    K.normbwd_sums(p, dy, keep, 1.25, bn2, False, G, HW, s)
+    dref, dg_ref, db_ref = K.normbwd_apply(p, dy, keep, 1.25, bn2, False, G, HW, s)
+    dpl, dg, db = K.normbwd_apply_planes(p, dy, keep, 1.25, bn2, False, G, HW, s)
+    torch.cuda.synchronize()
+    assert dpl.prec == 1 and float(dpl.inv) == 1.0
+    assert torch.equal(_plane0(dpl, G * HW, Co), dref.view(G * HW, Co)) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    full = dpl.buf[:dpl.plane].view(dpl.npanel, dpl.panel // 32, 32)[:, :G * HW].view(torch.float16)
+    assert float(full[-1, :, Co % 32:].abs().max()) == 0.0

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
     using L = Lds<S, CB>;
     static_assert(DW == 0 || (size_t)S * S * CB * sizeof(float) <= L::BYTES, "the activated plane fits the transform's LDS planes");
     __shared__ float po_red[NT / 64];
-    if (EX && po.buf) {
+    // po.pre < 0 (half storage, the mixed-precision mode): the half result itself laid into ONE plane, scale 1 — no bound needed
+    const bool po_raw = po.pre < 0.f;
+    if (EX && po.buf && !po_raw) {
         // max over ALL channels of the per-channel energy bound: this thread's share, folded per wave; the workgroup's fold
         // happens behind the barrier between the two passes
         float gm = 0.f;
@@ -365,11 +367,13 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
             f *= gf;
         }
         if (EX && po.buf) {
-            float gm = po_red[0];
+            float ps = 1.f, pinv = 1.f;
+            if (!po_raw) {
+                float gm = po_red[0];
 #pragma unroll
-            for (int i = 1; i < NT / 64; ++i) gm = fmaxf(gm, po_red[i]);
-            float ps, pinv;
-            ud_h2_scale(__float_as_uint(po.pre * gf * sqrtf(gm) * 1.002f), ps, pinv);      // (the 0.2 %: fp32 rounding of the transform)
+                for (int i = 1; i < NT / 64; ++i) gm = fmaxf(gm, po_red[i]);
+                ud_h2_scale(__float_as_uint(po.pre * gf * sqrtf(gm) * 1.002f), ps, pinv);      // (the 0.2 %: fp32 rounding of the transform)
+            }
             if (blockIdx.x == 0 && blockIdx.y == 0 && q == 0 && c == 0) *po.inv_scale = pinv;
             f *= ps;
             const long row0 = ((long)n * S) * L::WH + q;
@@ -378,10 +382,15 @@ __global__ __launch_bounds__(NT) void rfft2_kernel(const T* __restrict__ x, T* _
             uint16_t* pim_ = po.buf + (long)(cim >> 5) * po.panel + row0 * 32 + (cim & 31);
 #pragma unroll
             for (int ky = 0; ky < S; ++ky) {
+                const long o = (long)ky * L::WH * 32;
+                if (po_raw) {
+                    pre_[o] = __builtin_bit_cast(uint16_t, (_Float16)(re[ky] * f));
+                    pim_[o] = __builtin_bit_cast(uint16_t, (_Float16)(im[ky] * f));
+                    continue;
+                }
                 uint16_t a0, a1, b0, b1;
                 ud_split_h2(re[ky] * f, a0, a1);
                 ud_split_h2(im[ky] * f, b0, b1);
-                const long o = (long)ky * L::WH * 32;
                 pre_[o] = a0;
                 pre_[o + po.plane] = a1;
                 pim_[o] = b0;
@@ -1517,6 +1526,22 @@ int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long 
         return launch_rfft2_t<float, 32, 16, true, 5>(xf, nullptr, N, C, scale, w_interior, ex, st);
     }
     return rfft2_dispatch<float>(xf, (float*)nullptr, N, S, C, scale, w_interior, &ex, st);
+}
+
+int ud_rfft2_ex_plane_half(const void* x, uint16_t* plane, long panel_stride, float* inv_scale, int N, int S, int C, float scale,
+                           float w_interior, const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode,
+                           const double* gate_acc, float* gate_grad, ud_stream_t stream) {
+    if (N < 1 || C < 4 || (2 * C) % 32 || !x || !plane || !inv_scale) return UD_EINVAL;
+    if (S != 8 && S != 16 && S != 32 && S != 12 && S != 24 && S != 48) return UD_EINVAL;          // the one-kernel forms
+    if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
+    if (bn && bn->G != 1) return UD_EINVAL;
+    if (act_out && !bn) return UD_EINVAL;
+    if (gate_grad && (!gate_acc || !gate_alpha)) return UD_EINVAL;
+    const long rows = (long)N * S * (S / 2 + 1);
+    if (panel_stride < rows * 32 || panel_stride % 8) return UD_EINVAL;
+    RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad, nullptr,
+              PlanesOut{plane, panel_stride, 0, inv_scale, -1.f, nullptr}, DwOut{nullptr, nullptr}};
+    return rfft2_dispatch<_Float16>((const _Float16*)x, (_Float16*)nullptr, N, S, C, scale, w_interior, &ex, (hipStream_t)stream);
 }
 
 int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,

@@ -312,7 +312,9 @@ struct PlanesDst {
 };
 
 // MIX: also the SF-mix gradient: acc += dd * diff, diff = freq - spat as written by ud_irfft2_mix
-template <typename T, bool MIX, bool PL = false>
+// PL = 2 (the mixed-precision mode, half storage): the half result itself laid into the P32 plane ud_gemm_p3 prec 1 reads (scale 1) —
+// the row-major tensor had no other reader than the layout pass.
+template <typename T, bool MIX, int PL = 0>
 __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* __restrict__ x,
                                                            const T* __restrict__ dy, const float* __restrict__ keep,
                                                            float inv_keep, ud_bn_ref bn, int dy_is_dz,
@@ -324,7 +326,10 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
                                                            uint32_t* __restrict__ amax, double* __restrict__ energy,
                                                            PlanesDst pd) {
     float ps = 1.f;
-    if constexpr (PL) {
+    if constexpr (PL == 2) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *pd.inv_scale = 1.f;
+    }
+    if constexpr (PL == 1) {
         __shared__ float pl_red[NT / 64];
         float gm = 0.f;
         for (int i = threadIdx.x; i < q.C4 * 4; i += NT) {
@@ -378,7 +383,13 @@ __global__ __launch_bounds__(NT) void normbwd_apply_kernel(RedGeom q, const T* _
             dz_terms(x4[w.idx], d4[w.idx], cb, bn.act, dy_is_dz != 0, sc, dz, xh);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = cb.ga[e] * cb.is[e] * (dz[e] - t1[e] - xh[e] * t2[e]);
-            if constexpr (PL) {
+            if constexpr (PL == 2) {
+                typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+                Quad<T>::st(reinterpret_cast<T*>(po + prow * 32), 0, o);
+                for (int z = 1; z <= npad; ++z) *reinterpret_cast<u16x4*>(po + prow * 32 + 4 * z) = u16x4{0, 0, 0, 0};
+                continue;
+            }
+            if constexpr (PL == 1) {
                 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
                 uint16_t h0[4], h1[4];
 #pragma unroll
@@ -998,10 +1009,26 @@ int ud_normbwd_apply_planes(const float* x, const float* dy, const float* keep, 
     const long rows = (long)G * R;
     if (panel_stride < 32 * rows || plane_stride < (long)ud_cdiv(C, 32) * panel_stride) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
-    hipLaunchKernelGGL((normbwd_apply_kernel<float, false, true>), red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, dy, keep,
+    hipLaunchKernelGGL((normbwd_apply_kernel<float, false, 1>), red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, dy, keep,
                        inv_keep, *bn, dy_is_dz, s1, s2, s1_local, s2_local, (const float*)nullptr, (float*)nullptr,
                        (double*)nullptr, dgamma, dbeta, (uint32_t*)nullptr, (double*)nullptr,
                        PlanesDst{planes, panel_stride, plane_stride, inv_scale, energy});
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_normbwd_apply_plane_half(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,
+                                int dy_is_dz, const double* s1, const double* s2, const double* s1_local,
+                                const double* s2_local, int G, int R, int C, uint16_t* plane, long panel_stride,
+                                float* inv_scale, float* dgamma, float* dbeta, ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !dy || !bn || !s1 || !s2 || !plane || !inv_scale || bn->G != 1) return UD_EINVAL;
+    if ((dgamma || dbeta) && (!s1_local || !s2_local)) return UD_EINVAL;
+    if (panel_stride < 32L * G * R) return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL((normbwd_apply_kernel<_Float16, false, 2>), red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
+                       (const _Float16*)x, (const _Float16*)dy, keep, inv_keep, *bn, dy_is_dz, s1, s2, s1_local, s2_local,
+                       (const _Float16*)nullptr, (_Float16*)nullptr, (double*)nullptr, dgamma, dbeta, (uint32_t*)nullptr,
+                       (double*)nullptr, PlanesDst{plane, panel_stride, 0, inv_scale, nullptr});
     UD_LAUNCH_CHECK();
     return 0;
 }

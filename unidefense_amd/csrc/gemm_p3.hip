@@ -46,7 +46,9 @@ template <int PREC> struct Cfg {
     static constexpr int NPL = PREC;                    // planes per operand
     static constexpr int OP_IMG = NPL * PLANE_IMG;      // one operand, all planes
     static constexpr int STAGE = 2 * OP_IMG;            // A then B
-    static constexpr int NSTAGE = PREC == 3 ? 3 : 4;    // 144 KiB / 128 KiB of LDS (PREC 1: 64 KiB)
+    // 144 KiB / 128 KiB of LDS; PREC 1: 4 stages of 16 KiB = 64 KiB, TWO workgroups per CU — 3 / 6 / 8 stages measured slower
+    // (f16 bs-64 step 32.2 ms against 32.6 / 33.2 / 33.3: the deeper rings leave one workgroup per CU)
+    static constexpr int NSTAGE = PREC == 3 ? 3 : 4;
     static constexpr int PT = 4 * NPL;                  // DMA pieces per tile and loader wave
     static constexpr int NTERM = PREC == 3 ? 6 : PREC == 2 ? 3 : 1;     // piece products per 32x32x16
 };
@@ -85,7 +87,10 @@ __device__ __forceinline__ void wait_tiles_and_barrier(int tiles) {
     if (tiles <= 0) wait_dma_and_barrier<0>();
     else if (tiles == 1) wait_dma_and_barrier<PT>();
     else if (tiles == 2) wait_dma_and_barrier<2 * PT>();
-    else wait_dma_and_barrier<3 * PT>();
+    else if (tiles == 3 || PT > 4) wait_dma_and_barrier<3 * PT>();          // (NSTAGE <= 4: never more than 2)
+    else if (tiles == 4) wait_dma_and_barrier<4 * PT>();
+    else if (tiles == 5) wait_dma_and_barrier<5 * PT>();
+    else wait_dma_and_barrier<6 * PT>();
 }
 __device__ __forceinline__ void wait_lds_and_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

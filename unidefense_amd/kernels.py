@@ -962,6 +962,46 @@ def _p2_default_plan(kind, M, N, K):
     return ("plain",)
 
 
+_HALF_LIKE = {}
+
+
+def _half_like(t):
+    """an (empty) half tensor on t's device: the `like` of launches whose activation results are half-stored"""
+    h = _HALF_LIKE.get(t.device)
+    if h is None:
+        h = _HALF_LIKE[t.device] = torch.empty(0, dtype=torch.float16, device=t.device)
+    return h
+
+
+def spectral_takes_plane_half(M, N, Kd):
+    """does the 1x1 conv [M, Kd] x [N, Kd]^T of the mixed-precision mode run on the planes kernel (prec 1)?"""
+    return _p1_plans_for(M, N, Kd) is not None
+
+
+def rfft2_plane_half_ok(x):
+    """can ud_rfft2_ex_plane_half lay this half-stored transform's result into the spectral GEMM's plane?"""
+    if not (_P1_PLANES and _P1_DIRECT and _RFFT_PLANES and x.dtype == torch.float16 and CFG.spectral_p2 != "off"):
+        return False
+    N, S, _, Cc = x.shape
+    return S in (8, 16, 32, 12, 24, 48) and (2 * Cc) % 32 == 0 and not _fft_two_pass("rfft_ex", S, 1)
+
+
+def rfft2_ex_plane_half(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None, gate_mode=0, update=False,
+                        gate_acc=None):
+    """rfft2_ex of a half-stored x whose half result goes straight into the ONE plane ud_gemm_p3 prec 1 reads (scale 1).
+    Returns (Planes, activated input or None[, gate gradient])."""
+    _act(x)
+    N, S, S2, Cc = x.shape
+    assert S == S2 and x.dtype == torch.float16
+    pl = Planes(N * S * (S // 2 + 1), 2 * Cc, x, 1, False)
+    act = torch.empty_like(x) if (want_act and bn is not None) else None
+    ggrad = empty((), x) if gate_acc is not None else None
+    _call("ud_rfft2_ex_plane_half", _p(x), _p(pl.buf), pl.panel, _p(pl.inv), N, S, Cc, float(scale), float(w_interior),
+          C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode),
+          _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), _stream())
+    return (pl, act, ggrad) if gate_acc is not None else (pl, act)
+
+
 def planes_from_half(x2):
     """a half-stored [R, C] matrix as the ONE fp16 plane ud_gemm_p3 prec 1 reads (P32 layout, values unchanged)"""
     R, Cc = x2.shape
@@ -976,6 +1016,7 @@ def planes_from_half(x2):
 # The half-stored activation becomes a plane by a layout pass (ud_planes_from_half), the weights' planes come from the step's
 # batch (their first plane), half results are stored by the epilogue: plain launches only (no atomics onto half).
 _P1_PLANES = True          # A/B: tools/run_with.py kernels._P1_PLANES=False
+_P1_DIRECT = True          # ... the producers lay half results into the plane themselves (no ud_planes_from_half pass)
 _P1_MIN = (1024, 128)      # M, min(N, K) from which the layout pass pays (f16 bs 64: (1024, 512) 32.5 ms, (1024, 256) 32.0,
 #                            (1024, 128) 31.9, (4096, 64) 33.2; without the path 35.4 — profiles/r05/f16_p1_planes_ab.txt)
 
@@ -1032,10 +1073,15 @@ def spectral_fwd(x2, w2, stats=None, x_absmax=None, force=False):
     ctx.dy = None
     if isinstance(x2, Planes):
         ctx.M, ctx.K = x2.R, x2.C
-        ctx.plans = _p2_plans_for(ctx.M, ctx.N, ctx.K, stats is not None, w2, None, force=force)
+        if x2.prec == 1:          # the mixed-precision mode: a half-stored activation its producer laid into the plane
+            ctx.plans = _p1_plans_for(ctx.M, ctx.N, ctx.K)
+            like = _half_like(w2)
+        else:
+            ctx.plans = _p2_plans_for(ctx.M, ctx.N, ctx.K, stats is not None, w2, None, force=force)
+            like = w2
         assert ctx.plans is not None
         ctx.x, ctx.w = x2, weight_planes(w2)
-        return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, w2, stats=stats), ctx
+        return _p2_run("nt", ctx.plans["nt"], ctx.x, ctx.w, ctx.M, ctx.N, ctx.K, like, stats=stats), ctx
     ctx.M, ctx.K = x2.shape
     ctx.plans = _p2_block_plans(x2, w2, stats is not None)
     if ctx.plans is None:
@@ -2328,19 +2374,30 @@ _NORMBWD_PLANES = True          # A/B: tools/run_with.py kernels._NORMBWD_PLANES
 
 def normbwd_planes_ok(x, ctx):
     """does the BatchNorm backward in front of a 1x1 conv write its result as that conv's GEMM planes itself?  (the conv's
-    backward runs on the planes GEMM — ctx.plans — and the tensor is fp32 with whole channel quads)"""
-    return (_NORMBWD_PLANES and _RFFT_PLANES and ctx.plans is not None and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and
-            CFG.spectral_p2 != "off")
+    backward runs on the planes GEMM — ctx.plans — and the tensor has whole channel quads.)  1: fp32 — prec-2 planes, scaled by the
+    energy bound (a 3C sum accumulator); 2: half storage — the half result laid into the prec-1 plane as it is; 0: no."""
+    if not (_NORMBWD_PLANES and _RFFT_PLANES and ctx.plans is not None and x.shape[-1] % 4 == 0 and CFG.spectral_p2 != "off"):
+        return 0
+    return 1 if x.dtype == torch.float32 else 2 if (_P1_DIRECT and x.dtype == torch.float16 and x.shape[-1] % 8 == 0) else 0
 
 
 def normbwd_apply_planes(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=None):
     """normbwd_apply whose result is prec-2 Planes over [G R] x C (no fp32 tensor, no split pass); sacc: 3C sums over all ranks
     (sum dz | sum dz xhat | energy sum dz^2).  Returns (Planes, dgamma, dbeta)."""
+    Cc = x.shape[-1]
+    loc = sacc if sacc_local is None else sacc_local
+    if x.dtype == torch.float16:          # the mixed-precision mode: one plane, values unchanged
+        _act(x, dy)
+        _chk(keep)
+        pl = Planes(G * R, Cc, x, 1, False)
+        dg = empty((Cc,), x)
+        db = empty((Cc,), x)
+        _call("ud_normbwd_apply_plane_half", _p(x), _p(dy), _p(keep), float(inv_keep), C.byref(bn.ref()), int(dy_is_dz), _pd(sacc),
+              _pd(sacc, Cc), _pd(loc), _pd(loc, Cc), G, R, Cc, _p(pl.buf), pl.panel, _p(pl.inv), _p(dg), _p(db), _stream())
+        return pl, dg, db
     _chk(x, dy, keep)
     assert x.dtype == torch.float32 and dy.dtype == torch.float32
-    Cc = x.shape[-1]
     assert sacc.numel() >= 3 * Cc
-    loc = sacc if sacc_local is None else sacc_local
     pl = Planes(G * R, Cc, x, 2, False)
     dg = empty((Cc,), x)
     db = empty((Cc,), x)

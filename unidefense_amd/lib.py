@@ -164,6 +164,7 @@ _SIGNATURES = {
     "ud_se_scale_bn_planes": [_P, _BN, _P, _P, _L, _L, _P, _P, _I, _I, _I, _P],
     "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P],
     "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "ud_normbwd_apply_plane_half": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P, _P, _P],
     "ud_normbwd_apply_planes": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _L, _P, _P, _P, _P],
     "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "ud_normbwd_apply_mix": [_P, _P, _BN, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
@@ -188,6 +189,7 @@ _SIGNATURES = {
     "ud_dwtile_wgrad": [_P, _BN, _P, _P, _I, _P, _P, _L] + [_I] * 9 + [_I, _I, _P],
     "ud_dwtile_wgrad_finalize": [_P, _I, _I, _I, _P, _I, _P, _P],
     "ud_dwtile_wgrad_finalize_multi": [C.POINTER(WgradFold), _I, _P],
+    "ud_rfft2_ex_plane_half": [_P, _P, _L, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _P],
     "ud_irfft2_dwbwd": [_P, _I, _I, _I, _F, _F, _P, _P, _BN, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "ud_dwtile_bwd": [_P, _P, _BN, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P] + [_I] * 8 + [_P],
     "ud_rfft2_planes_ws_floats": [_L, _I],

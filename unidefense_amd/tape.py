@@ -1040,6 +1040,9 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                                                     dw_k=k)
                 else:
                     xf, a = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
+            elif K.rfft2_plane_half_ok(src) and K.spectral_takes_plane_half(N * S * (S // 2 + 1), 2 * Ce, 2 * Ce):
+                # the mixed-precision mode: the half result laid into the prec-1 plane by the transform (no layout pass)
+                xf, a = K.rfft2_ex_plane_half(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
             else:
                 xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True, want_absmax=True)
         else:
@@ -1123,13 +1126,13 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         # ---- BN2 (+ drop-connect scale) backward
         # the project conv's backward on the planes GEMM: the apply pass writes its operand's planes itself, scaled by the bound
         # the sums pass leaves behind (the energy of the incoming gradient: a third sum)
-        dp_pl = K.normbwd_planes_ok(p4, pctx)
-        sb2 = K.zeros64((3 if dp_pl else 2) * Co, x)
+        dp_pl = K.normbwd_planes_ok(p4, pctx)          # (1: fp32, the energy bound as a third sum; 2: half storage, one plane)
+        sb2 = K.zeros64((3 if dp_pl == 1 else 2) * Co, x)
         K.normbwd_sums(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2)
         loc2 = dp.reduce(sb2, keep_local=True)
         if dp_pl:
             pctx.dy, dg2, db2 = K.normbwd_apply_planes(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2, loc2)
-            dp2, dp_amax = pctx.w.buf, None                        # (a tensor of the right device for the launch wrappers)
+            dp2, dp_amax = (dout if dp_pl == 2 else pctx.w.buf), None          # (device — and, half storage, dtype — for the launch wrappers)
         else:
             dp_, dg2, db2 = K.normbwd_apply(p4, dout, keep, inv_keep, bn2, False, N, HWo, sb2, loc2, want_absmax=True)
             dp2, dp_amax = dp_.view(Mo, Co), getattr(dp_, "_ud_absmax", None)
@@ -1161,6 +1164,8 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 if dyf_pl:
                     # ... and writes the GEMMs' planes itself: scale from the energy of dd the apply pass just summed
                     dyf, _, dalpha = K.rfft2_ex_planes(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc, energy=en)
+                elif sctx.plans is not None and K.rfft2_plane_half_ok(dd):
+                    dyf, _, dalpha = K.rfft2_ex_plane_half(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc)
                 else:
                     dyf, _, dalpha = K.rfft2_ex(dd, s_i, 2.0, gate_alpha=alpha, gate_mode=1, gate_acc=dacc, want_absmax=True)
                 tape.add_param_grad(alpha, dalpha)
@@ -1172,7 +1177,8 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 dyf = K.rfft2(dfr, s_i, 2.0, want_absmax=True)
             if isinstance(dyf, K.Planes):
                 sctx.dy = dyf                                          # the products' dy operand, already in planes
-                dyf2, dyf_amax = sctx.w.buf, None                      # (an fp32 tensor of the right device for the launch wrappers)
+                # (a tensor of the right device — and, half storage, of the results' dtype — for the launch wrappers)
+                dyf2, dyf_amax = (dd if dyf.prec == 1 else sctx.w.buf), None
             else:
                 dyf2, dyf_amax = dyf.view(-1, 2 * Ce), getattr(dyf, "_ud_absmax", None)
             dxf, dWf = K.spectral_bwd(sctx, dyf2, dy_absmax=dyf_amax)
@@ -1191,8 +1197,8 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         de_pl = False
         if sf and irdw:
             # (+ the energy of dz0 where the expand conv's backward takes its operand as planes: K.normbwd_apply_planes below)
-            de_pl = lazy_in is None and K.normbwd_planes_ok(src, ectx)
-            sb0 = K.zeros64((3 if de_pl else 2) * src.shape[-1], x)
+            de_pl = K.normbwd_planes_ok(src, ectx) if lazy_in is None else 0
+            sb0 = K.zeros64((3 if de_pl == 1 else 2) * src.shape[-1], x)
             dz0, dw_f = K.irfft2_dwbwd(dxf, s_f, 0.5, g_sp, src, src_bn, wt, k, g_alpha, g_mode, sb0)
             is_dz = True
             tape.add_param_grad(dwm.weight, dw_f)
@@ -1237,9 +1243,11 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                 lazy_in.backward(dz0, sb0, is_dz)
                 return
             loc0 = dp.reduce(sb0, keep_local=True)
+            if not de_pl and x.dtype == torch.float16 and sp.expand != 1 and K.normbwd_planes_ok(e, ectx) == 2:
+                de_pl = 2          # half storage: the plane needs no bound, whichever kernel produced dz0
             if de_pl:
                 ectx.dy, dg0, db0 = K.normbwd_apply_planes(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0)
-                de2, de_amax = ectx.w.buf, None
+                de2, de_amax = (dz0 if de_pl == 2 else ectx.w.buf), None
             else:
                 de, dg0, db0 = K.normbwd_apply(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0, want_absmax=True)
                 de2, de_amax = de.view(M, Ce), getattr(de, "_ud_absmax", None)
