@@ -665,8 +665,8 @@ int ud_dwtile_wgrad_finalize_multi(const ud_wgrad_fold* items, int n, ud_stream_
 int ud_rfft2_ex_plane_half(const void* x, uint16_t* plane, long panel_stride, float* inv_scale, int N, int S, int C, float scale,
                            float w_interior, const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode,
                            const double* gate_acc, float* gate_grad, ud_stream_t stream);
-/* Backward of an SF block's spatial branch inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel; S = 8, K in {3, 5},
- * fp32): da_f = scale * C2R(f(kx) Y) as ud_irfft2 (the adjoint of rfft2: w_interior = 1/2), then with dd = dL/d(conv output)
+/* Backward of an SF block's spatial branch inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel; S in {8, 16}, K in
+ * {3, 5}; f16: Y, dd, x, dz half-stored): da_f = scale * C2R(f(kx) Y) as ud_irfft2 (the adjoint of rfft2: w_interior = 1/2), then with dd = dL/d(conv output)
  * [N][S][S][C], x the conv's raw input and bn the BatchNorm in front of it:
  *   dz = (gate * conv_flipped(dd) + da_f) * act'(bn(x));  s1 += sum dz, s2 += sum dz * xhat;  s3 (optional) += sum dz^2, rounded
  *   up (the energy bound ud_normbwd_apply_planes takes);
@@ -675,7 +675,7 @@ int ud_rfft2_ex_plane_half(const void* x, uint16_t* plane, long panel_stride, fl
  * Replaces ud_irfft2 + the depthwise weight-gradient kernel + its finalize + the depthwise data-gradient kernel. */
 int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,
                     const ud_bn_ref* bn, const float* wt, int K, const float* gate_alpha, int gate_mode, void* dz, double* s1,
-                    double* s2, double* s3, float* wpart, float* wacc, ud_stream_t stream);
+                    double* s2, double* s3, float* wpart, float* wacc, int f16, ud_stream_t stream);
 
 /* ---- large real 2-D FFT of image planes (csrc/fft_large.hip), S in {128, 256, 320} ------------------------------------
  * torch.fft.rfft2 on [N,3,S,S] images: the frequency reconstruction loss (model/unidefense.py:246-253; ResNet variants

@@ -247,3 +247,37 @@ def test_half_producers_lay_their_results_into_the_gemm_plane():
     assert torch.equal(_plane0(dpl, G * HW, Co), dref.view(G * HW, Co)) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
     full = dpl.buf[:dpl.plane].view(dpl.npanel, dpl.panel // 32, 32)[:, :G * HW].view(torch.float16)
     assert float(full[-1, :, Co % 32:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,S,Cc,k", [(3, 8, 64, 5), (2, 16, 48, 3), (4, 16, 32, 5)])
+def test_adjoint_transform_does_the_depthwise_backward_in_half_storage(N, S, Cc, k):
+    """ud_irfft2_dwbwd with half-stored tensors (round 5, the mixed-precision mode): the adjoint transform + the depthwise data /
+    weight gradient + the BatchNorm sums in one kernel, against the separate half-storage kernels — whose intermediate da_f is rounded
+    to half where the fused kernel keeps it in fp32: agreement to half precision (2e-3 of the scale), sums and weight gradient to
+    1e-3."""
+    from unidefense_amd import kernels as K
+    dev = torch.device("cuda:0")
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N * 10 + Cc + k)
+    x = torch.randn(N, S, S, Cc, generator=g).to(dev).half()
+    dd = torch.randn(N, S, S, Cc, generator=g).to(dev).half()
+    Yf = torch.randn(N, S, S // 2 + 1, 2 * Cc, generator=g).to(dev).half()
+    wt = (0.3 * torch.randn(k * k, Cc, generator=g)).to(dev)
+    gamma, beta = (1.0 + 0.3 * torch.randn(Cc, generator=g)).to(dev), (0.2 * torch.randn(Cc, generator=g)).to(dev)
+    alpha = torch.tensor([0.4], device=dev)
+    acc = K.zeros64(2 * Cc, x)
+    K.colstats(x.view(-1, Cc), acc)
+    bn = K.DeferredBN(acc, Cc, N * S * S, gamma, beta, 1e-3, 1)
+    pad = (k - 1) // 2
+    assert K.irfft2_dwbwd_ok(S, k, 1, (pad,) * 4, x.dtype)
+    da_f = K.irfft2(Yf, 1.0 / S, 0.5)
+    s_ref = K.zeros64(2 * Cc, x)
+    dz_ref, dw_ref = K.dwtile_bwd(dd, x, wt, k, pad, pad, bn=bn, gate_alpha=alpha, gate_mode=2, add=da_f, sacc=s_ref)
+    s_new = K.zeros64(2 * Cc, x)
+    dz, dw = K.irfft2_dwbwd(Yf, 1.0 / S, 0.5, dd, x, bn, wt, k, alpha, 2, s_new)
+    torch.cuda.synchronize()
+    assert dz.dtype == torch.float16 and dw.dtype == torch.float32
+    top = float(dz_ref.float().abs().max())
+    assert float((dz.float() - dz_ref.float()).abs().max()) <= 2e-3 * top
+    assert float((s_new - s_ref).abs().max() / s_ref.abs().max()) < 1e-3
+    assert float((dw - dw_ref).abs().max() / dw_ref.abs().max()) < 1e-3

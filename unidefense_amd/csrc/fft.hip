@@ -582,12 +582,12 @@ struct LdsBwd {
     static constexpr size_t BYTES = L::BYTES > PLANES ? (L::BYTES > FOLD ? L::BYTES : FOLD) : (PLANES > FOLD ? PLANES : FOLD);
 };
 
-template <int S, int CB, int K>
-__global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __restrict__ Y, int C, float scale, float w_int,
-                                                         const float* __restrict__ dd, const float* __restrict__ x,
+template <typename T, int S, int CB, int K>
+__global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const T* __restrict__ Y, int C, float scale, float w_int,
+                                                         const T* __restrict__ dd, const T* __restrict__ x,
                                                          ud_bn_ref bn, const float* __restrict__ wt,
                                                          const float* __restrict__ gate_alpha, int gate_mode,
-                                                         float* __restrict__ dz, double* __restrict__ s1,
+                                                         T* __restrict__ dz, double* __restrict__ s1,
                                                          double* __restrict__ s2, double* __restrict__ s3,
                                                          float* __restrict__ wpart, float* __restrict__ wacc, int xcd_remap) {
     using L = Lds<S, CB>;
@@ -609,18 +609,18 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
     constexpr int NHELP = S - (S / 2 + 1);
     if (q > S / 2) {
         const int kx = q - (S / 2 + 1);
-        const float* src = Y + (((long)n * S) * L::WH + kx) * (2L * C) + chl + C;
+        const T* src = Y + (((long)n * S) * L::WH + kx) * (2L * C) + chl + C;
 #pragma unroll
-        for (int ky = 0; ky < S; ++ky) re[ky] = cok ? src[(long)ky * L::WH * 2 * C] : 0.f;
+        for (int ky = 0; ky < S; ++ky) re[ky] = cok ? (float)src[(long)ky * L::WH * 2 * C] : 0.f;
 #pragma unroll
         for (int ky = 0; ky < S; ++ky) Lim[kx * L::KSTRIDE + ky * CB + c] = re[ky];
     } else {
-        const float* src = Y + (((long)n * S) * L::WH + q) * (2L * C) + chl;
+        const T* src = Y + (((long)n * S) * L::WH + q) * (2L * C) + chl;
 #pragma unroll
-        for (int ky = 0; ky < S; ++ky) re[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C] : 0.f;
+        for (int ky = 0; ky < S; ++ky) re[brev<S>(ky)] = cok ? (float)src[(long)ky * L::WH * 2 * C] : 0.f;
         if (q >= NHELP) {
 #pragma unroll
-            for (int ky = 0; ky < S; ++ky) im[brev<S>(ky)] = cok ? src[(long)ky * L::WH * 2 * C + C] : 0.f;
+            for (int ky = 0; ky < S; ++ky) im[brev<S>(ky)] = cok ? (float)src[(long)ky * L::WH * 2 * C + C] : 0.f;
         }
     }
     // this thread's rows of the conv's output gradient and of the conv's raw input: in flight behind the transform
@@ -629,8 +629,8 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
         const long o = (((long)n * S + q) * S) * C + chl;
 #pragma unroll
         for (int w = 0; w < S; ++w) {
-            ddr[w] = dd[o + (long)w * C];
-            er[w] = x[o + (long)w * C];
+            ddr[w] = (float)dd[o + (long)w * C];
+            er[w] = (float)x[o + (long)w * C];
         }
     }
     __syncthreads();
@@ -711,13 +711,14 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
         }
         const float gs = gate_factor_f(gate_alpha, gate_mode);
         if (cok) {
-            float* o = dz + (((long)n * S + q) * S) * C + ch;
+            T* o = dz + (((long)n * S + q) * S) * C + ch;
 #pragma unroll
             for (int w = 0; w < S; ++w) {
                 const float xh = (er[w] - mu) * is;
                 float d = acc[w] * gs + re[w] * scale;
                 if (bn.act) d *= ud_act_grad_fast(ga * xh + be, bn.act);
-                o[(long)w * C] = d;
+                d = ud_rounded<T>(d);          // the sums are taken of what consumers will read back
+                o[(long)w * C] = (T)d;
                 v1 += (double)d;
                 v2 += (double)d * (double)xh;
                 v3 += d * d;
@@ -776,20 +777,20 @@ __global__ __launch_bounds__(NT, 4) void irfft2_dwbwd_kernel(const float* __rest
     }
 }
 
-template <int S, int CB, int K>
-int launch_irfft2_dwbwd(const float* Y, int N, int C, float scale, float w_int, const float* dd, const float* x,
-                        const ud_bn_ref& bn, const float* wt, const float* gate_alpha, int gate_mode, float* dz, double* s1,
+template <typename T, int S, int CB, int K>
+int launch_irfft2_dwbwd(const T* Y, int N, int C, float scale, float w_int, const T* dd, const T* x,
+                        const ud_bn_ref& bn, const float* wt, const float* gate_alpha, int gate_mode, T* dz, double* s1,
                         double* s2, double* s3, float* wpart, float* wacc, hipStream_t s) {
     using LB = LdsBwd<S, CB, K>;
     static bool attr_set = false;
     if (LB::BYTES > 65536 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&irfft2_dwbwd_kernel<S, CB, K>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&irfft2_dwbwd_kernel<T, S, CB, K>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LB::BYTES);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     dim3 grid((unsigned)ud_cdiv(C, CB), (unsigned)N);
-    hipLaunchKernelGGL((irfft2_dwbwd_kernel<S, CB, K>), grid, dim3(NT), LB::BYTES, s, Y, C, scale, w_int, dd, x, bn, wt,
+    hipLaunchKernelGGL((irfft2_dwbwd_kernel<T, S, CB, K>), grid, dim3(NT), LB::BYTES, s, Y, C, scale, w_int, dd, x, bn, wt,
                        gate_alpha, gate_mode, dz, s1, s2, s3, wpart, wacc, xcd_remap_on(CB * (int)sizeof(float)));
     UD_LAUNCH_CHECK();
     return 0;
@@ -1546,22 +1547,19 @@ int ud_rfft2_ex_plane_half(const void* x, uint16_t* plane, long panel_stride, fl
 
 int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,
                     const ud_bn_ref* bn, const float* wt, int K, const float* gate_alpha, int gate_mode, void* dz, double* s1,
-                    double* s2, double* s3, float* wpart, float* wacc, ud_stream_t stream) {
+                    double* s2, double* s3, float* wpart, float* wacc, int f16, ud_stream_t stream) {
     if (N < 1 || C < 1 || !Y || !dd || !x || !bn || bn->G != 1 || !wt || !dz || !s1 || !s2 || (!wpart && !wacc)) return UD_EINVAL;
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (S == 8 && K == 5)
-        return launch_irfft2_dwbwd<8, 64, 5>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                             gate_alpha, gate_mode, (float*)dz, s1, s2, s3, wpart, wacc, st);
-    if (S == 8 && K == 3)
-        return launch_irfft2_dwbwd<8, 64, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                             gate_alpha, gate_mode, (float*)dz, s1, s2, s3, wpart, wacc, st);
-    if (S == 16 && K == 5)
-        return launch_irfft2_dwbwd<16, 32, 5>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                              gate_alpha, gate_mode, (float*)dz, s1, s2, s3, wpart, wacc, st);
-    if (S == 16 && K == 3)
-        return launch_irfft2_dwbwd<16, 32, 3>((const float*)Y, N, C, scale, w_interior, (const float*)dd, (const float*)x, *bn, wt,
-                                              gate_alpha, gate_mode, (float*)dz, s1, s2, s3, wpart, wacc, st);
+#define UD_IDW(SS, CC, KK)                                                                                                       \
+    UD_STORAGE_DISPATCH(f16, return (launch_irfft2_dwbwd<T, SS, CC, KK>((const T*)Y, N, C, scale, w_interior, (const T*)dd,     \
+                                                                        (const T*)x, *bn, wt, gate_alpha, gate_mode, (T*)dz, s1, \
+                                                                        s2, s3, wpart, wacc, st)))
+    if (S == 8 && K == 5) UD_IDW(8, 64, 5);
+    if (S == 8 && K == 3) UD_IDW(8, 64, 3);
+    if (S == 16 && K == 5) UD_IDW(16, 32, 5);
+    if (S == 16 && K == 3) UD_IDW(16, 32, 3);
+#undef UD_IDW
     return UD_EINVAL;
 }
 

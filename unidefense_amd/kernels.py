@@ -2716,6 +2716,7 @@ def dwtile_bwd(dy, x, wt, K, pad_t, pad_l, bn=None, gate_alpha=None, gate_mode=0
 
 _IRFFT_DWBWD = True          # A/B: tools/run_with.py kernels._IRFFT_DWBWD=False
 _IRFFT_DWBWD_SIZES = (8, 16)
+_IRFFT_DWBWD_HALF = True          # ... also with half-stored tensors (the mixed-precision mode); A/B: =False
 # weight gradient of ud_irfft2_dwbwd by fp32 atomics onto the parameter-layout gradient instead of partial rows + the fold launch:
 # OFF — 1600 device-scope atomics per workgroup make the 8 x 8 kernel 81-92 us instead of 29 (16 x 16, k 5: 63 vs 52); the step
 # with the 18 fold launches is 25.93 ms against 26.28 (profiles/r05/dwbwd_wgrad_atomics_ab.txt; A/B: tools/run_with.py
@@ -2726,14 +2727,15 @@ _IRFFT_DWBWD_ATOMIC = False
 def irfft2_dwbwd_ok(S, k, stride, pad, dtype):
     """the SF block's spatial-branch backward inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel): the 8 x 8 maps"""
     return (_IRFFT_DWBWD and S in _IRFFT_DWBWD_SIZES and k in (3, 5) and stride == 1 and tuple(pad) == ((k - 1) // 2,) * 4
-            and dtype == torch.float32)
+            and (dtype == torch.float32 or (_IRFFT_DWBWD_HALF and dtype == torch.float16)))
 
 
 def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, sacc):
     """da_f = irfft2(Y) (the adjoint of rfft2), dz = (gate * dwconv_bwd_data(dd) + da_f) * act'(bn(x)), sacc += BatchNorm backward
     sums of dz (a 3C accumulator: + its energy), dw[C, k*k] = gate * sum act(bn(x))(window) * dd — ONE kernel over the (n, c)
     planes + the partials' fold.  Returns (dz, dw)."""
-    _chk(Y, dd, x, wt)
+    h = _act(Y, dd, x)
+    _chk(wt)
     N, S, Wh, C2 = Y.shape
     Cc = C2 // 2
     assert dd.shape == (N, S, S, Cc) and x.shape == dd.shape
@@ -2743,12 +2745,12 @@ def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, 
         # the weight gradient by fp32 atomics onto a zeroed [C, k*k] (N adds per address): no partial rows, no fold launch
         dwt = zeros((Cc, k * k), x)
         _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
-              _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), en, None, _p(dwt), _stream())
+              _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), en, None, _p(dwt), h, _stream())
         return dz, dwt
     part, defer = _wgrad_part(x, N * k * k * Cc)
     dwt = empty((Cc, k * k), x)
     _call("ud_irfft2_dwbwd", _p(Y), N, S, Cc, float(scale), float(w_interior), _p(dd), _p(x), C.byref(bn.ref()), _p(wt), int(k),
-          _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), en, _p(part), None, _stream())
+          _p(gate_alpha), int(gate_mode), _p(dz), _pd(sacc), _pd(sacc, Cc), en, _p(part), None, h, _stream())
     if defer:
         _defer_wgrad_fold(part, N, int(k), Cc, gate_alpha, gate_mode, dwt)
     else:
