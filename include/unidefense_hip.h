@@ -661,10 +661,12 @@ typedef struct {
 int ud_dwtile_wgrad_finalize_multi(const ud_wgrad_fold* items, int n, ud_stream_t stream);
 /* Half storage (the mixed-precision mode): ud_rfft2_ex of a half-stored x whose half result is laid straight into the ONE fp16
  * plane (P32 layout over [N S (S/2+1)] x 2C, scale 1) that ud_gemm_p3 prec 1 reads — no row-major spectrum, no layout pass.  The
- * one-kernel transform sizes (8, 16, 32, 12, 24, 48). */
+ * one-kernel transform sizes (8, 16, 32, 12, 24, 48).  dw_wt / dw_out / dw_k as in ud_rfft2_ex_planes (the stride-1 depthwise conv
+ * of the activated plane, half-stored result; S in {8, 16, 32}). */
 int ud_rfft2_ex_plane_half(const void* x, uint16_t* plane, long panel_stride, float* inv_scale, int N, int S, int C, float scale,
                            float w_interior, const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode,
-                           const double* gate_acc, float* gate_grad, ud_stream_t stream);
+                           const double* gate_acc, float* gate_grad, const float* dw_wt, void* dw_out, int dw_k,
+                           ud_stream_t stream);
 /* Backward of an SF block's spatial branch inside the adjoint transform (csrc/fft.hip: irfft2_dwbwd_kernel; S in {8, 16}, K in
  * {3, 5}; f16: Y, dd, x, dz half-stored): da_f = scale * C2R(f(kx) Y) as ud_irfft2 (the adjoint of rfft2: w_interior = 1/2), then with dd = dL/d(conv output)
  * [N][S][S][C], x the conv's raw input and bn the BatchNorm in front of it:

@@ -1531,7 +1531,9 @@ int ud_rfft2_ex_planes(const void* x, uint16_t* planes, long panel_stride, long 
 
 int ud_rfft2_ex_plane_half(const void* x, uint16_t* plane, long panel_stride, float* inv_scale, int N, int S, int C, float scale,
                            float w_interior, const ud_bn_ref* bn, void* act_out, const float* gate_alpha, int gate_mode,
-                           const double* gate_acc, float* gate_grad, ud_stream_t stream) {
+                           const double* gate_acc, float* gate_grad, const float* dw_wt, void* dw_out, int dw_k,
+                           ud_stream_t stream) {
+    if (dw_k != 0 && (!dw_wt || !dw_out || (dw_k != 3 && dw_k != 5) || (S != 8 && S != 16 && S != 32))) return UD_EINVAL;
     if (N < 1 || C < 4 || (2 * C) % 32 || !x || !plane || !inv_scale) return UD_EINVAL;
     if (S != 8 && S != 16 && S != 32 && S != 12 && S != 24 && S != 48) return UD_EINVAL;          // the one-kernel forms
     if (gate_mode < 0 || gate_mode > 2 || (gate_mode != 0 && !gate_alpha)) return UD_EINVAL;
@@ -1541,8 +1543,20 @@ int ud_rfft2_ex_plane_half(const void* x, uint16_t* plane, long panel_stride, fl
     const long rows = (long)N * S * (S / 2 + 1);
     if (panel_stride < rows * 32 || panel_stride % 8) return UD_EINVAL;
     RfftEx ex{bn, act_out, gate_alpha, gate_mode, gate_acc, gate_grad, nullptr,
-              PlanesOut{plane, panel_stride, 0, inv_scale, -1.f, nullptr}, DwOut{nullptr, nullptr}};
-    return rfft2_dispatch<_Float16>((const _Float16*)x, (_Float16*)nullptr, N, S, C, scale, w_interior, &ex, (hipStream_t)stream);
+              PlanesOut{plane, panel_stride, 0, inv_scale, -1.f, nullptr}, DwOut{dw_wt, dw_out}};
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* xh = (const _Float16*)x;
+    if (dw_k == 3) {
+        if (S == 8) return launch_rfft2_t<_Float16, 8, 64, true, 3>(xh, nullptr, N, C, scale, w_interior, ex, st);
+        if (S == 16) return launch_rfft2_t<_Float16, 16, 32, true, 3>(xh, nullptr, N, C, scale, w_interior, ex, st);
+        return launch_rfft2_t<_Float16, 32, 16, true, 3>(xh, nullptr, N, C, scale, w_interior, ex, st);
+    }
+    if (dw_k == 5) {
+        if (S == 8) return launch_rfft2_t<_Float16, 8, 64, true, 5>(xh, nullptr, N, C, scale, w_interior, ex, st);
+        if (S == 16) return launch_rfft2_t<_Float16, 16, 32, true, 5>(xh, nullptr, N, C, scale, w_interior, ex, st);
+        return launch_rfft2_t<_Float16, 32, 16, true, 5>(xh, nullptr, N, C, scale, w_interior, ex, st);
+    }
+    return rfft2_dispatch<_Float16>(xh, (_Float16*)nullptr, N, S, C, scale, w_interior, &ex, st);
 }
 
 int ud_irfft2_dwbwd(const void* Y, int N, int S, int C, float scale, float w_interior, const void* dd, const void* x,

@@ -987,19 +987,22 @@ def rfft2_plane_half_ok(x):
 
 
 def rfft2_ex_plane_half(x, scale, w_interior=1.0, bn=None, want_act=False, gate_alpha=None, gate_mode=0, update=False,
-                        gate_acc=None):
+                        gate_acc=None, dw_wt=None, dw_k=0):
     """rfft2_ex of a half-stored x whose half result goes straight into the ONE plane ud_gemm_p3 prec 1 reads (scale 1).
-    Returns (Planes, activated input or None[, gate gradient])."""
+    dw_wt / dw_k: also the stride-1 depthwise conv of the activated plane (appended to the result).
+    Returns (Planes, activated input or None[, gate gradient][, conv result])."""
     _act(x)
     N, S, S2, Cc = x.shape
     assert S == S2 and x.dtype == torch.float16
     pl = Planes(N * S * (S // 2 + 1), 2 * Cc, x, 1, False)
     act = torch.empty_like(x) if (want_act and bn is not None) else None
     ggrad = empty((), x) if gate_acc is not None else None
+    spat = torch.empty_like(x) if dw_k else None
     _call("ud_rfft2_ex_plane_half", _p(x), _p(pl.buf), pl.panel, _p(pl.inv), N, S, Cc, float(scale), float(w_interior),
           C.byref(bn.ref(update)) if bn is not None else None, _p(act), _p(gate_alpha), int(gate_mode),
-          _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), _stream())
-    return (pl, act, ggrad) if gate_acc is not None else (pl, act)
+          _pd(gate_acc) if gate_acc is not None else None, _p(ggrad), _p(dw_wt), _p(spat), int(dw_k), _stream())
+    out = (pl, act, ggrad) if gate_acc is not None else (pl, act)
+    return out + (spat,) if dw_k else out
 
 
 def planes_from_half(x2):
@@ -1017,6 +1020,7 @@ def planes_from_half(x2):
 # batch (their first plane), half results are stored by the epilogue: plain launches only (no atomics onto half).
 _P1_PLANES = True          # A/B: tools/run_with.py kernels._P1_PLANES=False
 _P1_DIRECT = True          # ... the producers lay half results into the plane themselves (no ud_planes_from_half pass)
+_P1_DW = True              # ... and the transform also computes the stride-1 depthwise conv (as in the fp32 mode)
 _P1_MIN = (1024, 128)      # M, min(N, K) from which the layout pass pays (f16 bs 64: (1024, 512) 32.5 ms, (1024, 256) 32.0,
 #                            (1024, 128) 31.9, (4096, 64) 33.2; without the path 35.4 — profiles/r05/f16_p1_planes_ab.txt)
 

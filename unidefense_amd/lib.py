@@ -189,7 +189,7 @@ _SIGNATURES = {
     "ud_dwtile_wgrad": [_P, _BN, _P, _P, _I, _P, _P, _L] + [_I] * 9 + [_I, _I, _P],
     "ud_dwtile_wgrad_finalize": [_P, _I, _I, _I, _P, _I, _P, _P],
     "ud_dwtile_wgrad_finalize_multi": [C.POINTER(WgradFold), _I, _P],
-    "ud_rfft2_ex_plane_half": [_P, _P, _L, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _P],
+    "ud_rfft2_ex_plane_half": [_P, _P, _L, _P, _I, _I, _I, _F, _F, _BN, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "ud_irfft2_dwbwd": [_P, _I, _I, _I, _F, _F, _P, _P, _BN, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "ud_dwtile_bwd": [_P, _P, _BN, _P, _P, _I, _P, _P, _P, _P, _L, _P, _P, _P] + [_I] * 8 + [_P],
     "ud_rfft2_planes_ws_floats": [_L, _I],

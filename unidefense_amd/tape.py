@@ -1042,7 +1042,11 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
                     xf, a = K.rfft2_ex_planes(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
             elif K.rfft2_plane_half_ok(src) and K.spectral_takes_plane_half(N * S * (S // 2 + 1), 2 * Ce, 2 * Ce):
                 # the mixed-precision mode: the half result laid into the prec-1 plane by the transform (no layout pass)
-                xf, a = K.rfft2_ex_plane_half(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
+                if K._P1_DW and K.rfft2_dw_ok(S, k, stride, sp.pad):
+                    xf, a, spat = K.rfft2_ex_plane_half(src, s_f, 1.0, bn=src_bn, want_act=not (t_wg or t_fused or bwd_in_fft),
+                                                        update=True, dw_wt=wt, dw_k=k)
+                else:
+                    xf, a = K.rfft2_ex_plane_half(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True)
             else:
                 xf, a = K.rfft2_ex(src, s_f, 1.0, bn=src_bn, want_act=want_a, update=True, want_absmax=True)
         else:
