@@ -483,6 +483,9 @@ int ud_colsum_bn_amax(const void* x, const ud_bn_ref* bn, int G, int R, int C, d
 int ud_se_scale_bn_planes(const void* x, const ud_bn_ref* bn, const float* s, uint16_t* planes, long panel_stride,
                           long plane_stride, float* inv_scale, const uint32_t* amax_in, int G, int R, int C,
                           ud_stream_t stream);
+/* half storage (the mixed-precision mode): ud_se_scale_bn whose half result is laid into the ONE fp16 plane of ud_gemm_p3 prec 1 */
+int ud_se_scale_bn_plane_half(const void* x, const ud_bn_ref* bn, const float* s, uint16_t* plane, long panel_stride,
+                              float* inv_scale, int G, int R, int C, ud_stream_t stream);
 /* out = bn(x) * (keep[g] * inv_keep) + skip   (BN2 + drop_connect + residual, model.py:126-134; keep / skip may be
  * NULL; bn->running_* are updated here) */
 int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const void* skip,

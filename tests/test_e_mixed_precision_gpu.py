@@ -247,6 +247,15 @@ def test_half_producers_lay_their_results_into_the_gemm_plane():
     assert torch.equal(_plane0(dpl, G * HW, Co), dref.view(G * HW, Co)) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
     full = dpl.buf[:dpl.plane].view(dpl.npanel, dpl.panel // 32, 32)[:, :G * HW].view(torch.float16)
     assert float(full[-1, :, Co % 32:].abs().max()) == 0.0
+    # the SE gate pass (ud_se_scale_bn_plane_half)
+    sg = torch.randn(G, Co, generator=g).to(dev)
+    bn3 = K.DeferredBN(acc2, Co, G * HW, ga, be, 1e-3, 1)
+    cref = K.se_scale_bn(p, bn3, sg, G, HW)
+    cpl = K.se_scale_bn_plane_half(p, bn3, sg, G, HW)
+    torch.cuda.synchronize()
+    assert torch.equal(_plane0(cpl, G * HW, Co), cref.view(G * HW, Co)) and float(cpl.inv) == 1.0
+    full = cpl.buf[:cpl.plane].view(cpl.npanel, cpl.panel // 32, 32)[:, :G * HW].view(torch.float16)
+    assert float(full[-1, :, Co % 32:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("N,S,Cc,k", [(3, 8, 64, 5), (2, 16, 48, 3), (4, 16, 32, 5)])

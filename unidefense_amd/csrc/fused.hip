@@ -204,6 +204,32 @@ __global__ __launch_bounds__(NT) void se_scale_bn_planes_kernel(RedGeom q, const
     }
 }
 
+// half storage (the mixed-precision mode): the gated tensor laid straight into the ONE fp16 plane ud_gemm_p3 prec 1 reads
+// (scale 1, pad columns of the last panel zero) — bit for bit se_scale_bn_kernel<_Float16>'s values
+__global__ __launch_bounds__(NT) void se_scale_bn_plane_half_kernel(RedGeom q, const _Float16* __restrict__ x, ud_bn_ref bn,
+                                                                    const float* __restrict__ s, uint16_t* __restrict__ plane,
+                                                                    long panel, float* __restrict__ inv_scale) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *inv_scale = 1.f;
+    int ri, c4;
+    if (!thread_coords(q, ri, c4)) return;
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    const In4<_Float16> x4{x};
+    const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, false);
+    f32x4 gate = reinterpret_cast<const f32x4*>(s)[(long)blockIdx.z * q.C4 + c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gate[e] = ud_sigmoid_fast(gate[e]);
+    Rows w = rows_of(q, ri, c4);
+    uint16_t* o = plane + (long)(c4 >> 3) * panel + (c4 & 7) * 4;
+    const int npad = (c4 == q.C4 - 1) ? 7 - (c4 & 7) : 0;
+    long row = (long)blockIdx.z * q.R + w.r;
+#pragma unroll 4
+    for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step, row += q.rpi) {
+        const f32x4 v = bn_apply(x4[w.idx], cb, bn.act) * gate;
+        Quad<_Float16>::st(reinterpret_cast<_Float16*>(o + row * 32), 0, v);
+        for (int z = 1; z <= npad; ++z) *reinterpret_cast<u16x4*>(o + row * 32 + 4 * z) = u16x4{0, 0, 0, 0};
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void residual_bn_kernel(RedGeom q, const T* __restrict__ x, ud_bn_ref bn,
                                                          const float* __restrict__ keep, float inv_keep,
@@ -965,6 +991,17 @@ int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float 
     RedGeom q = geom_ew(G, R, C);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(residual_bn_kernel<T>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
                                                 (const T*)x, *bn, keep, inv_keep, (const T*)skip, (T*)out, absmax));
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_se_scale_bn_plane_half(const void* x, const ud_bn_ref* bn, const float* s, uint16_t* plane, long panel_stride,
+                              float* inv_scale, int G, int R, int C, ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !bn || !s || !plane || !inv_scale || (bn->G != 1 && bn->G != G)) return UD_EINVAL;
+    if (panel_stride < 32L * G * R) return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL(se_scale_bn_plane_half_kernel, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, (const _Float16*)x, *bn, s,
+                       plane, panel_stride, inv_scale);
     UD_LAUNCH_CHECK();
     return 0;
 }

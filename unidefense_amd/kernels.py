@@ -2318,6 +2318,16 @@ def se_scale_bn_planes(x, bn, s, G, R, amax):
     return pl
 
 
+def se_scale_bn_plane_half(x, bn, s, G, R):
+    """half storage: act(bn(x)) * sigmoid(s) laid straight into the prec-1 plane over [G R] x C (the project conv's GEMM operand)"""
+    _act(x)
+    _chk(s)
+    Cc = x.shape[-1]
+    pl = Planes(G * R, Cc, x, 1, False)
+    _call("ud_se_scale_bn_plane_half", _p(x), C.byref(bn.ref()), _p(s), _p(pl.buf), pl.panel, _p(pl.inv), G, R, Cc, _stream())
+    return pl
+
+
 def coldot_bn(dy, x, bn, G, R, out):
     h = _act(dy, x)
     Cc = x.shape[-1]

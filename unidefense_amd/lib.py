@@ -161,6 +161,7 @@ _SIGNATURES = {
     "ud_fc_fwd_d": [_P, _F, _P, _P, _P, _I, _I, _I, _P],
     "ud_se_scale_bn": [_P, _BN, _P, _P, _I, _I, _I, _I, _P, _P],
     "ud_colsum_bn_amax": [_P, _BN, _I, _I, _I, _P, _P, _P, _P],
+    "ud_se_scale_bn_plane_half": [_P, _BN, _P, _P, _L, _P, _I, _I, _I, _P],
     "ud_se_scale_bn_planes": [_P, _BN, _P, _P, _L, _L, _P, _P, _I, _I, _I, _P],
     "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P],
     "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],

@@ -1109,6 +1109,9 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
     if c_pl:
         c = K.se_scale_bn_planes(d, bn1, s2, N, HWo, c_amax)
         (p, done), pctx = K.spectral_fwd(c, Wp, stats=acc2)
+    elif (K._P1_DIRECT and d.dtype == torch.float16 and Ce % 8 == 0 and K.spectral_takes_plane_half(Mo, Co, Ce)):
+        c = K.se_scale_bn_plane_half(d, bn1, s2, N, HWo)          # the mixed-precision mode: no row-major c, no layout pass
+        (p, done), pctx = K.spectral_fwd(c, Wp, stats=acc2)
     else:
         c = K.se_scale_bn(d, bn1, s2, N, HWo, want_absmax=True)
         (p, done), pctx = K.spectral_fwd(c.view(Mo, Ce), Wp, stats=acc2, x_absmax=getattr(c, "_ud_absmax", None))
