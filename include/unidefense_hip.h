@@ -155,7 +155,8 @@ int ud_gemm_p3(const ud_gemm_p3_desc* d, ud_stream_t stream);
 /* TWO products in one launch: the data gradient (nn: a_mode 0, b_mode 1) and the weight gradient (tn: a_mode 1, b_mode 1) of one
  * 1x1 conv — prec 2, out_mode 0 / 1 / 2, split_k >= 1, no stream-K form, no epilogue statistics.  The weight gradient's workgroups
  * follow the data gradient's in the same grid, so they start on the CUs the data gradient's last round of tiles leaves idle
- * (540 + 225 tiles on 256 CUs: 3 rounds instead of 3 + 1).  Results are those of two ud_gemm_p3 calls. */
+ * (540 + 225 tiles on 256 CUs: 3 rounds instead of 3 + 1); tn->tile_cfg bit 16 (0x10000): the weight gradient's workgroups lead
+ * the grid instead (few long tiles: the pair's critical path).  Results are those of two ud_gemm_p3 calls. */
 int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc* tn, ud_stream_t stream);
 /* A half-stored matrix X[R][C] (row stride ld elements, C % 8 == 0, 16-byte aligned) as ONE fp16 plane in the P32 layout, values
  * unchanged (*inv_scale = 1): the operand of ud_gemm_p3 prec 1 for the activations of the mixed-precision mode (BASELINE

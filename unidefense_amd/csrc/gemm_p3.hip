@@ -528,12 +528,15 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_pair_kernel(const ud_gemm_p3_de
                                                               const ud_gemm_p3_desc d1, int tm1, int tn1) {
     using CF = Cfg<PREC>;
     __shared__ __attribute__((aligned(1024))) char L[CF::NSTAGE * CF::STAGE];
+    // n0 > 0: the data gradient's workgroups first; n0 < 0: the weight gradient's first (its |n0| workgroups)
     const int b = (int)blockIdx.x;
-    if (b < n0) {
+    const bool first = b < (n0 < 0 ? -n0 : n0);
+    const int l = first ? b : b - (n0 < 0 ? -n0 : n0);
+    if (first == (n0 > 0)) {
         const int T = tm0 * tn0;
-        p3_body<PREC, 0, 1, false>(d0, tm0, tn0, L, b % T, b / T, T);
+        p3_body<PREC, 0, 1, false>(d0, tm0, tn0, L, l % T, l / T, T);
     } else {
-        const int l = b - n0, T = tm1 * tn1;
+        const int T = tm1 * tn1;
         p3_body<PREC, 1, 1, false>(d1, tm1, tn1, L, l % T, l / T, T);
     }
 }
@@ -1004,12 +1007,15 @@ extern "C" int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc*
     const int tm0 = ud_cdiv(d0.M, BM), tn0 = ud_cdiv(d0.N, BN), tm1 = ud_cdiv(d1.M, BM), tn1 = ud_cdiv(d1.N, BN);
     const long n0 = (long)tm0 * tn0 * d0.split_k, n1 = (long)tm1 * tn1 * d1.split_k;
     if (n0 + n1 > 0x7fffffffL) return UD_EINVAL;
+    // tile_cfg bit 16 of the weight gradient's descriptor: ITS workgroups go first (a long-K weight gradient with few tiles is the
+    // pair's critical path: started first, the data gradient's many short tiles fill in around it)
+    const int nfirst = (d1.tile_cfg & 0x10000) ? -(int)n1 : (int)n0;
     if (d0.prec == 1)
         hipLaunchKernelGGL((gemm_p3_pair_kernel<1>), dim3((unsigned)(n0 + n1)), dim3(NT), 0, (hipStream_t)stream, d0, tm0, tn0,
-                           (int)n0, d1, tm1, tn1);
+                           nfirst, d1, tm1, tn1);
     else
         hipLaunchKernelGGL((gemm_p3_pair_kernel<2>), dim3((unsigned)(n0 + n1)), dim3(NT), 0, (hipStream_t)stream, d0, tm0, tn0,
-                           (int)n0, d1, tm1, tn1);
+                           nfirst, d1, tm1, tn1);
     UD_LAUNCH_CHECK();
     return 0;
 }

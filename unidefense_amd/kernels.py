@@ -521,6 +521,21 @@ _P3_PAIR = True          # A/B: tools/run_with.py kernels._P3_PAIR=False
 _P3_PAIR_SK = True       # ... also the shapes whose data gradient alone runs stream-K (as plain tiles in the pair: 25.67 -> 25.39 ms)
 
 
+_P3_PAIR_ORDER = 2          # 0: the data gradient's workgroups first, 1: the weight gradient's, 2: by rule (A/B below)
+
+
+def _p3_pair_tn_first(M, N, Kd, pn, pt):
+    """which problem's workgroups lead the pair's grid?  A weight gradient with FEW, LONG tiles (reduction over the M pixels per
+    split-K slice well above the data gradient's reduction N, at most one round of workgroups) is the pair's critical path: started
+    first, the data gradient's many short tiles fill in around it.  Bench step: data gradient first 25.49 ms, weight gradient
+    first everywhere 25.51, this rule 25.34 (thresholds x 0.5 ... x 2 within noise; profiles/r05/p3_pair_ab.txt)."""
+    if _P3_PAIR_ORDER != 2:
+        return _P3_PAIR_ORDER == 1
+    sp = int(pt[1]) if pt[0] == "split" else 1
+    t1 = -(-N // 128) * -(-Kd // 128) * sp
+    return M / sp > 2.0 * N and t1 <= 256
+
+
 def _p3_pair_ok(pn, pt):
     """can the data gradient and the weight gradient of a 1x1 conv go out as ONE launch of the planes kernel (ud_gemm_p3_pair)?
     Both plans plain or split-K, or a stream-K data gradient (run as plain tiles: the weight gradient's workgroups even out its
@@ -558,6 +573,8 @@ def spectral_bwd(ctx, dy2, out=None, dy_absmax=None):
     else:
         dw = split_out((N, Kd), dy2)
         d1 = _p3_desc(dy, ctx.x, dw, N, Kd, -(-M // 32) * 32, 1, 1, 2, int(pt[1]))
+    if _p3_pair_tn_first(M, N, Kd, pn, pt):
+        d1.tile_cfg |= 0x10000
     _call("ud_gemm_p3_pair", C.byref(d0), C.byref(d1), _stream())
     return dx, dw
 
