@@ -130,3 +130,29 @@ def test_pixel_major_dft_matrices_against_torch_fft():
         Yc = torch.complex(Yin.reshape(N, S, Wh, 2, C)[:, :, :, 0], Yin.reshape(N, S, Wh, 2, C)[:, :, :, 1]).permute(0, 3, 1, 2)
         refx = (torch.fft.irfft2(Yc * colw, s=(S, S), norm="forward") * scale).permute(0, 2, 3, 1)
         assert float((xo - refx).abs().max()) < 2e-5 * float(refx.abs().max())
+
+
+def test_pair_and_mixed_precision_plan_rules():
+    """host-side rules of the paired planes-GEMM launches (kernels.spectral_bwd) and of the mixed-precision mode's plans: which
+    plans pair, which problem leads the grid, when a half-stored 1x1 conv goes to the planes kernel (only under ud_gemm path 3)."""
+    from unidefense_amd import kernels as K, lib
+    assert K._p3_pair_ok(("plain",), ("plain",)) and K._p3_pair_ok(("split", 3), ("split", 2)) and K._p3_pair_ok(("sk",), ("plain",))
+    assert not K._p3_pair_ok(("tail", 1024, 2), ("plain",)) and not K._p3_pair_ok(("plain",), ("sk",))
+    # a weight gradient with few long tiles leads: the 16 x 16 spectral conv (225 tiles, reduction 4608 > 2 x 1920) and the 32 x 32
+    # one (36 tiles x split 4, 4352 rows per slice); not the 8 x 8 one (676 short tiles) nor a thin project conv
+    assert K._p3_pair_tn_first(4608, 1920, 1920, ("plain",), ("plain",))
+    assert K._p3_pair_tn_first(17408, 672, 672, ("plain",), ("split", 4))
+    assert not K._p3_pair_tn_first(1280, 3264, 3264, ("plain",), ("plain",))
+    assert not K._p3_pair_tn_first(2048, 1632, 272, ("plain",), ("split", 3))
+    prev = lib.call("ud_gemm_get_path")
+    try:
+        lib.call("ud_gemm_set_path", 0)
+        assert K._p1_plans_for(9216, 1920, 1920) is None                      # the fp32 mode never takes the one-plane form
+        lib.call("ud_gemm_set_path", 3)
+        pl = K._p1_plans_for(9216, 1920, 1920)
+        assert pl is not None and pl["nt"] == ("plain",) and pl["nn"] == ("plain",)      # half results: no atomics, plain launches
+        assert pl["tn"][0] in ("plain", "split")
+        assert K._p1_plans_for(512, 1920, 1920) is None and K._p1_plans_for(9216, 64, 1920) is None      # below the thresholds
+        assert K._p1_plans_for(9216, 1920, 1924) is None                      # K % 8: whole 16-byte groups of half values
+    finally:
+        lib.call("ud_gemm_set_path", prev)
