@@ -2793,7 +2793,7 @@ def irfft2_dwbwd(Y, scale, w_interior, dd, x, bn, wt, k, gate_alpha, gate_mode, 
 _CONV_IM2COL = True                  # A/B: tools/run_with.py kernels._CONV_IM2COL=False
 _CONV_IM2COL_MIN_K = 1152            # reduction length KH*KW*Cin from which the im2col form is taken
 _CONV_IM2COL_MAX_BYTES = 768 << 20   # ... and the largest im2col matrix (4 bytes per element as planes)
-_CONV_IM2COL_MIN_FLOP = 5e9          # 2 M K N below which the conv is launch-bound: the gather GEMM is ONE launch (UDR18 bs 8 at 2.4 GFLOP per conv, the UDEB4 decoder at 3.8: slower as im2col; UDR50 bottlenecks at 7.5: faster)
+_CONV_IM2COL_MIN_FLOP = 2e9          # 2 M K N below which the conv stays on the gather GEMM (ONE launch).  With the paired backward launches: UDR18 bs 8 (2.4 GFLOP per conv) 4.81 -> 4.70 ms, bs 32 9.1 -> 8.95, UDR50 and the UDEB4 decoder (3.8) unchanged; at 5e9 before the pairs (UDR18 slower as im2col then)
 
 
 def conv_im2col_ok(g, Co, x):
