@@ -9,7 +9,7 @@ mkdir -p $out
 export PYTHONDONTWRITEBYTECODE=1
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-export UD_GEMM_TUNE_CACHE=${UD_GEMM_TUNE_CACHE:-$PWD/profiles/r04/gemm_plans_retuned.json}     # no tuner launches among the counted ones
+export UD_GEMM_TUNE_CACHE=${UD_GEMM_TUNE_CACHE:-$PWD/unidefense_amd/gemm_plans_gfx950.json}     # the shipped plans: no tuner launches among the counted ones
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -o $c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --eager $BENCH_ARGS > $out/$c.log 2>&1
   echo "$c pass exit $?"
