@@ -25,6 +25,31 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Two streams (tape.side_branch: the reconstruction decoder beside the trunk): every scratch buffer / zero pool below is
+# shared by the launches of ONE stream in order — a reduction's finalize launch has consumed the scratch before the next
+# reduction on that stream starts — so the pools are keyed by (device, branch) and the branch's launches take their own.
+_BR = 0
+
+
+class branch:
+    def __init__(self, b):
+        self.b = b
+
+    def __enter__(self):
+        global _BR
+        self.prev, _BR = _BR, self.b
+        return self
+
+    def __exit__(self, *exc):
+        global _BR
+        _BR = self.prev
+        return False
+
+
+def _key(ref):
+    return (ref.device.index, _BR)
+
+
 def _p(t):
     if t is None:
         return None
@@ -84,7 +109,7 @@ _ZERO64_POOL = {}
 def zeros64(n, like):
     """n zero-initialised doubles (a view; never recycled within a forward / backward)."""
     n = int(n)
-    key = like.device.index
+    key = _key(like)
     st = _ZERO64_POOL.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
     if st is None or st[1] + n > st[0].numel() or st[2] != capturing:
@@ -101,7 +126,7 @@ def zeros(shape, like):
         n *= int(d)
     if not _ZERO_POOL_ON or n >= _ZERO_OWN or n == 0:
         return torch.zeros(shape, dtype=torch.float32, device=like.device)
-    key = like.device.index
+    key = _key(like)
     st = _ZERO_POOL.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
     # a block filled outside a capture must not serve carves inside one (the replay would not re-zero it), nor vice versa
@@ -134,9 +159,9 @@ _SLICE_WS = {}
 
 
 def _slice_ws(ref, n):
-    ws = _SLICE_WS.get(ref.device.index)
+    ws = _SLICE_WS.get(_key(ref))
     if ws is None or ws.numel() < n:
-        ws = _SLICE_WS[ref.device.index] = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=ref.device)
+        ws = _SLICE_WS[_key(ref)] = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=ref.device)
     return ws
 
 
@@ -465,6 +490,23 @@ def end_forward():
     """end of the forward: the batch's planes are not handed out any more (weights may change before the next forward)"""
     _WEIGHT_PLANES.active = False
     _WEIGHT_LAYOUTS.active = False
+
+
+def weight_batch_snapshot():
+    """what the persistent plane / layout buffers of the forward in progress were made from: (batch, {key: parameter version}).
+    The backward closures keep raw pointers into those buffers, and every begin_forward re-fills them IN PLACE."""
+    return [(b, {k: e[2] for k, e in b.entries.items()}) for b in (_WEIGHT_PLANES, _WEIGHT_LAYOUTS)]
+
+
+def weight_batch_check(snapshot):
+    """raise if a later forward re-filled the buffers from OTHER weight values (forward A, optimizer step, forward B, backward A
+    would otherwise compute A's data gradients with B's weights, silently — torch's version counters raise in that sequence)"""
+    for b, versions in snapshot:
+        for k, v in versions.items():
+            e = b.entries.get(k)
+            if e is not None and v >= 0 and e[2] >= 0 and e[2] != v:
+                raise RuntimeError("backward of a forward whose weight planes / layouts have been re-made from updated weights "
+                                   "by a later forward (forward A, optimizer step, forward B, backward A): run A's backward first")
 
 
 def weight_planes(w2):
@@ -1072,6 +1114,9 @@ def _p2_plans_for(M, N, Kd, want_stats, w2, x2, tune=True, force=False):
         return None
     key = ("p2c", M, N, Kd, bool(CFG.deterministic), mode == "on", bool(want_stats))
     plans = _TUNED.get(key, "?")
+    if plans is None and force:
+        plans = "?"          # a producer-made operand (im2col planes) has no other path: a table entry that judged a 1x1 conv of
+        tune = False         # the same M, N, K slower on planes does not apply — take the default plans
     if plans == "?":
         if tune and x2 is not None and CFG.gemm_tune and not torch.cuda.is_current_stream_capturing():
             plans = _p2_tune(key, x2, w2, M, N, Kd, mode == "on", want_stats)
@@ -1325,9 +1370,9 @@ def conv_gather_wgrad(a, x, g):
     if _CONV_SMALL and Kdim >= _CONV_SMALL_MIN_M and _conv_small_wgrad_supported(g.Cin, Ma, g.KH, g.KW):
         # a 20 x 180 (3 x 180, 48 x 27) result reduced over 524 288 rows: streamed through LDS, register-blocked
         need = _call("ud_conv_small_wgrad_ws_floats", g.Cin, Ma)
-        ws = _CONV_SMALL_WS.get(a.device.index)
+        ws = _CONV_SMALL_WS.get(_key(a))
         if ws is None or ws.numel() < need:
-            ws = _CONV_SMALL_WS[a.device.index] = empty((need,), a)
+            ws = _CONV_SMALL_WS[_key(a)] = empty((need,), a)
         out = empty((Ma, Ncols), a)
         _call("ud_conv_small_wgrad", C.byref(g), _p(a), _p(x), _p(ws), _p(out), Ma, _stream())
         return out
@@ -1365,10 +1410,10 @@ def _reduce_ws(ref, G, R, Cc):
     """Scratch for the per-workgroup partial sums (include/unidefense_hip.h): a reduction's finalize launch has
     consumed it before the next reduction on the stream starts, so one buffer per device serves all calls."""
     need = _call("ud_reduce_ws_doubles", G, R, Cc)
-    ws = _REDUCE_WS.get(ref.device)
+    ws = _REDUCE_WS.get(_key(ref))
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, _REDUCE_WS_MIN), dtype=torch.float64, device=ref.device)
-        _REDUCE_WS[ref.device] = ws
+        _REDUCE_WS[_key(ref)] = ws
     return ws
 
 
@@ -2003,9 +2048,9 @@ _FFT_PLANES_SIZES = (128, 256, 320)          # csrc/fft_large.hip
 
 def _fft_planes_ws(ref, P, S):
     need = _call("ud_rfft2_planes_ws_floats", P, S)
-    ws = _FFT_PLANES_WS.get(ref.device)
+    ws = _FFT_PLANES_WS.get(_key(ref))
     if ws is None or ws.numel() < need:
-        ws = _FFT_PLANES_WS[ref.device] = empty((need,), ref)
+        ws = _FFT_PLANES_WS[_key(ref)] = empty((need,), ref)
     return ws
 
 
@@ -2295,10 +2340,10 @@ def _fused_ws(ref, G, R, C_, per_group, min_rows=8):
 def _ws64(ref, need):
     if need <= 0:
         return None
-    ws = _REDUCE_WS.get(ref.device)
+    ws = _REDUCE_WS.get(_key(ref))
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, _REDUCE_WS_MIN), dtype=torch.float64, device=ref.device)
-        _REDUCE_WS[ref.device] = ws
+        _REDUCE_WS[_key(ref)] = ws
     return C.c_void_p(ws.data_ptr())
 
 
@@ -2674,6 +2719,8 @@ _WGRAD_FOLD_DEFER = True          # A/B: tools/run_with.py kernels._WGRAD_FOLD_D
 
 def begin_wgrad_folds():
     global _WGRAD_FOLDS
+    if _WGRAD_FOLDS:
+        flush_wgrad_folds()          # a backward started inside another one's: the outer tape's pending folds are done first, not dropped
     _WGRAD_FOLDS = [] if _WGRAD_FOLD_DEFER else None
 
 
@@ -2697,9 +2744,9 @@ def _wgrad_part(like, need):
     """the partial-row buffer of one depthwise weight gradient: the shared scratch, or (folds being collected) its own"""
     if _WGRAD_FOLDS is not None:
         return torch.empty(need, dtype=torch.float32, device=like.device), True
-    part = _DWTILE_PART.get(like.device.index)
+    part = _DWTILE_PART.get(_key(like))
     if part is None or part.numel() < need:
-        part = _DWTILE_PART[like.device.index] = torch.empty(need, dtype=torch.float32, device=like.device)
+        part = _DWTILE_PART[_key(like)] = torch.empty(need, dtype=torch.float32, device=like.device)
     return part, False
 
 

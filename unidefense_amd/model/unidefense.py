@@ -147,6 +147,7 @@ class _NetFunction(torch.autograd.Function):
             tape.kinks = {}
         try:
             outs = model._run(x, tape, rng, noise_x)
+            tape.weight_snapshot = K.weight_batch_snapshot()
         finally:
             K.end_forward()
         if debug:                                            # tests: capture activation gradients / ReLU patterns
@@ -439,9 +440,15 @@ class UniDefenseModelEb4(nn.Module):
         fresh = None
         if any(given.get(idx) is None for idx, _ in todo):
             # all Bernoulli draws of the step in ONE launch (torch.bernoulli of a probability tensor; rounds 1-4: rand, compare, cast)
-            keep_p = getattr(self, "_dc_keep_p", None)
-            if keep_p is None or keep_p.device != device or keep_p.shape[1] != n:
-                keep_p = self._dc_keep_p = torch.tensor([1.0 - r for _, r in todo], device=device).view(-1, 1).expand(-1, n).contiguous()
+            # one probability tensor per (device, batch size), NEVER replaced: a captured step bakes its address in, and hipGraphs
+            # do not keep their inputs alive — a cache of one entry would hand a replay of the earlier shape freed memory
+            cache = self.__dict__.setdefault("_dc_keep_p", {})
+            keep_p = cache.get((device, n))
+            if keep_p is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("drop-connect probabilities for a new batch size inside a graph capture: run one eager "
+                                       "step with this shape first (the engine and bench.py do)")
+                keep_p = cache[(device, n)] = torch.tensor([1.0 - r for _, r in todo], device=device).view(-1, 1).expand(-1, n).contiguous()
             fresh = torch.bernoulli(keep_p)
         for j, (idx, rate) in enumerate(todo):
             k_ = given.get(idx)
@@ -502,12 +509,21 @@ class UniDefenseModelEb4(nn.Module):
         # only draw that drop_rate = 0 / drop_connect_rate = 0 leave, to compare two executions bit for bit)
         if self.training and getattr(self, "_dec_dropout", True):
             d_in = T.dropout_mask(tape, x_b4, self._keep_mask(rng, "dec_keep", x_b4, 0.8), 0.2)
-        dec1 = self._decoder(tape, d_in, self.dec_block1, False)
-        dec2 = self._decoder(tape, dec1, self.dec_block2, False)
-        dec3_pix = self._decoder(tape, dec2, self.dec_block3, True)
-        dec3 = T.tanh_to_planes(tape, dec3_pix)                          # [N,3,128,128]
+        # The reconstruction branch (decoder -> rec -> spatial / frequency loss terms, unidefense.py:214-216, 244-253) shares only
+        # its input with the trunk's stage 5: with cfg.side_branch it runs — forward and backward — on a second stream beside
+        # stage 5 (both are latency-bound chains of small kernels); the attention, which reads the reconstruction, joins them.
+        with T.side_branch(tape, x_b4, (d_in, x)) as side:
+            dec1 = self._decoder(tape, d_in, self.dec_block1, False)
+            dec2 = self._decoder(tape, dec1, self.dec_block2, False)
+            dec3_pix = self._decoder(tape, dec2, self.dec_block3, True)
+            dec3 = T.tanh_to_planes(tape, dec3_pix)                          # [N,3,128,128]
+            t1 = T.mean_hw(tape, dec1)
+            t2 = T.mean_hw(tape, dec2)
+            rec = T.bilinear(tape, dec3, H, W)
+            spatial, freq = T.rec_losses(tape, rec, x, self.freq_norm)
 
         x_b5 = T.cast(tape, self._blocks(tape, x_b4h, 5, rng), f32)
+        side.join((dec1, dec2, dec3, t1, t2, rec, spatial, freq))
         att, freq_mask, spat_mask = self._attention(tape, dec3, x, x_b5, rng)
         x_b6 = T.cast(tape, self._blocks(tape, T.cast(tape, att, torch.float16) if st16 else att, 6, rng), f32)
 
@@ -522,11 +538,6 @@ class UniDefenseModelEb4(nn.Module):
         cls_out = T.linear(tape, feat, self.classifier.fc.weight, self.classifier.fc.bias)
 
         t0 = T.mean_hw(tape, x_b4)
-        t1 = T.mean_hw(tape, dec1)
-        t2 = T.mean_hw(tape, dec2)
-
-        rec = T.bilinear(tape, dec3, H, W)
-        spatial, freq = T.rec_losses(tape, rec, x, self.freq_norm)
         return {"cls_out": cls_out, "rec": rec, "factorization": feat, "triplet0": t0, "triplet1": t1,
                 "triplet2": t2, "freq_mask": freq_mask, "spat_mask": spat_mask,
                 "spatial": spatial, "freq": freq,

@@ -34,10 +34,20 @@ class Tape:
         self.param_ready = None
         self.param_uses = None
         self.param_seen = {}
+        self._deferred = set()   # id(param) whose stored gradient still waits for the one-launch fold (kernels.flush_wgrad_folds)
+        self.weight_snapshot = None      # kernels.weight_batch_snapshot() of the forward (checked before the replay)
+        # side branch (cfg.side_branch): nodes recorded inside `side_branch(tape, ...)` — the reconstruction decoder and its loss
+        # tail, independent of the trunk's stage 5 / attention / stage 6 / head — replay on a second stream
+        self.side = None         # torch.cuda.Stream of the branch, or None
+        self.side_nodes = set()  # id(fn) of the closures recorded on it
+        self._in_side = False
+        self._side_param_grads = []
 
     # -- recording -------------------------------------------------------------------------
     def record(self, fn):
         self.nodes.append(fn)
+        if self._in_side:
+            self.side_nodes.add(id(fn))
 
     def add_grad(self, t: torch.Tensor, g: torch.Tensor):
         """Accumulate g into the gradient slot of activation t (functional: never mutates g)."""
@@ -57,11 +67,18 @@ class Tape:
 
     def add_param_grad(self, p, g: torch.Tensor):
         cur = self.param_grads.get(p)
-        if getattr(g, "_ud_deferred", False) and (cur is not None or self.param_ready is not None):
+        deferred = getattr(g, "_ud_deferred", False)
+        if (deferred or id(p) in self._deferred) and (cur is not None or self.param_ready is not None):
             K.flush_wgrad_folds()          # read right away (summed with an earlier use / handed to the gradient reducer): fold now
+            self._deferred.clear()         # (the flush folds every pending gradient, the stored ones included)
+            deferred = False
         g = g.reshape(p.shape)
         g = g if cur is None else K.axpby(cur, 1.0, g, 1.0)
         self.param_grads[p] = g
+        if self._in_side:
+            self._side_param_grads.append(g)
+        if deferred:
+            self._deferred.add(id(p))      # stored unfolded: a later contribution to p must flush before it reads `cur`
         n = self.param_seen[id(p)] = self.param_seen.get(id(p), 0) + 1
         if self.param_ready is not None and n == self.param_uses.get(id(p)):
             self.param_ready(id(p), g)
@@ -76,19 +93,118 @@ class Tape:
 
     # -- replay ----------------------------------------------------------------------------
     def backward(self):
+        if self.weight_snapshot is not None:
+            K.weight_batch_check(self.weight_snapshot)
         K.begin_wgrad_folds()          # the depthwise weight gradients' folds: one launch at the end instead of one per conv
         try:
-            for fn in reversed(self.nodes):
-                fn()
+            if self.side is None or not self.side_nodes:
+                for fn in reversed(self.nodes):
+                    fn()
+            else:
+                self._backward_two_streams()
         finally:
             K.flush_wgrad_folds(end=True)
         self.nodes = []
         self.grads = {}
         self._keep = []
+        self.side_nodes = set()
+
+    def _backward_two_streams(self):
+        """The replay with the side branch's closures on its stream.  The recorded order is a valid serial order, so each stream
+        runs its closures in that order; the branch starts (waits for the main stream) at its first closure — everything it
+        reads from outside are the output gradients, set before the replay — and the main stream waits for it before the first
+        closure recorded BEFORE the branch began (the consumer of the branch input's gradient).  Closures of the main stream in
+        between (stage 5 ... head) exchange nothing with the branch: the attention reads the reconstruction detached."""
+        main, side = torch.cuda.current_stream(), self.side
+        side_ids = self.side_nodes
+        first = min(i for i, fn in enumerate(self.nodes) if id(fn) in side_ids)
+        started = joined = False
+        for i in range(len(self.nodes) - 1, -1, -1):
+            fn = self.nodes[i]
+            if id(fn) in side_ids:
+                if not started:
+                    for g in self.grads.values():          # output gradients made on the main stream, read on the branch
+                        g.record_stream(side)
+                    side.wait_stream(main)
+                    started = True
+                with torch.cuda.stream(side), K.branch(1):
+                    self._in_side = True
+                    try:
+                        fn()
+                    finally:
+                        self._in_side = False
+            else:
+                if started and not joined and i < first:
+                    self._join(main, side)
+                    joined = True
+                fn()
+        if started and not joined:
+            self._join(main, side)
+
+    def _join(self, main, side):
+        for g in self.grads.values():                      # the branch input's gradient: made on the branch, read on main
+            g.record_stream(main)
+        for g in self._side_param_grads:
+            g.record_stream(main)
+        self._side_param_grads = []
+        main.wait_stream(side)
 
 
 def _needs(tape):
     return tape is not None
+
+
+_SIDE_STREAMS = {}
+
+
+class side_branch:
+    """`with side_branch(tape, like, inputs): ...` — the enclosed operators run on a second stream, concurrently with whatever
+    the caller launches on the main stream until `.join(outputs)`; their backward closures replay on that stream too
+    (Tape.backward).  Used for the reconstruction decoder (model/unidefense.py:214-216 of the reference), which shares only its
+    input with the trunk's stage 5: the two are latency-bound chains of small kernels on different tensors.  `inputs`: tensors
+    made on the main stream that the branch reads (their memory must not be recycled under it).  Off (plain serial execution)
+    without a tape, with cfg.side_branch = False, or on a tape that already carries a branch."""
+
+    def __init__(self, tape, like, inputs=()):
+        self.tape = tape
+        self.on = bool(tape is not None and cfg.side_branch and like.is_cuda and tape.side is None)
+        self.like, self.inputs = like, inputs
+        self.ctx = None
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        dev = self.like.device.index
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=self.like.device)
+        self.main = torch.cuda.current_stream()
+        for t in self.inputs:
+            t.record_stream(side)
+        side.wait_stream(self.main)
+        self.tape.side = side
+        self.tape._in_side = True
+        self.ctx = (torch.cuda.stream(side), K.branch(1))
+        self.ctx[0].__enter__()
+        self.ctx[1].__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx[1].__exit__(*exc)
+            self.ctx[0].__exit__(*exc)
+            self.tape._in_side = False
+        return False
+
+    def join(self, outputs=()):
+        """the main stream waits for the branch; `outputs`: tensors the branch made that the main stream goes on to read"""
+        if self.ctx is None:
+            return
+        for t in outputs:
+            if t is not None:
+                t.record_stream(self.main)
+        self.main.wait_stream(self.tape.side)
+        self.ctx = None
 
 
 # ---------------------------------------------------------------------------------------------
