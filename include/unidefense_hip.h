@@ -234,6 +234,20 @@ int ud_norm_apply_fwd(const float* x, int G, int R, int C, const float* mean, co
 int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, const float* mean, const float* invstd,
                 const float* gamma, const float* beta, int act, double* ws, float* s1, float* s2, float* dgamma,
                 float* dbeta, float* dx, ud_stream_t stream);
+/* One-launch forms of the two above (csrc/norm.hip, round 6): statistics + apply / sums + apply in ONE kernel — the P workgroups
+ * sharing a (group, column group) publish their fp64 partials with returning agent-scope atomic exchanges, meet at a counter and
+ * fold the partials in a fixed order (deterministic; no fence, no L2 write-back), then apply out of L2.  For the launch-bound
+ * InstanceNorms of the decoder (model/unidefense.py:59-102) and the ResNet variants' BatchNorms (model/resnet/exp.py:79-232).
+ * slots: ud_norm_fused_ws_doubles doubles (contents arbitrary); counters: ud_norm_fused_counters ZERO 32-bit words.
+ * ud_norm_bwd_fused: G > 1 needs s1 / s2 [G][C] (one extra launch sums them into dgamma / dbeta); dx may be NULL. */
+long ud_norm_fused_ws_doubles(int G, int R, int C);
+int ud_norm_fused_counters(int G, int R, int C);
+int ud_norm_fwd_fused(const float* x, int G, int R, int C, const float* gamma, const float* beta, int act, float eps,
+                      double* slots, uint32_t* counters, float* mean, float* invstd, float momentum, float* running_mean,
+                      float* running_var, float* y, ud_stream_t stream);
+int ud_norm_bwd_fused(const float* x, const float* dy, int G, int R, int C, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int act, double* slots, uint32_t* counters, float* s1,
+                      float* s2, float* dgamma, float* dbeta, float* dx, ud_stream_t stream);
 /* the elementwise half of ud_norm_bwd with caller-provided sums (already all-reduced over the ranks) and
  * inv_count = 1 / (rows of all ranks): SyncBatchNorm backward (engine/forgery_engine.py:142) */
 int ud_norm_bwd_apply(const float* x, const float* dy, int G, int R, int C, const float* mean,
@@ -378,6 +392,25 @@ int ud_copy_cols(float* narrow, float* wide, long M, int Cn, int Cw, int off, in
  * ws: n_real * (N + 1) floats of scratch. */
 int ud_aw_triplet(const float* feat, int N, int D, int n_real, float* loss, float* dfeat, float* ws,
                   ud_stream_t stream);
+
+/* ---- the scalar tail of one pass's loss in two launches (engine/abstract_engine.py:241-281 of the reference: `softmax`
+ * criterion on cls_out :250-254, the mask means :256-263, the triplet terms :232-240, the real / fake means of the per-sample
+ * reconstruction and frequency terms :241-249, their weighted sum :264-270 — ~45 torch launches of 4-5 us per pass):
+ *   vals[0] = w_cls CE(cls, tgt) + w_fm mean(fm) + w_sm mean(sm) + w_trip sum_f awtriplet(feat_f) + w_rec mean(spatial[:R])
+ *             + w_freq mean(freq[:R]);  vals[1..8] = CE, sum of triplet terms, real / fake mean of spatial, real / fake mean
+ *   of freq, mean(fm), mean(sm);  d* = d vals[0] / d (that input).  The first R rows are the real samples, the next F the fake
+ * ones (triplet_loss.py:46-53).  NULL fm / sm / spatial / freq: the term is absent.  ws: ud_loss_tail_ws_floats floats. */
+typedef struct {
+    const float* feat[3]; float* dfeat[3]; int D[3]; int nfeat;          /* triplet features [N][D_f] */
+    const float* cls; const long long* tgt; float* dcls; int N, C, R, F;   /* logits [N][C], int64 labels */
+    const float* fm; float* dfm; int nfm; const float* sm; float* dsm; int nsm;
+    const float* spatial; float* dspatial; const float* freq; float* dfreq; /* [N] */
+    float w_cls, w_fm, w_sm, w_trip, w_rec, w_freq;
+    float* vals;                                                            /* 9 floats */
+    float* ws;
+} ud_loss_tail;
+int ud_loss_tail_ws_floats(int N, int n_real, int nfeat);
+int ud_loss_tail_run(const ud_loss_tail* t, ud_stream_t stream);
 
 /* ---- direct 3x3 conv for small channel counts (csrc/conv_small.hip): the image-resolution end of the decoder
  * (model/unidefense.py:59-102: 40 -> 20 -> 3 channels at 64x64 / 128x128), its data gradients / transposed conv, and

@@ -7,10 +7,11 @@ steps in total: tools/gpu_round.sh prints the count); gemm_table: bench.py --gem
 pipe = 2 for the split-bf16 kernel).  Prints the per-step time of gemm_x3_kernel from the profiler, its algorithmic
 fp32 TFLOP/s, the executed bf16 MFMA TFLOP/s (x 6) and the fraction of the 2500 TFLOP/s dense BF16 pipe peak."""
 import csv
+import json
 import sys
 
 
-def main(stats_csv, table_txt, steps):
+def main(stats_csv, table_txt, steps, json_out=None):
     steps = float(steps)
     x3_ns = f32_ns = p3_ns = total_ns = 0.0
     with open(stats_csv) as fh:
@@ -55,7 +56,23 @@ def main(stats_csv, table_txt, steps):
               f"executed MFMA {fam_ex / fam_ms:8.1f} TFLOP/s = {fam_ex / fam_ms / 2500:.3f} of the pipe (roofline.frac); priced at six "
               f"MFMAs per product like rounds 1-3: {6 * fam_gf / fam_ms / 2500:.3f}")
     print(f"non-GEMM kernels      : {(total_ns - x3_ns - f32_ns - p3_ns) / steps / 1e6:8.3f} ms/step")
+    if json_out and p3_ns > 0:
+        # machine-readable, stamped with the hash of the GEMM sources (bench.py prints it as roofline.replayed only for this tree)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        with open(json_out, "w") as fh:
+            json.dump({"gemm_src_sha": bench._gemm_src_sha(), "source": stats_csv, "executed_steps": steps,
+                       "what": "rocprofv3 --kernel-trace --stats of the bench command (graph-replayed + eager steps): kernel time "
+                               "per executed step; GFLOP per step from bench.py --gemm-table",
+                       "family_ms_per_step": fam_ms, "family_gflop_per_step": fam_gf, "family_tflops_fp32_equiv": fam_gf / fam_ms,
+                       "family_frac_of_pipe": fam_ex / fam_ms / 2500,
+                       "planes_kernel_ms_per_step": p3_ms, "planes_kernel_tflops_fp32_equiv": p3_gflop / p3_ms,
+                       "planes_kernel_frac_of_pipe": 3 * p3_gflop / p3_ms / 2500,
+                       "x3_ms_per_step": x3_ms, "x3_tflops_fp32_equiv": alg, "x3_frac_of_pipe": 6 * alg / 2500,
+                       "non_gemm_ms_per_step": (total_ns - x3_ns - f32_ns - p3_ns) / steps / 1e6,
+                       "all_kernels_ms_per_step": total_ns / steps / 1e6}, fh, indent=1)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])

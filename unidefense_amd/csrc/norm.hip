@@ -291,6 +291,241 @@ __global__ __launch_bounds__(NT) void norm_apply_bwd(long total4, int R, int C4,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// One-launch normalisation (round 6): statistics + apply (forward), sums + apply (backward) in ONE kernel.
+//
+// The three-launch forms above cost their launches, not their bytes, on the tensors of the reconstruction decoder
+// (InstanceNorm on 0.3 ... 42 MB: 22-36 us forward, 45-58 us backward) and of the ResNet variants' BatchNorms.  Here the
+// P workgroups that share a (group g, column group) form a CLUSTER: each reduces its row chunk, PUBLISHES its fp64 partials
+// (returning atomic exchanges at agent scope: the returned value is the acknowledgement that the word is visible
+// device-wide — no fence, no L2 write-back; round 1's "last workgroup finalizes" paid 3-6x a launch for its device-scope
+// fences), counts itself in on the cluster's counter and waits for the other P - 1; then every workgroup folds the P partials
+// of its columns IN THE SAME ORDER (bit-identical statistics in all of them, deterministic), and walks its row chunk a second
+// time — out of L2 — to apply.  Progress: workgroups are dispatched in order of their linear index and a cluster's indices
+// are consecutive (p = blockIdx.x), so the lowest-indexed incomplete cluster is always resident as a whole; the wait is
+// bounded by wall-clock time all the same (2 s: results become NaN, never a hung queue).  counters: P-cluster counters,
+// zero before the launch (kernels.zeros: part of a captured step's fills).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void publish64(double* p, double v) {
+    unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p),
+                                                   (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));          // wait for the returned word: the exchange has been performed
+}
+__device__ __forceinline__ double peek64(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// v[0..NQ): this thread's sums over its rows -> the cluster's totals for its channel quad, in EVERY thread of the column.
+// slots: [(g * CG + cg) * P + p][CW][8] doubles.  Returns false after a timed-out wait (a peer never arrived).
+template <int NQ>
+__device__ __forceinline__ bool cluster_allsum(const RedGeom& q, int ri, bool active, double (&v)[8],
+                                               double* __restrict__ slots, unsigned* __restrict__ counters) {
+    __shared__ double tot[UD_COL_NT / 4 * 8];          // [column lane][8] (CW <= 64)
+    __shared__ int ok_flag;
+    const int cl = threadIdx.x % q.CW;
+    const int CG = gridDim.y;
+    const long cluster = (long)blockIdx.z * CG + blockIdx.y;
+    block_fold<NQ>(q, ri, active, v);
+    bool ok = true;
+    if (q.P > 1) {
+        double* mine = slots + ((cluster * q.P + blockIdx.x) * q.CW + cl) * 8;
+        if (active && ri == 0) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) publish64(mine + i, v[i]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* ctr = counters + cluster;
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = wall_clock64();
+            int good = 1;
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)q.P) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > 200000000LL) { good = 0; break; }          // 2 s of the 100 MHz clock
+            }
+            ok_flag = good;
+        }
+        __syncthreads();
+        ok = ok_flag != 0;
+        // fold the P partials of this column: lane ri takes p = ri, ri + rpi, ... (ascending), the lanes fold through LDS in
+        // ascending ri — the same order in every workgroup of the cluster
+        double w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (active) {
+            const double* base = slots + (cluster * q.P * q.CW + cl) * 8;
+            for (int p = ri; p < q.P; p += q.rpi) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) w[i] += peek64(base + (long)p * q.CW * 8 + i);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = w[i];
+        __syncthreads();                                   // (block_fold's LDS is reused)
+        block_fold<NQ>(q, ri, active, v);
+    }
+    __syncthreads();
+    if (active && ri == 0) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) tot[cl * 8 + i] = v[i];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) v[i] = tot[cl * 8 + i];
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(NT) void norm_fwd_fused(RedGeom q, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int act, float eps, double* __restrict__ slots,
+                                                     unsigned* __restrict__ counters, float* __restrict__ mean_o,
+                                                     float* __restrict__ invstd_o, float momentum,
+                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                     float* __restrict__ y) {
+    int ri, c4;
+    const bool active = thread_coords(q, ri, c4);
+    const int g = blockIdx.z, p = blockIdx.x;
+    const int r_begin = p * q.rows_per_chunk;
+    int r_end = r_begin + q.rows_per_chunk;
+    if (r_end > q.R) r_end = q.R;
+    const long gbase = (long)g * q.R * q.C4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    const long step = (long)q.rpi * q.C4;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 mu = {0, 0, 0, 0}, is = mu, ga = mu, be = mu;
+    if (active) {
+        int r = r_begin + ri;
+        long idx = gbase + (long)r * q.C4 + c4;
+        for (; r + 3 * q.rpi < r_end; r += 4 * q.rpi, idx += 4 * step) {
+            f32x4 a0 = x4[idx], a1 = x4[idx + step], a2 = x4[idx + 2 * step], a3 = x4[idx + 3 * step];
+            accumulate<RED_STATS>(a0, a0, mu, is, ga, be, 0, v);
+            accumulate<RED_STATS>(a1, a1, mu, is, ga, be, 0, v);
+            accumulate<RED_STATS>(a2, a2, mu, is, ga, be, 0, v);
+            accumulate<RED_STATS>(a3, a3, mu, is, ga, be, 0, v);
+        }
+        for (; r < r_end; r += q.rpi, idx += step) {
+            f32x4 a = x4[idx];
+            accumulate<RED_STATS>(a, a, mu, is, ga, be, 0, v);
+        }
+    }
+    const bool ok = cluster_allsum<8>(q, ri, active, v, slots, counters);
+    if (!active) return;
+    const double n = (double)q.R;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double m = v[e] / n;
+        double var = v[4 + e] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mu[e] = (float)m;
+        is[e] = ok ? (float)(1.0 / sqrt(var + (double)eps)) : __builtin_nanf("");
+        if (p == 0 && ri == 0) {
+            const int c = c4 * 4 + e;
+            mean_o[(long)g * q.C4 * 4 + c] = mu[e];
+            invstd_o[(long)g * q.C4 * 4 + c] = is[e];
+            if (running_mean && q.G == 1) {
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+                const double unb = (q.R > 1) ? var * n / (n - 1.0) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+    }
+    ga = reinterpret_cast<const f32x4*>(gamma)[c4];
+    be = reinterpret_cast<const f32x4*>(beta)[c4];
+    int r = r_begin + ri;
+    long idx = gbase + (long)r * q.C4 + c4;
+#pragma unroll 4
+    for (; r < r_end; r += q.rpi, idx += step) {
+        const f32x4 a = x4[idx];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = ud_act(ga[k] * ((a[k] - mu[k]) * is[k]) + be[k], act);
+        y4[idx] = o;
+    }
+}
+
+// s1o / s2o: [G][C] sums (G > 1: ud_norm_bwd's group_sum turns them into dgamma / dbeta); G == 1: dgamma / dbeta written here
+__global__ __launch_bounds__(NT) void norm_bwd_fused(RedGeom q, const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int act, double* __restrict__ slots, unsigned* __restrict__ counters,
+                                                     float* __restrict__ s1o, float* __restrict__ s2o,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dx) {
+    int ri, c4;
+    const bool active = thread_coords(q, ri, c4);
+    const int g = blockIdx.z, p = blockIdx.x;
+    const int r_begin = p * q.rows_per_chunk;
+    int r_end = r_begin + q.rows_per_chunk;
+    if (r_end > q.R) r_end = q.R;
+    const long gbase = (long)g * q.R * q.C4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    f32x4* o4 = reinterpret_cast<f32x4*>(dx);
+    const long step = (long)q.rpi * q.C4;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 mu = {0, 0, 0, 0}, is = mu, ga = mu, be = mu;
+    if (active) {
+        mu = reinterpret_cast<const f32x4*>(mean)[(long)g * q.C4 + c4];
+        is = reinterpret_cast<const f32x4*>(invstd)[(long)g * q.C4 + c4];
+        ga = reinterpret_cast<const f32x4*>(gamma)[c4];
+        be = reinterpret_cast<const f32x4*>(beta)[c4];
+        int r = r_begin + ri;
+        long idx = gbase + (long)r * q.C4 + c4;
+        for (; r + 3 * q.rpi < r_end; r += 4 * q.rpi, idx += 4 * step) {
+            f32x4 a0 = x4[idx], a1 = x4[idx + step], a2 = x4[idx + 2 * step], a3 = x4[idx + 3 * step];
+            f32x4 b0 = d4[idx], b1 = d4[idx + step], b2 = d4[idx + 2 * step], b3 = d4[idx + 3 * step];
+            accumulate<RED_NORMBWD>(a0, b0, mu, is, ga, be, act, v);
+            accumulate<RED_NORMBWD>(a1, b1, mu, is, ga, be, act, v);
+            accumulate<RED_NORMBWD>(a2, b2, mu, is, ga, be, act, v);
+            accumulate<RED_NORMBWD>(a3, b3, mu, is, ga, be, act, v);
+        }
+        for (; r < r_end; r += q.rpi, idx += step) accumulate<RED_NORMBWD>(x4[idx], d4[idx], mu, is, ga, be, act, v);
+    }
+    const bool ok = cluster_allsum<8>(q, ri, active, v, slots, counters);
+    if (!active) return;
+    f32x4 t1, t2;
+    const float invR = 1.f / (float)q.R;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // (the three-launch form rounds the sums to fp32 in its finalize: the same values here)
+        const float s1 = ok ? (float)v[e] : __builtin_nanf(""), s2 = (float)v[4 + e];
+        t1[e] = s1 * invR;
+        t2[e] = s2 * invR;
+        if (p == 0 && ri == 0) {
+            const long o = (long)g * q.C4 * 4 + c4 * 4 + e;
+            if (s1o) s1o[o] = s1;
+            if (s2o) s2o[o] = s2;
+            if (q.G == 1) {
+                if (dbeta) dbeta[o] = s1;
+                if (dgamma) dgamma[o] = s2;
+            }
+        }
+    }
+    if (!dx) return;
+    int r = r_begin + ri;
+    long idx = gbase + (long)r * q.C4 + c4;
+#pragma unroll 4
+    for (; r < r_end; r += q.rpi, idx += step) {
+        const f32x4 a = x4[idx], d = d4[idx];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (a[k] - mu[k]) * is[k];
+            float dz = d[k];
+            if (act) dz *= ud_act_grad(ga[k] * xh + be[k], act);
+            o[k] = ga[k] * is[k] * (dz - t1[k] - xh * t2[k]);
+        }
+        o4[idx] = o;
+    }
+}
+
+// geometry of the one-launch forms: at most 64 workgroups per cluster (the fold reads P partials per column), ~768 workgroups
+// in all (they must be resident together: 3 per CU)
+inline RedGeom fused_norm_geom(int G, int R, int C) { return make_geom_ex(G, R, C, 768, 64, 4); }
+
 int ew_blocks(long total4) {
     long b = (total4 + NT - 1) / NT;
     if (b > 4096) b = 4096;
@@ -368,6 +603,50 @@ int ud_norm_bwd(const float* x, const float* dy, int G, int R, int C, const floa
         long total4 = (long)G * R * (C / 4);
         hipLaunchKernelGGL(norm_apply_bwd, dim3(ew_blocks(total4)), dim3(NT), 0, s, total4, R, C / 4, x, dy, mean,
                            invstd, gamma, beta, s1, s2, 1.f / (float)R, act, dx);
+        UD_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// One-launch forms (see norm_fwd_fused).  slots: ud_norm_fused_ws_doubles(G, R, C) doubles of scratch (contents arbitrary);
+// counters: ud_norm_fused_counters(G, R, C) ZERO 32-bit words.  Results equal ud_norm_stats + ud_norm_apply_fwd (ud_norm_bwd)
+// up to the summation order of the fp64 partials.
+long ud_norm_fused_ws_doubles(int G, int R, int C) {
+    if (C % 4 || G < 1 || R < 1 || C < 4) return UD_EINVAL;
+    RedGeom q = fused_norm_geom(G, R, C);
+    const dim3 gr = red_grid(q);
+    return (long)gr.z * gr.y * q.P * q.CW * 8;
+}
+int ud_norm_fused_counters(int G, int R, int C) {
+    if (C % 4 || G < 1 || R < 1 || C < 4) return UD_EINVAL;
+    RedGeom q = fused_norm_geom(G, R, C);
+    const dim3 gr = red_grid(q);
+    return (int)(gr.z * gr.y);
+}
+int ud_norm_fwd_fused(const float* x, int G, int R, int C, const float* gamma, const float* beta, int act, float eps,
+                      double* slots, uint32_t* counters, float* mean, float* invstd, float momentum, float* running_mean,
+                      float* running_var, float* y, ud_stream_t stream) {
+    if (C % 4 || G < 1 || R < 1 || C < 4 || !x || !gamma || !beta || !slots || !counters || !mean || !invstd || !y)
+        return UD_EINVAL;
+    RedGeom q = fused_norm_geom(G, R, C);
+    hipLaunchKernelGGL(norm_fwd_fused, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, gamma, beta, act, eps, slots,
+                       counters, mean, invstd, momentum, running_mean, running_var, y);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+int ud_norm_bwd_fused(const float* x, const float* dy, int G, int R, int C, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int act, double* slots, uint32_t* counters, float* s1,
+                      float* s2, float* dgamma, float* dbeta, float* dx, ud_stream_t stream) {
+    if (C % 4 || G < 1 || R < 1 || C < 4 || !x || !dy || !mean || !invstd || !gamma || !beta || !slots || !counters ||
+        (G > 1 && (!s1 || !s2)))
+        return UD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    RedGeom q = fused_norm_geom(G, R, C);
+    hipLaunchKernelGGL(norm_bwd_fused, red_grid(q), dim3(NT), 0, s, q, x, dy, mean, invstd, gamma, beta, act, slots, counters,
+                       s1, s2, dgamma, dbeta, dx);
+    UD_LAUNCH_CHECK();
+    if (G > 1 && (dgamma || dbeta)) {
+        hipLaunchKernelGGL(group_sum, dim3(ud_cdiv(C, 256)), dim3(256), 0, s, G, C, s1, s2, dgamma, dbeta);
         UD_LAUNCH_CHECK();
     }
     return 0;

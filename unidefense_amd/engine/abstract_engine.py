@@ -117,12 +117,22 @@ class AbstractEngine(object):
         gts = {"freq_mask": loss_dict["freq_mask"].clone().detach() if has_fm else None,
                "spat_mask": loss_dict["spat_mask"].clone().detach() if has_sm else None,
                "fac": loss_dict["factorization"].clone().detach()}
-        freq_mask_loss = torch.mean(loss_dict["freq_mask"]) if has_fm else _zero(self.device)
-        spat_mask_loss = torch.mean(loss_dict["spat_mask"]) if has_sm else _zero(self.device)
-        t = self._common_terms(out_dict, in_tgt, sum_real, sum_fake)
-        total_loss = t["cls"] + self._lam("lambda_mask") * freq_mask_loss + self._lam("lambda_mask") * spat_mask_loss \
-            + self._lam("lambda_triplet") * t["triplet"] + self._lam("lambda_recons") * t["real_rec"] \
-            + self._lam("lambda_freq") * t["real_freq"]
+        # the scalar tail (criteria, means, weighted sum) as two HIP launches where the criteria are the standard ones
+        # (loss/pass_tail.py); the torch formulation below stays the definition and the fallback
+        f = self._fused_tail(out_dict, in_tgt, sum_real, sum_fake,
+                             dict(cls=1.0, mask=self._lam("lambda_mask"), triplet=self._lam("lambda_triplet"),
+                                  rec=self._lam("lambda_recons"), freq=self._lam("lambda_freq")))
+        if f is not None:
+            t = {"cls": f["cls"], "triplet": f["triplet"], "real_rec": f["real_rec"], "fake_rec": f["fake_rec"],
+                 "real_freq": f["real_freq"], "fake_freq": f["fake_freq"]}
+            total_loss = f["total"]
+        else:
+            freq_mask_loss = torch.mean(loss_dict["freq_mask"]) if has_fm else _zero(self.device)
+            spat_mask_loss = torch.mean(loss_dict["spat_mask"]) if has_sm else _zero(self.device)
+            t = self._common_terms(out_dict, in_tgt, sum_real, sum_fake)
+            total_loss = t["cls"] + self._lam("lambda_mask") * freq_mask_loss + self._lam("lambda_mask") * spat_mask_loss \
+                + self._lam("lambda_triplet") * t["triplet"] + self._lam("lambda_recons") * t["real_rec"] \
+                + self._lam("lambda_freq") * t["real_freq"]
         ret_dict = {
             "total_loss": total_loss, "cls_out": out_dict["cls_out"], "cls_loss": t["cls"],
             "triplet_loss": t["triplet"], "real_rec_loss": t["real_rec"], "fake_rec_loss": t["fake_rec"],
@@ -130,10 +140,35 @@ class AbstractEngine(object):
         }
         return ret_dict, gts, total_loss
 
+    def _kld(self, pred, gt):
+        """mask alignment: KL between the log-softmaxed flattened masks of the two passes (abstract_engine.py:296-300)"""
+        pred = torch.log_softmax(pred.reshape(pred.shape[0], -1), dim=-1)
+        gt = torch.log_softmax(gt.reshape(gt.shape[0], -1), dim=-1)
+        return self.loss_criterion["kl_div"](pred, gt)
+
+    def _fused_tail(self, out_dict, in_tgt, sum_real, sum_fake, weights, masks=True):
+        if not getattr(self, "fused_loss_tail", True):
+            return None
+        from ..loss.pass_tail import pass_tail
+        return pass_tail(out_dict, in_tgt, sum_real, sum_fake, self.loss_criterion, weights, masks=masks)
+
     def _pass2(self, out_dict, in_tgt, sum_real, sum_fake, gts, kl):
         """Loss assembly of the perturbed pass (engine/abstract_engine.py:294-371); kl = cur_step > 0.1 num_steps."""
         loss_dict = out_dict.get("loss_dict", dict())
         has_fm, has_sm = gts["freq_mask"] is not None, gts["spat_mask"] is not None
+        f = self._fused_tail(out_dict, in_tgt, sum_real, sum_fake,
+                             dict(cls=0.1, mask=self._lam("lambda_mask"), triplet=self._lam("lambda_triplet"),
+                                  rec=0.1 * self._lam("lambda_recons"), freq=0.1 * self._lam("lambda_freq")), masks=not kl)
+        if f is not None:
+            fac_loss = self.loss_criterion["fac"](loss_dict["factorization"], gts["fac"])
+            total_loss = f["total"] + self._lam("lambda_fac") * fac_loss
+            if kl:
+                freq_mask_loss = self._kld(loss_dict["freq_mask"], gts["freq_mask"]) if has_fm else torch.zeros_like(fac_loss)
+                spat_mask_loss = self._kld(loss_dict["spat_mask"], gts["spat_mask"]) if has_sm else torch.zeros_like(fac_loss)
+                total_loss = total_loss + self._lam("lambda_mask") * freq_mask_loss + self._lam("lambda_mask") * spat_mask_loss
+            else:
+                freq_mask_loss, spat_mask_loss = f["freq_mask"], f["spat_mask"]
+            return {"freq_mask_loss": freq_mask_loss, "spat_mask_loss": spat_mask_loss, "fac_loss": fac_loss}, total_loss
         t = self._common_terms(out_dict, in_tgt, sum_real, sum_fake)
         zero_like = torch.zeros_like(t["cls"])
         if kl:

@@ -1491,6 +1491,50 @@ def norm_bwd(x2, dy, G, R, mean, invstd, gamma, beta, act):
     return dx, dg, db
 
 
+# One-launch normalisation (csrc/norm.hip: norm_fwd_fused / norm_bwd_fused): statistics + apply in ONE kernel whose workgroups
+# exchange their partial sums through agent-scope atomics.  Taken where the three-launch form is launch-bound: C % 4 == 0 and
+# at most _NORM_FUSED_MAX_BYTES of input (beyond that the passes are bandwidth-bound and want ~2000 workgroups, where the
+# one-launch form runs <= 768 resident ones).  A/B: tools/run_with.py kernels._NORM_FUSED=False
+_NORM_FUSED = True
+_NORM_FUSED_MAX_BYTES = 64 << 20
+
+
+def norm_fused_ok(x2, G, R):
+    Cc = x2.shape[-1]
+    return (_NORM_FUSED and x2.is_cuda and x2.dtype == torch.float32 and Cc % 4 == 0 and Cc >= 4
+            and x2.numel() * 4 <= _NORM_FUSED_MAX_BYTES and G * R == x2.shape[0])
+
+
+def _norm_fused_ws(x2, G, R):
+    Cc = x2.shape[-1]
+    slots = _ws64_t(x2, _call("ud_norm_fused_ws_doubles", G, R, Cc))
+    counters = zeros((_call("ud_norm_fused_counters", G, R, Cc),), x2)          # (zero words: 32-bit counters)
+    return slots, counters
+
+
+def norm_fwd_fused(x2, G, R, gamma, beta, act, eps, momentum=0.0, running_mean=None, running_var=None):
+    """(y, mean[G,C], invstd[G,C]) = ud_norm_stats + ud_norm_apply_fwd in one launch; running statistics moved when given (G = 1)"""
+    _chk(x2, gamma, beta)
+    Cc = x2.shape[-1]
+    mean, invstd, y = empty((G, Cc), x2), empty((G, Cc), x2), torch.empty_like(x2)
+    slots, counters = _norm_fused_ws(x2, G, R)
+    _call("ud_norm_fwd_fused", _p(x2), G, R, Cc, _p(gamma), _p(beta), int(act), eps, _p(slots), _p(counters), _p(mean), _p(invstd),
+          momentum, _p(running_mean), _p(running_var), _p(y), _stream())
+    return y, mean, invstd
+
+
+def norm_bwd_fused(x2, dy, G, R, mean, invstd, gamma, beta, act):
+    """(dx, dgamma[C], dbeta[C]) = ud_norm_bwd in one launch (G > 1: + the group sum of dgamma / dbeta)"""
+    _chk(x2, dy)
+    Cc = x2.shape[-1]
+    s = empty((2, G, Cc), x2)
+    dg, db, dx = empty((Cc,), x2), empty((Cc,), x2), torch.empty_like(x2)
+    slots, counters = _norm_fused_ws(x2, G, R)
+    _call("ud_norm_bwd_fused", _p(x2), _p(dy), G, R, Cc, _p(mean), _p(invstd), _p(gamma), _p(beta), int(act), _p(slots),
+          _p(counters), _p(s[0]), _p(s[1]), _p(dg), _p(db), _p(dx), _stream())
+    return dx, dg, db
+
+
 def group_colsum(x2, G, R, scale):
     _chk(x2)
     Cc = x2.shape[-1]
@@ -2226,6 +2270,48 @@ def aw_triplet(feat, n_real):
     return loss, dfeat
 
 
+def loss_tail(cls_out, tgt, n_real, n_fake, feats, fm, sm, spatial, freq, weights):
+    """The scalar tail of a pass's loss in two launches (ud_loss_tail_run): returns (vals[9], grads) with vals[0] the weighted
+    total (see include/unidefense_hip.h) and grads a dict of d total / d input views into ONE flat buffer `grads["_flat"]` (so
+    that the incoming loss gradient multiplies them all with one launch).  weights: (w_cls, w_fm, w_sm, w_trip, w_rec, w_freq)."""
+    from .lib import LossTail
+    _chk(cls_out, fm, sm, spatial, freq, *feats)
+    N, Cc = cls_out.shape
+    parts = [("cls", cls_out)] + [(f"feat{i}", f) for i, f in enumerate(feats)] + [("fm", fm), ("sm", sm), ("spatial", spatial),
+                                                                                    ("freq", freq)]
+    sizes = [(k, t) for k, t in parts if t is not None]
+    total = sum((t.numel() + 3) // 4 * 4 for _, t in sizes)
+    flat = empty((total,), cls_out)
+    grads, off = {"_flat": flat}, 0
+    for k, t in sizes:
+        grads[k] = flat[off:off + t.numel()].view(t.shape)
+        off += (t.numel() + 3) // 4 * 4
+    vals = empty((9,), cls_out)
+    t = LossTail()
+    t.nfeat = len(feats)
+    for i, f in enumerate(feats):
+        assert f.shape[0] == N
+        t.feat[i], t.dfeat[i], t.D[i] = f.data_ptr(), grads[f"feat{i}"].data_ptr(), f.shape[1]
+    t.cls, t.tgt, t.dcls = cls_out.data_ptr(), tgt.data_ptr(), grads["cls"].data_ptr()
+    t.N, t.C, t.R, t.F = N, Cc, int(n_real), int(n_fake)
+    if fm is not None:
+        t.fm, t.dfm, t.nfm = fm.data_ptr(), grads["fm"].data_ptr(), fm.numel()
+    if sm is not None:
+        t.sm, t.dsm, t.nsm = sm.data_ptr(), grads["sm"].data_ptr(), sm.numel()
+    if spatial is not None:
+        t.spatial, t.dspatial = spatial.data_ptr(), grads["spatial"].data_ptr()
+    if freq is not None:
+        t.freq, t.dfreq = freq.data_ptr(), grads["freq"].data_ptr()
+    t.w_cls, t.w_fm, t.w_sm, t.w_trip, t.w_rec, t.w_freq = [float(w) for w in weights]
+    t.vals = vals.data_ptr()
+    ws = None
+    if feats:
+        ws = empty((_call("ud_loss_tail_ws_floats", N, int(n_real), len(feats)),), cls_out)
+        t.ws = ws.data_ptr()
+    _call("ud_loss_tail_run", C.byref(t), _stream())
+    return vals, grads
+
+
 # ---------------------------------------------------------------------------------------------
 # pass-2 input perturbations on NCHW planes (perturb.hip; model/unidefense.py:177-198 of the reference)
 # ---------------------------------------------------------------------------------------------
@@ -2335,6 +2421,15 @@ def _fused_ws(ref, G, R, C_, per_group, min_rows=8):
     """Scratch pointer for the two-launch form of a fused reduction (None when it runs as one launch of atomics)."""
     need = _call("ud_fused_reduce_ws_doubles", G, R, C_, int(per_group), min_rows)
     return _ws64(ref, need)
+
+
+def _ws64_t(ref, need):
+    """the (device, branch) fp64 scratch as a tensor of at least `need` doubles"""
+    ws = _REDUCE_WS.get(_key(ref))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, _REDUCE_WS_MIN), dtype=torch.float64, device=ref.device)
+        _REDUCE_WS[_key(ref)] = ws
+    return ws
 
 
 def _ws64(ref, need):

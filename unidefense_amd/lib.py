@@ -63,6 +63,17 @@ class BnRef(C.Structure):
                 ("act", C.c_int), ("G", C.c_int), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
 
 
+class LossTail(C.Structure):
+    """ud_loss_tail of include/unidefense_hip.h (the scalar tail of a pass's loss, ud_loss_tail_run)"""
+    _fields_ = [("feat", C.c_void_p * 3), ("dfeat", C.c_void_p * 3), ("D", C.c_int * 3), ("nfeat", C.c_int),
+                ("cls", C.c_void_p), ("tgt", C.c_void_p), ("dcls", C.c_void_p), ("N", C.c_int), ("C", C.c_int), ("R", C.c_int),
+                ("F", C.c_int),
+                ("fm", C.c_void_p), ("dfm", C.c_void_p), ("nfm", C.c_int), ("sm", C.c_void_p), ("dsm", C.c_void_p), ("nsm", C.c_int),
+                ("spatial", C.c_void_p), ("dspatial", C.c_void_p), ("freq", C.c_void_p), ("dfreq", C.c_void_p),
+                ("w_cls", C.c_float), ("w_fm", C.c_float), ("w_sm", C.c_float), ("w_trip", C.c_float), ("w_rec", C.c_float),
+                ("w_freq", C.c_float), ("vals", C.c_void_p), ("ws", C.c_void_p)]
+
+
 class WgradFold(C.Structure):
     """ud_wgrad_fold: one depthwise weight-gradient fold of ud_dwtile_wgrad_finalize_multi"""
     _fields_ = [("part", C.c_void_p), ("dwt", C.c_void_p), ("gate_alpha", C.c_void_p), ("nparts", C.c_int), ("K", C.c_int),
@@ -96,6 +107,10 @@ _SIGNATURES = {
     "ud_syncbn_combine": [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P],
     "ud_norm_apply_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "ud_norm_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "ud_norm_fused_ws_doubles": [_I, _I, _I],
+    "ud_norm_fused_counters": [_I, _I, _I],
+    "ud_norm_fwd_fused": [_P, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _F, _P, _P, _P, _P],
+    "ud_norm_bwd_fused": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "ud_norm_bwd_apply": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P],
     "ud_group_colsum": [_P, _I, _I, _I, _F, _P, _P, _P],
     "ud_group_coldot": [_P, _P, _I, _I, _I, _F, _P, _P, _P],
@@ -141,6 +156,8 @@ _SIGNATURES = {
     "ud_relu_bwd": [_P, _P, _P, _L, _P],
     "ud_copy_cols": [_P, _P, _L, _I, _I, _I, _I, _P],
     "ud_aw_triplet": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "ud_loss_tail_ws_floats": [_I, _I, _I],
+    "ud_loss_tail_run": [C.POINTER(LossTail), _P],
     "ud_conv_small_supported": [_I, _I, _I, _I],
     "ud_conv_small": [C.POINTER(ConvGeom), _P, _P, _P, _I, _P],
     "ud_conv_small_wgrad_supported": [_I, _I, _I, _I],
@@ -210,10 +227,10 @@ _SIGNATURES = {
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_dwtile_wgrad", "ud_dwtile_bwd", "ud_fft32_set_wave", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_loss_tail_ws_floats", "ud_norm_fused_ws_doubles", "ud_norm_fused_counters", "ud_dwtile_wgrad", "ud_dwtile_bwd", "ud_fft32_set_wave", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
                 "ud_conv_small_wgrad_ws_floats", "ud_xchg_bytes"}
-_LONG_FUNCS = {"ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
+_LONG_FUNCS = {"ud_norm_fused_ws_doubles", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",
                "ud_dwconv_bwd_data_bn_ws_doubles"}        # return a C long
 
 EXPORTED = tuple(_SIGNATURES)

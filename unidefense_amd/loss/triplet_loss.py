@@ -1,11 +1,11 @@
 """Asymmetrical weighted triplet loss on [N, d] feature vectors.
 
-Reference semantics: loss/triplet_loss.py:16-82.  The tensors are tiny (N = batch, d <= 1792); SURVEY.md
-K17 keeps these as device-side torch ops (latency-, not bandwidth-bound), so there is no HIP kernel behind
-this module — it is host logic around a handful of [N,N] ops.  Written with multiplicative masks instead
-of the reference's boolean gather + reshape, so it needs no host synchronisation (graph-capture safe) when
-``n_real`` is supplied; the value is identical whenever every anchor has at least one positive and one
-negative (the reference additionally requires equal counts per anchor for its reshape).
+Reference semantics: loss/triplet_loss.py:16-82.  On the GPU, with the batch layout known (`n_real` set by the engine),
+the value AND the feature gradient come from two HIP launches (`_FusedAWTriplet` -> csrc/loss.hip, `ud_aw_triplet`) instead of
+~90 tiny torch kernels per feature.  Everything else (CPU tensors, unknown layout, normalised features handled before the call)
+takes the torch formulation below, written with multiplicative masks instead of the reference's boolean gather + reshape so
+that it needs no host synchronisation (graph-capture safe) when ``n_real`` is supplied; the value is identical whenever every
+anchor has at least one positive and one negative (the reference additionally requires equal counts per anchor for its reshape).
 """
 import torch
 import torch.nn as nn

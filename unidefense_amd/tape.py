@@ -583,7 +583,7 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
     affine = weight is not None
     if not affine:
         weight, bias = _const_affine(Cc, x)
-    synced = False
+    synced = one = False
     if training and sync_group is not None:
         import torch.distributed as dist
         synced = dist.get_world_size(sync_group) > 1 or cfg.force_collectives
@@ -599,12 +599,18 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
         mean, invstd = K.syncbn_combine(gathered, world, Cc, R, eps, momentum, running_mean, running_var)
     elif training:
         world = 1
-        mean, invstd = K.norm_stats(x2, 1, R, eps, momentum, running_mean, running_var)
+        one = K.norm_fused_ok(x2, 1, R)          # statistics + apply in one launch (csrc/norm.hip, norm_fwd_fused)
+        if one:
+            y, mean, invstd = K.norm_fwd_fused(x2, 1, R, weight, bias, act, eps, momentum, running_mean, running_var)
+        else:
+            mean, invstd = K.norm_stats(x2, 1, R, eps, momentum, running_mean, running_var)
     else:
         world = 1
         mean = running_mean.view(1, Cc)
         invstd = torch.rsqrt(running_var + eps).view(1, Cc)
-    y = K.norm_apply(x2, 1, R, mean, invstd, weight, bias, act).view(x.shape)
+    if not one:
+        y = K.norm_apply(x2, 1, R, mean, invstd, weight, bias, act)
+    y = y.view(x.shape)
     if act == 2 and tape is not None and tape.kinks is not None:
         tape.kinks[id(weight)] = y
     if _needs(tape):
@@ -625,7 +631,7 @@ def batchnorm_act(tape, x, weight, bias, running_mean, running_var, eps, momentu
                 dx = K.norm_bwd_apply(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, s,
                                       1.0 / float(R * world), act)
             else:
-                dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
+                dx, dg, db = (K.norm_bwd_fused if one else K.norm_bwd)(x2, dy.view(-1, Cc), 1, R, mean, invstd, weight, bias, act)
             tape.add_grad(x, dx.view(x.shape))
             if affine:
                 tape.add_param_grad(weight, dg)
@@ -677,8 +683,13 @@ def instancenorm_act(tape, x, weight, bias, eps, act):
     affine = weight is not None
     if not affine:
         weight, bias = _const_affine(Cc, x)
-    mean, invstd = K.norm_stats(x2, N, H * W, eps)
-    y = K.norm_apply(x2, N, H * W, mean, invstd, weight, bias, act).view(x.shape)
+    one = K.norm_fused_ok(x2, N, H * W)          # statistics + apply in one launch (csrc/norm.hip, norm_fwd_fused)
+    if one:
+        y, mean, invstd = K.norm_fwd_fused(x2, N, H * W, weight, bias, act, eps)
+        y = y.view(x.shape)
+    else:
+        mean, invstd = K.norm_stats(x2, N, H * W, eps)
+        y = K.norm_apply(x2, N, H * W, mean, invstd, weight, bias, act).view(x.shape)
     if act == 2 and tape is not None and tape.kinks is not None:
         tape.kinks[id(weight)] = y
     if _needs(tape):
@@ -686,7 +697,7 @@ def instancenorm_act(tape, x, weight, bias, eps, act):
             dy = tape.pop_grad(y)
             if dy is None:
                 return
-            dx, dg, db = K.norm_bwd(x2, dy.view(-1, Cc), N, H * W, mean, invstd, weight, bias, act)
+            dx, dg, db = (K.norm_bwd_fused if one else K.norm_bwd)(x2, dy.view(-1, Cc), N, H * W, mean, invstd, weight, bias, act)
             tape.add_grad(x, dx.view(x.shape))
             if affine:
                 tape.add_param_grad(weight, dg)
