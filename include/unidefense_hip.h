@@ -524,6 +524,12 @@ int ud_se_scale_bn_plane_half(const void* x, const ud_bn_ref* bn, const float* s
  * NULL; bn->running_* are updated here) */
 int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const void* skip,
     void* out, int G, int R, int C, int f16, uint32_t* absmax, ud_stream_t stream);
+/* ud_residual_bn (fp32 storage) that ALSO writes its result as the fp16 x 2 planes of the next block's expand conv (ud_gemm_p3 prec 2,
+ * P32 layout over [G R] x C) — no split pass over the block output.  Scale from an a-priori bound: |bn(x)_c| <= |gamma_c| sqrt(count)
+ * + |beta_c| (times inv_keep under drop-connect) + max |skip| (skip_absmax: the 256 absmax slots its producer left; required with skip). */
+int ud_residual_bn_planes(const float* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const float* skip,
+                          const uint32_t* skip_absmax, float* out, uint16_t* planes, long panel_stride, long plane_stride,
+                          float* inv_scale, int G, int R, int C, uint32_t* absmax, ud_stream_t stream);
 /* BatchNorm backward, reductions: dz = dy * (keep[g] * inv_keep) * act'(z)  (dy_is_dz: dz = dy);
  * s1[c] += sum dz, s2[c] += sum dz * xhat;  s3 (optional) [c] += sum dz^2, rounded up (ud_normbwd_apply_planes' energy) */
 int ud_normbwd_sums(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn, int

@@ -86,7 +86,7 @@ def test_gemm_nt_nn_tn(M, N, K):
     check("tn", Kk.gemm_tn(at.to(dev), bt.to(dev)), at.double().t() @ bt.double())
 
 
-@pytest.mark.parametrize("ci,co", [(20, 20), (20, 3), (3, 20), (3, 48)])
+@pytest.mark.parametrize("ci,co", [(20, 20), (20, 3), (3, 20), (3, 48), (32, 3), (3, 32)])
 @pytest.mark.parametrize("geom", ["same", "stem_s2", "transposed_s2", "dgrad_of_convT"])
 def test_conv_small_direct_kernel_equals_implicit_gemm(ci, co, geom):
     """csrc/conv_small.hip (one thread per output pixel, scalar-loaded weights) against F.conv2d / F.conv_transpose2d
@@ -133,7 +133,7 @@ def test_conv_small_direct_kernel_equals_implicit_gemm(ci, co, geom):
     check(f"conv_small {geom} {ci}->{co} vs implicit GEMM", direct, gemm, 1e-5)
 
 
-@pytest.mark.parametrize("ci,ma", [(20, 20), (20, 3), (3, 48), (3, 20)])
+@pytest.mark.parametrize("ci,ma", [(20, 20), (20, 3), (3, 48), (3, 20), (32, 3)])
 @pytest.mark.parametrize("geom", ["same", "stem_s2", "stride2_pad1"])
 def test_conv_small_wgrad_equals_implicit_gemm(ci, ma, geom):
     """csrc/conv_small.hip weight gradient (LDS-staged rows, 4x4 register blocks, partials + sum) against the
@@ -853,3 +853,46 @@ def test_conv_as_im2col_planes_gemm(N, H, Ci, Co, k, stride, pad):
         check(f"{tag}: y", to_nchw(outs[0]), yr)
         check(f"{tag}: dx", to_nchw(gin[0]), xr.grad)
         check(f"{tag}: dw", gp[0], wr.grad)
+
+
+@pytest.mark.parametrize("G,R,C,act", [(32, 16384, 20, 1), (32, 4096, 40, 1), (32, 1024, 80, 1), (32, 256, 80, 1),      # the decoder's InstanceNorms
+                                         (1, 8 * 64 * 64, 64, 2), (1, 16 * 40 * 40, 512, 2), (1, 2048, 272, 1),           # BatchNorm shapes
+                                         (3, 1000, 12, 0), (1, 37, 4, 1), (5, 7, 260, 2), (1, 100000, 8, 0)])            # ragged
+def test_one_launch_norm_equals_three_launch_form(G, R, C, act):
+    """csrc/norm.hip norm_fwd_fused / norm_bwd_fused (statistics + apply in one kernel, the workgroups of a column group exchanging
+    their partial sums through agent-scope atomics) against float64 and against the three-launch kernels they replace, twice in a
+    row on the same scratch (the counters are fresh zeros per call) — y, mean, invstd, running statistics, dx, dgamma, dbeta."""
+    dev = _dev()
+    from tests.margins import within
+    from unidefense_amd import kernels as K
+    x = (rnd(G * R, C, seed=1) * 1.5 + 0.3).to(dev)
+    dy = rnd(G * R, C, seed=2).to(dev)
+    ga, be = (rnd(C, seed=3) * 0.1 + 1).to(dev), (rnd(C, seed=4) * 0.1).to(dev)
+    assert K.norm_fused_takes(x, G, R)
+    for rep in range(2):
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        rm0, rv0 = rm.clone(), rv.clone()
+        y, mean, invstd = K.norm_fwd_fused(x, G, R, ga, be, act, 1e-5, 0.1, rm if G == 1 else None, rv if G == 1 else None)
+        mean3, invstd3 = K.norm_stats(x, G, R, 1e-5, 0.1, rm0 if G == 1 else None, rv0 if G == 1 else None)
+        y3 = K.norm_apply(x, G, R, mean3, invstd3, ga, be, act)
+        dx, dg, db = K.norm_bwd_fused(x, dy, G, R, mean, invstd, ga, be, act)
+        dx3, dg3, db3 = K.norm_bwd(x, dy, G, R, mean3, invstd3, ga, be, act)
+        torch.cuda.synchronize()
+        # float64 reference
+        xd = x.double().view(G, R, C).requires_grad_()
+        gd, bd = ga.double().requires_grad_(), be.double().requires_grad_()
+        mu = xd.mean(1, keepdim=True)
+        var = xd.var(1, unbiased=False, keepdim=True)
+        z = (xd - mu) / torch.sqrt(var + 1e-5) * gd + bd
+        yd = z * torch.sigmoid(z) if act == 1 else (torch.relu(z) if act == 2 else z)
+        yd.backward(dy.double().view(G, R, C))
+        for name, got, got3, want in (("y", y, y3, yd.view(G * R, C)), ("mean", mean, mean3, mu.view(G, C)),
+                                      ("invstd", invstd, invstd3, (1 / torch.sqrt(var + 1e-5)).view(G, C)),
+                                      ("dx", dx, dx3, xd.grad.view(G * R, C)), ("dgamma", dg, dg3, gd.grad), ("dbeta", db, db3, bd.grad)):
+            sc = float(want.detach().abs().max().clamp_min(1e-6))
+            e = float((got.double() - want.detach()).abs().max()) / sc
+            e3 = float((got3.double() - want.detach()).abs().max()) / sc
+            assert within(f"fused norm {name}", e, max(2e-5, 3 * e3)), (name, e, e3)
+        if G == 1:
+            assert within("fused norm running_mean", float((rm - rm0).abs().max()), 1e-6)
+            assert within("fused norm running_var", float((rv - rv0).abs().max() / rv0.abs().max()), 1e-6)

@@ -884,3 +884,52 @@ def test_normbwd_apply_writes_the_gemm_planes_itself(N, HW, Cc, act, dz):
     loose = 2.0 ** 15 / (top / inv)
     assert 1.0 <= loose < 128.0, loose
     assert float(((h[0] + h[1] / 2048.0) * inv - yd).abs().max()) <= 2.0 ** -21 * top * loose
+
+
+@pytest.mark.parametrize("N,HW,Cc,skip,keep_p", [(32, 256, 160, True, 0.9), (32, 64, 272, True, 1.0), (4, 256, 112, False, 1.0),
+                                                  (3, 50, 36, True, 0.8)])
+def test_residual_bn_writes_the_next_expand_planes(N, HW, Cc, skip, keep_p):
+    """ud_residual_bn_planes (round 6): BN2 + drop-connect + skip also written as the fp16 x 2 planes of the NEXT block's expand
+    conv, scaled by the a-priori bound max_c(|gamma_c| sqrt(count) + |beta_c|) / keep_prob + max |skip|.  The fp32 result and its
+    absmax slots are those of ud_residual_bn bit for bit; the planes re-assemble to it to 2^-21 of the scale; the bound holds and is
+    within 2^8 of the exact maximum; pad columns of the last panel are zero."""
+    from unidefense_amd import kernels as K
+    from unidefense_amd.lib import call as _call
+    import ctypes as C
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N + HW + Cc)
+    p = (torch.randn(N, HW, Cc, generator=g) * (0.5 + torch.rand(Cc, generator=g))).to(dev)
+    sk = None
+    if skip:
+        prev = torch.randn(N, HW, Cc, generator=g).to(dev) * 2.0
+        acc0 = K.zeros64(2 * Cc, p)
+        K.colstats(prev.view(-1, Cc), acc0)
+        bn0 = K.DeferredBN(acc0, Cc, N * HW, torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev), 1e-3, 0)
+        sk = K.residual_bn(prev, bn0, None, 1.0, None, N, HW, want_absmax=True)          # a skip with its producer's absmax slots
+    keep = (torch.rand(N, generator=g) < keep_p).float().to(dev) if keep_p < 1.0 else None
+    gamma, beta = (1.0 + 0.3 * torch.randn(Cc, generator=g)).to(dev), (0.2 * torch.randn(Cc, generator=g)).to(dev)
+    acc = K.zeros64(2 * Cc, p)
+    K.colstats(p.view(-1, Cc), acc)
+    bn = K.DeferredBN(acc, Cc, N * HW, gamma, beta, 1e-3, 0)
+    ref = K.residual_bn(p, bn, keep, 1.0 / keep_p, sk, N, HW, want_absmax=True)
+    out = torch.empty_like(p)
+    amax = K.amax_slots(p, True)
+    pl = K.Planes(N * HW, Cc, p, 2, False)
+    _call("ud_residual_bn_planes", K._p(p), C.byref(bn.ref()), K._p(keep), float(1.0 / keep_p), K._p(sk),
+          K._p(sk._ud_absmax if sk is not None else None), K._p(out), K._p(pl.buf), pl.panel, pl.plane, K._p(pl.inv), N, HW, Cc,
+          K._p(amax), K._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert float(amax.view(torch.float32).max()) == float(ref._ud_absmax.view(torch.float32).max()) == float(ref.abs().max())
+    R = N * HW
+    full = pl.buf.view(2, pl.npanel, pl.panel // 32, 32)[:, :, :R].view(torch.float16).permute(0, 2, 1, 3).reshape(2, R, pl.npanel * 32)
+    h = full[:, :, :Cc].double()
+    assert float(full[:, :, Cc:].abs().max() if pl.npanel * 32 > Cc else 0.0) == 0.0
+    inv = float(pl.inv)
+    yd = ref.view(R, Cc).double()
+    top = float(yd.abs().max())
+    loose = 2.0 ** 15 / (top / inv)
+    assert within("residual planes: bound / exact maximum", loose, 256.0) and loose >= 1.0, loose
+    assert within("residual planes: re-assembled error / (2^-21 scale)", float(((h[0] + h[1] / 2048.0) * inv - yd).abs().max()) /
+                  (2.0 ** -21 * top * loose), 1.0)

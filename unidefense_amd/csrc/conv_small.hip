@@ -248,7 +248,7 @@ int ud_conv_small_supported(int Cin, int Cout, int KH, int KW) {
     if (KH != 3 || KW != 3) return 0;
     const int key = Cin * 100 + Cout;
     switch (key) {
-        case 2020: case 2003: case 320: case 348: return 1;
+        case 2020: case 2003: case 320: case 348: case 3203: case 332: return 1;          // (32 <-> 3: the UDR50 decoder's image end)
         default: return 0;
     }
 }
@@ -263,6 +263,8 @@ int ud_conv_small(const ud_conv_geom* g, const float* x, const float* wmat, floa
         case 2003: return launch<20, 3>(*g, x, wmat, y, s);
         case 320: return launch<3, 20>(*g, x, wmat, y, s);
         case 348: return launch<3, 48>(*g, x, wmat, y, s);
+        case 3203: return launch<32, 3>(*g, x, wmat, y, s);
+        case 332: return launch<3, 32>(*g, x, wmat, y, s);
         default: return UD_EINVAL;
     }
 }
@@ -271,7 +273,7 @@ int ud_conv_small(const ud_conv_geom* g, const float* x, const float* wmat, floa
 int ud_conv_small_wgrad_supported(int Cin, int Ma, int KH, int KW) {
     if (KH != 3 || KW != 3) return 0;
     switch (Cin * 100 + Ma) {
-        case 2020: case 2003: case 348: case 320: return 1;
+        case 2020: case 2003: case 348: case 320: case 3203: return 1;
         default: return 0;
     }
 }
@@ -290,6 +292,7 @@ int ud_conv_small_wgrad(const ud_conv_geom* g, const float* a, const float* x, f
         case 2003: return launch_wgrad<20, 3>(*g, a, x, part, out, s);
         case 348: return launch_wgrad<3, 48>(*g, a, x, part, out, s);
         case 320: return launch_wgrad<3, 20>(*g, a, x, part, out, s);
+        case 3203: return launch_wgrad<32, 3>(*g, a, x, part, out, s);
         default: return UD_EINVAL;
     }
 }

@@ -230,11 +230,51 @@ __global__ __launch_bounds__(NT) void se_scale_bn_plane_half_kernel(RedGeom q, c
     }
 }
 
-template <typename T>
+// PL (round 6): ALSO written as the fp16 x 2 planes of the NEXT block's expand conv (ud_gemm_p3 prec 2, P32 layout over [G R] x C)
+// — the block output is that conv's operand, and splitting it took a pass of its own (17 launches per step).  The scale comes from
+// an a-priori bound: |bn(p)_c| <= |gamma_c| sqrt(count) + |beta_c| (a z-score never exceeds sqrt(count - 1)), times the
+// drop-connect factor, plus the skip's exact maximum (its producer's absmax slots); every workgroup derives the same scale.
+struct ResPlanes {
+    uint16_t* buf;
+    long panel, plane;
+    float* inv_scale;
+    const uint32_t* skip_amax;          // 256 slots: max |skip| (NULL: no skip)
+};
+
+template <typename T, int PL = 0>
 __global__ __launch_bounds__(NT) void residual_bn_kernel(RedGeom q, const T* __restrict__ x, ud_bn_ref bn,
                                                          const float* __restrict__ keep, float inv_keep,
                                                          const T* __restrict__ skip, T* __restrict__ out,
-                                                         uint32_t* __restrict__ amax) {
+                                                         uint32_t* __restrict__ amax, ResPlanes rp) {
+    float ps = 1.f;
+    if constexpr (PL == 1) {
+        __shared__ float pl_red[NT / 64];
+        const float rc = sqrtf((float)(1.0 / bn.inv_count));
+        float gm = 0.f;
+        for (int i = threadIdx.x; i < q.C4 * 4; i += NT) gm = fmaxf(gm, fabsf(bn.gamma[i]) * rc + fabsf(bn.beta[i]));
+        gm *= keep ? inv_keep : 1.f;
+        gm = ud_wave_max(gm);
+        if ((threadIdx.x & 63) == 0) pl_red[threadIdx.x >> 6] = gm;
+        __syncthreads();
+        gm = pl_red[0];
+#pragma unroll
+        for (int i = 1; i < NT / 64; ++i) gm = fmaxf(gm, pl_red[i]);
+        float sk = 0.f;
+        if (rp.skip_amax) {
+            uint32_t mb = rp.skip_amax[threadIdx.x & 255];          // NT = 256 slots: one each
+            sk = __uint_as_float(mb);
+            sk = ud_wave_max(sk);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) pl_red[threadIdx.x >> 6] = sk;
+            __syncthreads();
+            sk = pl_red[0];
+#pragma unroll
+            for (int i = 1; i < NT / 64; ++i) sk = fmaxf(sk, pl_red[i]);
+        }
+        float pinv;
+        ud_h2_scale(__float_as_uint((gm + sk) * 1.001f), ps, pinv);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *rp.inv_scale = pinv;
+    }
     int ri, c4;
     float m = 0.f;
     if (thread_coords(q, ri, c4)) {
@@ -243,12 +283,27 @@ __global__ __launch_bounds__(NT) void residual_bn_kernel(RedGeom q, const T* __r
         const Bn4 cb = bn_load(bn, blockIdx.z, q.C4, c4, is_updater(ri));
         const float sc = keep ? keep[blockIdx.z] * inv_keep : 1.f;
         Rows w = rows_of(q, ri, c4);
+        uint16_t* po = PL ? rp.buf + (long)(c4 >> 3) * rp.panel + (c4 & 7) * 4 : nullptr;
+        const int npad = (PL && c4 == q.C4 - 1) ? 7 - (c4 & 7) : 0;
+        long prow = (long)blockIdx.z * q.R + w.r;
 #pragma unroll kRowUnroll<T>
-        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step) {
+        for (; w.r < w.r_end; w.r += q.rpi, w.idx += w.step, prow += q.rpi) {
             f32x4 v = bn_apply(x4[w.idx], cb, bn.act) * sc;
             if (skip) v += k4[w.idx];
             o4.st(w.idx, v);
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            if constexpr (PL == 1) {
+                typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+                uint16_t h0[4], h1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ud_split_h2(v[e] * ps, h0[e], h1[e]);
+                *reinterpret_cast<u16x4*>(po + prow * 32) = u16x4{h0[0], h0[1], h0[2], h0[3]};
+                *reinterpret_cast<u16x4*>(po + prow * 32 + rp.plane) = u16x4{h1[0], h1[1], h1[2], h1[3]};
+                for (int z = 1; z <= npad; ++z) {
+                    *reinterpret_cast<u16x4*>(po + prow * 32 + 4 * z) = u16x4{0, 0, 0, 0};
+                    *reinterpret_cast<u16x4*>(po + prow * 32 + 4 * z + rp.plane) = u16x4{0, 0, 0, 0};
+                }
+            }
         }
     }
     ud_absmax_commit(m, amax);
@@ -990,7 +1045,20 @@ int ud_residual_bn(const void* x, const ud_bn_ref* bn, const float* keep, float 
     if (!shape_ok(G, R, C) || !x || !bn || !out) return UD_EINVAL;
     RedGeom q = geom_ew(G, R, C);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(residual_bn_kernel<T>, red_grid(q), dim3(NT), 0, (hipStream_t)stream, q,
-                                                (const T*)x, *bn, keep, inv_keep, (const T*)skip, (T*)out, absmax));
+                                                (const T*)x, *bn, keep, inv_keep, (const T*)skip, (T*)out, absmax, ResPlanes{}));
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
+int ud_residual_bn_planes(const float* x, const ud_bn_ref* bn, const float* keep, float inv_keep, const float* skip,
+                          const uint32_t* skip_absmax, float* out, uint16_t* planes, long panel_stride, long plane_stride,
+                          float* inv_scale, int G, int R, int C, uint32_t* absmax, ud_stream_t stream) {
+    if (!shape_ok(G, R, C) || !x || !bn || !out || !planes || !inv_scale || panel_stride < 32L * G * R ||
+        plane_stride < panel_stride * ((C + 31) / 32) || (skip && !skip_absmax))
+        return UD_EINVAL;
+    RedGeom q = geom_ew(G, R, C);
+    hipLaunchKernelGGL((residual_bn_kernel<float, 1>), red_grid(q), dim3(NT), 0, (hipStream_t)stream, q, x, *bn, keep, inv_keep,
+                       skip, out, absmax, ResPlanes{planes, panel_stride, plane_stride, inv_scale, skip ? skip_absmax : nullptr});
     UD_LAUNCH_CHECK();
     return 0;
 }

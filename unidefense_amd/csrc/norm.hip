@@ -306,11 +306,17 @@ __global__ __launch_bounds__(NT) void norm_apply_bwd(long total4, int R, int C4,
 // bounded by wall-clock time all the same (2 s: results become NaN, never a hung queue).  counters: P-cluster counters,
 // zero before the launch (kernels.zeros: part of a captured step's fills).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void publish64(double* p, double v) {
-    unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p),
-                                                   (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::"v"(old));          // wait for the returned word: the exchange has been performed
+// all NQ exchanges are issued back to back, THEN their returned words are waited for (one round trip, not NQ: the first version
+// waited per word and cost 20-25 us per kernel)
+template <int NQ>
+__device__ __forceinline__ void publish64(double* p, const double (&v)[8]) {
+    unsigned long long old[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        old[i] = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p + i), (unsigned long long)__double_as_longlong(v[i]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) asm volatile("" ::"v"(old[i]));          // the returned word: the exchange has been performed
 }
 __device__ __forceinline__ double peek64(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
@@ -331,10 +337,7 @@ __device__ __forceinline__ bool cluster_allsum(const RedGeom& q, int ri, bool ac
     bool ok = true;
     if (q.P > 1) {
         double* mine = slots + ((cluster * q.P + blockIdx.x) * q.CW + cl) * 8;
-        if (active && ri == 0) {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) publish64(mine + i, v[i]);
-        }
+        if (active && ri == 0) publish64<NQ>(mine, v);
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned* ctr = counters + cluster;

@@ -1492,16 +1492,24 @@ def norm_bwd(x2, dy, G, R, mean, invstd, gamma, beta, act):
 
 
 # One-launch normalisation (csrc/norm.hip: norm_fwd_fused / norm_bwd_fused): statistics + apply in ONE kernel whose workgroups
-# exchange their partial sums through agent-scope atomics.  Taken where the three-launch form is launch-bound: C % 4 == 0 and
-# at most _NORM_FUSED_MAX_BYTES of input (beyond that the passes are bandwidth-bound and want ~2000 workgroups, where the
-# one-launch form runs <= 768 resident ones).  A/B: tools/run_with.py kernels._NORM_FUSED=False
-_NORM_FUSED = True
+# exchange their partial sums through agent-scope atomics (no fence).  Built to cut the launch-bound InstanceNorms of the decoder
+# and the ResNet variants' BatchNorms from 3 / 4-5 launches to 1 / 1-2 — correct (tests/test_a_kernels_gpu.py), and measured
+# SLOWER on this part: the exchange is four dependent round trips to the memory side (publish, count, poll, read: ~17 us per
+# kernel) against two ~4.5 us launches — UDEB4 bs 32 25.07 -> 25.51 ms, UDR50 320^2 22.6 -> 25.2 (its 50 MB tensors also want
+# 2000 workgroups, the one-launch form runs <= 768 resident ones), UDR18 4.66 -> 5.00 (profiles/r06/norm_one_launch_ab.txt).
+# OFF; kept as the measured answer to "exchange inside the kernel instead of a launch".  A/B: tools/run_with.py kernels._NORM_FUSED=True
+_NORM_FUSED = False
 _NORM_FUSED_MAX_BYTES = 64 << 20
 
 
 def norm_fused_ok(x2, G, R):
     Cc = x2.shape[-1]
-    return (_NORM_FUSED and x2.is_cuda and x2.dtype == torch.float32 and Cc % 4 == 0 and Cc >= 4
+    return (_NORM_FUSED and norm_fused_takes(x2, G, R))
+
+
+def norm_fused_takes(x2, G, R):
+    Cc = x2.shape[-1]
+    return (x2.is_cuda and x2.dtype == torch.float32 and Cc % 4 == 0 and Cc >= 4
             and x2.numel() * 4 <= _NORM_FUSED_MAX_BYTES and G * R == x2.shape[0])
 
 
@@ -2518,13 +2526,29 @@ def se_scale_bn(x, bn, s, G, R, want_absmax=False):
     return y
 
 
-def residual_bn(x, bn, keep, inv_keep, skip, G, R, update=False, want_absmax=False):
+_RESIDUAL_PLANES = True          # A/B: tools/run_with.py kernels._RESIDUAL_PLANES=False
+
+
+def residual_bn(x, bn, keep, inv_keep, skip, G, R, update=False, want_absmax=False, planes_for=None):
+    """out = bn(x) [* keep / keep_prob] [+ skip].  planes_for = (M, N, w2) of the 1x1 conv that reads `out` next (the following
+    block's expand conv): where that conv runs on the planes GEMM, `out` is ALSO written as its fp16 x 2 planes
+    (out._ud_planes; scale from an a-priori bound, ud_residual_bn_planes) — no split pass over the block output."""
     h = _act(x, skip)
     _chk(keep)
     out = torch.empty_like(x)
     amax = amax_slots(x, want_absmax)
-    _call("ud_residual_bn", _p(x), C.byref(bn.ref(update)), _p(keep), float(inv_keep), _p(skip), _p(out), G, R,
-          x.shape[-1], h, _p(amax), _stream())
+    Cc = x.shape[-1]
+    skip_amax = getattr(skip, "_ud_absmax", None) if skip is not None else None
+    if (planes_for is not None and _RESIDUAL_PLANES and _RFFT_PLANES and h == 0 and Cc % 4 == 0 and CFG.spectral_p2 != "off"
+            and (skip is None or skip_amax is not None)
+            and spectral_takes_planes(planes_for[0], planes_for[1], Cc, planes_for[2], want_stats=True)):
+        pl = Planes(G * R, Cc, x, 2, False)
+        _call("ud_residual_bn_planes", _p(x), C.byref(bn.ref(update)), _p(keep), float(inv_keep), _p(skip), _p(skip_amax), _p(out),
+              _p(pl.buf), pl.panel, pl.plane, _p(pl.inv), G, R, Cc, _p(amax), _stream())
+        out._ud_planes = pl
+    else:
+        _call("ud_residual_bn", _p(x), C.byref(bn.ref(update)), _p(keep), float(inv_keep), _p(skip), _p(out), G, R,
+              Cc, h, _p(amax), _stream())
     out._ud_absmax = amax
     return out
 

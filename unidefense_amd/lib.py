@@ -181,6 +181,7 @@ _SIGNATURES = {
     "ud_se_scale_bn_plane_half": [_P, _BN, _P, _P, _L, _P, _I, _I, _I, _P],
     "ud_se_scale_bn_planes": [_P, _BN, _P, _P, _L, _L, _P, _P, _I, _I, _I, _P],
     "ud_residual_bn": [_P, _BN, _P, _F, _P, _P, _I, _I, _I, _I, _P, _P],
+    "ud_residual_bn_planes": [_P, _BN, _P, _F, _P, _P, _P, _P, _L, _L, _P, _I, _I, _I, _P, _P],
     "ud_normbwd_sums": [_P, _P, _P, _F, _BN, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "ud_normbwd_apply_plane_half": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P, _P, _P],
     "ud_normbwd_apply_planes": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _L, _P, _P, _P, _P],

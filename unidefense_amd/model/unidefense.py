@@ -364,8 +364,9 @@ class UniDefenseModelEb4(nn.Module):
                 pend = self.__dict__.setdefault("_nbt_pending", [])
                 pend.extend(b.num_batches_tracked for b in (getattr(blk, "_bn0", None), blk._bn1, blk._bn2)
                             if b is not None and b.num_batches_tracked is not None)
+                nxt = self.backbone._blocks[idx + 1] if idx + 1 < end else None          # (within the stage: its input IS this output)
                 x = T.mbconv_fused(tape, x, blk, keep, 1.0 - rate, fused["wt"][id(blk._depthwise_conv.weight)],
-                                   fused["dp"], lazy_in if idx == 0 else None)
+                                   fused["dp"], lazy_in if idx == 0 else None, next_blk=nxt)
             else:
                 dt = x.dtype                                   # the operator path computes in fp32 storage
                 if dt != torch.float32:

@@ -1106,7 +1106,7 @@ def stem_fused(tape, x_pix, w, bn_mod, stride, pad_t, pad_l, Ho, Wo, dp, storage
     return h, LazyInput(bn, backward)
 
 
-def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
+def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None, next_blk=None):
     """MBConvBlock.forward (model/efficientnet/model.py:94-135) in training mode as ONE tape node.
     x [N,H,W,Cin]: the block input (for block 0: the raw stem output, lazy_in its deferred BatchNorm);
     wt: the depthwise weight in tap-major layout [k*k][C]; keep: drop-connect keep vector [N] or None.
@@ -1134,7 +1134,10 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
         We = blk._expand_conv.weight.view(Ce, Cin)
         x2 = x.view(M, Cin)
         acc0 = K.zeros64(2 * Ce, x)
-        (e, done), ectx = K.spectral_fwd(x2, We, stats=acc0, x_absmax=getattr(x, "_ud_absmax", None))          # BN0 statistics in the GEMM epilogue where the launch is plain
+        xp = getattr(x, "_ud_planes", None)          # the previous block's residual pass wrote this conv's operand planes itself
+        if xp is not None and not (xp.R == M and xp.C == Cin and K.spectral_takes_planes(M, Ce, Cin, We, want_stats=True)):
+            xp = None
+        (e, done), ectx = K.spectral_fwd(x2 if xp is None else xp, We, stats=acc0, x_absmax=getattr(x, "_ud_absmax", None))          # BN0 statistics in the GEMM epilogue where the launch is plain
         if not done:
             K.colstats(e, acc0)
         e = e.view(N, H, W, Ce)
@@ -1247,7 +1250,11 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None):
     dp.reduce(acc2)
     bn2 = _bn_of(blk._bn2, acc2, Mo * dp.world, 0)
     p4 = p.view(N, Ho, Wo, Co)
-    out = K.residual_bn(p4, bn2, keep, inv_keep, x if sp.skip else None, N, HWo, update=True, want_absmax=True)
+    # the block output is the next block's expand-conv operand: written as that GEMM's planes in the same pass where it takes them
+    nxt = None
+    if next_blk is not None and next_blk.spec.expand != 1:
+        nxt = (Mo, next_blk.spec.cexp, next_blk._expand_conv.weight.view(next_blk.spec.cexp, Co))
+    out = K.residual_bn(p4, bn2, keep, inv_keep, x if sp.skip else None, N, HWo, update=True, want_absmax=True, planes_for=nxt)
     if not _needs(tape):
         return out
 
