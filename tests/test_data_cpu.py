@@ -96,3 +96,23 @@ def test_every_rank_gets_the_same_number_of_equal_batches(n, world, bs, drop_las
     if not drop_last:
         assert set(seen) == set(range(n))                   # padding only ever repeats samples, never drops one
         assert len(seen) == -(-n // world) * world
+
+
+def test_uint8_hand_over_is_converted_by_the_device_transform():
+    """sources may yield uint8 pixels (a quarter of the bytes through the worker IPC / staging copy / PCIe): they stay uint8 up to
+    the device, where `device_transform` makes the float batch; the default is a plain .float()"""
+    from unidefense_amd.engine.data import DecodedBatches, RealFakePrefetcher
+
+    class U8Faces(_ToyFaces):
+        def load_item(self, paths, labels, crop=None):
+            return {"images": torch.full((len(paths), 3, 4, 4), 255, dtype=torch.uint8), "path": paths}
+    db = DecodedBatches(U8Faces(8, 0), 4, shuffle=False, keep_dtype=True)
+    img, lab = db[0]
+    assert img.dtype == torch.uint8 and lab.dtype == torch.int64
+    assert DecodedBatches(U8Faces(8, 0), 4, shuffle=False)[0][0].dtype == torch.float32
+    src = [(torch.full((2, 3, 4, 4), 255, dtype=torch.uint8), torch.zeros(2, dtype=torch.int32))]
+    pf = RealFakePrefetcher(src, src, device_transform=lambda u8: u8.float().mul_(2.0 / 255.0).sub_(1.0))
+    xr, yr, xf, yf = pf(1, 2, 4, "cpu")
+    assert xr.dtype == torch.float32 and torch.allclose(xr, torch.ones_like(xr)) and yr.dtype == torch.int64
+    xr, _, _, _ = RealFakePrefetcher(src, src)(1, 2, 4, "cpu")
+    assert xr.dtype == torch.float32 and float(xr.max()) == 255.0

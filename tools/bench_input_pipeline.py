@@ -24,8 +24,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 class SyntheticFaces(torch.utils.data.Dataset):
     """(path, label) items + the reference's `load_item(paths, labels) -> {'images': [B,3,H,W]}` batch decode"""
 
-    def __init__(self, n, label, size):
-        self.n, self.label, self.size = n, label, size
+    def __init__(self, n, label, size, uint8=False):
+        self.n, self.label, self.size, self.uint8 = n, label, size, uint8
 
     def __len__(self):
         return self.n
@@ -35,13 +35,13 @@ class SyntheticFaces(torch.utils.data.Dataset):
 
     def load_item(self, paths, labels, crop=None):
         S = self.size
-        out = np.empty((len(paths), 3, S, S), dtype=np.float32)
+        out = np.empty((len(paths), 3, S, S), dtype=np.uint8 if self.uint8 else np.float32)
         for k, p in enumerate(paths):
             rng = np.random.default_rng(abs(hash(p)) % (1 << 32))
             img = rng.integers(0, 256, size=(S, S, 3), dtype=np.uint8)          # the "decoded" image
             if rng.random() < 0.5:
                 img = img[:, ::-1]
-            out[k] = (img.astype(np.float32) * (2.0 / 255.0) - 1.0).transpose(2, 0, 1)
+            out[k] = img.transpose(2, 0, 1) if self.uint8 else (img.astype(np.float32) * (2.0 / 255.0) - 1.0).transpose(2, 0, 1)
         return {"images": torch.from_numpy(out), "path": paths}
 
 
@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workers", type=int, default=6, help="decode processes per source (real, fake)")
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--uint8", action="store_true", help="the dataset hands over uint8 pixels; float conversion + normalisation on "
+                                                        "the device (RealFakePrefetcher(device_transform=...))")
     args = ap.parse_args()
     import bench
     from unidefense_amd.engine.data import RealFakePrefetcher, worker_loader
@@ -102,9 +104,10 @@ def main():
     # (b) fed by the pipeline: real + fake sources, decode in worker processes, pinned H2D one step ahead, D2D into the
     # captured step's static input
     n_img = half * (args.steps + args.warmup + 8)
-    real = worker_loader(SyntheticFaces(n_img, 0, 256), half, workers=args.workers)
-    fake = worker_loader(SyntheticFaces(n_img, 1, 256), half, workers=args.workers)
-    feeder = RealFakePrefetcher(real, fake, depth=3)
+    real = worker_loader(SyntheticFaces(n_img, 0, 256, args.uint8), half, workers=args.workers, keep_dtype=args.uint8)
+    fake = worker_loader(SyntheticFaces(n_img, 1, 256, args.uint8), half, workers=args.workers, keep_dtype=args.uint8)
+    feeder = RealFakePrefetcher(real, fake, depth=3,
+                                device_transform=(lambda u8: u8.float().mul_(2.0 / 255.0).sub_(1.0)) if args.uint8 else None)
 
     def feed(i):
         xr, yr, xf, yf = feeder(i, bs, 256, dev)
@@ -116,18 +119,19 @@ def main():
     t_fed = timed(feed, args.steps)
 
     # (c) the decode alone in ONE process (what the reference's main-process load_item would cost per step)
-    ds = SyntheticFaces(64, 0, 256)
+    ds = SyntheticFaces(64, 0, 256, args.uint8)
     t0 = time.perf_counter()
     for r in range(4):
         ds.load_item([ds[j][0] for j in range(16 * r, 16 * r + 16)], None)
     t_dec = (time.perf_counter() - t0) / 4 * 2          # two sources per step
 
-    gb = bs * 3 * 256 * 256 * 4 / 1e9
+    gb = bs * 3 * 256 * 256 * (1 if args.uint8 else 4) / 1e9
+    print(f"# {'uint8 hand-over, float conversion on the device' if args.uint8 else 'float32 hand-over (the reference load_item contract)'}")
     print(f"# UDEB4 256x256 bs {bs} fwd + pass-1 loss + bwd (hipGraph replay), {args.steps} steps; {args.workers} decode workers per source; "
           f"host CPU quota {bench.host_cores()} cores")
     print(f"step alone (inputs resident in HBM):                 {1e3 * t_alone:7.2f} ms  {bs / t_alone:7.0f} img/s")
     print(f"step fed by worker_loader + RealFakePrefetcher:      {1e3 * t_fed:7.2f} ms  {bs / t_fed:7.0f} img/s   "
-          f"H2D {gb / t_fed:5.2f} GB/s of fp32 pixels   ({100 * (t_fed / t_alone - 1):+.1f} % vs resident)")
+          f"H2D {gb / t_fed:5.2f} GB/s of pixels   ({100 * (t_fed / t_alone - 1):+.1f} % vs resident)")
     print(f"synthetic decode of one step's 2 x {half} images in ONE process (the reference's main-process load_item): "
           f"{1e3 * t_dec:7.1f} ms  -> {bs / t_dec:6.0f} img/s if it ran in the training process")
     sys.stdout.flush()

@@ -17,7 +17,11 @@ class RealFakePrefetcher:
 
     real, fake: re-iterable sources (e.g. DataLoaders) yielding `(images [B,3,H,W] float, labels [B] int64)`."""
 
-    def __init__(self, real, fake, depth=2):
+    def __init__(self, real, fake, depth=2, device_transform=None):
+        """device_transform: optional callable applied to each image batch ON THE DEVICE (copy stream) after the H2D copy —
+        for sources that hand over uint8 pixels (a quarter of the bytes through the worker IPC, the pinned staging copy and
+        PCIe: profiles/r06/input_pipeline.txt), e.g. `lambda u8: u8.float().mul_(2 / 255).sub_(1)`; default: `.float()`."""
+        self.device_transform = device_transform
         self.sources = (real, fake)
         self.q = queue.Queue(maxsize=depth)
         self.stream = None
@@ -41,14 +45,17 @@ class RealFakePrefetcher:
             cuda = self.device.type == "cuda"
             while True:
                 (xr, yr), (xf, yf) = next(its[0]), next(its[1])
-                batch = [xr.float(), yr.long(), xf.float(), yf.long()]
+                tf = self.device_transform or (lambda t: t.float())
                 if cuda:
-                    batch = [t.pin_memory() for t in batch]
+                    # images travel in the dtype the source yields (uint8 stays uint8 until it is on the device)
+                    batch = [t.pin_memory() for t in (xr, yr.long(), xf, yf.long())]
                     with torch.cuda.stream(self.stream):
                         batch = [t.to(self.device, non_blocking=True) for t in batch]
+                        batch[0], batch[2] = tf(batch[0]), tf(batch[2])
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
                 else:
+                    batch = [tf(xr), yr.long(), tf(xf), yf.long()]
                     ev = None
                 self.q.put((batch, ev))
         except Exception as e:                      # noqa: BLE001 — surfaced on the consumer side
@@ -86,7 +93,10 @@ class DecodedBatches(torch.utils.data.Dataset):
     same number of equally sized batches — unequal step counts would leave the gradient all-reduces and the SyncBN
     exchange of the longer ranks waiting for peers that have finished."""
 
-    def __init__(self, dataset, batch_size, crop=None, shuffle=True, seed=0, rank=0, world=1, drop_last=True):
+    def __init__(self, dataset, batch_size, crop=None, shuffle=True, seed=0, rank=0, world=1, drop_last=True, keep_dtype=False):
+        """keep_dtype: hand `load_item`'s images over as they are (e.g. uint8, converted on the device by the prefetcher's
+        `device_transform`) instead of as float32"""
+        self.keep_dtype = bool(keep_dtype)
         self.dataset, self.batch_size, self.crop = dataset, int(batch_size), crop
         self.shuffle, self.seed, self.rank, self.world, self.drop_last = shuffle, int(seed), int(rank), int(world), drop_last
         self.epoch = 0
@@ -120,7 +130,8 @@ class DecodedBatches(torch.utils.data.Dataset):
         labels = torch.as_tensor([int(it[1]) for it in items], dtype=torch.int64)
         kw = {} if self.crop is None else {"crop": self.crop}
         out = self.dataset.load_item(paths, labels, **kw)
-        return out["images"].float().contiguous(), labels
+        img = out["images"]
+        return (img if self.keep_dtype else img.float()).contiguous(), labels
 
 
 def worker_loader(dataset, batch_size, workers=4, **kw):
