@@ -741,14 +741,16 @@ int ud_rfft2_planes_adjoint(const float* dY, float* dx, float* ws, long P, int S
  * words advanced by the kernel (hipGraph replays keep counting); a peer that does not arrive within timeout_ms of
  * wall-clock time sets *err (1 + its rank) and turns the affected sums into NaN (never a partial sum) instead of hanging.  world <= 16.  Setup: ud_xchg_create on every rank, handles exchanged by the
  * host (64 bytes each), ud_xchg_open on every peer's handle, the `world` pointers (own base at [rank]) copied to a
- * device array.  max_doubles bounds n; slots >= 2 (a rank is never more than one exchange ahead of the slowest). */
+ * device array.  max_doubles bounds n; slots >= 2 (a rank is never more than one exchange ahead of the slowest).
+ * local_out (may be NULL): receives this rank's OWN n doubles as they were before the sum (the local dgamma / dbeta of a
+ * BatchNorm backward) — the copy a separate launch made before round 6. */
 long ud_xchg_bytes(int world, int max_doubles, int slots);
 int ud_xchg_create(int world, int max_doubles, int slots, void** base, char* handle);
 int ud_xchg_open(const char* handle, void** ptr);
 int ud_xchg_close(void* ptr);
 int ud_xchg_destroy(void* base);
 int ud_xchg_allreduce(double* acc, int n, void* const* peers, int rank, int world, int max_doubles, int slots,
-                      unsigned long long* seq_counter, int* err, long timeout_ms, ud_stream_t stream);
+                      unsigned long long* seq_counter, int* err, long timeout_ms, double* local_out, ud_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,9 @@ RTOL = 1e-3
 GRAD_RTOL, GRAD_ATOL = 1e-3, 2e-5
 FULL_RTOL = 2e-2
 # BN2 biases whose gradient is analytically zero (the block's output reaches nothing but BatchNorm-ed paths)
+# the N = 8 fixture's gate gradients on which the REFERENCE's own fp32 record is 3e-5 off the float64 value (5.5e-3): held to 1e-2
+# of the reference there and to the plain 1e-3 against float64 (test_train_grads_vs_oracle_elementwise_n8_plain_bound)
+N8_REF_FP32_NOISE = ("backbone._blocks.9._depthwise_conv.sf_coef",)
 STRUCT_ZERO_GRADS = {f"backbone._blocks.{i}._bn2.bias" for i in list(range(16)) + [30, 31]}
 # ... and the same biases in the stage whose output x_b4 also reaches the decoder / the triplet feature: still almost
 # entirely cancelled (reference norm 1e-4 against 1e-2 .. 1e+1 elsewhere)
@@ -172,12 +175,13 @@ def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant, fname, run_mode)
     # own fp32 value of one of them (blocks.9, 5.5e-3) sits 3e-5 from the float64 result, which this path reproduces to the plain
     # 1e-3 bound (test_train_grads_vs_oracle_elementwise_n8_plain_bound: 504 of 504).  Against the reference's fp32 record such a
     # scalar is held to 1e-2 of its value; at most two may need it, every other tensor meets the bound above.
-    scal = [r for r in rows if not r[0] <= rtol and r[1].endswith("sf_coef") and max(r[2], r[3]) <= 1e-2 * r[4]]
+    # The exemption is pinned to the NAMED tensor (N8_REF_FP32_NOISE): any other scalar gate leaving the bound fails.
+    scal = [r for r in rows if not r[0] <= rtol and n >= 8 and r[1] in N8_REF_FP32_NOISE and max(r[2], r[3]) <= 1e-2 * r[4]]
     rows_strict = [r for r in rows if r not in scal]
     within(f"worst of 504 gradient tensors (N = {n}): max(norm err, head err) / (ref norm + floor)", rows_strict[0][0], rtol)
     bad = [r for r in rows_strict if not r[0] <= rtol]
     assert not bad, bad[:10]
-    assert within(f"N = {n} {variant}: scalar sf_coef gradients held to 1e-2 of the reference's fp32 value instead", len(scal), 2 if n >= 8 else 0)
+    assert within(f"N = {n} {variant}: scalar sf_coef gradients held to 1e-2 of the reference's fp32 value instead", len(scal), 1 if n >= 8 else 0)
     assert len(rows) == 504 and within_1e3 >= len(rows) - len(scal)
     # Who needs the absolute floor at all?  Only gradients that are zero up to rounding on BOTH sides: BatchNorm biases
     # of the STRUCT_ZERO_GRADS family, reference norm < 1e-4 (against 1e-2 .. 1e+1 for every other tensor), and their
@@ -186,7 +190,7 @@ def test_train_fwd_bwd_vs_reference_golden(golden_dir, variant, fname, run_mode)
     print("  tensors outside a purely relative 1e-3:", [(r[1], "%.1e" % r[4]) for r in floor_users])
     odd = [(r[1], r[4]) for r in floor_users
            if not ((r[1] in STRUCT_ZERO_GRADS and r[4] < 1e-4) or (r[1] in NEAR_ZERO_GRADS and r[4] < 1e-3) or
-                   (n >= 8 and r[1].endswith("sf_coef") and max(r[2], r[3]) <= 1e-2 * r[4]))]
+                   (n >= 8 and r[1] in N8_REF_FP32_NOISE and max(r[2], r[3]) <= 1e-2 * r[4]))]
     assert not odd, odd
 
 

@@ -201,7 +201,12 @@ def _xchg_worker(rank, port, q, world=2, skew=False):
                     torch.cuda.synchronize()
                     time.sleep(0.05)
                 a = (v[rank] * (rep + 1)).to(dev)
-                ex.allreduce(a)
+                if (i + rep) % 2:
+                    own = torch.full_like(a, float("nan"))
+                    ex.allreduce(a, own)                                      # + this rank's own values, written by the same launch
+                    assert torch.equal(own.cpu(), v[rank] * (rep + 1)), "local_out"
+                else:
+                    ex.allreduce(a)
                 want = v[0] * (rep + 1)
                 for r in range(1, world):                                     # rank order 0 + 1 + ...: exactly this fp64 sum
                     want = want + v[r] * (rep + 1)

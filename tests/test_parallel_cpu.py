@@ -75,15 +75,20 @@ def _worker(rank, world, port, q):
         class _Exchange:
             MAX_DOUBLES, calls = 4, 0
 
-            def allreduce(self, a):
+            def allreduce(self, a, local_out=None):          # (BnExchange's contract: the rank's own values out of the same call)
                 self.calls += 1
+                if local_out is not None:
+                    local_out.copy_(a)
                 dist.all_reduce(a)
         ex = _Exchange()
         dpx = T.DataParallelCtx(dist.group.WORLD, ex)
         small, big = torch.ones(4, dtype=torch.float64), torch.ones(6, dtype=torch.float64)
         dpx.reduce(small)
         dpx.reduce(big)
-        ok_ctx = ok_ctx and ex.calls == 1 and bool((small == world).all()) and bool((big == world).all())
+        mine = torch.full((4,), float(rank + 1), dtype=torch.float64)
+        loc_x = dpx.reduce(mine, keep_local=True)
+        ok_ctx = ok_ctx and ex.calls == 2 and bool((small == world).all()) and bool((big == world).all()) \
+            and torch.equal(loc_x, torch.full((4,), float(rank + 1), dtype=torch.float64)) and bool((mine == tri).all())
         ok_bn = ok_bn and ok_ctx
         q.put((rank, ok_bcast, ok_avg, ok_bn, hasattr(net, "_sync_bn_group")))
     except Exception as e:          # surface the failure instead of letting the parent time out

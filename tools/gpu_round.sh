@@ -19,11 +19,11 @@ echo "bench exit $?"; tail -1 $out/bench.json | cut -c1-400
 echo "== rocprofv3 kernel stats (STEPS executed: 2 eager warm-ups + 3 + 10 replays + 3 eager instrumented = 18)"
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_under_rocprof.log 2>&1
 echo "rocprof exit $?"
 find $out/prof -name "*kernel_trace.csv" -delete
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" $out/kernel_stats.csv && python3 tools/roofline_from_rocprof.py $out/kernel_stats.csv $out/gemm_table.txt 18
+[ -n "$f" ] && cp "$f" $out/kernel_stats.csv && python3 tools/roofline_from_rocprof.py $out/kernel_stats.csv $out/gemm_table.txt 18 $out/roofline_replayed.json | tee $out/roofline_from_rocprof.txt
 echo "== informational configs"
 timeout 600 python bench.py --dtype f16 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_f16_bs64.json
 timeout 600 python bench.py --model UDR50 --size 320 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_udr50_320.json

@@ -956,11 +956,13 @@ int ud_colstats(const void* x, int G, int R, int C, double* sum, double* sumsq, 
                 ud_stream_t stream) {
     if (!shape_ok(G, R, C) || !x || !sum || !sumsq) return UD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    RedPlan pl = plan_reduce(G, R, C, true, ws);
+    // G == 1 is ONE set of accumulators: planned like the other whole-batch reductions, so that a large tensor (the stem conv's
+    // 100 MB output: 64 workgroups of atomics took 48 us) runs as ~500 workgroups of partials + a fold
+    RedPlan pl = plan_reduce(G, R, C, G != 1, ws);
     UD_STORAGE_DISPATCH(f16, hipLaunchKernelGGL(colstats_kernel<T>, red_grid(pl.q), dim3(NT), 0, s, pl.q, (const T*)x, sum,
                                                 sumsq, pl.use_part ? ws : nullptr));
     UD_LAUNCH_CHECK();
-    return finish_reduce(pl, 2, true, C, ws, sum, sumsq, s);
+    return finish_reduce(pl, 2, G != 1, C, ws, sum, sumsq, s);
 }
 
 int ud_colsum_bn(const void* x, const ud_bn_ref* bn, int G, int R, int C, double* out, double* ws, int f16,

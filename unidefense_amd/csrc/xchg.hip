@@ -40,13 +40,15 @@ constexpr int MAXW = 16;          // ranks of one node
 __global__ __launch_bounds__(NT) void xchg_allreduce_kernel(double* __restrict__ acc, int n, void* const* __restrict__ peers,
                                                             int rank, int world, int max_doubles, int slots,
                                                             u64* __restrict__ counters, int* __restrict__ err,
-                                                            long long timeout_ticks) {
+                                                            long long timeout_ticks, double* __restrict__ local_out) {
     const int i = blockIdx.x * NT + threadIdx.x;
     const u64 seq = __hip_atomic_load(counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    __syncthreads();                                            // every wave of this workgroup has read it
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const u64 arrived = atomicAdd(counters + 1, 1ull) + 1;
+    asm volatile("" ::"v"(seq));                                // the loaded value has ARRIVED in this wave before it reaches the barrier
+    __syncthreads();                                            // every wave of this workgroup has read it (the barrier's
+    if (threadIdx.x == 0) {                                     //  own fence does not wait for loads: hence the line above)
+        // (rounds 2-5 had a __threadfence() here: an agent-scope release + acquire, i.e. an L2 write-back and invalidate per
+        //  exchange, for an ordering the returned atomic load above and this returning atomic already give)
+        const u64 arrived = __hip_atomic_fetch_add(counters + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
         if (arrived == gridDim.x) {                             // all workgroups have read counters[0]
             __hip_atomic_store(counters + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(counters, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -58,7 +60,9 @@ __global__ __launch_bounds__(NT) void xchg_allreduce_kernel(double* __restrict__
     if (tag == 0) tag = 0x80000000ull;                         // 0 is what a fresh mailbox holds
     tag <<= 32;
     // 1. publish
-    const u64 bits = (u64)__double_as_longlong(acc[i]);
+    const double mine_v = acc[i];
+    if (local_out) local_out[i] = mine_v;                      // this rank's own sums (the BatchNorm's dgamma / dbeta): no clone launch
+    const u64 bits = (u64)__double_as_longlong(mine_v);
     const u64 w0 = (bits & 0xffffffffull) | tag, w1 = (bits >> 32) | tag;
     for (int r = 0; r < world; ++r) {
         u64* dst = mailbox_row(peers[r], world, max_doubles, slot, rank) + 2 * i;
@@ -158,7 +162,7 @@ int ud_xchg_destroy(void* base) {
 // caller, zero-initialised.  timeout_ms: wall-clock wait for the slowest peer before it is reported missing through *err
 // (and the affected sums set to NaN).
 int ud_xchg_allreduce(double* acc, int n, void* const* peers, int rank, int world, int max_doubles, int slots,
-                      unsigned long long* seq_counter, int* err, long timeout_ms, ud_stream_t stream) {
+                      unsigned long long* seq_counter, int* err, long timeout_ms, double* local_out, ud_stream_t stream) {
     if (!acc || n < 1 || n > max_doubles || !peers || rank < 0 || rank >= world || world > MAXW || slots < 2 ||
         !seq_counter || !err || timeout_ms < 1)
         return UD_EINVAL;
@@ -170,7 +174,7 @@ int ud_xchg_allreduce(double* acc, int n, void* const* peers, int rank, int worl
         return (long long)rate;
     }();
     hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(ud_cdiv(n, NT)), dim3(NT), 0, (hipStream_t)stream, acc, n, peers,
-                       rank, world, max_doubles, slots, seq_counter, err, khz * (long long)timeout_ms);
+                       rank, world, max_doubles, slots, seq_counter, err, khz * (long long)timeout_ms, local_out);
     UD_LAUNCH_CHECK();
     return 0;
 }

@@ -191,13 +191,15 @@ class BnExchange:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag.item()) == 1
 
-    def allreduce(self, acc):
-        """acc (contiguous fp64, <= MAX_DOUBLES): summed over the ranks in place, in rank order."""
+    def allreduce(self, acc, local_out=None):
+        """acc (contiguous fp64, <= MAX_DOUBLES): summed over the ranks in place, in rank order.  local_out: optional buffer of
+        the same size that receives this rank's own values as they were before the sum (written by the same launch)."""
         from .. import kernels as K
         from .. import lib
         assert acc.dtype == torch.float64 and acc.is_contiguous() and acc.numel() <= self.MAX_DOUBLES
+        assert local_out is None or (local_out.dtype == torch.float64 and local_out.is_contiguous() and local_out.numel() == acc.numel())
         lib.call("ud_xchg_allreduce", K._p(acc), acc.numel(), K._p(self.peers), self.rank, self.world, self.MAX_DOUBLES,
-                 self.SLOTS, K._p(self.seq), K._p(self.err), int(self._timeout_s * 1000), K._stream())
+                 self.SLOTS, K._p(self.seq), K._p(self.err), int(self._timeout_s * 1000), K._p(local_out), K._stream())
 
     def check(self):
         """Host-side check (synchronises): a rank that timed out waiting for a peer raises here.  The engine calls it at

@@ -2455,7 +2455,7 @@ def colstats(x2, acc, G=1, R=None):
     h = _act(x2)
     Cc = x2.shape[-1]
     R = x2.numel() // (G * Cc) if R is None else R
-    _call("ud_colstats", _p(x2), G, R, Cc, _pd(acc), _pd(acc, G * Cc), _fused_ws(x2, G, R, Cc, True), h, _stream())
+    _call("ud_colstats", _p(x2), G, R, Cc, _pd(acc), _pd(acc, G * Cc), _fused_ws(x2, G, R, Cc, G != 1), h, _stream())
 
 
 def colsum_bn(x, bn, G, R, out, update=False):

@@ -224,7 +224,7 @@ _SIGNATURES = {
     "ud_xchg_open": [_P, _P],
     "ud_xchg_close": [_P],
     "ud_xchg_destroy": [_P],
-    "ud_xchg_allreduce": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _L, _P],
+    "ud_xchg_allreduce": [_P, _I, _P, _I, _I, _I, _I, _P, _P, _L, _P, _P],
 }
 
 # helpers that return a count rather than a status code

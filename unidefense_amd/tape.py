@@ -57,7 +57,9 @@ class Tape:
             self.grads[k] = g
             self._keep.append(t)
         else:
-            self.grads[k] = K.axpby(cur, 1.0, g.reshape(cur.shape), 1.0)
+            s = K.axpby(cur, 1.0, g.reshape(cur.shape), 1.0)
+            s._ud_owned = True          # a fresh tensor only the tape holds: its consumer may accumulate onto it in place
+            self.grads[k] = s
 
     def pop_grad(self, t: torch.Tensor) -> Optional[torch.Tensor]:
         g = self.grads.pop(id(t), None)
@@ -1041,13 +1043,15 @@ class DataParallelCtx:
         """Sum `acc` over the ranks in place; returns this rank's own sums (a copy) when keep_local, else None."""
         if not self.synced:
             return None
-        loc = acc.clone() if keep_local else None
+        via_exchange = self.exchange is not None and acc.numel() <= self.exchange.MAX_DOUBLES
+        # the rank's own sums: written by the exchange kernel itself (round 6; a clone launch per BatchNorm backward before)
+        loc = (torch.empty_like(acc) if via_exchange else acc.clone()) if keep_local else None
         prof = DP_PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.exchange is not None and acc.numel() <= self.exchange.MAX_DOUBLES:
-            self.exchange.allreduce(acc)
+        if via_exchange:
+            self.exchange.allreduce(acc, loc)
         else:
             import torch.distributed as dist
             dist.all_reduce(acc, group=self.group)
