@@ -156,7 +156,10 @@ int ud_gemm_p3(const ud_gemm_p3_desc* d, ud_stream_t stream);
  * 1x1 conv — prec 2, out_mode 0 / 1 / 2, split_k >= 1, no stream-K form, no epilogue statistics.  The weight gradient's workgroups
  * follow the data gradient's in the same grid, so they start on the CUs the data gradient's last round of tiles leaves idle
  * (540 + 225 tiles on 256 CUs: 3 rounds instead of 3 + 1); tn->tile_cfg bit 16 (0x10000): the weight gradient's workgroups lead
- * the grid instead (few long tiles: the pair's critical path).  Results are those of two ud_gemm_p3 calls. */
+ * the grid instead (few long tiles: the pair's critical path).  Results are those of two ud_gemm_p3 calls.
+ * Round 6, the TAIL PAIR of one forward product (both descriptors a_mode 0, b_mode 0, prec 2): `nn` = the leading row tiles of
+ * y = x w^T that fill whole rounds of the CUs (plain), `tn` = the remaining row tiles (A / C advanced to their first row) split
+ * over K with atomics onto zeroed rows — their short workgroups fill what the plain part's last round leaves idle. */
 int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc* tn, ud_stream_t stream);
 /* A half-stored matrix X[R][C] (row stride ld elements, C % 8 == 0, 16-byte aligned) as ONE fp16 plane in the P32 layout, values
  * unchanged (*inv_scale = 1): the operand of ud_gemm_p3 prec 1 for the activations of the mixed-precision mode (BASELINE

@@ -523,7 +523,11 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_kernel(const ud_gemm_p3_desc d,
 // [0, n0) = problem 0 (tile, split-K slice) pairs, the rest problem 1; the dispatcher hands them out in order, so problem 1 starts on
 // the CUs problem 0's last round leaves free.  Each problem keeps its own XCD-aware raster over its LOCAL index (the hardware XCD
 // is (local + n0) % 8: the ranges stay contiguous per XCD, rotated).
-template <int PREC>
+// Round 6: the operand modes of the two problems are template parameters.  <0, 1, 1, 1>: data + weight gradient (round 5).
+// <0, 0, 0, 0>: the TAIL PAIR of one forward product — problem 0 the leading row tiles that fill whole rounds of the CUs as plain
+// tiles, problem 1 the last row tiles split over K (atomics onto zeroed rows) whose short workgroups fill what problem 0's last
+// round leaves free: 540 tiles on 256 CUs are 2.1 rounds instead of 3, in ONE launch (the "tail" plan needed two + a fill).
+template <int PREC, int A0 = 0, int B0 = 1, int A1 = 1, int B1 = 1>
 __global__ __launch_bounds__(NT, 1) void gemm_p3_pair_kernel(const ud_gemm_p3_desc d0, int tm0, int tn0, int n0,
                                                               const ud_gemm_p3_desc d1, int tm1, int tn1) {
     using CF = Cfg<PREC>;
@@ -534,10 +538,10 @@ __global__ __launch_bounds__(NT, 1) void gemm_p3_pair_kernel(const ud_gemm_p3_de
     const int l = first ? b : b - (n0 < 0 ? -n0 : n0);
     if (first == (n0 > 0)) {
         const int T = tm0 * tn0;
-        p3_body<PREC, 0, 1, false>(d0, tm0, tn0, L, l % T, l / T, T);
+        p3_body<PREC, A0, B0, false>(d0, tm0, tn0, L, l % T, l / T, T);
     } else {
         const int T = tm1 * tn1;
-        p3_body<PREC, 1, 1, false>(d1, tm1, tn1, L, l % T, l / T, T);
+        p3_body<PREC, A1, B1, false>(d1, tm1, tn1, L, l % T, l / T, T);
     }
 }
 
@@ -1001,7 +1005,9 @@ static bool p3_desc_ok(const ud_gemm_p3_desc& d);
 extern "C" int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc* tn, ud_stream_t stream) {
     if (!nn || !tn || !p3_desc_ok(*nn) || !p3_desc_ok(*tn)) return UD_EINVAL;
     const ud_gemm_p3_desc &d0 = *nn, &d1 = *tn;
-    if ((d0.prec != 2 && d0.prec != 1) || d1.prec != d0.prec || d0.a_mode != 0 || d0.b_mode != 1 || d1.a_mode != 1 || d1.b_mode != 1) return UD_EINVAL;
+    const bool grads = d0.a_mode == 0 && d0.b_mode == 1 && d1.a_mode == 1 && d1.b_mode == 1;          // data + weight gradient
+    const bool tailp = d0.a_mode == 0 && d0.b_mode == 0 && d1.a_mode == 0 && d1.b_mode == 0 && d0.prec == 2;      // tail pair of a forward product
+    if ((d0.prec != 2 && d0.prec != 1) || d1.prec != d0.prec || !(grads || tailp)) return UD_EINVAL;
     if ((d0.tile_cfg | d1.tile_cfg) & 0x800) return UD_EINVAL;          // no stream-K form
     if (d0.stat_sum || d1.stat_sum || d0.out_mode == 3 || d1.out_mode == 3) return UD_EINVAL;
     const int tm0 = ud_cdiv(d0.M, BM), tn0 = ud_cdiv(d0.N, BN), tm1 = ud_cdiv(d1.M, BM), tn1 = ud_cdiv(d1.N, BN);
@@ -1010,7 +1016,10 @@ extern "C" int ud_gemm_p3_pair(const ud_gemm_p3_desc* nn, const ud_gemm_p3_desc*
     // tile_cfg bit 16 of the weight gradient's descriptor: ITS workgroups go first (a long-K weight gradient with few tiles is the
     // pair's critical path: started first, the data gradient's many short tiles fill in around it)
     const int nfirst = (d1.tile_cfg & 0x10000) ? -(int)n1 : (int)n0;
-    if (d0.prec == 1)
+    if (tailp)
+        hipLaunchKernelGGL((gemm_p3_pair_kernel<2, 0, 0, 0, 0>), dim3((unsigned)(n0 + n1)), dim3(NT), 0, (hipStream_t)stream, d0, tm0,
+                           tn0, nfirst, d1, tm1, tn1);
+    else if (d0.prec == 1)
         hipLaunchKernelGGL((gemm_p3_pair_kernel<1>), dim3((unsigned)(n0 + n1)), dim3(NT), 0, (hipStream_t)stream, d0, tm0, tn0,
                            nfirst, d1, tm1, tn1);
     else

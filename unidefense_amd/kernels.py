@@ -964,9 +964,35 @@ def _p2_plans(kind, M, N, K):
         tp = _tail_plan(M, N, K)
         if tp is not None:
             out.append(("tail", tp[0], tp[1]))
+        if kind == "nt" and not CFG.deterministic:
+            out += [("tailp", m1, s_) for m1, s_ in _tailp_plans(M, N, K)]
     if not CFG.deterministic:
         out.append(("sk",))
     return out or [("plain",)]
+
+
+_TAILP = True          # A/B: tools/run_with.py kernels._TAILP=False
+
+
+def _tailp_plans(M, N, K):
+    """the tail PAIR of a forward product (ud_gemm_p3_pair, round 6): (rows of the plain part, split-K of the remaining row tiles)
+    candidates — the row tiles beyond whole rounds of the 256 CUs go out in the SAME grid as short split-K workgroups"""
+    if not _TAILP or M < 256 or N < 128 or K < 256:
+        return []
+    mt, nt = -(-M // 128), -(-N // 128)
+    full, tail = divmod(mt * nt, 256)
+    if full < 1 or tail == 0:
+        return []
+    out = []
+    for extra in (0, 1):                                  # one more row tile in the tail: the plain part just UNDER whole rounds
+        rows_tail = -(-tail // nt) + extra
+        tail_tiles = rows_tail * nt
+        if rows_tail >= mt or tail_tiles > 224:
+            continue
+        for s_ in sorted({max(2, min(16, 256 // tail_tiles)), max(2, min(16, 512 // tail_tiles))}):
+            if K // 32 // s_ >= 4:
+                out.append(((mt - rows_tail) * 128, s_))
+    return out
 
 
 def _p2_run(kind, plan, ap, bp, M, N, K, like, stats=None, out=None):
@@ -976,6 +1002,8 @@ def _p2_run(kind, plan, ap, bp, M, N, K, like, stats=None, out=None):
     am, bm = _P2_MODES[kind]
     Kp = -(-K // 32) * 32                      # the operands' zero padding makes up the last K-tile
     how = plan[0]
+    if how == "tailp" and GEMM_PROFILE is not None:
+        how = "tail"          # the instrumented steps time every product through _gemm_p3: the same two problems as two launches
     acc = out is not None
     assert not (acc and stats is not None)
     # the mixed-precision mode (prec-1 operands of half-stored activations): activations come out half-stored too, weight
@@ -989,6 +1017,17 @@ def _p2_run(kind, plan, ap, bp, M, N, K, like, stats=None, out=None):
         res = _gemm_p3(ap, bp, out if acc else split_out((M, N), like), M, N, Kp, am, bm, 2, int(plan[1]))
     elif how == "sk":
         res = _gemm_p3(ap, bp, out if acc else zeros((M, N), like), M, N, Kp, am, bm, 1 if acc else 0, 1, cfg=0x800)
+    elif how == "tailp":
+        # the tail pair (nt): plain leading row tiles + split-K last row tiles as ONE grid (ud_gemm_p3_pair)
+        m1, s_ = int(plan[1]), int(plan[2])
+        assert kind == "nt" and stats is None
+        res = out if acc else empty((M, N), like)
+        tail = res[m1:]
+        if not acc:
+            tail.zero_()
+        d0 = _p3_desc(ap, bp, res, m1, N, Kp, am, bm, 1 if acc else 0, 1)
+        d1 = _p3_desc(ap, bp, tail, M - m1, N, Kp, am, bm, 2, s_, a_row0=m1)
+        _call("ud_gemm_p3_pair", C.byref(d0), C.byref(d1), _stream())
     else:
         m1, s_ = int(plan[1]), int(plan[2])          # "tail" (nt / nn): whole rounds of tiles plain, the last row tiles split
         res = out if acc else empty((M, N), like)
