@@ -382,8 +382,21 @@ _DW_FUSED_ADD = True
 _DW_TILED = True
 
 
+# per-shape overrides of the two depthwise policies below, {(sf, k, stride, H, half): value}: measured IN the replayed step by
+# tools/tune_in_step.py --knobs (the rules come from per-kernel timings); empty = the rules
+_DW_TILE_OVERRIDE = {}
+_DW_BWD_FUSED_OVERRIDE = {}
+
+
 def _dw_tile_policy(sf, k, stride, H, half):
     """(forward, weight gradient, data gradient) on the tiled kernels?"""
+    ov = _DW_TILE_OVERRIDE.get((bool(sf), k, stride, H, bool(half)))
+    if ov is not None and _DW_TILED:
+        return ov
+    return _dw_tile_rule(sf, k, stride, H, half)
+
+
+def _dw_tile_rule(sf, k, stride, H, half):
     if not _DW_TILED:
         return False, False, False
     if stride == 2:
@@ -416,6 +429,9 @@ def _dw_bwd_fused_policy(sf, k, stride, H, half):
     163 -> 156, 73 -> 71; a tie at 16^2 k5 and 8^2 k3, 72 vs 96 at 8^2 k5."""
     if not _DW_BWD_FUSED or stride != 1:
         return False
+    ov = _DW_BWD_FUSED_OVERRIDE.get((bool(sf), k, stride, H, bool(half)))
+    if ov is not None:
+        return ov
     if H <= 8:
         return k == 3 and not half
     if half:
