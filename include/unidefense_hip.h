@@ -553,6 +553,21 @@ int ud_normbwd_apply_planes(const float* x, const float* dy, const float* keep, 
                             const double* s2_local, const double* energy, int G, int R, int C, uint16_t* planes,
                             long panel_stride, long plane_stride, float* inv_scale, float* dgamma, float* dbeta,
                             ud_stream_t stream);
+/* Backward of a THIN expand 1x1 conv (model/efficientnet/model.py:101-109: _expand_conv + _bn0 of the 128 x 128 / 64 x 64 blocks) in
+ * ONE pass over its two big tensors: ud_normbwd_apply (dy_is_dz = 1) + the conv's weight gradient + its data gradient —
+ *     de = gamma invstd (dz - s1 / count - xhat s2 / count)   formed in registers from (dz, e), never written
+ *     dw[CE][CIN] = de^T x        dx[M][CIN] = de w (+ add; add may alias dx)
+ * with gemm_x3's arithmetic (exact three-way bf16 split, six piece products, fp32 accumulation).  (CE, CIN) must be a pair
+ * ud_pw_bwd_fused_ok accepts; part: ud_pw_bwd_fused_grid(M) * CE * CIN floats of scratch (one weight-gradient partial per workgroup,
+ * folded in workgroup order: bit-reproducible).  dgamma / dbeta (optional) from this rank's sums, as ud_normbwd_apply. */
+int ud_pw_bwd_fused_ok(int CE, int CIN);
+/* launch form of ud_pw_bwd_fused (kernel bench, tools/bench_pwbwd.py): 0 the shipped form per shape; 1..4 = (tiles of loads in flight
+ * per thread, workgroups per CU) in (1, 2), (2, 2), (3, 1), (4, 1) */
+int ud_pw_bwd_set_form(int form);
+long ud_pw_bwd_fused_grid(long M);
+int ud_pw_bwd_fused(const float* e, const float* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
+                    const double* s1_local, const double* s2_local, const float* x, const float* w, const float* add, long M,
+                    int CE, int CIN, float* dx, float* dw, float* part, float* dgamma, float* dbeta, ud_stream_t stream);
 /* Half storage (the mixed-precision mode): ud_normbwd_apply whose half result is laid straight into the ONE fp16 plane (P32 layout,
  * scale 1) that ud_gemm_p3 prec 1 reads — the row-major tensor and the ud_planes_from_half pass over it are not needed. */
 int ud_normbwd_apply_plane_half(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,

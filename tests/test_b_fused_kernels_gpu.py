@@ -933,3 +933,58 @@ def test_residual_bn_writes_the_next_expand_planes(N, HW, Cc, skip, keep_p):
     assert within("residual planes: bound / exact maximum", loose, 256.0) and loose >= 1.0, loose
     assert within("residual planes: re-assembled error / (2^-21 scale)", float(((h[0] + h[1] / 2048.0) * inv - yd).abs().max()) /
                   (2.0 ** -21 * top * loose), 1.0)
+
+
+@pytest.mark.parametrize("M,Ce,Cin,with_add", [(32 * 40, 144, 24, False), (32 * 7 + 5, 144, 24, True), (3001, 192, 32, True),
+                                                (32 * 600 + 17, 192, 32, False), (131072, 144, 24, True)])
+def test_expand_conv_backward_in_one_pass(M, Ce, Cin, with_add):
+    """ud_pw_bwd_fused (round 6): BatchNorm-0 backward applied on load + the thin expand conv's weight and data gradient from one
+    LDS image, against float64 (model/efficientnet/model.py:101-109 differentiated) and against the three launches it replaces
+    (ud_normbwd_apply + gemm_tn + gemm_nn).  Ragged row counts (a last tile of 5 / 25 / 17 rows), fewer tiles than workgroups and
+    more (the strided tile loop), with and without the skip path's gradient added in place."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(M % 1000 + Ce)
+    x = torch.randn(M, Cin, generator=g).to(dev)
+    w = (torch.randn(Ce, Cin, generator=g) / Cin ** 0.5).to(dev)
+    e = (x @ w.t()).contiguous()
+    dz = (torch.randn(M, Ce, generator=g) * (0.2 + torch.rand(Ce, generator=g))).to(dev)
+    gamma, beta = (1.0 + 0.3 * torch.randn(Ce, generator=g)).to(dev), (0.2 * torch.randn(Ce, generator=g)).to(dev)
+    skip = torch.randn(M, Cin, generator=g).to(dev) if with_add else None
+    acc = K.zeros64(2 * Ce, x)
+    K.colstats(e, acc)
+    bn = K.DeferredBN(acc, Ce, M, gamma, beta, 1e-3, 1)
+    sb = K.zeros64(2 * Ce, x)
+    K.normbwd_sums(e.view(1, M, Ce), dz.view(1, M, Ce), None, 1.0, bn, True, 1, M, sb)
+    assert K.expand_bwd_fused_ok(e, w, True) and not K.expand_bwd_fused_ok(e, w, False)
+    # the three launches
+    de, dg_ref, db_ref = K.normbwd_apply(e.view(1, M, Ce), dz.view(1, M, Ce), None, 1.0, bn, True, 1, M, sb)
+    dw_ref = K.gemm_tn(de.view(M, Ce), x)
+    dx_ref = K.gemm_nn(de.view(M, Ce), w)
+    if with_add:
+        dx_ref = dx_ref + skip
+    add = skip.clone() if with_add else None
+    dx, dw, dg, db = K.expand_bwd_fused(e, dz, bn, sb, None, x, w, add=add)
+    if with_add:
+        assert dx.data_ptr() == add.data_ptr()
+    # float64
+    ed, dzd = e.double(), dz.double()
+    mean, var = ed.mean(0), ed.var(0, unbiased=False)
+    inv = 1.0 / torch.sqrt(var + 1e-3)
+    xh = (ed - mean) * inv
+    ded = gamma.double() * inv * (dzd - dzd.mean(0) - xh * (dzd * xh).mean(0))
+    dw64 = ded.t() @ x.double()
+    dx64 = ded @ w.double()
+    if with_add:
+        dx64 = dx64 + skip.double()
+    torch.cuda.synchronize()
+    r_dx, r_dw = _rel(dx, dx64), _rel(dw, dw64)
+    r_dx0, r_dw0 = _rel(dx_ref, dx64), _rel(dw_ref, dw64)
+    assert within("pw_bwd dx vs float64", r_dx, max(2e-6, 2 * r_dx0))
+    assert within("pw_bwd dw vs float64", r_dw, max(2e-6, 2 * r_dw0))
+    assert _rel(dg, dg_ref) < 1e-6 and _rel(db, db_ref) < 1e-6
+    # bit-reproducible (partials folded in workgroup order)
+    add2 = skip.clone() if with_add else None
+    dx2, dw2, _, _ = K.expand_bwd_fused(e, dz, bn, sb, None, x, w, add=add2)
+    assert torch.equal(dx2, dx) and torch.equal(dw2, dw)

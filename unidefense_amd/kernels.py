@@ -2657,6 +2657,34 @@ def normbwd_apply(x, dy, keep, inv_keep, bn, dy_is_dz, G, R, sacc, sacc_local=No
     return dx, dg, db
 
 
+def expand_bwd_fused_ok(e, w2, dy_is_dz):
+    """does ud_pw_bwd_fused take this expand conv's backward (fp32 storage, a thin (Ce, Cin) pair it is built for)?"""
+    return (CFG.expand_bwd_fused and e.dtype == torch.float32 and bool(dy_is_dz) and w2.dtype == torch.float32 and
+            _lib.call("ud_pw_bwd_fused_ok", int(w2.shape[0]), int(w2.shape[1])) == 1)
+
+
+def expand_bwd_fused(e, dz, bn, sacc, sacc_local, x2, w2, add=None):
+    """BatchNorm-0 backward + the expand conv's weight and data gradient in one pass over (dz, e): returns (dx, dw, dgamma, dbeta).
+    e, dz: [.., Ce] (M rows); x2 [M, Cin]; w2 [Ce, Cin]; add: a term of dx to add onto IN PLACE (dx is add then), or None."""
+    _chk(e, dz, x2, w2)
+    Ce, Cin = w2.shape
+    M = x2.shape[0]
+    assert e.numel() == M * Ce and dz.numel() == M * Ce and x2.is_contiguous() and w2.is_contiguous()
+    loc = sacc if sacc_local is None else sacc_local
+    dx = add if add is not None else torch.empty_like(x2)
+    if add is not None:
+        _chk(add)
+        assert add.numel() == M * Cin
+    dw = empty((Ce, Cin), x2)
+    dg = empty((Ce,), x2)
+    db = empty((Ce,), x2)
+    grid = _lib.call("ud_pw_bwd_fused_grid", M)
+    part = empty((grid, Ce * Cin), x2)
+    _call("ud_pw_bwd_fused", _p(e), _p(dz), C.byref(bn.ref()), _pd(sacc), _pd(sacc, Ce), _pd(loc), _pd(loc, Ce), _p(x2), _p(w2),
+          _p(add), M, Ce, Cin, _p(dx), _p(dw), _p(part), _p(dg), _p(db), _stream())
+    return dx, dw, dg, db
+
+
 def normbwd_apply_mix(x, dz, bn, G, R, sacc, diff, dalpha_acc, sacc_local=None, energy=None):
     """diff = freq - spat (irfft2_mix).  energy: C zeroed doubles that receive sum_rows dd^2 per channel (rfft2_ex_planes' bound)."""
     h = _act(x, dz, diff)

@@ -1406,6 +1406,19 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None, next_blk=N
             loc0 = dp.reduce(sb0, keep_local=True)
             if not de_pl and x.dtype == torch.float16 and sp.expand != 1 and K.normbwd_planes_ok(e, ectx) == 2:
                 de_pl = 2          # half storage: the plane needs no bound, whichever kernel produced dz0
+            if not de_pl and sp.expand != 1 and ectx.plans is None and K.expand_bwd_fused_ok(e, ectx.w, is_dz):
+                # thin expand conv (the 128 x 128 / 64 x 64 blocks): BatchNorm backward + both gradients in ONE pass over (dz0, e)
+                add = dout.view(M, Cin) if (sp.skip and tape.watch is None and getattr(dout, "_ud_owned", False)) else None
+                dx, dWe, dg0, db0 = K.expand_bwd_fused(e, dz0, bn0, sb0, loc0, ectx.x, ectx.w, add=add)
+                dx = dx.view(x.shape)
+                if sp.skip and add is None:
+                    dx = K.axpby(dx, 1.0, dout, 1.0, out=dx)
+                tape.add_param_grad(blk._bn0.weight, dg0)
+                tape.add_param_grad(blk._bn0.bias, db0)
+                tape.add_param_grad(blk._expand_conv.weight, dWe)
+                dx._ud_owned = True
+                tape.add_grad(x, dx)
+                return
             if de_pl:
                 ectx.dy, dg0, db0 = K.normbwd_apply_planes(e, dz0, None, 1.0, bn0, is_dz, 1, M, sb0, loc0)
                 de2, de_amax = (dz0 if de_pl == 2 else ectx.w.buf), None
