@@ -568,6 +568,22 @@ long ud_pw_bwd_fused_grid(long M);
 int ud_pw_bwd_fused(const float* e, const float* dz, const ud_bn_ref* bn, const double* s1, const double* s2,
                     const double* s1_local, const double* s2_local, const float* x, const float* w, const float* add, long M,
                     int CE, int CIN, float* dx, float* dw, float* part, float* dgamma, float* dbeta, ud_stream_t stream);
+/* Backward of a THIN project 1x1 conv and the squeeze-excite gate in front of it (model/efficientnet/model.py:113-126 of the 64 x 64
+ * blocks: c = swish(bn1(d)) sigmoid(s), p = c Wp^T) WITHOUT the conv's data gradient dc = dp Wp ever written: a 32-row tile of dc is
+ * re-made from the thin dp [N HW][CO] inside each of the two passes over d that need it —
+ *   ud_pj_bwd_fused_a:  dw[CO][CE] = dp^T c  (c re-made from d on load, as ud_se_scale_bn makes it)   and
+ *                       dgate[n][ch] += sum_hw dc act(bn1(d))   (ud_coldot_bn's result; dgate zeroed by the caller);
+ *                       part: ud_pj_bwd_fused_grid(N, HW) * CO * CE floats of scratch (partials folded in a fixed order);
+ *   ud_pj_bwd_fused_b:  dz = (dc sigmoid(s) + dpool inv_hw) act'(bn1(d)),  s1[ch] += sum dz, s2[ch] += sum dz xhat
+ *                       (ud_se_scale_bwd_bn's results).
+ * gemm_x3's arithmetic for the products.  (CE, CO, HW) must be a triple ud_pj_bwd_fused_ok accepts (HW % 32 == 0: a tile of rows
+ * belongs to one sample). */
+int ud_pj_bwd_fused_ok(int CE, int CO, int HW);
+long ud_pj_bwd_fused_grid(int N, int HW);
+int ud_pj_bwd_fused_a(const float* d, const float* dp, const ud_bn_ref* bn, const float* s, const float* w, int N, int HW, int CE,
+                      int CO, float* dw, double* dgate, float* part, ud_stream_t stream);
+int ud_pj_bwd_fused_b(const float* d, const float* dp, const ud_bn_ref* bn, const float* s, const float* dpool, float inv_hw,
+                      const float* w, int N, int HW, int CE, int CO, float* dz, double* s1, double* s2, ud_stream_t stream);
 /* Half storage (the mixed-precision mode): ud_normbwd_apply whose half result is laid straight into the ONE fp16 plane (P32 layout,
  * scale 1) that ud_gemm_p3 prec 1 reads — the row-major tensor and the ud_planes_from_half pass over it are not needed. */
 int ud_normbwd_apply_plane_half(const void* x, const void* dy, const float* keep, float inv_keep, const ud_bn_ref* bn,

@@ -988,3 +988,60 @@ def test_expand_conv_backward_in_one_pass(M, Ce, Cin, with_add):
     add2 = skip.clone() if with_add else None
     dx2, dw2, _, _ = K.expand_bwd_fused(e, dz, bn, sb, None, x, w, add=add2)
     assert torch.equal(dx2, dx) and torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize("N,HW,Ce,Co,act", [(2, 64, 144, 32, 1), (3, 32 * 9, 192, 32, 1), (5, 4096, 192, 32, 1), (32, 4096, 144, 32, 1),
+                                            (2, 96, 192, 32, 0)])
+def test_project_conv_backward_without_its_data_gradient(N, HW, Ce, Co, act):
+    """ud_pj_bwd_fused_a / _b (round 6): the thin project conv's backward with dc = dp Wp re-made per 32-row tile inside the two
+    passes over d — weight gradient + SE dot; gate / swish backward + BatchNorm-1 sums — against float64
+    (model/efficientnet/model.py:113-126 differentiated) and against the four launches they replace (gemm_tn, gemm_nn,
+    ud_coldot_bn, ud_se_scale_bwd_bn).  One sample per workgroup chunk and several, fewer tiles than workgroups and more."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N * 7 + HW + Ce)
+    M = N * HW
+    d = (torch.randn(N, HW, Ce, generator=g) * 1.3 + 0.2).to(dev)
+    w = (torch.randn(Co, Ce, generator=g) / Ce ** 0.5).to(dev)
+    dp = (torch.randn(M, Co, generator=g) * (0.3 + torch.rand(Co, generator=g))).to(dev)
+    s = torch.randn(N, Ce, generator=g).to(dev)
+    dpool = torch.randn(N, Ce, generator=g).to(dev)
+    gamma, beta = (1.0 + 0.3 * torch.randn(Ce, generator=g)).to(dev), (0.2 * torch.randn(Ce, generator=g)).to(dev)
+    acc = K.zeros64(2 * Ce, d)
+    K.colstats(d.view(M, Ce), acc)
+    bn = K.DeferredBN(acc, Ce, M, gamma, beta, 1e-3, act)
+    assert K.project_bwd_fused_ok(d, w, HW) and not K.project_bwd_fused_ok(d, w, HW + 4)
+    # the launches they replace
+    c = K.se_scale_bn(d, bn, s, N, HW)
+    dw_ref = K.gemm_tn(dp, c.view(M, Ce))
+    dc = K.gemm_nn(dp, w).view(N, HW, Ce)
+    dg_ref = K.zeros64(N * Ce, d)
+    K.coldot_bn(dc, d, bn, N, HW, dg_ref)
+    sb_ref = K.zeros64(2 * Ce, d)
+    dz_ref = K.se_scale_bwd_bn(dc, d, bn, s, dpool, 1.0 / HW, N, HW, sb_ref)
+    # one pass each
+    dgate = K.zeros64(N * Ce, d)
+    dw = K.project_bwd_fused_a(d, bn, s, dp, w, N, HW, dgate)
+    sb = K.zeros64(2 * Ce, d)
+    dz = K.project_bwd_fused_b(d, bn, s, dpool, 1.0 / HW, dp, w, N, HW, sb)
+    # float64
+    dd = d.double()
+    mean, var = dd.mean((0, 1)), dd.var((0, 1), unbiased=False)
+    xh = (dd - mean) / torch.sqrt(var + 1e-3)
+    z = gamma.double() * xh + beta.double()
+    sg = torch.sigmoid(z)
+    a = z * sg if act else z
+    da = sg * (1 + z * (1 - sg)) if act else torch.ones_like(z)
+    gate = torch.sigmoid(s.double()).view(N, 1, Ce)
+    c64 = (a * gate).view(M, Ce)
+    dc64 = (dp.double() @ w.double()).view(N, HW, Ce)
+    dw64 = dp.double().t() @ c64
+    dg64 = (dc64 * a).sum(1).view(-1)
+    dz64 = (dc64 * gate + dpool.double().view(N, 1, Ce) / HW) * da
+    s164, s264 = dz64.sum((0, 1)), (dz64 * xh).sum((0, 1))
+    torch.cuda.synchronize()
+    for name, got, ref, want in (("dw", dw, dw_ref, dw64), ("dgate", dgate, dg_ref, dg64), ("dz", dz, dz_ref, dz64),
+                                 ("s1", sb[:Ce], sb_ref[:Ce], s164), ("s2", sb[Ce:], sb_ref[Ce:], s264)):
+        r, r0 = _rel(got, want), _rel(ref, want)
+        assert within("pj_bwd %s vs float64" % name, r, max(3e-6, 2 * r0)), (name, r, r0)

@@ -13,7 +13,7 @@
 // in registers as bf16 fragments for the whole kernel; the weight gradient accumulates in registers over all the workgroup's tiles
 // and leaves one partial per workgroup, folded in a fixed order by pw_bwd_fold_kernel (deterministic by construction).
 // Arithmetic = gemm_x3's: six piece products of order <= 2^-16 per k-step on v_mfma_f32_16x16x32_bf16, fp32 accumulation.
-#include "ud_common.h"
+#include "pw_common.h"
 
 #include <type_traits>
 
@@ -22,26 +22,7 @@ namespace {
 constexpr int NTH = 256;          // 4 waves
 constexpr int R = 32;             // rows per tile = the k of one weight-gradient MFMA
 
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) char lds_char;
-
-__device__ __forceinline__ uint32_t pack_bf16(float x, float y) {
-    bf16x2v v = {(__bf16)x, (__bf16)y};
-    return __builtin_bit_cast(uint32_t, v);
-}
-// exact three-way split of two floats (gemm_x3.hip: split2); p[i] packs piece i of (x, y)
-__device__ __forceinline__ void split2(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    p0 = pack_bf16(x, y);
-    const float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
-    p1 = pack_bf16(rx, ry);
-    const float sx = rx - __uint_as_float(p1 << 16), sy = ry - __uint_as_float(p1 & 0xffff0000u);
-    p2 = pack_bf16(sx, sy);
-}
+using namespace pw;
 
 template <int CE, int CIN> struct PwCfg {
     static_assert(CE % 16 == 0 && CIN % 8 == 0 && CIN > 16 && CIN <= 32, "thin expand convs: 16 < CIN <= 32");
@@ -372,6 +353,14 @@ int g_pw_form = 0;          // tools/bench_pwbwd.py: 0 the shipped form per shap
 
 }  // namespace
 
+int pw::fold_launch(const float* part, int nparts, int numel, float* dw, const double* s1l, const double* s2l, int CE, float* dgamma,
+                    float* dbeta, hipStream_t s) {
+    hipLaunchKernelGGL(pw_bwd_fold_kernel, dim3((unsigned)ud_cdiv(numel, 16)), dim3(256), 0, s, part, nparts, numel, dw, s1l, s2l, CE,
+                       dgamma, dbeta);
+    UD_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" {
 
 int ud_pw_bwd_set_form(int form) {
@@ -411,11 +400,7 @@ int ud_pw_bwd_fused(const float* e, const float* dz, const ud_bn_ref* bn, const 
            : form == 3 ? launch<192, 32, 3, 1>(a, grid, s) : launch<192, 32, 4, 1>(a, grid, s);
     if (rc) return rc;
     UD_LAUNCH_CHECK();
-    const int numel = CE * CIN;
-    hipLaunchKernelGGL(pw_bwd_fold_kernel, dim3((unsigned)ud_cdiv(numel, 16)), dim3(256), 0, s, part, grid, numel, dw, s1_local, s2_local,
-                       CE, dgamma, dbeta);
-    UD_LAUNCH_CHECK();
-    return 0;
+    return pw::fold_launch(part, grid, CE * CIN, dw, s1_local, s2_local, CE, dgamma, dbeta, s);
 }
 
 }  // extern "C"

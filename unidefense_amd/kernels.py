@@ -2685,6 +2685,36 @@ def expand_bwd_fused(e, dz, bn, sacc, sacc_local, x2, w2, add=None):
     return dx, dw, dg, db
 
 
+def project_bwd_fused_ok(d, w2, HW):
+    """do ud_pj_bwd_fused_a / _b take this project conv's backward (fp32 storage, a thin (Ce, Co) pair they are built for, whole
+    32-row tiles per sample)?"""
+    return (CFG.project_bwd_fused and d.dtype == torch.float32 and w2.dtype == torch.float32 and
+            _lib.call("ud_pj_bwd_fused_ok", int(w2.shape[1]), int(w2.shape[0]), int(HW)) == 1)
+
+
+def project_bwd_fused_a(d, bn, s, dp2, w2, N, HW, dgate):
+    """dw[Co, Ce] = dp^T (act(bn(d)) sigmoid(s)) and dgate[N, Ce] (fp64, zeroed by the caller) += sum_hw (dp w) act(bn(d)) in one
+    pass over d [N, .., Ce]; dp2 [N HW, Co]; w2 [Co, Ce]; s [N, Ce]."""
+    _chk(d, dp2, w2, s)
+    Co, Ce = w2.shape
+    assert d.numel() == N * HW * Ce and dp2.numel() == N * HW * Co and s.numel() == N * Ce and dp2.is_contiguous()
+    dw = empty((Co, Ce), d)
+    grid = _lib.call("ud_pj_bwd_fused_grid", N, HW)
+    part = empty((grid, Co * Ce), d)
+    _call("ud_pj_bwd_fused_a", _p(d), _p(dp2), C.byref(bn.ref()), _p(s), _p(w2), N, HW, Ce, Co, _p(dw), _pd(dgate), _p(part), _stream())
+    return dw
+
+
+def project_bwd_fused_b(d, bn, s, dpool, inv_hw, dp2, w2, N, HW, sacc):
+    """dz = ((dp w) sigmoid(s) + dpool inv_hw) act'(bn(d)) [like d]; sacc (fp64 [2 Ce]) += sum dz, sum dz xhat"""
+    _chk(d, dp2, w2, s, dpool)
+    Co, Ce = w2.shape
+    dz = torch.empty_like(d)
+    _call("ud_pj_bwd_fused_b", _p(d), _p(dp2), C.byref(bn.ref()), _p(s), _p(dpool), float(inv_hw), _p(w2), N, HW, Ce, Co, _p(dz),
+          _pd(sacc), _pd(sacc, Ce), _stream())
+    return dz
+
+
 def normbwd_apply_mix(x, dz, bn, G, R, sacc, diff, dalpha_acc, sacc_local=None, energy=None):
     """diff = freq - spat (irfft2_mix).  energy: C zeroed doubles that receive sum_rows dd^2 per channel (rfft2_ex_planes' bound)."""
     h = _act(x, dz, diff)

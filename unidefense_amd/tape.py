@@ -1299,12 +1299,18 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None, next_blk=N
             dp2, dp_amax = dp_.view(Mo, Co), getattr(dp_, "_ud_absmax", None)
         tape.add_param_grad(blk._bn2.weight, dg2)
         tape.add_param_grad(blk._bn2.bias, db2)
-        dc, dWp = K.spectral_bwd(pctx, dp2, dy_absmax=dp_amax)          # (one launch for both where that fills the chip better)
-        tape.add_param_grad(blk._project_conv.weight, dWp)
-        dc = dc.view(N, Ho, Wo, Ce)
-        # ---- squeeze-excite backward
+        # thin project conv (the 64 x 64 blocks): its data gradient dc is never written — each of the two passes over d that need it
+        # re-makes its tile from the thin dp (csrc/pjbwd.hip)
+        pj_fused = not dp_pl and pctx.plans is None and K.project_bwd_fused_ok(d, Wp, HWo)
         dgate = K.zeros64(N * Ce, x)
-        K.coldot_bn(dc, d, bn1, N, HWo, dgate)
+        if pj_fused:
+            dWp = K.project_bwd_fused_a(d, bn1, s2, dp2, Wp, N, HWo, dgate)
+        else:
+            dc, dWp = K.spectral_bwd(pctx, dp2, dy_absmax=dp_amax)          # (one launch for both where that fills the chip better)
+            dc = dc.view(N, Ho, Wo, Ce)
+            K.coldot_bn(dc, d, bn1, N, HWo, dgate)
+        tape.add_param_grad(blk._project_conv.weight, dWp)
+        # ---- squeeze-excite backward
         dpool, dWe2, dbe2, dWr, dbr = K.se_bwd(dgate, s2, s1, we2, wr2, pool, 1.0 / HWo)
         tape.add_param_grad(blk._se_expand.weight, dWe2)
         tape.add_param_grad(blk._se_expand.bias, dbe2)
@@ -1312,7 +1318,10 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None, next_blk=N
         tape.add_param_grad(blk._se_reduce.bias, dbr)
         # ---- gate + swish + BN1 backward sums in one pass
         sb1 = K.zeros64(2 * Ce, x)
-        dz1 = K.se_scale_bwd_bn(dc, d, bn1, s2, dpool, 1.0 / HWo, N, HWo, sb1)
+        if pj_fused:
+            dz1 = K.project_bwd_fused_b(d, bn1, s2, dpool, 1.0 / HWo, dp2, Wp, N, HWo, sb1)
+        else:
+            dz1 = K.se_scale_bwd_bn(dc, d, bn1, s2, dpool, 1.0 / HWo, N, HWo, sb1)
         loc1 = dp.reduce(sb1, keep_local=True)
         g_alpha, g_mode, da_f = None, 0, None
         if sf:
