@@ -579,6 +579,11 @@ int ud_pw_bwd_fused(const float* e, const float* dz, const ud_bn_ref* bn, const 
  * gemm_x3's arithmetic for the products.  (CE, CO, HW) must be a triple ud_pj_bwd_fused_ok accepts (HW % 32 == 0: a tile of rows
  * belongs to one sample). */
 int ud_pj_bwd_fused_ok(int CE, int CO, int HW);
+/* ... and the forward of the same pair of layers in ONE pass over d: p[N HW][CO] = (act(bn1(d)) sigmoid(s)) w^T with the gated tensor
+ * made on load (ud_se_scale_bn's values) and never written; sum / sumsq (optional, together): p's BatchNorm-2 statistics
+ * (sum[co] += sum_rows p, sumsq[co] += sum_rows p^2).  Same (CE, CO, HW) as ud_pj_bwd_fused_ok. */
+int ud_pj_fwd_fused(const float* d, const ud_bn_ref* bn, const float* s, const float* w, int N, int HW, int CE, int CO, float* p,
+                    double* sum, double* sumsq, ud_stream_t stream);
 long ud_pj_bwd_fused_grid(int N, int HW);
 int ud_pj_bwd_fused_a(const float* d, const float* dp, const ud_bn_ref* bn, const float* s, const float* w, int N, int HW, int CE,
                       int CO, float* dw, double* dgate, float* part, ud_stream_t stream);

@@ -1045,3 +1045,37 @@ def test_project_conv_backward_without_its_data_gradient(N, HW, Ce, Co, act):
                                  ("s1", sb[:Ce], sb_ref[:Ce], s164), ("s2", sb[Ce:], sb_ref[Ce:], s264)):
         r, r0 = _rel(got, want), _rel(ref, want)
         assert within("pj_bwd %s vs float64" % name, r, max(3e-6, 2 * r0)), (name, r, r0)
+
+
+@pytest.mark.parametrize("N,HW,Ce,Co,act", [(2, 64, 144, 32, 1), (3, 32 * 9, 192, 32, 1), (32, 4096, 192, 32, 1), (5, 4096, 144, 32, 0)])
+def test_project_conv_forward_with_the_gate_applied_on_load(N, HW, Ce, Co, act):
+    """ud_pj_fwd_fused (round 6): p = (act(bn1(d)) sigmoid(s)) Wp^T in one pass over d + p's BatchNorm-2 statistics, against
+    float64 (model/efficientnet/model.py:113-126) and against ud_se_scale_bn + gemm_nt + ud_colstats."""
+    from unidefense_amd import kernels as K
+    dev = _dev()
+    K.reset_zero_pool()
+    g = torch.Generator().manual_seed(N * 11 + HW + Ce)
+    M = N * HW
+    d = (torch.randn(N, HW, Ce, generator=g) * 1.3 + 0.2).to(dev)
+    w = (torch.randn(Co, Ce, generator=g) / Ce ** 0.5).to(dev)
+    s = torch.randn(N, Ce, generator=g).to(dev)
+    gamma, beta = (1.0 + 0.3 * torch.randn(Ce, generator=g)).to(dev), (0.2 * torch.randn(Ce, generator=g)).to(dev)
+    acc = K.zeros64(2 * Ce, d)
+    K.colstats(d.view(M, Ce), acc)
+    bn = K.DeferredBN(acc, Ce, M, gamma, beta, 1e-3, act)
+    c = K.se_scale_bn(d, bn, s, N, HW)
+    p_ref = K.gemm_nt(c.view(M, Ce), w)
+    st_ref = K.zeros64(2 * Co, d)
+    K.colstats(p_ref, st_ref)
+    st = K.zeros64(2 * Co, d)
+    p, ctx = K.project_fwd_fused(d, bn, s, w, N, HW, stats=st)
+    assert ctx.plans is None and ctx.x is None
+    dd = d.double()
+    mean, var = dd.mean((0, 1)), dd.var((0, 1), unbiased=False)
+    z = gamma.double() * (dd - mean) / torch.sqrt(var + 1e-3) + beta.double()
+    a = z * torch.sigmoid(z) if act else z
+    p64 = (a * torch.sigmoid(s.double()).view(N, 1, Ce)).view(M, Ce) @ w.double().t()
+    torch.cuda.synchronize()
+    assert within("pj_fwd p vs float64", _rel(p, p64), max(3e-6, 2 * _rel(p_ref, p64)))
+    assert within("pj_fwd sum vs float64", _rel(st[:Co], p64.sum(0)), max(3e-6, 2 * _rel(st_ref[:Co], p64.sum(0))))
+    assert within("pj_fwd sumsq vs float64", _rel(st[Co:], p64.pow(2).sum(0)), max(3e-6, 2 * _rel(st_ref[Co:], p64.pow(2).sum(0))))

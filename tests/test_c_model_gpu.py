@@ -36,7 +36,11 @@ FULL_RTOL = 2e-2
 # BN2 biases whose gradient is analytically zero (the block's output reaches nothing but BatchNorm-ed paths)
 # the N = 8 fixture's gate gradients on which the REFERENCE's own fp32 record is 3e-5 off the float64 value (5.5e-3): held to 1e-2
 # of the reference there and to the plain 1e-3 against float64 (test_train_grads_vs_oracle_elementwise_n8_plain_bound)
-N8_REF_FP32_NOISE = ("backbone._blocks.9._depthwise_conv.sf_coef",)
+# ... and blocks.23's gate gradient (1.085e-2): the reference's fp32 record sits 9.1e-6 (8.4e-4 of the value) from the float64 result —
+# measured twice against both: this path with the one-pass project forward 1.25e-5 from the record and 3.4e-6 from float64, without
+# it 6.9e-6 and 2.2e-6 (profiles/r06/pj_bwd_fused.txt) — so "1e-3 of the record" leaves 1.7e-6 around the true value.  It meets the
+# floored bound of this test (4e-4) and the plain 1e-3 against float64 (3.1e-4); the name only admits it to the purely relative check.
+N8_REF_FP32_NOISE = ("backbone._blocks.9._depthwise_conv.sf_coef", "backbone._blocks.23._depthwise_conv.sf_coef")
 STRUCT_ZERO_GRADS = {f"backbone._blocks.{i}._bn2.bias" for i in list(range(16)) + [30, 31]}
 # ... and the same biases in the stage whose output x_b4 also reaches the decoder / the triplet feature: still almost
 # entirely cancelled (reference norm 1e-4 against 1e-2 .. 1e+1 elsewhere)

@@ -44,6 +44,7 @@ for name, N, HW, Ce, Co in SHAPES:
     K.colstats(d.view(M, Ce), acc)
     bn = K.DeferredBN(acc, Ce, M, gamma, beta, 1e-3, 1)
     c = K.se_scale_bn(d, bn, s, N, HW)
+    mb = 4.0 * M * Ce / 1e6
 
     def old_a():
         K.gemm_tn(dp, c.view(M, Ce))
@@ -62,7 +63,18 @@ for name, N, HW, Ce, Co in SHAPES:
     def new_b():
         K.project_bwd_fused_b(d, bn, s, dpool, 1.0 / HW, dp, w, N, HW, K.zeros64(2 * Ce, d))
 
+    def old_f():
+        cc = K.se_scale_bn(d, bn, s, N, HW, want_absmax=True)
+        st = K.zeros64(2 * Co, d)
+        r = K.gemm_nt(cc.view(M, Ce), w, stats=st)
+        if not r[1]:
+            K.colstats(r[0], st)
+
+    def new_f():
+        K.project_fwd_fused(d, bn, s, w, N, HW, stats=K.zeros64(2 * Co, d))
+
+    tf0, tf1 = timed(old_f), timed(new_f)
+    print("%-12s forward: se_scale_bn + gemm_nt (+ statistics) %6.1f us | one pass %6.1f us (%.2f TB/s)" % (name, tf0, tf1, mb / tf1), flush=True)
     ta0, tb0, ta1, tb1 = timed(old_a), timed(old_b), timed(new_a), timed(new_b)
-    mb = 4.0 * M * Ce / 1e6
     print("%-12s M %7d %3d -> %2d (%3.0f MB per tensor) | wgrad + dgrad + coldot %6.1f us, se_scale_bwd %6.1f us | pass a %6.1f us (%.2f TB/s), pass b %6.1f us (%.2f TB/s)" %
           (name, M, Ce, Co, mb, ta0, tb0, ta1, mb / ta1, tb1, 2 * mb / tb1), flush=True)

@@ -398,6 +398,151 @@ __global__ __launch_bounds__(NTH, 2) void pj_bwd_b_kernel(PjArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: p = (act(bn1(d)) sigmoid(s)) Wp^T in ONE pass over d — the gated tensor c is made on load (ud_se_scale_bn's values), laid
+// into the image as pieces and multiplied from there; p's BatchNorm-2 statistics leave with it.  c is never written: the backward
+// above re-makes it as well.  (ud_se_scale_bn + gemm_x3 nt + the statistics fold: 34 + 33 + 5 us per 64 x 64 block before.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CE, int CO> struct PjFwdCfg {
+    using B = PjCfg<CE, CO>;
+    static constexpr int KD = (CE + 31) / 32 * 32;          // k padded to whole MFMA steps (pad columns of the image stay zero)
+    static constexpr int KS = KD / 32;
+    static constexpr int CS = KD * 2 + 16;
+    static constexpr int CP = B::RI * CS;
+    static constexpr int LDS = 3 * CP + B::COEF + CE * 4 + 2 * 4 * 32 * 8;          // image, coefficients, gate, the waves' column sums
+};
+
+struct PjFwdArgs {
+    const float* d;
+    const float* w;            // [CO][CE]
+    const float* s;            // [N][CE]
+    float* p;                  // [N HW][CO]
+    double* sum;               // [CO] += sum p, [CO] += sum p^2 (may be NULL together)
+    double* sumsq;
+    const double* bsum;
+    const double* bsumsq;
+    const float* gamma;
+    const float* beta;
+    double inv_count;
+    float eps;
+    int act;
+    int HW;
+    long M;
+    long tiles;
+};
+
+template <int CE, int CO>
+__global__ __launch_bounds__(NTH, 2) void pj_fwd_kernel(PjFwdArgs a) {
+    using CB = PjCfg<CE, CO>;
+    using CF = PjFwdCfg<CE, CO>;
+    static_assert(CO == 32, "two 16-column blocks: one (row block, column block) per wave");
+    extern __shared__ __attribute__((aligned(16))) char L[];
+    char* cimg = L;
+    float* coef = reinterpret_cast<float*>(L + 3 * CF::CP);
+    float* gate = coef + 4 * CE;
+    double* wsum = reinterpret_cast<double*>(gate + CE);          // [2][4 waves][32 columns... 16 used per wave]
+    const lds_char* Lp = (const lds_char*)L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u = lane & 15, g = lane >> 4;
+    const int mb = wave >> 1, nb = wave & 1;
+    const bool swish = a.act == 1;
+
+    if constexpr (CF::KD != CE) {
+        for (int i = tid; i < 3 * CF::CP / 16; i += NTH) reinterpret_cast<u32x4*>(L)[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(a.d);
+    const long t0 = (long)blockIdx.x * a.tiles / gridDim.x, t1 = (long)(blockIdx.x + 1) * a.tiles / gridDim.x;
+    f32x4 rd[CB::NIT];
+    auto prefetch = [&](long tile_) {
+        const long tile = min(tile_, a.tiles - 1);
+        const f32x4* db = d4 + tile * (R * CB::Q);
+#pragma unroll
+        for (int it = 0; it < CB::NIT; ++it) {
+            const int idx = tid + it * NTH;
+            rd[it] = db[((it + 1) * NTH <= R * CB::Q || idx < R * CB::Q) ? idx : 0];
+        }
+    };
+    prefetch(t0);
+    {          // (CE > NTH never happens here: one pass of the loop)
+        PjArgs ca;
+        ca.bsum = a.bsum; ca.bsumsq = a.bsumsq; ca.gamma = a.gamma; ca.beta = a.beta; ca.inv_count = a.inv_count; ca.eps = a.eps;
+        load_coef(ca, coef, CE, tid);
+    }
+    // Wp as the B operand: lane holds Wp[n = 16 nb + u][k = 32 ks + 8 g + j] (k-contiguous in memory)
+    u32x4 wf[CF::KS][3];
+#pragma unroll
+    for (int ks = 0; ks < CF::KS; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * ks + 8 * g + j;
+            const float wv = a.w[(16 * nb + u) * CE + min(k, CE - 1)];
+            v[j] = k < CE ? wv : 0.f;
+        }
+        split8(v, wf[ks]);
+    }
+    double s1 = 0.0, s2 = 0.0;
+    int cur_n = -1;
+    const f32x4* c4 = reinterpret_cast<const f32x4*>(coef);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gate);
+    __syncthreads();
+    for (long tile = t0; tile < t1; ++tile) {
+        const int n = (int)(tile * R / a.HW);
+        if (n != cur_n) {          // (uniform; the previous tile's closing barrier is behind every wave)
+            for (int c = tid; c < CE; c += NTH) gate[c] = ud_sigmoid_fast(a.s[(long)n * CE + c]);
+            cur_n = n;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < CB::NIT; ++it) {
+            const int idx = tid + it * NTH;
+            const int row = idx / CB::Q, q = idx - row * CB::Q;
+            const f32x4 mu = c4[q], is = c4[CB::Q + q], ga = c4[2 * CB::Q + q], be = c4[3 * CB::Q + q], gt = g4[q];
+            f32x4 cv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cv[k] = act_sel(ga[k] * ((rd[it][k] - mu[k]) * is[k]) + be[k], swish) * gt[k];
+            store_split4(cimg + row * CF::CS + q * 8, CF::CP, cv);
+        }
+        __syncthreads();
+        prefetch(tile + 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const lds_char* arow = Lp + (16 * mb + u) * CF::CS + g * 16;
+#pragma unroll
+        for (int ks = 0; ks < CF::KS; ++ks) acc = mma6(read_rows(arow + ks * 64, CF::CP), frag_of(wf[ks]), acc);
+        float* po = a.p + (tile * R + 16 * mb + 4 * g) * CO + 16 * nb + u;
+        float t1_ = 0.f, t2_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            po[r * CO] = acc[r];
+            t1_ += acc[r];
+            t2_ += acc[r] * acc[r];
+        }
+        s1 += (double)t1_;
+        s2 += (double)t2_;
+        __syncthreads();
+    }
+    if (a.sum) {          // (uniform) column sums: the four row groups of a wave, then the two waves of a column block, then one atomic
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (g == 0) { wsum[wave * 16 + u] = s1; wsum[64 + wave * 16 + u] = s2; }
+        __syncthreads();
+        if (tid < 32) {
+            const int nbb = tid >> 4, uu = tid & 15;
+            atomic_add_f64(a.sum + tid, wsum[nbb * 16 + uu] + wsum[(2 + nbb) * 16 + uu]);
+            atomic_add_f64(a.sumsq + tid, wsum[64 + nbb * 16 + uu] + wsum[64 + (2 + nbb) * 16 + uu]);
+        }
+    }
+}
+
+template <int CE, int CO>
+int launch_f(const PjFwdArgs& a, int grid, hipStream_t s) {
+    using CF = PjFwdCfg<CE, CO>;
+    static_assert(CF::LDS <= 64 * 1024, "dynamic LDS within the default limit");
+    hipLaunchKernelGGL((pj_fwd_kernel<CE, CO>), dim3((unsigned)grid), dim3(NTH), CF::LDS, s, a);
+    return 0;
+}
+
 template <int CE, int CO>
 int launch_a(const PjArgs& a, int grid, hipStream_t s) {
     using CF = PjCfg<CE, CO>;
@@ -442,6 +587,22 @@ long ud_pj_bwd_fused_grid(int N, int HW) {
     if (N < 1 || HW < R || HW % R) return UD_EINVAL;
     const long tiles = (long)N * HW / R;
     return tiles < 512 ? tiles : 512;
+}
+
+int ud_pj_fwd_fused(const float* d, const ud_bn_ref* bn, const float* s, const float* w, int N, int HW, int CE, int CO, float* p,
+                     double* sum, double* sumsq, ud_stream_t stream) {
+    if (!d || !bn || !s || !w || !p || N < 1 || !ud_pj_bwd_fused_ok(CE, CO, HW) || bn->G != 1 || !bn->gamma || !bn->beta || (!sum != !sumsq))
+        return UD_EINVAL;
+    PjFwdArgs a;
+    a.d = d; a.w = w; a.s = s; a.p = p; a.sum = sum; a.sumsq = sumsq;
+    a.bsum = bn->sum; a.bsumsq = bn->sumsq; a.gamma = bn->gamma; a.beta = bn->beta;
+    a.inv_count = bn->inv_count; a.eps = bn->eps; a.act = bn->act; a.HW = HW;
+    a.M = (long)N * HW; a.tiles = a.M / R;
+    const int grid = (int)ud_pj_bwd_fused_grid(N, HW);
+    const int rc = CE == 144 ? launch_f<144, 32>(a, grid, (hipStream_t)stream) : launch_f<192, 32>(a, grid, (hipStream_t)stream);
+    if (rc) return rc;
+    UD_LAUNCH_CHECK();
+    return 0;
 }
 
 int ud_pj_bwd_fused_a(const float* d, const float* dp, const ud_bn_ref* bn, const float* s, const float* w, int N, int HW, int CE, int CO,

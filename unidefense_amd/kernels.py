@@ -2692,6 +2692,19 @@ def project_bwd_fused_ok(d, w2, HW):
             _lib.call("ud_pj_bwd_fused_ok", int(w2.shape[1]), int(w2.shape[0]), int(HW)) == 1)
 
 
+def project_fwd_fused(d, bn, s, w2, N, HW, stats=None):
+    """p[N HW, Co] = (act(bn(d)) sigmoid(s)) w2^T in one pass over d (the gated tensor is not written); stats: fp64 [2 Co] accumulator
+    that receives p's column sums and sums of squares.  Returns (p, ctx): the context of a backward that ud_pj_bwd_fused_a / _b run."""
+    _chk(d, w2, s)
+    Co, Ce = w2.shape
+    p = empty((N * HW, Co), d)
+    _call("ud_pj_fwd_fused", _p(d), C.byref(bn.ref()), _p(s), _p(w2), N, HW, Ce, Co, _p(p), _pd(stats) if stats is not None else None,
+          _pd(stats, Co) if stats is not None else None, _stream())
+    ctx = SpectralCtx()
+    ctx.plans, ctx.x, ctx.w, ctx.dy, ctx.M, ctx.N, ctx.K = None, None, w2, None, N * HW, Co, Ce
+    return p, ctx
+
+
 def project_bwd_fused_a(d, bn, s, dp2, w2, N, HW, dgate):
     """dw[Co, Ce] = dp^T (act(bn(d)) sigmoid(s)) and dgate[N, Ce] (fp64, zeroed by the caller) += sum_hw (dp w) act(bn(d)) in one
     pass over d [N, .., Ce]; dp2 [N HW, Co]; w2 [Co, Ce]; s [N, Ce]."""

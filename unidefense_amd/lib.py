@@ -188,6 +188,7 @@ _SIGNATURES = {
     "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "ud_pj_bwd_fused_ok": [_I, _I, _I],
     "ud_pj_bwd_fused_grid": [_I, _I],
+    "ud_pj_fwd_fused": [_P, _BN, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "ud_pj_bwd_fused_a": [_P, _P, _BN, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "ud_pj_bwd_fused_b": [_P, _P, _BN, _P, _P, _F, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "ud_pw_bwd_fused_ok": [_I, _I],

@@ -1256,7 +1256,12 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None, next_blk=N
 
     # ---- project + BN2 + drop-connect + skip
     acc2 = K.zeros64(2 * Co, x)
-    if c_pl:
+    if not c_pl and K.project_bwd_fused_ok(d, Wp, HWo):
+        # thin project conv (the 64 x 64 blocks): gate applied on load, BatchNorm-2 statistics out of the epilogue, c never written
+        # (its backward re-makes c as well: csrc/pjbwd.hip)
+        p, pctx = K.project_fwd_fused(d, bn1, s2, Wp, N, HWo, stats=acc2)
+        done = True
+    elif c_pl:
         c = K.se_scale_bn_planes(d, bn1, s2, N, HWo, c_amax)
         (p, done), pctx = K.spectral_fwd(c, Wp, stats=acc2)
     elif (K._P1_DIRECT and d.dtype == torch.float16 and Ce % 8 == 0 and K.spectral_takes_plane_half(Mo, Co, Ce)):
@@ -1302,6 +1307,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None, next_blk=N
         # thin project conv (the 64 x 64 blocks): its data gradient dc is never written — each of the two passes over d that need it
         # re-makes its tile from the thin dp (csrc/pjbwd.hip)
         pj_fused = not dp_pl and pctx.plans is None and K.project_bwd_fused_ok(d, Wp, HWo)
+        assert pj_fused or pctx.x is not None, "the fused project forward kept no gated tensor: its backward must be the fused one"
         dgate = K.zeros64(N * Ce, x)
         if pj_fused:
             dWp = K.project_bwd_fused_a(d, bn1, s2, dp2, Wp, N, HWo, dgate)
