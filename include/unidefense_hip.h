@@ -573,18 +573,19 @@ int ud_pw_bwd_fused(const float* e, const float* dz, const ud_bn_ref* bn, const 
  * re-made from the thin dp [N HW][CO] inside each of the two passes over d that need it —
  *   ud_pj_bwd_fused_a:  dw[CO][CE] = dp^T c  (c re-made from d on load, as ud_se_scale_bn makes it)   and
  *                       dgate[n][ch] += sum_hw dc act(bn1(d))   (ud_coldot_bn's result; dgate zeroed by the caller);
- *                       part: ud_pj_bwd_fused_grid(N, HW) * CO * CE floats of scratch (partials folded in a fixed order);
+ *                       part: ud_pj_bwd_fused_grid(N, HW, CE, CO) * CO * CE floats of scratch (partials folded in a fixed order);
  *   ud_pj_bwd_fused_b:  dz = (dc sigmoid(s) + dpool inv_hw) act'(bn1(d)),  s1[ch] += sum dz, s2[ch] += sum dz xhat
  *                       (ud_se_scale_bwd_bn's results).
  * gemm_x3's arithmetic for the products.  (CE, CO, HW) must be a triple ud_pj_bwd_fused_ok accepts (HW % 32 == 0: a tile of rows
  * belongs to one sample). */
 int ud_pj_bwd_fused_ok(int CE, int CO, int HW);
+int ud_pj_fwd_fused_ok(int CE, int CO, int HW);
 /* ... and the forward of the same pair of layers in ONE pass over d: p[N HW][CO] = (act(bn1(d)) sigmoid(s)) w^T with the gated tensor
  * made on load (ud_se_scale_bn's values) and never written; sum / sumsq (optional, together): p's BatchNorm-2 statistics
- * (sum[co] += sum_rows p, sumsq[co] += sum_rows p^2).  Same (CE, CO, HW) as ud_pj_bwd_fused_ok. */
+ * (sum[co] += sum_rows p, sumsq[co] += sum_rows p^2).  (CE, CO, HW): a triple ud_pj_fwd_fused_ok accepts. */
 int ud_pj_fwd_fused(const float* d, const ud_bn_ref* bn, const float* s, const float* w, int N, int HW, int CE, int CO, float* p,
                     double* sum, double* sumsq, ud_stream_t stream);
-long ud_pj_bwd_fused_grid(int N, int HW);
+long ud_pj_bwd_fused_grid(int N, int HW, int CE, int CO);
 int ud_pj_bwd_fused_a(const float* d, const float* dp, const ud_bn_ref* bn, const float* s, const float* w, int N, int HW, int CE,
                       int CO, float* dw, double* dgate, float* part, ud_stream_t stream);
 int ud_pj_bwd_fused_b(const float* d, const float* dp, const ud_bn_ref* bn, const float* s, const float* dpool, float inv_hw,

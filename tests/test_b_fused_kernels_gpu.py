@@ -991,10 +991,12 @@ def test_expand_conv_backward_in_one_pass(M, Ce, Cin, with_add):
 
 
 @pytest.mark.parametrize("N,HW,Ce,Co,act", [(2, 64, 144, 32, 1), (3, 32 * 9, 192, 32, 1), (5, 4096, 192, 32, 1), (32, 4096, 144, 32, 1),
-                                            (2, 96, 192, 32, 0)])
+                                            (2, 96, 192, 32, 0), (2, 64, 336, 56, 1), (32, 1024, 336, 56, 1), (3, 1024, 192, 56, 1),
+                                            (7, 32 * 5, 336, 56, 0)])
 def test_project_conv_backward_without_its_data_gradient(N, HW, Ce, Co, act):
     """ud_pj_bwd_fused_a / _b (round 6): the thin project conv's backward with dc = dp Wp re-made per 32-row tile inside the two
-    passes over d — weight gradient + SE dot; gate / swish backward + BatchNorm-1 sums — against float64
+    passes over d — weight gradient + SE dot; gate / swish backward + BatchNorm-1 sums; the 336- and 192-channel tensors in front of
+    a 56-channel output walked as column chunks (112 / 96 wide, CO padded to two MFMA k-steps) — against float64
     (model/efficientnet/model.py:113-126 differentiated) and against the four launches they replace (gemm_tn, gemm_nn,
     ud_coldot_bn, ud_se_scale_bwd_bn).  One sample per workgroup chunk and several, fewer tiles than workgroups and more."""
     from unidefense_amd import kernels as K

@@ -7,7 +7,8 @@ sys.path.insert(0, ".")
 from unidefense_amd import kernels as K          # noqa: E402
 
 dev = torch.device("cuda:0")
-SHAPES = [("b2 64x64", 32, 64 * 64, 144, 32), ("b3-5 64x64", 32, 64 * 64, 192, 32)]
+SHAPES = [("b2 64x64", 32, 64 * 64, 144, 32), ("b3-5 64x64", 32, 64 * 64, 192, 32), ("b6 32x32", 32, 32 * 32, 192, 56),
+          ("b7-9 32x32", 32, 32 * 32, 336, 56)]
 
 
 def timed(fn, reps=10):
@@ -73,8 +74,9 @@ for name, N, HW, Ce, Co in SHAPES:
     def new_f():
         K.project_fwd_fused(d, bn, s, w, N, HW, stats=K.zeros64(2 * Co, d))
 
-    tf0, tf1 = timed(old_f), timed(new_f)
-    print("%-12s forward: se_scale_bn + gemm_nt (+ statistics) %6.1f us | one pass %6.1f us (%.2f TB/s)" % (name, tf0, tf1, mb / tf1), flush=True)
+    if K.project_fwd_fused_ok(d, w, HW):
+        tf0, tf1 = timed(old_f), timed(new_f)
+        print("%-12s forward: se_scale_bn + gemm_nt (+ statistics) %6.1f us | one pass %6.1f us (%.2f TB/s)" % (name, tf0, tf1, mb / tf1), flush=True)
     ta0, tb0, ta1, tb1 = timed(old_a), timed(old_b), timed(new_a), timed(new_b)
     print("%-12s M %7d %3d -> %2d (%3.0f MB per tensor) | wgrad + dgrad + coldot %6.1f us, se_scale_bwd %6.1f us | pass a %6.1f us (%.2f TB/s), pass b %6.1f us (%.2f TB/s)" %
           (name, M, Ce, Co, mb, ta0, tb0, ta1, mb / ta1, tb1, 2 * mb / tb1), flush=True)

@@ -23,6 +23,7 @@ through the environment (tools/run_with.py does).  Anything not listed here is a
 | side_branch | UD_SIDE_BRANCH | 0 | training forward / backward of UDEB4: the reconstruction decoder and its loss tail on a second stream beside the trunk's stage 5 ... head (tape.side_branch).  Correct (the model and engine goldens pass with it) but measured SLOWER on this runtime: 24.07 -> 24.44 ms per step, the two hardware queues overlap for 0.25 of the branch's 1.85 ms (profiles/r06/side_branch_ab.txt) |
 | expand_bwd_fused | UD_EXPAND_BWD_FUSED | 1 | the thin expand convs' backward (24 -> 144, 32 -> 192: the 128 x 128 / 64 x 64 blocks) as ONE pass over (dz, e): BatchNorm backward applied on load, weight and data gradient from one LDS image (ud_pw_bwd_fused) instead of ud_normbwd_apply + two gemm_x3 launches |
 | project_bwd_fused | UD_PROJECT_BWD_FUSED | 1 | the thin project convs' backward (144 / 192 -> 32: the 64 x 64 blocks) without the conv's data gradient in HBM: weight gradient + SE dot in one pass over d, gate / swish backward + BatchNorm-1 sums in a second, each re-making its 32-row tile of dc = dp Wp from the thin dp (ud_pj_bwd_fused_a / _b) instead of two gemm_x3 launches + ud_coldot_bn + ud_se_scale_bwd_bn; and their forward in one pass over d (ud_pj_fwd_fused: gate applied on load, BatchNorm-2 statistics out of the epilogue, the gated tensor never written) instead of ud_se_scale_bn + gemm_x3 |
+| project_bwd_fused_wide | UD_PROJECT_BWD_FUSED_WIDE | 1 | ... also for the 32 x 32 blocks' project convs (192 / 336 -> 56), their tensors walked as 96- / 112-channel column chunks (0: only the 64 x 64 blocks) |
 
 The shared library itself reads four variables when it is loaded, for hosts that do not go through Python:
 UD_GEMM_PATH (the initial `ud_gemm_set_path` value: 0 auto, 1 fp32 pipe, 2 split-bf16 everywhere, 3 fp16 MFMA), UD_FFT32_WAVE
@@ -56,6 +57,7 @@ class Config:
     side_branch: bool = False
     expand_bwd_fused: bool = True
     project_bwd_fused: bool = True
+    project_bwd_fused_wide: bool = True
 
     @classmethod
     def from_env(cls):

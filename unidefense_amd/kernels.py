@@ -2689,7 +2689,13 @@ def project_bwd_fused_ok(d, w2, HW):
     """do ud_pj_bwd_fused_a / _b take this project conv's backward (fp32 storage, a thin (Ce, Co) pair they are built for, whole
     32-row tiles per sample)?"""
     return (CFG.project_bwd_fused and d.dtype == torch.float32 and w2.dtype == torch.float32 and
+            (CFG.project_bwd_fused_wide or w2.shape[0] == 32) and
             _lib.call("ud_pj_bwd_fused_ok", int(w2.shape[1]), int(w2.shape[0]), int(HW)) == 1)
+
+
+def project_fwd_fused_ok(d, w2, HW):
+    """does ud_pj_fwd_fused take this project conv's forward (and ud_pj_bwd_fused_a / _b its backward)?"""
+    return (project_bwd_fused_ok(d, w2, HW) and _lib.call("ud_pj_fwd_fused_ok", int(w2.shape[1]), int(w2.shape[0]), int(HW)) == 1)
 
 
 def project_fwd_fused(d, bn, s, w2, N, HW, stats=None):
@@ -2712,8 +2718,8 @@ def project_bwd_fused_a(d, bn, s, dp2, w2, N, HW, dgate):
     Co, Ce = w2.shape
     assert d.numel() == N * HW * Ce and dp2.numel() == N * HW * Co and s.numel() == N * Ce and dp2.is_contiguous()
     dw = empty((Co, Ce), d)
-    grid = _lib.call("ud_pj_bwd_fused_grid", N, HW)
-    part = empty((grid, Co * Ce), d)
+    grid = _lib.call("ud_pj_bwd_fused_grid", N, HW, Ce, Co)
+    part = empty((grid, Co * Ce), d)          # (an upper bound: a workgroup's partial covers its chunk of the Ce columns)
     _call("ud_pj_bwd_fused_a", _p(d), _p(dp2), C.byref(bn.ref()), _p(s), _p(w2), N, HW, Ce, Co, _p(dw), _pd(dgate), _p(part), _stream())
     return dw
 

@@ -187,7 +187,8 @@ _SIGNATURES = {
     "ud_normbwd_apply_planes": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _L, _L, _P, _P, _P, _P],
     "ud_normbwd_apply": [_P, _P, _P, _F, _BN, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "ud_pj_bwd_fused_ok": [_I, _I, _I],
-    "ud_pj_bwd_fused_grid": [_I, _I],
+    "ud_pj_bwd_fused_grid": [_I, _I, _I, _I],
+    "ud_pj_fwd_fused_ok": [_I, _I, _I],
     "ud_pj_fwd_fused": [_P, _BN, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "ud_pj_bwd_fused_a": [_P, _P, _BN, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "ud_pj_bwd_fused_b": [_P, _P, _BN, _P, _P, _F, _P, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -237,7 +238,7 @@ _SIGNATURES = {
 }
 
 # helpers that return a count rather than a status code
-_COUNT_FUNCS = {"ud_pj_bwd_fused_ok", "ud_pj_bwd_fused_grid", "ud_pw_bwd_fused_ok", "ud_pw_bwd_fused_grid", "ud_loss_tail_ws_floats", "ud_norm_fused_ws_doubles", "ud_norm_fused_counters", "ud_dwtile_wgrad", "ud_dwtile_bwd", "ud_fft32_set_wave", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
+_COUNT_FUNCS = {"ud_pj_fwd_fused_ok", "ud_pj_bwd_fused_ok", "ud_pj_bwd_fused_grid", "ud_pw_bwd_fused_ok", "ud_pw_bwd_fused_grid", "ud_loss_tail_ws_floats", "ud_norm_fused_ws_doubles", "ud_norm_fused_counters", "ud_dwtile_wgrad", "ud_dwtile_bwd", "ud_fft32_set_wave", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_reduce_ws_doubles", "ud_gemm_query_path", "ud_gemm_get_path", "ud_gemm_stats_slots", "ud_adamw_chunk_elems", "ud_rfft2_planes_ws_floats", "ud_fused_reduce_ws_doubles", "ud_dwconv_bwd_data_bn_ws_doubles", "ud_dwconv_bwd_weight_parts", "ud_sfmix_blocks", "ud_gate_mix_blocks",
                 "ud_l1_chunks", "ud_efdm_ws_bytes", "ud_conv_small_supported", "ud_conv_small_wgrad_supported",
                 "ud_conv_small_wgrad_ws_floats", "ud_xchg_bytes"}
 _LONG_FUNCS = {"ud_pj_bwd_fused_grid", "ud_pw_bwd_fused_grid", "ud_norm_fused_ws_doubles", "ud_fft2_two_pass_ws_floats", "ud_dwtile_ws_doubles", "ud_dwtile_wgrad_part_rows", "ud_xchg_bytes", "ud_efdm_ws_bytes", "ud_rfft2_planes_ws_floats", "ud_conv_small_wgrad_ws_floats", "ud_fused_reduce_ws_doubles",

@@ -1256,7 +1256,7 @@ def mbconv_fused(tape, x, blk, keep, keep_prob, wt, dp, lazy_in=None, next_blk=N
 
     # ---- project + BN2 + drop-connect + skip
     acc2 = K.zeros64(2 * Co, x)
-    if not c_pl and K.project_bwd_fused_ok(d, Wp, HWo):
+    if not c_pl and K.project_fwd_fused_ok(d, Wp, HWo):
         # thin project conv (the 64 x 64 blocks): gate applied on load, BatchNorm-2 statistics out of the epilogue, c never written
         # (its backward re-makes c as well: csrc/pjbwd.hip)
         p, pctx = K.project_fwd_fused(d, bn1, s2, Wp, N, HWo, stats=acc2)
