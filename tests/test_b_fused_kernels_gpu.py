@@ -992,14 +992,16 @@ def test_expand_conv_backward_in_one_pass(M, Ce, Cin, with_add):
 
 @pytest.mark.parametrize("N,HW,Ce,Co,act", [(2, 64, 144, 32, 1), (3, 32 * 9, 192, 32, 1), (5, 4096, 192, 32, 1), (32, 4096, 144, 32, 1),
                                             (2, 96, 192, 32, 0), (2, 64, 336, 56, 1), (32, 1024, 336, 56, 1), (3, 1024, 192, 56, 1),
-                                            (7, 32 * 5, 336, 56, 0)])
-def test_project_conv_backward_without_its_data_gradient(N, HW, Ce, Co, act):
+                                            (7, 32 * 5, 336, 56, 0), (3, 4096, 48, 24, 1), (2, 16384, 24, 24, 1), (5, 96, 24, 24, 0)])
+def test_project_conv_backward_without_its_data_gradient(N, HW, Ce, Co, act, monkeypatch):
     """ud_pj_bwd_fused_a / _b (round 6): the thin project conv's backward with dc = dp Wp re-made per 32-row tile inside the two
     passes over d — weight gradient + SE dot; gate / swish backward + BatchNorm-1 sums; the 336- and 192-channel tensors in front of
     a 56-channel output walked as column chunks (112 / 96 wide, CO padded to two MFMA k-steps) — against float64
     (model/efficientnet/model.py:113-126 differentiated) and against the four launches they replace (gemm_tn, gemm_nn,
     ud_coldot_bn, ud_se_scale_bwd_bn).  One sample per workgroup chunk and several, fewer tiles than workgroups and more."""
     from unidefense_amd import kernels as K
+    from unidefense_amd.config import cfg
+    monkeypatch.setattr(cfg, "project_fused_narrow", True)          # (the 24-channel outputs are built and tested, shipped off: config.py)
     dev = _dev()
     K.reset_zero_pool()
     g = torch.Generator().manual_seed(N * 7 + HW + Ce)
@@ -1049,11 +1051,14 @@ def test_project_conv_backward_without_its_data_gradient(N, HW, Ce, Co, act):
         assert within("pj_bwd %s vs float64" % name, r, max(3e-6, 2 * r0)), (name, r, r0)
 
 
-@pytest.mark.parametrize("N,HW,Ce,Co,act", [(2, 64, 144, 32, 1), (3, 32 * 9, 192, 32, 1), (32, 4096, 192, 32, 1), (5, 4096, 144, 32, 0)])
-def test_project_conv_forward_with_the_gate_applied_on_load(N, HW, Ce, Co, act):
+@pytest.mark.parametrize("N,HW,Ce,Co,act", [(2, 64, 144, 32, 1), (3, 32 * 9, 192, 32, 1), (32, 4096, 192, 32, 1), (5, 4096, 144, 32, 0),
+                                            (3, 4096, 48, 24, 1), (2, 16384, 24, 24, 1), (5, 96, 24, 24, 0)])
+def test_project_conv_forward_with_the_gate_applied_on_load(N, HW, Ce, Co, act, monkeypatch):
     """ud_pj_fwd_fused (round 6): p = (act(bn1(d)) sigmoid(s)) Wp^T in one pass over d + p's BatchNorm-2 statistics, against
     float64 (model/efficientnet/model.py:113-126) and against ud_se_scale_bn + gemm_nt + ud_colstats."""
     from unidefense_amd import kernels as K
+    from unidefense_amd.config import cfg
+    monkeypatch.setattr(cfg, "project_fused_narrow", True)
     dev = _dev()
     K.reset_zero_pool()
     g = torch.Generator().manual_seed(N * 11 + HW + Ce)

@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 from unidefense_amd import kernels as K          # noqa: E402
 
 dev = torch.device("cuda:0")
-SHAPES = [("b2 64x64", 32, 64 * 64, 144, 32), ("b3-5 64x64", 32, 64 * 64, 192, 32), ("b6 32x32", 32, 32 * 32, 192, 56),
+SHAPES = [("b0 128x128", 32, 128 * 128, 48, 24), ("b1 128x128", 32, 128 * 128, 24, 24), ("b2 64x64", 32, 64 * 64, 144, 32), ("b3-5 64x64", 32, 64 * 64, 192, 32), ("b6 32x32", 32, 32 * 32, 192, 56),
           ("b7-9 32x32", 32, 32 * 32, 336, 56)]
 
 

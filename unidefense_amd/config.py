@@ -24,6 +24,7 @@ through the environment (tools/run_with.py does).  Anything not listed here is a
 | expand_bwd_fused | UD_EXPAND_BWD_FUSED | 1 | the thin expand convs' backward (24 -> 144, 32 -> 192: the 128 x 128 / 64 x 64 blocks) as ONE pass over (dz, e): BatchNorm backward applied on load, weight and data gradient from one LDS image (ud_pw_bwd_fused) instead of ud_normbwd_apply + two gemm_x3 launches |
 | project_bwd_fused | UD_PROJECT_BWD_FUSED | 1 | the thin project convs' backward (144 / 192 -> 32: the 64 x 64 blocks) without the conv's data gradient in HBM: weight gradient + SE dot in one pass over d, gate / swish backward + BatchNorm-1 sums in a second, each re-making its 32-row tile of dc = dp Wp from the thin dp (ud_pj_bwd_fused_a / _b) instead of two gemm_x3 launches + ud_coldot_bn + ud_se_scale_bwd_bn; and their forward in one pass over d (ud_pj_fwd_fused: gate applied on load, BatchNorm-2 statistics out of the epilogue, the gated tensor never written) instead of ud_se_scale_bn + gemm_x3 |
 | project_bwd_fused_wide | UD_PROJECT_BWD_FUSED_WIDE | 1 | ... also for the 32 x 32 blocks' project convs (192 / 336 -> 56), their tensors walked as 96- / 112-channel column chunks (0: only the 64 x 64 blocks) |
+| project_fused_narrow | UD_PROJECT_FUSED_NARROW | 0 | ... and for the 128 x 128 blocks' project convs (48 / 24 -> 24).  Built and operator-tested (tests/test_b_fused_kernels_gpu.py), worth 0.2 ms of the bs-32 step, and OFF: with it the N = 8 fixture's blocks.9 gate gradient — a single heavily cancelling sum on which the oracle's own fp32 run is 1.8e-5 off float64 — moves from 0.19 to 0.74 of the plain bound in the `bench` run mode and 1 % past the reference's fp32 record (profiles/r06/pj_bwd_fused.txt); not a margin to ship on |
 
 The shared library itself reads four variables when it is loaded, for hosts that do not go through Python:
 UD_GEMM_PATH (the initial `ud_gemm_set_path` value: 0 auto, 1 fp32 pipe, 2 split-bf16 everywhere, 3 fp16 MFMA), UD_FFT32_WAVE
@@ -58,6 +59,7 @@ class Config:
     expand_bwd_fused: bool = True
     project_bwd_fused: bool = True
     project_bwd_fused_wide: bool = True
+    project_fused_narrow: bool = False
 
     @classmethod
     def from_env(cls):

@@ -14,6 +14,8 @@
 // three-way bf16 split, six piece products, fp32 accumulation); element-wise math = ud_se_scale_bn / ud_se_scale_bwd_bn's.
 #include "pw_common.h"
 
+#include <type_traits>
+
 namespace {
 
 using namespace pw;
@@ -26,17 +28,18 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtom
 // CC: channels per CHUNK (CE % CC == 0): a wide tensor (336 channels) is walked as CE / CC column chunks — a workgroup stays inside one
 // chunk, so its image, its fragments of w and its registers are those of a CC-channel problem with row stride CE.
 template <int CE, int CO, int CC = CE> struct PjCfg {
-    static_assert(CE % CC == 0 && CC % 16 == 0 && CO % 8 == 0 && CO > 16 && CO <= 64, "thin project convs");
+    static_assert(CE % CC == 0 && CC % 8 == 0 && (CC % 16 == 0 || CC == CE) && CO % 8 == 0 && CO > 16 && CO <= 64, "thin project convs");
+    static constexpr int CCP = (CC + 15) / 16 * 16;              // chunk width padded to whole 16-channel blocks (CE = 24: pad columns stay zero)
     static constexpr int NCH = CE / CC;
     static constexpr int QT = CE / 4;                            // quads per tensor row
     static constexpr int Q = CC / 4;                             // quads per row of the chunk
     static constexpr int NIT = (R * Q + NTH - 1) / NTH;          // float4 items of d per thread and tile
     static constexpr int RI = (NIT * NTH + Q - 1) / Q;           // image rows (items past row 31 land in rows nobody reads)
-    static constexpr int NBC = CC / 16;                          // 16-channel blocks of the chunk
+    static constexpr int NBC = CCP / 16;                         // 16-channel blocks of the chunk
     static constexpr int NBW = (NBC + 3) / 4;                    // ... per wave: wave w owns blocks w, w + 4, ...
-    static constexpr int CS = CC * 2 + 16;                       // bytes of a c-image row
+    static constexpr int CS = CCP * 2 + 16;                      // bytes of a c-image row
     static constexpr int CP = RI * CS;
-    static constexpr int AS = (CC + 4) * 4;                      // bytes of an fp32 tile row (a / dc)
+    static constexpr int AS = (CCP + 4) * 4;                     // bytes of an fp32 tile row (a / dc)
     static constexpr int AP = RI * AS;
     static constexpr int COP = (CO + 31) / 32 * 32;              // CO padded to whole MFMA k-steps (pad columns of the dp image stay zero)
     static constexpr int KS2 = COP / 32;
@@ -105,15 +108,15 @@ template <int CE, int CO, int NBC, int NBW, int KS2>
 __device__ __forceinline__ void load_wfrags(const float* w, int c0, int wave, int u, int g, u32x4 (&wf)[NBW][KS2][3]) {
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
-        const int n = c0 + 16 * min(wave + 4 * j, NBC - 1) + u;
+        const int n = c0 + 16 * min(wave + 4 * j, NBC - 1) + u;          // (n >= CE only where CE is not whole 16-channel blocks)
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
             float v[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int k = 32 * ks + 8 * g + jj;
-                const float wv = w[min(k, CO - 1) * CE + n];
-                v[jj] = k < CO ? wv : 0.f;
+                const float wv = w[min(k, CO - 1) * CE + min(n, CE - 1)];
+                v[jj] = (k < CO && n < CE) ? wv : 0.f;
             }
             split8(v, wf[j][ks]);
         }
@@ -145,14 +148,17 @@ __global__ __launch_bounds__(NTH, 2) void pj_bwd_a_kernel(PjArgs a) {
     if constexpr (CF::COP != CO) {
         for (int i = tid; i < 3 * CF::DPL / 16; i += NTH) reinterpret_cast<u32x4*>(dimg)[i] = u32x4{0u, 0u, 0u, 0u};
     }
+    if constexpr (CF::CCP != CC) {          // (pad channels of the c image and the a tile: zero once, never written)
+        for (int i = tid; i < (3 * CF::CP + CF::AP) / 16; i += NTH) reinterpret_cast<u32x4*>(L)[i] = u32x4{0u, 0u, 0u, 0u};
+    }
 
     f32x4 accw[CF::NBW][CF::NB2];
-    float dot[CF::NBW];
+    double dot[CF::NBW];          // (per tile: 8 products per lane in fp32, then fp64 — a sample of 128 x 128 pixels is 512 tiles)
 #pragma unroll
     for (int j = 0; j < CF::NBW; ++j) {
 #pragma unroll
         for (int m = 0; m < CF::NB2; ++m) accw[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dot[j] = 0.f;
+        dot[j] = 0.0;
     }
 
     const f32x4* d4 = reinterpret_cast<const f32x4*>(a.d) + chunk * CF::Q;
@@ -179,10 +185,11 @@ __global__ __launch_bounds__(NTH, 2) void pj_bwd_a_kernel(PjArgs a) {
         if (g == 0) {
 #pragma unroll
             for (int j = 0; j < CF::NBW; ++j)
-                if (wave + 4 * j < CF::NBC) atomic_add_f64(a.dgate + (long)n * CE + c0 + 16 * (wave + 4 * j) + u, (double)dot[j]);
+                if (wave + 4 * j < CF::NBC && 16 * (wave + 4 * j) + u < CC)
+                    atomic_add_f64(a.dgate + (long)n * CE + c0 + 16 * (wave + 4 * j) + u, dot[j]);
         }
 #pragma unroll
-        for (int j = 0; j < CF::NBW; ++j) dot[j] = 0.f;
+        for (int j = 0; j < CF::NBW; ++j) dot[j] = 0.0;
     };
 
     prefetch(t0);          // the first tile's loads, then everything else the prologue needs: one memory latency for all of it
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(NTH, 2) void pj_bwd_a_kernel(PjArgs a) {
                 }
                 t += __shfl_xor(t, 16, 64);
                 t += __shfl_xor(t, 32, 64);
-                dot[j] += t;
+                dot[j] += (double)t;
             }
         }
         // ---- weight gradient: dWp[co block][channel block] += dp^T c, k = the tile's rows (transposed reads of both images)
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(NTH, 2) void pj_bwd_a_kernel(PjArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int co = 16 * m + 4 * g + r;
-                        if (co < CO) part[co * CC + ch] = accw[j][m][r];
+                        if (co < CO && ch < CC) part[co * CC + ch] = accw[j][m][r];
                     }
             }
         }
@@ -349,11 +356,14 @@ __global__ __launch_bounds__(NTH, 2) void pj_bwd_b_kernel(PjArgs a) {
     }
     for (int c = tid; c < 2 * CC; c += NTH) lacc[c] = 0.0;
 
-    float sa[CF::NIT][4], sb[CF::NIT][4];
+    // a thread's column sums over its tiles: fp64 where that costs few registers (the narrow tensors: up to 64 tiles per workgroup),
+    // fp32 over <= 16 tiles otherwise (then fp64 through LDS and the atomics)
+    using ST = typename std::conditional<(CF::NIT <= 2), double, float>::type;
+    ST sa[CF::NIT][4], sb[CF::NIT][4];
 #pragma unroll
     for (int it = 0; it < CF::NIT; ++it)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sa[it][k] = sb[it][k] = 0.f;
+        for (int k = 0; k < 4; ++k) sa[it][k] = sb[it][k] = (ST)0;
 
     const f32x4* d4 = reinterpret_cast<const f32x4*>(a.d) + chunk * CF::Q;
     const f32x4* dp4 = reinterpret_cast<const f32x4*>(a.dp);
@@ -453,8 +463,8 @@ __global__ __launch_bounds__(NTH, 2) void pj_bwd_b_kernel(PjArgs a) {
                     float gg = (dc[k] * gt[k] + pl[k]) * act_grad_sel(ga[k] * xh + be[k], swish);
                     gg = ok ? gg : 0.f;
                     o[k] = gg;
-                    sa[it][k] += gg;
-                    sb[it][k] += gg * xh;
+                    sa[it][k] += (ST)gg;
+                    sb[it][k] += (ST)(gg * xh);
                 }
                 if (ok) ob4[row * CF::QT + q] = o;
             }
@@ -520,7 +530,7 @@ template <int CE, int CO>
 __global__ __launch_bounds__(NTH, 2) void pj_fwd_kernel(PjFwdArgs a) {
     using CB = PjCfg<CE, CO>;
     using CF = PjFwdCfg<CE, CO>;
-    static_assert(CO == 32, "two 16-column blocks: one (row block, column block) per wave");
+    static_assert(CO > 16 && CO <= 32, "two 16-column blocks: one (row block, column block) per wave");
     extern __shared__ __attribute__((aligned(16))) char L[];
     char* cimg = L;
     float* coef = reinterpret_cast<float*>(L + 3 * CF::CP);
@@ -562,8 +572,8 @@ __global__ __launch_bounds__(NTH, 2) void pj_fwd_kernel(PjFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 32 * ks + 8 * g + j;
-            const float wv = a.w[(16 * nb + u) * CE + min(k, CE - 1)];
-            v[j] = k < CE ? wv : 0.f;
+            const float wv = a.w[min(16 * nb + u, CO - 1) * CE + min(k, CE - 1)];
+            v[j] = (k < CE && 16 * nb + u < CO) ? wv : 0.f;
         }
         split8(v, wf[ks]);
     }
@@ -599,7 +609,7 @@ __global__ __launch_bounds__(NTH, 2) void pj_fwd_kernel(PjFwdArgs a) {
         float t1_ = 0.f, t2_ = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            po[r * CO] = acc[r];
+            if (CO == 32 || 16 * nb + u < CO) po[r * CO] = acc[r];          // (a pad column's accumulator is zero: its sums add nothing)
             t1_ += acc[r];
             t2_ += acc[r] * acc[r];
         }
@@ -612,7 +622,7 @@ __global__ __launch_bounds__(NTH, 2) void pj_fwd_kernel(PjFwdArgs a) {
         s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
         if (g == 0) { wsum[wave * 16 + u] = s1; wsum[64 + wave * 16 + u] = s2; }
         __syncthreads();
-        if (tid < 32) {
+        if (tid < CO) {
             const int nbb = tid >> 4, uu = tid & 15;
             atomic_add_f64(a.sum + tid, wsum[nbb * 16 + uu] + wsum[(2 + nbb) * 16 + uu]);
             atomic_add_f64(a.sumsq + tid, wsum[64 + nbb * 16 + uu] + wsum[64 + (2 + nbb) * 16 + uu]);
@@ -653,6 +663,7 @@ int launch_b(const PjArgs& a, int grid, hipStream_t s) {
 // the (CE, CO) pairs built, and the chunk width each is walked in
 int chunk_of(int CE, int CO) {
     if (CO == 32 && (CE == 144 || CE == 192)) return CE;
+    if (CO == 24 && (CE == 48 || CE == 24)) return CE;
     if (CO == 56 && CE == 336) return 112;
     if (CO == 56 && CE == 192) return 96;
     return 0;
@@ -676,7 +687,7 @@ void fill(PjArgs& a, const float* d, const float* dp, const ud_bn_ref* bn, const
 extern "C" {
 
 int ud_pj_bwd_fused_ok(int CE, int CO, int HW) { return (chunk_of(CE, CO) && HW >= R && HW % R == 0) ? 1 : 0; }
-int ud_pj_fwd_fused_ok(int CE, int CO, int HW) { return (CO == 32 && chunk_of(CE, CO) == CE && HW >= R && HW % R == 0) ? 1 : 0; }
+int ud_pj_fwd_fused_ok(int CE, int CO, int HW) { return (CO <= 32 && chunk_of(CE, CO) == CE && HW >= R && HW % R == 0) ? 1 : 0; }
 
 long ud_pj_bwd_fused_grid(int N, int HW, int CE, int CO) {
     const int cc = chunk_of(CE, CO);
@@ -695,7 +706,9 @@ int ud_pj_fwd_fused(const float* d, const ud_bn_ref* bn, const float* s, const f
     a.inv_count = bn->inv_count; a.eps = bn->eps; a.act = bn->act; a.HW = HW;
     a.M = (long)N * HW; a.tiles = a.M / R;
     const int grid = (int)ud_pj_bwd_fused_grid(N, HW, CE, CO);
-    const int rc = CE == 144 ? launch_f<144, 32>(a, grid, (hipStream_t)stream) : launch_f<192, 32>(a, grid, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = CO == 32 ? (CE == 144 ? launch_f<144, 32>(a, grid, st) : launch_f<192, 32>(a, grid, st))
+                            : (CE == 48 ? launch_f<48, 24>(a, grid, st) : launch_f<24, 24>(a, grid, st));
     if (rc) return rc;
     UD_LAUNCH_CHECK();
     return 0;
@@ -710,6 +723,7 @@ int ud_pj_bwd_fused_a(const float* d, const float* dp, const ud_bn_ref* bn, cons
     a.part = part; a.dgate = dgate;
     const int grid = (int)ud_pj_bwd_fused_grid(N, HW, CE, CO);
     const int rc = CO == 32 ? (CE == 144 ? launch_a<144, 32, 144>(a, grid, st) : launch_a<192, 32, 192>(a, grid, st))
+                 : CO == 24 ? (CE == 48 ? launch_a<48, 24, 48>(a, grid, st) : launch_a<24, 24, 24>(a, grid, st))
                             : (CE == 336 ? launch_a<336, 56, 112>(a, grid, st) : launch_a<192, 56, 96>(a, grid, st));
     if (rc) return rc;
     UD_LAUNCH_CHECK();
@@ -727,6 +741,7 @@ int ud_pj_bwd_fused_b(const float* d, const float* dp, const ud_bn_ref* bn, cons
     a.dpool = dpool; a.inv_hw = inv_hw; a.dz = dz; a.s1 = s1; a.s2 = s2;
     const int grid = (int)ud_pj_bwd_fused_grid(N, HW, CE, CO);
     const int rc = CO == 32 ? (CE == 144 ? launch_b<144, 32, 144>(a, grid, st) : launch_b<192, 32, 192>(a, grid, st))
+                 : CO == 24 ? (CE == 48 ? launch_b<48, 24, 48>(a, grid, st) : launch_b<24, 24, 24>(a, grid, st))
                             : (CE == 336 ? launch_b<336, 56, 112>(a, grid, st) : launch_b<192, 56, 96>(a, grid, st));
     if (rc) return rc;
     UD_LAUNCH_CHECK();

@@ -2689,7 +2689,7 @@ def project_bwd_fused_ok(d, w2, HW):
     """do ud_pj_bwd_fused_a / _b take this project conv's backward (fp32 storage, a thin (Ce, Co) pair they are built for, whole
     32-row tiles per sample)?"""
     return (CFG.project_bwd_fused and d.dtype == torch.float32 and w2.dtype == torch.float32 and
-            (CFG.project_bwd_fused_wide or w2.shape[0] == 32) and
+            (CFG.project_bwd_fused_wide or w2.shape[0] != 56) and (CFG.project_fused_narrow or w2.shape[0] != 24) and
             _lib.call("ud_pj_bwd_fused_ok", int(w2.shape[1]), int(w2.shape[0]), int(HW)) == 1)
 
 
