@@ -17,6 +17,7 @@ json_out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else N
 json_steps = float(sys.argv[sys.argv.index("--json") + 2]) if "--json" in sys.argv else 1.0
 
 CLASSES = (("gemm", ("gemm_",)),
+           ("thin_conv_passes", ("pw_bwd_", "pj_bwd_", "pj_fwd_", "pj_fold")),          # round 6: BatchNorm / SE element-wise work + a thin 1x1 conv in one pass
            ("batchnorm", ("normbwd_", "colstats", "partials_to_acc", "residual_bn", "colreduce_partial", "bn_apply", "stats_finalize",
                           "norm_apply", "group_sum", "partial_sum_finalize", "stat_slots")),
            ("transform", ("rfft2", "irfft2", "rows_fwd", "cols_fwd", "rows_inv", "cols_inv", "cols_pass", "rows_adj", "sfmix")),
