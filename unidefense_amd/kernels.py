@@ -1020,7 +1020,7 @@ def _p2_run(kind, plan, ap, bp, M, N, K, like, stats=None, out=None):
     elif how == "tailp":
         # the tail pair (nt): plain leading row tiles + split-K last row tiles as ONE grid (ud_gemm_p3_pair)
         m1, s_ = int(plan[1]), int(plan[2])
-        assert kind == "nt" and stats is None
+        assert kind == "nt"          # (statistics wanted: left to ud_colstats like every non-plain plan — (res, False) below)
         res = out if acc else empty((M, N), like)
         tail = res[m1:]
         if not acc:
