@@ -616,7 +616,7 @@ def main():
                                      "stream (events cannot be read inside the replayed graph the headline number comes "
                                      "from; these steps launch every product by itself — the replayed step sends the data and "
                                      "weight gradient of a 1x1 conv out as ONE grid of the planes kernel, ud_gemm_p3_pair, "
-                                     "which is ~0.5 ms per step faster than the sum timed here); profiles/r05/ holds the rocprofv3 --kernel-trace --stats summary of the "
+                                     "which is ~0.5 ms per step faster than the sum timed here); profiles/r06/ holds the rocprofv3 --kernel-trace --stats summary of the "
                                      "graph-replayed steps of this same command (tools/gpu_round.sh), and "
                                      "tools/roofline_from_rocprof.py recomputes these numbers from it"},
         }
